@@ -1,0 +1,205 @@
+"""Seeded synthetic FASTQ workloads.
+
+Everything here is numpy-vectorised so that the 10 M-read bench workload is
+generated in well under a minute.  The same generators feed
+  * tests/golden/make_golden.py  (inputs handed to the imported reference),
+  * the parity tests             (same seeds -> same bytes),
+  * bench.py                     (SoA arrays straight to the device).
+
+Reads are produced as fixed-width uint8 matrices (n x L) plus a length vector,
+which is exactly the padded form the SoA packer wants; `write_fastq` renders
+them as the 4-line text records the reference's fastq.Reader consumes
+(fastq.py:37-49).
+"""
+import gzip
+import numpy as np
+
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+COMP_IDX = np.array([3, 2, 1, 0], dtype=np.uint8)  # A<->T, C<->G on indices into BASES
+# quality alphabet / weights measured on the reference's testdata
+QUAL_CHARS = np.frombuffer(b"#/6<AE", dtype=np.uint8)
+QUAL_WEIGHTS = np.array([0.01, 0.09, 0.02, 0.06, 0.18, 0.64])
+ADAPTER1 = np.frombuffer(b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", dtype=np.uint8)
+ADAPTER2 = np.frombuffer(b"AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT", dtype=np.uint8)
+
+
+def _quals(rng, shape):
+    idx = rng.choice(len(QUAL_CHARS), size=shape, p=QUAL_WEIGHTS).astype(np.uint8)
+    return QUAL_CHARS[idx]
+
+
+def make_names(rng, n, mate=1, start=0):
+    """@SIM:1:FC1:<lane 1-4>:<tile 1101-2316>:<x 1000-25000>:<y 1000-20000> <mate>:N:0:ACGT"""
+    lane = rng.integers(1, 5, n)
+    tile = rng.integers(1101, 2317, n)
+    x = rng.integers(1000, 25001, n)
+    y = rng.integers(1000, 20001, n)
+    return lane, tile, x, y
+
+
+def render_names(lane, tile, x, y, mate):
+    return ["@SIM:1:FC1:%d:%d:%d:%d %d:N:0:ACGT" % (lane[i], tile[i], x[i], y[i], mate)
+            for i in range(len(lane))]
+
+
+def make_single(n, L=150, seed=1002):
+    """Config 2: single-end reads with N bursts, poly-X tails and low-quality stretches."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    seq = BASES[rng.integers(0, 4, (n, L), dtype=np.uint8)]
+    qual = _quals(rng, (n, L))
+    # per-base N
+    nmask = rng.random((n, L)) < 0.002
+    # 0.5 % of reads with 8-20 N
+    burst = np.nonzero(rng.random(n) < 0.005)[0]
+    for r in burst:
+        k = int(rng.integers(8, 21))
+        nmask[r, rng.choice(L, k, replace=False)] = True
+    seq[nmask] = ord("N")
+    qual[nmask] = ord("#")
+    # 1 % poly-G / poly-A tails of 35-80
+    tails = np.nonzero(rng.random(n) < 0.01)[0]
+    for r in tails:
+        k = int(rng.integers(35, 81))
+        seq[r, L - k:] = ord("G") if rng.random() < 0.7 else ord("A")
+    # 2 % of reads with 61-100 low quality bases
+    lows = np.nonzero(rng.random(n) < 0.02)[0]
+    for r in lows:
+        k = int(rng.integers(61, 101))
+        qual[r, rng.choice(L, k, replace=False)] = ord("#")
+    lens = np.full(n, L, dtype=np.uint32)
+    meta = make_names(rng, n)
+    return dict(seq1=seq, qual1=qual, len1=lens, meta=meta)
+
+
+def make_pairs(n, L=150, seed=1003, ragged=False, chunk=250_000, lowercase=0.0, dirty=False, short_frac=0.03):
+    """Config 3: paired-end reads, insert = 2L - ov with ov ~ round(N(30, 8)) in [0, L],
+    3 % short inserts (60 .. L-1) with adapter read-through, 0.5 %/base substitution errors
+    carrying low quality ('/' or '#') and 0.1 %/base carrying high quality, N at 0.2 %/base.
+
+    ragged=True additionally truncates every read to a random length (tests only).
+    lowercase>0 soft-masks that fraction of reads' first 20 bases to lower case (tests only).
+    dirty=True adds config-2 style artefacts to both mates (poly-X tails, low-quality stretches,
+    N bursts) so that every filter fires in the small golden cases (tests only).
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = dict(seq1=[], qual1=[], len1=[], seq2=[], qual2=[], len2=[])
+    metas = []
+    done = 0
+    while done < n:
+        m = min(chunk, n - done)
+        ov = np.clip(np.rint(rng.normal(30.0, 8.0, m)), 0, L).astype(np.int64)
+        ins = 2 * L - ov
+        short = rng.random(m) < short_frac
+        ins[short] = rng.integers(60, L, int(short.sum()))
+        T = 2 * L
+        frag = rng.integers(0, 4, (m, T), dtype=np.uint8)
+        j = np.arange(L, dtype=np.int64)[None, :]
+        rows = np.arange(m)[:, None]
+        # read 1 = fragment[0:L], adapter1 + random past the insert end
+        r1 = BASES[frag[:, :L]]
+        past = j - ins[:, None]
+        a1 = np.where(past < len(ADAPTER1), ADAPTER1[np.clip(past, 0, len(ADAPTER1) - 1)],
+                      BASES[rng.integers(0, 4, (m, L), dtype=np.uint8)])
+        r1 = np.where(past >= 0, a1, r1)
+        # read 2 = revcomp(fragment[0:ins])[0:L], adapter2 + random past the insert end
+        idx = ins[:, None] - 1 - j
+        r2 = BASES[COMP_IDX[frag[rows, np.clip(idx, 0, T - 1)]]]
+        a2 = np.where(past < len(ADAPTER2), ADAPTER2[np.clip(past, 0, len(ADAPTER2) - 1)],
+                      BASES[rng.integers(0, 4, (m, L), dtype=np.uint8)])
+        r2 = np.where(idx >= 0, r2, a2)
+        q1 = _quals(rng, (m, L))
+        q2 = _quals(rng, (m, L))
+        for r, q in ((r1, q1), (r2, q2)):
+            u = rng.random((m, L))
+            err_lo = u < 0.005
+            err_hi = (u >= 0.005) & (u < 0.006)
+            err = err_lo | err_hi
+            # substitute with a different base: rotate within ACGT
+            code = np.searchsorted(BASES, r)  # A,C,G,T -> 0..3 (BASES sorted ascending)
+            sub = BASES[(code + rng.integers(1, 4, (m, L))) % 4]
+            r[err] = sub[err]
+            lowq = np.where(rng.random((m, L)) < 0.5, ord("/"), ord("#")).astype(np.uint8)
+            q[err_lo] = lowq[err_lo]
+            q[err_hi] = ord("E")
+            nm = rng.random((m, L)) < 0.002
+            r[nm] = ord("N")
+            q[nm] = ord("#")
+        if dirty:
+            for r, q in ((r1, q1), (r2, q2)):
+                for row in np.nonzero(rng.random(m) < 0.01)[0]:
+                    k = int(rng.integers(30, min(81, L)))
+                    r[row, L - k:] = ord("G") if rng.random() < 0.7 else ord("A")
+                for row in np.nonzero(rng.random(m) < 0.02)[0]:
+                    k = int(rng.integers(min(55, L // 2), min(101, L)))
+                    q[row, rng.choice(L, k, replace=False)] = ord("#")
+                for row in np.nonzero(rng.random(m) < 0.01)[0]:
+                    k = int(rng.integers(3, 12))
+                    r[row, rng.choice(L, k, replace=False)] = ord("N")
+        if lowercase > 0:
+            lc = rng.random(m) < lowercase
+            r1[lc, :20] |= 0x20
+            r2[lc, :20] |= 0x20
+            # 'n' is not in the reference's COMP table; keep N upper case
+            r1[r1 == ord("n")] = ord("N")
+            r2[r2 == ord("n")] = ord("N")
+        if ragged:
+            l1 = rng.integers(20, L + 1, m).astype(np.uint32)
+            l2 = rng.integers(20, L + 1, m).astype(np.uint32)
+            keep = rng.random(m) < 0.5
+            l1[keep] = L
+            l2[keep] = L
+        else:
+            l1 = np.full(m, L, dtype=np.uint32)
+            l2 = np.full(m, L, dtype=np.uint32)
+        out["seq1"].append(r1.astype(np.uint8)); out["qual1"].append(q1); out["len1"].append(l1)
+        out["seq2"].append(r2.astype(np.uint8)); out["qual2"].append(q2); out["len2"].append(l2)
+        metas.append(make_names(rng, m))
+        done += m
+    res = {k: np.concatenate(v) for k, v in out.items()}
+    res["meta"] = tuple(np.concatenate([mm[i] for mm in metas]) for i in range(4))
+    return res
+
+
+def add_barcodes(d, seed, barcode_len=12, verify=b"CAGTA"):
+    """Config 5 flavour: prepend <barcode><verify> to both mates; 10 % of R1 verify sequences get
+    one mismatch, 3 % are destroyed (-> BADBCD1); a few R2 are destroyed too (-> BADBCD2)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n, L = d["seq1"].shape
+    ver = np.frombuffer(verify, dtype=np.uint8)
+    P = barcode_len + len(ver)
+    for k, frac_bad in (("1", 0.03), ("2", 0.01)):
+        pre = np.empty((n, P), dtype=np.uint8)
+        pre[:, :barcode_len] = BASES[rng.integers(0, 4, (n, barcode_len), dtype=np.uint8)]
+        pre[:, barcode_len:] = ver[None, :]
+        one = np.nonzero(rng.random(n) < 0.10)[0]
+        pos = rng.integers(0, len(ver), len(one))
+        cur = pre[one, barcode_len + pos]
+        pre[one, barcode_len + pos] = np.where(cur == ord("A"), ord("C"), ord("A"))
+        bad = np.nonzero(rng.random(n) < frac_bad)[0]
+        pre[bad, barcode_len:] = BASES[rng.integers(0, 4, (len(bad), len(ver)), dtype=np.uint8)]
+        # some barcodes are one base short / long (verify found at 11 or 13)
+        shift = rng.random(n)
+        seq = np.concatenate([pre, d["seq" + k]], axis=1)
+        qual = np.concatenate([_quals(rng, (n, P)), d["qual" + k]], axis=1)
+        shorter = np.nonzero(shift < 0.02)[0]
+        seq[shorter, :-1] = seq[shorter, 1:]
+        longer = np.nonzero((shift >= 0.02) & (shift < 0.04))[0]
+        seq[longer, 1:] = seq[longer, :-1]
+        d["seq" + k] = seq
+        d["qual" + k] = qual
+        d["len" + k] = (d["len" + k] + P).astype(np.uint32)
+    return d
+
+
+def write_fastq(path, names, seq, qual, lens, plus="+"):
+    """Render records as 4-line FASTQ text; '.gz' suffix selects gzip (fastq.py:63-76)."""
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "wb") as f:
+        buf = []
+        for i in range(len(names)):
+            l = int(lens[i])
+            buf.append(names[i].encode() + b"\n" + seq[i, :l].tobytes() + b"\n" + plus.encode() + b"\n"
+                       + qual[i, :l].tobytes() + b"\n")
+            if len(buf) >= 4096:
+                f.write(b"".join(buf)); buf = []
+        f.write(b"".join(buf))
