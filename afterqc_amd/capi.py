@@ -1,0 +1,401 @@
+"""ctypes binding of include/afterqc_hip.h (the C ABI of libafterqc_hip.so).
+
+The structures and enums below mirror the header field by field.  Loading is strict: if the HIP
+library has not been built, or no GPU is visible, the product path raises — there is NO CPU
+fallback anywhere in afterqc_amd (the CPU restatement lives in oracle/ and is test-only).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libafterqc_hip.so")
+
+AQC_MAX_READ_LEN = 1000
+AQC_QC_COLS = 1024
+
+FLAG_NAMES = ["GOOD", "BADBCD1", "BADBCD2", "BADTRIM1", "BADTRIM2", "BADBBL", "BADLEN", "BADPOL", "BADLQC",
+              "BADNCT", "BADDIFF", "BADMISMATCH"]
+(GOOD, BADBCD1, BADBCD2, BADTRIM1, BADTRIM2, BADBBL, BADLEN, BADPOL, BADLQC, BADNCT, BADDIFF,
+ BADMISMATCH) = range(12)
+N_FLAGS = 12
+EDIT_FIX_R2, EDIT_FIX_R1, EDIT_MASK = 1, 2, 3
+
+# enum aqc_counter
+C_TOTAL_READS, C_TOTAL_BASES, C_GOOD_READS, C_GOOD_BASES, C_FLAG0 = 0, 1, 2, 3, 4
+C_READ_CORRECTED = C_FLAG0 + N_FLAGS
+(C_BASE_CORRECTED, C_BASE_SKIPPED_CORRECTION, C_BASE_ZERO_QUAL_MASKED, C_OVERLAPPED, C_OVERLAP_LEN_SUM,
+ C_OVERLAP_BASE_SUM, C_OVERLAP_BASE_ERR, C_TRIMMED_ADAPTER_BASE, C_TRIMMED_ADAPTER_READ,
+ C_ERR_MATRIX0) = range(C_READ_CORRECTED + 1, C_READ_CORRECTED + 11)
+N_COUNTERS = C_ERR_MATRIX0 + 16
+
+# enum aqc_qc_row
+(QC_TOTAL_NUM, QC_TOTAL_QUAL, QC_BASE_COUNT_A, QC_BASE_COUNT_T, QC_BASE_COUNT_C, QC_BASE_COUNT_G, QC_BASE_QUAL_A,
+ QC_BASE_QUAL_T, QC_BASE_QUAL_C, QC_BASE_QUAL_G, QC_DISCONTINUITY, QC_GC_HIST, QC_SCALARS, QC_ROWS) = range(14)
+QC_R1_PRE, QC_R2_PRE, QC_R1_POST, QC_R2_POST = range(4)
+K_FILTER_OVERLAP, K_QC_STAT, N_KERNELS = 0, 1, 2
+UINT64_MAX = (1 << 64) - 1
+
+ERRORS = {-1: "HIP runtime error", -2: "bad argument", -3: "read longer than AQC_MAX_READ_LEN", -4: "no gfx950 device",
+          -5: "bad call sequence", -6: "byte outside the reference's COMP alphabet", -7: "unsupported option value"}
+
+# numpy view of struct aqc_result (packed, 32 bytes)
+EDIT_DTYPE = np.dtype([("o", "<u2"), ("kind", "u1"), ("base", "u1"), ("qual", "u1")])
+RESULT_DTYPE = np.dtype([("flag", "u1"), ("n_edits", "u1"), ("start1", "<u2"), ("len1", "<u2"), ("start2", "<u2"),
+                         ("len2", "<u2"), ("offset", "<i2"), ("overlap_len", "<u2"), ("distance", "<u2"),
+                         ("edits", EDIT_DTYPE, (3,)), ("barcode", "u1")])
+assert RESULT_DTYPE.itemsize == 32
+
+
+class Config(C.Structure):
+    """struct aqc_config"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "paired", "count_r2_bases", "trim_front", "trim_tail", "trim_front2", "trim_tail2", "seq_len_req",
+        "poly_size_limit", "allow_mismatch_in_poly", "qualified_quality_phred", "unqualified_base_limit",
+        "n_base_limit", "no_overlap", "no_correction", "mask_mismatch", "barcode", "barcode_length",
+        "barcode_verify_len")] + [("barcode_verify", C.c_uint8 * 32), ("debubble", C.c_int32), ("qc_kmer", C.c_int32)]
+
+    def set_verify(self, verify):
+        v = verify.encode() if isinstance(verify, str) else bytes(verify)
+        if len(v) > 32:
+            raise ValueError("barcode_verify longer than 32 bytes")
+        self.barcode_verify_len = len(v)
+        for i, ch in enumerate(v):
+            self.barcode_verify[i] = ch
+
+
+class BatchStruct(C.Structure):
+    """struct aqc_batch"""
+    _fields_ = [("n", C.c_uint64), ("first_index", C.c_uint64),
+                ("seq1", C.c_void_p), ("qual1", C.c_void_p), ("off1", C.c_void_p), ("qoff1", C.c_void_p),
+                ("len1", C.c_void_p), ("bytes1", C.c_uint64), ("qbytes1", C.c_uint64),
+                ("seq2", C.c_void_p), ("qual2", C.c_void_p), ("off2", C.c_void_p), ("qoff2", C.c_void_p),
+                ("len2", C.c_void_p), ("bytes2", C.c_uint64), ("qbytes2", C.c_uint64),
+                ("aux_lane", C.c_void_p), ("aux_tile", C.c_void_p), ("aux_x", C.c_void_p), ("aux_y", C.c_void_p),
+                ("aux_ok", C.c_void_p)]
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Batch:
+    """Host-side packed SoA batch (numpy owned).  Arenas are 16-byte aligned per record and padded
+    with 64 zero bytes so that vector loads past the last record stay inside the allocation."""
+
+    ALIGN = 16
+    PAD = 64
+
+    def __init__(self, n, first_index=0):
+        self.n = n
+        self.first_index = first_index
+        self.seq1 = self.qual1 = self.off1 = self.len1 = self.qoff1 = None
+        self.seq2 = self.qual2 = self.off2 = self.len2 = self.qoff2 = None
+        self.aux = None  # (lane, tile, x, y, ok) int32 x4 + uint8
+        self._keep = None
+
+    @staticmethod
+    def _offsets(lens):
+        padded = (lens.astype(np.uint64) + np.uint64(Batch.ALIGN - 1)) & ~np.uint64(Batch.ALIGN - 1)
+        off = np.zeros(len(lens), dtype=np.uint64)
+        if len(lens) > 1:
+            np.cumsum(padded[:-1], out=off[1:])
+        total = int(padded.sum()) + Batch.PAD
+        return off, total
+
+    @classmethod
+    def from_matrices(cls, seq1, qual1, len1, seq2=None, qual2=None, len2=None, first_index=0):
+        """From fixed-width uint8 matrices (synthetic workloads)."""
+        b = cls(len(len1), first_index)
+        b.seq1, b.qual1, b.off1, b.len1 = cls._pack_matrix(seq1, qual1, len1)
+        if seq2 is not None:
+            b.seq2, b.qual2, b.off2, b.len2 = cls._pack_matrix(seq2, qual2, len2)
+        return b
+
+    @staticmethod
+    def _pack_matrix(seq, qual, lens):
+        n, W = seq.shape
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        stride = (W + Batch.ALIGN - 1) // Batch.ALIGN * Batch.ALIGN
+        if np.all(lens == W):
+            # uniform lengths: the padded matrix IS the arena
+            off = (np.arange(n, dtype=np.uint64) * np.uint64(stride))
+            sa = np.zeros(n * stride + Batch.PAD, dtype=np.uint8)
+            qa = np.zeros(n * stride + Batch.PAD, dtype=np.uint8)
+            sa[:n * stride].reshape(n, stride)[:, :W] = seq
+            qa[:n * stride].reshape(n, stride)[:, :W] = qual
+            return sa, qa, off, lens
+        off, total = Batch._offsets(lens)
+        sa = np.zeros(total, dtype=np.uint8)
+        qa = np.zeros(total, dtype=np.uint8)
+        for i in range(n):
+            l = int(lens[i]); o = int(off[i])
+            sa[o:o + l] = seq[i, :l]
+            qa[o:o + l] = qual[i, :l]
+        return sa, qa, off, lens
+
+    @classmethod
+    def from_strings(cls, seqs1, quals1=None, seqs2=None, quals2=None, first_index=0):
+        """From Python bytes/str lists (tests, function seams)."""
+        b = cls(len(seqs1), first_index)
+        b.seq1, b.qual1, b.off1, b.len1 = cls._pack_strings(seqs1, quals1)
+        if seqs2 is not None:
+            b.seq2, b.qual2, b.off2, b.len2 = cls._pack_strings(seqs2, quals2)
+        return b
+
+    @staticmethod
+    def _pack_strings(seqs, quals):
+        enc = [s.encode("latin-1") if isinstance(s, str) else bytes(s) for s in seqs]
+        lens = np.array([len(s) for s in enc], dtype=np.uint32)
+        off, total = Batch._offsets(lens)
+        sa = np.zeros(total, dtype=np.uint8)
+        qa = np.zeros(total, dtype=np.uint8)
+        for i, s in enumerate(enc):
+            o = int(off[i])
+            sa[o:o + len(s)] = np.frombuffer(s, dtype=np.uint8)
+        if quals is not None:
+            for i, q in enumerate(quals):
+                q = q.encode("latin-1") if isinstance(q, str) else bytes(q)
+                if len(q) != int(lens[i]):
+                    raise ValueError("record %d: quality length %d != sequence length %d" % (i, len(q), int(lens[i])))
+                o = int(off[i])
+                qa[o:o + len(q)] = np.frombuffer(q, dtype=np.uint8)
+        else:
+            for i in range(len(enc)):
+                o = int(off[i])
+                qa[o:o + int(lens[i])] = ord("I")
+        return sa, qa, off, lens
+
+    @classmethod
+    def from_raw(cls, rb1, rb2=None, first_index=0):
+        """Zero-copy view of framed FASTQ text (afterqc_amd.fastq.RawBatch): the text chunk is the arena."""
+        b = cls(rb1.n, first_index)
+        if not np.array_equal(rb1.seq_len, rb1.qual_len):
+            raise ValueError("malformed FASTQ: sequence and quality lines differ in length (read 1)")
+        b.seq1 = b.qual1 = rb1.text
+        b.off1, b.qoff1, b.len1 = rb1.seq_off, rb1.qual_off, rb1.seq_len
+        if rb2 is not None:
+            if not np.array_equal(rb2.seq_len, rb2.qual_len):
+                raise ValueError("malformed FASTQ: sequence and quality lines differ in length (read 2)")
+            b.seq2 = b.qual2 = rb2.text
+            b.off2, b.qoff2, b.len2 = rb2.seq_off, rb2.qual_off, rb2.seq_len
+        return b
+
+    def set_aux(self, lane, tile, x, y, ok):
+        self.aux = (np.ascontiguousarray(lane, dtype=np.int32), np.ascontiguousarray(tile, dtype=np.int32),
+                    np.ascontiguousarray(x, dtype=np.int32), np.ascontiguousarray(y, dtype=np.int32),
+                    np.ascontiguousarray(ok, dtype=np.uint8))
+
+    def max_len(self):
+        m = int(self.len1.max()) if self.n else 0
+        if self.len2 is not None and self.n:
+            m = max(m, int(self.len2.max()))
+        return m
+
+    def as_struct(self):
+        s = BatchStruct()
+        s.n = self.n
+        s.first_index = self.first_index
+        s.seq1, s.qual1, s.off1, s.len1 = _ptr(self.seq1), _ptr(self.qual1), _ptr(self.off1), _ptr(self.len1)
+        s.qoff1 = _ptr(self.qoff1)
+        s.bytes1 = 0 if self.seq1 is None else self.seq1.size
+        s.qbytes1 = 0 if self.qual1 is None else self.qual1.size
+        s.seq2, s.qual2, s.off2, s.len2 = _ptr(self.seq2), _ptr(self.qual2), _ptr(self.off2), _ptr(self.len2)
+        s.qoff2 = _ptr(self.qoff2)
+        s.bytes2 = 0 if self.seq2 is None else self.seq2.size
+        s.qbytes2 = 0 if self.qual2 is None else self.qual2.size
+        if self.aux is not None:
+            s.aux_lane, s.aux_tile, s.aux_x, s.aux_y, s.aux_ok = (_ptr(a) for a in self.aux)
+        return s
+
+    def read1(self, i):
+        o = int(self.off1[i]); l = int(self.len1[i])
+        q = o if self.qoff1 is None else int(self.qoff1[i])
+        return self.seq1[o:o + l].tobytes(), self.qual1[q:q + l].tobytes()
+
+    def read2(self, i):
+        o = int(self.off2[i]); l = int(self.len2[i])
+        q = o if self.qoff2 is None else int(self.qoff2[i])
+        return self.seq2[o:o + l].tobytes(), self.qual2[q:q + l].tobytes()
+
+
+class AqcError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "afterqc_hip error %d (%s): %s" % (code, ERRORS.get(code, "?"), msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Load libafterqc_hip.so or raise: the product path has no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("HIP library %s is missing: build it with `python __graft_entry__.py build` "
+                           "(hipcc --offload-arch=gfx950); afterqc_amd has no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    lib.aqc_abi_version.restype = C.c_int
+    lib.aqc_device_count.restype = C.c_int
+    lib.aqc_last_error.restype = C.c_char_p
+    lib.aqc_create.argtypes = [C.c_int, C.c_int, C.POINTER(P)]
+    lib.aqc_destroy.argtypes = [P]
+    lib.aqc_destroy.restype = None
+    lib.aqc_device_name.argtypes = [P, C.c_char_p, C.c_int]
+    lib.aqc_set_config.argtypes = [P, C.POINTER(Config)]
+    lib.aqc_set_circles.argtypes = [P, P, P, P, P, P, C.c_int32]
+    lib.aqc_reset_stats.argtypes = [P]
+    lib.aqc_upload.argtypes = [P, C.c_int, C.POINTER(BatchStruct)]
+    lib.aqc_run.argtypes = [P, C.c_int, C.c_uint64]
+    lib.aqc_qc_stat.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int]
+    lib.aqc_fetch_results.argtypes = [P, C.c_int, P, C.c_uint64]
+    lib.aqc_sync.argtypes = [P, C.c_int]
+    lib.aqc_kernel_ms.argtypes = [P, C.c_int, P]
+    lib.aqc_get_counters.argtypes = [P, P]
+    lib.aqc_get_histograms.argtypes = [P, P, P, C.c_int32]
+    lib.aqc_get_qc.argtypes = [P, C.c_int, P]
+    lib.aqc_get_kmers.argtypes = [P, C.c_int, P, P, P, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.aqc_overlap.argtypes = [P, C.POINTER(BatchStruct), P, P, P]
+    lib.aqc_read_stats.argtypes = [P, C.POINTER(BatchStruct), C.c_int32, C.c_int32, C.c_int32, P, P, P]
+    lib.aqc_edit_distance.argtypes = [P, C.POINTER(BatchStruct), P]
+    for name in ("aqc_create", "aqc_device_name", "aqc_set_config", "aqc_set_circles", "aqc_reset_stats", "aqc_upload",
+                 "aqc_run", "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_get_counters",
+                 "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
+                 "aqc_edit_distance"):
+        getattr(lib, name).restype = C.c_int
+    if lib.aqc_abi_version() != 1:
+        raise RuntimeError("libafterqc_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_last_error", "aqc_create", "aqc_destroy",
+                    "aqc_device_name", "aqc_set_config", "aqc_set_circles", "aqc_reset_stats", "aqc_upload", "aqc_run",
+                    "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_get_counters",
+                    "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
+                    "aqc_edit_distance"]
+
+
+class Engine:
+    """One GPU context (struct aqc_ctx).  Thin, 1:1 with the C ABI."""
+
+    def __init__(self, device=0, n_slots=2):
+        self.lib = load_library()
+        if self.lib.aqc_device_count() <= 0:
+            raise RuntimeError("afterqc_amd: no AMD GPU visible (aqc_device_count() == 0); the HIP path is the only "
+                               "path — there is no CPU fallback")
+        h = C.c_void_p()
+        self._check(self.lib.aqc_create(device, n_slots, C.byref(h)))
+        self.h = h
+        self.n_slots = n_slots
+        self.slot_n = [0] * n_slots
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AqcError(rc, (self.lib.aqc_last_error() or b"").decode("utf-8", "replace"))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.aqc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.aqc_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def set_config(self, cfg):
+        self._check(self.lib.aqc_set_config(self.h, C.byref(cfg)))
+
+    def set_circles(self, circles):
+        """circles: list of (x, y, radius, lane, tile) as loaded from circles.csv"""
+        n = len(circles)
+        cx = np.array([c[0] for c in circles], dtype=np.float64)
+        cy = np.array([c[1] for c in circles], dtype=np.float64)
+        cr = np.array([c[2] for c in circles], dtype=np.float64)
+        ln = np.array([c[3] for c in circles], dtype=np.int32)
+        tl = np.array([c[4] for c in circles], dtype=np.int32)
+        self._check(self.lib.aqc_set_circles(self.h, _ptr(cx), _ptr(cy), _ptr(cr), _ptr(ln), _ptr(tl), n))
+
+    def reset_stats(self):
+        self._check(self.lib.aqc_reset_stats(self.h))
+
+    def upload(self, slot, batch):
+        s = batch.as_struct()
+        self._check(self.lib.aqc_upload(self.h, slot, C.byref(s)))
+        self.slot_n[slot] = batch.n
+
+    def run(self, slot, accum_limit=UINT64_MAX):
+        self._check(self.lib.aqc_run(self.h, slot, accum_limit))
+
+    def qc_stat(self, slot, which, mate, first, count, post):
+        self._check(self.lib.aqc_qc_stat(self.h, slot, which, mate, first, count, 1 if post else 0))
+
+    def fetch_results(self, slot):
+        out = np.zeros(self.slot_n[slot], dtype=RESULT_DTYPE)
+        self._check(self.lib.aqc_fetch_results(self.h, slot, _ptr(out), self.slot_n[slot]))
+        return out
+
+    def sync(self, slot):
+        self._check(self.lib.aqc_sync(self.h, slot))
+
+    def kernel_ms(self, slot):
+        ms = np.zeros(N_KERNELS, dtype=np.float32)
+        self._check(self.lib.aqc_kernel_ms(self.h, slot, _ptr(ms)))
+        return ms
+
+    def counters(self):
+        out = np.zeros(N_COUNTERS, dtype=np.int64)
+        self._check(self.lib.aqc_get_counters(self.h, _ptr(out)))
+        return out
+
+    def histograms(self, n=AQC_QC_COLS):
+        a = np.zeros(n, dtype=np.int64)
+        b = np.zeros(n, dtype=np.int64)
+        self._check(self.lib.aqc_get_histograms(self.h, _ptr(a), _ptr(b), n))
+        return a, b
+
+    def qc(self, which):
+        out = np.zeros((QC_ROWS, AQC_QC_COLS), dtype=np.int64)
+        self._check(self.lib.aqc_get_qc(self.h, which, _ptr(out)))
+        return out
+
+    def kmers(self, which, cap=1 << 22):
+        keys = np.zeros(cap, dtype=np.uint64)
+        counts = np.zeros(cap, dtype=np.int64)
+        order = np.zeros(cap, dtype=np.uint64)
+        n = C.c_uint64(0)
+        self._check(self.lib.aqc_get_kmers(self.h, which, _ptr(keys), _ptr(counts), _ptr(order), cap, C.byref(n)))
+        m = n.value
+        return keys[:m], counts[:m], order[:m]
+
+    # ---- function seams --------------------------------------------------------------------
+    def overlap(self, batch):
+        n = batch.n
+        off = np.zeros(n, dtype=np.int32); ol = np.zeros(n, dtype=np.int32); df = np.zeros(n, dtype=np.int32)
+        s = batch.as_struct()
+        self._check(self.lib.aqc_overlap(self.h, C.byref(s), _ptr(off), _ptr(ol), _ptr(df)))
+        return off, ol, df
+
+    def read_stats(self, batch, max_poly, mismatch, qual):
+        n = batch.n
+        px = np.zeros(n, dtype=np.uint8); lq = np.zeros(n, dtype=np.int32); nn = np.zeros(n, dtype=np.int32)
+        s = batch.as_struct()
+        self._check(self.lib.aqc_read_stats(self.h, C.byref(s), max_poly, mismatch, qual, _ptr(px), _ptr(lq), _ptr(nn)))
+        return px, lq, nn
+
+    def edit_distance(self, batch):
+        d = np.zeros(batch.n, dtype=np.int32)
+        s = batch.as_struct()
+        self._check(self.lib.aqc_edit_distance(self.h, C.byref(s), _ptr(d)))
+        return d

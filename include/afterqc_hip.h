@@ -1,0 +1,257 @@
+/*
+ * afterqc_hip.h — C ABI of the MI355X-native AfterQC hot path (libafterqc_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of OpenGene/AfterQC: the per-read loop of
+ * preprocesser.py:411-631 (filter / trim / R1xR2 overlap + correction) and the per-cycle QC
+ * accumulators of qualitycontrol.py:73-122.  Everything crossing it is a plain pointer + size;
+ * no Python / torch type appears in a signature.  The reference has no batch FFI of its own (its
+ * only native seam is editdistance/_editdistance.h:16,23), so each entry point below cites the
+ * reference *function(s)* whose work it replaces; INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative AQC_ERR_* code; aqc_last_error() returns a
+ *     thread-local human readable message for the last failure;
+ *   - one aqc_ctx per GPU, used from one host thread at a time; contexts are independent;
+ *   - host buffers are borrowed for the duration of the call only (aqc_upload copies them through
+ *     pinned staging with hipMemcpyAsync on the slot's stream);
+ *   - a "record" is one read (single-end) or one read pair; reads are byte strings exactly as in the
+ *     FASTQ file (no recoding), addressed by (offset, length) into a packed arena (SoA);
+ *   - all integer results are bit-exact restatements of the reference's arithmetic.
+ */
+#ifndef AFTERQC_HIP_H
+#define AFTERQC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AQC_ABI_VERSION 1
+
+/* longest read the reference's QC can hold (qualitycontrol.py:23 MAX_LEN = 1000) */
+#define AQC_MAX_READ_LEN 1000
+#define AQC_QC_COLS 1024 /* padded MAX_LEN */
+
+/* error codes */
+#define AQC_OK 0
+#define AQC_ERR_HIP -1          /* a HIP runtime call failed */
+#define AQC_ERR_ARG -2          /* bad argument */
+#define AQC_ERR_READ_TOO_LONG -3 /* a read is longer than AQC_MAX_READ_LEN */
+#define AQC_ERR_NO_DEVICE -4    /* no gfx950 device visible */
+#define AQC_ERR_STATE -5        /* call sequence error (e.g. results of a slot that never ran) */
+#define AQC_ERR_ALPHABET -6     /* a byte the reference would raise KeyError on (util.py:27,36-37) */
+#define AQC_ERR_UNSUPPORTED -7  /* option value outside what the device path implements */
+
+/* record verdicts == the reference's flag strings (preprocesser.py:436-614); AQC_GOOD = written to good/ */
+enum aqc_flag {
+    AQC_GOOD = 0,
+    AQC_BADBCD1 = 1,
+    AQC_BADBCD2 = 2,
+    AQC_BADTRIM1 = 3,
+    AQC_BADTRIM2 = 4,
+    AQC_BADBBL = 5,
+    AQC_BADLEN = 6,
+    AQC_BADPOL = 7,
+    AQC_BADLQC = 8,
+    AQC_BADNCT = 9,
+    AQC_BADDIFF = 10,
+    AQC_BADMISMATCH = 11,
+    AQC_N_FLAGS = 12
+};
+
+/* edit kinds recorded by the correction walk (preprocesser.py:563-598) */
+#define AQC_EDIT_FIX_R2 1 /* R2 base := complement(b1), R2 qual := q1   (preprocesser.py:575-576) */
+#define AQC_EDIT_FIX_R1 2 /* R1 base := b2, R1 qual := q2               (preprocesser.py:583-584) */
+#define AQC_EDIT_MASK 3   /* both quals := '!'                           (preprocesser.py:590-592) */
+
+#pragma pack(push, 1)
+/* one edit: `o` is the walk index of preprocesser.py:563; with the record's final len1/len2 and
+ * overlap_len the touched positions are R1[len1 - overlap_len + o] and R2[len2 - 1 - o]
+ * (indices into the FINAL, i.e. trimmed / adapter-cut, reads). */
+typedef struct aqc_edit {
+    uint16_t o;
+    uint8_t kind; /* AQC_EDIT_* */
+    uint8_t base; /* new base for FIX_*, unused for MASK */
+    uint8_t qual; /* new quality character for FIX_*, '!' for MASK */
+} aqc_edit;
+
+/* 32-byte per-record result: everything the writer needs to emit the good/bad/overlap records
+ * (preprocesser.py:206-232) without touching the sequence bytes again except to apply <=3 edits. */
+typedef struct aqc_result {
+    uint8_t flag;       /* enum aqc_flag */
+    uint8_t n_edits;    /* 0..3, applied in order even when flag == AQC_BADMISMATCH */
+    uint16_t start1;    /* final R1 = original R1[start1 : start1 + len1] */
+    uint16_t len1;
+    uint16_t start2;    /* final R2 (paired only) */
+    uint16_t len2;
+    int16_t offset;     /* final util.overlap() offset   (util.py:184,207,212) */
+    uint16_t overlap_len; /* final overlap_len */
+    uint16_t distance;  /* final diff */
+    aqc_edit edits[3];
+    uint8_t barcode;    /* low nibble: barcode length found in R1, high nibble: in R2, each coded
+                           0 none, 1 barcode_length-1, 2 barcode_length, 3 barcode_length+1
+                           (barcodeprocesser.py:19-32) */
+} aqc_result;
+#pragma pack(pop)
+
+/* options of after.py:17-92 that the per-read loop consults, after the post-processing of
+ * after.py:196-221 and the auto-trim of preprocesser.py:261-280 */
+typedef struct aqc_config {
+    int32_t paired;                  /* read2_file given */
+    int32_t count_r2_bases;          /* index2 file present -> R2 bases enter total/good bases (preprocesser.py:426-431,622-623) */
+    int32_t trim_front, trim_tail;   /* R1 (preprocesser.py:455-456) */
+    int32_t trim_front2, trim_tail2; /* R2 (preprocesser.py:462) */
+    int32_t seq_len_req;             /* -s */
+    int32_t poly_size_limit;         /* -p */
+    int32_t allow_mismatch_in_poly;  /* -a */
+    int32_t qualified_quality_phred; /* -q */
+    int32_t unqualified_base_limit;  /* -u */
+    int32_t n_base_limit;            /* -n */
+    int32_t no_overlap;              /* --no_overlap */
+    int32_t no_correction;           /* --no_correction */
+    int32_t mask_mismatch;           /* --mask_mismatch */
+    int32_t barcode;                 /* options.barcode after after.py:215-221 */
+    int32_t barcode_length;          /* --barcode_length */
+    int32_t barcode_verify_len;
+    uint8_t barcode_verify[32];      /* --barcode_verify */
+    int32_t debubble;                /* --debubble */
+    int32_t qc_kmer;                 /* --qc_kmer (1..8 on the device path) */
+} aqc_config;
+
+/* one batch of records in host memory, packed SoA.  Read i's bases are seq1[off1[i] .. +len1[i]) and
+ * its qualities qual1[qoff1[i] .. +len1[i]); qoff == NULL means "same offsets as the bases".  The
+ * two arenas may be one and the same buffer — e.g. the raw FASTQ text chunk itself, addressed in
+ * place (zero-copy framing).  Arenas must be followed by >= 64 readable bytes of padding
+ * (bytes1/bytes2 include it).  seq2/qual2/off2/len2 are NULL for single-end input.  aux_* (may be NULL unless cfg.debubble)
+ * carry the integers the reference parses out of the R1 name (preprocesser.py:180-192);
+ * aux_ok[i] == 0 means the name did not match the pattern (-> not in a bubble). */
+typedef struct aqc_batch {
+    uint64_t n;                 /* records */
+    uint64_t first_index;       /* 0-based global index of record 0 (TOTAL_READS - 1 of preprocesser.py:433) */
+    const uint8_t* seq1;
+    const uint8_t* qual1;
+    const uint64_t* off1;
+    const uint64_t* qoff1;      /* NULL -> off1 */
+    const uint32_t* len1;
+    uint64_t bytes1;            /* size of the seq1 arena (and of qual1 unless qbytes1 != 0) */
+    uint64_t qbytes1;           /* size of the qual1 arena, 0 -> bytes1 */
+    const uint8_t* seq2;
+    const uint8_t* qual2;
+    const uint64_t* off2;
+    const uint64_t* qoff2;
+    const uint32_t* len2;
+    uint64_t bytes2;
+    uint64_t qbytes2;
+    const int32_t* aux_lane;
+    const int32_t* aux_tile;
+    const int32_t* aux_x;
+    const int32_t* aux_y;
+    const uint8_t* aux_ok;
+} aqc_batch;
+
+/* scalar counters of preprocesser.py:378-409 (+ the 12-cell error matrix, init_error_matrix :125-132) */
+enum aqc_counter {
+    AQC_C_TOTAL_READS = 0,
+    AQC_C_TOTAL_BASES,
+    AQC_C_GOOD_READS,
+    AQC_C_GOOD_BASES,
+    AQC_C_FLAG0, /* AQC_C_FLAG0 + flag = number of records with that verdict (AQC_GOOD..AQC_BADMISMATCH) */
+    AQC_C_READ_CORRECTED = AQC_C_FLAG0 + AQC_N_FLAGS,
+    AQC_C_BASE_CORRECTED,
+    AQC_C_BASE_SKIPPED_CORRECTION,
+    AQC_C_BASE_ZERO_QUAL_MASKED,
+    AQC_C_OVERLAPPED,
+    AQC_C_OVERLAP_LEN_SUM,
+    AQC_C_OVERLAP_BASE_SUM,
+    AQC_C_OVERLAP_BASE_ERR,
+    AQC_C_TRIMMED_ADAPTER_BASE,
+    AQC_C_TRIMMED_ADAPTER_READ,
+    AQC_C_ERR_MATRIX0, /* 16 cells [correct][error] over A,T,C,G (diagonal unused) */
+    AQC_N_COUNTERS = AQC_C_ERR_MATRIX0 + 16
+};
+
+/* rows of one QualityControl accumulator block (qualitycontrol.py:33-57), each AQC_QC_COLS int64 */
+enum aqc_qc_row {
+    AQC_QC_TOTAL_NUM = 0,
+    AQC_QC_TOTAL_QUAL,
+    AQC_QC_BASE_COUNT_A, AQC_QC_BASE_COUNT_T, AQC_QC_BASE_COUNT_C, AQC_QC_BASE_COUNT_G,
+    AQC_QC_BASE_QUAL_A, AQC_QC_BASE_QUAL_T, AQC_QC_BASE_QUAL_C, AQC_QC_BASE_QUAL_G,
+    AQC_QC_DISCONTINUITY,
+    AQC_QC_GC_HIST,
+    AQC_QC_SCALARS, /* [0] totalKmer, [1] reads stat'd */
+    AQC_QC_ROWS
+};
+/* which QualityControl object (preprocesser.py:247-254) */
+#define AQC_QC_R1_PRE 0
+#define AQC_QC_R2_PRE 1
+#define AQC_QC_R1_POST 2
+#define AQC_QC_R2_POST 3
+
+/* kernels whose last launch duration aqc_kernel_ms() reports (HIP events on the slot's stream) */
+enum aqc_kernel_id { AQC_K_FILTER_OVERLAP = 0, AQC_K_QC_STAT = 1, AQC_N_KERNELS = 2 };
+
+typedef struct aqc_ctx aqc_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+int aqc_abi_version(void);
+int aqc_device_count(void);
+const char* aqc_last_error(void);
+/* one context per GPU; n_slots >= 1 double/triple-buffer slots, each with its own HIP stream */
+int aqc_create(int device, int n_slots, aqc_ctx** out);
+void aqc_destroy(aqc_ctx* ctx);
+int aqc_device_name(aqc_ctx* ctx, char* buf, int buflen);
+
+/* ---- configuration ---------------------------------------------------------------------------- */
+int aqc_set_config(aqc_ctx* ctx, const aqc_config* cfg);
+/* circles.csv rows (preprocesser.py:157-174): float64 x, y, radius; int lane, tile */
+int aqc_set_circles(aqc_ctx* ctx, const double* cx, const double* cy, const double* radius,
+                    const int32_t* lane, const int32_t* tile, int32_t n);
+/* zero the counters, histograms, QC accumulators and k-mer tables of the context */
+int aqc_reset_stats(aqc_ctx* ctx);
+
+/* ---- the hot path: preprocesser.py:411-631 over a batch --------------------------------------- */
+/* copy a batch into slot `slot` (async on the slot's stream, pinned staging inside) */
+int aqc_upload(aqc_ctx* ctx, int slot, const aqc_batch* batch);
+/* run filter / trim / overlap / correction over the slot's records (async).  Records with batch
+ * index >= accum_limit still get a result but do not enter counters / histograms (used for the
+ * --qc_only early break, preprocesser.py:630-631).  Pass UINT64_MAX for "all". */
+int aqc_run(aqc_ctx* ctx, int slot, uint64_t accum_limit);
+/* QualityControl.statRead (qualitycontrol.py:73-122) over records [first, first+count) of the slot
+ * into accumulator `which`, reading mate 0 (seq1/qual1) or mate 1 (seq2/qual2) of each record.
+ * post != 0: stat the FINAL reads (trim + edits from the slot's results applied) and only records
+ * whose verdict is AQC_GOOD (preprocesser.py:624-627). */
+int aqc_qc_stat(aqc_ctx* ctx, int slot, int which, int mate, uint64_t first, uint64_t count, int post);
+/* wait for the slot and copy its n result records to `out` */
+int aqc_fetch_results(aqc_ctx* ctx, int slot, aqc_result* out, uint64_t n);
+int aqc_sync(aqc_ctx* ctx, int slot);
+/* duration in ms of the last launch of each kernel on this slot (valid after aqc_sync) */
+int aqc_kernel_ms(aqc_ctx* ctx, int slot, float* ms /* [AQC_N_KERNELS] */);
+
+/* ---- accumulated statistics (host-side merge across GPUs is a plain integer sum) -------------- */
+int aqc_get_counters(aqc_ctx* ctx, int64_t* out /* [AQC_N_COUNTERS] */);
+/* overlap_histgram / distance_histgram of preprocesser.py:256-258,517,536; n <= AQC_QC_COLS entries each */
+int aqc_get_histograms(aqc_ctx* ctx, int64_t* overlap_hist, int64_t* distance_hist, int32_t n);
+int aqc_get_qc(aqc_ctx* ctx, int which, int64_t* out /* [AQC_QC_ROWS * AQC_QC_COLS] */);
+/* k-mer dictionary of QualityControl `which` (qualitycontrol.py:113-122): keys as 8 raw bytes
+ * (zero padded above qc_kmer), counts, and the dict insertion rank (ties in sortKmer keep it).
+ * Returns the number of entries through *n (<= cap). */
+int aqc_get_kmers(aqc_ctx* ctx, int which, uint64_t* keys, int64_t* counts, uint64_t* order,
+                  uint64_t cap, uint64_t* n);
+
+/* ---- function seams (same device code as the hot path, one result per input) ------------------ */
+/* util.overlap(r1, r2) (util.py:88-89,158-212) for n pairs -> offset / overlap_len / diff */
+int aqc_overlap(aqc_ctx* ctx, const aqc_batch* pairs, int32_t* offset, int32_t* overlap_len, int32_t* diff);
+/* hasPolyX(seq, maxPoly, mismatch) (preprocesser.py:30-51) on seq1 -> the byte found or 0 for None;
+ * lowQualityNum(read, qual) (:61-68) on qual1; nNumber(read) (:70-76) on seq1 */
+int aqc_read_stats(aqc_ctx* ctx, const aqc_batch* reads, int32_t max_poly, int32_t mismatch, int32_t qual,
+                   uint8_t* polyx, int32_t* low_qual, int32_t* n_count);
+/* util.editDistance(a, b) (util.py:65-83; native twin editdistance/_editdistance.h:16) for n string pairs
+ * given as seq1 (a) / seq2 (b) of a batch; strings up to 64 bytes on the device path */
+int aqc_edit_distance(aqc_ctx* ctx, const aqc_batch* pairs, int32_t* dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFTERQC_HIP_H */

@@ -1,0 +1,84 @@
+"""End-to-end golden cases on CPU: the product's host driver (afterqc_amd.after / preprocesser / qc /
+fastq) runs with the ORACLE engine injected, and its outputs are compared with what the real
+reference produced for the same inputs (tests/golden/e2e_cases.json.gz): byte-identical good / bad /
+overlap FASTQ (sha256 of the decompressed files) and an identical stats JSON.
+
+This pins (a) the oracle end to end and (b) every piece of host logic — framing, sampling policy,
+auto-trim floats, writers, JSON schema.  The same cases run against the HIP engine in
+tests/test_gpu_e2e.py (-m gpu)."""
+import gzip
+import hashlib
+import json
+import math
+import os
+
+import pytest
+
+import cases
+from afterqc_amd import after
+
+CASE_TABLE = {c[0]: c for c in cases.CASES}
+
+
+def run_case(name, tmp_path, engine):
+    _, argv, spec, _ = CASE_TABLE[name]
+    work = str(tmp_path)
+    cases.materialize(spec, work)
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        (options, args) = after.parseCommand(list(argv))
+        after.finalize_options(options)
+        if options.barcode_flag in options.read1_file and after.parseBool(options.barcode):
+            options.barcode = True
+            options.trim_front = 0
+            options.trim_front2 = 0
+        else:
+            options.barcode = False
+        stat = after.processOptions(options, engine=engine)
+    finally:
+        os.chdir(cwd)
+    return work, stat
+
+
+def digest(path):
+    op = gzip.open if path.endswith(".gz") else open
+    with op(path, "rb") as f:
+        data = f.read()
+    return {"sha256": hashlib.sha256(data).hexdigest(), "lines": data.count(b"\n"), "bytes": len(data)}
+
+
+def check_case(name, work, stat, golden):
+    rec = golden[name]
+    # ---- files: same set, same decompressed bytes
+    for rel, exp in rec["files"].items():
+        path = os.path.join(work, rel)
+        assert os.path.exists(path), "missing output " + rel
+        got = digest(path)
+        assert got == exp, (name, rel, got, exp)
+    for sub in ("good", "bad", "overlap", "gout", "bout"):
+        d = os.path.join(work, sub)
+        if os.path.isdir(d):
+            for fn in os.listdir(d):
+                assert sub + "/" + fn in rec["files"], "unexpected output %s/%s" % (sub, fn)
+    # ---- stats JSON: identical after the two documented py2/py3 deltas
+    with open(os.path.join(work, rec["stat_file"])) as f:
+        mine = json.load(f)
+    exp = rec["stat"]
+    if "afterqc_overlap" in exp:
+        # golden was captured under py3 (true division); the reference under py2 floors it
+        exp = json.loads(json.dumps(exp))
+        exp["afterqc_overlap"]["average_overlap_length"] = float(math.floor(exp["afterqc_overlap"]["average_overlap_length"]))
+    assert mine.keys() == exp.keys()
+    for k in exp:
+        assert mine[k] == exp[k], (name, k)
+
+
+CPU_CASES = [c[0] for c in cases.CASES]
+
+
+@pytest.mark.parametrize("name", CPU_CASES)
+def test_host_with_oracle_engine(name, tmp_path, e2e):
+    from oracle import oracle
+    work, stat = run_case(name, tmp_path, oracle.OracleEngine())
+    check_case(name, work, stat, e2e)
