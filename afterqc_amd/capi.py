@@ -255,6 +255,8 @@ def load_library():
     lib.aqc_fetch_results.argtypes = [P, C.c_int, P, C.c_uint64]
     lib.aqc_sync.argtypes = [P, C.c_int]
     lib.aqc_kernel_ms.argtypes = [P, C.c_int, P]
+    lib.aqc_timing_reset.argtypes = [P, C.c_int]
+    lib.aqc_timing_mean.argtypes = [P, C.c_int, P, P]
     lib.aqc_get_counters.argtypes = [P, P]
     lib.aqc_get_histograms.argtypes = [P, P, P, C.c_int32]
     lib.aqc_get_qc.argtypes = [P, C.c_int, P]
@@ -263,9 +265,9 @@ def load_library():
     lib.aqc_read_stats.argtypes = [P, C.POINTER(BatchStruct), C.c_int32, C.c_int32, C.c_int32, P, P, P]
     lib.aqc_edit_distance.argtypes = [P, C.POINTER(BatchStruct), P]
     for name in ("aqc_create", "aqc_device_name", "aqc_set_config", "aqc_set_circles", "aqc_reset_stats", "aqc_upload",
-                 "aqc_run", "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_get_counters",
-                 "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
-                 "aqc_edit_distance"):
+                 "aqc_run", "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_timing_reset",
+                 "aqc_timing_mean", "aqc_get_counters", "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers",
+                 "aqc_overlap", "aqc_read_stats", "aqc_edit_distance"):
         getattr(lib, name).restype = C.c_int
     if lib.aqc_abi_version() != 1:
         raise RuntimeError("libafterqc_hip.so ABI version mismatch")
@@ -275,7 +277,8 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_last_error", "aqc_create", "aqc_destroy",
                     "aqc_device_name", "aqc_set_config", "aqc_set_circles", "aqc_reset_stats", "aqc_upload", "aqc_run",
-                    "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_get_counters",
+                    "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_timing_reset",
+                    "aqc_timing_mean", "aqc_get_counters",
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
                     "aqc_edit_distance"]
 
@@ -353,6 +356,15 @@ class Engine:
         ms = np.zeros(N_KERNELS, dtype=np.float32)
         self._check(self.lib.aqc_kernel_ms(self.h, slot, _ptr(ms)))
         return ms
+
+    def timing_reset(self, slot):
+        self._check(self.lib.aqc_timing_reset(self.h, slot))
+
+    def timing_mean(self, slot):
+        ms = np.zeros(N_KERNELS, dtype=np.float32)
+        n = np.zeros(N_KERNELS, dtype=np.int32)
+        self._check(self.lib.aqc_timing_mean(self.h, slot, _ptr(ms), _ptr(n)))
+        return ms, n
 
     def counters(self):
         out = np.zeros(N_COUNTERS, dtype=np.int64)

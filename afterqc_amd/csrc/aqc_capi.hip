@@ -1,0 +1,609 @@
+// aqc_capi.hip — host side of libafterqc_hip.so: the C ABI declared in include/afterqc_hip.h.
+//
+// One aqc_ctx per GPU.  Each slot owns a HIP stream, device copies of one batch (grow-on-demand,
+// sized for 288 GB parts: batches of millions of pairs are the norm) and a result buffer; uploads
+// are hipMemcpyAsync on the slot's stream so that slot k+1 uploads while slot k computes.
+// Statistics (counters, histograms, QC accumulators, k-mer tables) live in HBM for the lifetime of
+// the context and are only copied back on request.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "aqc_kernels.hpp"
+
+using namespace aqc;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(AQC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) return -1;
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    DevBuf seq1, qual1, off1, qoff1, len1, seq2, qual2, off2, qoff2, len2, aux[5], results;
+    DevBatch view{};
+    uint64_t n = 0;
+    bool paired = false, ran = false, same_arena1 = false, same_arena2 = false;
+    hipEvent_t ev[AQC_N_KERNELS][2] = {};
+    bool timed[AQC_N_KERNELS] = {};
+    // timing region (aqc_timing_reset / aqc_timing_mean): one event pair per launch
+    std::vector<hipEvent_t> ring[AQC_N_KERNELS][2];
+    int ring_used[AQC_N_KERNELS] = {};
+    bool collecting = false;
+};
+
+constexpr int RING_CAP = 256;
+
+// record the start/stop event of a launch: the "last launch" pair, or the next ring pair while collecting
+static hipEvent_t launch_event(Slot& s, int k, int which) {
+    if (s.collecting && s.ring_used[k] < RING_CAP) {
+        if ((int)s.ring[k][which].size() <= s.ring_used[k]) {
+            hipEvent_t e = nullptr;
+            (void)hipEventCreate(&e);
+            s.ring[k][which].push_back(e);
+        }
+        hipEvent_t e = s.ring[k][which][s.ring_used[k]];
+        if (which == 1) s.ring_used[k]++;
+        return e;
+    }
+    return s.ev[k][which];
+}
+
+constexpr uint64_t KMER_CAP = 1ull << 21;
+
+struct QcDev {
+    unsigned long long* acc = nullptr;   // [QC_ROWS * QC_COLS]
+    KmerTable kt{};
+    unsigned long long order_base = 0;
+};
+
+}  // namespace
+
+struct aqc_ctx {
+    int device = 0;
+    int n_slots = 0;
+    std::vector<Slot> slots;
+    aqc_config cfg{};
+    bool has_cfg = false;
+    DevBuf circ[5];
+    DevCircles circles{};
+    unsigned long long *counters = nullptr, *ovl_hist = nullptr, *dist_hist = nullptr;
+    int* status = nullptr;
+    QcDev qc[4];
+    int n_cu = 256;
+    char name[256] = "";
+};
+
+static int check_status(aqc_ctx* c) {
+    int st = 0;
+    HIP_TRY(hipMemcpy(&st, c->status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st != 0) {
+        int zero = 0;
+        (void)hipMemcpy(c->status, &zero, sizeof(int), hipMemcpyHostToDevice);
+        const char* what = st == AQC_ERR_ALPHABET ? "a base outside the reference's COMP table reached the correction walk (KeyError upstream)"
+                         : st == AQC_ERR_READ_TOO_LONG ? "a read is longer than AQC_MAX_READ_LEN"
+                         : st == AQC_ERR_ARG ? "a read shorter than 5 bases reached statRead (IndexError upstream)"
+                         : st == AQC_ERR_UNSUPPORTED ? "device limit exceeded (k-mer table full or string longer than 64)"
+                                                     : "device-side error";
+        return fail(st, "%s", what);
+    }
+    return 0;
+}
+
+extern "C" {
+
+int aqc_abi_version(void) { return AQC_ABI_VERSION; }
+
+int aqc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* aqc_last_error(void) { return g_err; }
+
+int aqc_create(int device, int n_slots, aqc_ctx** out) {
+    if (!out || n_slots < 1 || n_slots > 16) return fail(AQC_ERR_ARG, "aqc_create: bad arguments");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(AQC_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(AQC_ERR_ARG, "device %d out of range (%d visible)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    aqc_ctx* c = new aqc_ctx();
+    c->device = device;
+    c->n_slots = n_slots;
+    c->slots.resize(n_slots);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(c->name, sizeof(c->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    for (auto& s : c->slots) {
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        for (int k = 0; k < AQC_N_KERNELS; k++)
+            for (int j = 0; j < 2; j++) HIP_TRY(hipEventCreate(&s.ev[k][j]));
+    }
+    HIP_TRY(hipMalloc((void**)&c->counters, sizeof(unsigned long long) * AQC_N_COUNTERS));
+    HIP_TRY(hipMalloc((void**)&c->ovl_hist, sizeof(unsigned long long) * AQC_QC_COLS));
+    HIP_TRY(hipMalloc((void**)&c->dist_hist, sizeof(unsigned long long) * AQC_QC_COLS));
+    HIP_TRY(hipMalloc((void**)&c->status, sizeof(int)));
+    for (int k = 0; k < 4; k++)
+        HIP_TRY(hipMalloc((void**)&c->qc[k].acc, sizeof(unsigned long long) * AQC_QC_ROWS * AQC_QC_COLS));
+    *out = c;
+    return aqc_reset_stats(c);
+}
+
+void aqc_destroy(aqc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& s : c->slots) {
+        DevBuf* bufs[] = {&s.seq1, &s.qual1, &s.off1, &s.qoff1, &s.len1, &s.seq2, &s.qual2, &s.off2, &s.qoff2, &s.len2,
+                          &s.aux[0], &s.aux[1], &s.aux[2], &s.aux[3], &s.aux[4], &s.results};
+        for (DevBuf* b : bufs) b->release();
+        for (int k = 0; k < AQC_N_KERNELS; k++)
+            for (int j = 0; j < 2; j++) {
+                if (s.ev[k][j]) (void)hipEventDestroy(s.ev[k][j]);
+                for (hipEvent_t e : s.ring[k][j]) (void)hipEventDestroy(e);
+            }
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    for (auto& b : c->circ) b.release();
+    (void)hipFree(c->counters); (void)hipFree(c->ovl_hist); (void)hipFree(c->dist_hist); (void)hipFree(c->status);
+    for (int k = 0; k < 4; k++) {
+        (void)hipFree(c->qc[k].acc);
+        if (c->qc[k].kt.keys) { (void)hipFree(c->qc[k].kt.keys); (void)hipFree(c->qc[k].kt.counts); (void)hipFree(c->qc[k].kt.order); }
+    }
+    delete c;
+}
+
+int aqc_device_name(aqc_ctx* c, char* buf, int buflen) {
+    if (!c || !buf || buflen <= 0) return fail(AQC_ERR_ARG, "aqc_device_name: bad arguments");
+    snprintf(buf, (size_t)buflen, "%s", c->name);
+    return 0;
+}
+
+int aqc_set_config(aqc_ctx* c, const aqc_config* cfg) {
+    if (!c || !cfg) return fail(AQC_ERR_ARG, "aqc_set_config: null argument");
+    if (cfg->trim_front < 0 || cfg->trim_tail < 0 || cfg->trim_front2 < 0 || cfg->trim_tail2 < 0)
+        return fail(AQC_ERR_ARG, "trim values must be resolved (>= 0) before they reach the device");
+    if (cfg->qc_kmer < 1 || cfg->qc_kmer > 8) return fail(AQC_ERR_UNSUPPORTED, "qc_kmer %d outside 1..8", cfg->qc_kmer);
+    if (cfg->barcode) {
+        if (cfg->barcode_verify_len < 0 || cfg->barcode_verify_len > 32 || cfg->barcode_length < 1 ||
+            cfg->barcode_length + 1 + cfg->barcode_verify_len > 62)
+            return fail(AQC_ERR_UNSUPPORTED, "barcode_length + verify too long for the device path");
+    }
+    c->cfg = *cfg;
+    c->has_cfg = true;
+    return 0;
+}
+
+int aqc_set_circles(aqc_ctx* c, const double* cx, const double* cy, const double* r, const int32_t* lane,
+                    const int32_t* tile, int32_t n) {
+    if (!c || n < 0) return fail(AQC_ERR_ARG, "aqc_set_circles: bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    c->circles = DevCircles{};
+    c->circles.n = n;
+    if (n == 0) return 0;
+    const void* src[5] = {cx, cy, r, lane, tile};
+    const size_t sz[5] = {sizeof(double) * n, sizeof(double) * n, sizeof(double) * n, sizeof(int32_t) * n, sizeof(int32_t) * n};
+    for (int k = 0; k < 5; k++) {
+        if (!src[k]) return fail(AQC_ERR_ARG, "aqc_set_circles: null array");
+        if (c->circ[k].reserve(sz[k])) return fail(AQC_ERR_HIP, "hipMalloc failed");
+        HIP_TRY(hipMemcpy(c->circ[k].p, src[k], sz[k], hipMemcpyHostToDevice));
+    }
+    c->circles.cx = (const double*)c->circ[0].p;
+    c->circles.cy = (const double*)c->circ[1].p;
+    c->circles.cr = (const double*)c->circ[2].p;
+    c->circles.lane = (const int32_t*)c->circ[3].p;
+    c->circles.tile = (const int32_t*)c->circ[4].p;
+    return 0;
+}
+
+int aqc_reset_stats(aqc_ctx* c) {
+    if (!c) return fail(AQC_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(c->counters, 0, sizeof(unsigned long long) * AQC_N_COUNTERS));
+    HIP_TRY(hipMemset(c->ovl_hist, 0, sizeof(unsigned long long) * AQC_QC_COLS));
+    HIP_TRY(hipMemset(c->dist_hist, 0, sizeof(unsigned long long) * AQC_QC_COLS));
+    HIP_TRY(hipMemset(c->status, 0, sizeof(int)));
+    for (int k = 0; k < 4; k++) {
+        HIP_TRY(hipMemset(c->qc[k].acc, 0, sizeof(unsigned long long) * AQC_QC_ROWS * AQC_QC_COLS));
+        c->qc[k].order_base = 0;
+        if (c->qc[k].kt.keys) {
+            HIP_TRY(hipMemset(c->qc[k].kt.keys, 0, sizeof(unsigned long long) * KMER_CAP));
+            HIP_TRY(hipMemset(c->qc[k].kt.counts, 0, sizeof(unsigned long long) * KMER_CAP));
+            HIP_TRY(hipMemset(c->qc[k].kt.order, 0xff, sizeof(unsigned long long) * KMER_CAP));
+        }
+    }
+    return 0;
+}
+
+static int up(DevBuf& d, const void* src, size_t bytes, hipStream_t st) {
+    if (d.reserve(bytes)) return fail(AQC_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
+    if (bytes == 0) return 0;
+    HIP_TRY(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+static int fill_slot(aqc_ctx* c, Slot& s, const aqc_batch* b, bool need_qual, bool need_pair) {
+    const uint64_t n = b->n;
+    if (!b->seq1 || !b->off1 || !b->len1) return fail(AQC_ERR_ARG, "batch: seq1/off1/len1 are required");
+    const bool paired = b->seq2 != nullptr;
+    if (need_pair && !paired) return fail(AQC_ERR_ARG, "batch: this call needs seq2/off2/len2");
+    if (paired && (!b->off2 || !b->len2)) return fail(AQC_ERR_ARG, "batch: off2/len2 missing");
+    // make sure earlier work on this slot has drained before its buffers are overwritten / regrown
+    HIP_TRY(hipStreamSynchronize(s.stream));
+    int rc;
+    DevBatch v{};
+    v.n = n;
+    v.first_index = b->first_index;
+    if ((rc = up(s.seq1, b->seq1, b->bytes1, s.stream))) return rc;
+    v.seq1 = (const uint8_t*)s.seq1.p;
+    if (b->qual1 && need_qual) {
+        if (b->qual1 == b->seq1) v.qual1 = v.seq1;
+        else {
+            if ((rc = up(s.qual1, b->qual1, b->qbytes1 ? b->qbytes1 : b->bytes1, s.stream))) return rc;
+            v.qual1 = (const uint8_t*)s.qual1.p;
+        }
+    } else if (need_qual) return fail(AQC_ERR_ARG, "batch: qual1 is required");
+    if ((rc = up(s.off1, b->off1, sizeof(uint64_t) * n, s.stream))) return rc;
+    v.off1 = (const uint64_t*)s.off1.p;
+    if (b->qoff1) {
+        if ((rc = up(s.qoff1, b->qoff1, sizeof(uint64_t) * n, s.stream))) return rc;
+        v.qoff1 = (const uint64_t*)s.qoff1.p;
+    }
+    if ((rc = up(s.len1, b->len1, sizeof(uint32_t) * n, s.stream))) return rc;
+    v.len1 = (const uint32_t*)s.len1.p;
+    if (paired) {
+        if ((rc = up(s.seq2, b->seq2, b->bytes2, s.stream))) return rc;
+        v.seq2 = (const uint8_t*)s.seq2.p;
+        if (b->qual2 && need_qual) {
+            if (b->qual2 == b->seq2) v.qual2 = v.seq2;
+            else {
+                if ((rc = up(s.qual2, b->qual2, b->qbytes2 ? b->qbytes2 : b->bytes2, s.stream))) return rc;
+                v.qual2 = (const uint8_t*)s.qual2.p;
+            }
+        } else if (need_qual) return fail(AQC_ERR_ARG, "batch: qual2 is required");
+        if ((rc = up(s.off2, b->off2, sizeof(uint64_t) * n, s.stream))) return rc;
+        v.off2 = (const uint64_t*)s.off2.p;
+        if (b->qoff2) {
+            if ((rc = up(s.qoff2, b->qoff2, sizeof(uint64_t) * n, s.stream))) return rc;
+            v.qoff2 = (const uint64_t*)s.qoff2.p;
+        }
+        if ((rc = up(s.len2, b->len2, sizeof(uint32_t) * n, s.stream))) return rc;
+        v.len2 = (const uint32_t*)s.len2.p;
+    }
+    if (b->aux_ok && b->aux_lane && b->aux_tile && b->aux_x && b->aux_y) {
+        const void* src[5] = {b->aux_lane, b->aux_tile, b->aux_x, b->aux_y, b->aux_ok};
+        for (int k = 0; k < 5; k++)
+            if ((rc = up(s.aux[k], src[k], (k < 4 ? sizeof(int32_t) : 1) * n, s.stream))) return rc;
+        v.aux_lane = (const int32_t*)s.aux[0].p;
+        v.aux_tile = (const int32_t*)s.aux[1].p;
+        v.aux_x = (const int32_t*)s.aux[2].p;
+        v.aux_y = (const int32_t*)s.aux[3].p;
+        v.aux_ok = (const uint8_t*)s.aux[4].p;
+    }
+    if (s.results.reserve(sizeof(aqc_result) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    s.view = v;
+    s.n = n;
+    s.paired = paired;
+    s.ran = false;
+    return 0;
+}
+
+static int get_slot(aqc_ctx* c, int slot, Slot** out) {
+    if (!c) return fail(AQC_ERR_ARG, "null context");
+    if (slot < 0 || slot >= c->n_slots) return fail(AQC_ERR_ARG, "slot %d out of range", slot);
+    HIP_TRY(hipSetDevice(c->device));
+    *out = &c->slots[slot];
+    return 0;
+}
+
+int aqc_upload(aqc_ctx* c, int slot, const aqc_batch* b) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!b) return fail(AQC_ERR_ARG, "null batch");
+    return fill_slot(c, *s, b, true, false);
+}
+
+static int grid_for(const aqc_ctx* c, uint64_t n) {
+    // persistent grid: enough workgroups to fill every CU several times over, records grid-strided
+    uint64_t blocks = (n + WPB - 1) / WPB;
+    uint64_t cap = (uint64_t)c->n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!c->has_cfg) return fail(AQC_ERR_STATE, "aqc_run before aqc_set_config");
+    if (c->cfg.paired && !s->paired) return fail(AQC_ERR_STATE, "config says paired but the slot holds single-end records");
+    if (c->cfg.debubble && c->circles.n > 0 && !s->view.aux_ok) return fail(AQC_ERR_ARG, "debubble needs the aux_* arrays");
+    if (s->n == 0) { s->ran = true; return 0; }
+    aqc_config cfg = c->cfg;
+    if (!cfg.paired) cfg.no_overlap = 1;
+    DevStats st{c->counters, c->ovl_hist, c->dist_hist, c->status};
+    HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_FILTER_OVERLAP, 0), s->stream));
+    hipLaunchKernelGGL(filter_overlap_kernel, dim3(grid_for(c, s->n)), dim3(BLOCK), 0, s->stream, s->view, cfg, c->circles,
+                       (aqc_result*)s->results.p, st, accum_limit);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_FILTER_OVERLAP, 1), s->stream));
+    s->timed[AQC_K_FILTER_OVERLAP] = !s->collecting;
+    s->ran = true;
+    return 0;
+}
+
+static int ensure_kmer(aqc_ctx* c, QcDev& q) {
+    if (q.kt.keys) return 0;
+    HIP_TRY(hipMalloc((void**)&q.kt.keys, sizeof(unsigned long long) * KMER_CAP));
+    HIP_TRY(hipMalloc((void**)&q.kt.counts, sizeof(unsigned long long) * KMER_CAP));
+    HIP_TRY(hipMalloc((void**)&q.kt.order, sizeof(unsigned long long) * KMER_CAP));
+    HIP_TRY(hipMemset(q.kt.keys, 0, sizeof(unsigned long long) * KMER_CAP));
+    HIP_TRY(hipMemset(q.kt.counts, 0, sizeof(unsigned long long) * KMER_CAP));
+    HIP_TRY(hipMemset(q.kt.order, 0xff, sizeof(unsigned long long) * KMER_CAP));
+    q.kt.mask = KMER_CAP - 1;
+    return 0;
+}
+
+int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint64_t count, int post) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (which < 0 || which > 3 || mate < 0 || mate > 1) return fail(AQC_ERR_ARG, "aqc_qc_stat: bad which/mate");
+    if (!c->has_cfg) return fail(AQC_ERR_STATE, "aqc_qc_stat before aqc_set_config");
+    if (first + count > s->n) return fail(AQC_ERR_ARG, "aqc_qc_stat: range exceeds the slot's %llu records", (unsigned long long)s->n);
+    if (mate == 1 && !s->paired) return fail(AQC_ERR_ARG, "aqc_qc_stat: mate 1 of a single-end slot");
+    if (post && !s->ran) return fail(AQC_ERR_STATE, "aqc_qc_stat(post) before aqc_run");
+    if (count == 0) return 0;
+    QcDev& q = c->qc[which];
+    if ((rc = ensure_kmer(c, q))) return rc;
+    HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 0), s->stream));
+    uint64_t blocks = (count + WPB - 1) / WPB;
+    if (blocks > (uint64_t)c->n_cu * 2) blocks = (uint64_t)c->n_cu * 2;
+    hipLaunchKernelGGL(qc_stat_kernel, dim3((int)blocks), dim3(BLOCK), 0, s->stream, s->view, mate, first, count, post,
+                       (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, q.kt, q.order_base, c->status);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 1), s->stream));
+    s->timed[AQC_K_QC_STAT] = !s->collecting;
+    q.order_base += count;
+    return 0;
+}
+
+int aqc_sync(aqc_ctx* c, int slot) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return check_status(c);
+}
+
+int aqc_fetch_results(aqc_ctx* c, int slot, aqc_result* out, uint64_t n) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!s->ran) return fail(AQC_ERR_STATE, "aqc_fetch_results before aqc_run");
+    if (n > s->n) return fail(AQC_ERR_ARG, "aqc_fetch_results: n exceeds the slot's records");
+    if (n) HIP_TRY(hipMemcpyAsync(out, s->results.p, sizeof(aqc_result) * n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return check_status(c);
+}
+
+int aqc_kernel_ms(aqc_ctx* c, int slot, float* ms) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int k = 0; k < AQC_N_KERNELS; k++) {
+        ms[k] = 0.f;
+        if (s->timed[k]) HIP_TRY(hipEventElapsedTime(&ms[k], s->ev[k][0], s->ev[k][1]));
+    }
+    return 0;
+}
+
+int aqc_timing_reset(aqc_ctx* c, int slot) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int k = 0; k < AQC_N_KERNELS; k++) { s->ring_used[k] = 0; s->timed[k] = false; }
+    s->collecting = true;
+    return 0;
+}
+
+int aqc_timing_mean(aqc_ctx* c, int slot, float* mean_ms, int32_t* launches) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!mean_ms || !launches) return fail(AQC_ERR_ARG, "null argument");
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int k = 0; k < AQC_N_KERNELS; k++) {
+        double sum = 0;
+        for (int i = 0; i < s->ring_used[k]; i++) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, s->ring[k][0][i], s->ring[k][1][i]));
+            sum += ms;
+        }
+        launches[k] = s->ring_used[k];
+        mean_ms[k] = s->ring_used[k] ? (float)(sum / s->ring_used[k]) : 0.f;
+    }
+    s->collecting = false;
+    return 0;
+}
+
+static int sync_all(aqc_ctx* c) {
+    HIP_TRY(hipSetDevice(c->device));
+    for (auto& s : c->slots) HIP_TRY(hipStreamSynchronize(s.stream));
+    return check_status(c);
+}
+
+int aqc_get_counters(aqc_ctx* c, int64_t* out) {
+    if (!c || !out) return fail(AQC_ERR_ARG, "null argument");
+    int rc = sync_all(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, c->counters, sizeof(int64_t) * AQC_N_COUNTERS, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int aqc_get_histograms(aqc_ctx* c, int64_t* ovl, int64_t* dist, int32_t n) {
+    if (!c || !ovl || !dist || n < 0 || n > AQC_QC_COLS) return fail(AQC_ERR_ARG, "bad argument");
+    int rc = sync_all(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(ovl, c->ovl_hist, sizeof(int64_t) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dist, c->dist_hist, sizeof(int64_t) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int aqc_get_qc(aqc_ctx* c, int which, int64_t* out) {
+    if (!c || !out || which < 0 || which > 3) return fail(AQC_ERR_ARG, "bad argument");
+    int rc = sync_all(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, c->qc[which].acc, sizeof(int64_t) * AQC_QC_ROWS * AQC_QC_COLS, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int aqc_get_kmers(aqc_ctx* c, int which, uint64_t* keys, int64_t* counts, uint64_t* order, uint64_t cap, uint64_t* n) {
+    if (!c || !n || which < 0 || which > 3) return fail(AQC_ERR_ARG, "bad argument");
+    int rc = sync_all(c);
+    if (rc) return rc;
+    *n = 0;
+    QcDev& q = c->qc[which];
+    if (!q.kt.keys) return 0;
+    const uint64_t dcap = cap < KMER_CAP ? cap : KMER_CAP;
+    unsigned long long *dk = nullptr, *dc = nullptr, *dord = nullptr, *dn = nullptr;
+    HIP_TRY(hipMalloc((void**)&dk, 8 * (dcap + 1)));
+    HIP_TRY(hipMalloc((void**)&dc, 8 * (dcap + 1)));
+    HIP_TRY(hipMalloc((void**)&dord, 8 * (dcap + 1)));
+    HIP_TRY(hipMalloc((void**)&dn, 8));
+    HIP_TRY(hipMemset(dn, 0, 8));
+    hipLaunchKernelGGL(kmer_compact_kernel, dim3((unsigned)(KMER_CAP / 256)), dim3(256), 0, 0, q.kt, dk, dc, dord,
+                       (unsigned long long)dcap, dn);
+    HIP_TRY(hipGetLastError());
+    unsigned long long m = 0;
+    HIP_TRY(hipMemcpy(&m, dn, 8, hipMemcpyDeviceToHost));
+    const uint64_t w = m < dcap ? m : dcap;
+    if (w) {
+        HIP_TRY(hipMemcpy(keys, dk, 8 * w, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(counts, dc, 8 * w, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(order, dord, 8 * w, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dk); (void)hipFree(dc); (void)hipFree(dord); (void)hipFree(dn);
+    *n = m;
+    if (m > dcap) return fail(AQC_ERR_ARG, "aqc_get_kmers: %llu entries exceed cap %llu", m, (unsigned long long)dcap);
+    return 0;
+}
+
+// ---- function seams: run on a scratch slot (the last one) -------------------------------------------
+static int seam_prepare(aqc_ctx* c, const aqc_batch* b, bool need_qual, bool need_pair, Slot** out) {
+    if (!c || !b) return fail(AQC_ERR_ARG, "null argument");
+    Slot* s;
+    int rc = get_slot(c, c->n_slots - 1, &s);
+    if (rc) return rc;
+    if ((rc = fill_slot(c, *s, b, need_qual, need_pair))) return rc;
+    for (uint64_t i = 0; i < b->n; i++)
+        if (b->len1[i] > AQC_MAX_READ_LEN || (need_pair && b->len2[i] > AQC_MAX_READ_LEN))
+            return fail(AQC_ERR_READ_TOO_LONG, "record %llu is longer than %d", (unsigned long long)i, AQC_MAX_READ_LEN);
+    *out = s;
+    return 0;
+}
+
+static int seam_out_bytes(Slot* s, DevBuf& d, void* host, size_t bytes) {
+    if (bytes) HIP_TRY(hipMemcpyAsync(host, d.p, bytes, hipMemcpyDeviceToHost, s->stream));
+    return 0;
+}
+#define seam_out(s, d, host, n) seam_out_bytes(s, d, host, sizeof(*(host)) * (n))
+
+int aqc_overlap(aqc_ctx* c, const aqc_batch* b, int32_t* offset, int32_t* overlap_len, int32_t* diff) {
+    Slot* s;
+    int rc = seam_prepare(c, b, false, true, &s);
+    if (rc) return rc;
+    const uint64_t n = b->n;
+    if (n == 0) return 0;
+    DevBuf o[3];
+    for (auto& d : o)
+        if (d.reserve(4 * n)) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    hipLaunchKernelGGL(overlap_seam_kernel, dim3((unsigned)((n + WPB - 1) / WPB)), dim3(BLOCK), 0, s->stream, s->view,
+                       (int32_t*)o[0].p, (int32_t*)o[1].p, (int32_t*)o[2].p);
+    HIP_TRY(hipGetLastError());
+    if ((rc = seam_out(s, o[0], offset, n)) || (rc = seam_out(s, o[1], overlap_len, n)) || (rc = seam_out(s, o[2], diff, n))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (auto& d : o) d.release();
+    return 0;
+}
+
+int aqc_read_stats(aqc_ctx* c, const aqc_batch* b, int32_t max_poly, int32_t mismatch, int32_t qual, uint8_t* polyx,
+                   int32_t* low_qual, int32_t* n_count) {
+    Slot* s;
+    int rc = seam_prepare(c, b, true, false, &s);
+    if (rc) return rc;
+    const uint64_t n = b->n;
+    if (n == 0) return 0;
+    DevBuf o[3];
+    if (o[0].reserve(n) || o[1].reserve(4 * n) || o[2].reserve(4 * n)) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    hipLaunchKernelGGL(read_stats_seam_kernel, dim3((unsigned)((n + WPB - 1) / WPB)), dim3(BLOCK), 0, s->stream, s->view,
+                       max_poly, mismatch, qual, (uint8_t*)o[0].p, (int32_t*)o[1].p, (int32_t*)o[2].p);
+    HIP_TRY(hipGetLastError());
+    if ((rc = seam_out(s, o[0], polyx, n)) || (rc = seam_out(s, o[1], low_qual, n)) || (rc = seam_out(s, o[2], n_count, n))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (auto& d : o) d.release();
+    return 0;
+}
+
+int aqc_edit_distance(aqc_ctx* c, const aqc_batch* b, int32_t* dist) {
+    Slot* s;
+    int rc = seam_prepare(c, b, false, true, &s);
+    if (rc) return rc;
+    const uint64_t n = b->n;
+    if (n == 0) return 0;
+    DevBuf o;
+    if (o.reserve(4 * n)) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    hipLaunchKernelGGL(edit_distance_seam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->view,
+                       (int32_t*)o.p, c->status);
+    HIP_TRY(hipGetLastError());
+    if ((rc = seam_out(s, o, dist, n))) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    o.release();
+    return check_status(c);
+}
+
+}  // extern "C"

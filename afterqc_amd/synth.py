@@ -21,11 +21,12 @@ QUAL_CHARS = np.frombuffer(b"#/6<AE", dtype=np.uint8)
 QUAL_WEIGHTS = np.array([0.01, 0.09, 0.02, 0.06, 0.18, 0.64])
 ADAPTER1 = np.frombuffer(b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCA", dtype=np.uint8)
 ADAPTER2 = np.frombuffer(b"AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGT", dtype=np.uint8)
+# 256-entry lookup: a uniform byte -> quality character with the testdata weights (1/256 resolution)
+_QUAL_LUT = np.repeat(QUAL_CHARS, [3, 23, 5, 15, 46, 164]).astype(np.uint8)
 
 
 def _quals(rng, shape):
-    idx = rng.choice(len(QUAL_CHARS), size=shape, p=QUAL_WEIGHTS).astype(np.uint8)
-    return QUAL_CHARS[idx]
+    return _QUAL_LUT[rng.integers(0, 256, shape, dtype=np.uint8)]
 
 
 def make_names(rng, n, mate=1, start=0):
@@ -71,92 +72,110 @@ def make_single(n, L=150, seed=1002):
     return dict(seq1=seq, qual1=qual, len1=lens, meta=meta)
 
 
-def make_pairs(n, L=150, seed=1003, ragged=False, chunk=250_000, lowercase=0.0, dirty=False, short_frac=0.03):
+def _pairs_chunk(args):
+    """One independently seeded chunk of make_pairs (so chunks can be generated in parallel)."""
+    (m, L, seedseq, ragged, lowercase, dirty, short_frac) = args
+    rng = np.random.Generator(np.random.PCG64(seedseq))
+    T = 2 * L
+    j = np.arange(L, dtype=np.int32)[None, :]
+    ov = np.clip(np.rint(rng.normal(30.0, 8.0, m)), 0, L).astype(np.int32)
+    ins = (2 * L - ov).astype(np.int32)
+    short = rng.random(m) < short_frac
+    ins[short] = rng.integers(60, L, int(short.sum()))
+    frag = rng.integers(0, 4, (m, T), dtype=np.uint8)          # base codes 0..3 = A,C,G,T
+    rows = np.arange(m, dtype=np.int32)[:, None]
+    past = j - ins[:, None]                                      # >= 0: past the insert end
+    filler = frag[:, ::-1][:, :L]                                # pseudo-random tail behind the adapter
+    # read 1 = fragment[0:L]; adapter1 + filler past the insert end
+    c1 = frag[:, :L].copy()
+    # read 2 = revcomp(fragment[0:ins])[0:L]; adapter2 + filler past the insert end
+    idx = ins[:, None] - 1 - j
+    c2 = (3 - frag[rows, np.clip(idx, 0, T - 1)]).astype(np.uint8)
+    rt = np.flatnonzero(ins < L)                                 # rows with read-through
+    if len(rt):
+        pr = past[rt]
+        for c, ad in ((c1, ADAPTER1), (c2, ADAPTER2)):
+            adc = np.searchsorted(BASES, ad).astype(np.uint8)
+            sub = np.where(pr < len(adc), adc[np.clip(pr, 0, len(adc) - 1)], filler[rt])
+            c[rt] = np.where(pr >= 0, sub, c[rt])
+    reads = []
+    for c in (c1, c2):
+        u = rng.integers(0, 65536, (m, L), dtype=np.uint16)      # one draw decides error / N per base
+        v = rng.integers(0, 256, (m, L), dtype=np.uint8)         # substitution offset + low-quality flavour
+        w = rng.integers(0, 256, (m, L), dtype=np.uint8)         # quality
+        q = _QUAL_LUT[w]
+        err_lo = u < 328                                         # 0.5 %
+        err_hi = (u >= 328) & (u < 393)                          # 0.1 %
+        nm = (u >= 393) & (u < 524)                              # 0.2 %
+        err = err_lo | err_hi
+        c[err] = (c[err] + (v[err] % 3) + 1) & 3
+        r = BASES[c]
+        q[err_lo] = np.where(v[err_lo] & 128, ord("/"), ord("#")).astype(np.uint8)
+        q[err_hi] = ord("E")
+        r[nm] = ord("N")
+        q[nm] = ord("#")
+        reads.append((r, q))
+    (r1, q1), (r2, q2) = reads
+    if dirty:
+        for r, q in ((r1, q1), (r2, q2)):
+            for row in np.nonzero(rng.random(m) < 0.01)[0]:
+                k = int(rng.integers(30, min(81, L)))
+                r[row, L - k:] = ord("G") if rng.random() < 0.7 else ord("A")
+            for row in np.nonzero(rng.random(m) < 0.02)[0]:
+                k = int(rng.integers(min(55, L // 2), min(101, L)))
+                q[row, rng.choice(L, k, replace=False)] = ord("#")
+            for row in np.nonzero(rng.random(m) < 0.01)[0]:
+                k = int(rng.integers(3, 12))
+                r[row, rng.choice(L, k, replace=False)] = ord("N")
+    if lowercase > 0:
+        lc = rng.random(m) < lowercase
+        r1[lc, :20] |= 0x20
+        r2[lc, :20] |= 0x20
+        # 'n' is not in the reference's COMP table; keep N upper case
+        r1[r1 == ord("n")] = ord("N")
+        r2[r2 == ord("n")] = ord("N")
+    if ragged:
+        l1 = rng.integers(20, L + 1, m).astype(np.uint32)
+        l2 = rng.integers(20, L + 1, m).astype(np.uint32)
+        keep = rng.random(m) < 0.5
+        l1[keep] = L
+        l2[keep] = L
+    else:
+        l1 = np.full(m, L, dtype=np.uint32)
+        l2 = np.full(m, L, dtype=np.uint32)
+    return r1, q1, l1, r2, q2, l2, make_names(rng, m)
+
+
+def make_pairs(n, L=150, seed=1003, ragged=False, chunk=250_000, lowercase=0.0, dirty=False, short_frac=0.03,
+               workers=None):
     """Config 3: paired-end reads, insert = 2L - ov with ov ~ round(N(30, 8)) in [0, L],
     3 % short inserts (60 .. L-1) with adapter read-through, 0.5 %/base substitution errors
     carrying low quality ('/' or '#') and 0.1 %/base carrying high quality, N at 0.2 %/base.
+
+    Chunks of `chunk` pairs are seeded independently (SeedSequence(seed).spawn), so the result does
+    not depend on `workers` (processes used to generate chunks in parallel; default: all cores when
+    there is more than one chunk).
 
     ragged=True additionally truncates every read to a random length (tests only).
     lowercase>0 soft-masks that fraction of reads' first 20 bases to lower case (tests only).
     dirty=True adds config-2 style artefacts to both mates (poly-X tails, low-quality stretches,
     N bursts) so that every filter fires in the small golden cases (tests only).
     """
-    rng = np.random.Generator(np.random.PCG64(seed))
-    out = dict(seq1=[], qual1=[], len1=[], seq2=[], qual2=[], len2=[])
-    metas = []
-    done = 0
-    while done < n:
-        m = min(chunk, n - done)
-        ov = np.clip(np.rint(rng.normal(30.0, 8.0, m)), 0, L).astype(np.int64)
-        ins = 2 * L - ov
-        short = rng.random(m) < short_frac
-        ins[short] = rng.integers(60, L, int(short.sum()))
-        T = 2 * L
-        frag = rng.integers(0, 4, (m, T), dtype=np.uint8)
-        j = np.arange(L, dtype=np.int64)[None, :]
-        rows = np.arange(m)[:, None]
-        # read 1 = fragment[0:L], adapter1 + random past the insert end
-        r1 = BASES[frag[:, :L]]
-        past = j - ins[:, None]
-        a1 = np.where(past < len(ADAPTER1), ADAPTER1[np.clip(past, 0, len(ADAPTER1) - 1)],
-                      BASES[rng.integers(0, 4, (m, L), dtype=np.uint8)])
-        r1 = np.where(past >= 0, a1, r1)
-        # read 2 = revcomp(fragment[0:ins])[0:L], adapter2 + random past the insert end
-        idx = ins[:, None] - 1 - j
-        r2 = BASES[COMP_IDX[frag[rows, np.clip(idx, 0, T - 1)]]]
-        a2 = np.where(past < len(ADAPTER2), ADAPTER2[np.clip(past, 0, len(ADAPTER2) - 1)],
-                      BASES[rng.integers(0, 4, (m, L), dtype=np.uint8)])
-        r2 = np.where(idx >= 0, r2, a2)
-        q1 = _quals(rng, (m, L))
-        q2 = _quals(rng, (m, L))
-        for r, q in ((r1, q1), (r2, q2)):
-            u = rng.random((m, L))
-            err_lo = u < 0.005
-            err_hi = (u >= 0.005) & (u < 0.006)
-            err = err_lo | err_hi
-            # substitute with a different base: rotate within ACGT
-            code = np.searchsorted(BASES, r)  # A,C,G,T -> 0..3 (BASES sorted ascending)
-            sub = BASES[(code + rng.integers(1, 4, (m, L))) % 4]
-            r[err] = sub[err]
-            lowq = np.where(rng.random((m, L)) < 0.5, ord("/"), ord("#")).astype(np.uint8)
-            q[err_lo] = lowq[err_lo]
-            q[err_hi] = ord("E")
-            nm = rng.random((m, L)) < 0.002
-            r[nm] = ord("N")
-            q[nm] = ord("#")
-        if dirty:
-            for r, q in ((r1, q1), (r2, q2)):
-                for row in np.nonzero(rng.random(m) < 0.01)[0]:
-                    k = int(rng.integers(30, min(81, L)))
-                    r[row, L - k:] = ord("G") if rng.random() < 0.7 else ord("A")
-                for row in np.nonzero(rng.random(m) < 0.02)[0]:
-                    k = int(rng.integers(min(55, L // 2), min(101, L)))
-                    q[row, rng.choice(L, k, replace=False)] = ord("#")
-                for row in np.nonzero(rng.random(m) < 0.01)[0]:
-                    k = int(rng.integers(3, 12))
-                    r[row, rng.choice(L, k, replace=False)] = ord("N")
-        if lowercase > 0:
-            lc = rng.random(m) < lowercase
-            r1[lc, :20] |= 0x20
-            r2[lc, :20] |= 0x20
-            # 'n' is not in the reference's COMP table; keep N upper case
-            r1[r1 == ord("n")] = ord("N")
-            r2[r2 == ord("n")] = ord("N")
-        if ragged:
-            l1 = rng.integers(20, L + 1, m).astype(np.uint32)
-            l2 = rng.integers(20, L + 1, m).astype(np.uint32)
-            keep = rng.random(m) < 0.5
-            l1[keep] = L
-            l2[keep] = L
-        else:
-            l1 = np.full(m, L, dtype=np.uint32)
-            l2 = np.full(m, L, dtype=np.uint32)
-        out["seq1"].append(r1.astype(np.uint8)); out["qual1"].append(q1); out["len1"].append(l1)
-        out["seq2"].append(r2.astype(np.uint8)); out["qual2"].append(q2); out["len2"].append(l2)
-        metas.append(make_names(rng, m))
-        done += m
-    res = {k: np.concatenate(v) for k, v in out.items()}
-    res["meta"] = tuple(np.concatenate([mm[i] for mm in metas]) for i in range(4))
+    sizes = [min(chunk, n - a) for a in range(0, n, chunk)]
+    seeds = np.random.SeedSequence(seed).spawn(len(sizes))
+    jobs = [(m, L, sq, ragged, lowercase, dirty, short_frac) for m, sq in zip(sizes, seeds)]
+    if len(jobs) > 1 and (workers is None or workers > 1):
+        import concurrent.futures as cf
+        import multiprocessing as mp
+        import os
+        nw = min(len(jobs), workers or os.cpu_count() or 1)
+        with cf.ProcessPoolExecutor(max_workers=nw, mp_context=mp.get_context("fork")) as ex:
+            parts = list(ex.map(_pairs_chunk, jobs))
+    else:
+        parts = [_pairs_chunk(jb) for jb in jobs]
+    keys = ("seq1", "qual1", "len1", "seq2", "qual2", "len2")
+    res = {k: (parts[0][i] if len(parts) == 1 else np.concatenate([p[i] for p in parts])) for i, k in enumerate(keys)}
+    res["meta"] = tuple(np.concatenate([p[6][i] for p in parts]) for i in range(4))
     return res
 
 

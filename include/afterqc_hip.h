@@ -228,6 +228,11 @@ int aqc_fetch_results(aqc_ctx* ctx, int slot, aqc_result* out, uint64_t n);
 int aqc_sync(aqc_ctx* ctx, int slot);
 /* duration in ms of the last launch of each kernel on this slot (valid after aqc_sync) */
 int aqc_kernel_ms(aqc_ctx* ctx, int slot, float* ms /* [AQC_N_KERNELS] */);
+/* HIP-event timing over a region: aqc_timing_reset() starts collecting one event pair per kernel
+ * launch on the slot's stream (up to 256 launches per kernel); aqc_timing_mean() waits for the slot
+ * and returns the mean launch duration and the number of launches per kernel since the reset. */
+int aqc_timing_reset(aqc_ctx* ctx, int slot);
+int aqc_timing_mean(aqc_ctx* ctx, int slot, float* mean_ms /* [AQC_N_KERNELS] */, int32_t* launches /* [AQC_N_KERNELS] */);
 
 /* ---- accumulated statistics (host-side merge across GPUs is a plain integer sum) -------------- */
 int aqc_get_counters(aqc_ctx* ctx, int64_t* out /* [AQC_N_COUNTERS] */);
