@@ -418,7 +418,7 @@ __global__ __launch_bounds__(BLOCK) void filter_overlap_kernel(DevBatch b, aqc_c
             if (offset < 0 && ovl > 30) {
                 len1 = ovl; len2 = ovl;                      // all four strings := [0:overlap_len]
                 c_adapter_base = 2 * (-offset); c_adapter_read = 1;
-                if (len1 < cfg.seq_len_req) flag = AQC_BADLEN;
+                if (len1 < cfg.seq_len_req) { flag = AQC_BADLEN; offset = 0; ovl = 0; dist = 0; }   // record carries no overlap
                 else overlap_hm_wave(s1 + a1, len1, c2 + a2, len2, offset, ovl, dist);
             }
             if (flag < 0) {
