@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "aqc_kernels.hpp"
+#include "aqc_fast.hpp"
 
 using namespace aqc;
 
@@ -58,6 +59,13 @@ struct DevBuf {
 struct Slot {
     hipStream_t stream = nullptr;
     DevBuf seq1, qual1, off1, qoff1, len1, seq2, qual2, off2, qoff2, len2, aux[5], results;
+    // canonical layout for the lane-per-pair kernel: 16-byte aligned records, offsets in 16-byte units
+    DevBuf cseq1, cqual1, cseq2, cqual2, co1, co2;
+    uint32_t* h_o16[2] = {nullptr, nullptr};   // pinned staging for the canonical offsets
+    size_t h_o16_cap[2] = {0, 0};
+    FastBatch fview{};
+    bool has_canonical = false;
+    uint32_t max_len = 0;
     DevBatch view{};
     uint64_t n = 0;
     bool paired = false, ran = false, same_arena1 = false, same_arena2 = false;
@@ -97,6 +105,7 @@ struct QcDev {
 }  // namespace
 
 struct aqc_ctx {
+    bool force_generic = false;
     int device = 0;
     int n_slots = 0;
     std::vector<Slot> slots;
@@ -127,6 +136,16 @@ static int check_status(aqc_ctx* c) {
     return 0;
 }
 
+template <int NW, bool PAIRED, int WPBT>
+static void launch_fast(aqc_ctx* c, Slot* s, const aqc_config& cfg, const DevStats& st, uint64_t accum_limit) {
+    uint64_t blocks = (s->n + (uint64_t)WPBT * WAVE - 1) / ((uint64_t)WPBT * WAVE);
+    const uint64_t cap = (uint64_t)c->n_cu * 2;     // LDS admits two workgroups per CU; batches are grid-strided
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((fast_filter_overlap_kernel<NW, PAIRED, WPBT>), dim3((unsigned)blocks), dim3(WPBT * WAVE), 0, s->stream,
+                       s->fview, s->view, cfg, c->circles, (aqc_result*)s->results.p, st, accum_limit);
+}
+
+
 extern "C" {
 
 int aqc_abi_version(void) { return AQC_ABI_VERSION; }
@@ -153,6 +172,8 @@ int aqc_create(int device, int n_slots, aqc_ctx** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     snprintf(c->name, sizeof(c->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const char* fg = getenv("AQC_FORCE_GENERIC");
+    c->force_generic = fg && fg[0] == '1';
     for (auto& s : c->slots) {
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         for (int k = 0; k < AQC_N_KERNELS; k++)
@@ -174,8 +195,11 @@ void aqc_destroy(aqc_ctx* c) {
     (void)hipDeviceSynchronize();
     for (auto& s : c->slots) {
         DevBuf* bufs[] = {&s.seq1, &s.qual1, &s.off1, &s.qoff1, &s.len1, &s.seq2, &s.qual2, &s.off2, &s.qoff2, &s.len2,
-                          &s.aux[0], &s.aux[1], &s.aux[2], &s.aux[3], &s.aux[4], &s.results};
+                          &s.aux[0], &s.aux[1], &s.aux[2], &s.aux[3], &s.aux[4], &s.results,
+                          &s.cseq1, &s.cqual1, &s.cseq2, &s.cqual2, &s.co1, &s.co2};
         for (DevBuf* b : bufs) b->release();
+        for (int k = 0; k < 2; k++)
+            if (s.h_o16[k]) (void)hipHostFree(s.h_o16[k]);
         for (int k = 0; k < AQC_N_KERNELS; k++)
             for (int j = 0; j < 2; j++) {
                 if (s.ev[k][j]) (void)hipEventDestroy(s.ev[k][j]);
@@ -336,12 +360,71 @@ static int get_slot(aqc_ctx* c, int slot, Slot** out) {
     return 0;
 }
 
+// Build the canonical device layout of one mate: offsets / 16 on the host (prefix sum of ceil(len/16)),
+// then a device-side copy of every record to its aligned slot ('A' / 0xff padding of the last chunk).
+static int canonicalize(aqc_ctx* c, Slot& s, int mate, const uint32_t* len, uint64_t n, const uint8_t* d_seq,
+                        const uint8_t* d_qual, const uint64_t* d_off, const uint64_t* d_qoff, const uint32_t* d_len,
+                        DevBuf& cseq, DevBuf& cqual, DevBuf& co, uint32_t* max_len) {
+    if (s.h_o16_cap[mate] < n + 1) {
+        if (s.h_o16[mate]) (void)hipHostFree(s.h_o16[mate]);
+        s.h_o16[mate] = nullptr;
+        s.h_o16_cap[mate] = 0;
+        size_t want = (size_t)(n + n / 8 + 64);
+        HIP_TRY(hipHostMalloc((void**)&s.h_o16[mate], want * sizeof(uint32_t), hipHostMallocDefault));
+        s.h_o16_cap[mate] = want;
+    }
+    uint32_t* o = s.h_o16[mate];
+    uint64_t acc = 0;
+    uint32_t mx = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        o[i] = (uint32_t)acc;
+        acc += (len[i] + 15u) >> 4;
+        if (len[i] > mx) mx = len[i];
+    }
+    if (acc >= (1ull << 32)) return fail(AQC_ERR_ARG, "batch too large for 32-bit chunk offsets (>64 GiB of bases)");
+    if (mx > *max_len) *max_len = mx;
+    const size_t bytes = (size_t)acc * 16 + 16 * 64 + 256;   // tail slack: the kernel always loads NW chunks per record
+    if (cseq.reserve(bytes) || cqual.reserve(bytes) || co.reserve(sizeof(uint32_t) * (n ? n : 1)))
+        return fail(AQC_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemcpyAsync(co.p, o, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(hipMemsetAsync((uint8_t*)cseq.p + (size_t)acc * 16, 'A', bytes - (size_t)acc * 16, s.stream));
+    HIP_TRY(hipMemsetAsync((uint8_t*)cqual.p + (size_t)acc * 16, 0x7f, bytes - (size_t)acc * 16, s.stream));
+    if (n) {
+        const unsigned blocks = (unsigned)((n * 16 + 255) / 256);
+        hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_seq, d_off, d_len,
+                           (const uint32_t*)co.p, n, (uint8_t*)cseq.p, (uint8_t)'A');
+        hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_qual, d_qoff ? d_qoff : d_off, d_len,
+                           (const uint32_t*)co.p, n, (uint8_t*)cqual.p, (uint8_t)0x7f);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
 int aqc_upload(aqc_ctx* c, int slot, const aqc_batch* b) {
     Slot* s;
     int rc = get_slot(c, slot, &s);
     if (rc) return rc;
     if (!b) return fail(AQC_ERR_ARG, "null batch");
-    return fill_slot(c, *s, b, true, false);
+    if ((rc = fill_slot(c, *s, b, true, false))) return rc;
+    s->has_canonical = false;
+    s->max_len = 0;
+    if (c->force_generic) return 0;
+    FastBatch f{};
+    f.n = b->n;
+    if ((rc = canonicalize(c, *s, 0, b->len1, b->n, s->view.seq1, s->view.qual1, s->view.off1, s->view.qoff1, s->view.len1,
+                           s->cseq1, s->cqual1, s->co1, &s->max_len)))
+        return rc;
+    f.seq1 = (const uint8_t*)s->cseq1.p; f.qual1 = (const uint8_t*)s->cqual1.p; f.o1 = (const uint32_t*)s->co1.p; f.len1 = s->view.len1;
+    if (s->paired) {
+        if ((rc = canonicalize(c, *s, 1, b->len2, b->n, s->view.seq2, s->view.qual2, s->view.off2, s->view.qoff2, s->view.len2,
+                               s->cseq2, s->cqual2, s->co2, &s->max_len)))
+            return rc;
+        f.seq2 = (const uint8_t*)s->cseq2.p; f.qual2 = (const uint8_t*)s->cqual2.p; f.o2 = (const uint32_t*)s->co2.p; f.len2 = s->view.len2;
+    }
+    f.aux_lane = s->view.aux_lane; f.aux_tile = s->view.aux_tile; f.aux_x = s->view.aux_x; f.aux_y = s->view.aux_y; f.aux_ok = s->view.aux_ok;
+    s->fview = f;
+    s->has_canonical = true;
+    return 0;
 }
 
 static int grid_for(const aqc_ctx* c, uint64_t n) {
@@ -365,8 +448,19 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
     if (!cfg.paired) cfg.no_overlap = 1;
     DevStats st{c->counters, c->ovl_hist, c->dist_hist, c->status};
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_FILTER_OVERLAP, 0), s->stream));
-    hipLaunchKernelGGL(filter_overlap_kernel, dim3(grid_for(c, s->n)), dim3(BLOCK), 0, s->stream, s->view, cfg, c->circles,
-                       (aqc_result*)s->results.p, st, accum_limit);
+    // lane-per-pair kernel whenever its preconditions hold; the general wave-per-record kernel otherwise
+    const int thr = cfg.qualified_quality_phred + 33;
+    const bool fast_ok = s->has_canonical && !cfg.barcode && thr >= 0 && thr <= 127 && s->max_len <= 256;
+    if (!fast_ok) {
+        hipLaunchKernelGGL(filter_overlap_kernel, dim3(grid_for(c, s->n)), dim3(BLOCK), 0, s->stream, s->view, cfg, c->circles,
+                           (aqc_result*)s->results.p, st, accum_limit);
+    } else if (s->max_len <= 160) {
+        if (cfg.paired) launch_fast<10, true, 4>(c, s, cfg, st, accum_limit);
+        else launch_fast<10, false, 4>(c, s, cfg, st, accum_limit);
+    } else {
+        if (cfg.paired) launch_fast<16, true, 2>(c, s, cfg, st, accum_limit);
+        else launch_fast<16, false, 2>(c, s, cfg, st, accum_limit);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_FILTER_OVERLAP, 1), s->stream));
     s->timed[AQC_K_FILTER_OVERLAP] = !s->collecting;

@@ -293,34 +293,32 @@ struct BlockAcc {
 };
 
 // ------------------------------------------------------------------------------------------------
-// The hot kernel: preprocesser.py:436-631 for every record of the batch.
-// grid-stride over records, one wave per record, block-private counters flushed once at the end.
+// One record through preprocesser.py:436-631, executed by ONE wavefront on byte strings staged in
+// LDS ("generation 1", fully general: any alphabet, any length <= AQC_MAX_READ_LEN, barcodes,
+// bubbles).  Used by the generic kernel for every record and by the fast kernel (aqc_fast.hpp) for
+// the records it defers.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void filter_overlap_kernel(DevBatch b, aqc_config cfg, DevCircles circ,
-                                                               aqc_result* __restrict__ results, DevStats st,
-                                                               uint64_t accum_limit) {
-    __shared__ uint8_t lds[WPB][5][LSTR];
-    __shared__ uint8_t rsbuf[WPB][2][64];
-    __shared__ BlockAcc acc;
+struct WaveLds {
+    uint8_t *s1, *q1, *s2, *q2, *c2;   // 5 x LSTR bytes
+    uint8_t *rs1, *rs2;                // 2 x 64 bytes (barcode readStart strings)
+};
+
+__device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, const aqc_config& cfg, const DevCircles& circ,
+                                           const WaveLds& w, aqc_result* __restrict__ results, BlockAcc& acc,
+                                           const DevStats& st, bool accum) {
     const int lane = lane_id();
-    const int wave = threadIdx.x / WAVE;
-    for (int i = threadIdx.x; i < (int)(sizeof(BlockAcc) / 4); i += BLOCK) ((unsigned int*)&acc)[i] = 0;
-    __syncthreads();
-
-    uint8_t* s1 = lds[wave][0];
-    uint8_t* q1 = lds[wave][1];
-    uint8_t* s2 = lds[wave][2];
-    uint8_t* q2 = lds[wave][3];
-    uint8_t* c2 = lds[wave][4];   // complement-or-N of s2, same orientation
+    uint8_t* s1 = w.s1;
+    uint8_t* q1 = w.q1;
+    uint8_t* s2 = w.s2;
+    uint8_t* q2 = w.q2;
+    uint8_t* c2 = w.c2;   // complement-or-N of s2, same orientation
     const bool paired = cfg.paired != 0;
-    const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
-
-    for (uint64_t rec = (uint64_t)blockIdx.x * WPB + wave; rec < b.n; rec += nwaves) {
+    {
         const int L1 = (int)b.len1[rec];
         const int L2 = paired ? (int)b.len2[rec] : 0;
         if (L1 > AQC_MAX_READ_LEN || L2 > AQC_MAX_READ_LEN) {
             if (lane == 0) atomicCAS(st.status, 0, AQC_ERR_READ_TOO_LONG);
-            continue;
+            return;
         }
         stage(s1, b.seq1 + b.off1[rec], L1);
         stage(q1, b.qual1 + (b.qoff1 ? b.qoff1[rec] : b.off1[rec]), L1);
@@ -332,7 +330,6 @@ __global__ __launch_bounds__(BLOCK) void filter_overlap_kernel(DevBatch b, aqc_c
         // (wave-private LDS region: no barrier needed, the compiler orders LDS ops of one wave)
         __builtin_amdgcn_wave_barrier();
 
-        const bool accum = rec < accum_limit;
         int a1 = 0, len1 = L1, a2 = 0, len2 = L2;     // current views: s1[a1 .. a1+len1), s2[a2 .. a2+len2)
         int flag = -1;
         int offset = 0, ovl = 0, dist = 0, n_edits = 0;
@@ -359,8 +356,8 @@ __global__ __launch_bounds__(BLOCK) void filter_overlap_kernel(DevBatch b, aqc_c
                     else {
                         bcode |= (uint8_t)((b2 - bl + 2) << 4);
                         // readStart = seq[0:barcodeLen] + verify (barcodeprocesser.py:78-79)
-                        uint8_t* rs1 = rsbuf[wave][0];
-                        uint8_t* rs2 = rsbuf[wave][1];
+                        uint8_t* rs1 = w.rs1;
+                        uint8_t* rs2 = w.rs2;
                         if (lane < b1) rs1[lane] = s1[lane];
                         if (lane < vl) rs1[b1 + lane] = cfg.barcode_verify[lane];
                         if (lane < b2) rs2[lane] = s2[lane];
@@ -542,14 +539,36 @@ __global__ __launch_bounds__(BLOCK) void filter_overlap_kernel(DevBatch b, aqc_c
             }
         }
         __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < AQC_N_COUNTERS; i += BLOCK)
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic kernel: grid-stride over records, one wave per record, block-private counters flushed once.
+// ------------------------------------------------------------------------------------------------
+__device__ inline void flush_block_acc(BlockAcc& acc, const DevStats& st) {
+    for (int i = threadIdx.x; i < AQC_N_COUNTERS; i += blockDim.x)
         if (acc.counters[i]) atomicAdd(&st.counters[i], acc.counters[i]);
-    for (int i = threadIdx.x; i < AQC_QC_COLS; i += BLOCK) {
+    for (int i = threadIdx.x; i < AQC_QC_COLS; i += blockDim.x) {
         if (acc.ovl_hist[i]) atomicAdd(&st.ovl_hist[i], (unsigned long long)acc.ovl_hist[i]);
         if (acc.dist_hist[i]) atomicAdd(&st.dist_hist[i], (unsigned long long)acc.dist_hist[i]);
     }
+}
+
+__global__ __launch_bounds__(BLOCK) void filter_overlap_kernel(DevBatch b, aqc_config cfg, DevCircles circ,
+                                                               aqc_result* __restrict__ results, DevStats st,
+                                                               uint64_t accum_limit) {
+    __shared__ uint8_t lds[WPB][5][LSTR];
+    __shared__ uint8_t rsbuf[WPB][2][64];
+    __shared__ BlockAcc acc;
+    const int wave = threadIdx.x / WAVE;
+    for (int i = threadIdx.x; i < (int)(sizeof(BlockAcc) / 4); i += BLOCK) ((unsigned int*)&acc)[i] = 0;
+    __syncthreads();
+    const WaveLds w{lds[wave][0], lds[wave][1], lds[wave][2], lds[wave][3], lds[wave][4], rsbuf[wave][0], rsbuf[wave][1]};
+    const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
+    for (uint64_t rec = (uint64_t)blockIdx.x * WPB + wave; rec < b.n; rec += nwaves)
+        process_record_wave(b, rec, cfg, circ, w, results, acc, st, rec < accum_limit);
+    __syncthreads();
+    flush_block_acc(acc, st);
 }
 
 // ------------------------------------------------------------------------------------------------
