@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libafterqc_hip.so")
+LIB_PATH = os.environ.get("AQC_LIB") or os.path.join(HERE, "csrc", "libafterqc_hip.so")   # AQC_LIB: A/B builds only
 
 AQC_MAX_READ_LEN = 1000
 AQC_QC_COLS = 1024

@@ -179,7 +179,7 @@ int aqc_create(int device, int n_slots, aqc_ctx** out) {
         for (int k = 0; k < AQC_N_KERNELS; k++)
             for (int j = 0; j < 2; j++) HIP_TRY(hipEventCreate(&s.ev[k][j]));
     }
-    HIP_TRY(hipMalloc((void**)&c->counters, sizeof(unsigned long long) * AQC_N_COUNTERS));
+    HIP_TRY(hipMalloc((void**)&c->counters, sizeof(unsigned long long) * (AQC_N_COUNTERS + 16)));   // +16: AQC_PROFILE builds
     HIP_TRY(hipMalloc((void**)&c->ovl_hist, sizeof(unsigned long long) * AQC_QC_COLS));
     HIP_TRY(hipMalloc((void**)&c->dist_hist, sizeof(unsigned long long) * AQC_QC_COLS));
     HIP_TRY(hipMalloc((void**)&c->status, sizeof(int)));
@@ -263,7 +263,7 @@ int aqc_reset_stats(aqc_ctx* c) {
     if (!c) return fail(AQC_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(c->counters, 0, sizeof(unsigned long long) * AQC_N_COUNTERS));
+    HIP_TRY(hipMemset(c->counters, 0, sizeof(unsigned long long) * (AQC_N_COUNTERS + 16)));
     HIP_TRY(hipMemset(c->ovl_hist, 0, sizeof(unsigned long long) * AQC_QC_COLS));
     HIP_TRY(hipMemset(c->dist_hist, 0, sizeof(unsigned long long) * AQC_QC_COLS));
     HIP_TRY(hipMemset(c->status, 0, sizeof(int)));
@@ -575,6 +575,16 @@ int aqc_get_counters(aqc_ctx* c, int64_t* out) {
     if (!c || !out) return fail(AQC_ERR_ARG, "null argument");
     int rc = sync_all(c);
     if (rc) return rc;
+#ifdef AQC_PROFILE
+    {
+        unsigned long long pr[16];
+        (void)hipMemcpy(pr, c->counters + AQC_N_COUNTERS, sizeof(pr), hipMemcpyDeviceToHost);
+        unsigned long long tot = 0;
+        for (int k = 0; k < 10; k++) tot += pr[k];
+        static const char* nm[10] = {"phase1", "normalise", "bubble+len+polyX", "lowq+N", "scan", "verify", "post+walk", "results+counters", "deferred", "-"};
+        for (int k = 0; k < 9; k++) fprintf(stderr, "PROF %-18s %6.2f %%\n", nm[k], tot ? 100.0 * pr[k] / tot : 0.0);
+    }
+#endif
     HIP_TRY(hipMemcpy(out, c->counters, sizeof(int64_t) * AQC_N_COUNTERS, hipMemcpyDeviceToHost));
     return 0;
 }

@@ -113,6 +113,16 @@ __device__ __forceinline__ uint32_t mm_word(uint32_t mlo0, uint32_t mlo1, uint32
     return mm & base_mask(nb);
 }
 
+#ifdef AQC_PROFILE
+#define PROF_DECL unsigned long long prof_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#define PROF(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof_t[k] += now_ - prof_last; prof_last = now_; } while (0)
+#define PROF_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 10; ++k_) atomicAdd(&st.counters[AQC_N_COUNTERS + k_], prof_t[k_]); } while (0)
+#else
+#define PROF_DECL
+#define PROF(k)
+#define PROF_FLUSH
+#endif
+
 template <int NW, bool PAIRED, int WPBT>
 __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBatch fb, DevBatch raw, aqc_config cfg, DevCircles circ,
                                                                     aqc_result* __restrict__ results, DevStats st,
@@ -121,6 +131,11 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
     constexpr int STRIDE = WL::STRIDE;
     __shared__ WL wls[WPBT];
     __shared__ BlockAcc acc;
+#if defined(AQC_ABLATE) && AQC_ABLATE == 9   /* occupancy probe: one workgroup per CU */
+    __shared__ uint32_t occ_pad[11000];
+    if (threadIdx.x == 0 && fb.n == 1234567891234ull) occ_pad[blockIdx.x % 11000] = 1;
+    if (fb.n == 1234567891235ull && occ_pad[threadIdx.x] == 77) return;
+#endif
     static_assert(sizeof(uint32_t) * WAVE * STRIDE >= 5 * LSTR, "generation-1 staging must fit into the plane region");
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
@@ -134,71 +149,112 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
     const int need = cfg.poly_size_limit - cfg.allow_mismatch_in_poly;
     const int run_req = cfg.allow_mismatch_in_poly >= 0 ? (need + cfg.allow_mismatch_in_poly) / (cfg.allow_mismatch_in_poly + 1) : 0;
 
+    PROF_DECL
     const uint64_t stride = (uint64_t)gridDim.x * WPBT * WAVE;
-    for (uint64_t base = ((uint64_t)blockIdx.x * WPBT + wave) * WAVE; base < fb.n; base += stride) {
+    const uint64_t base0 = ((uint64_t)blockIdx.x * WPBT + wave) * WAVE;
+    // record descriptors of the NEXT batch are fetched one iteration ahead (no round trip at the top of the loop)
+    uint32_t m_o1 = 0, m_l1 = 0, m_o2 = 0, m_l2 = 0;
+    if (base0 + lane < fb.n) {
+        m_o1 = fb.o1[base0 + lane]; m_l1 = fb.len1[base0 + lane];
+        if (PAIRED) { m_o2 = fb.o2[base0 + lane]; m_l2 = fb.len2[base0 + lane]; }
+    }
+    for (uint64_t base = base0; base < fb.n; base += stride) {
         const uint64_t rec = base + lane;
         const bool valid = rec < fb.n;
         // ------------------------------------------------------------------ phase 1: load + pack
-        L.o1[lane] = valid ? fb.o1[rec] : 0;
-        L.l1[lane] = valid ? fb.len1[rec] : 0;
-        if (PAIRED) {
-            L.o2[lane] = valid ? fb.o2[rec] : 0;
-            L.l2[lane] = valid ? fb.len2[rec] : 0;
-        }
+        L.o1[lane] = m_o1;
+        L.l1[lane] = m_l1;
+        if (PAIRED) { L.o2[lane] = m_o2; L.l2[lane] = m_l2; }
         L.lq[lane] = 0;
         L.exo[lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < NW; ++it) {
-            const int t = it * WAVE + lane;
-            const int sp = t / NW, c = t - sp * NW;
-            const uint4 v = *reinterpret_cast<const uint4*>(fb.seq1 + ((uint64_t)(L.o1[sp] + c) << 4));
-            uint32_t lo, e, bad;
-            pack_chunk(v, lo, e, bad);
-            L.planes[sp][c] = lo;
-            L.planes[sp][NW + c] = e;
-            if (bad && c * 16 < (int)L.l1[sp]) L.exo[sp] = 1;
+        {
+            const uint64_t nrec = rec + stride;
+            m_o1 = m_l1 = m_o2 = m_l2 = 0;
+            if (nrec < fb.n) {
+                m_o1 = fb.o1[nrec]; m_l1 = fb.len1[nrec];
+                if (PAIRED) { m_o2 = fb.o2[nrec]; m_l2 = fb.len2[nrec]; }
+            }
         }
-        if (PAIRED) {
+        __builtin_amdgcn_wave_barrier();
+        // each pass: descriptors from LDS, then all NW 16-byte loads in flight at once, then the packing
+        {
+            uint4 v[NW];
+            int sp[NW], len[NW];
 #pragma unroll
             for (int it = 0; it < NW; ++it) {
                 const int t = it * WAVE + lane;
-                const int sp = t / NW, c = t - sp * NW;
-                const uint4 v = *reinterpret_cast<const uint4*>(fb.seq2 + ((uint64_t)(L.o2[sp] + c) << 4));
+                sp[it] = t / NW;
+                len[it] = (int)L.l1[sp[it]];
+                v[it] = *reinterpret_cast<const uint4*>(fb.seq1 + ((uint64_t)(L.o1[sp[it]] + (t - sp[it] * NW)) << 4));
+            }
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const int c = it * WAVE + lane - sp[it] * NW;
                 uint32_t lo, e, bad;
-                pack_chunk(v, lo, e, bad);
+                pack_chunk(v[it], lo, e, bad);
+                L.planes[sp[it]][c] = lo;
+                L.planes[sp[it]][NW + c] = e;
+                if (bad && c * 16 < len[it]) L.exo[sp[it]] = 1;
+            }
+        }
+        if (PAIRED) {
+            uint4 v[NW];
+            int sp[NW], len[NW];
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const int t = it * WAVE + lane;
+                sp[it] = t / NW;
+                len[it] = (int)L.l2[sp[it]];
+                v[it] = *reinterpret_cast<const uint4*>(fb.seq2 + ((uint64_t)(L.o2[sp[it]] + (t - sp[it] * NW)) << 4));
+            }
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const int c = it * WAVE + lane - sp[it] * NW;
+                uint32_t lo, e, bad;
+                pack_chunk(v[it], lo, e, bad);
                 // complement (A<->T, C<->G: flip the high bit of the field), keep N at code 3, then reverse the chunk
                 lo = (lo ^ ODD) | e | (e >> 1);
-                L.planes[sp][2 * NW + (NW - 1 - c)] = rev2(lo);
-                L.planes[sp][3 * NW + (NW - 1 - c)] = __builtin_bitreverse32(e) << 1;
-                if (bad && c * 16 < (int)L.l2[sp]) L.exo[sp] = 1;
+                L.planes[sp[it]][2 * NW + (NW - 1 - c)] = rev2(lo);
+                L.planes[sp[it]][3 * NW + (NW - 1 - c)] = __builtin_bitreverse32(e) << 1;
+                if (bad && c * 16 < len[it]) L.exo[sp[it]] = 1;
             }
         }
         if (cfg.unqualified_base_limit > 0) {
+            uint4 v[NW];
+            int sp[NW], len[NW];
 #pragma unroll
             for (int it = 0; it < NW; ++it) {
                 const int t = it * WAVE + lane;
-                const int sp = t / NW, c = t - sp * NW;
-                const int len = (int)L.l1[sp];
-                const uint4 v = *reinterpret_cast<const uint4*>(fb.qual1 + ((uint64_t)(L.o1[sp] + c) << 4));
-                int a = 0, nl = len;
-                if (do_trim) trim_view(len, cfg.trim_front, cfg.trim_tail, a, nl);
+                sp[it] = t / NW;
+                len[it] = (int)L.l1[sp[it]];
+                v[it] = *reinterpret_cast<const uint4*>(fb.qual1 + ((uint64_t)(L.o1[sp[it]] + (t - sp[it] * NW)) << 4));
+            }
+#pragma unroll
+            for (int it = 0; it < NW; ++it) {
+                const int c = it * WAVE + lane - sp[it] * NW;
+                int a = 0, nl = len[it];
+                if (do_trim) trim_view(len[it], cfg.trim_front, cfg.trim_tail, a, nl);
                 // byte < thr  <=>  high bit of ((byte | 0x80) - thr) clear   (bytes < 0x80, thr <= 0x7f)
-                const uint32_t f0 = (~((v.x | 0x80808080u) - thr4) & 0x80808080u) >> 7;
-                const uint32_t f1 = (~((v.y | 0x80808080u) - thr4) & 0x80808080u) >> 7;
-                const uint32_t f2 = (~((v.z | 0x80808080u) - thr4) & 0x80808080u) >> 7;
-                const uint32_t f3 = (~((v.w | 0x80808080u) - thr4) & 0x80808080u) >> 7;
+                const uint32_t f0 = (~((v[it].x | 0x80808080u) - thr4) & 0x80808080u) >> 7;
+                const uint32_t f1 = (~((v[it].y | 0x80808080u) - thr4) & 0x80808080u) >> 7;
+                const uint32_t f2 = (~((v[it].z | 0x80808080u) - thr4) & 0x80808080u) >> 7;
+                const uint32_t f3 = (~((v[it].w | 0x80808080u) - thr4) & 0x80808080u) >> 7;
                 const uint32_t f16 = udot4(f0, 0x08040201u, 0u) | (udot4(f1, 0x08040201u, 0u) << 4) |
                                      (udot4(f2, 0x08040201u, 0u) << 8) | (udot4(f3, 0x08040201u, 0u) << 12);
                 const int lo_b = min(max(a - 16 * c, 0), 16), hi_b = min(max(a + nl - 16 * c, 0), 16);
                 const uint32_t m16 = ((1u << hi_b) - 1u) & ~((1u << lo_b) - 1u);
                 const int cnt = __popc(f16 & m16);
-                if (cnt) atomicAdd(&L.lq[sp], (uint32_t)cnt);
-                if (((v.x | v.y | v.z | v.w) & 0x80808080u) && c * 16 < len) L.exo[sp] = 1;   // non-ASCII quality byte
+                if (cnt) atomicAdd(&L.lq[sp[it]], (uint32_t)cnt);
+                if (((v[it].x | v[it].y | v[it].z | v[it].w) & 0x80808080u) && c * 16 < len[it]) L.exo[sp[it]] = 1;   // non-ASCII quality byte
             }
         }
         __builtin_amdgcn_wave_barrier();
+        PROF(0);
 
+#if defined(AQC_ABLATE) && AQC_ABLATE == 1   /* phase 1 only */
+        if (valid) results[rec].flag = (uint8_t)(L.planes[lane][0] + L.lq[lane] + L.exo[lane]);
+        continue;
+#endif
         // ------------------------------------------------------------------ phase 2: lane per pair
         const int L1 = (int)L.l1[lane];
         const int L2 = PAIRED ? (int)L.l2[lane] : 0;
@@ -260,6 +316,7 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
         my[4 * NW] = 0; my[4 * NW + 1] = 0; my[4 * NW + 2] = 0; my[4 * NW + 3] = 0; my[4 * NW + 4] = 0;
         __builtin_amdgcn_wave_barrier();
 
+        PROF(1);
         // ---- bubble (preprocesser.py:469-473)
         if (cfg.debubble && circ.n > 0 && fb.aux_ok) {
             bool hit = false;
@@ -276,8 +333,12 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
         }
         // ---- length (preprocesser.py:476-479)
         if (flag < 0 && len1 < cfg.seq_len_req) flag = AQC_BADLEN;
+#if defined(AQC_ABLATE) && AQC_ABLATE == 4   /* no polyX */
+        if (false) {
+#else
         // ---- polyX (preprocesser.py:482-490): run-length screen per lane, exact check by the wave for the few hits
         if (cfg.poly_size_limit > 0) {
+#endif
             bool sus1 = false, sus2 = false;
             if (run_req < 2) {
                 sus1 = len1 >= cfg.poly_size_limit;
@@ -337,6 +398,7 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
             }
             if (poly) flag = AQC_BADPOL;
         }
+        PROF(2);
         // ---- low quality: read 1 only (preprocesser.py:498)
         if (flag < 0 && cfg.unqualified_base_limit > 0 && (int)L.lq[lane] > cfg.unqualified_base_limit) flag = AQC_BADLQC;
         // ---- N (preprocesser.py:504-512)
@@ -347,6 +409,7 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
             if (n1 > cfg.n_base_limit || n2 > cfg.n_base_limit) flag = AQC_BADNCT;
         }
 
+        PROF(3);
         // ---- overlap (util.py:158-212) --------------------------------------------------------------
         int offset = 0, ovl = 0, dist = 0, ovl0 = -1, dist_final = -1, n_edits = 0;
         int c_adapter_base = 0, c_adapter_read = 0, c_overlapped = 0, c_corrected = 0, c_masked = 0, c_skipped = 0, c_read_corrected = 0;
@@ -360,24 +423,33 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
             int from = 0;               // first candidate (in the reference's enumeration order) still to be examined
             bool found = false;
             const uint32_t F2 = W2lo[0], F1 = W1lo[0];
+#if defined(AQC_ABLATE) && AQC_ABLATE == 3   /* no scan */
+            scan = false;
+#endif
             while (true) {
                 const int wmax_f = wave_max_i(scan && !found ? nf : 0);
                 const int wmax_r = wave_max_i(scan && !found ? nr : 0);
                 if (wmax_f == 0 && wmax_r == 0) break;
                 int s0 = NONE_CAND, s1 = NONE_CAND, s2 = NONE_CAND;   // first three prefix survivors >= from
                 const bool live = scan && !found;
-                // forward diagonals d = 16k + r: read1[d + i] against reverse_r2[i]
+                // forward diagonals d = 16k + r: read1[d + i] against reverse_r2[i].  Eight diagonals are
+                // evaluated back to back (independent alignbit/xor/popcount chains) and share one branch.
 #pragma unroll
                 for (int k = 0; k < NW; ++k) {
                     if (16 * k >= wmax_f) break;
-#pragma unroll 4
-                    for (int r = 0; r < 16; ++r) {
-                        const uint32_t win = alignbit(W1lo[k + 1], W1lo[k], 2 * r);
-                        const bool hit = __popc(win ^ F2) < 5;
-                        if (__ballot(hit)) {
-                            const int c = 16 * k + r;
-                            if (hit && live && c < nf && c >= from) {
-                                if (s0 == NONE_CAND) s0 = c; else if (s1 == NONE_CAND) s1 = c; else if (s2 == NONE_CAND) s2 = c;
+#pragma unroll
+                    for (int r0 = 0; r0 < 16; r0 += 8) {
+                        uint32_t cnt[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) cnt[q] = __popc(alignbit(W1lo[k + 1], W1lo[k], 2 * (r0 + q)) ^ F2);
+                        const uint32_t best = min(min(min(cnt[0], cnt[1]), min(cnt[2], cnt[3])), min(min(cnt[4], cnt[5]), min(cnt[6], cnt[7])));
+                        if (__ballot(best < 5)) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int c = 16 * k + r0 + q;
+                                if (cnt[q] < 5 && live && c < nf && c >= from) {
+                                    if (s0 == NONE_CAND) s0 = c; else if (s1 == NONE_CAND) s1 = c; else if (s2 == NONE_CAND) s2 = c;
+                                }
                             }
                         }
                     }
@@ -386,18 +458,25 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
 #pragma unroll
                 for (int k = 0; k < NW; ++k) {
                     if (16 * k >= wmax_r) break;
-#pragma unroll 4
-                    for (int r = 0; r < 16; ++r) {
-                        const uint32_t win = alignbit(W2lo[k + 1], W2lo[k], 2 * r);
-                        const bool hit = __popc(win ^ F1) < 5;
-                        if (__ballot(hit)) {
-                            const int c = nf + 16 * k + r;
-                            if (hit && live && (16 * k + r) < nr && c >= from) {
-                                if (s0 == NONE_CAND) s0 = c; else if (s1 == NONE_CAND) s1 = c; else if (s2 == NONE_CAND) s2 = c;
+#pragma unroll
+                    for (int r0 = 0; r0 < 16; r0 += 8) {
+                        uint32_t cnt[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) cnt[q] = __popc(alignbit(W2lo[k + 1], W2lo[k], 2 * (r0 + q)) ^ F1);
+                        const uint32_t best = min(min(min(cnt[0], cnt[1]), min(cnt[2], cnt[3])), min(min(cnt[4], cnt[5]), min(cnt[6], cnt[7])));
+                        if (__ballot(best < 5)) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int a = 16 * k + r0 + q;
+                                const int c = nf + a;
+                                if (cnt[q] < 5 && live && a < nr && c >= from) {
+                                    if (s0 == NONE_CAND) s0 = c; else if (s1 == NONE_CAND) s1 = c; else if (s2 == NONE_CAND) s2 = c;
+                                }
                             }
                         }
                     }
                 }
+                PROF(4);
                 // exact verification of up to three survivors per lane, in order (util.py:177-184 / 200-207)
 #pragma unroll
                 for (int v = 0; v < 3; ++v) {
@@ -432,6 +511,7 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
                         }
                     }
                 }
+                PROF(5);
                 // a lane whose three survivors all failed and that may have more continues after the third one
                 const bool more = live && !found && s2 != NONE_CAND;
                 if (more) from = s2 + 1;
@@ -439,6 +519,7 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
                 if (!__ballot(more)) break;
             }
 
+            PROF(5);
             // ---- post-processing (preprocesser.py:516-617)
             const bool reached = valid && !defer && flag < 0;
             if (reached) {
@@ -466,7 +547,11 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
                 }
             }
             // ---- correction walk (preprocesser.py:563-598): first `dist` mismatches of the tail-anchored diagonal
+#if defined(AQC_ABLATE) && AQC_ABLATE == 5   /* no correction walk */
+            const bool walk = false;
+#else
             const bool walk = reached && !defer && flag < 0 && c_overlapped && dist > 0;
+#endif
             if (__ballot(walk)) {
                 int p0 = -1, p1 = -1, p2 = -1, nfound = 0;
                 // coordinates in the ORIGINAL (pre adapter cut) normalised streams held in LDS
@@ -495,19 +580,27 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
                     }
                 }
                 const int handled = min(nfound, dist);
-                // bytes of the handled mismatches straight from the canonical arenas
+                // bytes of the (<= 3) handled mismatches straight from the canonical arenas: all loads issued
+                // before any is consumed, so the walk costs one memory round trip
                 const uint8_t* g1 = fb.seq1 + ((uint64_t)L.o1[lane] << 4) + a1;
                 const uint8_t* h1 = fb.qual1 + ((uint64_t)L.o1[lane] << 4) + a1;
                 const uint8_t* g2 = fb.seq2 + ((uint64_t)L.o2[lane] << 4) + a2;
                 const uint8_t* h2 = fb.qual2 + ((uint64_t)L.o2[lane] << 4) + a2;
+                uint8_t wb1[3], wb2[3], wq1[3], wq2[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int oo = q == 0 ? p0 : q == 1 ? p1 : p2;
+                    const bool use = walk && q < handled;
+                    const int i1 = use ? len1 - ovl + oo : 0, i2 = use ? len2 - 1 - oo : 0;
+                    wb1[q] = g1[i1]; wb2[q] = g2[i2]; wq1[q] = h1[i1]; wq2[q] = h2[i2];
+                }
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int oo = q == 0 ? p0 : q == 1 ? p1 : p2;
                     if (walk && q < handled) {
-                        const int i1 = len1 - ovl + oo, i2 = len2 - 1 - oo;
-                        const uint8_t bA = g1[i1], r2o = g2[i2];
+                        const uint8_t bA = wb1[q], r2o = wb2[q];
                         const uint8_t bB = comp_strict(r2o);
-                        const int qa = h1[i1], qb = h2[i2];
+                        const int qa = wq1[q], qb = wq2[q];
                         bool fixed = false;
                         int em = -1;
                         aqc_edit ed = {0, 0, 0, 0};
@@ -547,6 +640,7 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
             }
         }
         if (flag < 0) flag = AQC_GOOD;
+        PROF(6);
 
         // ------------------------------------------------------------------ results + counters
         const bool mine = valid && !defer;
@@ -615,6 +709,7 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
             }
         }
         __builtin_amdgcn_wave_barrier();
+        PROF(7);
         // ------------------------------------------------------------------ deferred pairs: general pipeline, one at a time
         unsigned long long dmask = __ballot(valid && defer);
         if (dmask) {
@@ -629,7 +724,9 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
             }
         }
         __builtin_amdgcn_wave_barrier();
+        PROF(8);
     }
+    PROF_FLUSH;
     __syncthreads();
     flush_block_acc(acc, st);
 }
