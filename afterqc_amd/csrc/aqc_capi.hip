@@ -60,7 +60,7 @@ struct Slot {
     hipStream_t stream = nullptr;
     DevBuf seq1, qual1, off1, qoff1, len1, seq2, qual2, off2, qoff2, len2, aux[5], results;
     // canonical layout for the lane-per-pair kernel: 16-byte aligned records, offsets in 16-byte units
-    DevBuf cseq1, cqual1, cseq2, cqual2, co1, co2;
+    DevBuf cseq1, cqual1, cseq2, cqual2, co1, co2, deferred, n_deferred;
     uint32_t* h_o16[2] = {nullptr, nullptr};   // pinned staging for the canonical offsets
     size_t h_o16_cap[2] = {0, 0};
     FastBatch fview{};
@@ -138,13 +138,22 @@ static int check_status(aqc_ctx* c) {
 
 template <int NW, bool PAIRED, int WPBT>
 static void launch_fast(aqc_ctx* c, Slot* s, const aqc_config& cfg, const DevStats& st, uint64_t accum_limit) {
-    uint64_t blocks = (s->n + (uint64_t)WPBT * WAVE - 1) / ((uint64_t)WPBT * WAVE);
-    const uint64_t cap = (uint64_t)c->n_cu * 2;     // LDS admits two workgroups per CU; batches are grid-strided
+    constexpr uint64_t per_block = (uint64_t)WPBT * FastWaveLds<NW, PAIRED>::PPW;
+    uint64_t blocks = (s->n + per_block - 1) / per_block;
+    // persistent grid: as many workgroups as the LDS footprint lets a CU hold; batches are grid-strided
+    const size_t lds = sizeof(FastWaveLds<NW, PAIRED>) * WPBT + sizeof(BlockAcc) + 64;
+    uint64_t per_cu = (160 * 1024) / lds;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const uint64_t cap = (uint64_t)c->n_cu * per_cu;
     if (blocks > cap) blocks = cap;
+    // pairs the fast kernel cannot decide exactly (exotic bytes, very short reads, ...) are queued and
+    // finished by the general wave-per-record pipeline right behind it on the same stream
+    (void)hipMemsetAsync(s->n_deferred.p, 0, sizeof(unsigned int), s->stream);
     hipLaunchKernelGGL((fast_filter_overlap_kernel<NW, PAIRED, WPBT>), dim3((unsigned)blocks), dim3(WPBT * WAVE), 0, s->stream,
-                       s->fview, s->view, cfg, c->circles, (aqc_result*)s->results.p, st, accum_limit);
+                       s->fview, cfg, c->circles, (aqc_result*)s->results.p, st, accum_limit, (uint32_t*)s->deferred.p,
+                       (unsigned int*)s->n_deferred.p);
 }
-
 
 extern "C" {
 
@@ -196,7 +205,7 @@ void aqc_destroy(aqc_ctx* c) {
     for (auto& s : c->slots) {
         DevBuf* bufs[] = {&s.seq1, &s.qual1, &s.off1, &s.qoff1, &s.len1, &s.seq2, &s.qual2, &s.off2, &s.qoff2, &s.len2,
                           &s.aux[0], &s.aux[1], &s.aux[2], &s.aux[3], &s.aux[4], &s.results,
-                          &s.cseq1, &s.cqual1, &s.cseq2, &s.cqual2, &s.co1, &s.co2};
+                          &s.cseq1, &s.cqual1, &s.cseq2, &s.cqual2, &s.co1, &s.co2, &s.deferred, &s.n_deferred};
         for (DevBuf* b : bufs) b->release();
         for (int k = 0; k < 2; k++)
             if (s.h_o16[k]) (void)hipHostFree(s.h_o16[k]);
@@ -454,12 +463,19 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
     if (!fast_ok) {
         hipLaunchKernelGGL(filter_overlap_kernel, dim3(grid_for(c, s->n)), dim3(BLOCK), 0, s->stream, s->view, cfg, c->circles,
                            (aqc_result*)s->results.p, st, accum_limit);
-    } else if (s->max_len <= 160) {
-        if (cfg.paired) launch_fast<10, true, 4>(c, s, cfg, st, accum_limit);
-        else launch_fast<10, false, 4>(c, s, cfg, st, accum_limit);
     } else {
-        if (cfg.paired) launch_fast<16, true, 2>(c, s, cfg, st, accum_limit);
-        else launch_fast<16, false, 2>(c, s, cfg, st, accum_limit);
+        if (s->deferred.reserve(sizeof(uint32_t) * (s->n + 1)) || s->n_deferred.reserve(sizeof(unsigned int)))
+            return fail(AQC_ERR_HIP, "hipMalloc failed");
+        if (s->max_len <= 160) {
+            if (cfg.paired) launch_fast<10, true, 4>(c, s, cfg, st, accum_limit);
+            else launch_fast<10, false, 4>(c, s, cfg, st, accum_limit);
+        } else {
+            if (cfg.paired) launch_fast<16, true, 4>(c, s, cfg, st, accum_limit);
+            else launch_fast<16, false, 4>(c, s, cfg, st, accum_limit);
+        }
+        hipLaunchKernelGGL(filter_overlap_list_kernel, dim3((unsigned)c->n_cu), dim3(BLOCK), 0, s->stream, s->view, cfg, c->circles,
+                           (aqc_result*)s->results.p, st, accum_limit, (const uint32_t*)s->deferred.p,
+                           (const unsigned int*)s->n_deferred.p);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_FILTER_OVERLAP, 1), s->stream));

@@ -1,4 +1,4 @@
-// aqc_fast.hpp — generation 2 of the hot kernel: "one LANE per read pair".
+// aqc_fast.hpp — generation 2/3 of the hot kernel: "one LANE per READ" (two lanes per pair).
 //
 // Why: the wave-per-record kernel (aqc_kernels.hpp) spends ~1500 wave-instructions per pair, which
 // caps it at ~1 % of the HBM roofline.  To stream pairs at a useful fraction of 8 TB/s the whole
@@ -6,16 +6,21 @@
 // wave-instr/s / 5 G pairs/s), i.e. every lane has to do useful work all the time and byte
 // compares have to become word compares.  Design:
 //
-//   phase 1 (cooperative, coalesced)   the wave owns 64 consecutive pairs.  Each lane loads one
+//   phase 1 (cooperative, coalesced)   the wave owns 32 consecutive pairs.  Each lane loads one
 //       16-byte chunk of one string per step (global_load_dwordx4: 16 lanes cover a 160-byte read,
 //       4 reads per instruction) and converts it with SWAR + v_dot4/v_perm into
 //         lo  : 2 bits per base  ((c >> 1) & 3: A=0 C=1 T=2 G=3; N shares 3)            32 bits/chunk
 //         e   : 1 bit per base (odd bit of the 2-bit field) set for 'N'                32 bits/chunk
 //       Read 2 is stored complemented and reversed, so that reverse_r2 (util.py:161) is a forward
 //       2-bit stream.  Low-quality counts of read 1 are reduced per chunk.  The planes go to LDS.
-//   phase 2 (lane per pair)            every lane pulls the planes of ITS pair into registers,
-//       normalises them (trim offsets, reverse-complement alignment) and runs the pipeline of
-//       preprocesser.py:455-617 on 32-bit words:
+//   phase 2 (lane per read)            lanes 2p / 2p+1 own read 1 / reverse_r2 of pair p.  Each pulls the
+//       planes of ITS read into registers, normalises them (trim offsets, reverse-complement
+//       alignment) and runs the pipeline of preprocesser.py:455-617 on 32-bit words.  The two roles are
+//       symmetric: the read-1 lane scans the forward offsets of util.py:172-186 (its stream moves over the
+//       partner's 16-base prefix), the read-2 lane the reverse offsets of :194-209 — same instructions,
+//       different data, values exchanged with one DPP quad_perm.  Halving the per-lane state (22 plane
+//       registers, 5.8 KB of LDS per wave) is what lifts occupancy from 2 to 4 waves per SIMD; the
+//       VALU issue rate of this code roughly doubles with it (tools/ubench/valu_rate.hip).
 //         * overlap scan: one diagonal = v_alignbit + v_xor + v_bcnt on a 16-base prefix window;
 //           >= 5 differing bits imply >= 3 mismatching bases, which util.py:180-183 can never accept;
 //         * the rare survivors are verified exactly over the full diagonal (lo and e planes);
@@ -89,16 +94,21 @@ __device__ __forceinline__ void trim_view(int len, int front, int tail, int& st,
     nl = max(end - st, 0);
 }
 
-template <int NW>
+template <int NW, bool PAIRED>
 struct FastWaveLds {
-    static constexpr int STRIDE = 4 * NW + 5;   // odd: conflict-free lane-strided access
-    uint32_t planes[WAVE][STRIDE];
-    uint32_t o1[WAVE], o2[WAVE], l1[WAVE], l2[WAVE];
-    uint32_t lq[WAVE];
-    uint32_t exo[WAVE];
+    static constexpr int PPW = PAIRED ? 32 : 64;               // records per wave batch
+    static constexpr int STRIDE = (PAIRED ? 4 : 2) * NW + 5;   // odd: conflict-free lane-strided access
+    uint32_t planes[PPW][STRIDE];
+    uint32_t o1[PPW], o2[PPW], l1[PPW], l2[PPW];
+    uint32_t lq[PPW];
+    uint32_t exo[PPW];
     uint8_t stage[16 * NW + 16];
-    uint8_t rs[2][64];
 };
+
+// exchange a value with the partner lane (lane ^ 1): DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ int xchg(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
+// the partner lane's predicate, through a ballot (all lanes must call it)
+__device__ __forceinline__ bool xchg_pred(bool b) { return ((__ballot(b) >> (lane_id() ^ 1)) & 1ull) != 0; }
 
 // mismatch word j of a diagonal: moving stream (lo/e at word index k+j, sub-word shift s) against the
 // fixed stream's word j; returns one flag per base on the ODD bits, limited to the first nb bases.
@@ -123,72 +133,78 @@ __device__ __forceinline__ uint32_t mm_word(uint32_t mlo0, uint32_t mlo1, uint32
 #define PROF_FLUSH
 #endif
 
+#ifndef AQC_MIN_WAVES
+#define AQC_MIN_WAVES 4
+#endif
 template <int NW, bool PAIRED, int WPBT>
-__global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBatch fb, DevBatch raw, aqc_config cfg, DevCircles circ,
+__global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overlap_kernel(FastBatch fb, aqc_config cfg, DevCircles circ,
                                                                     aqc_result* __restrict__ results, DevStats st,
-                                                                    uint64_t accum_limit) {
-    using WL = FastWaveLds<NW>;
+                                                                    uint64_t accum_limit, uint32_t* __restrict__ deferred,
+                                                                    unsigned int* __restrict__ n_deferred) {
+    using WL = FastWaveLds<NW, PAIRED>;
     constexpr int STRIDE = WL::STRIDE;
+    constexpr int PPW = WL::PPW;
+    constexpr int ITERS = PPW * NW / WAVE;        // 16-byte chunk tasks per lane and string kind
+    static_assert(PPW * NW % WAVE == 0, "chunk tasks must tile the wave");
     __shared__ WL wls[WPBT];
     __shared__ BlockAcc acc;
-#if defined(AQC_ABLATE) && AQC_ABLATE == 9   /* occupancy probe: one workgroup per CU */
-    __shared__ uint32_t occ_pad[11000];
-    if (threadIdx.x == 0 && fb.n == 1234567891234ull) occ_pad[blockIdx.x % 11000] = 1;
-    if (fb.n == 1234567891235ull && occ_pad[threadIdx.x] == 77) return;
-#endif
-    static_assert(sizeof(uint32_t) * WAVE * STRIDE >= 5 * LSTR, "generation-1 staging must fit into the plane region");
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
     for (int i = threadIdx.x; i < (int)(sizeof(BlockAcc) / 4); i += WPBT * WAVE) ((unsigned int*)&acc)[i] = 0;
     __syncthreads();
     WL& L = wls[wave];
-    uint32_t* const my = L.planes[lane];
+    const int p = PAIRED ? lane >> 1 : lane;      // record of this lane within the batch
+    const int role = PAIRED ? lane & 1 : 0;       // 0: owns read 1 (forward offsets), 1: owns reverse_r2 (reverse offsets)
+    uint32_t* const pr = L.planes[p];
+    uint32_t* const own = pr + (role ? 2 * NW : 0);         // own stream: lo at own[j], e at own[NW + j]
+    const uint32_t* const par = pr + (role ? 0 : 2 * NW);   // partner stream
     const int thr4 = (cfg.qualified_quality_phred + 33) * 0x01010101;
     const bool do_trim = cfg.trim_front > 0 || cfg.trim_tail > 0;
     // longest run of identical bases any firing polyX window must contain (pigeonhole over the mismatches)
     const int need = cfg.poly_size_limit - cfg.allow_mismatch_in_poly;
     const int run_req = cfg.allow_mismatch_in_poly >= 0 ? (need + cfg.allow_mismatch_in_poly) / (cfg.allow_mismatch_in_poly + 1) : 0;
+    const int r2b = (PAIRED && cfg.count_r2_bases) ? 1 : 0;
+
+    // per-lane running totals, reduced once at the end of the kernel
+    uint32_t r_n = 0, r_good = 0, r_tb = 0, r_gb = 0, r_ab = 0, r_ar = 0, r_ov = 0, r_ol = 0, r_od = 0, r_rc = 0, r_bc = 0, r_mk = 0, r_sk = 0;
 
     PROF_DECL
-    const uint64_t stride = (uint64_t)gridDim.x * WPBT * WAVE;
-    const uint64_t base0 = ((uint64_t)blockIdx.x * WPBT + wave) * WAVE;
-    // record descriptors of the NEXT batch are fetched one iteration ahead (no round trip at the top of the loop)
-    uint32_t m_o1 = 0, m_l1 = 0, m_o2 = 0, m_l2 = 0;
-    if (base0 + lane < fb.n) {
-        m_o1 = fb.o1[base0 + lane]; m_l1 = fb.len1[base0 + lane];
-        if (PAIRED) { m_o2 = fb.o2[base0 + lane]; m_l2 = fb.len2[base0 + lane]; }
+    const uint64_t stride = (uint64_t)gridDim.x * WPBT * PPW;
+    const uint64_t base0 = ((uint64_t)blockIdx.x * WPBT + wave) * PPW;
+    // the descriptor of this lane's read in the NEXT batch is fetched one iteration ahead
+    uint32_t m_o = 0, m_l = 0;
+    if (base0 + p < fb.n) {
+        m_o = role ? fb.o2[base0 + p] : fb.o1[base0 + p];
+        m_l = role ? fb.len2[base0 + p] : fb.len1[base0 + p];
     }
     for (uint64_t base = base0; base < fb.n; base += stride) {
-        const uint64_t rec = base + lane;
+        const uint64_t rec = base + p;
         const bool valid = rec < fb.n;
         // ------------------------------------------------------------------ phase 1: load + pack
-        L.o1[lane] = m_o1;
-        L.l1[lane] = m_l1;
-        if (PAIRED) { L.o2[lane] = m_o2; L.l2[lane] = m_l2; }
-        L.lq[lane] = 0;
-        L.exo[lane] = 0;
+        if (role == 0) { L.o1[p] = m_o; L.l1[p] = m_l; L.lq[p] = 0; L.exo[p] = 0; }
+        else { L.o2[p] = m_o; L.l2[p] = m_l; }
         {
             const uint64_t nrec = rec + stride;
-            m_o1 = m_l1 = m_o2 = m_l2 = 0;
+            m_o = m_l = 0;
             if (nrec < fb.n) {
-                m_o1 = fb.o1[nrec]; m_l1 = fb.len1[nrec];
-                if (PAIRED) { m_o2 = fb.o2[nrec]; m_l2 = fb.len2[nrec]; }
+                m_o = role ? fb.o2[nrec] : fb.o1[nrec];
+                m_l = role ? fb.len2[nrec] : fb.len1[nrec];
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // each pass: descriptors from LDS, then all NW 16-byte loads in flight at once, then the packing
+        // each pass: descriptors from LDS, then all 16-byte loads of the pass in flight at once, then the packing
         {
-            uint4 v[NW];
-            int sp[NW], len[NW];
+            uint4 v[ITERS];
+            int sp[ITERS], len[ITERS];
 #pragma unroll
-            for (int it = 0; it < NW; ++it) {
+            for (int it = 0; it < ITERS; ++it) {
                 const int t = it * WAVE + lane;
                 sp[it] = t / NW;
                 len[it] = (int)L.l1[sp[it]];
                 v[it] = *reinterpret_cast<const uint4*>(fb.seq1 + ((uint64_t)(L.o1[sp[it]] + (t - sp[it] * NW)) << 4));
             }
 #pragma unroll
-            for (int it = 0; it < NW; ++it) {
+            for (int it = 0; it < ITERS; ++it) {
                 const int c = it * WAVE + lane - sp[it] * NW;
                 uint32_t lo, e, bad;
                 pack_chunk(v[it], lo, e, bad);
@@ -198,17 +214,17 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
             }
         }
         if (PAIRED) {
-            uint4 v[NW];
-            int sp[NW], len[NW];
+            uint4 v[ITERS];
+            int sp[ITERS], len[ITERS];
 #pragma unroll
-            for (int it = 0; it < NW; ++it) {
+            for (int it = 0; it < ITERS; ++it) {
                 const int t = it * WAVE + lane;
                 sp[it] = t / NW;
                 len[it] = (int)L.l2[sp[it]];
                 v[it] = *reinterpret_cast<const uint4*>(fb.seq2 + ((uint64_t)(L.o2[sp[it]] + (t - sp[it] * NW)) << 4));
             }
 #pragma unroll
-            for (int it = 0; it < NW; ++it) {
+            for (int it = 0; it < ITERS; ++it) {
                 const int c = it * WAVE + lane - sp[it] * NW;
                 uint32_t lo, e, bad;
                 pack_chunk(v[it], lo, e, bad);
@@ -220,17 +236,17 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
             }
         }
         if (cfg.unqualified_base_limit > 0) {
-            uint4 v[NW];
-            int sp[NW], len[NW];
+            uint4 v[ITERS];
+            int sp[ITERS], len[ITERS];
 #pragma unroll
-            for (int it = 0; it < NW; ++it) {
+            for (int it = 0; it < ITERS; ++it) {
                 const int t = it * WAVE + lane;
                 sp[it] = t / NW;
                 len[it] = (int)L.l1[sp[it]];
                 v[it] = *reinterpret_cast<const uint4*>(fb.qual1 + ((uint64_t)(L.o1[sp[it]] + (t - sp[it] * NW)) << 4));
             }
 #pragma unroll
-            for (int it = 0; it < NW; ++it) {
+            for (int it = 0; it < ITERS; ++it) {
                 const int c = it * WAVE + lane - sp[it] * NW;
                 int a = 0, nl = len[it];
                 if (do_trim) trim_view(len[it], cfg.trim_front, cfg.trim_tail, a, nl);
@@ -252,71 +268,57 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
         PROF(0);
 
 #if defined(AQC_ABLATE) && AQC_ABLATE == 1   /* phase 1 only */
-        if (valid) results[rec].flag = (uint8_t)(L.planes[lane][0] + L.lq[lane] + L.exo[lane]);
+        if (valid && role == 0) results[rec].flag = (uint8_t)(L.planes[p][0] + L.lq[p] + L.exo[p]);
         continue;
 #endif
-        // ------------------------------------------------------------------ phase 2: lane per pair
-        const int L1 = (int)L.l1[lane];
-        const int L2 = PAIRED ? (int)L.l2[lane] : 0;
+        // ------------------------------------------------------------------ phase 2: lane per read
+        const int L1 = (int)L.l1[p];
+        const int L2 = PAIRED ? (int)L.l2[p] : 0;
         const bool accum = valid && rec < accum_limit;
-        bool defer = valid && (L.exo[lane] != 0 || L1 > 16 * NW || L2 > 16 * NW || L1 == 0 || (PAIRED && L2 == 0));
-        int a1 = 0, len1 = L1, a2 = 0, len2 = L2;
+        bool defer = valid && (L.exo[p] != 0 || L1 > 16 * NW || L2 > 16 * NW || L1 == 0 || (PAIRED && L2 == 0));
+        // trim (preprocesser.py:455-466): every lane trims its own read
+        const int Lown = role ? L2 : L1;
+        int a_own = 0, len_own = Lown;
+        if (do_trim) trim_view(Lown, role ? cfg.trim_front2 : cfg.trim_front, role ? cfg.trim_tail2 : cfg.trim_tail, a_own, len_own);
+        int a_par = 0, len_par = 0;
+        if (PAIRED) { a_par = xchg(a_own); len_par = xchg(len_own); }
+        int a1 = role ? a_par : a_own, len1 = role ? len_par : len_own;
+        int a2 = role ? a_own : a_par, len2 = role ? len_own : len_par;
         int flag = -1;
         if (do_trim) {
-            trim_view(L1, cfg.trim_front, cfg.trim_tail, a1, len1);
-            if (len1 < 5) flag = AQC_BADTRIM1;
-            else if (PAIRED) {
-                trim_view(L2, cfg.trim_front2, cfg.trim_tail2, a2, len2);
-                if (len2 < 5) flag = AQC_BADTRIM2;
-            }
+            if (len1 < 5) { flag = AQC_BADTRIM1; a2 = 0; len2 = L2; }       // read 2 is not trimmed in this case
+            else if (PAIRED && len2 < 5) flag = AQC_BADTRIM2;
         }
-        // ---- normalise the planes into registers: W1*[j] holds read1 bases 16j..16j+15, W2* the same for reverse_r2
-        uint32_t W1lo[NW + 1], W1e[NW + 1], W2lo[NW + 1], W2e[NW + 1];
+        // ---- normalise the own stream IN PLACE in LDS: afterwards own[j] / own[NW + j] hold bases 16j..16j+15 of
+        //      read 1 (role 0) or of reverse_r2 (role 1); everything beyond the read's length is zero.  Later
+        //      stages fetch the few words they need from LDS instead of pinning 2 x NW registers per lane.
         {
-            const int k0 = a1 >> 4;
-            const uint32_t s = (uint32_t)(a1 & 15) * 2;
-#pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                const int i0 = k0 + j, i1 = k0 + j + 1;
-                const uint32_t lo0 = i0 < NW ? my[i0] : 0u, lo1 = i1 < NW ? my[i1] : 0u;
-                const uint32_t e0 = i0 < NW ? my[NW + i0] : 0u, e1 = i1 < NW ? my[NW + i1] : 0u;
-                const uint32_t m = base_mask(min(max(len1 - 16 * j, 0), 16));
-                W1lo[j] = alignbit(lo1, lo0, s) & m;
-                W1e[j] = alignbit(e1, e0, s) & m;
+            int b0 = a_own;
+            if (role) {
+                // reverse_r2[i] sits at stream position p0 + i of the reversed chunk sequence
+                const int tl = a_own + len_own - 1;                     // last base of the current read 2
+                b0 = 16 * (NW - 1 - (tl >> 4)) + 15 - (tl & 15);
             }
-            W1lo[NW] = 0; W1e[NW] = 0;
+            const int k0 = b0 >> 4;
+            const uint32_t s = (uint32_t)(b0 & 15) * 2;
+            uint32_t lo0 = k0 < NW ? own[k0] : 0u, e0 = k0 < NW ? own[NW + k0] : 0u;
+#pragma nounroll
+            for (int j = 0; j < NW; ++j) {
+                const int i1 = k0 + j + 1;
+                const uint32_t lo1 = i1 < NW ? own[i1] : 0u, e1 = i1 < NW ? own[NW + i1] : 0u;
+                const uint32_t m = base_mask(min(max(len_own - 16 * j, 0), 16));
+                own[j] = alignbit(lo1, lo0, s) & m;          // index j <= k0 + j: never overwrites a word still to be read
+                own[NW + j] = alignbit(e1, e0, s) & m;
+                lo0 = lo1; e0 = e1;
+            }
         }
-        if (PAIRED) {
-            // reverse_r2[i] sits at stream position p0 + i of the reversed chunk sequence
-            const int tl = a2 + len2 - 1;                       // last base of the current read 2
-            const int p0 = 16 * (NW - 1 - (tl >> 4)) + 15 - (tl & 15);
-            const int k0 = p0 >> 4;
-            const uint32_t s = (uint32_t)(p0 & 15) * 2;
+        if (role == 0) {
 #pragma unroll
-            for (int j = 0; j < NW; ++j) {
-                const int i0 = k0 + j, i1 = k0 + j + 1;
-                const bool ok0 = i0 >= 0 && i0 < NW, ok1 = i1 >= 0 && i1 < NW;
-                const uint32_t lo0 = ok0 ? my[2 * NW + i0] : 0u, lo1 = ok1 ? my[2 * NW + i1] : 0u;
-                const uint32_t e0 = ok0 ? my[3 * NW + i0] : 0u, e1 = ok1 ? my[3 * NW + i1] : 0u;
-                const uint32_t m = base_mask(min(max(len2 - 16 * j, 0), 16));
-                W2lo[j] = alignbit(lo1, lo0, s) & m;
-                W2e[j] = alignbit(e1, e0, s) & m;
-            }
-            W2lo[NW] = 0; W2e[NW] = 0;
-        } else {
-#pragma unroll
-            for (int j = 0; j <= NW; ++j) { W2lo[j] = 0; W2e[j] = 0; }
+            for (int j = 0; j < 5; ++j) pr[(PAIRED ? 4 : 2) * NW + j] = 0;
         }
         __builtin_amdgcn_wave_barrier();
-        // keep the normalised streams in LDS as well: the verify / walk steps index them with per-lane offsets
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            my[j] = W1lo[j]; my[NW + j] = W1e[j]; my[2 * NW + j] = W2lo[j]; my[3 * NW + j] = W2e[j];
-        }
-        my[4 * NW] = 0; my[4 * NW + 1] = 0; my[4 * NW + 2] = 0; my[4 * NW + 3] = 0; my[4 * NW + 4] = 0;
-        __builtin_amdgcn_wave_barrier();
-
         PROF(1);
+
         // ---- bubble (preprocesser.py:469-473)
         if (cfg.debubble && circ.n > 0 && fb.aux_ok) {
             bool hit = false;
@@ -333,148 +335,138 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
         }
         // ---- length (preprocesser.py:476-479)
         if (flag < 0 && len1 < cfg.seq_len_req) flag = AQC_BADLEN;
+#ifdef AQC_DEBUG_POLY
+        uint8_t dbg_byte = 0;
+#endif
+        // ---- polyX (preprocesser.py:482-490): run-length screen per read, exact check by the wave for the few hits
 #if defined(AQC_ABLATE) && AQC_ABLATE == 4   /* no polyX */
         if (false) {
 #else
-        // ---- polyX (preprocesser.py:482-490): run-length screen per lane, exact check by the wave for the few hits
         if (cfg.poly_size_limit > 0) {
 #endif
-            bool sus1 = false, sus2 = false;
-            if (run_req < 2) {
-                sus1 = len1 >= cfg.poly_size_limit;
-                sus2 = PAIRED && len2 >= cfg.poly_size_limit;
-            } else {
+            bool sus = false;
+#if defined(AQC_ABLATE) && AQC_ABLATE == 11
+            if (true) sus = len_own >= cfg.poly_size_limit;
+#else
+            if (run_req < 2) sus = len_own >= cfg.poly_size_limit;
+#endif
+            else {
+                uint32_t r[NW + 1], Wlo[NW + 1], We[NW + 1];
 #pragma unroll
-                for (int which = 0; which < (PAIRED ? 2 : 1); ++which) {
-                    const uint32_t* Wl = which ? W2lo : W1lo;
-                    const uint32_t* We = which ? W2e : W1e;
-                    const int ln = which ? len2 : len1;
-                    uint32_t r[NW + 1];
+                for (int j = 0; j < NW; ++j) { Wlo[j] = own[j]; We[j] = own[NW + j]; }
+                Wlo[NW] = 0; We[NW] = 0;
 #pragma unroll
-                    for (int j = 0; j < NW; ++j) {
-                        const uint32_t x = Wl[j] ^ alignbit(Wl[j + 1], Wl[j], 2);
-                        const uint32_t ex = We[j] ^ alignbit(We[j + 1], We[j], 2);
-                        // base i equals base i+1, only for i <= ln-2
-                        r[j] = ~(((x << 1) | x | ex)) & ODD & base_mask(min(max(ln - 1 - 16 * j, 0), 16));
-                    }
-                    r[NW] = 0;
-                    int covered = 1;
-                    while (covered < run_req - 1) {
-                        const int step = min(min(covered, run_req - 1 - covered), 15);
-#pragma unroll
-                        for (int j = 0; j < NW; ++j) r[j] &= alignbit(r[j + 1], r[j], 2 * step);
-                        covered += step;
-                    }
-                    uint32_t any = 0;
-#pragma unroll
-                    for (int j = 0; j < NW; ++j) any |= r[j];
-                    if (which) sus2 = any != 0 && ln >= cfg.poly_size_limit;
-                    else sus1 = any != 0 && ln >= cfg.poly_size_limit;
+                for (int j = 0; j < NW; ++j) {
+                    const uint32_t x = Wlo[j] ^ alignbit(Wlo[j + 1], Wlo[j], 2);
+                    const uint32_t ex = We[j] ^ alignbit(We[j + 1], We[j], 2);
+                    // base i equals base i+1, only for i <= len-2
+                    r[j] = ~(((x << 1) | x | ex)) & ODD & base_mask(min(max(len_own - 1 - 16 * j, 0), 16));
                 }
+                r[NW] = 0;
+                int covered = 1;
+                while (covered < run_req - 1) {
+                    const int step = min(min(covered, run_req - 1 - covered), 15);
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) r[j] &= alignbit(r[j + 1], r[j], 2 * step);
+                    covered += step;
+                }
+                uint32_t any = 0;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) any |= r[j];
+                sus = any != 0 && len_own >= cfg.poly_size_limit;
             }
             bool poly = false;
-            unsigned long long todo = __ballot(valid && !defer && flag < 0 && (sus1 || sus2));
+            unsigned long long todo = __ballot(valid && !defer && flag < 0 && sus);
             while (todo) {
                 const int l = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
-                const uint64_t r2 = base + l;
-                const int s1f = __shfl((int)sus1, l, WAVE), s2f = __shfl((int)sus2, l, WAVE);
-                const int ta1 = __shfl(a1, l, WAVE), tl1 = __shfl(len1, l, WAVE), ta2 = __shfl(a2, l, WAVE), tl2 = __shfl(len2, l, WAVE);
-                int p = 0;
-                if (s1f) {
-                    stage(L.stage, fb.seq1 + ((uint64_t)fb.o1[r2] << 4) + ta1, tl1);
-                    __builtin_amdgcn_wave_barrier();
-                    p = has_polyx_wave(L.stage, tl1, cfg.poly_size_limit, cfg.allow_mismatch_in_poly);
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (p == 0 && s2f) {
-                    // hasPolyX runs on read 2 as sequenced (not reverse-complemented)
-                    stage(L.stage, fb.seq2 + ((uint64_t)fb.o2[r2] << 4) + ta2, tl2);
-                    __builtin_amdgcn_wave_barrier();
-                    p = has_polyx_wave(L.stage, tl2, cfg.poly_size_limit, cfg.allow_mismatch_in_poly);
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (p != 0 && lane == l) poly = true;
+                const int lp = PAIRED ? l >> 1 : l, lr = PAIRED ? l & 1 : 0;
+                const int ta = __shfl(a_own, l, WAVE), tl = __shfl(len_own, l, WAVE);
+                // hasPolyX runs on the read as sequenced (read 2 is NOT reverse-complemented)
+                const uint8_t* src = (lr ? fb.seq2 + ((uint64_t)L.o2[lp] << 4) : fb.seq1 + ((uint64_t)L.o1[lp] << 4)) + ta;
+                stage(L.stage, src, tl);
+                __builtin_amdgcn_wave_barrier();
+                const int px = has_polyx_wave(L.stage, tl, cfg.poly_size_limit, cfg.allow_mismatch_in_poly);
+                __builtin_amdgcn_wave_barrier();
+                if (px != 0 && lane == l) poly = true;
             }
-            if (poly) flag = AQC_BADPOL;
+            // (the exchange must run on all lanes: a DPP read from a masked-off partner returns 0)
+            const bool poly_par = PAIRED ? xchg_pred(poly) : false;
+            const bool poly_pair = poly || poly_par;
+#ifdef AQC_DEBUG_POLY
+            dbg_byte = (uint8_t)((sus ? 1 : 0) | (poly ? 2 : 0) | (poly_par ? 4 : 0) | (flag < 0 ? 8 : 0) | (defer ? 16 : 0) | 128);
+#endif
+            if (flag < 0 && poly_pair) flag = AQC_BADPOL;
         }
         PROF(2);
         // ---- low quality: read 1 only (preprocesser.py:498)
-        if (flag < 0 && cfg.unqualified_base_limit > 0 && (int)L.lq[lane] > cfg.unqualified_base_limit) flag = AQC_BADLQC;
+        if (flag < 0 && cfg.unqualified_base_limit > 0 && (int)L.lq[p] > cfg.unqualified_base_limit) flag = AQC_BADLQC;
         // ---- N (preprocesser.py:504-512)
-        if (flag < 0 && cfg.n_base_limit > 0) {
-            int n1 = 0, n2 = 0;
+        if (cfg.n_base_limit > 0) {
+            int n_own = 0;
 #pragma unroll
-            for (int j = 0; j < NW; ++j) { n1 += __popc(W1e[j]); n2 += __popc(W2e[j]); }
-            if (n1 > cfg.n_base_limit || n2 > cfg.n_base_limit) flag = AQC_BADNCT;
+            for (int j = 0; j < NW; ++j) n_own += __popc(own[NW + j]);
+            const int n_par = PAIRED ? xchg(n_own) : 0;
+            if (flag < 0 && (n_own > cfg.n_base_limit || n_par > cfg.n_base_limit)) flag = AQC_BADNCT;
         }
-
         PROF(3);
+
         // ---- overlap (util.py:158-212) --------------------------------------------------------------
         int offset = 0, ovl = 0, dist = 0, ovl0 = -1, dist_final = -1, n_edits = 0;
         int c_adapter_base = 0, c_adapter_read = 0, c_overlapped = 0, c_corrected = 0, c_masked = 0, c_skipped = 0, c_read_corrected = 0;
         int em0 = -1, em1 = -1, em2 = -1;
         aqc_edit ed0 = {0, 0, 0, 0}, ed1 = {0, 0, 0, 0}, ed2 = {0, 0, 0, 0};
+        bool walker = false, walk_pair = false;
+#ifdef AQC_DEBUG_POLY
+        if (valid) reinterpret_cast<volatile uint8_t*>(results + rec)[28 + role] = dbg_byte;
+#endif
         if (PAIRED && !cfg.no_overlap) {
+            // own candidates: offsets c = 0 .. len_own - 31, the own stream moving over the partner's prefix
+            const int n_own = len_own > 30 ? len_own - 30 : 0;
             bool scan = valid && !defer && flag < 0;
-            const int nf = len1 > 30 ? len1 - 30 : 0, nr = len2 > 30 ? len2 - 30 : 0;
-            // the 16-base prefix test needs 16 columns on every diagonal
-            if (scan && ((nf > 0 && len2 < 16) || (nr > 0 && len1 < 16))) { defer = true; scan = false; }
-            int from = 0;               // first candidate (in the reference's enumeration order) still to be examined
-            bool found = false;
-            const uint32_t F2 = W2lo[0], F1 = W1lo[0];
+            {
+                // the 16-base prefix test needs 16 columns on every diagonal
+                const bool short16 = scan && n_own > 0 && len_par < 16;
+                const bool short16_par = xchg_pred(short16);
+                if (short16 || short16_par) { defer = true; scan = false; }
+            }
 #if defined(AQC_ABLATE) && AQC_ABLATE == 3   /* no scan */
             scan = false;
 #endif
+            int from = 0;               // first own candidate still to be examined
+            bool found = false;
+            int f_off = 0, f_len = 0, f_tot = 0;
+            const uint32_t F = par[0];                          // partner's first 16 bases
             while (true) {
-                const int wmax_f = wave_max_i(scan && !found ? nf : 0);
-                const int wmax_r = wave_max_i(scan && !found ? nr : 0);
-                if (wmax_f == 0 && wmax_r == 0) break;
+                const int wmax = wave_max_i(scan && !found ? n_own : 0);
+                if (wmax == 0) break;
                 int s0 = NONE_CAND, s1 = NONE_CAND, s2 = NONE_CAND;   // first three prefix survivors >= from
                 const bool live = scan && !found;
-                // forward diagonals d = 16k + r: read1[d + i] against reverse_r2[i].  Eight diagonals are
-                // evaluated back to back (independent alignbit/xor/popcount chains) and share one branch.
-#pragma unroll
-                for (int k = 0; k < NW; ++k) {
-                    if (16 * k >= wmax_f) break;
+                // sixteen diagonals per 32-bit word pair; eight are evaluated back to back (independent
+                // alignbit / xor / popcount chains) per branch
+                uint32_t w0 = own[0];
+#pragma nounroll
+                for (int k = 0; 16 * k < wmax; ++k) {
+                    const uint32_t w1 = (k + 1 < NW) ? own[k + 1] : 0u;
 #pragma unroll
                     for (int r0 = 0; r0 < 16; r0 += 8) {
                         uint32_t cnt[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) cnt[q] = __popc(alignbit(W1lo[k + 1], W1lo[k], 2 * (r0 + q)) ^ F2);
+                        for (int q = 0; q < 8; ++q) cnt[q] = __popc(alignbit(w1, w0, 2 * (r0 + q)) ^ F);
                         const uint32_t best = min(min(min(cnt[0], cnt[1]), min(cnt[2], cnt[3])), min(min(cnt[4], cnt[5]), min(cnt[6], cnt[7])));
                         if (__ballot(best < 5)) {
-#pragma unroll
+                            // rare: re-derive the eight counts in a rolled loop, keeping this path out of the hot code
+#pragma nounroll
                             for (int q = 0; q < 8; ++q) {
                                 const int c = 16 * k + r0 + q;
-                                if (cnt[q] < 5 && live && c < nf && c >= from) {
+                                const uint32_t cq = __popc(alignbit(w1, w0, 2 * (r0 + q)) ^ F);
+                                if (cq < 5 && live && c < n_own && c >= from) {
                                     if (s0 == NONE_CAND) s0 = c; else if (s1 == NONE_CAND) s1 = c; else if (s2 == NONE_CAND) s2 = c;
                                 }
                             }
                         }
                     }
-                }
-                // reverse diagonals a = 16k + r: read1[i] against reverse_r2[a + i]
-#pragma unroll
-                for (int k = 0; k < NW; ++k) {
-                    if (16 * k >= wmax_r) break;
-#pragma unroll
-                    for (int r0 = 0; r0 < 16; r0 += 8) {
-                        uint32_t cnt[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) cnt[q] = __popc(alignbit(W2lo[k + 1], W2lo[k], 2 * (r0 + q)) ^ F1);
-                        const uint32_t best = min(min(min(cnt[0], cnt[1]), min(cnt[2], cnt[3])), min(min(cnt[4], cnt[5]), min(cnt[6], cnt[7])));
-                        if (__ballot(best < 5)) {
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const int a = 16 * k + r0 + q;
-                                const int c = nf + a;
-                                if (cnt[q] < 5 && live && a < nr && c >= from) {
-                                    if (s0 == NONE_CAND) s0 = c; else if (s1 == NONE_CAND) s1 = c; else if (s2 == NONE_CAND) s2 = c;
-                                }
-                            }
-                        }
-                    }
+                    w0 = w1;
                 }
                 PROF(4);
                 // exact verification of up to three survivors per lane, in order (util.py:177-184 / 200-207)
@@ -483,45 +475,46 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
                     const int c = v == 0 ? s0 : v == 1 ? s1 : s2;
                     const bool check = live && !found && c != NONE_CAND;
                     if (!__ballot(check)) break;
-                    const bool fwd = c < nf;
-                    const int off = fwd ? c : c - nf;
-                    const int QL = fwd ? min(len1 - off, len2) : min(len1, len2 - off);
-                    const uint32_t* mv = my + (fwd ? 0 : 2 * NW);      // moving stream: lo at mv[], e at mv[NW + ]
-                    const uint32_t* fx = my + (fwd ? 2 * NW : 0);      // fixed stream
-                    const int k = off >> 4;
-                    const uint32_t s = (uint32_t)(off & 15) * 2;
+                    const int QL = min(len_own - c, len_par);
+                    const int k = c >> 4;
+                    const uint32_t s = (uint32_t)(c & 15) * 2;
                     int tot = 0, c50 = 0;
+                    const int jmax = (wave_max_i(check ? QL : 0) + 15) >> 4;
                     if (check) {
-                        uint32_t lo0 = mv[k], e0 = mv[NW + k];
-#pragma unroll
-                        for (int j = 0; j < NW; ++j) {
-                            const uint32_t lo1 = (k + j + 1 < NW) ? mv[k + j + 1] : 0u, e1 = (k + j + 1 < NW) ? mv[NW + k + j + 1] : 0u;
-                            const uint32_t mm = mm_word(lo0, lo1, e0, e1, s, fx[j], fx[NW + j], min(max(QL - 16 * j, 0), 16));
+                        uint32_t lo0 = own[k], e0 = own[NW + k];
+#pragma nounroll
+                        for (int j = 0; j < jmax; ++j) {
+                            const uint32_t lo1 = (k + j + 1 < NW) ? own[k + j + 1] : 0u, e1 = (k + j + 1 < NW) ? own[NW + k + j + 1] : 0u;
+                            const uint32_t mm = mm_word(lo0, lo1, e0, e1, s, par[j], par[NW + j], min(max(QL - 16 * j, 0), 16));
                             const int pc = __popc(mm);
                             tot += pc;
                             if (j < 3) c50 += pc;
                             else if (j == 3) c50 += __popc(mm & 0xFu);
                             lo0 = lo1; e0 = e1;
                         }
-                        if (tot < 3 || (c50 < 3 && QL >= 52)) {
-                            found = true;
-                            offset = fwd ? off : -off;
-                            ovl = QL;
-                            dist = tot;
-                        }
+                        if (tot < 3 || (c50 < 3 && QL >= 52)) { found = true; f_off = c; f_len = QL; f_tot = tot; }
                     }
                 }
                 PROF(5);
                 // a lane whose three survivors all failed and that may have more continues after the third one
                 const bool more = live && !found && s2 != NONE_CAND;
                 if (more) from = s2 + 1;
-                if (live && !found && s2 == NONE_CAND) scan = false;   // exhausted: (0, 0, 0)
+                if (live && !found && s2 == NONE_CAND) scan = false;   // exhausted
                 if (!__ballot(more)) break;
             }
-
             PROF(5);
-            // ---- post-processing (preprocesser.py:516-617)
+            // ---- merge: an accepted forward offset wins over any reverse offset (util.py:170-212)
+            {
+                const bool x_found = xchg_pred(found);
+                const int x_off = xchg(f_off), x_len = xchg(f_len), x_tot = xchg(f_tot);
+                const bool fw = role ? x_found : found, rv = role ? found : x_found;
+                if (fw) { offset = role ? x_off : f_off; ovl = role ? x_len : f_len; dist = role ? x_tot : f_tot; }
+                else if (rv) { offset = -(role ? f_off : x_off); ovl = role ? f_len : x_len; dist = role ? f_tot : x_tot; }
+            }
+            // ---- post-processing (preprocesser.py:516-617), identical on both lanes of the pair
             const bool reached = valid && !defer && flag < 0;
+            bool adapter = false;
+            int walk_a = 0;
             if (reached) {
                 ovl0 = ovl;
                 if (offset < 0 && ovl > 30) {
@@ -530,43 +523,39 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
                     // diagonal just accepted, so it returns (0, overlap_len, diff) again; otherwise defer.
                     if (ovl != len2 + offset) defer = true;
                     else {
+                        adapter = true;
+                        walk_a = -offset;
                         c_adapter_base = -2 * offset; c_adapter_read = 1;
-                        // the accepted diagonal in the cut reads: read1[i] vs reverse_r2[|offset| + i]
-                        if (ovl < cfg.seq_len_req) { flag = AQC_BADLEN; len1 = ovl; len2 = ovl; offset = 0; ovl = 0; dist = 0; }
+                        len1 = ovl; len2 = ovl; offset = 0;
+                        if (len1 < cfg.seq_len_req) { flag = AQC_BADLEN; ovl = 0; dist = 0; }
                     }
                 }
             }
-            const bool adapter = reached && !defer && c_adapter_read;
-            const int walk_a = adapter ? -offset : 0;      // reverse diagonal of the walk in the adapter case
-            if (adapter && flag < 0) { len1 = ovl; len2 = ovl; offset = 0; }
             if (reached && !defer && flag < 0) {
                 dist_final = dist;
                 if (dist > 3) flag = AQC_BADDIFF;
-                else if (ovl > 30) {
-                    c_overlapped = 1;
-                }
+                else if (ovl > 30) c_overlapped = 1;
             }
-            // ---- correction walk (preprocesser.py:563-598): first `dist` mismatches of the tail-anchored diagonal
+            // ---- correction walk (preprocesser.py:563-598): first `dist` mismatches of the tail-anchored diagonal,
+            //      done by the lane whose stream moves on that diagonal (read 1 normally, reverse_r2 after an adapter cut)
 #if defined(AQC_ABLATE) && AQC_ABLATE == 5   /* no correction walk */
-            const bool walk = false;
+            walk_pair = false;
 #else
-            const bool walk = reached && !defer && flag < 0 && c_overlapped && dist > 0;
+            walk_pair = reached && !defer && flag < 0 && c_overlapped && dist > 0;
 #endif
-            if (__ballot(walk)) {
+            walker = walk_pair && role == (adapter ? 1 : 0);
+            if (__ballot(walker)) {
                 int p0 = -1, p1 = -1, p2 = -1, nfound = 0;
-                // coordinates in the ORIGINAL (pre adapter cut) normalised streams held in LDS
-                const bool fwd = !adapter;
-                const int off = fwd ? (len1 - ovl) : walk_a;
-                const uint32_t* mv = my + (fwd ? 0 : 2 * NW);
-                const uint32_t* fx = my + (fwd ? 2 * NW : 0);
+                const int off = adapter ? walk_a : (len1 - ovl);
                 const int k = off >> 4;
                 const uint32_t s = (uint32_t)(off & 15) * 2;
-                if (walk) {
-                    uint32_t lo0 = mv[k], e0 = mv[NW + k];
-#pragma unroll
-                    for (int j = 0; j < NW; ++j) {
-                        const uint32_t lo1 = (k + j + 1 < NW) ? mv[k + j + 1] : 0u, e1 = (k + j + 1 < NW) ? mv[NW + k + j + 1] : 0u;
-                        uint32_t mm = mm_word(lo0, lo1, e0, e1, s, fx[j], fx[NW + j], min(max(ovl - 16 * j, 0), 16));
+                const int jmax = (wave_max_i(walker ? ovl : 0) + 15) >> 4;
+                if (walker) {
+                    uint32_t lo0 = own[k], e0 = own[NW + k];
+#pragma nounroll
+                    for (int j = 0; j < jmax; ++j) {
+                        const uint32_t lo1 = (k + j + 1 < NW) ? own[k + j + 1] : 0u, e1 = (k + j + 1 < NW) ? own[NW + k + j + 1] : 0u;
+                        uint32_t mm = mm_word(lo0, lo1, e0, e1, s, par[j], par[NW + j], min(max(ovl - 16 * j, 0), 16));
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
                             if (mm != 0 && nfound < 3) {
@@ -582,22 +571,22 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
                 const int handled = min(nfound, dist);
                 // bytes of the (<= 3) handled mismatches straight from the canonical arenas: all loads issued
                 // before any is consumed, so the walk costs one memory round trip
-                const uint8_t* g1 = fb.seq1 + ((uint64_t)L.o1[lane] << 4) + a1;
-                const uint8_t* h1 = fb.qual1 + ((uint64_t)L.o1[lane] << 4) + a1;
-                const uint8_t* g2 = fb.seq2 + ((uint64_t)L.o2[lane] << 4) + a2;
-                const uint8_t* h2 = fb.qual2 + ((uint64_t)L.o2[lane] << 4) + a2;
+                const uint8_t* g1 = fb.seq1 + ((uint64_t)L.o1[p] << 4) + a1;
+                const uint8_t* h1 = fb.qual1 + ((uint64_t)L.o1[p] << 4) + a1;
+                const uint8_t* g2 = fb.seq2 + ((uint64_t)L.o2[p] << 4) + a2;
+                const uint8_t* h2 = fb.qual2 + ((uint64_t)L.o2[p] << 4) + a2;
                 uint8_t wb1[3], wb2[3], wq1[3], wq2[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int oo = q == 0 ? p0 : q == 1 ? p1 : p2;
-                    const bool use = walk && q < handled;
+                    const bool use = walker && q < handled;
                     const int i1 = use ? len1 - ovl + oo : 0, i2 = use ? len2 - 1 - oo : 0;
                     wb1[q] = g1[i1]; wb2[q] = g2[i2]; wq1[q] = h1[i1]; wq2[q] = h2[i2];
                 }
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int oo = q == 0 ? p0 : q == 1 ? p1 : p2;
-                    if (walk && q < handled) {
+                    if (walker && q < handled) {
                         const uint8_t bA = wb1[q], r2o = wb2[q];
                         const uint8_t bB = comp_strict(r2o);
                         const int qa = wq1[q], qb = wq2[q];
@@ -629,7 +618,7 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
                         }
                     }
                 }
-                if (walk) {
+                if (walker) {
                     if (handled == dist) { if (c_corrected > 0) c_read_corrected = 1; }
                     else {
                         flag = AQC_BADMISMATCH;
@@ -643,7 +632,8 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
         PROF(6);
 
         // ------------------------------------------------------------------ results + counters
-        const bool mine = valid && !defer;
+        // one lane per pair writes: the walker if there was a walk (it holds the edits), the read-1 lane otherwise
+        const bool mine = valid && !defer && (walk_pair ? walker : role == 0);
         if (mine) {
             // struct aqc_result (packed, 32 bytes) assembled in registers and written as two 16-byte stores
             auto e40 = [](const aqc_edit& e) {
@@ -660,71 +650,77 @@ __global__ __launch_bounds__(WPBT * WAVE) void fast_filter_overlap_kernel(FastBa
             hi.x = (uint32_t)q0; hi.y = (uint32_t)(q0 >> 32); hi.z = (uint32_t)q1; hi.w = (uint32_t)(q1 >> 32);
             uint4* out = reinterpret_cast<uint4*>(results + rec);
             out[0] = lo;
+#ifndef AQC_DEBUG_POLY
             out[1] = hi;
+#endif
         }
         const bool cnt = mine && accum;
-        {
-            unsigned long long* C = acc.counters;
-            const unsigned long long mcnt = __ballot(cnt);
-            if (mcnt) {
-                const int r2b = (PAIRED && cfg.count_r2_bases) ? 1 : 0;
-                const int tb = wave_sum(cnt ? L1 + r2b * L2 : 0);
-                const int gb = wave_sum(cnt && flag == AQC_GOOD ? len1 + r2b * len2 : 0);
-                const int ng = __popcll(__ballot(cnt && flag == AQC_GOOD));
-                if (lane == 0) {
-                    atomicAdd(&C[AQC_C_TOTAL_READS], (unsigned long long)__popcll(mcnt));
-                    atomicAdd(&C[AQC_C_TOTAL_BASES], (unsigned long long)tb);
-                    atomicAdd(&C[AQC_C_GOOD_READS], (unsigned long long)ng);
-                    atomicAdd(&C[AQC_C_GOOD_BASES], (unsigned long long)gb);
-                }
-                for (int f = 0; f < AQC_N_FLAGS; ++f) {
-                    const int k = __popcll(__ballot(cnt && flag == f));
-                    if (k && lane == 0) atomicAdd(&C[AQC_C_FLAG0 + f], (unsigned long long)k);
-                }
-                if (PAIRED) {
-                    if (cnt && ovl0 >= 0) atomicAdd(&acc.ovl_hist[ovl0], 1u);
-                    if (cnt && dist_final >= 0) atomicAdd(&acc.dist_hist[min(dist_final, AQC_QC_COLS - 1)], 1u);
-                    const int s_ab = wave_sum(cnt ? c_adapter_base : 0), s_ar = wave_sum(cnt ? c_adapter_read : 0);
-                    const int s_ov = wave_sum(cnt ? c_overlapped : 0), s_ol = wave_sum(cnt && c_overlapped ? ovl : 0);
-                    const int s_od = wave_sum(cnt && c_overlapped ? dist : 0);
-                    const int s_rc = wave_sum(cnt ? c_read_corrected : 0), s_bc = wave_sum(cnt ? c_corrected : 0);
-                    const int s_mk = wave_sum(cnt ? c_masked : 0), s_sk = wave_sum(cnt ? c_skipped : 0);
-                    if (lane == 0) {
-                        if (s_ar) { atomicAdd(&C[AQC_C_TRIMMED_ADAPTER_BASE], (unsigned long long)s_ab); atomicAdd(&C[AQC_C_TRIMMED_ADAPTER_READ], (unsigned long long)s_ar); }
-                        if (s_ov) {
-                            atomicAdd(&C[AQC_C_OVERLAPPED], (unsigned long long)s_ov);
-                            atomicAdd(&C[AQC_C_OVERLAP_LEN_SUM], (unsigned long long)s_ol);
-                            atomicAdd(&C[AQC_C_OVERLAP_BASE_SUM], (unsigned long long)(2 * s_ol));
-                            atomicAdd(&C[AQC_C_OVERLAP_BASE_ERR], (unsigned long long)s_od);
-                        }
-                        if (s_rc) atomicAdd(&C[AQC_C_READ_CORRECTED], (unsigned long long)s_rc);
-                        if (s_bc) atomicAdd(&C[AQC_C_BASE_CORRECTED], (unsigned long long)s_bc);
-                        if (s_mk) atomicAdd(&C[AQC_C_BASE_ZERO_QUAL_MASKED], (unsigned long long)(2 * s_mk));
-                        if (s_sk) atomicAdd(&C[AQC_C_BASE_SKIPPED_CORRECTION], (unsigned long long)(2 * s_sk));
-                    }
-                    if (cnt && em0 >= 0) atomicAdd(&C[AQC_C_ERR_MATRIX0 + em0], 1ull);
-                    if (cnt && em1 >= 0) atomicAdd(&C[AQC_C_ERR_MATRIX0 + em1], 1ull);
-                    if (cnt && em2 >= 0) atomicAdd(&C[AQC_C_ERR_MATRIX0 + em2], 1ull);
-                }
+        if (cnt) {
+            r_n += 1;
+            r_tb += (uint32_t)(L1 + r2b * L2);
+            if (flag == AQC_GOOD) { r_good += 1; r_gb += (uint32_t)(len1 + r2b * len2); }
+            else atomicAdd(&acc.counters[AQC_C_FLAG0 + flag], 1ull);
+            if (PAIRED) {
+                r_ab += (uint32_t)c_adapter_base; r_ar += (uint32_t)c_adapter_read;
+                if (c_overlapped) { r_ov += 1; r_ol += (uint32_t)ovl; r_od += (uint32_t)dist; }
+                r_rc += (uint32_t)c_read_corrected; r_bc += (uint32_t)c_corrected; r_mk += (uint32_t)c_masked; r_sk += (uint32_t)c_skipped;
+                if (em0 >= 0) atomicAdd(&acc.counters[AQC_C_ERR_MATRIX0 + em0], 1ull);
+                if (em1 >= 0) atomicAdd(&acc.counters[AQC_C_ERR_MATRIX0 + em1], 1ull);
+                if (em2 >= 0) atomicAdd(&acc.counters[AQC_C_ERR_MATRIX0 + em2], 1ull);
             }
+        }
+        if (PAIRED) {
+            // histograms (preprocesser.py:517,536): the dominant bins (no overlap, distance 0) are counted with a ballot
+            const unsigned long long z0 = __ballot(cnt && ovl0 == 0), d0 = __ballot(cnt && dist_final == 0);
+            if (lane == 0) {
+                if (z0) atomicAdd(&acc.ovl_hist[0], (unsigned int)__popcll(z0));
+                if (d0) atomicAdd(&acc.dist_hist[0], (unsigned int)__popcll(d0));
+            }
+            if (cnt && ovl0 > 0) atomicAdd(&acc.ovl_hist[ovl0], 1u);
+            if (cnt && dist_final > 0) atomicAdd(&acc.dist_hist[min(dist_final, AQC_QC_COLS - 1)], 1u);
         }
         __builtin_amdgcn_wave_barrier();
         PROF(7);
-        // ------------------------------------------------------------------ deferred pairs: general pipeline, one at a time
-        unsigned long long dmask = __ballot(valid && defer);
-        if (dmask) {
-            uint8_t* area = reinterpret_cast<uint8_t*>(&L.planes[0][0]);
-            const WaveLds w{area, area + LSTR, area + 2 * LSTR, area + 3 * LSTR, area + 4 * LSTR, L.rs[0], L.rs[1]};
-            while (dmask) {
-                const int l = __ffsll((long long)dmask) - 1;
-                dmask &= dmask - 1;
-                const uint64_t r2 = base + l;
-                process_record_wave(raw, r2, cfg, circ, w, results, acc, st, r2 < accum_limit);
-                __builtin_amdgcn_wave_barrier();
+        // ------------------------------------------------------------------ deferred pairs: queued for the general kernel
+        {
+            const unsigned long long dmask = __ballot(valid && defer && role == 0);
+            if (dmask) {
+                unsigned int slot0 = 0;
+                if (lane == 0) slot0 = atomicAdd(n_deferred, (unsigned int)__popcll(dmask));
+                slot0 = (unsigned int)__shfl((int)slot0, 0, WAVE);
+                if (valid && defer && role == 0)
+                    deferred[slot0 + (unsigned int)__popcll(dmask & ((1ull << lane) - 1ull))] = (uint32_t)(rec - 0);
             }
         }
         __builtin_amdgcn_wave_barrier();
         PROF(8);
+    }
+    // ---- reduce the per-lane running totals once
+    {
+        unsigned long long* C = acc.counters;
+        const uint32_t t_n = (uint32_t)wave_sum((int)r_n), t_good = (uint32_t)wave_sum((int)r_good);
+        const uint32_t t_tb = (uint32_t)wave_sum((int)r_tb), t_gb = (uint32_t)wave_sum((int)r_gb);
+        const uint32_t t_ab = (uint32_t)wave_sum((int)r_ab), t_ar = (uint32_t)wave_sum((int)r_ar);
+        const uint32_t t_ov = (uint32_t)wave_sum((int)r_ov), t_ol = (uint32_t)wave_sum((int)r_ol), t_od = (uint32_t)wave_sum((int)r_od);
+        const uint32_t t_rc = (uint32_t)wave_sum((int)r_rc), t_bc = (uint32_t)wave_sum((int)r_bc);
+        const uint32_t t_mk = (uint32_t)wave_sum((int)r_mk), t_sk = (uint32_t)wave_sum((int)r_sk);
+        if (lane == 0) {
+            atomicAdd(&C[AQC_C_TOTAL_READS], (unsigned long long)t_n);
+            atomicAdd(&C[AQC_C_TOTAL_BASES], (unsigned long long)t_tb);
+            atomicAdd(&C[AQC_C_GOOD_READS], (unsigned long long)t_good);
+            atomicAdd(&C[AQC_C_GOOD_BASES], (unsigned long long)t_gb);
+            atomicAdd(&C[AQC_C_FLAG0 + AQC_GOOD], (unsigned long long)t_good);
+            atomicAdd(&C[AQC_C_TRIMMED_ADAPTER_BASE], (unsigned long long)t_ab);
+            atomicAdd(&C[AQC_C_TRIMMED_ADAPTER_READ], (unsigned long long)t_ar);
+            atomicAdd(&C[AQC_C_OVERLAPPED], (unsigned long long)t_ov);
+            atomicAdd(&C[AQC_C_OVERLAP_LEN_SUM], (unsigned long long)t_ol);
+            atomicAdd(&C[AQC_C_OVERLAP_BASE_SUM], 2ull * t_ol);
+            atomicAdd(&C[AQC_C_OVERLAP_BASE_ERR], (unsigned long long)t_od);
+            atomicAdd(&C[AQC_C_READ_CORRECTED], (unsigned long long)t_rc);
+            atomicAdd(&C[AQC_C_BASE_CORRECTED], (unsigned long long)t_bc);
+            atomicAdd(&C[AQC_C_BASE_ZERO_QUAL_MASKED], 2ull * t_mk);
+            atomicAdd(&C[AQC_C_BASE_SKIPPED_CORRECTION], 2ull * t_sk);
+        }
     }
     PROF_FLUSH;
     __syncthreads();

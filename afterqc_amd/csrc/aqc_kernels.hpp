@@ -571,6 +571,30 @@ __global__ __launch_bounds__(BLOCK) void filter_overlap_kernel(DevBatch b, aqc_c
     flush_block_acc(acc, st);
 }
 
+// The same pipeline over an explicit list of record indices (the pairs the lane-per-read kernel deferred);
+// the list length lives in device memory, so the launch needs no host round trip.
+__global__ __launch_bounds__(BLOCK) void filter_overlap_list_kernel(DevBatch b, aqc_config cfg, DevCircles circ,
+                                                                    aqc_result* __restrict__ results, DevStats st,
+                                                                    uint64_t accum_limit, const uint32_t* __restrict__ list,
+                                                                    const unsigned int* __restrict__ n_list) {
+    __shared__ uint8_t lds[WPB][5][LSTR];
+    __shared__ uint8_t rsbuf[WPB][2][64];
+    __shared__ BlockAcc acc;
+    const unsigned int n = *n_list;
+    if (n == 0) return;
+    const int wave = threadIdx.x / WAVE;
+    for (int i = threadIdx.x; i < (int)(sizeof(BlockAcc) / 4); i += BLOCK) ((unsigned int*)&acc)[i] = 0;
+    __syncthreads();
+    const WaveLds w{lds[wave][0], lds[wave][1], lds[wave][2], lds[wave][3], lds[wave][4], rsbuf[wave][0], rsbuf[wave][1]};
+    const unsigned int nwaves = gridDim.x * WPB;
+    for (unsigned int i = blockIdx.x * WPB + wave; i < n; i += nwaves) {
+        const uint64_t rec = list[i];
+        process_record_wave(b, rec, cfg, circ, w, results, acc, st, rec < accum_limit);
+    }
+    __syncthreads();
+    flush_block_acc(acc, st);
+}
+
 // ------------------------------------------------------------------------------------------------
 // QualityControl.statRead (qualitycontrol.py:73-122): one wave per read, lane = cycle.
 // Block-private u32 accumulators in LDS, flushed with 64-bit global atomics at the end.
