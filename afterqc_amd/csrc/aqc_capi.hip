@@ -60,7 +60,9 @@ struct Slot {
     hipStream_t stream = nullptr;
     DevBuf seq1, qual1, off1, qoff1, len1, seq2, qual2, off2, qoff2, len2, aux[5], results;
     // canonical layout for the lane-per-pair kernel: 16-byte aligned records, offsets in 16-byte units
-    DevBuf cseq1, cqual1, cseq2, cqual2, co1, co2, deferred, n_deferred;
+    DevBuf cseq1, cqual1, cseq2, cqual2, co1, co2, deferred, n_deferred, walk_q, n_walk;
+    unsigned int walk_segs = 0;
+    uint64_t walk_seg_cap = 0;
     uint32_t* h_o16[2] = {nullptr, nullptr};   // pinned staging for the canonical offsets
     size_t h_o16_cap[2] = {0, 0};
     FastBatch fview{};
@@ -205,7 +207,7 @@ void aqc_destroy(aqc_ctx* c) {
     for (auto& s : c->slots) {
         DevBuf* bufs[] = {&s.seq1, &s.qual1, &s.off1, &s.qoff1, &s.len1, &s.seq2, &s.qual2, &s.off2, &s.qoff2, &s.len2,
                           &s.aux[0], &s.aux[1], &s.aux[2], &s.aux[3], &s.aux[4], &s.results,
-                          &s.cseq1, &s.cqual1, &s.cseq2, &s.cqual2, &s.co1, &s.co2, &s.deferred, &s.n_deferred};
+                          &s.cseq1, &s.cqual1, &s.cseq2, &s.cqual2, &s.co1, &s.co2, &s.deferred, &s.n_deferred, &s.walk_q, &s.n_walk};
         for (DevBuf* b : bufs) b->release();
         for (int k = 0; k < 2; k++)
             if (s.h_o16[k]) (void)hipHostFree(s.h_o16[k]);
@@ -383,7 +385,7 @@ static int canonicalize(aqc_ctx* c, Slot& s, int mate, const uint32_t* len, uint
         s.h_o16_cap[mate] = want;
     }
     uint32_t* o = s.h_o16[mate];
-    uint64_t acc = 0;
+    uint64_t acc = 4;     // 64 bytes of front padding: the correction walk reads up to 15 bytes before a read
     uint32_t mx = 0;
     for (uint64_t i = 0; i < n; i++) {
         o[i] = (uint32_t)acc;
@@ -396,6 +398,8 @@ static int canonicalize(aqc_ctx* c, Slot& s, int mate, const uint32_t* len, uint
     if (cseq.reserve(bytes) || cqual.reserve(bytes) || co.reserve(sizeof(uint32_t) * (n ? n : 1)))
         return fail(AQC_ERR_HIP, "hipMalloc failed");
     HIP_TRY(hipMemcpyAsync(co.p, o, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(hipMemsetAsync((uint8_t*)cseq.p, 'A', 64, s.stream));
+    HIP_TRY(hipMemsetAsync((uint8_t*)cqual.p, 0x7f, 64, s.stream));
     HIP_TRY(hipMemsetAsync((uint8_t*)cseq.p + (size_t)acc * 16, 'A', bytes - (size_t)acc * 16, s.stream));
     HIP_TRY(hipMemsetAsync((uint8_t*)cqual.p + (size_t)acc * 16, 0x7f, bytes - (size_t)acc * 16, s.stream));
     if (n) {

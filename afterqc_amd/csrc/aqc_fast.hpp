@@ -105,6 +105,15 @@ struct FastWaveLds {
     uint8_t stage[16 * NW + 16];
 };
 
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+
+// complement / ALL_BASES index of a byte KNOWN to be one of A,C,G,T,N (the fast path only sees such bytes):
+// index (c >> 1) & 7 is A=0 C=1 T=2 G=3 N=7
+__device__ __forceinline__ uint32_t comp_acgtn(uint32_t c) {
+    return __builtin_amdgcn_perm(0x4e000000u, 0x43414754u, (c >> 1) & 7u) & 0xffu;   // T G A C . . . N
+}
+__device__ __forceinline__ int base_idx_acgt(uint32_t c) { return (int)((0x3120u >> (((c >> 1) & 3u) * 4u)) & 0xfu); }   // A T C G -> 0 1 2 3
+
 // exchange a value with the partner lane (lane ^ 1): DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ int xchg(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
 // the partner lane's predicate, through a ballot (all lanes must call it)
@@ -414,9 +423,9 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         // ---- overlap (util.py:158-212) --------------------------------------------------------------
         int offset = 0, ovl = 0, dist = 0, ovl0 = -1, dist_final = -1, n_edits = 0;
         int c_adapter_base = 0, c_adapter_read = 0, c_overlapped = 0, c_corrected = 0, c_masked = 0, c_skipped = 0, c_read_corrected = 0;
-        int em0 = -1, em1 = -1, em2 = -1;
-        aqc_edit ed0 = {0, 0, 0, 0}, ed1 = {0, 0, 0, 0}, ed2 = {0, 0, 0, 0};
-        bool walker = false, walk_pair = false;
+        int em0 = -1, em1 = -1, em2 = -1, walk_a = 0;
+        unsigned long long E0 = 0, E1 = 0, E2 = 0;
+        bool walk_pair = false, walker = false;
 #ifdef AQC_DEBUG_POLY
         if (valid) reinterpret_cast<volatile uint8_t*>(results + rec)[28 + role] = dbg_byte;
 #endif
@@ -433,9 +442,10 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
 #if defined(AQC_ABLATE) && AQC_ABLATE == 3   /* no scan */
             scan = false;
 #endif
+            bool i_found_it = false;    // this lane's stream moves on the accepted diagonal
             int from = 0;               // first own candidate still to be examined
             bool found = false;
-            int f_off = 0, f_len = 0, f_tot = 0;
+            int f_off = 0, f_len = 0, f_tot = 0, f_p0 = 0, f_p1 = 0, f_p2 = 0;   // accepted candidate + its first mismatch columns
             const uint32_t F = par[0];                          // partner's first 16 bases
             while (true) {
                 const int wmax = wave_max_i(scan && !found ? n_own : 0);
@@ -478,21 +488,29 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                     const int QL = min(len_own - c, len_par);
                     const int k = c >> 4;
                     const uint32_t s = (uint32_t)(c & 15) * 2;
-                    int tot = 0, c50 = 0;
+                    int tot = 0, c50 = 0, vp0 = 0, vp1 = 0, vp2 = 0;
                     const int jmax = (wave_max_i(check ? QL : 0) + 15) >> 4;
                     if (check) {
                         uint32_t lo0 = own[k], e0 = own[NW + k];
+                        int rem = QL;
 #pragma nounroll
                         for (int j = 0; j < jmax; ++j) {
-                            const uint32_t lo1 = (k + j + 1 < NW) ? own[k + j + 1] : 0u, e1 = (k + j + 1 < NW) ? own[NW + k + j + 1] : 0u;
-                            const uint32_t mm = mm_word(lo0, lo1, e0, e1, s, par[j], par[NW + j], min(max(QL - 16 * j, 0), 16));
-                            const int pc = __popc(mm);
-                            tot += pc;
-                            if (j < 3) c50 += pc;
-                            else if (j == 3) c50 += __popc(mm & 0xFu);
+                            const bool in = k + j + 1 < NW;
+                            const uint32_t lo1 = in ? own[k + j + 1] : 0u, e1 = in ? own[NW + k + j + 1] : 0u;
+                            uint32_t mm = mm_word(lo0, lo1, e0, e1, s, par[j], par[NW + j], rem);
+                            if (j < 4) c50 += __popc(j < 3 ? mm : (mm & 0xFu));      // columns 0..49 (wave-uniform branch)
+                            // remember the columns of the first three mismatches: the correction walk needs them
+                            while (mm != 0 && tot < 3) {
+                                const int col = 16 * j + ((__ffs((int)mm) - 1) >> 1);
+                                if (tot == 0) vp0 = col; else if (tot == 1) vp1 = col; else vp2 = col;
+                                tot++;
+                                mm &= mm - 1;
+                            }
+                            tot += __popc(mm);
+                            rem = max(rem - 16, 0);
                             lo0 = lo1; e0 = e1;
                         }
-                        if (tot < 3 || (c50 < 3 && QL >= 52)) { found = true; f_off = c; f_len = QL; f_tot = tot; }
+                        if (tot < 3 || (c50 < 3 && QL >= 52)) { found = true; f_off = c; f_len = QL; f_tot = tot; f_p0 = vp0; f_p1 = vp1; f_p2 = vp2; }
                     }
                 }
                 PROF(5);
@@ -508,13 +526,12 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const bool x_found = xchg_pred(found);
                 const int x_off = xchg(f_off), x_len = xchg(f_len), x_tot = xchg(f_tot);
                 const bool fw = role ? x_found : found, rv = role ? found : x_found;
+                i_found_it = fw ? role == 0 : (rv && role == 1);
                 if (fw) { offset = role ? x_off : f_off; ovl = role ? x_len : f_len; dist = role ? x_tot : f_tot; }
                 else if (rv) { offset = -(role ? f_off : x_off); ovl = role ? f_len : x_len; dist = role ? f_tot : x_tot; }
             }
             // ---- post-processing (preprocesser.py:516-617), identical on both lanes of the pair
             const bool reached = valid && !defer && flag < 0;
-            bool adapter = false;
-            int walk_a = 0;
             if (reached) {
                 ovl0 = ovl;
                 if (offset < 0 && ovl > 30) {
@@ -523,9 +540,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                     // diagonal just accepted, so it returns (0, overlap_len, diff) again; otherwise defer.
                     if (ovl != len2 + offset) defer = true;
                     else {
-                        adapter = true;
-                        walk_a = -offset;
                         c_adapter_base = -2 * offset; c_adapter_read = 1;
+                        walk_a = -offset;
                         len1 = ovl; len2 = ovl; offset = 0;
                         if (len1 < cfg.seq_len_req) { flag = AQC_BADLEN; ovl = 0; dist = 0; }
                     }
@@ -536,96 +552,66 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 if (dist > 3) flag = AQC_BADDIFF;
                 else if (ovl > 30) c_overlapped = 1;
             }
-            // ---- correction walk (preprocesser.py:563-598): first `dist` mismatches of the tail-anchored diagonal,
-            //      done by the lane whose stream moves on that diagonal (read 1 normally, reverse_r2 after an adapter cut)
+            // ---- correction walk (preprocesser.py:563-598).  The walk is anchored at the tails: b1 = r1[len1 - ovl + o],
+            //      b2 = complement(r2[-o-1]).  Whenever overlap_len == len1 - offset (always after an adapter cut) those
+            //      are exactly the columns of the accepted diagonal, whose first three mismatches the verification
+            //      already located; otherwise (read 2 shorter than the rest of read 1) the pair is deferred.
 #if defined(AQC_ABLATE) && AQC_ABLATE == 5   /* no correction walk */
             walk_pair = false;
 #else
             walk_pair = reached && !defer && flag < 0 && c_overlapped && dist > 0;
 #endif
-            walker = walk_pair && role == (adapter ? 1 : 0);
+            if (walk_pair && !c_adapter_read && ovl != len1 - offset) { defer = true; walk_pair = false; }
+            walker = walk_pair && i_found_it;
             if (__ballot(walker)) {
-                int p0 = -1, p1 = -1, p2 = -1, nfound = 0;
-                const int off = adapter ? walk_a : (len1 - ovl);
-                const int k = off >> 4;
-                const uint32_t s = (uint32_t)(off & 15) * 2;
-                const int jmax = (wave_max_i(walker ? ovl : 0) + 15) >> 4;
-                if (walker) {
-                    uint32_t lo0 = own[k], e0 = own[NW + k];
-#pragma nounroll
-                    for (int j = 0; j < jmax; ++j) {
-                        const uint32_t lo1 = (k + j + 1 < NW) ? own[k + j + 1] : 0u, e1 = (k + j + 1 < NW) ? own[NW + k + j + 1] : 0u;
-                        uint32_t mm = mm_word(lo0, lo1, e0, e1, s, par[j], par[NW + j], min(max(ovl - 16 * j, 0), 16));
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) {
-                            if (mm != 0 && nfound < 3) {
-                                const int pos = 16 * j + ((__ffs((int)mm) - 1) >> 1);
-                                if (nfound == 0) p0 = pos; else if (nfound == 1) p1 = pos; else p2 = pos;
-                                nfound++;
-                                mm &= mm - 1;
-                            }
-                        }
-                        lo0 = lo1; e0 = e1;
-                    }
-                }
-                const int handled = min(nfound, dist);
-                // bytes of the (<= 3) handled mismatches straight from the canonical arenas: all loads issued
-                // before any is consumed, so the walk costs one memory round trip
-                const uint8_t* g1 = fb.seq1 + ((uint64_t)L.o1[p] << 4) + a1;
-                const uint8_t* h1 = fb.qual1 + ((uint64_t)L.o1[p] << 4) + a1;
-                const uint8_t* g2 = fb.seq2 + ((uint64_t)L.o2[p] << 4) + a2;
-                const uint8_t* h2 = fb.qual2 + ((uint64_t)L.o2[p] << 4) + a2;
-                uint8_t wb1[3], wb2[3], wq1[3], wq2[3];
+                // (<= 3 mismatches, all handled: the walk can never end short here, so BADMISMATCH cannot arise)
+                const int shift1 = c_adapter_read ? 0 : len1 - ovl;        // read-1 position of walk column o: shift1 + o
+                const int shift2 = c_adapter_read ? walk_a : 0;            // reverse_r2 position of column o
+                const uint32_t* s1w = pr;                                  // read-1 stream
+                const uint32_t* s2w = pr + 2 * NW;                         // reverse_r2 stream
+                // (lanes that do not walk still execute the loads below: keep their addresses inside the arenas)
+                const uint8_t* h1 = fb.qual1 + (walker ? ((uint64_t)L.o1[p] << 4) + a1 + (len1 - ovl) : 0);
+                const uint8_t* h2 = fb.qual2 + (walker ? ((uint64_t)L.o2[p] << 4) + a2 + (len2 - 1) : 64);
+                int wq1[3], wq2[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    const int oo = q == 0 ? p0 : q == 1 ? p1 : p2;
-                    const bool use = walker && q < handled;
-                    const int i1 = use ? len1 - ovl + oo : 0, i2 = use ? len2 - 1 - oo : 0;
-                    wb1[q] = g1[i1]; wb2[q] = g2[i2]; wq1[q] = h1[i1]; wq2[q] = h2[i2];
+                    const int oo = walker && q < dist ? (q == 0 ? f_p0 : q == 1 ? f_p1 : f_p2) : 0;
+                    wq1[q] = h1[oo]; wq2[q] = h2[-oo];
                 }
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    const int oo = q == 0 ? p0 : q == 1 ? p1 : p2;
-                    if (walker && q < handled) {
-                        const uint8_t bA = wb1[q], r2o = wb2[q];
-                        const uint8_t bB = comp_strict(r2o);
+                    if (walker && q < dist) {
+                        const int oo = q == 0 ? f_p0 : q == 1 ? f_p1 : f_p2;
+                        const int x1 = shift1 + oo, x2 = shift2 + oo;
+                        const uint32_t c1 = (s1w[x1 >> 4] >> (2 * (x1 & 15))) & 3u, n1 = (s1w[NW + (x1 >> 4)] >> (2 * (x1 & 15) + 1)) & 1u;
+                        const uint32_t c2 = (s2w[x2 >> 4] >> (2 * (x2 & 15))) & 3u, n2 = (s2w[NW + (x2 >> 4)] >> (2 * (x2 & 15) + 1)) & 1u;
+                        const uint32_t bA = n1 ? (uint32_t)'N' : ((0x47544341u >> (8 * c1)) & 0xffu);      // code -> A C T G
+                        const uint32_t bB = n2 ? (uint32_t)'N' : ((0x47544341u >> (8 * c2)) & 0xffu);      // = complement(r2 base)
+                        const uint32_t r2o = comp_acgtn(bB);
                         const int qa = wq1[q], qb = wq2[q];
-                        bool fixed = false;
+                        const bool r2_wrong = qa - 33 >= 30 && qb - 33 <= 14;     // trust read 1 (preprocesser.py:571)
+                        const bool r1_wrong = !r2_wrong && qb - 33 >= 30 && qa - 33 <= 14;   // trust read 2 (:579)
+                        const bool both_acgt = bA != 'N' && bB != 'N';
                         int em = -1;
-                        aqc_edit ed = {0, 0, 0, 0};
-                        bool have_edit = false;
-                        if (qa - 33 >= 30 && qb - 33 <= 14) {
-                            if (bA != 'N' && bB != 'N') em = base_idx(comp_strict(bA)) * 4 + base_idx(r2o);
-                            if (!cfg.no_correction) {
-                                ed = aqc_edit{(uint16_t)oo, AQC_EDIT_FIX_R2, comp_strict(bA), (uint8_t)qa};
-                                have_edit = true; c_corrected++; fixed = true;
-                            }
-                        } else if (qb - 33 >= 30 && qa - 33 <= 14) {
-                            if (bA != 'N' && bB != 'N') em = base_idx(bB) * 4 + base_idx(bA);
-                            if (!cfg.no_correction) {
-                                ed = aqc_edit{(uint16_t)oo, AQC_EDIT_FIX_R1, bB, (uint8_t)qb};
-                                have_edit = true; c_corrected++; fixed = true;
-                            }
-                        }
-                        if (!fixed) {
-                            if (cfg.mask_mismatch) { ed = aqc_edit{(uint16_t)oo, AQC_EDIT_MASK, 0, (uint8_t)'!'}; have_edit = true; c_masked++; }
-                            else c_skipped++;
-                        }
+                        if (r2_wrong && both_acgt) em = base_idx_acgt(comp_acgtn(bA)) * 4 + base_idx_acgt(r2o);
+                        if (r1_wrong && both_acgt) em = base_idx_acgt(bB) * 4 + base_idx_acgt(bA);
+                        const bool fix = (r2_wrong || r1_wrong) && !cfg.no_correction;
+                        const bool mask = !fix && cfg.mask_mismatch;
+                        const unsigned long long kind = fix ? (r2_wrong ? AQC_EDIT_FIX_R2 : AQC_EDIT_FIX_R1) : AQC_EDIT_MASK;
+                        const unsigned long long base = fix ? (r2_wrong ? comp_acgtn(bA) : bB) : 0u;
+                        const unsigned long long qual = fix ? (unsigned long long)(r2_wrong ? qa : qb) : (unsigned long long)'!';
+                        const unsigned long long e40 = (unsigned long long)oo | (kind << 16) | (base << 24) | (qual << 32);
+                        c_corrected += fix ? 1 : 0;
+                        c_masked += mask ? 1 : 0;
+                        c_skipped += (!fix && !mask) ? 1 : 0;
                         if (q == 0) em0 = em; else if (q == 1) em1 = em; else em2 = em;
-                        if (have_edit) {
-                            if (n_edits == 0) ed0 = ed; else if (n_edits == 1) ed1 = ed; else ed2 = ed;
+                        if (fix || mask) {
+                            if (n_edits == 0) E0 = e40; else if (n_edits == 1) E1 = e40; else E2 = e40;
                             n_edits++;
                         }
                     }
                 }
-                if (walker) {
-                    if (handled == dist) { if (c_corrected > 0) c_read_corrected = 1; }
-                    else {
-                        flag = AQC_BADMISMATCH;
-                        em0 = em1 = em2 = -1;
-                        c_corrected = c_masked = c_skipped = 0;
-                    }
-                }
+                if (walker && c_corrected > 0) c_read_corrected = 1;
             }
         }
         if (flag < 0) flag = AQC_GOOD;
@@ -636,11 +622,6 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         const bool mine = valid && !defer && (walk_pair ? walker : role == 0);
         if (mine) {
             // struct aqc_result (packed, 32 bytes) assembled in registers and written as two 16-byte stores
-            auto e40 = [](const aqc_edit& e) {
-                return (unsigned long long)e.o | ((unsigned long long)e.kind << 16) | ((unsigned long long)e.base << 24) |
-                       ((unsigned long long)e.qual << 32);
-            };
-            const unsigned long long E0 = e40(ed0), E1 = e40(ed1), E2 = e40(ed2);
             uint4 lo, hi;
             lo.x = (uint32_t)flag | ((uint32_t)n_edits << 8) | ((uint32_t)(a1 & 0xffff) << 16);
             lo.y = (uint32_t)(len1 & 0xffff) | ((uint32_t)(a2 & 0xffff) << 16);
@@ -650,9 +631,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             hi.x = (uint32_t)q0; hi.y = (uint32_t)(q0 >> 32); hi.z = (uint32_t)q1; hi.w = (uint32_t)(q1 >> 32);
             uint4* out = reinterpret_cast<uint4*>(results + rec);
             out[0] = lo;
-#ifndef AQC_DEBUG_POLY
             out[1] = hi;
-#endif
         }
         const bool cnt = mine && accum;
         if (cnt) {
