@@ -97,6 +97,7 @@ static hipEvent_t launch_event(Slot& s, int k, int which) {
 }
 
 constexpr uint64_t KMER_CAP = 1ull << 21;
+constexpr uint64_t DENSE_CAP = 1ull << 16;   // 4^8 pure A/C/G/T k-mers
 
 struct QcDev {
     unsigned long long* acc = nullptr;   // [QC_ROWS * QC_COLS]
@@ -222,7 +223,10 @@ void aqc_destroy(aqc_ctx* c) {
     (void)hipFree(c->counters); (void)hipFree(c->ovl_hist); (void)hipFree(c->dist_hist); (void)hipFree(c->status);
     for (int k = 0; k < 4; k++) {
         (void)hipFree(c->qc[k].acc);
-        if (c->qc[k].kt.keys) { (void)hipFree(c->qc[k].kt.keys); (void)hipFree(c->qc[k].kt.counts); (void)hipFree(c->qc[k].kt.order); }
+        if (c->qc[k].kt.keys) {
+            (void)hipFree(c->qc[k].kt.keys); (void)hipFree(c->qc[k].kt.counts); (void)hipFree(c->qc[k].kt.order);
+            (void)hipFree(c->qc[k].kt.dense_count); (void)hipFree(c->qc[k].kt.dense_first);
+        }
     }
     delete c;
 }
@@ -285,6 +289,8 @@ int aqc_reset_stats(aqc_ctx* c) {
             HIP_TRY(hipMemset(c->qc[k].kt.keys, 0, sizeof(unsigned long long) * KMER_CAP));
             HIP_TRY(hipMemset(c->qc[k].kt.counts, 0, sizeof(unsigned long long) * KMER_CAP));
             HIP_TRY(hipMemset(c->qc[k].kt.order, 0xff, sizeof(unsigned long long) * KMER_CAP));
+            HIP_TRY(hipMemset(c->qc[k].kt.dense_count, 0, sizeof(unsigned int) * DENSE_CAP));
+            HIP_TRY(hipMemset(c->qc[k].kt.dense_first, 0xff, sizeof(unsigned long long) * DENSE_CAP));
         }
     }
     return 0;
@@ -497,6 +503,10 @@ static int ensure_kmer(aqc_ctx* c, QcDev& q) {
     HIP_TRY(hipMemset(q.kt.counts, 0, sizeof(unsigned long long) * KMER_CAP));
     HIP_TRY(hipMemset(q.kt.order, 0xff, sizeof(unsigned long long) * KMER_CAP));
     q.kt.mask = KMER_CAP - 1;
+    HIP_TRY(hipMalloc((void**)&q.kt.dense_count, sizeof(unsigned int) * DENSE_CAP));
+    HIP_TRY(hipMalloc((void**)&q.kt.dense_first, sizeof(unsigned long long) * DENSE_CAP));
+    HIP_TRY(hipMemset(q.kt.dense_count, 0, sizeof(unsigned int) * DENSE_CAP));
+    HIP_TRY(hipMemset(q.kt.dense_first, 0xff, sizeof(unsigned long long) * DENSE_CAP));
     return 0;
 }
 
@@ -633,7 +643,7 @@ int aqc_get_kmers(aqc_ctx* c, int which, uint64_t* keys, int64_t* counts, uint64
     *n = 0;
     QcDev& q = c->qc[which];
     if (!q.kt.keys) return 0;
-    const uint64_t dcap = cap < KMER_CAP ? cap : KMER_CAP;
+    const uint64_t dcap = cap < KMER_CAP + DENSE_CAP ? cap : KMER_CAP + DENSE_CAP;
     unsigned long long *dk = nullptr, *dc = nullptr, *dord = nullptr, *dn = nullptr;
     HIP_TRY(hipMalloc((void**)&dk, 8 * (dcap + 1)));
     HIP_TRY(hipMalloc((void**)&dc, 8 * (dcap + 1)));
@@ -642,6 +652,8 @@ int aqc_get_kmers(aqc_ctx* c, int which, uint64_t* keys, int64_t* counts, uint64
     HIP_TRY(hipMemset(dn, 0, 8));
     hipLaunchKernelGGL(kmer_compact_kernel, dim3((unsigned)(KMER_CAP / 256)), dim3(256), 0, 0, q.kt, dk, dc, dord,
                        (unsigned long long)dcap, dn);
+    hipLaunchKernelGGL(kmer_compact_dense_kernel, dim3((unsigned)(DENSE_CAP / 256)), dim3(256), 0, 0, q.kt, c->cfg.qc_kmer, dk, dc,
+                       dord, (unsigned long long)dcap, dn);
     HIP_TRY(hipGetLastError());
     unsigned long long m = 0;
     HIP_TRY(hipMemcpy(&m, dn, 8, hipMemcpyDeviceToHost));

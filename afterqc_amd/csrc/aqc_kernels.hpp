@@ -601,11 +601,27 @@ __global__ __launch_bounds__(BLOCK) void filter_overlap_list_kernel(DevBatch b, 
 // k-mers go to an open-addressing table in HBM keyed by the k raw bytes (k <= 8).
 // ------------------------------------------------------------------------------------------------
 struct KmerTable {
+    // open-addressing table for k-mers containing anything but A,C,G,T (rare): keyed by the k raw bytes
     unsigned long long* keys;    // 0 = empty
     unsigned long long* counts;
     unsigned long long* order;   // min over 2*t (seen) / 2*t+1 (inserted as reverse complement)
     uint64_t mask;               // capacity - 1
+    // dense tables for pure A/C/G/T k-mers, 4^k entries.  Index = (bit-1 plane << k) | bit-0 plane of the
+    // per-base code (c >> 1) & 3 (A=0 C=1 T=2 G=3); base j of the k-mer sits at bit j of each plane.
+    unsigned int* dense_count;
+    unsigned long long* dense_first;   // smallest scan time t at which the k-mer was seen (~0 = never)
 };
+
+// reverse complement of a dense k-mer index: complement flips the code's high bit, the order of bases reverses
+__device__ __host__ inline uint32_t dense_rc(uint32_t idx, int k) {
+    const uint32_t m = (1u << k) - 1u;
+    uint32_t b0 = idx & m, b1 = (idx >> k) & m, r0 = 0, r1 = 0;
+    for (int j = 0; j < k; ++j) {
+        r0 |= ((b0 >> j) & 1u) << (k - 1 - j);
+        r1 |= ((b1 >> j) & 1u) << (k - 1 - j);
+    }
+    return ((~r1 & m) << k) | r0;
+}
 
 __device__ __forceinline__ uint64_t hash64(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
@@ -713,24 +729,52 @@ __global__ __launch_bounds__(BLOCK) void qc_stat_kernel(DevBatch b, int mate, ui
             atomicAdd(&scal[1], 1ull);
             if (len > kmer_len) atomicAdd(&scal[0], (unsigned long long)(len - kmer_len));
         }
-        // k-mers (qualitycontrol.py:113-122): i in range(seqlen - k)
+        // k-mers (qualitycontrol.py:113-122): i in range(seqlen - k).  Per 64-position chunk three ballots give the
+        // code bit planes and the "is A/C/G/T" plane; lane i reads its k-mer off them with two 64-bit shifts.
         const unsigned long long t0 = (order_base + k) * (unsigned long long)AQC_QC_COLS;
-        for (int i0 = 0; i0 < len - kmer_len; i0 += WAVE) {
-            const int i = i0 + lane;
-            if (i < len - kmer_len) {
-                unsigned long long key = 0, rkey = 0;
-                for (int j = 0; j < kmer_len; j++) {
-                    key |= (unsigned long long)s[i + j] << (8 * j);
-                    rkey |= (unsigned long long)comp_or_n(s[i + kmer_len - 1 - j]) << (8 * j);
+        const int nk = len - kmer_len;
+        if (nk > 0) {
+            const unsigned long long km = (1ull << kmer_len) - 1ull;
+            unsigned long long c0, c1, cv;
+            {
+                const uint8_t c = lane < len ? s[lane] : (uint8_t)0;
+                c0 = __ballot((c >> 1) & 1); c1 = __ballot((c >> 2) & 1);
+                cv = __ballot(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+            }
+            for (int i0 = 0; i0 < nk; i0 += WAVE) {
+                unsigned long long n0, n1, nv;
+                {
+                    const int x = i0 + WAVE + lane;
+                    const uint8_t c = x < len ? s[x] : (uint8_t)0;
+                    n0 = __ballot((c >> 1) & 1); n1 = __ballot((c >> 2) & 1);
+                    nv = __ballot(c == 'A' || c == 'C' || c == 'G' || c == 'T');
                 }
-                const long long h = kmer_slot(kt, key);
-                const long long hr = kmer_slot(kt, rkey);
-                if (h < 0 || hr < 0) atomicCAS(status, 0, AQC_ERR_UNSUPPORTED);
-                else {
-                    atomicAdd(&kt.counts[h], 1ull);
-                    atomicMin(&kt.order[h], 2 * (t0 + i));
-                    atomicMin(&kt.order[hr], 2 * (t0 + i) + 1);
+                const int i = i0 + lane;
+                if (i < nk) {
+                    const unsigned long long p0 = ((c0 >> lane) | (lane ? n0 << (64 - lane) : 0ull)) & km;
+                    const unsigned long long p1 = ((c1 >> lane) | (lane ? n1 << (64 - lane) : 0ull)) & km;
+                    const unsigned long long pv = ((cv >> lane) | (lane ? nv << (64 - lane) : 0ull)) & km;
+                    if (pv == km) {
+                        const uint32_t idx = (uint32_t)((p1 << kmer_len) | p0);
+                        atomicAdd(&kt.dense_count[idx], 1u);
+                        if (kt.dense_first[idx] > t0 + i) atomicMin(&kt.dense_first[idx], t0 + i);
+                    } else {
+                        unsigned long long key = 0, rkey = 0;
+                        for (int j = 0; j < kmer_len; j++) {
+                            key |= (unsigned long long)s[i + j] << (8 * j);
+                            rkey |= (unsigned long long)comp_or_n(s[i + kmer_len - 1 - j]) << (8 * j);
+                        }
+                        const long long h = kmer_slot(kt, key);
+                        const long long hr = kmer_slot(kt, rkey);
+                        if (h < 0 || hr < 0) atomicCAS(status, 0, AQC_ERR_UNSUPPORTED);
+                        else {
+                            atomicAdd(&kt.counts[h], 1ull);
+                            atomicMin(&kt.order[h], 2 * (t0 + i));
+                            atomicMin(&kt.order[hr], 2 * (t0 + i) + 1);
+                        }
+                    }
                 }
+                c0 = n0; c1 = n1; cv = nv;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -754,6 +798,27 @@ __global__ void kmer_compact_kernel(KmerTable kt, unsigned long long* keys, unsi
     if (key == 0) return;
     const unsigned long long w = atomicAdd(n_out, 1ull);
     if (w < cap) { keys[w] = key; counts[w] = kt.counts[i]; order[w] = kt.order[i]; }
+}
+
+// ... and the dense A/C/G/T table: k-mer X is in the dictionary iff X or its reverse complement was scanned;
+// its insertion rank is min(2 * first(X), 2 * first(rc X) + 1) (qualitycontrol.py:116-122)
+__global__ void kmer_compact_dense_kernel(KmerTable kt, int k, unsigned long long* keys, unsigned long long* counts,
+                                          unsigned long long* order, unsigned long long cap, unsigned long long* n_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << (2 * k))) return;
+    const unsigned long long f = kt.dense_first[i], fr = kt.dense_first[dense_rc(i, k)];
+    const unsigned long long never = ~0ull;
+    if (f == never && fr == never) return;
+    unsigned long long ord = never;
+    if (f != never) ord = 2 * f;
+    if (fr != never && 2 * fr + 1 < ord) ord = 2 * fr + 1;
+    unsigned long long key = 0;
+    for (int j = 0; j < k; ++j) {
+        const uint32_t code = ((i >> j) & 1u) | (((i >> (k + j)) & 1u) << 1);
+        key |= (unsigned long long)((0x47544341u >> (8 * code)) & 0xffu) << (8 * j);      // code -> A C T G
+    }
+    const unsigned long long w = atomicAdd(n_out, 1ull);
+    if (w < cap) { keys[w] = key; counts[w] = kt.dense_count[i]; order[w] = ord; }
 }
 
 // ------------------------------------------------------------------------------------------------
