@@ -102,7 +102,10 @@ constexpr uint64_t DENSE_CAP = 1ull << 16;   // 4^8 pure A/C/G/T k-mers
 struct QcDev {
     unsigned long long* acc = nullptr;   // [QC_ROWS * QC_COLS]
     KmerTable kt{};
-    unsigned long long order_base = 0;
+    // k-mer time keys: (epoch << 34 | global record index) * 1024 + position.  The epoch is bumped when a call
+    // goes back in the file (statFile's "stat the skipped reads afterwards", qualitycontrol.py:353-355), so the
+    // keys order insertions exactly like the reference's sequential dict and merge across GPUs with min().
+    unsigned long long last_end = 0, epoch = 0;
 };
 
 }  // namespace
@@ -284,7 +287,8 @@ int aqc_reset_stats(aqc_ctx* c) {
     HIP_TRY(hipMemset(c->status, 0, sizeof(int)));
     for (int k = 0; k < 4; k++) {
         HIP_TRY(hipMemset(c->qc[k].acc, 0, sizeof(unsigned long long) * AQC_QC_ROWS * AQC_QC_COLS));
-        c->qc[k].order_base = 0;
+        c->qc[k].last_end = 0;
+        c->qc[k].epoch = 0;
         if (c->qc[k].kt.keys) {
             HIP_TRY(hipMemset(c->qc[k].kt.keys, 0, sizeof(unsigned long long) * KMER_CAP));
             HIP_TRY(hipMemset(c->qc[k].kt.counts, 0, sizeof(unsigned long long) * KMER_CAP));
@@ -525,12 +529,15 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 0), s->stream));
     uint64_t blocks = (count + WPB - 1) / WPB;
     if (blocks > (uint64_t)c->n_cu * 2) blocks = (uint64_t)c->n_cu * 2;
+    const unsigned long long g0 = s->view.first_index + first;
+    if (g0 < q.last_end) q.epoch++;
+    q.last_end = g0 + count;
+    const unsigned long long order_base = (q.epoch << 34) | g0;
     hipLaunchKernelGGL(qc_stat_kernel, dim3((int)blocks), dim3(BLOCK), 0, s->stream, s->view, mate, first, count, post,
-                       (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, q.kt, q.order_base, c->status);
+                       (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, q.kt, order_base, c->status);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 1), s->stream));
     s->timed[AQC_K_QC_STAT] = !s->collecting;
-    q.order_base += count;
     return 0;
 }
 

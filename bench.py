@@ -75,8 +75,10 @@ def main():
     eng = capi.Engine(local_rank if world > 1 else 0, 1)
     eng.set_config(cfg)
     eng.reset_stats()
+    t_up = time.perf_counter()
     eng.upload(0, batch)          # inputs resident in HBM before the timed region
     eng.sync(0)
+    t_up = time.perf_counter() - t_up   # host -> HBM incl. canonicalisation; reported, never part of `value`
     n_qc = max(0, min(batch.n, args.qc_sample - 1))
 
     def step():
@@ -142,6 +144,8 @@ def main():
                      "qc_stat_kernel_ms": round(float(kms[capi.K_QC_STAT]), 4)},
         "good_reads_frac": round(float(counters[capi.C_GOOD_READS]) / max(1, float(counters[capi.C_TOTAL_READS])), 5),
         "gen_s": round(t_gen, 1),
+        "upload_s": round(t_up, 3),
+        "pcie_inclusive_mreads_s": round(2 * args.pairs / (t_up + elapsed / max(1, args.steps)) / 1e6, 1),
     }
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle, 1 core, bounded sample of the same workload

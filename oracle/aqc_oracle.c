@@ -505,7 +505,10 @@ static orc_kmer_entry* kmer_find(orc_qc* q, const uint8_t* k, int insert) {
     return &q->tab[h];
 }
 
-int orc_qc_stat_read(orc_qc* qc, const uint8_t* seq, const uint8_t* qual, int seqlen) {
+/* t0: global scan time of base 0 of this read (monotonic over the reference's sequential order); entries
+ * remember 2*(t0+i) when first scanned / 2*(t0+i)+1 when first inserted as a reverse complement, which is the
+ * dict insertion order and — unlike a local rank — can be merged across shards with min(). */
+int orc_qc_stat_read(orc_qc* qc, const uint8_t* seq, const uint8_t* qual, int seqlen, uint64_t t0) {
     if (seqlen > AQC_MAX_READ_LEN) return AQC_ERR_READ_TOO_LONG;
     if (seqlen < 5 && seqlen > 0) return AQC_ERR_ARG; /* seq[j+1] IndexError upstream (qualitycontrol.py:106-107) */
     int64_t* A = qc->acc;
@@ -540,13 +543,13 @@ int orc_qc_stat_read(orc_qc* qc, const uint8_t* seq, const uint8_t* qual, int se
         } else {
             e = kmer_find(qc, seq + i, 1);
             e->count = 1;
-            e->order = qc->n; /* insertion rank (n already counts this entry: ranks start at 1) */
+            e->order = 2 * (t0 + (uint64_t)i);
             uint8_t rc[16];
             orc_reverse_complement(seq + i, k, rc);
             if (!kmer_find(qc, rc, 0)) {
                 orc_kmer_entry* r = kmer_find(qc, rc, 1);
                 r->count = 0;
-                r->order = qc->n;
+                r->order = 2 * (t0 + (uint64_t)i) + 1;
             }
         }
     }
@@ -563,7 +566,7 @@ static int cmp_order(const void* a, const void* b) {
     return x->order < y->order ? -1 : (x->order > y->order ? 1 : 0);
 }
 
-uint64_t orc_qc_get_kmers(const orc_qc* qc, uint8_t* keys, int64_t* counts, uint64_t cap) {
+uint64_t orc_qc_get_kmers(const orc_qc* qc, uint8_t* keys, int64_t* counts, uint64_t* orders, uint64_t cap) {
     orc_kmer_entry* tmp = (orc_kmer_entry*)malloc(sizeof(orc_kmer_entry) * (qc->n + 1));
     uint64_t m = 0;
     for (uint64_t i = 0; i < qc->cap; i++) if (qc->tab[i].used) tmp[m++] = qc->tab[i];
@@ -572,6 +575,7 @@ uint64_t orc_qc_get_kmers(const orc_qc* qc, uint8_t* keys, int64_t* counts, uint
     for (uint64_t i = 0; i < w; i++) {
         memcpy(keys + i * (uint64_t)qc->kmer_len, tmp[i].key, (size_t)qc->kmer_len);
         counts[i] = tmp[i].count;
+        if (orders) orders[i] = tmp[i].order;
     }
     free(tmp);
     return m;

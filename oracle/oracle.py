@@ -44,12 +44,12 @@ def lib():
         L.orc_qc_new.restype = P
         L.orc_qc_free.argtypes = [P]
         L.orc_qc_free.restype = None
-        L.orc_qc_stat_read.argtypes = [P, P, P, C.c_int]
+        L.orc_qc_stat_read.argtypes = [P, P, P, C.c_int, C.c_uint64]
         L.orc_qc_get.argtypes = [P, P]
         L.orc_qc_get.restype = None
         L.orc_qc_kmer_count.argtypes = [P]
         L.orc_qc_kmer_count.restype = C.c_uint64
-        L.orc_qc_get_kmers.argtypes = [P, P, P, C.c_uint64]
+        L.orc_qc_get_kmers.argtypes = [P, P, P, P, C.c_uint64]
         L.orc_qc_get_kmers.restype = C.c_uint64
         _lib = L
     return _lib
@@ -109,6 +109,7 @@ class OracleQC:
     def __init__(self, kmer_len=8):
         self.k = kmer_len
         self.h = lib().orc_qc_new(kmer_len)
+        self._t = 0
 
     def __del__(self):
         try:
@@ -116,9 +117,13 @@ class OracleQC:
         except Exception:
             pass
 
-    def statRead(self, seq, qual):
+    def statRead(self, seq, qual, t0=None):
+        """t0: global scan time of the read's first base (see orc_qc_stat_read); default: sequential"""
         s, q = _b(seq), _b(qual)
-        rc = lib().orc_qc_stat_read(self.h, s, q, len(s))
+        if t0 is None:
+            t0 = self._t
+            self._t += 1024
+        rc = lib().orc_qc_stat_read(self.h, s, q, len(s), t0)
         if rc != 0:
             raise capi.AqcError(rc, "oracle statRead")
 
@@ -127,12 +132,15 @@ class OracleQC:
         lib().orc_qc_get(self.h, out.ctypes.data)
         return out
 
-    def kmers(self):
-        """[(kmer bytes, count)] in dict insertion order"""
+    def kmers(self, with_order=False):
+        """[(kmer bytes, count)] in dict insertion order (optionally with the time key of the insertion)"""
         n = lib().orc_qc_kmer_count(self.h)
         keys = np.zeros(max(1, n) * self.k, dtype=np.uint8)
         counts = np.zeros(max(1, n), dtype=np.int64)
-        lib().orc_qc_get_kmers(self.h, keys.ctypes.data, counts.ctypes.data, n)
+        orders = np.zeros(max(1, n), dtype=np.uint64)
+        lib().orc_qc_get_kmers(self.h, keys.ctypes.data, counts.ctypes.data, orders.ctypes.data, n)
+        if with_order:
+            return [(keys[i * self.k:(i + 1) * self.k].tobytes(), int(counts[i]), int(orders[i])) for i in range(n)]
         return [(keys[i * self.k:(i + 1) * self.k].tobytes(), int(counts[i])) for i in range(n)]
 
 
@@ -163,6 +171,8 @@ class OracleEngine:
         self.circles = list(circles)
 
     def reset_stats(self):
+        self._qc_last_end = [0] * 4
+        self._qc_epoch = [0] * 4
         self._counters = np.zeros(capi.N_COUNTERS, dtype=np.int64)
         self._ovl = np.zeros(capi.AQC_QC_COLS, dtype=np.int64)
         self._dist = np.zeros(capi.AQC_QC_COLS, dtype=np.int64)
@@ -192,6 +202,11 @@ class OracleEngine:
         qc = self._get_qc(which)
         r2 = mate == 1
         res = self.results[slot]
+        # same time keys as the device: epoch (bumped when a call goes back in the file) | global index | position
+        g0 = b.first_index + first
+        if g0 < self._qc_last_end[which]:
+            self._qc_epoch[which] += 1
+        self._qc_last_end[which] = g0 + count
         for i in range(first, min(first + count, b.n)):
             seq, qual = b.read2(i) if r2 else b.read1(i)
             if post:
@@ -199,7 +214,7 @@ class OracleEngine:
                 if r["flag"] != capi.GOOD:
                     continue
                 seq, qual = final_read(seq, qual, r, 2 if r2 else 1)
-            qc.statRead(seq, qual)
+            qc.statRead(seq, qual, (self._qc_epoch[which] << 44) | ((b.first_index + i) << 10))
 
     def fetch_results(self, slot):
         return self.results[slot].copy()
@@ -225,12 +240,12 @@ class OracleEngine:
         return self._get_qc(which).acc()
 
     def kmers(self, which, cap=1 << 22):
-        items = self._get_qc(which).kmers()
+        items = self._get_qc(which).kmers(with_order=True)
         keys = np.zeros(len(items), dtype=np.uint64)
-        for i, (kb, _) in enumerate(items):
+        for i, (kb, _, _) in enumerate(items):
             keys[i] = int.from_bytes(kb.ljust(8, b"\0"), "little")
-        counts = np.array([c for _, c in items], dtype=np.int64)
-        order = np.arange(1, len(items) + 1, dtype=np.uint64)
+        counts = np.array([c for _, c, _ in items], dtype=np.int64)
+        order = np.array([o for _, _, o in items], dtype=np.uint64)
         return keys, counts, order
 
     def overlap(self, batch):
