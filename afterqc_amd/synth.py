@@ -43,33 +43,48 @@ def render_names(lane, tile, x, y, mate):
             for i in range(len(lane))]
 
 
-def make_single(n, L=150, seed=1002):
-    """Config 2: single-end reads with N bursts, poly-X tails and low-quality stretches."""
-    rng = np.random.Generator(np.random.PCG64(seed))
+def _single_chunk(args):
+    (n, L, seedseq) = args
+    rng = np.random.Generator(np.random.PCG64(seedseq))
     seq = BASES[rng.integers(0, 4, (n, L), dtype=np.uint8)]
-    qual = _quals(rng, (n, L))
+    qual = _QUAL_LUT[rng.integers(0, 256, (n, L), dtype=np.uint8)]
     # per-base N
-    nmask = rng.random((n, L)) < 0.002
+    nmask = rng.integers(0, 65536, (n, L), dtype=np.uint16) < 131
     # 0.5 % of reads with 8-20 N
-    burst = np.nonzero(rng.random(n) < 0.005)[0]
-    for r in burst:
-        k = int(rng.integers(8, 21))
-        nmask[r, rng.choice(L, k, replace=False)] = True
+    for r in np.nonzero(rng.random(n) < 0.005)[0]:
+        nmask[r, rng.choice(L, int(rng.integers(8, 21)), replace=False)] = True
     seq[nmask] = ord("N")
     qual[nmask] = ord("#")
     # 1 % poly-G / poly-A tails of 35-80
-    tails = np.nonzero(rng.random(n) < 0.01)[0]
-    for r in tails:
-        k = int(rng.integers(35, 81))
+    for r in np.nonzero(rng.random(n) < 0.01)[0]:
+        k = int(rng.integers(35, min(81, L)))
         seq[r, L - k:] = ord("G") if rng.random() < 0.7 else ord("A")
     # 2 % of reads with 61-100 low quality bases
-    lows = np.nonzero(rng.random(n) < 0.02)[0]
-    for r in lows:
-        k = int(rng.integers(61, 101))
+    for r in np.nonzero(rng.random(n) < 0.02)[0]:
+        k = int(rng.integers(min(61, L // 2), min(101, L)))
         qual[r, rng.choice(L, k, replace=False)] = ord("#")
-    lens = np.full(n, L, dtype=np.uint32)
-    meta = make_names(rng, n)
-    return dict(seq1=seq, qual1=qual, len1=lens, meta=meta)
+    return seq, qual, make_names(rng, n)
+
+
+def make_single(n, L=150, seed=1002, chunk=250_000, workers=None):
+    """Config 2: single-end reads with N bursts, poly-X tails and low-quality stretches
+    (independently seeded chunks, generated in parallel like make_pairs)."""
+    sizes = [min(chunk, n - a) for a in range(0, n, chunk)]
+    seeds = np.random.SeedSequence(seed).spawn(len(sizes))
+    jobs = [(m, L, sq) for m, sq in zip(sizes, seeds)]
+    if len(jobs) > 1 and (workers is None or workers > 1):
+        import concurrent.futures as cf
+        import multiprocessing as mp
+        import os
+        nw = min(len(jobs), workers or os.cpu_count() or 1)
+        with cf.ProcessPoolExecutor(max_workers=nw, mp_context=mp.get_context("fork")) as ex:
+            parts = list(ex.map(_single_chunk, jobs))
+    else:
+        parts = [_single_chunk(jb) for jb in jobs]
+    seq = parts[0][0] if len(parts) == 1 else np.concatenate([p[0] for p in parts])
+    qual = parts[0][1] if len(parts) == 1 else np.concatenate([p[1] for p in parts])
+    meta = tuple(np.concatenate([p[2][i] for p in parts]) for i in range(4))
+    return dict(seq1=seq, qual1=qual, len1=np.full(n, L, dtype=np.uint32), meta=meta)
 
 
 def _pairs_chunk(args):

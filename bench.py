@@ -39,6 +39,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=5_000_000, help="pairs per GPU (default: config 3 = 10 M reads)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs timed on the CPU baseline (0 = skip)")
     ap.add_argument("--qc-sample", type=int, default=200_000)
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5"],
+                    help="config3 (default, the metric's workload): PE 2x150; config2: SE 1x150 filter+trim only; "
+                         "config5-like: PE 2x250 (no barcode/gzip) — the non-default ones are for DESIGN.md numbers")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -52,8 +55,15 @@ def main():
     # ---- workload: seed 1003 (+rank: independent shards).  Generated with forked numpy workers, so it
     # happens BEFORE torch / the HIP runtime are loaded into this process.
     t_gen = time.time()
-    d = synth.make_pairs(args.pairs, L, seed=1003 + rank, workers=max(1, (os.cpu_count() or 8) // max(1, world)))
-    batch = capi.Batch.from_matrices(d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
+    nworkers = max(1, (os.cpu_count() or 8) // max(1, world))
+    paired = args.workload != "config2"
+    RL = 250 if args.workload == "config5" else L
+    if paired:
+        d = synth.make_pairs(args.pairs, RL, seed=(1003 if RL == L else 1005) + rank, workers=nworkers)
+        batch = capi.Batch.from_matrices(d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
+    else:
+        d = synth.make_single(2 * args.pairs, RL, seed=1002 + rank, workers=nworkers)
+        batch = capi.Batch.from_matrices(d["seq1"], d["qual1"], d["len1"])
     t_gen = time.time() - t_gen
 
     import torch  # plumbing only (barrier / max-over-ranks); loaded before libafterqc_hip.so so both share one HIP runtime
@@ -64,8 +74,8 @@ def main():
         dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
 
     cfg = capi.Config()
-    cfg.paired = 1
-    cfg.trim_front = cfg.trim_tail = cfg.trim_front2 = cfg.trim_tail2 = 0      # config 3: defaults except -f 0 -t 0
+    cfg.paired = 1 if paired else 0
+    cfg.trim_front = cfg.trim_tail = cfg.trim_front2 = cfg.trim_tail2 = 0 if paired else 5   # config 3: -f 0 -t 0; config 2: -f 5 -t 5
     cfg.seq_len_req, cfg.poly_size_limit, cfg.allow_mismatch_in_poly = 35, 35, 2
     cfg.qualified_quality_phred, cfg.unqualified_base_limit, cfg.n_base_limit = 15, 60, 5
     cfg.barcode_length = 12
@@ -85,7 +95,8 @@ def main():
         eng.run(0)
         if n_qc:
             eng.qc_stat(0, capi.QC_R1_POST, 0, 0, n_qc, 1)
-            eng.qc_stat(0, capi.QC_R2_POST, 1, 0, n_qc, 1)
+            if paired:
+                eng.qc_stat(0, capi.QC_R2_POST, 1, 0, n_qc, 1)
 
     def barrier():
         eng.sync(0)
@@ -114,17 +125,19 @@ def main():
 
     ms_per_step = 1000.0 * elapsed / max(1, args.steps)
     reads_total = 2 * args.pairs * world
+    records = batch.n
+    bytes_per_record = (4 * RL + 56) if paired else (2 * RL + 20)
     value = reads_total / (elapsed / max(1, args.steps)) / 1e6
 
     k_ms = float(kms[capi.K_FILTER_OVERLAP])
-    achieved = args.pairs * BYTES_PER_PAIR / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    achieved = records * bytes_per_record / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("pairs") == args.pairs:
+            if tj.get("pairs") == args.pairs and args.workload == "config3":
                 traffic = tj.get("bytes_per_launch")
         except Exception:
             traffic = None
@@ -133,14 +146,15 @@ def main():
         "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "config3: %d synthetic PE 2x150 bp pairs per GPU (%.1f M reads), seed 1003+rank, overlap ~N(30,8), "
-                               "3%% adapter read-through, defaults with -f 0 -t 0, qc_sample %d; inputs resident in HBM"
-                               % (args.pairs, 2 * args.pairs / 1e6, args.qc_sample),
-                   "pairs_per_gpu": args.pairs, "read_len": L, "parallelism": "independent shards x%d" % world},
+        "config": {"workload": ("config3: %d synthetic PE 2x150 bp pairs per GPU (%.1f M reads), seed 1003+rank, overlap ~N(30,8), "
+                                "3%% adapter read-through, defaults with -f 0 -t 0, qc_sample %d; inputs resident in HBM"
+                                % (args.pairs, 2 * args.pairs / 1e6, args.qc_sample)) if args.workload == "config3" else
+                               ("%s: %d records of length %d per GPU, qc_sample %d; inputs resident in HBM" % (args.workload, records, RL, args.qc_sample)),
+                   "pairs_per_gpu": args.pairs, "read_len": RL, "parallelism": "independent shards x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "filter_overlap_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "kernel_ms": round(k_ms, 4), "launches": int(klaunch[capi.K_FILTER_OVERLAP]),
-                     "algorithmic_bytes_per_launch": args.pairs * BYTES_PER_PAIR,
+                     "algorithmic_bytes_per_launch": records * bytes_per_record,
                      "qc_stat_kernel_ms": round(float(kms[capi.K_QC_STAT]), 4)},
         "good_reads_frac": round(float(counters[capi.C_GOOD_READS]) / max(1, float(counters[capi.C_TOTAL_READS])), 5),
         "gen_s": round(t_gen, 1),
@@ -149,7 +163,7 @@ def main():
     }
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle, 1 core, bounded sample of the same workload
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and paired:
         from oracle import oracle
         m = min(args.cpu_sample, args.pairs)
         sub = capi.Batch.from_matrices(d["seq1"][:m], d["qual1"][:m], d["len1"][:m], d["seq2"][:m], d["qual2"][:m], d["len2"][:m])
