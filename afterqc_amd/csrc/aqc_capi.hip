@@ -68,6 +68,7 @@ struct Slot {
     FastBatch fview{};
     bool has_canonical = false;
     uint32_t max_len = 0;
+    uint32_t raw_max_len = 0;      // longest read of the slot (both mates), 0 = unknown
     DevBatch view{};
     uint64_t n = 0;
     bool paired = false, ran = false, same_arena1 = false, same_arena2 = false;
@@ -97,7 +98,7 @@ static hipEvent_t launch_event(Slot& s, int k, int which) {
 }
 
 constexpr uint64_t KMER_CAP = 1ull << 21;
-constexpr uint64_t DENSE_CAP = 1ull << 16;   // 4^8 pure A/C/G/T k-mers
+constexpr uint64_t DENSE_CAP = (uint64_t)N_XCD * DENSE_ENTRIES;   // 4^8 pure A/C/G/T k-mers, one copy per XCD
 
 struct QcDev {
     unsigned long long* acc = nullptr;   // [QC_ROWS * QC_COLS]
@@ -118,6 +119,7 @@ struct aqc_ctx {
     aqc_config cfg{};
     bool has_cfg = false;
     DevBuf circ[5];
+    DevBuf kmer_partial;          // per-round u16 count slices of kmer_count_kernel
     DevCircles circles{};
     unsigned long long *counters = nullptr, *ovl_hist = nullptr, *dist_hist = nullptr;
     int* status = nullptr;
@@ -189,6 +191,7 @@ int aqc_create(int device, int n_slots, aqc_ctx** out) {
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char* fg = getenv("AQC_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
+    HIP_TRY(hipFuncSetAttribute((const void*)kmer_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_ENTRIES * 2));
     for (auto& s : c->slots) {
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         for (int k = 0; k < AQC_N_KERNELS; k++)
@@ -223,6 +226,7 @@ void aqc_destroy(aqc_ctx* c) {
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     for (auto& b : c->circ) b.release();
+    c->kmer_partial.release();
     (void)hipFree(c->counters); (void)hipFree(c->ovl_hist); (void)hipFree(c->dist_hist); (void)hipFree(c->status);
     for (int k = 0; k < 4; k++) {
         (void)hipFree(c->qc[k].acc);
@@ -297,6 +301,7 @@ int aqc_reset_stats(aqc_ctx* c) {
             HIP_TRY(hipMemset(c->qc[k].kt.dense_first, 0xff, sizeof(unsigned long long) * DENSE_CAP));
         }
     }
+    HIP_TRY(hipDeviceSynchronize());   // (non-blocking slot streams do not wait for the null stream)
     return 0;
 }
 
@@ -366,6 +371,12 @@ static int fill_slot(aqc_ctx* c, Slot& s, const aqc_batch* b, bool need_qual, bo
         v.aux_ok = (const uint8_t*)s.aux[4].p;
     }
     if (s.results.reserve(sizeof(aqc_result) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    uint32_t mx = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (b->len1[i] > mx) mx = b->len1[i];
+        if (paired && b->len2[i] > mx) mx = b->len2[i];
+    }
+    s.raw_max_len = mx;
     s.view = v;
     s.n = n;
     s.paired = paired;
@@ -511,6 +522,8 @@ static int ensure_kmer(aqc_ctx* c, QcDev& q) {
     HIP_TRY(hipMalloc((void**)&q.kt.dense_first, sizeof(unsigned long long) * DENSE_CAP));
     HIP_TRY(hipMemset(q.kt.dense_count, 0, sizeof(unsigned int) * DENSE_CAP));
     HIP_TRY(hipMemset(q.kt.dense_first, 0xff, sizeof(unsigned long long) * DENSE_CAP));
+    // the slot streams are non-blocking: make sure the fills have landed before any kernel can touch the tables
+    HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
 
@@ -527,14 +540,43 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
     QcDev& q = c->qc[which];
     if ((rc = ensure_kmer(c, q))) return rc;
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 0), s->stream));
+    // LDS sized by the longest read of the slot: many resident workgroups for short reads
+    const uint32_t mx = s->raw_max_len ? s->raw_max_len : AQC_MAX_READ_LEN;
+    int cols = (int)((mx + 63) / 64 * 64);
+    if (cols > AQC_QC_COLS) cols = AQC_QC_COLS;
+    const size_t lds = sizeof(unsigned int) * (size_t)(QC_LDS_ROWS + 1) * cols + 16 + (size_t)WPB * 2 * (cols + 16);
+    uint64_t per_cu = (150 * 1024) / lds;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
     uint64_t blocks = (count + WPB - 1) / WPB;
-    if (blocks > (uint64_t)c->n_cu * 2) blocks = (uint64_t)c->n_cu * 2;
+    if (blocks > (uint64_t)c->n_cu * per_cu) blocks = (uint64_t)c->n_cu * per_cu;
     const unsigned long long g0 = s->view.first_index + first;
     if (g0 < q.last_end) q.epoch++;
     q.last_end = g0 + count;
     const unsigned long long order_base = (q.epoch << 34) | g0;
-    hipLaunchKernelGGL(qc_stat_kernel, dim3((int)blocks), dim3(BLOCK), 0, s->stream, s->view, mate, first, count, post,
-                       (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, q.kt, order_base, c->status);
+    hipLaunchKernelGGL(qc_stat_kernel, dim3((int)blocks), dim3(BLOCK), lds, s->stream, s->view, mate, first, count, post,
+                       (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, c->status, cols);
+    // k-mer dictionary: LDS-resident u16 counters, rounds of <= 65535 k-mers per workgroup, slices reduced afterwards
+    {
+        const uint32_t per_read = mx > (uint32_t)c->cfg.qc_kmer ? mx - (uint32_t)c->cfg.qc_kmer : 1;
+        uint32_t rpr = 65535u / per_read;
+        if (rpr < 1) rpr = 1;
+        const uint64_t max_rounds = 512;                       // 64 MiB of slices at most per launch
+        uint64_t done = 0;
+        while (done < count) {
+            uint64_t chunk = count - done;
+            if (chunk > max_rounds * rpr) chunk = max_rounds * rpr;
+            const uint32_t n_rounds = (uint32_t)((chunk + rpr - 1) / rpr);
+            if (c->kmer_partial.reserve((size_t)n_rounds * DENSE_ENTRIES * sizeof(uint16_t))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+            unsigned kb = n_rounds < (unsigned)c->n_cu ? n_rounds : (unsigned)c->n_cu;
+            hipLaunchKernelGGL(kmer_count_kernel, dim3(kb), dim3(KMER_BLOCK), DENSE_ENTRIES * 2, s->stream, s->view, mate, first + done,
+                               chunk, post, (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.kt, order_base + done,
+                               (uint16_t*)c->kmer_partial.p, rpr, n_rounds, c->status);
+            hipLaunchKernelGGL(kmer_reduce_kernel, dim3(DENSE_ENTRIES / 256), dim3(256), 0, s->stream,
+                               (const uint16_t*)c->kmer_partial.p, n_rounds, q.kt.dense_count);
+            done += chunk;
+        }
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 1), s->stream));
     s->timed[AQC_K_QC_STAT] = !s->collecting;
@@ -659,7 +701,7 @@ int aqc_get_kmers(aqc_ctx* c, int which, uint64_t* keys, int64_t* counts, uint64
     HIP_TRY(hipMemset(dn, 0, 8));
     hipLaunchKernelGGL(kmer_compact_kernel, dim3((unsigned)(KMER_CAP / 256)), dim3(256), 0, 0, q.kt, dk, dc, dord,
                        (unsigned long long)dcap, dn);
-    hipLaunchKernelGGL(kmer_compact_dense_kernel, dim3((unsigned)(DENSE_CAP / 256)), dim3(256), 0, 0, q.kt, c->cfg.qc_kmer, dk, dc,
+    hipLaunchKernelGGL(kmer_compact_dense_kernel, dim3((unsigned)(DENSE_ENTRIES / 256)), dim3(256), 0, 0, q.kt, c->cfg.qc_kmer, dk, dc,
                        dord, (unsigned long long)dcap, dn);
     HIP_TRY(hipGetLastError());
     unsigned long long m = 0;

@@ -286,6 +286,28 @@ __device__ __forceinline__ void stage(uint8_t* dst, const uint8_t* src, int len)
     for (int i = lane_id(); i < len; i += WAVE) dst[i] = src[i];
 }
 
+// stage two strings of the same length at once: all loads are issued before the first LDS store, so a read of up
+// to 256 bytes costs ONE memory round trip instead of one per 64 bytes and string
+__device__ __forceinline__ void stage2(uint8_t* d0, const uint8_t* s0, uint8_t* d1, const uint8_t* s1, int len) {
+    const int lane = lane_id();
+    if (len <= 4 * WAVE) {
+        uint8_t a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + WAVE * j;
+            a[j] = i < len ? s0[i] : (uint8_t)0;
+            b[j] = i < len ? s1[i] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = lane + WAVE * j;
+            if (i < len) { d0[i] = a[j]; d1[i] = b[j]; }
+        }
+    } else {
+        for (int i = lane; i < len; i += WAVE) { d0[i] = s0[i]; d1[i] = s1[i]; }
+    }
+}
+
 struct BlockAcc {
     unsigned long long counters[AQC_N_COUNTERS];
     unsigned int ovl_hist[AQC_QC_COLS];
@@ -608,9 +630,18 @@ struct KmerTable {
     uint64_t mask;               // capacity - 1
     // dense tables for pure A/C/G/T k-mers, 4^k entries.  Index = (bit-1 plane << k) | bit-0 plane of the
     // per-base code (c >> 1) & 3 (A=0 C=1 T=2 G=3); base j of the k-mer sits at bit j of each plane.
-    unsigned int* dense_count;
-    unsigned long long* dense_first;   // smallest scan time t at which the k-mer was seen (~0 = never)
+    // One copy of the dense tables PER XCD (8 on MI355X): a wave updates the copy of the XCD it runs on with
+    // atomics that execute in that XCD's L2 (workgroup scope is enough: every accessor of a copy shares the L2),
+    // instead of device-scope atomics that have to travel to the memory side.  Copies are summed / min-ed when
+    // the dictionary is read back.
+    unsigned int* dense_count;         // [N_XCD][4^k]
+    unsigned long long* dense_first;   // [N_XCD][4^k] smallest scan time t at which the k-mer was seen (~0 = never)
 };
+constexpr int N_XCD = 8;
+constexpr uint32_t DENSE_ENTRIES = 1u << 16;   // 4^8
+
+// id of the XCD this wave runs on (HW_REG_XCC_ID, bits 3:0)
+__device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (N_XCD - 1); }
 
 // reverse complement of a dense k-mer index: complement flips the code's high bit, the order of bases reverses
 __device__ __host__ inline uint32_t dense_rc(uint32_t idx, int k) {
@@ -647,20 +678,21 @@ constexpr int QC_LDS_ROWS = 11;   // TOTAL_NUM .. DISCONTINUITY (gc histogram ke
 __global__ __launch_bounds__(BLOCK) void qc_stat_kernel(DevBatch b, int mate, uint64_t first, uint64_t count, int post,
                                                         const aqc_result* __restrict__ results, int kmer_len,
                                                         unsigned long long* __restrict__ qc /* [QC_ROWS*QC_COLS] */,
-                                                        KmerTable kt, unsigned long long order_base, int* status) {
-    __shared__ unsigned int accs[QC_LDS_ROWS][AQC_QC_COLS];
-    __shared__ unsigned int gch[AQC_QC_COLS];
-    __shared__ uint8_t sbuf[WPB][LSTR + 16];
-    __shared__ uint8_t qbuf[WPB][LSTR + 16];
-    __shared__ unsigned long long scal[2];
+                                                        int* status, int cols) {
+    // dynamic LDS, sized by the longest read of the batch (cols = multiple of 64 <= 1024) so that short reads get
+    // many resident workgroups: [QC_LDS_ROWS][cols] + gc histogram [cols] u32, scalars, 2 staging strings per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned int qc_smem[];
+    unsigned int* const accs = qc_smem;                               // accs[row * cols + i]
+    unsigned int* const gch = qc_smem + QC_LDS_ROWS * cols;
+    unsigned long long* const scal = reinterpret_cast<unsigned long long*>(gch + cols);
+    uint8_t* const strings = reinterpret_cast<uint8_t*>(scal + 2);
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
-    for (int i = threadIdx.x; i < QC_LDS_ROWS * AQC_QC_COLS; i += BLOCK) (&accs[0][0])[i] = 0;
-    for (int i = threadIdx.x; i < AQC_QC_COLS; i += BLOCK) gch[i] = 0;
+    for (int i = threadIdx.x; i < (QC_LDS_ROWS + 1) * cols; i += BLOCK) qc_smem[i] = 0;
     if (threadIdx.x < 2) scal[threadIdx.x] = 0;
     __syncthreads();
-    uint8_t* s = sbuf[wave];
-    uint8_t* q = qbuf[wave];
+    uint8_t* s = strings + (size_t)(2 * wave) * (cols + 16);
+    uint8_t* q = s + (cols + 16);
     const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
     for (uint64_t k = (uint64_t)blockIdx.x * WPB + wave; k < count; k += nwaves) {
         const uint64_t rec = first + k;
@@ -682,10 +714,9 @@ __global__ __launch_bounds__(BLOCK) void qc_stat_kernel(DevBatch b, int mate, ui
             st = mate == 0 ? r.start1 : r.start2;
             len = mate == 0 ? r.len1 : r.len2;
         }
-        if (len > AQC_MAX_READ_LEN) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_READ_TOO_LONG); continue; }
+        if (len > AQC_MAX_READ_LEN || len > cols) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_READ_TOO_LONG); continue; }
         if (len < 5) { if (lane == 0 && len > 0) atomicCAS(status, 0, AQC_ERR_ARG); continue; }   // IndexError upstream (:106-107)
-        stage(s, gs + st, len);
-        stage(q, gq + st, len);
+        stage2(s, gs + st, q, gq + st, len);
         __builtin_amdgcn_wave_barrier();
         if (post && lane == 0) {
             // apply the <= 3 edits of the correction walk to the staged copy
@@ -701,18 +732,21 @@ __global__ __launch_bounds__(BLOCK) void qc_stat_kernel(DevBatch b, int mate, ui
         }
         __builtin_amdgcn_wave_barrier();
         int gc = 0;
+#if defined(AQC_ABLATE) && AQC_ABLATE == 21
+        if (false)
+#endif
         for (int i0 = 0; i0 < len; i0 += WAVE) {
             const int i = i0 + lane;
             const bool in = i < len;
             if (in) {
                 const int qn = (int)q[i] - 33;
                 const uint8_t c = s[i];
-                atomicAdd(&accs[AQC_QC_TOTAL_NUM][i], 1u);
-                atomicAdd(&accs[AQC_QC_TOTAL_QUAL][i], (unsigned int)qn);
+                atomicAdd(&accs[AQC_QC_TOTAL_NUM * cols + i], 1u);
+                atomicAdd(&accs[AQC_QC_TOTAL_QUAL * cols + i], (unsigned int)qn);
                 const int bi = base_idx(c);
                 if (bi >= 0) {
-                    atomicAdd(&accs[AQC_QC_BASE_COUNT_A + bi][i], 1u);
-                    atomicAdd(&accs[AQC_QC_BASE_QUAL_A + bi][i], (unsigned int)qn);
+                    atomicAdd(&accs[(AQC_QC_BASE_COUNT_A + bi) * cols + i], 1u);
+                    atomicAdd(&accs[(AQC_QC_BASE_QUAL_A + bi) * cols + i], (unsigned int)qn);
                 }
                 // discontinuity over the 5-wide window clamped to the read (qualitycontrol.py:97-109)
                 int left = i - 2, right = i + 3;
@@ -720,7 +754,7 @@ __global__ __launch_bounds__(BLOCK) void qc_stat_kernel(DevBatch b, int mate, ui
                 else if (right >= len) { right = len; left = len - 5; }
                 int d = 0;
                 for (int j = left; j < right - 1; j++) d += s[j] != s[j + 1];
-                if (d) atomicAdd(&accs[AQC_QC_DISCONTINUITY][i], (unsigned int)d);
+                if (d) atomicAdd(&accs[AQC_QC_DISCONTINUITY * cols + i], (unsigned int)d);
             }
             gc += __popcll(__ballot(in && (s[i] == 'G' || s[i] == 'C')));
         }
@@ -729,40 +763,134 @@ __global__ __launch_bounds__(BLOCK) void qc_stat_kernel(DevBatch b, int mate, ui
             atomicAdd(&scal[1], 1ull);
             if (len > kmer_len) atomicAdd(&scal[0], (unsigned long long)(len - kmer_len));
         }
-        // k-mers (qualitycontrol.py:113-122): i in range(seqlen - k).  Per 64-position chunk three ballots give the
-        // code bit planes and the "is A/C/G/T" plane; lane i reads its k-mer off them with two 64-bit shifts.
-        const unsigned long long t0 = (order_base + k) * (unsigned long long)AQC_QC_COLS;
-        const int nk = len - kmer_len;
-        if (nk > 0) {
-            const unsigned long long km = (1ull << kmer_len) - 1ull;
-            unsigned long long c0, c1, cv;
-            {
-                const uint8_t c = lane < len ? s[lane] : (uint8_t)0;
-                c0 = __ballot((c >> 1) & 1); c1 = __ballot((c >> 2) & 1);
-                cv = __ballot(c == 'A' || c == 'C' || c == 'G' || c == 'T');
-            }
-            for (int i0 = 0; i0 < nk; i0 += WAVE) {
-                unsigned long long n0, n1, nv;
-                {
-                    const int x = i0 + WAVE + lane;
-                    const uint8_t c = x < len ? s[x] : (uint8_t)0;
-                    n0 = __ballot((c >> 1) & 1); n1 = __ballot((c >> 2) & 1);
-                    nv = __ballot(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < QC_LDS_ROWS * cols; i += BLOCK) {
+        const unsigned int v = accs[i];
+        if (v) atomicAdd(&qc[(i / cols) * AQC_QC_COLS + (i % cols)], (unsigned long long)v);
+    }
+    for (int i = threadIdx.x; i < cols; i += BLOCK)
+        if (gch[i]) atomicAdd(&qc[AQC_QC_GC_HIST * AQC_QC_COLS + i], (unsigned long long)gch[i]);
+    if (threadIdx.x < 2 && scal[threadIdx.x]) atomicAdd(&qc[AQC_QC_SCALARS * AQC_QC_COLS + threadIdx.x], scal[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-mer dictionary of statRead (qualitycontrol.py:113-122), counting part.
+// Global atomics top out near 3e10 /s on this chip — 28 M k-mers of a 200 k-read sample would cost ~0.9 ms —
+// so the 4^k counters live in LDS: one 1024-thread workgroup per CU keeps a private table of 65536 u16 counters
+// (128 KiB) and works in ROUNDS of at most 65535 k-mers (no counter can overflow), then streams the table to
+// its own slice of `partial` with plain coalesced stores; kmer_reduce_kernel adds the slices up.  No global
+// atomic is issued for a pure A/C/G/T k-mer except the (rare, load-guarded) first-seen minimum.
+// Per 64 positions three ballots give the two code bit planes and the "is A/C/G/T" plane; lane i shifts its
+// k-mer out of them.  K-mers containing anything else go to the open-addressing table.
+// ------------------------------------------------------------------------------------------------
+constexpr int KMER_BLOCK = 1024;
+constexpr int KMER_WPB = KMER_BLOCK / WAVE;
+
+__global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int mate, uint64_t first, uint64_t count, int post,
+                                                                const aqc_result* __restrict__ results, int kmer_len,
+                                                                KmerTable kt, unsigned long long order_base,
+                                                                uint16_t* __restrict__ partial, uint32_t reads_per_round,
+                                                                uint32_t n_rounds, int* status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int ktab[];     // 32768 words = 65536 u16 counters
+    const int lane = lane_id();
+    const int wave = threadIdx.x / WAVE;
+    const unsigned long long km = (1ull << kmer_len) - 1ull;
+    unsigned long long* const my_first = kt.dense_first + (size_t)xcc_id() * DENSE_ENTRIES;
+    for (uint32_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
+        for (int i = threadIdx.x; i < (int)(DENSE_ENTRIES / 2); i += KMER_BLOCK) ktab[i] = 0;
+        __syncthreads();
+        const uint64_t r_lo = (uint64_t)round * reads_per_round;
+        const uint64_t r_hi = min(r_lo + reads_per_round, count);
+        for (uint64_t k = r_lo + wave; k < r_hi; k += KMER_WPB) {
+            const uint64_t rec = first + k;
+            int st = 0, len;
+            const uint8_t* gs;
+            if (mate == 0) { len = (int)b.len1[rec]; gs = b.seq1 + b.off1[rec]; }
+            else { len = (int)b.len2[rec]; gs = b.seq2 + b.off2[rec]; }
+            int e_pos[3] = {-1, -1, -1};
+            uint8_t e_base[3] = {0, 0, 0};
+            if (post) {
+#if defined(AQC_ABLATE) && AQC_ABLATE == 33
+                aqc_result r; r.flag = 0; r.start1 = r.start2 = 0; r.len1 = r.len2 = (uint16_t)len; r.n_edits = 0; r.overlap_len = 0;
+#else
+                const aqc_result r = results[rec];
+#endif
+                if (r.flag != AQC_GOOD) continue;                 // only good records reach preprocesser.py:624-627
+                st = mate == 0 ? r.start1 : r.start2;
+                len = mate == 0 ? r.len1 : r.len2;
+                // base corrections of the walk that touch this mate (final-read coordinates)
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    if (e < r.n_edits) {
+                        const aqc_edit ed = r.edits[e];
+                        if (ed.kind == AQC_EDIT_FIX_R1 && mate == 0) { e_pos[e] = (int)r.len1 - (int)r.overlap_len + ed.o; e_base[e] = ed.base; }
+                        if (ed.kind == AQC_EDIT_FIX_R2 && mate == 1) { e_pos[e] = (int)r.len2 - 1 - ed.o; e_base[e] = ed.base; }
+                    }
                 }
-                const int i = i0 + lane;
-                if (i < nk) {
-                    const unsigned long long p0 = ((c0 >> lane) | (lane ? n0 << (64 - lane) : 0ull)) & km;
-                    const unsigned long long p1 = ((c1 >> lane) | (lane ? n1 << (64 - lane) : 0ull)) & km;
-                    const unsigned long long pv = ((cv >> lane) | (lane ? nv << (64 - lane) : 0ull)) & km;
-                    if (pv == km) {
-                        const uint32_t idx = (uint32_t)((p1 << kmer_len) | p0);
-                        atomicAdd(&kt.dense_count[idx], 1u);
-                        if (kt.dense_first[idx] > t0 + i) atomicMin(&kt.dense_first[idx], t0 + i);
-                    } else {
+            }
+            if (len > AQC_MAX_READ_LEN || len < 5) continue;       // (reported by qc_stat_kernel)
+            const int nk = len - kmer_len;
+            if (nk <= 0) continue;
+            const uint8_t* src = gs + st;
+            auto base_at = [&](int x) -> uint8_t {
+                uint8_t c = x < len ? src[x] : (uint8_t)0;
+                if (x == e_pos[0]) c = e_base[0];
+                if (x == e_pos[1]) c = e_base[1];
+                if (x == e_pos[2]) c = e_base[2];
+                return c;
+            };
+            const unsigned long long t0 = (order_base + k) * (unsigned long long)AQC_QC_COLS;
+            // 256 positions per pass: the four byte loads, the four LDS adds and the four first-seen probes of a
+            // pass are each issued back to back, so a pass costs two memory round trips, not eight
+            for (int base0 = 0; base0 < nk; base0 += 4 * WAVE) {
+                unsigned long long m0[5], m1[5], mv[5];
+                uint8_t cb[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) cb[j] = base_at(base0 + WAVE * j + lane);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    m0[j] = __ballot((cb[j] >> 1) & 1); m1[j] = __ballot((cb[j] >> 2) & 1);
+                    mv[j] = __ballot(cb[j] == 'A' || cb[j] == 'C' || cb[j] == 'G' || cb[j] == 'T');
+                }
+                uint32_t idx[4];
+                bool dense[4], exotic[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = base0 + WAVE * j + lane;
+                    const unsigned long long p0 = ((m0[j] >> lane) | (lane ? m0[j + 1] << (64 - lane) : 0ull)) & km;
+                    const unsigned long long p1 = ((m1[j] >> lane) | (lane ? m1[j + 1] << (64 - lane) : 0ull)) & km;
+                    const unsigned long long pv = ((mv[j] >> lane) | (lane ? mv[j + 1] << (64 - lane) : 0ull)) & km;
+                    idx[j] = (uint32_t)((p1 << kmer_len) | p0);
+                    dense[j] = i < nk && pv == km;
+                    exotic[j] = i < nk && pv != km;
+#if !(defined(AQC_ABLATE) && AQC_ABLATE == 31)
+                    if (dense[j]) atomicAdd(&ktab[idx[j] >> 1], 1u << (16 * (idx[j] & 1)));
+#endif
+                }
+                unsigned long long seen[4];
+#if defined(AQC_ABLATE) && AQC_ABLATE == 32
+#pragma unroll
+                for (int j = 0; j < 4; ++j) seen[j] = 0ull;
+#else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) seen[j] = dense[j] ? my_first[idx[j]] : 0ull;
+#endif
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long t = t0 + (unsigned long long)(base0 + WAVE * j + lane);
+                    if (dense[j] && seen[j] > t) __hip_atomic_fetch_min(&my_first[idx[j]], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!__ballot(exotic[j])) continue;
+                    if (exotic[j]) {
+                        const int i = base0 + WAVE * j + lane;
                         unsigned long long key = 0, rkey = 0;
-                        for (int j = 0; j < kmer_len; j++) {
-                            key |= (unsigned long long)s[i + j] << (8 * j);
-                            rkey |= (unsigned long long)comp_or_n(s[i + kmer_len - 1 - j]) << (8 * j);
+                        for (int q = 0; q < kmer_len; q++) {
+                            key |= (unsigned long long)base_at(i + q) << (8 * q);
+                            rkey |= (unsigned long long)comp_or_n(base_at(i + kmer_len - 1 - q)) << (8 * q);
                         }
                         const long long h = kmer_slot(kt, key);
                         const long long hr = kmer_slot(kt, rkey);
@@ -774,19 +902,23 @@ __global__ __launch_bounds__(BLOCK) void qc_stat_kernel(DevBatch b, int mate, ui
                         }
                     }
                 }
-                c0 = n0; c1 = n1; cv = nv;
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        uint4* dst = reinterpret_cast<uint4*>(partial + (size_t)round * DENSE_ENTRIES);
+        const uint4* srcv = reinterpret_cast<const uint4*>(ktab);
+        for (int i = threadIdx.x; i < (int)(DENSE_ENTRIES * 2 / 16); i += KMER_BLOCK) dst[i] = srcv[i];
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < QC_LDS_ROWS * AQC_QC_COLS; i += BLOCK) {
-        const unsigned int v = (&accs[0][0])[i];
-        if (v) atomicAdd(&qc[i], (unsigned long long)v);
-    }
-    for (int i = threadIdx.x; i < AQC_QC_COLS; i += BLOCK)
-        if (gch[i]) atomicAdd(&qc[AQC_QC_GC_HIST * AQC_QC_COLS + i], (unsigned long long)gch[i]);
-    if (threadIdx.x < 2 && scal[threadIdx.x]) atomicAdd(&qc[AQC_QC_SCALARS * AQC_QC_COLS + threadIdx.x], scal[threadIdx.x]);
+}
+
+// dense_count[XCD 0 copy][idx] += sum over rounds of partial[round][idx]
+__global__ void kmer_reduce_kernel(const uint16_t* __restrict__ partial, uint32_t n_rounds, unsigned int* __restrict__ dense_count) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= DENSE_ENTRIES) return;
+    unsigned int sum = 0;
+    for (uint32_t r = 0; r < n_rounds; ++r) sum += partial[(size_t)r * DENSE_ENTRIES + idx];
+    dense_count[idx] += sum;
 }
 
 // compact the occupied k-mer slots into dense arrays
@@ -806,8 +938,15 @@ __global__ void kmer_compact_dense_kernel(KmerTable kt, int k, unsigned long lon
                                           unsigned long long* order, unsigned long long cap, unsigned long long* n_out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (1u << (2 * k))) return;
-    const unsigned long long f = kt.dense_first[i], fr = kt.dense_first[dense_rc(i, k)];
     const unsigned long long never = ~0ull;
+    unsigned long long f = never, fr = never, cnt = 0;
+    const uint32_t ir = dense_rc(i, k);
+    for (int x = 0; x < N_XCD; ++x) {
+        const unsigned long long a = kt.dense_first[(size_t)x * DENSE_ENTRIES + i], b = kt.dense_first[(size_t)x * DENSE_ENTRIES + ir];
+        f = a < f ? a : f;
+        fr = b < fr ? b : fr;
+        cnt += kt.dense_count[(size_t)x * DENSE_ENTRIES + i];
+    }
     if (f == never && fr == never) return;
     unsigned long long ord = never;
     if (f != never) ord = 2 * f;
@@ -818,7 +957,7 @@ __global__ void kmer_compact_dense_kernel(KmerTable kt, int k, unsigned long lon
         key |= (unsigned long long)((0x47544341u >> (8 * code)) & 0xffu) << (8 * j);      // code -> A C T G
     }
     const unsigned long long w = atomicAdd(n_out, 1ull);
-    if (w < cap) { keys[w] = key; counts[w] = kt.dense_count[i]; order[w] = ord; }
+    if (w < cap) { keys[w] = key; counts[w] = cnt; order[w] = ord; }
 }
 
 // ------------------------------------------------------------------------------------------------

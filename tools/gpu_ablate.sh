@@ -7,6 +7,6 @@ for f in afterqc_amd/csrc/libafterqc_hip.so build/ablate/*.so; do
   python - "$f" <<'PY'
 import json, sys
 d = json.loads(open("gpurun_out/b.log").read().strip().splitlines()[-1]); r = d["roofline"]
-print("%-40s kernel %.4f ms  frac %.4f" % (sys.argv[1][-40:], r["kernel_ms"], r["frac"]))
+print("%-40s kernel %.4f ms  frac %.4f  qc_stat %.4f ms" % (sys.argv[1][-40:], r["kernel_ms"], r["frac"], r["qc_stat_kernel_ms"]))
 PY
 done
