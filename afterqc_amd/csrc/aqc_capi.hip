@@ -191,7 +191,7 @@ int aqc_create(int device, int n_slots, aqc_ctx** out) {
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char* fg = getenv("AQC_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
-    HIP_TRY(hipFuncSetAttribute((const void*)kmer_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DENSE_ENTRIES * 2));
+    HIP_TRY(hipFuncSetAttribute((const void*)kmer_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KMER_LDS_BYTES));
     for (auto& s : c->slots) {
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         for (int k = 0; k < AQC_N_KERNELS; k++)
@@ -544,35 +544,43 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
     const uint32_t mx = s->raw_max_len ? s->raw_max_len : AQC_MAX_READ_LEN;
     int cols = (int)((mx + 63) / 64 * 64);
     if (cols > AQC_QC_COLS) cols = AQC_QC_COLS;
-    const size_t lds = sizeof(unsigned int) * (size_t)(QC_LDS_ROWS + 1) * cols + 16 + (size_t)WPB * 2 * (cols + 16);
-    uint64_t per_cu = (150 * 1024) / lds;
-    if (per_cu > 8) per_cu = 8;
-    if (per_cu < 1) per_cu = 1;
-    uint64_t blocks = (count + WPB - 1) / WPB;
-    if (blocks > (uint64_t)c->n_cu * per_cu) blocks = (uint64_t)c->n_cu * per_cu;
+    const size_t lds = sizeof(unsigned int) * (size_t)(QC_LDS_ROWS + 1) * cols + 16;
+    // two 1024-thread workgroups per CU (every wave slot taken) and as few workgroups as that allows: each one ends
+    // with ~11 global atomics per cycle; more only when a workgroup's packed counters would pass 4095 reads
+    uint64_t blocks = (count + QC_WPB - 1) / QC_WPB;
+    if (blocks > (uint64_t)c->n_cu * 2) blocks = (uint64_t)c->n_cu * 2;
+    const uint64_t need = (count + (QC_MAX_READS_PER_BLOCK - QC_WPB) - 1) / (QC_MAX_READS_PER_BLOCK - QC_WPB);
+    if (blocks < need) blocks = need;
     const unsigned long long g0 = s->view.first_index + first;
     if (g0 < q.last_end) q.epoch++;
     q.last_end = g0 + count;
     const unsigned long long order_base = (q.epoch << 34) | g0;
-    hipLaunchKernelGGL(qc_stat_kernel, dim3((int)blocks), dim3(BLOCK), lds, s->stream, s->view, mate, first, count, post,
+    hipLaunchKernelGGL(qc_stat_kernel, dim3((unsigned)blocks), dim3(QC_BLOCK), lds, s->stream, s->view, mate, first, count, post,
                        (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, c->status, cols);
     // k-mer dictionary: LDS-resident u16 counters, rounds of <= 65535 k-mers per workgroup, slices reduced afterwards
     {
         const uint32_t per_read = mx > (uint32_t)c->cfg.qc_kmer ? mx - (uint32_t)c->cfg.qc_kmer : 1;
-        uint32_t rpr = 65535u / per_read;
-        if (rpr < 1) rpr = 1;
+        uint32_t rpr_max = 65535u / per_read;
+        if (rpr_max < 1) rpr_max = 1;
         const uint64_t max_rounds = 512;                       // 64 MiB of slices at most per launch
         uint64_t done = 0;
         while (done < count) {
             uint64_t chunk = count - done;
-            if (chunk > max_rounds * rpr) chunk = max_rounds * rpr;
+            if (chunk > max_rounds * rpr_max) chunk = max_rounds * rpr_max;
+            // every workgroup the same number of rounds: round the count up to a multiple of the CU count
+            uint64_t n_rounds64 = (chunk + rpr_max - 1) / rpr_max;
+            if (n_rounds64 > (uint64_t)c->n_cu) {
+                n_rounds64 = (n_rounds64 + c->n_cu - 1) / c->n_cu * c->n_cu;
+                if (n_rounds64 > max_rounds) n_rounds64 = max_rounds;
+            }
+            const uint32_t rpr = (uint32_t)((chunk + n_rounds64 - 1) / n_rounds64);
             const uint32_t n_rounds = (uint32_t)((chunk + rpr - 1) / rpr);
             if (c->kmer_partial.reserve((size_t)n_rounds * DENSE_ENTRIES * sizeof(uint16_t))) return fail(AQC_ERR_HIP, "hipMalloc failed");
             unsigned kb = n_rounds < (unsigned)c->n_cu ? n_rounds : (unsigned)c->n_cu;
-            hipLaunchKernelGGL(kmer_count_kernel, dim3(kb), dim3(KMER_BLOCK), DENSE_ENTRIES * 2, s->stream, s->view, mate, first + done,
+            hipLaunchKernelGGL(kmer_count_kernel, dim3(kb), dim3(KMER_BLOCK), KMER_LDS_BYTES, s->stream, s->view, mate, first + done,
                                chunk, post, (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.kt, order_base + done,
                                (uint16_t*)c->kmer_partial.p, rpr, n_rounds, c->status);
-            hipLaunchKernelGGL(kmer_reduce_kernel, dim3(DENSE_ENTRIES / 256), dim3(256), 0, s->stream,
+            hipLaunchKernelGGL(kmer_reduce_kernel, dim3(DENSE_ENTRIES / KRED_ENTRIES), dim3(KRED_BLOCK), 0, s->stream,
                                (const uint16_t*)c->kmer_partial.p, n_rounds, q.kt.dense_count);
             done += chunk;
         }
@@ -662,6 +670,12 @@ int aqc_get_counters(aqc_ctx* c, int64_t* out) {
         for (int k = 0; k < 10; k++) tot += pr[k];
         static const char* nm[10] = {"phase1", "normalise", "bubble+len+polyX", "lowq+N", "scan", "verify", "post+walk", "results+counters", "deferred", "-"};
         for (int k = 0; k < 9; k++) fprintf(stderr, "PROF %-18s %6.2f %%\n", nm[k], tot ? 100.0 * pr[k] / tot : 0.0);
+        unsigned long long kp[16];
+        (void)hipMemcpyFromSymbol(kp, HIP_SYMBOL(g_kprof), sizeof(kp));
+        tot = 0;
+        for (int k = 0; k < 8; k++) tot += kp[k];
+        static const char* kn[8] = {"zero+sync", "descriptors", "front(ws,shfl)", "lds adds", "first-seen", "exotic", "round-end sync", "writeout"};
+        for (int k = 0; k < 8; k++) fprintf(stderr, "KPROF %-16s %6.2f %%\n", kn[k], tot ? 100.0 * kp[k] / tot : 0.0);
     }
 #endif
     HIP_TRY(hipMemcpy(out, c->counters, sizeof(int64_t) * AQC_N_COUNTERS, hipMemcpyDeviceToHost));

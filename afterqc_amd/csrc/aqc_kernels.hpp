@@ -645,13 +645,10 @@ __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg(
 
 // reverse complement of a dense k-mer index: complement flips the code's high bit, the order of bases reverses
 __device__ __host__ inline uint32_t dense_rc(uint32_t idx, int k) {
-    const uint32_t m = (1u << k) - 1u;
-    uint32_t b0 = idx & m, b1 = (idx >> k) & m, r0 = 0, r1 = 0;
-    for (int j = 0; j < k; ++j) {
-        r0 |= ((b0 >> j) & 1u) << (k - 1 - j);
-        r1 |= ((b1 >> j) & 1u) << (k - 1 - j);
-    }
-    return ((~r1 & m) << k) | r0;
+    // reverse the order of the 2-bit codes and complement each (A0 <-> T2, C1 <-> G3: code ^ 2)
+    uint32_t r = 0;
+    for (int j = 0; j < k; ++j) r |= (((idx >> (2 * j)) & 3u) ^ 2u) << (2 * (k - 1 - j));
+    return r;
 }
 
 __device__ __forceinline__ uint64_t hash64(uint64_t x) {
@@ -673,105 +670,264 @@ __device__ inline long long kmer_slot(const KmerTable& t, unsigned long long key
     return -1;
 }
 
-constexpr int QC_LDS_ROWS = 11;   // TOTAL_NUM .. DISCONTINUITY (gc histogram kept separately)
+// both slots of a k-mer and its reverse complement: the two first probes travel together (the common case, both
+// keys already present, costs ONE memory round trip)
+__device__ __forceinline__ void kmer_slot2(const KmerTable& t, unsigned long long key, unsigned long long rkey,
+                                           long long& h, long long& hr) {
+    const uint64_t a = hash64(key) & t.mask, b = hash64(rkey) & t.mask;
+    const unsigned long long ka = t.keys[a], kb = t.keys[b];
+    h = ka == key ? (long long)a : kmer_slot(t, key);
+    hr = kb == rkey ? (long long)b : kmer_slot(t, rkey);
+}
 
-__global__ __launch_bounds__(BLOCK) void qc_stat_kernel(DevBatch b, int mate, uint64_t first, uint64_t count, int post,
-                                                        const aqc_result* __restrict__ results, int kmer_len,
-                                                        unsigned long long* __restrict__ qc /* [QC_ROWS*QC_COLS] */,
-                                                        int* status, int cols) {
-    // dynamic LDS, sized by the longest read of the batch (cols = multiple of 64 <= 1024) so that short reads get
-    // many resident workgroups: [QC_LDS_ROWS][cols] + gc histogram [cols] u32, scalars, 2 staging strings per wave
+// ------------------------------------------------------------------------------------------------
+// Read descriptors for the sampling kernels.  A wavefront that walks its reads one by one pays the chain
+// len/offset -> verdict record -> bases -> table probe as four DEPENDENT memory round trips per read (~6 us on
+// this chip), which is what bounded both sampling kernels.  Instead lane j fetches the descriptor of the
+// wave's j-th read (64 descriptors per two round trips), the loop broadcasts one descriptor per iteration with
+// v_readlane, and the bases of read j+1 are loaded into registers while read j is being accumulated.
+//   len  < 0 : not part of the sample (verdict not GOOD / beyond the range)
+//   e[k]     : the walk's k-th edit as it applies to THIS mate in final-read coordinates,
+//              pos << 16 | new base << 8 | new quality   (base 0 = keep the base: a mask edit; pos 0xffff = none)
+// ------------------------------------------------------------------------------------------------
+struct ReadDesc {
+    unsigned long long s, q;
+    int len;
+    unsigned int e[3];
+};
+
+__device__ __forceinline__ ReadDesc lane_desc(const DevBatch& b, int mate, uint64_t rec, bool valid, int post,
+                                              const aqc_result* __restrict__ results) {
+    ReadDesc d;
+    d.s = d.q = 0ull;
+    d.len = -1;
+    d.e[0] = d.e[1] = d.e[2] = 0xffff0000u;
+    if (!valid) return d;
+    int len, st = 0;
+    if (mate == 0) {
+        len = (int)b.len1[rec];
+        const uint64_t o = b.off1[rec];
+        d.s = (unsigned long long)(b.seq1 + o);
+        d.q = (unsigned long long)(b.qual1 + (b.qoff1 ? b.qoff1[rec] : o));
+    } else {
+        len = (int)b.len2[rec];
+        const uint64_t o = b.off2[rec];
+        d.s = (unsigned long long)(b.seq2 + o);
+        d.q = (unsigned long long)(b.qual2 + (b.qoff2 ? b.qoff2[rec] : o));
+    }
+    if (post) {
+        // the 32-byte verdict record as two 16-byte loads; fields by shifts (aqc_result is packed, see the header)
+        const uint4* rp = reinterpret_cast<const uint4*>(results + rec);
+        const uint4 w0 = rp[0], w1 = rp[1];
+        if ((w0.x & 0xffu) != (unsigned int)AQC_GOOD) return d;   // only good records reach preprocesser.py:624-627
+        const int n_edits = (int)((w0.x >> 8) & 0xffu);
+        const int len1 = (int)(w0.y & 0xffffu), len2 = (int)(w0.z & 0xffffu), ovl = (int)(w0.w & 0xffffu);
+        st = mate == 0 ? (int)(w0.x >> 16) : (int)(w0.y >> 16);
+        len = mate == 0 ? len1 : len2;
+        const unsigned long long e_lo = ((unsigned long long)w1.y << 32) | w1.x, e_hi = ((unsigned long long)w1.w << 32) | w1.z;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            if (e < n_edits) {
+                // edit e = 5 bytes at byte 5e of the 16: o (u16), kind, base, qual
+                const int bit = 40 * e;
+                unsigned long long v = bit < 64 ? e_lo >> bit : 0ull;
+                if (bit + 40 > 64) v |= bit < 64 ? e_hi << (64 - bit) : e_hi >> (bit - 64);
+                const int o = (int)(v & 0xffffu);
+                const unsigned int kind = (unsigned int)(v >> 16) & 0xffu, base = (unsigned int)(v >> 24) & 0xffu, qual = (unsigned int)(v >> 32) & 0xffu;
+                const unsigned int pos = mate == 0 ? (unsigned int)(len1 - ovl + o) : (unsigned int)(len2 - 1 - o);
+                if (kind == AQC_EDIT_MASK) d.e[e] = (pos << 16) | (unsigned int)'!';
+                else if ((kind == AQC_EDIT_FIX_R1 && mate == 0) || (kind == AQC_EDIT_FIX_R2 && mate == 1))
+                    d.e[e] = (pos << 16) | (base << 8) | qual;
+            }
+        }
+    }
+    d.s += (unsigned int)st;
+    d.q += (unsigned int)st;
+    d.len = len;
+    return d;
+}
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int j) {
+    const unsigned int lo = __builtin_amdgcn_readlane((int)(unsigned int)v, j);
+    const unsigned int hi = __builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), j);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ ReadDesc bcast_desc(const ReadDesc& d, int j) {
+    ReadDesc o;
+    o.s = readlane64(d.s, j);
+    o.q = readlane64(d.q, j);
+    o.len = __builtin_amdgcn_readlane(d.len, j);
+    o.e[0] = (unsigned int)__builtin_amdgcn_readlane((int)d.e[0], j);
+    o.e[1] = (unsigned int)__builtin_amdgcn_readlane((int)d.e[1], j);
+    o.e[2] = (unsigned int)__builtin_amdgcn_readlane((int)d.e[2], j);
+    return o;
+}
+
+// four consecutive bytes of a read starting at byte x; bytes at or beyond `len` read as the (byte-uniform) `pad`.
+// Branch-free so that a prefetch stays asynchronous: ONE unaligned dword load from an address clamped into the
+// read (len >= 4), then a funnel shift brings the pad in from the top.
+__device__ __forceinline__ uint32_t load4(const uint8_t* p, int x, int len, uint32_t pad) {
+    const int xa = min(x, len - 4);
+    uint32_t dw = pad;
+    if (x < len) __builtin_memcpy(&dw, p + xa, 4);
+    return __builtin_amdgcn_alignbit(pad, dw, (unsigned)(8 * (x - xa)) & 31u);
+}
+
+// the walk's edits that fall into the dword at byte offset x (d is wave-uniform, so the outer tests are scalar)
+__device__ __forceinline__ void apply_edits(const ReadDesc& d, int x, uint32_t& ws, uint32_t& wq) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const unsigned int ed = d.e[e];
+        if ((ed >> 16) != 0xffffu) {
+            const unsigned int rel = (ed >> 16) - (unsigned int)x;
+            if (rel < 4u) {
+                const unsigned int sh = 8u * rel;
+                if ((ed >> 8) & 0xffu) ws = (ws & ~(0xffu << sh)) | (((ed >> 8) & 0xffu) << sh);
+                wq = (wq & ~(0xffu << sh)) | ((ed & 0xffu) << sh);
+            }
+        }
+    }
+}
+
+// 0x80 in every byte of x that is not zero
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x) {
+    return (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+}
+
+constexpr uint32_t CODE_TO_BASE = 0x47544341u;   // 2-bit code (c >> 1) & 3 -> 'A' 'C' 'T' 'G'
+
+// ------------------------------------------------------------------------------------------------
+// Per-cycle accumulators of statRead (qualitycontrol.py:73-111).  A lane owns FOUR consecutive cycles of the
+// read: one unaligned dword of bases and one of qualities live in registers (no LDS staging), the neighbours'
+// dwords come over the wave for the 5-wide discontinuity window, and a base's count and quality sum travel in
+// ONE LDS atomic (count << 20 | quality sum; at most 4095 reads per workgroup).  total_num / total_qual are
+// column sums of the five rows (A T C G other), formed when the workgroup flushes.
+// ------------------------------------------------------------------------------------------------
+constexpr int QC_BLOCK = 1024;
+constexpr int QC_WPB = QC_BLOCK / WAVE;
+constexpr int QC_LDS_ROWS = 6;            // A T C G other | discontinuity   (+ gc histogram)
+constexpr int QC_MAX_READS_PER_BLOCK = 4095;
+
+__global__ __launch_bounds__(QC_BLOCK) void qc_stat_kernel(DevBatch b, int mate, uint64_t first, uint64_t count, int post,
+                                                           const aqc_result* __restrict__ results, int kmer_len,
+                                                           unsigned long long* __restrict__ qc /* [QC_ROWS*QC_COLS] */,
+                                                           int* status, int cols) {
+    // dynamic LDS, sized by the longest read of the batch (cols = multiple of 64 <= 1024)
     extern __shared__ __attribute__((aligned(16))) unsigned int qc_smem[];
     unsigned int* const accs = qc_smem;                               // accs[row * cols + i]
     unsigned int* const gch = qc_smem + QC_LDS_ROWS * cols;
     unsigned long long* const scal = reinterpret_cast<unsigned long long*>(gch + cols);
-    uint8_t* const strings = reinterpret_cast<uint8_t*>(scal + 2);
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
-    for (int i = threadIdx.x; i < (QC_LDS_ROWS + 1) * cols; i += BLOCK) qc_smem[i] = 0;
+    for (int i = threadIdx.x; i < (QC_LDS_ROWS + 1) * cols; i += QC_BLOCK) qc_smem[i] = 0;
     if (threadIdx.x < 2) scal[threadIdx.x] = 0;
     __syncthreads();
-    uint8_t* s = strings + (size_t)(2 * wave) * (cols + 16);
-    uint8_t* q = s + (cols + 16);
-    const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
-    for (uint64_t k = (uint64_t)blockIdx.x * WPB + wave; k < count; k += nwaves) {
-        const uint64_t rec = first + k;
-        int st = 0, len;
-        const uint8_t *gs, *gq;
-        if (mate == 0) {
-            len = (int)b.len1[rec];
-            gs = b.seq1 + b.off1[rec];
-            gq = b.qual1 + (b.qoff1 ? b.qoff1[rec] : b.off1[rec]);
-        } else {
-            len = (int)b.len2[rec];
-            gs = b.seq2 + b.off2[rec];
-            gq = b.qual2 + (b.qoff2 ? b.qoff2[rec] : b.off2[rec]);
+    // column i lives at word (i & 3) * (cols / 4) + (i >> 2): the four cycles a lane owns are cols/4 words apart and
+    // neighbouring lanes hit neighbouring banks (the natural layout would be a 4-way bank conflict on every add)
+    const int cq = cols >> 2;
+    const uint64_t nwaves = (uint64_t)gridDim.x * QC_WPB;
+    if ((count + nwaves - 1) / nwaves * QC_WPB > (uint64_t)QC_MAX_READS_PER_BLOCK) {      // host sizes the grid; never silently overflow
+        if (threadIdx.x == 0) atomicCAS(status, 0, AQC_ERR_STATE);
+        return;
+    }
+    auto usable = [&](const ReadDesc& d) { return d.len >= 5 && d.len <= AQC_MAX_READ_LEN && d.len <= cols; };
+    for (uint64_t kb = (uint64_t)blockIdx.x * QC_WPB + wave; kb < count; kb += nwaves * WAVE) {
+        const uint64_t myk = kb + (uint64_t)lane * nwaves;
+        const ReadDesc mine = lane_desc(b, mate, first + myk, myk < count, post, results);
+        const int nr = (int)min((uint64_t)WAVE, (count - kb + nwaves - 1) / nwaves);
+        ReadDesc cur = bcast_desc(mine, 0);
+        uint32_t pre_s = 0, pre_q = 0;
+        if (usable(cur)) {
+            pre_s = load4(reinterpret_cast<const uint8_t*>(cur.s), 4 * lane, cur.len, 0);
+            pre_q = load4(reinterpret_cast<const uint8_t*>(cur.q), 4 * lane, cur.len, 0);
         }
-        aqc_result r;
-        if (post) {
-            r = results[rec];
-            if (r.flag != AQC_GOOD) continue;                 // only good records reach :624-627
-            st = mate == 0 ? r.start1 : r.start2;
-            len = mate == 0 ? r.len1 : r.len2;
-        }
-        if (len > AQC_MAX_READ_LEN || len > cols) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_READ_TOO_LONG); continue; }
-        if (len < 5) { if (lane == 0 && len > 0) atomicCAS(status, 0, AQC_ERR_ARG); continue; }   // IndexError upstream (:106-107)
-        stage2(s, gs + st, q, gq + st, len);
-        __builtin_amdgcn_wave_barrier();
-        if (post && lane == 0) {
-            // apply the <= 3 edits of the correction walk to the staged copy
-#pragma unroll
-            for (int e = 0; e < 3; e++) {
-                if (e >= r.n_edits) break;
-                const aqc_edit ed = r.edits[e];
-                const int p1 = (int)r.len1 - (int)r.overlap_len + ed.o, p2 = (int)r.len2 - 1 - ed.o;
-                if (ed.kind == AQC_EDIT_MASK) q[mate == 0 ? p1 : p2] = '!';
-                else if (ed.kind == AQC_EDIT_FIX_R1 && mate == 0) { s[p1] = ed.base; q[p1] = ed.qual; }
-                else if (ed.kind == AQC_EDIT_FIX_R2 && mate == 1) { s[p2] = ed.base; q[p2] = ed.qual; }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        int gc = 0;
-#if defined(AQC_ABLATE) && AQC_ABLATE == 21
-        if (false)
-#endif
-        for (int i0 = 0; i0 < len; i0 += WAVE) {
-            const int i = i0 + lane;
-            const bool in = i < len;
-            if (in) {
-                const int qn = (int)q[i] - 33;
-                const uint8_t c = s[i];
-                atomicAdd(&accs[AQC_QC_TOTAL_NUM * cols + i], 1u);
-                atomicAdd(&accs[AQC_QC_TOTAL_QUAL * cols + i], (unsigned int)qn);
-                const int bi = base_idx(c);
-                if (bi >= 0) {
-                    atomicAdd(&accs[(AQC_QC_BASE_COUNT_A + bi) * cols + i], 1u);
-                    atomicAdd(&accs[(AQC_QC_BASE_QUAL_A + bi) * cols + i], (unsigned int)qn);
+        for (int r = 0; r < nr; ++r) {
+            uint32_t ws = pre_s, wq = pre_q;
+            ReadDesc nxt = cur;
+            if (r + 1 < nr) {
+                nxt = bcast_desc(mine, r + 1);
+                if (usable(nxt)) {
+                    pre_s = load4(reinterpret_cast<const uint8_t*>(nxt.s), 4 * lane, nxt.len, 0);
+                    pre_q = load4(reinterpret_cast<const uint8_t*>(nxt.q), 4 * lane, nxt.len, 0);
                 }
-                // discontinuity over the 5-wide window clamped to the read (qualitycontrol.py:97-109)
-                int left = i - 2, right = i + 3;
-                if (left < 0) { left = 0; right = 5; }
-                else if (right >= len) { right = len; left = len - 5; }
-                int d = 0;
-                for (int j = left; j < right - 1; j++) d += s[j] != s[j + 1];
-                if (d) atomicAdd(&accs[AQC_QC_DISCONTINUITY * cols + i], (unsigned int)d);
             }
-            gc += __popcll(__ballot(in && (s[i] == 'G' || s[i] == 'C')));
+            const int len = cur.len;
+            if (len > AQC_MAX_READ_LEN || len > cols) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_READ_TOO_LONG); }
+            else if (len < 5 && len > 0) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_ARG); }   // IndexError upstream (:106-107)
+            if (usable(cur)) {
+                const uint8_t* gs = reinterpret_cast<const uint8_t*>(cur.s);
+                const uint8_t* gq = reinterpret_cast<const uint8_t*>(cur.q);
+                int gc = 0;
+                unsigned int d_head = 0, d_tail = 0;      // discontinuity of cycle 2 / cycle len-3: the clamped windows
+                for (int base0 = 0; base0 < len; base0 += 4 * WAVE) {
+                    const int x = base0 + 4 * lane;
+                    if (base0 > 0) { ws = load4(gs, x, len, 0); wq = load4(gq, x, len, 0); }
+                    apply_edits(cur, x, ws, wq);
+                    uint32_t prev = __shfl_up(ws, 1), next = __shfl_down(ws, 1);
+                    if (base0 > 0 && lane == 0) { uint32_t dq = 0; prev = load4(gs, x - 4, len, 0); apply_edits(cur, x - 4, prev, dq); }
+                    if (base0 + 4 * WAVE < len && lane == WAVE - 1) { uint32_t dq = 0; next = load4(gs, x + 4, len, 0); apply_edits(cur, x + 4, next, dq); }
+                    // bytes x-2 .. x+5 ; byte k of (v ^ v >> 8) is non-zero iff bases x-2+k and x-1+k differ
+                    const uint32_t vlo = __builtin_amdgcn_alignbit(ws, prev, 16), vhi = __builtin_amdgcn_alignbit(next, ws, 16);
+                    const uint32_t tlo = nonzero_bytes(vlo ^ __builtin_amdgcn_alignbit(vhi, vlo, 8));
+                    const uint32_t thi = nonzero_bytes(vhi ^ (vhi >> 8));
+                    unsigned int dpk = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dpk |= (unsigned int)__popc(__builtin_amdgcn_alignbit(thi, tlo, 8 * j)) << (3 * j);
+                    if (base0 == 0) d_head = ((unsigned int)__builtin_amdgcn_readlane((int)dpk, 0) >> 6) & 7u;
+                    const int tl = len - 3 - base0;                 // cycle len-3 relative to this pass (uniform)
+                    if (tl >= 0 && tl < 4 * WAVE)
+                        d_tail = ((unsigned int)__builtin_amdgcn_readlane((int)dpk, tl >> 2) >> (3 * (tl & 3))) & 7u;
+                    const uint32_t codes = (ws >> 1) & 0x03030303u;
+                    const uint32_t bad = __builtin_amdgcn_perm(0u, CODE_TO_BASE, codes) ^ ws;       // 0 where the byte is A/C/G/T
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = x + j;
+                        const bool in = i < len;
+                        const unsigned int code = (codes >> (8 * j)) & 3u;
+                        const bool acgt = ((bad >> (8 * j)) & 0xffu) == 0u;
+                        if (in) {
+                            const unsigned int row = acgt ? (0x3120u >> (4 * code)) & 0xfu : 4u;     // rows A T C G, other
+                            const unsigned int qn = ((wq >> (8 * j)) & 0xffu) - 33u;
+                            atomicAdd(&accs[row * cols + j * cq + (i >> 2)], (1u << 20) + qn);
+                            // discontinuity over the 5-wide window clamped to the read (qualitycontrol.py:97-109)
+                            const unsigned int d = i < 2 ? d_head : (i > len - 3 ? d_tail : (dpk >> (3 * j)) & 7u);
+                            if (d) atomicAdd(&accs[5 * cols + j * cq + (i >> 2)], d);
+                        }
+                        gc += __popcll(__ballot(in && acgt && (code & 1u)));                         // C = 1, G = 3
+                    }
+                }
+                if (lane == 0) {
+                    atomicAdd(&gch[gc], 1u);
+                    atomicAdd(&scal[1], 1ull);
+                    if (len > kmer_len) atomicAdd(&scal[0], (unsigned long long)(len - kmer_len));
+                }
+            }
+            cur = nxt;
         }
-        if (lane == 0) {
-            atomicAdd(&gch[gc], 1u);
-            atomicAdd(&scal[1], 1ull);
-            if (len > kmer_len) atomicAdd(&scal[0], (unsigned long long)(len - kmer_len));
-        }
-        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < QC_LDS_ROWS * cols; i += BLOCK) {
-        const unsigned int v = accs[i];
-        if (v) atomicAdd(&qc[(i / cols) * AQC_QC_COLS + (i % cols)], (unsigned long long)v);
-    }
-    for (int i = threadIdx.x; i < cols; i += BLOCK)
+    for (int i = threadIdx.x; i < cols; i += QC_BLOCK) {
+        const int ci = (i & 3) * cq + (i >> 2);
+        unsigned long long tn = 0, tq = 0;
+#pragma unroll
+        for (int row = 0; row < 5; ++row) {
+            const unsigned int v = accs[row * cols + ci];
+            const unsigned long long cnt = v >> 20, qs = v & 0xfffffu;
+            if (row < 4 && v) {
+                atomicAdd(&qc[(AQC_QC_BASE_COUNT_A + row) * AQC_QC_COLS + i], cnt);
+                atomicAdd(&qc[(AQC_QC_BASE_QUAL_A + row) * AQC_QC_COLS + i], qs);
+            }
+            tn += cnt; tq += qs;
+        }
+        if (tn) {
+            atomicAdd(&qc[AQC_QC_TOTAL_NUM * AQC_QC_COLS + i], tn);
+            atomicAdd(&qc[AQC_QC_TOTAL_QUAL * AQC_QC_COLS + i], tq);
+        }
+        const unsigned int dv = accs[5 * cols + ci];
+        if (dv) atomicAdd(&qc[AQC_QC_DISCONTINUITY * AQC_QC_COLS + i], (unsigned long long)dv);
         if (gch[i]) atomicAdd(&qc[AQC_QC_GC_HIST * AQC_QC_COLS + i], (unsigned long long)gch[i]);
+    }
     if (threadIdx.x < 2 && scal[threadIdx.x]) atomicAdd(&qc[AQC_QC_SCALARS * AQC_QC_COLS + threadIdx.x], scal[threadIdx.x]);
 }
 
@@ -782,11 +938,28 @@ __global__ __launch_bounds__(BLOCK) void qc_stat_kernel(DevBatch b, int mate, ui
 // (128 KiB) and works in ROUNDS of at most 65535 k-mers (no counter can overflow), then streams the table to
 // its own slice of `partial` with plain coalesced stores; kmer_reduce_kernel adds the slices up.  No global
 // atomic is issued for a pure A/C/G/T k-mer except the (rare, load-guarded) first-seen minimum.
-// Per 64 positions three ballots give the two code bit planes and the "is A/C/G/T" plane; lane i shifts its
-// k-mer out of them.  K-mers containing anything else go to the open-addressing table.
+// A lane owns four consecutive k-mer start positions: its dword of bases is packed to 4 x 2-bit codes, two
+// wave shifts assemble the codes of 16 consecutive bases, and the dense index of position j is
+// (window >> 2j) & (4^k - 1) — base q of the k-mer at bits 2q..2q+1, code (c >> 1) & 3 = A0 C1 T2 G3.
+// K-mers containing anything else go to the open-addressing table (byte keys).
+// Descriptors are fetched lane-parallel and the bases of the next read are prefetched (see ReadDesc).
 // ------------------------------------------------------------------------------------------------
+#ifdef AQC_PROFILE
+__device__ unsigned long long g_kprof[16];
+#define KPROF_DECL unsigned long long kp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long kp_last = __builtin_amdgcn_s_memtime();
+#define KPROF(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); kp_t[k] += now_ - kp_last; kp_last = now_; } while (0)
+#define KPROF_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_kprof[k_], kp_t[k_]); } while (0)
+#else
+#define KPROF_DECL
+#define KPROF(k)
+#define KPROF_FLUSH
+#endif
+
 constexpr int KMER_BLOCK = 1024;
 constexpr int KMER_WPB = KMER_BLOCK / WAVE;
+constexpr int KMER_EXQ = 1536;                  // LDS queue of k-mers bound for the open-addressing table (24 KiB)
+constexpr size_t KMER_LDS_BYTES = DENSE_ENTRIES * 2 + (size_t)KMER_EXQ * 16 + 16;
+constexpr int KMER_PASS_LANES = WAVE - 2;        // the last two lanes of a pass only supply bases to their neighbours
 
 __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int mate, uint64_t first, uint64_t count, int post,
                                                                 const aqc_result* __restrict__ results, int kmer_len,
@@ -794,131 +967,165 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
                                                                 uint16_t* __restrict__ partial, uint32_t reads_per_round,
                                                                 uint32_t n_rounds, int* status) {
     extern __shared__ __attribute__((aligned(16))) unsigned int ktab[];     // 32768 words = 65536 u16 counters
+    unsigned long long* const exq_key = reinterpret_cast<unsigned long long*>(ktab + DENSE_ENTRIES / 2);   // parked exotic k-mers
+    unsigned long long* const exq_t = exq_key + KMER_EXQ;
+    unsigned int* const exq_n = reinterpret_cast<unsigned int*>(exq_t + KMER_EXQ);
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
-    const unsigned long long km = (1ull << kmer_len) - 1ull;
+    const unsigned long long kmask = kmer_len >= 8 ? ~0ull : (1ull << (8 * kmer_len)) - 1ull;
+    // k-mer with a symbol outside A/C/G/T -> open-addressing table, keyed by its bytes (first seen at time t)
+    auto exotic_insert = [&](unsigned long long key, unsigned long long t) {
+        unsigned long long rkey = 0;
+        for (int qq = 0; qq < kmer_len; qq++)
+            rkey |= (unsigned long long)comp_or_n((uint8_t)(key >> (8 * (kmer_len - 1 - qq)))) << (8 * qq);
+        long long h, hr;
+        kmer_slot2(kt, key, rkey, h, hr);
+        if (h < 0 || hr < 0) atomicCAS(status, 0, AQC_ERR_UNSUPPORTED);
+        else {
+            atomicAdd(&kt.counts[h], 1ull);
+            atomicMin(&kt.order[h], 2 * t);
+            atomicMin(&kt.order[hr], 2 * t + 1);
+        }
+    };
+    const uint32_t imask = (1u << (2 * kmer_len)) - 1u, kbits = (1u << kmer_len) - 1u;
     unsigned long long* const my_first = kt.dense_first + (size_t)xcc_id() * DENSE_ENTRIES;
+    auto usable = [&](const ReadDesc& d) { return d.len >= 5 && d.len <= AQC_MAX_READ_LEN && d.len > kmer_len; };
+    KPROF_DECL
+    constexpr uint32_t PAD = 0x41414141u;      // 'AAAA': bases beyond the read never reach a counted k-mer
     for (uint32_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
         for (int i = threadIdx.x; i < (int)(DENSE_ENTRIES / 2); i += KMER_BLOCK) ktab[i] = 0;
+        if (threadIdx.x == 0) *exq_n = 0;
         __syncthreads();
+        KPROF(0);
         const uint64_t r_lo = (uint64_t)round * reads_per_round;
         const uint64_t r_hi = min(r_lo + reads_per_round, count);
-        for (uint64_t k = r_lo + wave; k < r_hi; k += KMER_WPB) {
-            const uint64_t rec = first + k;
-            int st = 0, len;
-            const uint8_t* gs;
-            if (mate == 0) { len = (int)b.len1[rec]; gs = b.seq1 + b.off1[rec]; }
-            else { len = (int)b.len2[rec]; gs = b.seq2 + b.off2[rec]; }
-            int e_pos[3] = {-1, -1, -1};
-            uint8_t e_base[3] = {0, 0, 0};
-            if (post) {
-#if defined(AQC_ABLATE) && AQC_ABLATE == 33
-                aqc_result r; r.flag = 0; r.start1 = r.start2 = 0; r.len1 = r.len2 = (uint16_t)len; r.n_edits = 0; r.overlap_len = 0;
-#else
-                const aqc_result r = results[rec];
-#endif
-                if (r.flag != AQC_GOOD) continue;                 // only good records reach preprocesser.py:624-627
-                st = mate == 0 ? r.start1 : r.start2;
-                len = mate == 0 ? r.len1 : r.len2;
-                // base corrections of the walk that touch this mate (final-read coordinates)
-#pragma unroll
-                for (int e = 0; e < 3; ++e) {
-                    if (e < r.n_edits) {
-                        const aqc_edit ed = r.edits[e];
-                        if (ed.kind == AQC_EDIT_FIX_R1 && mate == 0) { e_pos[e] = (int)r.len1 - (int)r.overlap_len + ed.o; e_base[e] = ed.base; }
-                        if (ed.kind == AQC_EDIT_FIX_R2 && mate == 1) { e_pos[e] = (int)r.len2 - 1 - ed.o; e_base[e] = ed.base; }
-                    }
+        for (uint64_t kb = r_lo + wave; kb < r_hi; kb += (uint64_t)KMER_WPB * WAVE) {
+            const uint64_t myk = kb + (uint64_t)lane * KMER_WPB;
+            const ReadDesc mine = lane_desc(b, mate, first + myk, myk < r_hi, post, results);
+            const int nr = (int)min((uint64_t)WAVE, (r_hi - kb + KMER_WPB - 1) / KMER_WPB);
+            ReadDesc cur = bcast_desc(mine, 0);
+            uint32_t pre = PAD;
+            if (usable(cur)) pre = load4(reinterpret_cast<const uint8_t*>(cur.s), 4 * lane, cur.len, PAD);
+            KPROF(1);
+            for (int r = 0; r < nr; ++r) {
+                uint32_t ws = pre;
+                ReadDesc nxt = cur;
+                if (r + 1 < nr) {
+                    nxt = bcast_desc(mine, r + 1);
+                    if (usable(nxt)) pre = load4(reinterpret_cast<const uint8_t*>(nxt.s), 4 * lane, nxt.len, PAD);
                 }
-            }
-            if (len > AQC_MAX_READ_LEN || len < 5) continue;       // (reported by qc_stat_kernel)
-            const int nk = len - kmer_len;
-            if (nk <= 0) continue;
-            const uint8_t* src = gs + st;
-            auto base_at = [&](int x) -> uint8_t {
-                uint8_t c = x < len ? src[x] : (uint8_t)0;
-                if (x == e_pos[0]) c = e_base[0];
-                if (x == e_pos[1]) c = e_base[1];
-                if (x == e_pos[2]) c = e_base[2];
-                return c;
-            };
-            const unsigned long long t0 = (order_base + k) * (unsigned long long)AQC_QC_COLS;
-            // 256 positions per pass: the four byte loads, the four LDS adds and the four first-seen probes of a
-            // pass are each issued back to back, so a pass costs two memory round trips, not eight
-            for (int base0 = 0; base0 < nk; base0 += 4 * WAVE) {
-                unsigned long long m0[5], m1[5], mv[5];
-                uint8_t cb[5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) cb[j] = base_at(base0 + WAVE * j + lane);
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    m0[j] = __ballot((cb[j] >> 1) & 1); m1[j] = __ballot((cb[j] >> 2) & 1);
-                    mv[j] = __ballot(cb[j] == 'A' || cb[j] == 'C' || cb[j] == 'G' || cb[j] == 'T');
-                }
-                uint32_t idx[4];
-                bool dense[4], exotic[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = base0 + WAVE * j + lane;
-                    const unsigned long long p0 = ((m0[j] >> lane) | (lane ? m0[j + 1] << (64 - lane) : 0ull)) & km;
-                    const unsigned long long p1 = ((m1[j] >> lane) | (lane ? m1[j + 1] << (64 - lane) : 0ull)) & km;
-                    const unsigned long long pv = ((mv[j] >> lane) | (lane ? mv[j + 1] << (64 - lane) : 0ull)) & km;
-                    idx[j] = (uint32_t)((p1 << kmer_len) | p0);
-                    dense[j] = i < nk && pv == km;
-                    exotic[j] = i < nk && pv != km;
-#if !(defined(AQC_ABLATE) && AQC_ABLATE == 31)
-                    if (dense[j]) atomicAdd(&ktab[idx[j] >> 1], 1u << (16 * (idx[j] & 1)));
-#endif
-                }
-                unsigned long long seen[4];
-#if defined(AQC_ABLATE) && AQC_ABLATE == 32
-#pragma unroll
-                for (int j = 0; j < 4; ++j) seen[j] = 0ull;
-#else
-#pragma unroll
-                for (int j = 0; j < 4; ++j) seen[j] = dense[j] ? my_first[idx[j]] : 0ull;
-#endif
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned long long t = t0 + (unsigned long long)(base0 + WAVE * j + lane);
-                    if (dense[j] && seen[j] > t) __hip_atomic_fetch_min(&my_first[idx[j]], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (!__ballot(exotic[j])) continue;
-                    if (exotic[j]) {
-                        const int i = base0 + WAVE * j + lane;
-                        unsigned long long key = 0, rkey = 0;
-                        for (int q = 0; q < kmer_len; q++) {
-                            key |= (unsigned long long)base_at(i + q) << (8 * q);
-                            rkey |= (unsigned long long)comp_or_n(base_at(i + kmer_len - 1 - q)) << (8 * q);
+                if (usable(cur)) {
+                    const int len = cur.len;
+                    const int nk = len - kmer_len;
+                    const uint64_t k = kb + (uint64_t)r * KMER_WPB;
+                    const unsigned long long t0 = (order_base + k) * (unsigned long long)AQC_QC_COLS;
+                    for (int base0 = 0; base0 < nk; base0 += 4 * KMER_PASS_LANES) {
+                        const int x = base0 + 4 * lane;
+                        if (base0 > 0) ws = load4(reinterpret_cast<const uint8_t*>(cur.s), x, len, PAD);
+                        uint32_t dq = 0;
+                        apply_edits(cur, x, ws, dq);
+                        const uint32_t codes = (ws >> 1) & 0x03030303u;
+                        const uint32_t bad = __builtin_amdgcn_perm(0u, CODE_TO_BASE, codes) ^ ws;    // 0 where the byte is A/C/G/T
+                        const uint32_t c8 = (codes | (codes >> 6) | (codes >> 12) | (codes >> 18)) & 0xffu;
+                        const uint32_t c16 = c8 | ((uint32_t)__shfl_down(c8, 1) << 8);
+                        const uint32_t win = c16 | ((uint32_t)__shfl_down(c16, 2) << 16);           // codes of bases x .. x+15
+                        uint32_t badwin = 0;                                                         // bit q: base x+q is not A/C/G/T
+                        if (__ballot(bad != 0u)) {
+                            const uint32_t nz = nonzero_bytes(bad);
+                            const uint32_t b4 = ((nz >> 7) | (nz >> 14) | (nz >> 21) | (nz >> 28)) & 0xfu;
+                            const uint32_t b8 = b4 | ((uint32_t)__shfl_down(b4, 1) << 4);
+                            badwin = b8 | ((uint32_t)__shfl_down(b8, 2) << 8);
                         }
-                        const long long h = kmer_slot(kt, key);
-                        const long long hr = kmer_slot(kt, rkey);
-                        if (h < 0 || hr < 0) atomicCAS(status, 0, AQC_ERR_UNSUPPORTED);
-                        else {
-                            atomicAdd(&kt.counts[h], 1ull);
-                            atomicMin(&kt.order[h], 2 * (t0 + i));
-                            atomicMin(&kt.order[hr], 2 * (t0 + i) + 1);
+                        KPROF(2);
+                        uint32_t idx[4];
+                        bool dense[4], exotic[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool act = lane < KMER_PASS_LANES && x + j < nk;
+                            idx[j] = (win >> (2 * j)) & imask;
+                            exotic[j] = act && ((badwin >> j) & kbits) != 0u;
+                            dense[j] = act && !exotic[j];
+#if !(defined(AQC_ABLATE) && (AQC_ABLATE == 41 || AQC_ABLATE == 43))
+                            if (dense[j]) atomicAdd(&ktab[idx[j] >> 1], 1u << (16 * (idx[j] & 1)));
+#endif
+                        }
+                        KPROF(3);
+                        unsigned long long seen[4];
+#pragma unroll
+#if defined(AQC_ABLATE) && (AQC_ABLATE == 42 || AQC_ABLATE == 43)
+                        for (int j = 0; j < 4; ++j) seen[j] = 0ull;
+#else
+                        for (int j = 0; j < 4; ++j) seen[j] = dense[j] ? my_first[idx[j]] : 0ull;
+#endif
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned long long t = t0 + (unsigned long long)(x + j);
+                            if (dense[j] && seen[j] > t) __hip_atomic_fetch_min(&my_first[idx[j]], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        KPROF(4);
+                        if (__ballot(badwin != 0u)) {
+                            // byte keys straight from registers: bases x .. x+11 = own dword + the next two lanes'.
+                            // The table insert is a chain of global round trips, so it is not done here: the
+                            // k-mer is parked in the workgroup's LDS queue and inserted when the round ends.
+                            const uint32_t w1 = (uint32_t)__shfl_down(ws, 1), w2 = (uint32_t)__shfl_down(ws, 2);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (exotic[j]) {
+                                    const uint32_t lo = __builtin_amdgcn_alignbit(w1, ws, 8 * j), hi = __builtin_amdgcn_alignbit(w2, w1, 8 * j);
+                                    const unsigned long long key = (((unsigned long long)hi << 32) | lo) & kmask;
+                                    const unsigned long long t = t0 + (unsigned long long)(x + j);
+                                    const unsigned int slot = atomicAdd(exq_n, 1u);
+                                    if (slot < (unsigned int)KMER_EXQ) { exq_key[slot] = key; exq_t[slot] = t; }
+                                    else exotic_insert(key, t);                       // queue full: insert in place
+                                }
+                            }
                         }
                     }
                 }
+                KPROF(5);
+                cur = nxt;
             }
         }
         __syncthreads();
+        KPROF(6);
+        {
+            const unsigned int nq = min(*exq_n, (unsigned int)KMER_EXQ);
+            for (unsigned int e = threadIdx.x; e < nq; e += KMER_BLOCK) exotic_insert(exq_key[e], exq_t[e]);
+        }
+        KPROF(5);
         uint4* dst = reinterpret_cast<uint4*>(partial + (size_t)round * DENSE_ENTRIES);
         const uint4* srcv = reinterpret_cast<const uint4*>(ktab);
         for (int i = threadIdx.x; i < (int)(DENSE_ENTRIES * 2 / 16); i += KMER_BLOCK) dst[i] = srcv[i];
-        __syncthreads();
+        // the table and the queue may be reused once every wave has READ them out of LDS: wait for the LDS reads
+        // only (lgkmcnt), not for the slice stores and table atomics still in flight — they drain under the next round
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        KPROF(7);
     }
+    KPROF_FLUSH;
 }
 
 // dense_count[XCD 0 copy][idx] += sum over rounds of partial[round][idx]
-__global__ void kmer_reduce_kernel(const uint16_t* __restrict__ partial, uint32_t n_rounds, unsigned int* __restrict__ dense_count) {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= DENSE_ENTRIES) return;
-    unsigned int sum = 0;
-    for (uint32_t r = 0; r < n_rounds; ++r) sum += partial[(size_t)r * DENSE_ENTRIES + idx];
-    dense_count[idx] += sum;
+// A workgroup owns 256 adjacent entries; its four waves take every fourth round each, a lane adds four entries
+// (one 8-byte load per round, 512 contiguous bytes per wave) and the four partial sums meet in LDS.
+constexpr int KRED_BLOCK = 256;
+constexpr int KRED_ENTRIES = 256;       // entries per workgroup
+
+__global__ __launch_bounds__(KRED_BLOCK) void kmer_reduce_kernel(const uint16_t* __restrict__ partial, uint32_t n_rounds,
+                                                                 unsigned int* __restrict__ dense_count) {
+    __shared__ unsigned int part[4][KRED_ENTRIES];
+    const int quad = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const uint32_t e0 = blockIdx.x * KRED_ENTRIES + 4 * quad;
+    unsigned int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll 8
+    for (uint32_t r = grp; r < n_rounds; r += 4) {
+        const uint2 v = *reinterpret_cast<const uint2*>(partial + (size_t)r * DENSE_ENTRIES + e0);
+        s0 += v.x & 0xffffu; s1 += v.x >> 16; s2 += v.y & 0xffffu; s3 += v.y >> 16;
+    }
+    part[grp][4 * quad + 0] = s0; part[grp][4 * quad + 1] = s1; part[grp][4 * quad + 2] = s2; part[grp][4 * quad + 3] = s3;
+    __syncthreads();
+    const int i = threadIdx.x;
+    dense_count[blockIdx.x * KRED_ENTRIES + i] += part[0][i] + part[1][i] + part[2][i] + part[3][i];
 }
 
 // compact the occupied k-mer slots into dense arrays
@@ -953,8 +1160,8 @@ __global__ void kmer_compact_dense_kernel(KmerTable kt, int k, unsigned long lon
     if (fr != never && 2 * fr + 1 < ord) ord = 2 * fr + 1;
     unsigned long long key = 0;
     for (int j = 0; j < k; ++j) {
-        const uint32_t code = ((i >> j) & 1u) | (((i >> (k + j)) & 1u) << 1);
-        key |= (unsigned long long)((0x47544341u >> (8 * code)) & 0xffu) << (8 * j);      // code -> A C T G
+        const uint32_t code = (i >> (2 * j)) & 3u;
+        key |= (unsigned long long)((CODE_TO_BASE >> (8 * code)) & 0xffu) << (8 * j);
     }
     const unsigned long long w = atomicAdd(n_out, 1ull);
     if (w < cap) { keys[w] = key; counts[w] = cnt; order[w] = ord; }
