@@ -68,10 +68,17 @@ def main():
 
     import torch  # plumbing only (barrier / max-over-ranks); loaded before libafterqc_hip.so so both share one HIP runtime
     dist = None
+    # AQC_BENCH_SHARE_GPU=1 (debug only): all ranks on GPU 0 with the gloo backend, to exercise the multi-rank code
+    # path on a one-GPU box.  The driver's runs use one GPU per rank over RCCL.
+    share_gpu = os.environ.get("AQC_BENCH_SHARE_GPU") == "1"
+    device_index = 0 if (world == 1 or share_gpu) else local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if share_gpu:
+            dist.init_process_group(backend="gloo", init_method="env://")
+        else:
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", device_index))
 
     cfg = capi.Config()
     cfg.paired = 1 if paired else 0
@@ -82,7 +89,7 @@ def main():
     cfg.set_verify("CAGTA")
     cfg.qc_kmer = 8
 
-    eng = capi.Engine(local_rank if world > 1 else 0, 1)
+    eng = capi.Engine(device_index, 1)
     eng.set_config(cfg)
     eng.reset_stats()
     t_up = time.perf_counter()
@@ -117,7 +124,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kms, klaunch = eng.timing_mean(0)
