@@ -80,6 +80,45 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+class TextChunk(C.Structure):
+    """struct aqc_text_chunk (include/afterqc_hip.h)"""
+    _fields_ = [("text1", C.c_void_p), ("bytes1", C.c_uint64), ("text2", C.c_void_p), ("bytes2", C.c_uint64),
+                ("final1", C.c_int32), ("final2", C.c_int32), ("max_records", C.c_uint64), ("first_index", C.c_uint64)]
+
+
+class FrameInfo(C.Structure):
+    """struct aqc_frame_info"""
+    _fields_ = [("n", C.c_uint64), ("avail1", C.c_uint64), ("avail2", C.c_uint64), ("consumed1", C.c_uint64),
+                ("consumed2", C.c_uint64), ("eof1", C.c_int32), ("eof2", C.c_int32), ("max_len", C.c_uint32),
+                ("next_len1", C.c_uint32)]
+
+
+class HostBuffer:
+    """Page-locked host memory from aqc_host_alloc, exposed as a writable numpy uint8 array / memoryview."""
+
+    def __init__(self, lib, nbytes):
+        self._lib = lib
+        self.nbytes = int(nbytes)
+        self.ptr = lib.aqc_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("aqc_host_alloc(%d) failed" % self.nbytes)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self.ptr))
+        self.view = memoryview(self.array)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self.view = None
+            self._lib.aqc_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Batch:
     """Host-side packed SoA batch (numpy owned).  Arenas are 16-byte aligned per record and padded
     with 64 zero bytes so that vector loads past the last record stay inside the allocation."""
@@ -264,10 +303,17 @@ def load_library():
     lib.aqc_overlap.argtypes = [P, C.POINTER(BatchStruct), P, P, P]
     lib.aqc_read_stats.argtypes = [P, C.POINTER(BatchStruct), C.c_int32, C.c_int32, C.c_int32, P, P, P]
     lib.aqc_edit_distance.argtypes = [P, C.POINTER(BatchStruct), P]
+    lib.aqc_frame.argtypes = [P, C.c_int, C.POINTER(TextChunk), C.POINTER(FrameInfo)]
+    lib.aqc_format.argtypes = [P, C.c_int, C.c_uint64, P]
+    lib.aqc_fetch_text.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.c_uint64]
+    lib.aqc_host_alloc.argtypes = [C.c_uint64]
+    lib.aqc_host_alloc.restype = C.c_void_p
+    lib.aqc_host_free.argtypes = [P]
+    lib.aqc_host_free.restype = None
     for name in ("aqc_create", "aqc_device_name", "aqc_set_config", "aqc_set_circles", "aqc_reset_stats", "aqc_upload",
                  "aqc_run", "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_timing_reset",
                  "aqc_timing_mean", "aqc_get_counters", "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers",
-                 "aqc_overlap", "aqc_read_stats", "aqc_edit_distance"):
+                 "aqc_overlap", "aqc_read_stats", "aqc_edit_distance", "aqc_frame", "aqc_format", "aqc_fetch_text"):
         getattr(lib, name).restype = C.c_int
     if lib.aqc_abi_version() != 1:
         raise RuntimeError("libafterqc_hip.so ABI version mismatch")
@@ -280,7 +326,7 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_last_error", "aq
                     "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_timing_reset",
                     "aqc_timing_mean", "aqc_get_counters",
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
-                    "aqc_edit_distance"]
+                    "aqc_edit_distance", "aqc_frame", "aqc_format", "aqc_fetch_text", "aqc_host_alloc", "aqc_host_free"]
 
 
 class Engine:
@@ -390,6 +436,31 @@ class Engine:
         self._check(self.lib.aqc_get_kmers(self.h, which, _ptr(keys), _ptr(counts), _ptr(order), cap, C.byref(n)))
         m = n.value
         return keys[:m], counts[:m], order[:m]
+
+    # ---- text in / text out ------------------------------------------------------------------
+    def host_buffer(self, nbytes):
+        return HostBuffer(self.lib, nbytes)
+
+    def frame(self, slot, text1, bytes1, final1, text2=None, bytes2=0, final2=False, max_records=UINT64_MAX, first_index=0):
+        """aqc_frame: text1/text2 are numpy uint8 arrays (or HostBuffer.array) holding raw FASTQ text."""
+        ch = TextChunk()
+        ch.text1, ch.bytes1, ch.final1 = text1.ctypes.data, int(bytes1), 1 if final1 else 0
+        if text2 is not None:
+            ch.text2, ch.bytes2, ch.final2 = text2.ctypes.data, int(bytes2), 1 if final2 else 0
+        ch.max_records, ch.first_index = int(max_records), int(first_index)
+        info = FrameInfo()
+        self._check(self.lib.aqc_frame(self.h, slot, C.byref(ch), C.byref(info)))
+        self.slot_n[slot] = info.n
+        return info
+
+    def format(self, slot, n):
+        sizes = np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.aqc_format(self.h, slot, int(n), _ptr(sizes)))
+        return [int(x) for x in sizes]
+
+    def fetch_text(self, slot, file, stream, dst, cap):
+        """dst: numpy uint8 array with room for the stream (sizes from format())"""
+        self._check(self.lib.aqc_fetch_text(self.h, slot, file, stream, dst.ctypes.data if dst is not None else None, int(cap)))
 
     # ---- function seams --------------------------------------------------------------------
     def overlap(self, batch):

@@ -15,6 +15,7 @@
 
 #include "aqc_kernels.hpp"
 #include "aqc_fast.hpp"
+#include "aqc_text.hpp"
 
 using namespace aqc;
 
@@ -65,6 +66,12 @@ struct Slot {
     uint64_t walk_seg_cap = 0;
     uint32_t* h_o16[2] = {nullptr, nullptr};   // pinned staging for the canonical offsets
     size_t h_o16_cap[2] = {0, 0};
+    // text in / text out (aqc_frame, aqc_format): per file the line table and the name / strand-line descriptors
+    DevBuf t_line_end[2], t_tile[2], t_name_off[2], t_name_len[2], t_plus_off[2], t_plus_len[2], t_qual_len[2];
+    DevBuf t_scratch;              // FrameMeta[2] + scan totals
+    DevBuf f_pos, f_tile, f_out[4];
+    uint64_t f_bytes[4] = {0, 0, 0, 0};
+    bool framed = false, formatted = false;
     FastBatch fview{};
     bool has_canonical = false;
     uint32_t max_len = 0;
@@ -163,6 +170,45 @@ static void launch_fast(aqc_ctx* c, Slot* s, const aqc_config& cfg, const DevSta
                        (unsigned int*)s->n_deferred.p);
 }
 
+// ---- text in / text out -----------------------------------------------------------------------------------------
+// exclusive scan of f(0..n) into out (+add); the grand total lands in *d_total (device)
+template <class F, class OutT>
+static int device_scan(Slot& s, F f, uint64_t n, DevBuf& tile, OutT* out, unsigned long long add, unsigned long long* d_total) {
+    const uint64_t tiles = n ? (n + SCAN_TILE - 1) / SCAN_TILE : 1;
+    if (tile.reserve(sizeof(unsigned long long) * tiles)) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    unsigned long long* t = (unsigned long long*)tile.p;
+    hipLaunchKernelGGL((scan_tile_sums_kernel<F>), dim3((unsigned)tiles), dim3(TXT_BLOCK), 0, s.stream, f, n, t);
+    hipLaunchKernelGGL(scan_tile_bases_kernel, dim3(1), dim3(TXT_BLOCK), 0, s.stream, t, tiles, d_total);
+    if (n) hipLaunchKernelGGL((scan_apply_kernel<F, OutT>), dim3((unsigned)tiles), dim3(TXT_BLOCK), 0, s.stream, f, n, t, out, add);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// device half of the canonical layout when the lengths only exist on the device (framed text)
+static int canonicalize_dev(aqc_ctx* c, Slot& s, uint64_t n, uint64_t text_bytes, const uint8_t* d_seq, const uint8_t* d_qual,
+                            const uint64_t* d_off, const uint64_t* d_qoff, const uint32_t* d_len, DevBuf& cseq, DevBuf& cqual,
+                            DevBuf& co, unsigned long long* d_total) {
+    const uint64_t max_chunks = 4 + text_bytes / 16 + n;              // upper bound of 4 + sum ceil(len / 16)
+    if (max_chunks >= (1ull << 32)) return fail(AQC_ERR_ARG, "chunk too large for 32-bit chunk offsets");
+    const size_t bytes = (size_t)max_chunks * 16 + 16 * 64 + 256;
+    if (cseq.reserve(bytes) || cqual.reserve(bytes) || co.reserve(sizeof(uint32_t) * (n ? n : 1)))
+        return fail(AQC_ERR_HIP, "hipMalloc failed");
+    // padding everywhere first ('A' / 0x7f): front pad, chunk tails and the slack behind the last record
+    HIP_TRY(hipMemsetAsync(cseq.p, 'A', bytes, s.stream));
+    HIP_TRY(hipMemsetAsync(cqual.p, 0x7f, bytes, s.stream));
+    int rc = device_scan(s, ChunksOf{d_len}, n, s.f_tile, (uint32_t*)co.p, 4ull, d_total);
+    if (rc) return rc;
+    if (n) {
+        const unsigned blocks = (unsigned)((n * 16 + 255) / 256);
+        hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_seq, d_off, d_len, (const uint32_t*)co.p, n,
+                           (uint8_t*)cseq.p, (uint8_t)'A');
+        hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_qual, d_qoff, d_len, (const uint32_t*)co.p, n,
+                           (uint8_t*)cqual.p, (uint8_t)0x7f);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
 extern "C" {
 
 int aqc_abi_version(void) { return AQC_ABI_VERSION; }
@@ -214,7 +260,11 @@ void aqc_destroy(aqc_ctx* c) {
     for (auto& s : c->slots) {
         DevBuf* bufs[] = {&s.seq1, &s.qual1, &s.off1, &s.qoff1, &s.len1, &s.seq2, &s.qual2, &s.off2, &s.qoff2, &s.len2,
                           &s.aux[0], &s.aux[1], &s.aux[2], &s.aux[3], &s.aux[4], &s.results,
-                          &s.cseq1, &s.cqual1, &s.cseq2, &s.cqual2, &s.co1, &s.co2, &s.deferred, &s.n_deferred, &s.walk_q, &s.n_walk};
+                          &s.cseq1, &s.cqual1, &s.cseq2, &s.cqual2, &s.co1, &s.co2, &s.deferred, &s.n_deferred, &s.walk_q, &s.n_walk,
+                          &s.t_line_end[0], &s.t_line_end[1], &s.t_tile[0], &s.t_tile[1], &s.t_name_off[0], &s.t_name_off[1],
+                          &s.t_name_len[0], &s.t_name_len[1], &s.t_plus_off[0], &s.t_plus_off[1], &s.t_plus_len[0], &s.t_plus_len[1],
+                          &s.t_qual_len[0], &s.t_qual_len[1], &s.t_scratch, &s.f_pos, &s.f_tile, &s.f_out[0], &s.f_out[1], &s.f_out[2],
+                          &s.f_out[3]};
         for (DevBuf* b : bufs) b->release();
         for (int k = 0; k < 2; k++)
             if (s.h_o16[k]) (void)hipHostFree(s.h_o16[k]);
@@ -440,6 +490,7 @@ int aqc_upload(aqc_ctx* c, int slot, const aqc_batch* b) {
     if (rc) return rc;
     if (!b) return fail(AQC_ERR_ARG, "null batch");
     if ((rc = fill_slot(c, *s, b, true, false))) return rc;
+    s->framed = s->formatted = false;
     s->has_canonical = false;
     s->max_len = 0;
     if (c->force_generic) return 0;
@@ -589,6 +640,225 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 1), s->stream));
     s->timed[AQC_K_QC_STAT] = !s->collecting;
     return 0;
+}
+
+// ---- text in / text out -----------------------------------------------------------------------------------------
+int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* info) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!ch || !info || !ch->text1) return fail(AQC_ERR_ARG, "aqc_frame: null argument");
+    const bool paired = ch->text2 != nullptr;
+    const int nf = paired ? 2 : 1;
+    const uint8_t* text[2] = {ch->text1, ch->text2};
+    const uint64_t bytes[2] = {ch->bytes1, paired ? ch->bytes2 : 0};
+    const int final_[2] = {ch->final1, ch->final2};
+    for (int k = 0; k < nf; k++)
+        if (bytes[k] >= (1ull << 32) - TXT_TILE) return fail(AQC_ERR_ARG, "aqc_frame: chunks must be < 4 GiB");
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->framed = s->formatted = false;
+    s->has_canonical = false;
+    s->ran = false;
+    DevBuf* arena[2] = {&s->seq1, &s->seq2};
+    DevBuf* seq_off[2] = {&s->off1, &s->off2};
+    DevBuf* qual_off[2] = {&s->qoff1, &s->qoff2};
+    DevBuf* seq_len[2] = {&s->len1, &s->len2};
+    // scratch: FrameMeta[2] | line totals[2] | canonical totals[2] | tail values[4]
+    if (s->t_scratch.reserve(256)) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    FrameMeta* d_meta = (FrameMeta*)s->t_scratch.p;
+    unsigned long long* d_tot = (unsigned long long*)((uint8_t*)s->t_scratch.p + 64);
+    // 1. text to the device, newline census
+    uint64_t tiles[2] = {0, 0};
+    for (int k = 0; k < nf; k++) {
+        const size_t slack = TXT_TILE + 64;
+        if (arena[k]->reserve(bytes[k] + slack)) return fail(AQC_ERR_HIP, "hipMalloc of %llu bytes failed", (unsigned long long)bytes[k]);
+        if (bytes[k]) HIP_TRY(hipMemcpyAsync(arena[k]->p, text[k], bytes[k], hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemsetAsync((uint8_t*)arena[k]->p + bytes[k], 0, slack, s->stream));
+        tiles[k] = bytes[k] ? (bytes[k] + TXT_TILE - 1) / TXT_TILE : 1;
+        if (s->t_tile[k].reserve(sizeof(unsigned long long) * tiles[k])) return fail(AQC_ERR_HIP, "hipMalloc failed");
+        hipLaunchKernelGGL(newline_count_kernel, dim3((unsigned)tiles[k]), dim3(TXT_BLOCK), 0, s->stream, (const uint8_t*)arena[k]->p,
+                           bytes[k], (unsigned long long*)s->t_tile[k].p);
+        hipLaunchKernelGGL(scan_tile_bases_kernel, dim3(1), dim3(TXT_BLOCK), 0, s->stream, (unsigned long long*)s->t_tile[k].p, tiles[k],
+                           d_tot + k);
+    }
+    HIP_TRY(hipGetLastError());
+    unsigned long long h_tot[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long) * nf, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    // 2. line table, then the four lines of every complete group
+    uint64_t lines[2] = {0, 0}, nrec[2] = {0, 0};
+    const FrameMeta init{0xffffffffu, 0u, 0xffffffffu, 0u};
+    FrameMeta h_meta[2] = {init, init};
+    HIP_TRY(hipMemcpyAsync(d_meta, h_meta, sizeof(h_meta), hipMemcpyHostToDevice, s->stream));
+    for (int k = 0; k < nf; k++) {
+        lines[k] = h_tot[k];
+        // an unterminated last line of the file is a line (readline() returns it)
+        const bool virt = final_[k] && bytes[k] > 0 && text[k][bytes[k] - 1] != '\n';
+        if (s->t_line_end[k].reserve(sizeof(uint32_t) * (lines[k] + 2))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+        hipLaunchKernelGGL(newline_emit_kernel, dim3((unsigned)tiles[k]), dim3(TXT_BLOCK), 0, s->stream, (const uint8_t*)arena[k]->p,
+                           bytes[k], (const unsigned long long*)s->t_tile[k].p, (uint32_t*)s->t_line_end[k].p);
+        if (virt) {
+            const uint32_t end = (uint32_t)bytes[k];
+            HIP_TRY(hipMemcpyAsync((uint32_t*)s->t_line_end[k].p + lines[k], &end, sizeof(end), hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));      // `end` lives on this stack frame
+            lines[k] += 1;
+        }
+        nrec[k] = lines[k] / 4;
+        const uint64_t m = nrec[k] ? nrec[k] : 1;
+        if (seq_off[k]->reserve(8 * m) || qual_off[k]->reserve(8 * m) || seq_len[k]->reserve(4 * m) || s->t_name_off[k].reserve(4 * m) ||
+            s->t_name_len[k].reserve(4 * m) || s->t_plus_off[k].reserve(4 * m) || s->t_plus_len[k].reserve(4 * m) ||
+            s->t_qual_len[k].reserve(4 * m))
+            return fail(AQC_ERR_HIP, "hipMalloc failed");
+        if (nrec[k]) {
+            FramedFile ff{(uint64_t*)seq_off[k]->p, (uint64_t*)qual_off[k]->p, (uint32_t*)seq_len[k]->p, (uint32_t*)s->t_name_off[k].p,
+                          (uint32_t*)s->t_name_len[k].p, (uint32_t*)s->t_plus_off[k].p, (uint32_t*)s->t_plus_len[k].p,
+                          (uint32_t*)s->t_qual_len[k].p};
+            hipLaunchKernelGGL(frame_records_kernel, dim3((unsigned)((nrec[k] + TXT_BLOCK - 1) / TXT_BLOCK)), dim3(TXT_BLOCK), 0, s->stream,
+                               (const uint8_t*)arena[k]->p, (const uint32_t*)s->t_line_end[k].p, nrec[k], ff, d_meta + k);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_meta, d_meta, sizeof(h_meta), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    // 3. lock-step record count (preprocesser.py:412-429)
+    uint64_t avail[2] = {0, 0};
+    for (int k = 0; k < nf; k++) avail[k] = h_meta[k].first_empty < nrec[k] ? h_meta[k].first_empty : nrec[k];
+    uint64_t n = avail[0];
+    if (paired && avail[1] < n) n = avail[1];
+    if (ch->max_records < n) n = ch->max_records;
+    for (int k = 0; k < nf; k++)
+        if (h_meta[k].first_mismatch < n)
+            return fail(AQC_ERR_ARG, "malformed FASTQ: sequence and quality lines differ in length (read %d, record %u of the chunk)", k + 1,
+                        h_meta[k].first_mismatch);
+    memset(info, 0, sizeof(*info));
+    info->n = n;
+    info->avail1 = avail[0];
+    info->avail2 = avail[1];
+    info->eof1 = h_meta[0].first_empty < nrec[0];
+    info->eof2 = paired && h_meta[1].first_empty < nrec[1];
+    info->max_len = h_meta[0].max_len > h_meta[1].max_len ? h_meta[0].max_len : h_meta[1].max_len;
+    // 4. slot view (the text is the arena) + canonical layout for the lane-per-read kernel
+    DevBatch v{};
+    v.n = n;
+    v.first_index = ch->first_index;
+    v.seq1 = v.qual1 = (const uint8_t*)s->seq1.p;
+    v.off1 = (const uint64_t*)s->off1.p; v.qoff1 = (const uint64_t*)s->qoff1.p; v.len1 = (const uint32_t*)s->len1.p;
+    if (paired) {
+        v.seq2 = v.qual2 = (const uint8_t*)s->seq2.p;
+        v.off2 = (const uint64_t*)s->off2.p; v.qoff2 = (const uint64_t*)s->qoff2.p; v.len2 = (const uint32_t*)s->len2.p;
+    }
+    if (s->results.reserve(sizeof(aqc_result) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    s->view = v;
+    s->n = n;
+    s->paired = paired;
+    s->raw_max_len = info->max_len;
+    s->max_len = info->max_len;
+    if (!c->force_generic) {
+        FastBatch f{};
+        f.n = n;
+        if ((rc = canonicalize_dev(c, *s, n, bytes[0], v.seq1, v.qual1, v.off1, v.qoff1, v.len1, s->cseq1, s->cqual1, s->co1, d_tot + 2))) return rc;
+        f.seq1 = (const uint8_t*)s->cseq1.p; f.qual1 = (const uint8_t*)s->cqual1.p; f.o1 = (const uint32_t*)s->co1.p; f.len1 = v.len1;
+        if (paired) {
+            if ((rc = canonicalize_dev(c, *s, n, bytes[1], v.seq2, v.qual2, v.off2, v.qoff2, v.len2, s->cseq2, s->cqual2, s->co2, d_tot + 3))) return rc;
+            f.seq2 = (const uint8_t*)s->cseq2.p; f.qual2 = (const uint8_t*)s->cqual2.p; f.o2 = (const uint32_t*)s->co2.p; f.len2 = v.len2;
+        }
+        s->fview = f;
+        s->has_canonical = true;
+    }
+    // 5. bytes consumed by the n records (+ R1's next sequence length for the TOTAL_BASES quirk)
+    uint32_t h_end[2] = {0, 0}, h_next = 0;
+    if (n) {
+        for (int k = 0; k < nf; k++)
+            HIP_TRY(hipMemcpyAsync(&h_end[k], (const uint32_t*)s->t_line_end[k].p + (4 * n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    }
+    if (avail[0] > n) HIP_TRY(hipMemcpyAsync(&h_next, (const uint32_t*)s->len1.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    uint64_t consumed[2] = {0, 0};
+    for (int k = 0; k < nf; k++)
+        if (n) consumed[k] = (uint64_t)h_end[k] + 1 < bytes[k] ? (uint64_t)h_end[k] + 1 : bytes[k];
+    info->consumed1 = consumed[0];
+    info->consumed2 = consumed[1];
+    info->next_len1 = h_next;
+    s->framed = true;
+    return 0;
+}
+
+int aqc_format(aqc_ctx* c, int slot, uint64_t n, uint64_t bytes_out[4]) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!bytes_out) return fail(AQC_ERR_ARG, "aqc_format: null argument");
+    if (!s->framed) return fail(AQC_ERR_STATE, "aqc_format needs a slot filled by aqc_frame");
+    if (!s->ran) return fail(AQC_ERR_STATE, "aqc_format before aqc_run");
+    if (n > s->n) return fail(AQC_ERR_ARG, "aqc_format: n exceeds the slot's records");
+    if (c->cfg.barcode) return fail(AQC_ERR_UNSUPPORTED, "aqc_format: barcode name rewriting is done on the host");
+    FormatView v{};
+    v.paired = s->paired ? 1 : 0;
+    v.results = (const aqc_result*)s->results.p;
+    const DevBuf* arena[2] = {&s->seq1, &s->seq2};
+    const DevBuf* so[2] = {&s->off1, &s->off2};
+    const DevBuf* qo[2] = {&s->qoff1, &s->qoff2};
+    for (int k = 0; k < (s->paired ? 2 : 1); k++) {
+        v.f[k].text = (const uint8_t*)arena[k]->p;
+        v.f[k].seq_off = (const uint64_t*)so[k]->p;
+        v.f[k].qual_off = (const uint64_t*)qo[k]->p;
+        v.f[k].name_off = (const uint32_t*)s->t_name_off[k].p;
+        v.f[k].name_len = (const uint32_t*)s->t_name_len[k].p;
+        v.f[k].plus_off = (const uint32_t*)s->t_plus_off[k].p;
+        v.f[k].plus_len = (const uint32_t*)s->t_plus_len[k].p;
+    }
+    const int nstreams = s->paired ? 4 : 2;
+    if (s->f_pos.reserve(sizeof(unsigned long long) * 4 * (n ? n : 1)) || s->t_scratch.reserve(256))
+        return fail(AQC_ERR_HIP, "hipMalloc failed");
+    unsigned long long* d_tot = (unsigned long long*)((uint8_t*)s->t_scratch.p + 128);
+    for (int q = 0; q < nstreams; q++) {
+        OutSize f{v, q >> 1, q & 1};
+        if ((rc = device_scan(*s, f, n, s->f_tile, (unsigned long long*)s->f_pos.p + (uint64_t)q * n, 0ull, d_tot + q))) return rc;
+    }
+    unsigned long long h_tot[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long) * nstreams, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    for (int q = 0; q < 4; q++) {
+        s->f_bytes[q] = q < nstreams ? h_tot[q] : 0;
+        bytes_out[q] = s->f_bytes[q];
+        if (s->f_out[q].reserve(s->f_bytes[q] + 64)) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    }
+    if (n) {
+        const uint64_t waves = n * (s->paired ? 2 : 1);
+        const uint64_t blocks = (waves * WAVE + TXT_BLOCK - 1) / TXT_BLOCK;
+        hipLaunchKernelGGL(format_write_kernel, dim3((unsigned)blocks), dim3(TXT_BLOCK), 0, s->stream, v, n,
+                           (const unsigned long long*)s->f_pos.p, (uint8_t*)s->f_out[0].p, (uint8_t*)s->f_out[1].p, (uint8_t*)s->f_out[2].p,
+                           (uint8_t*)s->f_out[3].p);
+        HIP_TRY(hipGetLastError());
+    }
+    s->formatted = true;
+    return 0;
+}
+
+int aqc_fetch_text(aqc_ctx* c, int slot, int file, int stream, uint8_t* dst, uint64_t cap) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!s->formatted) return fail(AQC_ERR_STATE, "aqc_fetch_text before aqc_format");
+    if (file < 0 || file > 1 || stream < 0 || stream > 1) return fail(AQC_ERR_ARG, "aqc_fetch_text: bad file/stream");
+    const int q = file * 2 + stream;
+    if (s->f_bytes[q] > cap) return fail(AQC_ERR_ARG, "aqc_fetch_text: %llu bytes do not fit %llu", (unsigned long long)s->f_bytes[q], (unsigned long long)cap);
+    if (s->f_bytes[q]) {
+        if (!dst) return fail(AQC_ERR_ARG, "aqc_fetch_text: null destination");
+        HIP_TRY(hipMemcpyAsync(dst, s->f_out[q].p, s->f_bytes[q], hipMemcpyDeviceToHost, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return check_status(c);
+}
+
+void* aqc_host_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void aqc_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int aqc_sync(aqc_ctx* c, int slot) {

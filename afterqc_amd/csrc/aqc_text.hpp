@@ -1,0 +1,307 @@
+// aqc_text.hpp — FASTQ text in, FASTQ text out, on the device.
+//
+//   framing    fastq.Reader.nextRead (fastq.py:37-49): a record is 4 lines, each `readline().rstrip()`; a line
+//              that is empty after stripping ends the file.  The raw text chunk is the byte arena; the kernels
+//              here find the newlines, strip trailing whitespace and emit (offset, length) per line.
+//   formatting seqFilter.writeReads (preprocesser.py:206-232) + fastq.Writer.writeLines (fastq.py:87-93):
+//              name, bases, strand line, qualities, each followed by "\n"; a bad record's name becomes
+//              "@" + FLAG + name[1:]; bases/qualities are the trimmed / adapter-cut slices with the <= 3 edits of
+//              the correction walk applied.  Good and bad records of each file are compacted into their own
+//              contiguous text streams in record order (sizes -> exclusive scan -> copy).
+//
+// All of it is byte shuffling bound by HBM bandwidth; no data-dependent host work remains per record.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "afterqc_hip.h"
+#include "aqc_kernels.hpp"
+
+namespace aqc {
+
+constexpr int TXT_BLOCK = 256;
+constexpr int TXT_BYTES_PER_THREAD = 64;
+constexpr int TXT_TILE = TXT_BLOCK * TXT_BYTES_PER_THREAD;    // 16 KiB of text per workgroup
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = TXT_BLOCK * SCAN_ITEMS;             // 4096 values per workgroup
+
+// exclusive prefix of one value per thread over a 256-thread workgroup; `total` = sum over the workgroup
+__device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v, unsigned long long* lds /* [4] */,
+                                                              unsigned long long& total) {
+    const int lane = lane_id(), wave = threadIdx.x / WAVE;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    __syncthreads();                       // lds may still be read by the previous call
+    if (lane == WAVE - 1) lds[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < TXT_BLOCK / WAVE; ++w) {
+        const unsigned long long t = lds[w];
+        if (w < wave) base += t;
+        total += t;
+    }
+    return base + inc - v;
+}
+
+// ---- generic three-pass exclusive scan of u32 values produced by a functor -----------------------------------
+template <class F>
+__global__ __launch_bounds__(TXT_BLOCK) void scan_tile_sums_kernel(F f, uint64_t n, unsigned long long* __restrict__ tile_sum) {
+    __shared__ unsigned long long lds[4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (i0 + k < n) s += f(i0 + k);
+    unsigned long long total;
+    (void)block_excl_scan(s, lds, total);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+
+// in-place exclusive scan of the tile sums by ONE workgroup; the grand total goes to *total_out
+__global__ __launch_bounds__(TXT_BLOCK) void scan_tile_bases_kernel(unsigned long long* __restrict__ tile_sum, uint64_t n_tiles,
+                                                                    unsigned long long* __restrict__ total_out) {
+    __shared__ unsigned long long lds[4];
+    unsigned long long carry = 0;
+    for (uint64_t t0 = 0; t0 < n_tiles; t0 += TXT_BLOCK) {
+        const uint64_t t = t0 + threadIdx.x;
+        const unsigned long long v = t < n_tiles ? tile_sum[t] : 0ull;
+        unsigned long long total;
+        const unsigned long long ex = block_excl_scan(v, lds, total);
+        if (t < n_tiles) tile_sum[t] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+template <class F, class OutT>
+__global__ __launch_bounds__(TXT_BLOCK) void scan_apply_kernel(F f, uint64_t n, const unsigned long long* __restrict__ tile_base,
+                                                               OutT* __restrict__ out, unsigned long long add) {
+    __shared__ unsigned long long lds[4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    unsigned long long s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = i0 + k < n ? f(i0 + k) : 0u;
+        s += v[k];
+    }
+    unsigned long long total;
+    unsigned long long run = tile_base[blockIdx.x] + add + block_excl_scan(s, lds, total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (i0 + k < n) out[i0 + k] = (OutT)run;
+        run += v[k];
+    }
+}
+
+// ---- framing ----------------------------------------------------------------------------------------------------
+// 64-bit mask of the '\n' bytes among the 64 bytes at p (16-byte aligned, readable: the device buffer is padded)
+__device__ __forceinline__ unsigned long long newline_mask64(const uint8_t* p, uint64_t pos, uint64_t bytes) {
+    unsigned long long mask = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint4 v = reinterpret_cast<const uint4*>(p)[k];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t x = w[d] ^ 0x0a0a0a0au;
+            const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;       // 0x80 where the byte is '\n'
+            const uint32_t nib = ((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xfu;
+            mask |= (unsigned long long)nib << (16 * k + 4 * d);
+        }
+    }
+    if (pos + 64 > bytes) mask &= pos >= bytes ? 0ull : ((1ull << (bytes - pos)) - 1ull);
+    return mask;
+}
+
+__global__ __launch_bounds__(TXT_BLOCK) void newline_count_kernel(const uint8_t* __restrict__ text, uint64_t bytes,
+                                                                  unsigned long long* __restrict__ tile_sum) {
+    __shared__ unsigned long long lds[4];
+    const uint64_t pos = (uint64_t)blockIdx.x * TXT_TILE + (uint64_t)threadIdx.x * TXT_BYTES_PER_THREAD;
+    const unsigned long long m = pos < bytes ? newline_mask64(text + pos, pos, bytes) : 0ull;
+    unsigned long long total;
+    (void)block_excl_scan((unsigned long long)__popcll(m), lds, total);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+
+// line_end[i] = byte position of the i-th '\n'
+__global__ __launch_bounds__(TXT_BLOCK) void newline_emit_kernel(const uint8_t* __restrict__ text, uint64_t bytes,
+                                                                 const unsigned long long* __restrict__ tile_base,
+                                                                 uint32_t* __restrict__ line_end) {
+    __shared__ unsigned long long lds[4];
+    const uint64_t pos = (uint64_t)blockIdx.x * TXT_TILE + (uint64_t)threadIdx.x * TXT_BYTES_PER_THREAD;
+    unsigned long long m = pos < bytes ? newline_mask64(text + pos, pos, bytes) : 0ull;
+    unsigned long long total;
+    unsigned long long i = tile_base[blockIdx.x] + block_excl_scan((unsigned long long)__popcll(m), lds, total);
+    while (m) {
+        line_end[i++] = (uint32_t)(pos + (uint64_t)__builtin_ctzll(m));
+        m &= m - 1;
+    }
+}
+
+// the whitespace bytes.rstrip() removes: space, \t \n \v \f \r
+__device__ __forceinline__ bool is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+
+struct FrameMeta {
+    unsigned int first_empty;   // first record with an empty line (0xffffffff = none)
+    unsigned int max_len;       // longest sequence line
+    unsigned int first_mismatch; // first record whose quality line is not as long as its sequence line
+    unsigned int pad_;
+};
+
+// the four lines of every complete group of the chunk (fastq.py:37-49); thread per record
+struct FramedFile {
+    uint64_t* seq_off;
+    uint64_t* qual_off;
+    uint32_t* seq_len;
+    uint32_t* name_off;
+    uint32_t* name_len;
+    uint32_t* plus_off;
+    uint32_t* plus_len;
+    uint32_t* qual_len;
+};
+
+__global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t* __restrict__ text,
+                                                                  const uint32_t* __restrict__ line_end, uint64_t n_rec,
+                                                                  FramedFile out, FrameMeta* __restrict__ meta) {
+    const uint64_t r = (uint64_t)blockIdx.x * TXT_BLOCK + threadIdx.x;
+    if (r >= n_rec) return;
+    uint32_t s[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t li = 4 * r + k;
+        const uint32_t b = li == 0 ? 0u : line_end[li - 1] + 1u;
+        uint32_t e = line_end[li];
+        while (e > b && is_space(text[e - 1])) --e;
+        s[k] = b;
+        l[k] = e - b;
+    }
+    out.name_off[r] = s[0]; out.name_len[r] = l[0];
+    out.seq_off[r] = s[1];  out.seq_len[r] = l[1];
+    out.plus_off[r] = s[2]; out.plus_len[r] = l[2];
+    out.qual_off[r] = s[3]; out.qual_len[r] = l[3];
+    if (l[0] == 0 || l[1] == 0 || l[2] == 0 || l[3] == 0) atomicMin(&meta->first_empty, (unsigned int)r);
+    else if (l[1] != l[3]) atomicMin(&meta->first_mismatch, (unsigned int)r);
+    atomicMax(&meta->max_len, l[1]);
+}
+
+// ---- canonical offsets on the device ------------------------------------------------------------------------------
+struct ChunksOf {      // 16-byte chunks a read occupies in the canonical layout
+    const uint32_t* len;
+    __device__ uint32_t operator()(uint64_t i) const { return (len[i] + 15u) >> 4; }
+};
+
+// ---- formatting -----------------------------------------------------------------------------------------------------
+__device__ __constant__ char FLAG_TEXT[AQC_N_FLAGS][12] = {"GOOD", "BADBCD1", "BADBCD2", "BADTRIM1", "BADTRIM2", "BADBBL",
+                                                            "BADLEN", "BADPOL", "BADLQC", "BADNCT", "BADDIFF", "BADMISMATCH"};
+__device__ __constant__ int FLAG_TEXT_LEN[AQC_N_FLAGS] = {4, 7, 7, 8, 8, 6, 6, 6, 6, 6, 7, 11};
+
+struct TextFile {
+    const uint8_t* text;
+    const uint64_t *seq_off, *qual_off;
+    const uint32_t *name_off, *name_len, *plus_off, *plus_len;
+};
+
+struct FormatView {
+    TextFile f[2];
+    const aqc_result* results;
+    int paired;
+};
+
+// bytes record r contributes to (file, stream); stream 0 = good, 1 = bad
+struct OutSize {
+    FormatView v;
+    int file, stream;
+    __device__ uint32_t operator()(uint64_t r) const {
+        const uint4 w0 = *reinterpret_cast<const uint4*>(v.results + r);
+        const int flag = (int)(w0.x & 0xffu);
+        if ((flag == AQC_GOOD ? 0 : 1) != stream) return 0u;
+        const uint32_t len = file == 0 ? (w0.y & 0xffffu) : (w0.z & 0xffffu);
+        const TextFile& t = v.f[file];
+        return t.name_len[r] + (flag == AQC_GOOD ? 0u : (uint32_t)FLAG_TEXT_LEN[flag]) + 2u * len + t.plus_len[r] + 4u;
+    }
+};
+
+// one wavefront per (record, file): the output record is assembled byte by byte, 64 bytes per step
+__global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, uint64_t n, const unsigned long long* __restrict__ pos /* [2 files][2 streams][n] */,
+                                                                 uint8_t* out00, uint8_t* out01, uint8_t* out10, uint8_t* out11) {
+    const int lane = lane_id();
+    const uint64_t wid = ((uint64_t)blockIdx.x * TXT_BLOCK + threadIdx.x) / WAVE;
+    const int nfiles = v.paired ? 2 : 1;
+    if (wid >= n * nfiles) return;
+    const uint64_t r = wid / nfiles;
+    const int file = (int)(wid % nfiles);
+    const uint4 w0 = *reinterpret_cast<const uint4*>(v.results + r);
+    const uint4 w1 = *(reinterpret_cast<const uint4*>(v.results + r) + 1);
+    const int flag = (int)(w0.x & 0xffu), n_edits = (int)((w0.x >> 8) & 0xffu);
+    const int stream = flag == AQC_GOOD ? 0 : 1;
+    const int len1 = (int)(w0.y & 0xffffu), len2 = (int)(w0.z & 0xffffu), ovl = (int)(w0.w & 0xffffu);
+    const int st = file == 0 ? (int)(w0.x >> 16) : (int)(w0.y >> 16);
+    const int len = file == 0 ? len1 : len2;
+    // the walk's edits in this mate's final coordinates: position, new base (0 = keep), new quality
+    int e_pos[3] = {-1, -1, -1};
+    uint32_t e_val[3] = {0, 0, 0};
+    const unsigned long long e_lo = ((unsigned long long)w1.y << 32) | w1.x, e_hi = ((unsigned long long)w1.w << 32) | w1.z;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        if (e < n_edits) {
+            const int bit = 40 * e;
+            unsigned long long x = bit < 64 ? e_lo >> bit : 0ull;
+            if (bit + 40 > 64) x |= bit < 64 ? e_hi << (64 - bit) : e_hi >> (bit - 64);
+            const int o = (int)(x & 0xffffu);
+            const uint32_t kind = (uint32_t)(x >> 16) & 0xffu, base = (uint32_t)(x >> 24) & 0xffu, qual = (uint32_t)(x >> 32) & 0xffu;
+            const int p = file == 0 ? len1 - ovl + o : len2 - 1 - o;
+            if (kind == AQC_EDIT_MASK) { e_pos[e] = p; e_val[e] = (uint32_t)'!'; }
+            else if ((kind == AQC_EDIT_FIX_R1 && file == 0) || (kind == AQC_EDIT_FIX_R2 && file == 1)) { e_pos[e] = p; e_val[e] = (base << 8) | qual; }
+        }
+    }
+    const TextFile& t = v.f[file];
+    const uint8_t* name = t.text + t.name_off[r];
+    const uint8_t* seq = t.text + t.seq_off[r] + st;
+    const uint8_t* plus = t.text + t.plus_off[r];
+    const uint8_t* qual = t.text + t.qual_off[r] + st;
+    const int nlen = (int)t.name_len[r], plen = (int)t.plus_len[r];
+    const int flen = stream ? FLAG_TEXT_LEN[flag] : 0;
+    // segment boundaries in the output record
+    const int b_name = nlen + flen;            // name' then '\n'
+    const int b_seq = b_name + 1 + len;        // bases then '\n'
+    const int b_plus = b_seq + 1 + plen;       // strand line then '\n'
+    const int b_qual = b_plus + 1 + len;       // qualities then '\n'
+    const int total = b_qual + 1;
+    uint8_t* const outs[4] = {out00, out01, out10, out11};
+    uint8_t* dst = outs[file * 2 + stream] + pos[(uint64_t)(file * 2 + stream) * n + r];
+    for (int j = lane; j < total; j += WAVE) {
+        uint8_t c;
+        if (j < b_name) {
+            // "@" + FLAG + name[1:] for a bad record (preprocesser.py:213-219), the name itself for a good one
+            if (j == 0 || !stream) c = stream ? (uint8_t)'@' : name[j];
+            else if (j <= flen) c = (uint8_t)FLAG_TEXT[flag][j - 1];
+            else c = name[j - flen];
+        } else if (j == b_name || j == b_seq || j == b_plus || j == b_qual) {
+            c = (uint8_t)'\n';
+        } else if (j < b_seq) {
+            const int i = j - b_name - 1;
+            c = seq[i];
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if (i == e_pos[e] && (e_val[e] >> 8)) c = (uint8_t)(e_val[e] >> 8);
+        } else if (j < b_plus) {
+            c = plus[j - b_seq - 1];
+        } else {
+            const int i = j - b_plus - 1;
+            c = qual[i];
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if (i == e_pos[e]) c = (uint8_t)e_val[e];
+        }
+        dst[j] = c;
+    }
+}
+
+}  // namespace aqc

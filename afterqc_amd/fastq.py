@@ -30,6 +30,19 @@ def isFastq(f):
     return False
 
 
+def open_binary(fname):
+    """the byte stream fastq.Reader reads (fastq.py:23-28): .gz / .bz2 decoded transparently"""
+    try:
+        if fname.endswith(".gz"):
+            return gzip.open(fname, "rb")
+        if fname.endswith(".bz2"):
+            return bz2.BZ2File(fname)
+        return open(fname, "rb", buffering=0)
+    except (IOError, OSError):
+        print("Failed to open file " + fname)
+        sys.exit(1)
+
+
 class RawBatch:
     """n framed records inside one text buffer: per line kind an (offset, length) array pair."""
 

@@ -6,7 +6,10 @@ batches, judged by the HIP kernels behind the C ABI (afterqc_amd.capi.Engine) an
 verdict records come back.  This module is I/O and bookkeeping:
 
   pass 1  pre-filter QC sampling + auto-trim            (preprocesser.py:247-280)
-  pass 2  upload -> aqc_run -> aqc_qc_stat(post) -> fetch -> write good/bad/overlap
+  pass 2  text path (default): raw text chunk -> aqc_frame -> aqc_run -> aqc_qc_stat(post) -> aqc_format ->
+          good/bad text back -> files; framing and formatting happen on the device, the host moves bytes
+          host path (barcodes, index files, --store_overlap, --debubble, --qc_only): host framing ->
+          upload -> aqc_run -> aqc_qc_stat(post) -> fetch verdicts -> host writer
   stats   counters -> JSON with the reference's schema  (preprocesser.py:660-778)
 
 There is no CPU compute path: `engine` defaults to the HIP engine, which raises if the library or
@@ -14,6 +17,8 @@ the GPU is missing.  (Tests inject the oracle engine to exercise THIS file's hos
 """
 import json
 import os
+import queue
+import threading
 
 import numpy as np
 
@@ -108,11 +113,150 @@ class _Outputs:
                     w.close()
 
 
+class _TextInput:
+    """One input file as a stream of raw text chunks in two page-locked buffers.  A side thread reads the file into
+    the buffer the main loop is not using; the unconsumed tail of a chunk is carried to the front of the next."""
+
+    def __init__(self, eng, fname, chunk_bytes):
+        self.eng = eng
+        self.f = fastq.open_binary(fname)
+        self.cap = max(int(chunk_bytes), 256)
+        self.bufs = [eng.host_buffer(self.cap), eng.host_buffer(self.cap)]
+        self.req = queue.Queue()
+        self.done = queue.Queue()
+        self.file_eof = False
+        self.thread = threading.Thread(target=self._reader, daemon=True)
+        self.thread.start()
+
+    def _reader(self):
+        while True:
+            job = self.req.get()
+            if job is None:
+                return
+            which, off = job
+            try:
+                view = self.bufs[which].view
+                end = off
+                final = self.file_eof
+                while not final and end < self.cap:
+                    got = self.f.readinto(view[end:self.cap])
+                    if not got:
+                        final = self.file_eof = True
+                    else:
+                        end += got
+                self.done.put((end, final))
+            except BaseException as e:      # surfaced by wait_fill on the main thread
+                self.done.put(e)
+
+    def start_fill(self, which, off):
+        self.req.put((which, off))
+
+    def wait_fill(self):
+        r = self.done.get()
+        if isinstance(r, BaseException):
+            raise r
+        return r
+
+    def grow(self, which):
+        """double both buffers (a single record did not fit)"""
+        ncap = self.cap * 2
+        nb = [self.eng.host_buffer(ncap), self.eng.host_buffer(ncap)]
+        nb[which].array[:self.cap] = self.bufs[which].array[:self.cap]
+        for b in self.bufs:
+            b.free()
+        self.bufs, self.cap = nb, ncap
+
+    def carry(self, cur, consumed, nbytes, final, finished):
+        """tail of buffer `cur` -> head of the other buffer, then ask the reader for the rest of it.
+        `finished`: an empty line ended this file (fastq.py:44-47): nothing after it is ever read"""
+        nxt = 1 - cur
+        if finished:
+            self.file_eof = True
+            self.done.put((0, True))
+            return
+        left = nbytes - consumed
+        if left:
+            self.bufs[nxt].array[:left] = self.bufs[cur].array[consumed:nbytes]
+        if final:
+            self.done.put((left, True))
+        else:
+            self.start_fill(nxt, left)
+
+    def close(self):
+        self.req.put(None)
+        self.thread.join()
+        self.f.close()
+        for b in self.bufs:
+            b.free()
+
+
+class _TextSink:
+    """The good / bad writers of every file fed from the device: formatted streams are fetched into page-locked
+    buffers (two sets) and written by a side thread in order."""
+
+    def __init__(self, eng, writers):
+        self.eng = eng
+        self.writers = writers                       # per file (good, bad)
+        self.sets = [[None] * 4, [None] * 4]
+        self.free = [threading.Semaphore(1), threading.Semaphore(1)]
+        self.q = queue.Queue()
+        self.err = None
+        self.cur = 0
+        self.thread = threading.Thread(target=self._writer, daemon=True)
+        self.thread.start()
+
+    def _writer(self):
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            which, sizes = job
+            try:
+                if self.err is None:
+                    for q4, nbytes in enumerate(sizes):
+                        if nbytes and q4 // 2 < len(self.writers):
+                            self.writers[q4 // 2][q4 % 2].write_bytes(self.sets[which][q4].view[:nbytes])
+            except BaseException as e:
+                self.err = e
+            finally:
+                self.free[which].release()
+
+    def emit(self, slot, sizes):
+        if self.err is not None:
+            raise self.err
+        which = self.cur
+        self.free[which].acquire()                   # the writer is done with this set
+        for q4, nbytes in enumerate(sizes):
+            if q4 // 2 >= len(self.writers) or nbytes == 0:
+                continue
+            buf = self.sets[which][q4]
+            if buf is None or buf.nbytes < nbytes:
+                if buf is not None:
+                    buf.free()
+                buf = self.sets[which][q4] = self.eng.host_buffer(nbytes + nbytes // 4 + 4096)
+            self.eng.fetch_text(slot, q4 // 2, q4 % 2, buf.array, buf.nbytes)
+        self.q.put((which, list(sizes)))
+        self.cur = 1 - which
+
+    def close(self):
+        self.q.put(None)
+        self.thread.join()
+        for st in self.sets:
+            for b in st:
+                if b is not None:
+                    b.free()
+        if self.err is not None:
+            raise self.err
+
+
 class seqFilter:
     """seqFilter(options).run() — preprocesser.py:141-155,234-783."""
 
-    def __init__(self, opt, engine=None, batch_records=1 << 20, device=0):
+    def __init__(self, opt, engine=None, batch_records=1 << 20, device=0, chunk_bytes=64 << 20, use_text_path=True):
         self.options = opt
+        self.chunk_bytes = chunk_bytes
+        self.use_text_path = use_text_path
+        self.text_path = False
         self.engine = engine
         self.device = device
         self.own_engine = False
@@ -208,6 +352,36 @@ class seqFilter:
         # ---- pass 2: the main loop (preprocesser.py:411-631), one batch at a time
         # the per-read settings now include the resolved trim values
         eng.set_config(build_config(opt, paired, has_i2))
+        # text in / text out on the device (aqc_frame / aqc_format) whenever the run needs nothing of the host per
+        # record; barcode name rewriting, index files, --store_overlap, --debubble (name parsing) and --qc_only keep
+        # the host-side framing and writer below
+        self.text_path = (self.use_text_path and not opt.barcode and not opt.store_overlap and not opt.debubble
+                          and not opt.qc_only and not has_i1 and not has_i2)
+        if self.text_path:
+            extra_bases = self._run_text(eng, opt, outs, paired)
+            readers = []
+        else:
+            readers, extra_bases = self._run_host(eng, opt, outs, paired, files)
+        for r in readers:
+            if r is not None:
+                r.close()
+        outs.close()
+
+        r1post.qc()
+        if paired:
+            r2post.qc()
+
+        self.stat = self._stats(eng, r1pre, r2pre, r1post, r2post, readLen, extra_bases)
+        stat_path = os.path.join(qc_dir, os.path.basename(opt.read1_file) + ".json")
+        with open(stat_path, "w") as f:
+            f.write(json.dumps(self.stat, sort_keys=True, indent=4, separators=(',', ': ')))
+        if self.own_engine:
+            eng.close()
+            self.engine = None
+        return self.stat
+
+    # ---- pass 2 with host-side framing / formatting (general: barcodes, index files, overlap store, bubbles) ------
+    def _run_host(self, eng, opt, outs, paired, files):
         readers = [fastq.Reader(f) if f is not None else None for f in files]
         total = 0          # TOTAL_READS so far
         extra_bases = 0    # R1 bases read for a record that a shorter mate file then cut off (:416-421)
@@ -254,23 +428,68 @@ class seqFilter:
             if not opt.qc_only:
                 self._write(outs, rbs, results, n)
             total += n
-        for r in readers:
-            if r is not None:
-                r.close()
-        outs.close()
+        return readers, extra_bases
 
-        r1post.qc()
-        if paired:
-            r2post.qc()
-
-        self.stat = self._stats(eng, r1pre, r2pre, r1post, r2post, readLen, extra_bases)
-        stat_path = os.path.join(qc_dir, os.path.basename(opt.read1_file) + ".json")
-        with open(stat_path, "w") as f:
-            f.write(json.dumps(self.stat, sort_keys=True, indent=4, separators=(',', ': ')))
-        if self.own_engine:
-            eng.close()
-            self.engine = None
-        return self.stat
+    # ---- pass 2, text in / text out: framing and formatting on the device -------------------
+    def _run_text(self, eng, opt, outs, paired):
+        """The loop of preprocesser.py:411-631 over raw text chunks.  Per chunk the host only moves bytes: file ->
+        page-locked buffer -> aqc_frame (records found on the device) -> aqc_run / aqc_qc_stat -> aqc_format
+        (good / bad text built on the device) -> page-locked buffer -> file.  File reads and writes run on side
+        threads while the main thread sits in the (GIL-free) C-ABI calls."""
+        files = [opt.read1_file] + ([opt.read2_file] if paired else [])
+        inputs = [_TextInput(eng, f, self.chunk_bytes) for f in files]
+        sink = _TextSink(eng, [(outs.good[k], outs.bad[k]) for k in range(len(files))])
+        total = 0
+        extra_bases = 0
+        slot = 0
+        cur = 0
+        try:
+            for inp in inputs:
+                inp.start_fill(cur, 0)
+            while True:
+                fills = [inp.wait_fill() for inp in inputs]          # (bytes in buffer `cur`, final)
+                a1, n1, f1 = inputs[0].bufs[cur].array, fills[0][0], fills[0][1]
+                if paired:
+                    info = eng.frame(slot, a1, n1, f1, inputs[1].bufs[cur].array, fills[1][0], fills[1][1], first_index=total)
+                else:
+                    info = eng.frame(slot, a1, n1, f1, first_index=total)
+                n = int(info.n)
+                # lock step (preprocesser.py:412-429): R1 is read first; the first reader to return None ends the loop,
+                # and an R1 record read just before R2 ran dry has already been counted into TOTAL_BASES (:416)
+                done1 = (info.eof1 or f1) and info.avail1 == n
+                done2 = paired and (info.eof2 or fills[1][1]) and info.avail2 == n
+                stop = False
+                if done1:
+                    stop = True
+                elif done2 and info.avail1 > n:
+                    extra_bases = int(info.next_len1)
+                    stop = True
+                if not stop:
+                    consumed = [int(info.consumed1), int(info.consumed2)]
+                    eofs = [bool(info.eof1), bool(info.eof2)]
+                    for k, inp in enumerate(inputs):
+                        if n == 0 and not fills[k][1] and not eofs[k] and (info.avail1, info.avail2)[k] == 0:
+                            inp.grow(cur)                                  # not even one record fits the buffer
+                        inp.carry(cur, consumed[k], fills[k][0], fills[k][1], eofs[k] or (k == 1 and done2))
+                if n:
+                    eng.run(slot)
+                    # post-filter QC on good records while TOTAL_READS < qc_sample (preprocesser.py:624-627)
+                    n_qc = n if opt.qc_sample <= 0 else max(0, min(n, opt.qc_sample - 1 - total))
+                    if n_qc > 0:
+                        eng.qc_stat(slot, capi.QC_R1_POST, 0, 0, n_qc, 1)
+                        if paired:
+                            eng.qc_stat(slot, capi.QC_R2_POST, 1, 0, n_qc, 1)
+                    sizes = eng.format(slot, n)
+                    sink.emit(slot, sizes)
+                    total += n
+                if stop:
+                    break
+                cur = 1 - cur
+        finally:
+            sink.close()
+            for inp in inputs:
+                inp.close()
+        return extra_bases
 
     # ---- output formatting (writeReads, preprocesser.py:206-232; fastq.Writer.writeLines) ------------
     def _write(self, outs, rbs, results, n):

@@ -245,6 +245,49 @@ int aqc_get_qc(aqc_ctx* ctx, int which, int64_t* out /* [AQC_QC_ROWS * AQC_QC_CO
 int aqc_get_kmers(aqc_ctx* ctx, int which, uint64_t* keys, int64_t* counts, uint64_t* order,
                   uint64_t cap, uint64_t* n);
 
+/* ---- text in / text out: FASTQ framing and output formatting on the device --------------------- */
+/* One chunk of raw FASTQ text per input file, exactly as read from the (decompressed) file.  aqc_frame
+ * replaces fastq.Reader.nextRead (fastq.py:37-49) for every record of the chunk: a record is 4 lines, each
+ * readline().rstrip(); a line that is empty after stripping ends that file (eof); a trailing partial record
+ * stays in the chunk (bytes >= consumed) and must be presented again at the head of the next chunk unless
+ * `final` (nothing follows: an unterminated last line counts as a line, a partial group is dropped).
+ * Mate files are read in lock step (preprocesser.py:412-429): n = min(avail1, avail2, max_records).
+ * After aqc_frame the slot holds the n records exactly as after aqc_upload (the text is the arena), so
+ * aqc_run / aqc_qc_stat / aqc_fetch_results apply.  Chunks must be < 4 GiB. */
+typedef struct aqc_text_chunk {
+    const uint8_t* text1;
+    uint64_t bytes1;
+    const uint8_t* text2;   /* NULL: single-end */
+    uint64_t bytes2;
+    int32_t final1, final2; /* no more bytes will follow this chunk in that file */
+    uint64_t max_records;   /* cap on n (UINT64_MAX: none) */
+    uint64_t first_index;   /* 0-based global index of the chunk's first record */
+} aqc_text_chunk;
+
+typedef struct aqc_frame_info {
+    uint64_t n;             /* records now in the slot */
+    uint64_t avail1, avail2;       /* complete records each chunk held before its first empty line */
+    uint64_t consumed1, consumed2; /* bytes of each chunk that belong to records [0, n) */
+    int32_t eof1, eof2;     /* an empty line ended that file inside this chunk (fastq.py:44-47) */
+    uint32_t max_len;       /* longest sequence line framed */
+    uint32_t next_len1;     /* bases of R1's record n when avail1 > n, else 0: the record the reference has
+                               already added to TOTAL_BASES when a shorter mate file ends the loop
+                               (preprocesser.py:416-421) */
+} aqc_frame_info;
+
+int aqc_frame(aqc_ctx* ctx, int slot, const aqc_text_chunk* chunk, aqc_frame_info* info);
+/* seqFilter.writeReads (preprocesser.py:206-232) + fastq.Writer.writeLines (fastq.py:87-93) for records
+ * [0, n) of a framed slot after aqc_run: builds, in record order, the text of the good and of the bad output
+ * of each file (name / bases / strand line / qualities + "\n"; bad names "@" + FLAG + name[1:]; trimmed
+ * slices with the walk's edits applied).  bytes_out = {good R1, bad R1, good R2, bad R2}.  Barcode name
+ * rewriting, index files and --store_overlap are not handled here (AQC_ERR_UNSUPPORTED / host side). */
+int aqc_format(aqc_ctx* ctx, int slot, uint64_t n, uint64_t bytes_out[4]);
+/* copy one formatted stream (file 0/1, stream 0 good / 1 bad) to host memory and wait for it */
+int aqc_fetch_text(aqc_ctx* ctx, int slot, int file, int stream, uint8_t* dst, uint64_t cap);
+/* page-locked host memory for text chunks and fetched streams (hipHostMalloc): full-rate DMA */
+void* aqc_host_alloc(uint64_t bytes);
+void aqc_host_free(void* p);
+
 /* ---- function seams (same device code as the hot path, one result per input) ------------------ */
 /* util.overlap(r1, r2) (util.py:88-89,158-212) for n pairs -> offset / overlap_len / diff */
 int aqc_overlap(aqc_ctx* ctx, const aqc_batch* pairs, int32_t* offset, int32_t* overlap_len, int32_t* diff);

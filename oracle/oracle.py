@@ -270,6 +270,121 @@ class OracleEngine:
         return np.array([editDistance(batch.read1(i)[0], batch.read2(i)[0]) for i in range(batch.n)], dtype=np.int32)
 
 
+# ---- text in / text out: scalar restatement of fastq.Reader.nextRead and seqFilter.writeReads ------------------
+FLAG_NAMES_B = [n.encode() for n in capi.FLAG_NAMES]
+
+
+def frame_text(buf, final):
+    """fastq.py:37-49 over one chunk of text.  Returns (records, avail, eof, line_ends) where records[r] = four
+    (start, stripped_length) pairs, avail = complete records before the first empty line, eof = such a line was
+    met, line_ends[i] = byte offset just behind line i (what a reader has consumed after readline() number i)."""
+    buf = bytes(buf)
+    lines, ends = [], []
+    pos, n = 0, len(buf)
+    while pos < n:
+        nl = buf.find(b"\n", pos)
+        if nl < 0:
+            if not final:
+                break                       # incomplete line: wait for more text
+            end, nxt = n, n                 # unterminated last line of the file: readline() still returns it
+        else:
+            end, nxt = nl, nl + 1
+        lines.append((pos, len(buf[pos:end].rstrip())))     # bytes.rstrip(): space \t \n \r \v \f
+        ends.append(nxt)
+        pos = nxt
+    nrec = len(lines) // 4
+    records = [lines[4 * r:4 * r + 4] for r in range(nrec)]
+    avail, eof = nrec, False
+    for r in range(nrec):
+        if any(l == 0 for _, l in records[r]):              # fastq.py:44-47
+            avail, eof = r, True
+            break
+    return records, avail, eof, ends
+
+
+class _HostBuffer:
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.array = np.zeros(self.nbytes, dtype=np.uint8)
+        self.view = memoryview(self.array)
+
+    def free(self):
+        pass
+
+
+def _oracle_frame(self, slot, text1, bytes1, final1, text2=None, bytes2=0, final2=False, max_records=capi.UINT64_MAX,
+                  first_index=0):
+    files = [(text1, bytes1, final1)] + ([(text2, bytes2, final2)] if text2 is not None else [])
+    framed = []
+    for text, nbytes, final in files:
+        buf = np.asarray(text)[:nbytes].tobytes()
+        framed.append((buf,) + frame_text(buf, final))
+    n = min(f[2] for f in framed)
+    n = min(n, max_records)
+    info = capi.FrameInfo()
+    info.n = n
+    b = capi.Batch(n, first_index)
+    lines = []
+    mx = 0
+    for k, (buf, records, avail, eof, ends) in enumerate(framed):
+        arena = np.zeros(len(buf) + 64, dtype=np.uint8)
+        arena[:len(buf)] = np.frombuffer(buf, dtype=np.uint8)
+        so = np.array([records[r][1][0] for r in range(n)], dtype=np.uint64)
+        sl = np.array([records[r][1][1] for r in range(n)], dtype=np.uint32)
+        qo = np.array([records[r][3][0] for r in range(n)], dtype=np.uint64)
+        ql = [records[r][3][1] for r in range(n)]
+        if list(sl) != ql:
+            raise capi.AqcError(-2, "malformed FASTQ: sequence and quality lines differ in length")
+        for r in range(len(records)):
+            mx = max(mx, records[r][1][1])
+        consumed = min(ends[4 * n - 1], len(buf)) if n else 0
+        if k == 0:
+            b.seq1 = b.qual1 = arena
+            b.off1, b.qoff1, b.len1 = so, qo, sl
+            info.avail1, info.eof1, info.consumed1 = avail, int(eof), consumed
+            info.next_len1 = records[n][1][1] if avail > n else 0
+        else:
+            b.seq2 = b.qual2 = arena
+            b.off2, b.qoff2, b.len2 = so, qo, sl
+            info.avail2, info.eof2, info.consumed2 = avail, int(eof), consumed
+        lines.append((buf, records))
+    info.max_len = mx
+    self.upload(slot, b)
+    self._text = getattr(self, "_text", {})
+    self._text[slot] = lines
+    self._fmt = getattr(self, "_fmt", {})
+    self._fmt.pop(slot, None)
+    return info
+
+
+def _oracle_format(self, slot, n):
+    """seqFilter.writeReads (preprocesser.py:206-232) + Writer.writeLines (fastq.py:87-93) without barcode/overlap"""
+    res = self.results[slot]
+    b = self.slots[slot]
+    out = [bytearray(), bytearray(), bytearray(), bytearray()]
+    for k, (buf, records) in enumerate(self._text[slot]):
+        for r in range(n):
+            (no, nl), (so, sl), (po, pl), (qo, ql) = records[r]
+            name, plus = buf[no:no + nl], buf[po:po + pl]
+            rr = res[r]
+            seq, qual = final_read(buf[so:so + sl], buf[qo:qo + ql], rr, k + 1)
+            flag = int(rr["flag"])
+            stream = 0 if flag == capi.GOOD else 1
+            if stream:
+                name = b"@" + FLAG_NAMES_B[flag] + name[1:]
+            out[2 * k + stream] += name + b"\n" + seq + b"\n" + plus + b"\n" + qual + b"\n"
+    self._fmt[slot] = [bytes(o) for o in out]
+    return [len(o) for o in out]
+
+
+def _oracle_fetch_text(self, slot, file, stream, dst, cap):
+    data = self._fmt[slot][2 * file + stream]
+    if len(data) > cap:
+        raise capi.AqcError(-2, "fetch_text: destination too small")
+    if data:
+        dst[:len(data)] = np.frombuffer(data, dtype=np.uint8)
+
+
 def final_read(seq, qual, r, which):
     """Apply a result record (trim extents + edits) to the original read -> final (seq, qual)."""
     if which == 1:
@@ -287,3 +402,9 @@ def final_read(seq, qual, r, which):
         elif (kind == capi.EDIT_FIX_R1 and which == 1) or (kind == capi.EDIT_FIX_R2 and which == 2):
             s[p] = int(e["base"]); q[p] = int(e["qual"])
     return bytes(s), bytes(q)
+
+
+OracleEngine.host_buffer = lambda self, nbytes: _HostBuffer(nbytes)
+OracleEngine.frame = _oracle_frame
+OracleEngine.format = _oracle_format
+OracleEngine.fetch_text = _oracle_fetch_text

@@ -374,6 +374,62 @@ def gen_function_vectors():
 
 
 # --------------------------------------------------------------------------------------------
+# record framing (fastq.Reader.nextRead, fastq.py:37-49) on awkward texts
+# --------------------------------------------------------------------------------------------
+def framing_texts():
+    import random
+    rng = random.Random(77)
+    rec = lambda i, L=12, name_extra="": "@r%d%s\n%s\n+\n%s\n" % (i, name_extra, rand_seq(rng, L), "I" * L)
+    base = "".join(rec(i, rng.randint(5, 40)) for i in range(6))
+    texts = {
+        "plain": base,
+        "crlf": base.replace("\n", "\r\n"),
+        "trailing_ws": "@a x \t\nACGTACGT \n+ \nIIIIIIII\t \n@b\nAC\n+\nII\n",
+        "no_final_newline": base[:-1],
+        "no_final_newline_ws": base[:-1] + "  ",
+        "partial_record": base + "@tail\nACGT\n",
+        "partial_one_line": base + "@tail",
+        "empty_line_mid": rec(0) + rec(1) + "\n" + rec(2) + rec(3),
+        "ws_only_line_mid": rec(0) + "@x\nACGT\n \t \nIIII\n" + rec(2),
+        "empty_seq_line": rec(0) + "@x\n\n+\n\n" + rec(2),
+        "empty_first_line": "\n" + base,
+        "empty_file": "",
+        "only_newlines": "\n\n\n\n",
+        "one_record": rec(0),
+        "long_lines": rec(0, 300) + rec(1, 1000) + rec(2, 65) + rec(3, 64) + rec(4, 63),
+        "name_with_spaces": rec(0, 10, " 1:N:0:ACGT extra  words") + rec(1, 10, "\tTAB"),
+        "plus_with_name": "@a\nACGT\n+a comment\nIIII\n@b\nAC\n+\nII\n",
+        "vt_ff_tail": "@a\x0b\nACGT\x0c\n+\nIIII\n",
+        "inner_ws_kept": "@a b\nAC GT\n+\nII II\n",
+        "at_in_quality": "@a\nACGT\n+\n@@@@\n@b\nACGT\n+\n@III\n",
+        "five_lines": rec(0) + "@x\nACGT\n+\n",
+        "many": "".join(rec(i, rng.randint(5, 120)) for i in range(300)),
+    }
+    return texts
+
+
+def gen_text_vectors():
+    install_shim()
+    import fastq as ref_fastq
+    out = {}
+    work = tempfile.mkdtemp(prefix="aqc_txt_")
+    for name, text in framing_texts().items():
+        path = os.path.join(work, name + ".fq")
+        with open(path, "w", newline="") as f:
+            f.write(text)
+        r = ref_fastq.Reader(path)
+        recs = []
+        while True:
+            rec = r.nextRead()
+            if rec is None:
+                break
+            recs.append(list(rec))
+        out[name] = {"text": text, "records": recs}
+    shutil.rmtree(work)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # end-to-end cases (G1, G3): the table lives in cases.py so the tests rebuild the same inputs
 # --------------------------------------------------------------------------------------------
 def e2e_cases():
@@ -399,6 +455,11 @@ def main():
         with gzip.open(os.path.join(HERE, "function_vectors.json.gz"), "wt") as f:
             json.dump(vec, f)
         print("function vectors:", {k: len(v) for k, v in vec.items()})
+    if not only or "text" in only:
+        vec = gen_text_vectors()
+        with gzip.open(os.path.join(HERE, "text_vectors.json.gz"), "wt") as f:
+            json.dump(vec, f, sort_keys=True)
+        print("framing vectors:", {k: len(v["records"]) for k, v in vec.items()})
     if not only or "e2e" in only or any(o.startswith("case:") for o in only):
         path = os.path.join(HERE, "e2e_cases.json.gz")
         recs = {}

@@ -3,12 +3,13 @@ reference's outputs byte for byte (the same 36 golden cases test_host_golden.py 
 import pytest
 
 import cases
-from test_host_golden import check_case, run_case
+from test_host_golden import MODES, check_case, run_case
 
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("name", [c[0] for c in cases.CASES])
-def test_e2e_on_gpu(name, tmp_path, e2e, gpu_engine):
-    work, stat = run_case(name, tmp_path, gpu_engine)
+def test_e2e_on_gpu(name, mode, tmp_path, e2e, gpu_engine):
+    work, stat = run_case(name, tmp_path, gpu_engine, mode)
     check_case(name, work, stat, e2e)

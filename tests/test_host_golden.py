@@ -20,7 +20,14 @@ from afterqc_amd import after
 CASE_TABLE = {c[0]: c for c in cases.CASES}
 
 
-def run_case(name, tmp_path, engine):
+# how pass 2 is driven: device-side framing/formatting with production-size chunks, the same with chunks of a few
+# records (every carry-over / lock-step corner is hit many times per file), and the host-side framing / writer
+MODES = {"text": dict(use_text_path=True), "text_tiny_chunks": dict(use_text_path=True, chunk_bytes=1500),
+         "host": dict(use_text_path=False)}
+
+
+def run_case(name, tmp_path, engine, mode="text", info=None):
+    from afterqc_amd import preprocesser
     _, argv, spec, _ = CASE_TABLE[name]
     work = str(tmp_path)
     cases.materialize(spec, work)
@@ -35,7 +42,10 @@ def run_case(name, tmp_path, engine):
             options.trim_front2 = 0
         else:
             options.barcode = False
-        stat = after.processOptions(options, engine=engine)
+        flt = preprocesser.seqFilter(options, engine=engine, **MODES[mode])     # what after.processOptions does
+        stat = flt.run()
+        if info is not None:
+            info["text_path"] = flt.text_path
     finally:
         os.chdir(cwd)
     return work, stat
@@ -77,8 +87,27 @@ def check_case(name, work, stat, golden):
 CPU_CASES = [c[0] for c in cases.CASES]
 
 
+@pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("name", CPU_CASES)
-def test_host_with_oracle_engine(name, tmp_path, e2e):
+def test_host_with_oracle_engine(name, mode, tmp_path, e2e):
     from oracle import oracle
-    work, stat = run_case(name, tmp_path, oracle.OracleEngine())
+    info = {}
+    work, stat = run_case(name, tmp_path, oracle.OracleEngine(), mode, info)
     check_case(name, work, stat, e2e)
+    if mode == "host":
+        assert not info["text_path"]
+
+
+def test_text_path_is_the_default_path():
+    """the plain PE / SE cases must go through aqc_frame / aqc_format, not through the host writer"""
+    from oracle import oracle
+    import tempfile
+    import pathlib
+    used = {}
+    for name in CPU_CASES:
+        with tempfile.TemporaryDirectory() as d:
+            info = {}
+            run_case(name, pathlib.Path(d), oracle.OracleEngine(), "text", info)
+            used[name] = info["text_path"]
+    assert sum(used.values()) >= len(used) // 2, used
+    assert used["g1_testdata"], used
