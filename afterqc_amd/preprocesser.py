@@ -252,7 +252,7 @@ class _TextSink:
 class seqFilter:
     """seqFilter(options).run() — preprocesser.py:141-155,234-783."""
 
-    def __init__(self, opt, engine=None, batch_records=1 << 20, device=0, chunk_bytes=64 << 20, use_text_path=True):
+    def __init__(self, opt, engine=None, batch_records=1 << 20, device=0, chunk_bytes=8 << 20, use_text_path=True):
         self.options = opt
         self.chunk_bytes = chunk_bytes
         self.use_text_path = use_text_path
@@ -292,6 +292,9 @@ class seqFilter:
         if opt.barcode:
             opt.trim_front = 0
 
+        import time
+        self.timing = {}
+        t_run = time.perf_counter()
         has_i1 = opt.index1_file is not None
         has_i2 = opt.index2_file is not None
         eng.set_config(build_config(opt, paired, has_i2))
@@ -309,6 +312,7 @@ class seqFilter:
             # the R2 file is stat'd through the same single-read path into its own accumulator
             r2pre.statFile(opt.read2_file, fastq.Reader, single, self.batch_records)
         readLen = r1pre.readLen
+        self.timing["pass1_s"] = time.perf_counter() - t_run
 
         # ---- auto trim (preprocesser.py:261-280)
         if opt.trim_front == -1 or opt.trim_tail == -1:
@@ -357,6 +361,7 @@ class seqFilter:
         # the host-side framing and writer below
         self.text_path = (self.use_text_path and not opt.barcode and not opt.store_overlap and not opt.debubble
                           and not opt.qc_only and not has_i1 and not has_i2)
+        t_p2 = time.perf_counter()
         if self.text_path:
             extra_bases = self._run_text(eng, opt, outs, paired)
             readers = []
@@ -366,6 +371,7 @@ class seqFilter:
             if r is not None:
                 r.close()
         outs.close()
+        self.timing["pass2_s"] = time.perf_counter() - t_p2
 
         r1post.qc()
         if paired:
@@ -375,6 +381,7 @@ class seqFilter:
         stat_path = os.path.join(qc_dir, os.path.basename(opt.read1_file) + ".json")
         with open(stat_path, "w") as f:
             f.write(json.dumps(self.stat, sort_keys=True, indent=4, separators=(',', ': ')))
+        self.timing["total_s"] = time.perf_counter() - t_run
         if self.own_engine:
             eng.close()
             self.engine = None

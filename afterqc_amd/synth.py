@@ -237,3 +237,37 @@ def write_fastq(path, names, seq, qual, lens, plus="+"):
             if len(buf) >= 4096:
                 f.write(b"".join(buf)); buf = []
         f.write(b"".join(buf))
+
+
+def write_fastq_fixed(path, seq, qual, mate=1, tile=1101):
+    """Fixed-length reads as FASTQ text, vectorised (benchmarks: millions of records).  Names follow SURVEY.md
+    §8d: @SIM:1:FC1:1:<tile>:<x = 7-digit record index>:<y> <mate>:N:0:ACGT"""
+    n, L = seq.shape
+    head = ("@SIM:1:FC1:1:%d:" % tile).encode()
+    tail = (" %d:N:0:ACGT\n" % mate).encode()
+    idx = np.arange(n, dtype=np.int64)
+    digits = np.empty((n, 7), dtype=np.uint8)
+    for d in range(7):
+        digits[:, 6 - d] = (idx // (10 ** d)) % 10 + 48
+    y = (idx * 7919) % 100000
+    ydig = np.empty((n, 5), dtype=np.uint8)
+    for d in range(5):
+        ydig[:, 4 - d] = (y // (10 ** d)) % 10 + 48
+    w = len(head) + 7 + 1 + 5 + len(tail) + L + 1 + 2 + L + 1
+    chunk = 1 << 18
+    with open(path, "wb") as f:
+        for a in range(0, n, chunk):
+            b = min(n, a + chunk)
+            m = np.empty((b - a, w), dtype=np.uint8)
+            c = 0
+            m[:, c:c + len(head)] = np.frombuffer(head, dtype=np.uint8); c += len(head)
+            m[:, c:c + 7] = digits[a:b]; c += 7
+            m[:, c] = ord(":"); c += 1
+            m[:, c:c + 5] = ydig[a:b]; c += 5
+            m[:, c:c + len(tail)] = np.frombuffer(tail, dtype=np.uint8); c += len(tail)
+            m[:, c:c + L] = seq[a:b]; c += L
+            m[:, c] = 10; c += 1
+            m[:, c] = ord("+"); m[:, c + 1] = 10; c += 2
+            m[:, c:c + L] = qual[a:b]; c += L
+            m[:, c] = 10
+            m.tofile(f)

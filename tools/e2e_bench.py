@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""File-to-file throughput of the drop-in CLI path (not the bench.py metric: that one is HBM-resident).
+
+  python tools/e2e_bench.py --pairs 2000000 --mode text      # device framing / formatting (default path)
+  python tools/e2e_bench.py --pairs 200000 --mode host       # host framing / Python writer (general path)
+
+Writes config-3 style R1/R2 FASTQ files to --dir, runs afterqc_amd.preprocesser.seqFilter on them exactly as
+`python -m afterqc_amd.after -1 R1.fq -2 R2.fq -f 0 -t 0` would, and prints one JSON line with the wall time of the
+pre-filter sampling pass, of pass 2 (read -> filter -> write) and of the whole run."""
+import argparse
+import json
+import os
+import shutil
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=2_000_000)
+    ap.add_argument("--mode", default="text", choices=["text", "host"])
+    ap.add_argument("--chunk-mb", type=int, default=8)
+    ap.add_argument("--dir", default="/tmp/aqc_e2e")
+    ap.add_argument("--single", action="store_true")
+    ap.add_argument("--keep", action="store_true")
+    args = ap.parse_args()
+    from afterqc_amd import after, preprocesser, synth
+    os.makedirs(args.dir, exist_ok=True)
+    r1, r2 = os.path.join(args.dir, "R1.fq"), os.path.join(args.dir, "R2.fq")
+    t = time.perf_counter()
+    d = synth.make_pairs(args.pairs, 150, seed=1003, workers=max(1, (os.cpu_count() or 8) // 2))
+    synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
+    if not args.single:
+        synth.write_fastq_fixed(r2, d["seq2"], d["qual2"], 2)
+    del d
+    gen_s = time.perf_counter() - t
+    argv = ["-1", r1] + ([] if args.single else ["-2", r2]) + ["-f", "0", "-t", "0", "-g", os.path.join(args.dir, "good"),
+                                                              "-b", os.path.join(args.dir, "bad"), "-r", os.path.join(args.dir, "QC")]
+    options, _ = after.parseCommand(argv)
+    after.finalize_options(options)
+    options.barcode = False
+    flt = preprocesser.seqFilter(options, use_text_path=args.mode == "text", chunk_bytes=args.chunk_mb << 20)
+    t = time.perf_counter()
+    stat = flt.run()
+    wall = time.perf_counter() - t
+    reads = args.pairs * (1 if args.single else 2)
+    in_bytes = os.path.getsize(r1) + (0 if args.single else os.path.getsize(r2))
+    s = stat["afterqc_main_summary"]
+    out = {"mode": args.mode, "pairs": args.pairs, "reads": reads, "input_bytes": in_bytes, "gen_s": round(gen_s, 1),
+           "wall_s": round(wall, 3), "pass1_s": round(flt.timing["pass1_s"], 3), "pass2_s": round(flt.timing["pass2_s"], 3),
+           "e2e_mreads_s": round(reads / wall / 1e6, 3), "pass2_mreads_s": round(reads / flt.timing["pass2_s"] / 1e6, 3),
+           "pass2_input_gb_s": round(in_bytes / flt.timing["pass2_s"] / 1e9, 3),
+           "good_reads": s["good_reads"], "bad_reads": s["bad_reads"], "text_path": flt.text_path}
+    print(json.dumps(out))
+    if not args.keep:
+        shutil.rmtree(args.dir, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
