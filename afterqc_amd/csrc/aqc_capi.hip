@@ -282,7 +282,7 @@ void aqc_destroy(aqc_ctx* c) {
         (void)hipFree(c->qc[k].acc);
         if (c->qc[k].kt.keys) {
             (void)hipFree(c->qc[k].kt.keys); (void)hipFree(c->qc[k].kt.counts); (void)hipFree(c->qc[k].kt.order);
-            (void)hipFree(c->qc[k].kt.dense_count); (void)hipFree(c->qc[k].kt.dense_first);
+            (void)hipFree(c->qc[k].kt.dense_count); (void)hipFree(c->qc[k].kt.dense_first); (void)hipFree(c->qc[k].kt.complete);
         }
     }
     delete c;
@@ -349,6 +349,7 @@ int aqc_reset_stats(aqc_ctx* c) {
             HIP_TRY(hipMemset(c->qc[k].kt.order, 0xff, sizeof(unsigned long long) * KMER_CAP));
             HIP_TRY(hipMemset(c->qc[k].kt.dense_count, 0, sizeof(unsigned int) * DENSE_CAP));
             HIP_TRY(hipMemset(c->qc[k].kt.dense_first, 0xff, sizeof(unsigned long long) * DENSE_CAP));
+            HIP_TRY(hipMemset(c->qc[k].kt.complete, 0, sizeof(unsigned int) * (DENSE_ENTRIES / KRED_ENTRIES)));
         }
     }
     HIP_TRY(hipDeviceSynchronize());   // (non-blocking slot streams do not wait for the null stream)
@@ -573,6 +574,8 @@ static int ensure_kmer(aqc_ctx* c, QcDev& q) {
     HIP_TRY(hipMalloc((void**)&q.kt.dense_first, sizeof(unsigned long long) * DENSE_CAP));
     HIP_TRY(hipMemset(q.kt.dense_count, 0, sizeof(unsigned int) * DENSE_CAP));
     HIP_TRY(hipMemset(q.kt.dense_first, 0xff, sizeof(unsigned long long) * DENSE_CAP));
+    HIP_TRY(hipMalloc((void**)&q.kt.complete, sizeof(unsigned int) * (DENSE_ENTRIES / KRED_ENTRIES)));
+    HIP_TRY(hipMemset(q.kt.complete, 0, sizeof(unsigned int) * (DENSE_ENTRIES / KRED_ENTRIES)));
     // the slot streams are non-blocking: make sure the fills have landed before any kernel can touch the tables
     HIP_TRY(hipDeviceSynchronize());
     return 0;
@@ -632,7 +635,7 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
                                chunk, post, (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.kt, order_base + done,
                                (uint16_t*)c->kmer_partial.p, rpr, n_rounds, c->status);
             hipLaunchKernelGGL(kmer_reduce_kernel, dim3(DENSE_ENTRIES / KRED_ENTRIES), dim3(KRED_BLOCK), 0, s->stream,
-                               (const uint16_t*)c->kmer_partial.p, n_rounds, q.kt.dense_count);
+                               (const uint16_t*)c->kmer_partial.p, n_rounds, q.kt, c->cfg.qc_kmer);
             done += chunk;
         }
     }

@@ -636,9 +636,15 @@ struct KmerTable {
     // the dictionary is read back.
     unsigned int* dense_count;         // [N_XCD][4^k]
     unsigned long long* dense_first;   // [N_XCD][4^k] smallest scan time t at which the k-mer was seen (~0 = never)
+    // complete[b] != 0: every dense entry of reduce-workgroup b has a first-seen time (written by kmer_reduce_kernel).
+    // Time keys only grow from launch to launch, so once every entry has one no later launch can lower any of them
+    // and kmer_count_kernel stops probing the first-seen table (for random DNA that is after ~10^4 reads).
+    unsigned int* complete;            // [DENSE_ENTRIES / KRED_ENTRIES]
 };
 constexpr int N_XCD = 8;
 constexpr uint32_t DENSE_ENTRIES = 1u << 16;   // 4^8
+constexpr int KRED_BLOCK = 256;
+constexpr int KRED_ENTRIES = 256;       // dense entries per kmer_reduce_kernel workgroup
 
 // id of the XCD this wave runs on (HW_REG_XCC_ID, bits 3:0)
 __device__ __forceinline__ uint32_t xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & (N_XCD - 1); }
@@ -982,15 +988,19 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
         kmer_slot2(kt, key, rkey, h, hr);
         if (h < 0 || hr < 0) atomicCAS(status, 0, AQC_ERR_UNSUPPORTED);
         else {
+            // (the minima are load-guarded: after its first occurrence a k-mer costs one atomic, not three)
+            const unsigned long long oa = kt.order[h], ob = kt.order[hr];
             atomicAdd(&kt.counts[h], 1ull);
-            atomicMin(&kt.order[h], 2 * t);
-            atomicMin(&kt.order[hr], 2 * t + 1);
+            if (oa > 2 * t) atomicMin(&kt.order[h], 2 * t);
+            if (ob > 2 * t + 1) atomicMin(&kt.order[hr], 2 * t + 1);
         }
     };
     const uint32_t imask = (1u << (2 * kmer_len)) - 1u, kbits = (1u << kmer_len) - 1u;
     unsigned long long* const my_first = kt.dense_first + (size_t)xcc_id() * DENSE_ENTRIES;
     auto usable = [&](const ReadDesc& d) { return d.len >= 5 && d.len <= AQC_MAX_READ_LEN && d.len > kmer_len; };
     KPROF_DECL
+    // every dense k-mer already has a first-seen time from an earlier launch: nothing this launch sees can be earlier
+    const bool complete = __syncthreads_and(threadIdx.x < (int)(DENSE_ENTRIES / KRED_ENTRIES) ? (int)kt.complete[threadIdx.x] : 1) != 0;
     constexpr uint32_t PAD = 0x41414141u;      // 'AAAA': bases beyond the read never reach a counted k-mer
     for (uint32_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
         for (int i = threadIdx.x; i < (int)(DENSE_ENTRIES / 2); i += KMER_BLOCK) ktab[i] = 0;
@@ -1045,22 +1055,18 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
                             idx[j] = (win >> (2 * j)) & imask;
                             exotic[j] = act && ((badwin >> j) & kbits) != 0u;
                             dense[j] = act && !exotic[j];
-#if !(defined(AQC_ABLATE) && (AQC_ABLATE == 41 || AQC_ABLATE == 43))
                             if (dense[j]) atomicAdd(&ktab[idx[j] >> 1], 1u << (16 * (idx[j] & 1)));
-#endif
                         }
                         KPROF(3);
-                        unsigned long long seen[4];
+                        if (!complete) {
+                            unsigned long long seen[4];
 #pragma unroll
-#if defined(AQC_ABLATE) && (AQC_ABLATE == 42 || AQC_ABLATE == 43)
-                        for (int j = 0; j < 4; ++j) seen[j] = 0ull;
-#else
-                        for (int j = 0; j < 4; ++j) seen[j] = dense[j] ? my_first[idx[j]] : 0ull;
-#endif
+                            for (int j = 0; j < 4; ++j) seen[j] = dense[j] ? my_first[idx[j]] : 0ull;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const unsigned long long t = t0 + (unsigned long long)(x + j);
-                            if (dense[j] && seen[j] > t) __hip_atomic_fetch_min(&my_first[idx[j]], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            for (int j = 0; j < 4; ++j) {
+                                const unsigned long long t = t0 + (unsigned long long)(x + j);
+                                if (dense[j] && seen[j] > t) __hip_atomic_fetch_min(&my_first[idx[j]], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
                         }
                         KPROF(4);
                         if (__ballot(badwin != 0u)) {
@@ -1108,11 +1114,8 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
 // dense_count[XCD 0 copy][idx] += sum over rounds of partial[round][idx]
 // A workgroup owns 256 adjacent entries; its four waves take every fourth round each, a lane adds four entries
 // (one 8-byte load per round, 512 contiguous bytes per wave) and the four partial sums meet in LDS.
-constexpr int KRED_BLOCK = 256;
-constexpr int KRED_ENTRIES = 256;       // entries per workgroup
-
 __global__ __launch_bounds__(KRED_BLOCK) void kmer_reduce_kernel(const uint16_t* __restrict__ partial, uint32_t n_rounds,
-                                                                 unsigned int* __restrict__ dense_count) {
+                                                                 KmerTable kt, int kmer_len) {
     __shared__ unsigned int part[4][KRED_ENTRIES];
     const int quad = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const uint32_t e0 = blockIdx.x * KRED_ENTRIES + 4 * quad;
@@ -1125,7 +1128,15 @@ __global__ __launch_bounds__(KRED_BLOCK) void kmer_reduce_kernel(const uint16_t*
     part[grp][4 * quad + 0] = s0; part[grp][4 * quad + 1] = s1; part[grp][4 * quad + 2] = s2; part[grp][4 * quad + 3] = s3;
     __syncthreads();
     const int i = threadIdx.x;
-    dense_count[blockIdx.x * KRED_ENTRIES + i] += part[0][i] + part[1][i] + part[2][i] + part[3][i];
+    const uint32_t idx = blockIdx.x * KRED_ENTRIES + i;
+    kt.dense_count[idx] += part[0][i] + part[1][i] + part[2][i] + part[3][i];
+    // does every entry of this workgroup have a first-seen time by now (in any XCD's copy)?
+    bool seen = idx >= (1u << (2 * kmer_len));
+    if (!kt.complete[blockIdx.x]) {
+        for (int x = 0; x < N_XCD && !seen; ++x) seen = kt.dense_first[(size_t)x * DENSE_ENTRIES + idx] != ~0ull;
+        const int all = __syncthreads_and(seen ? 1 : 0);
+        if (threadIdx.x == 0 && all) kt.complete[blockIdx.x] = 1u;
+    }
 }
 
 // compact the occupied k-mer slots into dense arrays
