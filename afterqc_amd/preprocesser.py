@@ -307,10 +307,15 @@ class seqFilter:
         r1post = QualityControl(opt.qc_sample, opt.qc_kmer, eng, capi.QC_R1_POST)
         r2post = QualityControl(opt.qc_sample, opt.qc_kmer, eng, capi.QC_R2_POST)
         single = lambda rb: capi.Batch.from_raw(rb)
-        r1pre.statFile(opt.read1_file, fastq.Reader, single, self.batch_records)
-        if paired:
-            # the R2 file is stat'd through the same single-read path into its own accumulator
-            r2pre.statFile(opt.read2_file, fastq.Reader, single, self.batch_records)
+        if self.use_text_path and hasattr(eng, "frame"):
+            r1pre.statFileText(opt.read1_file, self.chunk_bytes)
+            if paired:
+                r2pre.statFileText(opt.read2_file, self.chunk_bytes)
+        else:
+            r1pre.statFile(opt.read1_file, fastq.Reader, single, self.batch_records)
+            if paired:
+                # the R2 file is stat'd through the same single-read path into its own accumulator
+                r2pre.statFile(opt.read2_file, fastq.Reader, single, self.batch_records)
         readLen = r1pre.readLen
         self.timing["pass1_s"] = time.perf_counter() - t_run
 

@@ -22,6 +22,25 @@ READ_TO_SKIP = 1000                 # qualitycontrol.py:333
 _BASE_TOP, _BASE_BOTTOM, _GC_TOP, _GC_BOTTOM, _QUAL_BOTTOM = 0.4, 0.15, 0.7, 0.3, 20.0
 
 
+class _KmerView:
+    """(k-mer, count) pairs in sortKmer order without materialising 4^k Python strings"""
+
+    def __init__(self, qc, order):
+        self.qc, self.order = qc, order
+
+    def __len__(self):
+        return len(self.order)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [(self.qc._kmer_str(int(j)), int(self.qc._kmer_cnt[j])) for j in self.order[i]]
+        j = int(self.order[i])
+        return (self.qc._kmer_str(j), int(self.qc._kmer_cnt[j]))
+
+    def __iter__(self):
+        return iter(self[:])
+
+
 class QualityControl:
     """One of the four QC objects of preprocesser.py:247-254, backed by a device accumulator block."""
 
@@ -33,19 +52,35 @@ class QualityControl:
         self.readCount = 0
         self.readLen = 0
         self.acc = np.zeros((capi.QC_ROWS, capi.AQC_QC_COLS), dtype=np.int64)
-        self.kmerCount = {}
-        self.topKmerCount = []
+        self._kmer_raw = b""            # k-mer keys (8 bytes each) in dictionary (= first insertion) order
+        self._kmer_cnt = np.zeros(0, dtype=np.int64)
+        self._kmer_sorted = None
 
     # ---- device -> host -------------------------------------------------------------------------
     def pull(self):
         self.acc = self.engine.qc(self.which)
         keys, counts, order = self.engine.kmers(self.which)
         rank = np.argsort(order, kind="stable")
-        raw = np.ascontiguousarray(keys[rank]).astype("<u8").tobytes()
-        cnt = counts[rank].tolist()
-        k = self.kmerLen
-        # python dicts keep insertion order: this IS the reference's dict under py3 (ties: App. B-12)
-        self.kmerCount = {raw[8 * j:8 * j + k].decode("latin-1"): cnt[j] for j in range(len(cnt))}
+        # insertion order of the reference's dict under py3 (ties: App. B-12); strings are only built on demand
+        self._kmer_raw = np.ascontiguousarray(keys[rank]).astype("<u8").tobytes()
+        self._kmer_cnt = np.ascontiguousarray(counts[rank])
+        self._kmer_sorted = None
+
+    def _kmer_str(self, j):
+        return self._kmer_raw[8 * j:8 * j + self.kmerLen].decode("latin-1")
+
+    @property
+    def kmerCount(self):
+        """the reference's kmerCount dict (insertion-ordered)"""
+        cnt = self._kmer_cnt.tolist()
+        return {self._kmer_str(j): cnt[j] for j in range(len(cnt))}
+
+    @property
+    def topKmerCount(self):
+        """sortKmer (qualitycontrol.py:155-156): stable, count-descending over dict order; a lazy sequence"""
+        if self._kmer_sorted is None:
+            self._kmer_sorted = np.argsort(-self._kmer_cnt, kind="stable")
+        return _KmerView(self, self._kmer_sorted)
 
     # ---- derived statistics ----------------------------------------------------------------------
     def qc(self):
@@ -73,8 +108,7 @@ class QualityControl:
             self.baseMeanQual[b] = out
         self.meanDiscontinuity = a[capi.QC_DISCONTINUITY, :n].astype(np.float64) / num
         self.totalKmer = int(a[capi.QC_SCALARS, 0])
-        # sortKmer: stable, count-descending over dict order (qualitycontrol.py:155-156)
-        self.topKmerCount = sorted(self.kmerCount.items(), key=lambda kv: -kv[1])
+        self._kmer_sorted = None        # sortKmer happens lazily (topKmerCount)
 
     def autoTrim(self):
         """qualitycontrol.py:359-408 as two masked scans outward from the centre cycle."""
@@ -116,6 +150,67 @@ class QualityControl:
         return [[k, c] for k, c in self.topKmerCount[:top]]
 
     # ---- sampling policy ----------------------------------------------------------------------------
+    def statFileText(self, filename, chunk_bytes):
+        """statFile (qualitycontrol.py:331-357) with the records framed on the device (aqc_frame): the host only reads
+        the file into a page-locked buffer.  Same policy as statFile below."""
+        from . import fastq
+        eng = self.engine
+        cap = max(int(chunk_bytes), 4 << 20)          # the first chunk must hold the 999 skipped reads (fallback below)
+        f = fastq.open_binary(filename)
+        buf = eng.host_buffer(cap)
+        lo = READ_TO_SKIP - 1
+        hi = lo + self.sampleLimit if self.sampleLimit > 0 else None    # stat 0-based [lo, hi)
+        stop = None if hi is None else hi + 1      # the read whose arrival triggers the break is still consumed
+        head, head_n = None, 0
+        seen = 0
+        left = 0
+        file_eof = False
+        try:
+            while stop is None or seen < stop:
+                end = left
+                while not file_eof and end < cap:
+                    got = f.readinto(buf.view[end:cap])
+                    if not got:
+                        file_eof = True
+                    else:
+                        end += got
+                info = eng.frame(0, buf.array, end, file_eof, max_records=(2 ** 64 - 1) if stop is None else stop - seen,
+                                 first_index=seen)
+                n = int(info.n)
+                if head is None:
+                    head, head_n = buf.array[:int(info.consumed1)].copy(), n
+                a = max(lo, seen)
+                b = seen + n if hi is None else min(hi, seen + n)
+                if b > a:
+                    eng.qc_stat(0, self.which, 0, a - seen, b - a, 0)
+                    eng.sync(0)
+                seen += n
+                if info.eof1 or (file_eof and int(info.avail1) == n):
+                    break
+                if n == 0 and int(info.avail1) == 0:
+                    # not one record fits: double the buffer
+                    nb = eng.host_buffer(cap * 2)
+                    nb.array[:end] = buf.array[:end]
+                    buf.free()
+                    buf, cap, left = nb, cap * 2, end
+                    continue
+                left = end - int(info.consumed1)
+                if left:
+                    buf.array[:left] = buf.array[int(info.consumed1):end].copy()
+            self.readCount = seen
+            if max(0, seen - lo) < READ_TO_SKIP and head is not None and min(lo, seen) > 0:
+                if head_n < min(lo, seen):
+                    raise RuntimeError("the first chunk must hold at least %d records" % lo)
+                pad = np.zeros(len(head) + 64, dtype=np.uint8)
+                pad[:len(head)] = head
+                eng.frame(0, pad, len(head), True, max_records=min(lo, seen), first_index=0)
+                eng.qc_stat(0, self.which, 0, 0, min(lo, seen), 0)
+                eng.sync(0)
+        finally:
+            f.close()
+            buf.free()
+        self.qc()
+
     def statFile(self, filename, open_reader, to_batch, batch_records):
         """statFile (qualitycontrol.py:331-357): reads #1..999 are skipped, the next `sampleLimit`
         reads are stat'd; when fewer than 1000 reads followed the skipped ones, the skipped reads are
