@@ -191,23 +191,57 @@ class _TextInput:
 
 
 class _TextSink:
-    """The good / bad writers of every file fed from the device: formatted streams are fetched into page-locked
-    buffers (two sets) and written by a side thread in order."""
+    """The good / bad writers of every file fed from the device.  The main loop only queues (slot, sizes) after
+    aqc_format; a fetch thread copies the four formatted streams of that slot into page-locked buffers (and then
+    releases the slot for the next chunk), a write thread writes them in order.  With two slots the upload and
+    kernels of chunk i+1 overlap the download and file writes of chunk i."""
 
-    def __init__(self, eng, writers):
+    N_SETS = 3
+
+    def __init__(self, eng, writers, n_slots):
         self.eng = eng
         self.writers = writers                       # per file (good, bad)
-        self.sets = [[None] * 4, [None] * 4]
-        self.free = [threading.Semaphore(1), threading.Semaphore(1)]
-        self.q = queue.Queue()
+        self.sets = [[None] * 4 for _ in range(self.N_SETS)]
+        self.set_free = [threading.Semaphore(1) for _ in range(self.N_SETS)]
+        self.slot_free = [threading.Semaphore(1) for _ in range(n_slots)]
+        self.fq = queue.Queue()
+        self.wq = queue.Queue()
         self.err = None
-        self.cur = 0
-        self.thread = threading.Thread(target=self._writer, daemon=True)
-        self.thread.start()
+        self.fetcher = threading.Thread(target=self._fetch, daemon=True)
+        self.writer = threading.Thread(target=self._write, daemon=True)
+        self.fetcher.start()
+        self.writer.start()
 
-    def _writer(self):
+    def _fetch(self):
+        which = 0
         while True:
-            job = self.q.get()
+            job = self.fq.get()
+            if job is None:
+                self.wq.put(None)
+                return
+            slot, sizes = job
+            try:
+                self.set_free[which].acquire()           # the writer is done with this buffer set
+                if self.err is None:
+                    for q4, nbytes in enumerate(sizes):
+                        if q4 // 2 >= len(self.writers) or nbytes == 0:
+                            continue
+                        buf = self.sets[which][q4]
+                        if buf is None or buf.nbytes < nbytes:
+                            if buf is not None:
+                                buf.free()
+                            buf = self.sets[which][q4] = self.eng.host_buffer(nbytes + nbytes // 4 + 4096)
+                        self.eng.fetch_text(slot, q4 // 2, q4 % 2, buf.array, buf.nbytes)
+            except BaseException as e:
+                self.err = e
+            finally:
+                self.slot_free[slot].release()           # the slot may take the next chunk
+                self.wq.put((which, list(sizes)))
+                which = (which + 1) % self.N_SETS
+
+    def _write(self):
+        while True:
+            job = self.wq.get()
             if job is None:
                 return
             which, sizes = job
@@ -219,28 +253,25 @@ class _TextSink:
             except BaseException as e:
                 self.err = e
             finally:
-                self.free[which].release()
+                self.set_free[which].release()
+
+    def acquire_slot(self, slot):
+        """block until the previous chunk of this slot has been fetched"""
+        self.slot_free[slot].acquire()
+        if self.err is not None:
+            self.slot_free[slot].release()
+            raise self.err
+
+    def release_slot(self, slot):
+        self.slot_free[slot].release()
 
     def emit(self, slot, sizes):
-        if self.err is not None:
-            raise self.err
-        which = self.cur
-        self.free[which].acquire()                   # the writer is done with this set
-        for q4, nbytes in enumerate(sizes):
-            if q4 // 2 >= len(self.writers) or nbytes == 0:
-                continue
-            buf = self.sets[which][q4]
-            if buf is None or buf.nbytes < nbytes:
-                if buf is not None:
-                    buf.free()
-                buf = self.sets[which][q4] = self.eng.host_buffer(nbytes + nbytes // 4 + 4096)
-            self.eng.fetch_text(slot, q4 // 2, q4 % 2, buf.array, buf.nbytes)
-        self.q.put((which, list(sizes)))
-        self.cur = 1 - which
+        self.fq.put((slot, list(sizes)))
 
     def close(self):
-        self.q.put(None)
-        self.thread.join()
+        self.fq.put(None)
+        self.fetcher.join()
+        self.writer.join()
         for st in self.sets:
             for b in st:
                 if b is not None:
@@ -450,7 +481,8 @@ class seqFilter:
         threads while the main thread sits in the (GIL-free) C-ABI calls."""
         files = [opt.read1_file] + ([opt.read2_file] if paired else [])
         inputs = [_TextInput(eng, f, self.chunk_bytes) for f in files]
-        sink = _TextSink(eng, [(outs.good[k], outs.bad[k]) for k in range(len(files))])
+        n_slots = min(2, getattr(eng, "n_slots", 1))
+        sink = _TextSink(eng, [(outs.good[k], outs.bad[k]) for k in range(len(files))], n_slots)
         total = 0
         extra_bases = 0
         slot = 0
@@ -460,6 +492,7 @@ class seqFilter:
                 inp.start_fill(cur, 0)
             while True:
                 fills = [inp.wait_fill() for inp in inputs]          # (bytes in buffer `cur`, final)
+                sink.acquire_slot(slot)                               # its previous chunk has left the device
                 a1, n1, f1 = inputs[0].bufs[cur].array, fills[0][0], fills[0][1]
                 if paired:
                     info = eng.frame(slot, a1, n1, f1, inputs[1].bufs[cur].array, fills[1][0], fills[1][1], first_index=total)
@@ -491,12 +524,16 @@ class seqFilter:
                         eng.qc_stat(slot, capi.QC_R1_POST, 0, 0, n_qc, 1)
                         if paired:
                             eng.qc_stat(slot, capi.QC_R2_POST, 1, 0, n_qc, 1)
+                        eng.sync(slot)       # the sampling kernels share per-context scratch: never two chunks at once
                     sizes = eng.format(slot, n)
-                    sink.emit(slot, sizes)
+                    sink.emit(slot, sizes)   # (the fetch thread releases the slot)
                     total += n
+                else:
+                    sink.release_slot(slot)
                 if stop:
                     break
                 cur = 1 - cur
+                slot = (slot + 1) % n_slots
         finally:
             sink.close()
             for inp in inputs:
