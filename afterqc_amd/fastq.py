@@ -12,8 +12,10 @@ Rules reproduced:
 """
 import bz2
 import gzip
+import os
 import re
 import sys
+import zlib
 
 import numpy as np
 
@@ -177,6 +179,58 @@ class Reader:
         return rb.record(0)
 
 
+_POOL = None
+
+
+def _pool():
+    """shared worker threads for gzip members (zlib releases the GIL)"""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(2, min(32, (os.cpu_count() or 4))))
+    return _POOL
+
+
+def _gzip_member(data, level):
+    c = zlib.compressobj(level, zlib.DEFLATED, 31)       # wbits 31: a complete gzip member (header + CRC trailer)
+    return c.compress(data) + c.flush()
+
+
+class ParallelGzipFile:
+    """Write-only .gz file made of independent gzip members (RFC 1952 allows concatenation; gzip / zcat / Python's
+    gzip module read them as one stream), so that compression runs on many cores: every write() is cut into
+    blocks that are deflated concurrently and written in order.  The DECOMPRESSED bytes are what the reference's
+    gzip.open(..., "w", compresslevel) would have produced; the container bytes differ (upstream's embed mtime and
+    file name anyway)."""
+
+    BLOCK = 1 << 20
+
+    def __init__(self, filename, level):
+        self._f = open(filename, "wb")
+        self._level = level
+        self._wrote = False
+
+    def write(self, data):
+        mv = memoryview(data)
+        if len(mv) == 0:
+            return
+        if len(mv) <= self.BLOCK:
+            self._f.write(_gzip_member(mv, self._level))
+        else:
+            futs = [_pool().submit(_gzip_member, mv[o:o + self.BLOCK], self._level) for o in range(0, len(mv), self.BLOCK)]
+            for fu in futs:
+                self._f.write(fu.result())
+        self._wrote = True
+
+    def flush(self):
+        self._f.flush()
+
+    def close(self):
+        if not self._wrote:
+            self._f.write(_gzip_member(b"", self._level))      # an empty but valid gzip file
+        self._f.close()
+
+
 class Writer:
     """fastq.Writer (fastq.py:56-104) over bytes."""
 
@@ -185,7 +239,7 @@ class Writer:
         if not self.filename.endswith(".gz") and force_gzip:
             self.filename = self.filename + ".gz"
         if self.filename.endswith(".gz"):
-            self._f = gzip.open(self.filename, "wb", compresslevel=gzip_compression)
+            self._f = ParallelGzipFile(self.filename, gzip_compression)
         elif self.filename.endswith(".bz2"):
             print("ERROR: Write bzip2 stream is not supported")
             sys.exit(1)

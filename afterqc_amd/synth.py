@@ -255,7 +255,12 @@ def write_fastq_fixed(path, seq, qual, mate=1, tile=1101):
         ydig[:, 4 - d] = (y // (10 ** d)) % 10 + 48
     w = len(head) + 7 + 1 + 5 + len(tail) + L + 1 + 2 + L + 1
     chunk = 1 << 18
-    with open(path, "wb") as f:
+    if path.endswith(".gz"):
+        from .fastq import ParallelGzipFile
+        f = ParallelGzipFile(path, 2)
+    else:
+        f = open(path, "wb")
+    try:
         for a in range(0, n, chunk):
             b = min(n, a + chunk)
             m = np.empty((b - a, w), dtype=np.uint8)
@@ -270,4 +275,6 @@ def write_fastq_fixed(path, seq, qual, mate=1, tile=1101):
             m[:, c] = ord("+"); m[:, c + 1] = 10; c += 2
             m[:, c:c + L] = qual[a:b]; c += L
             m[:, c] = 10
-            m.tofile(f)
+            f.write(m.reshape(-1))
+    finally:
+        f.close()

@@ -26,10 +26,12 @@ def main():
     ap.add_argument("--dir", default="/tmp/aqc_e2e")
     ap.add_argument("--single", action="store_true")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--gz", action="store_true", help="gzip input (and therefore, like upstream, gzip output)")
     args = ap.parse_args()
     from afterqc_amd import after, preprocesser, synth
     os.makedirs(args.dir, exist_ok=True)
-    r1, r2 = os.path.join(args.dir, "R1.fq"), os.path.join(args.dir, "R2.fq")
+    ext = ".fq.gz" if args.gz else ".fq"
+    r1, r2 = os.path.join(args.dir, "R1" + ext), os.path.join(args.dir, "R2" + ext)
     t = time.perf_counter()
     d = synth.make_pairs(args.pairs, 150, seed=1003, workers=max(1, (os.cpu_count() or 8) // 2))
     synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
@@ -49,7 +51,7 @@ def main():
     reads = args.pairs * (1 if args.single else 2)
     in_bytes = os.path.getsize(r1) + (0 if args.single else os.path.getsize(r2))
     s = stat["afterqc_main_summary"]
-    out = {"mode": args.mode, "pairs": args.pairs, "reads": reads, "input_bytes": in_bytes, "gen_s": round(gen_s, 1),
+    out = {"mode": args.mode, "gz": args.gz, "pairs": args.pairs, "reads": reads, "input_bytes": in_bytes, "gen_s": round(gen_s, 1),
            "wall_s": round(wall, 3), "pass1_s": round(flt.timing["pass1_s"], 3), "pass2_s": round(flt.timing["pass2_s"], 3),
            "e2e_mreads_s": round(reads / wall / 1e6, 3), "pass2_mreads_s": round(reads / flt.timing["pass2_s"] / 1e6, 3),
            "pass2_input_gb_s": round(in_bytes / flt.timing["pass2_s"] / 1e9, 3),
