@@ -200,10 +200,10 @@ static int canonicalize_dev(aqc_ctx* c, Slot& s, uint64_t n, uint64_t text_bytes
     if (rc) return rc;
     if (n) {
         const unsigned blocks = (unsigned)((n * 16 + 255) / 256);
-        hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_seq, d_off, d_len, (const uint32_t*)co.p, n,
-                           (uint8_t*)cseq.p, (uint8_t)'A');
-        hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_qual, d_qoff, d_len, (const uint32_t*)co.p, n,
-                           (uint8_t*)cqual.p, (uint8_t)0x7f);
+        hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_seq, d_off, d_len, (uint32_t*)co.p, n,
+                           (uint8_t*)cseq.p, (uint8_t)'A', 0);
+        hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_qual, d_qoff, d_len, (uint32_t*)co.p, n,
+                           (uint8_t*)cqual.p, (uint8_t)0x7f, 1);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -477,9 +477,9 @@ static int canonicalize(aqc_ctx* c, Slot& s, int mate, const uint32_t* len, uint
     if (n) {
         const unsigned blocks = (unsigned)((n * 16 + 255) / 256);
         hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_seq, d_off, d_len,
-                           (const uint32_t*)co.p, n, (uint8_t*)cseq.p, (uint8_t)'A');
+                           (uint32_t*)co.p, n, (uint8_t*)cseq.p, (uint8_t)'A', 0);
         hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_qual, d_qoff ? d_qoff : d_off, d_len,
-                           (const uint32_t*)co.p, n, (uint8_t*)cqual.p, (uint8_t)0x7f);
+                           (uint32_t*)co.p, n, (uint8_t*)cqual.p, (uint8_t)0x7f, 1);
         HIP_TRY(hipGetLastError());
     }
     return 0;

@@ -48,6 +48,7 @@ struct FastBatch {
 };
 
 constexpr uint32_t ODD = 0xAAAAAAAAu;
+constexpr uint32_t EXOTIC_BIT = 0x80000000u;   // in a canonical chunk offset: the record holds bytes the packed arithmetic cannot take
 constexpr int NONE_CAND = 0x7fffffff;
 
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
@@ -61,22 +62,19 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
-// 16 sequence bytes -> lo plane (2 bits/base), e plane ('N' flag on the odd bit), bad != 0 iff a byte
-// is outside {A,C,G,T,N}.  Expected byte by 3-bit index (c>>1)&7 via v_perm: A C T G - - - N.
-__device__ __forceinline__ void pack_dword(uint32_t d, uint32_t& lo8, uint32_t& e8, uint32_t& bad) {
-    const uint32_t h = d >> 1;
-    lo8 = udot4(h & 0x03030303u, 0x40100401u, 0u);
+// 16 sequence bytes -> lo plane (2 bits/base: (c >> 1) & 3), e plane ('N' flag, bit 3 of the byte, on the odd bit)
+__device__ __forceinline__ void pack_dword(uint32_t d, uint32_t& lo8, uint32_t& e8) {
+    lo8 = udot4((d >> 1) & 0x03030303u, 0x40100401u, 0u);
     e8 = udot4((d >> 3) & 0x01010101u, 0x80200802u, 0u);
-    bad |= d ^ __builtin_amdgcn_perm(0x4e000000u, 0x47544341u, h & 0x07070707u);
 }
 
-__device__ __forceinline__ void pack_chunk(const uint4 v, uint32_t& lo, uint32_t& e, uint32_t& bad) {
+// (the bytes are known to be A C G T N: canonicalize_kernel flags every other record as exotic)
+__device__ __forceinline__ void pack_chunk(const uint4 v, uint32_t& lo, uint32_t& e) {
     uint32_t l0, l1, l2, l3, e0, e1, e2, e3;
-    bad = 0;
-    pack_dword(v.x, l0, e0, bad);
-    pack_dword(v.y, l1, e1, bad);
-    pack_dword(v.z, l2, e2, bad);
-    pack_dword(v.w, l3, e3, bad);
+    pack_dword(v.x, l0, e0);
+    pack_dword(v.y, l1, e1);
+    pack_dword(v.z, l2, e2);
+    pack_dword(v.w, l3, e3);
     lo = l0 | (l1 << 8) | (l2 << 16) | (l3 << 24);
     e = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
 }
@@ -190,8 +188,10 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         const uint64_t rec = base + p;
         const bool valid = rec < fb.n;
         // ------------------------------------------------------------------ phase 1: load + pack
-        if (role == 0) { L.o1[p] = m_o; L.l1[p] = m_l; L.lq[p] = 0; L.exo[p] = 0; }
-        else { L.o2[p] = m_o; L.l2[p] = m_l; }
+        // bit 31 of the chunk offset: canonicalize_kernel met a byte the packed arithmetic cannot take (exotic pair)
+        if (role == 0) { L.o1[p] = m_o & ~EXOTIC_BIT; L.l1[p] = m_l; L.lq[p] = 0; L.exo[p] = m_o >> 31; }
+        else { L.o2[p] = m_o & ~EXOTIC_BIT; L.l2[p] = m_l; }
+        if (role && (m_o >> 31)) L.exo[p] = 1;
         {
             const uint64_t nrec = rec + stride;
             m_o = m_l = 0;
@@ -215,11 +215,10 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 const int c = it * WAVE + lane - sp[it] * NW;
-                uint32_t lo, e, bad;
-                pack_chunk(v[it], lo, e, bad);
+                uint32_t lo, e;
+                pack_chunk(v[it], lo, e);
                 L.planes[sp[it]][c] = lo;
                 L.planes[sp[it]][NW + c] = e;
-                if (bad && c * 16 < len[it]) L.exo[sp[it]] = 1;
             }
         }
         if (PAIRED) {
@@ -235,13 +234,12 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 const int c = it * WAVE + lane - sp[it] * NW;
-                uint32_t lo, e, bad;
-                pack_chunk(v[it], lo, e, bad);
+                uint32_t lo, e;
+                pack_chunk(v[it], lo, e);
                 // complement (A<->T, C<->G: flip the high bit of the field), keep N at code 3, then reverse the chunk
                 lo = (lo ^ ODD) | e | (e >> 1);
                 L.planes[sp[it]][2 * NW + (NW - 1 - c)] = rev2(lo);
                 L.planes[sp[it]][3 * NW + (NW - 1 - c)] = __builtin_bitreverse32(e) << 1;
-                if (bad && c * 16 < len[it]) L.exo[sp[it]] = 1;
             }
         }
         if (cfg.unqualified_base_limit > 0) {
@@ -270,7 +268,6 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const uint32_t m16 = ((1u << hi_b) - 1u) & ~((1u << lo_b) - 1u);
                 const int cnt = __popc(f16 & m16);
                 if (cnt) atomicAdd(&L.lq[sp[it]], (uint32_t)cnt);
-                if (((v[it].x | v[it].y | v[it].z | v[it].w) & 0x80808080u) && c * 16 < len[it]) L.exo[sp[it]] = 1;   // non-ASCII quality byte
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -711,31 +708,46 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
 // (arbitrary alignment, e.g. FASTQ text addressed in place) to a 16-byte aligned slot and fill the
 // rest of the slot's last 16-byte chunk with `pad`.
 // ------------------------------------------------------------------------------------------------
+// While the bytes pass through, the kernel also validates them — bases must be one of A C G T N, quality bytes
+// below 0x80 (what the lane-per-read kernel's SWAR arithmetic assumes) — and sets bit 31 of the record's chunk
+// offset otherwise ("exotic": the pair is decided by the general kernel).  The hot kernel therefore does not spend
+// instructions re-checking every dword it packs.
 __global__ void canonicalize_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ off,
-                                    const uint32_t* __restrict__ len, const uint32_t* __restrict__ o16, uint64_t n,
-                                    uint8_t* __restrict__ dst, uint8_t pad) {
+                                    const uint32_t* __restrict__ len, uint32_t* __restrict__ o16, uint64_t n,
+                                    uint8_t* __restrict__ dst, uint8_t pad, int is_quality) {
     // 16 lanes per record, lane = 16-byte chunk of the record (looping for reads longer than 256 bytes)
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t rec = gid >> 4;
-    if (rec >= n) return;
-    const int l = (int)len[rec];
-    const uint8_t* s = src + off[rec];
-    uint8_t* d = dst + ((uint64_t)o16[rec] << 4);
+    const bool in = rec < n;
+    const int l = in ? (int)len[rec] : 0;
+    const uint32_t o = in ? o16[rec] : 0u;
+    const uint8_t* s = src + (in ? off[rec] : 0);
+    uint8_t* d = dst + ((uint64_t)(o & ~EXOTIC_BIT) << 4);
     const int nchunks = (l + 15) >> 4;
+    const uint32_t pad4 = (uint32_t)pad * 0x01010101u;
+    uint32_t bad = 0;
     for (int c = (int)(gid & 15); c < nchunks; c += 16) {
         uint32_t w[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint32_t v = 0;
+            const int i = 16 * c + 4 * k;
+            uint32_t v = pad4;
+            if (i + 4 <= l) __builtin_memcpy(&v, s + i, 4);            // unaligned dword load
+            else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = 16 * c + 4 * k + j;
-                v |= (uint32_t)(i < l ? s[i] : pad) << (8 * j);
+                for (int j = 0; j < 3; ++j)
+                    if (i + j < l) v = (v & ~(0xffu << (8 * j))) | ((uint32_t)s[i + j] << (8 * j));
             }
+            // (the pad bytes are valid symbols themselves)
+            bad |= is_quality ? (v & 0x80808080u) : (v ^ __builtin_amdgcn_perm(0x4e000000u, 0x47544341u, (v >> 1) & 0x07070707u));
             w[k] = v;
         }
         *reinterpret_cast<uint4*>(d + 16 * c) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    // the record's 16 lanes sit in one wavefront
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) bad |= (uint32_t)__shfl_xor((int)bad, m, WAVE);
+    if (in && bad && (gid & 15) == 0) o16[rec] = o | EXOTIC_BIT;
 }
 
 }  // namespace aqc
