@@ -255,18 +255,23 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 const int c = it * WAVE + lane - sp[it] * NW;
-                int a = 0, nl = len[it];
-                if (do_trim) trim_view(len[it], cfg.trim_front, cfg.trim_tail, a, nl);
-                // byte < thr  <=>  high bit of ((byte | 0x80) - thr) clear   (bytes < 0x80, thr <= 0x7f)
-                const uint32_t f0 = (~((v[it].x | 0x80808080u) - thr4) & 0x80808080u) >> 7;
-                const uint32_t f1 = (~((v[it].y | 0x80808080u) - thr4) & 0x80808080u) >> 7;
-                const uint32_t f2 = (~((v[it].z | 0x80808080u) - thr4) & 0x80808080u) >> 7;
-                const uint32_t f3 = (~((v[it].w | 0x80808080u) - thr4) & 0x80808080u) >> 7;
-                const uint32_t f16 = udot4(f0, 0x08040201u, 0u) | (udot4(f1, 0x08040201u, 0u) << 4) |
-                                     (udot4(f2, 0x08040201u, 0u) << 8) | (udot4(f3, 0x08040201u, 0u) << 12);
-                const int lo_b = min(max(a - 16 * c, 0), 16), hi_b = min(max(a + nl - 16 * c, 0), 16);
-                const uint32_t m16 = ((1u << hi_b) - 1u) & ~((1u << lo_b) - 1u);
-                const int cnt = __popc(f16 & m16);
+                // byte >= thr  <=>  high bit of ((byte | 0x80) - thr) set   (bytes < 0x80, thr <= 0x7f)
+                const uint32_t g0 = ((v[it].x | 0x80808080u) - thr4) & 0x80808080u, g1 = ((v[it].y | 0x80808080u) - thr4) & 0x80808080u;
+                const uint32_t g2 = ((v[it].z | 0x80808080u) - thr4) & 0x80808080u, g3 = ((v[it].w | 0x80808080u) - thr4) & 0x80808080u;
+                int cnt;
+                if (!do_trim) {
+                    // untrimmed: the 0x7f padding of the read's last chunk counts as "qualified", so no position mask is
+                    // needed; chunks wholly behind the read belong to the next record
+                    cnt = 16 * c < len[it] ? 16 - (__popc(g0) + __popc(g1) + __popc(g2) + __popc(g3)) : 0;
+                } else {
+                    int a = 0, nl = len[it];
+                    trim_view(len[it], cfg.trim_front, cfg.trim_tail, a, nl);
+                    const uint32_t f16 = udot4((g0 ^ 0x80808080u) >> 7, 0x08040201u, 0u) | (udot4((g1 ^ 0x80808080u) >> 7, 0x08040201u, 0u) << 4) |
+                                         (udot4((g2 ^ 0x80808080u) >> 7, 0x08040201u, 0u) << 8) | (udot4((g3 ^ 0x80808080u) >> 7, 0x08040201u, 0u) << 12);
+                    const int lo_b = min(max(a - 16 * c, 0), 16), hi_b = min(max(a + nl - 16 * c, 0), 16);
+                    const uint32_t m16 = ((1u << hi_b) - 1u) & ~((1u << lo_b) - 1u);
+                    cnt = __popc(f16 & m16);
+                }
                 if (cnt) atomicAdd(&L.lq[sp[it]], (uint32_t)cnt);
             }
         }
