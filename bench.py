@@ -186,6 +186,28 @@ def main():
                                "sample": "first %d pairs of the same batch, oracle/aqc_oracle.c (scalar C restatement of "
                                          "preprocesser.py:411-631), filter+overlap+correction only, %.1f s" % (m, tc),
                                "matches_gpu": same, "host_cpus": os.cpu_count()}
+        # the same port on every host core (independent slices, one oracle context per thread; the C call releases the
+        # GIL): SURVEY.md §8d asks for the 1-core and the all-cores figure side by side
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            T = max(1, min(os.cpu_count() or 1, 64))
+            per = max(1000, min(100_000, args.pairs // T))
+            engines = []
+            for k in range(T):
+                lo, hi = k * per, (k + 1) * per
+                e = oracle.OracleEngine()
+                e.set_config(cfg)
+                e.upload(0, capi.Batch.from_matrices(d["seq1"][lo:hi], d["qual1"][lo:hi], d["len1"][lo:hi],
+                                                     d["seq2"][lo:hi], d["qual2"][lo:hi], d["len2"][lo:hi]))
+                engines.append(e)
+            ta = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=T) as ex:
+                list(ex.map(lambda e: e.run(0), engines))
+            ta = time.perf_counter() - ta
+            out["cpu_baseline"]["all_cores"] = {"value": round(2 * per * T / ta / 1e6, 3), "unit": "Mreads/s", "cores": T,
+                                                "sample": "%d threads x %d pairs, %.2f s" % (T, per, ta)}
+        except Exception as e:      # the 1-core figure above is the contract; this one is extra
+            out["cpu_baseline"]["all_cores"] = {"error": str(e)}
     if rank == 0:
         print(json.dumps(out))
     eng.close()
