@@ -751,6 +751,18 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
         v.off2 = (const uint64_t*)s->off2.p; v.qoff2 = (const uint64_t*)s->qoff2.p; v.len2 = (const uint32_t*)s->len2.p;
     }
     if (s->results.reserve(sizeof(aqc_result) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    if (c->has_cfg && c->cfg.debubble) {
+        // lane / tile / x / y out of the R1 names (preprocesser.py:180-192) for the bubble filter
+        for (int k = 0; k < 5; k++)
+            if (s->aux[k].reserve((k < 4 ? sizeof(int32_t) : 1) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+        if (n)
+            hipLaunchKernelGGL(parse_names_kernel, dim3((unsigned)((n + TXT_BLOCK - 1) / TXT_BLOCK)), dim3(TXT_BLOCK), 0, s->stream,
+                               (const uint8_t*)s->seq1.p, (const uint32_t*)s->t_name_off[0].p, (const uint32_t*)s->t_name_len[0].p, n,
+                               (int32_t*)s->aux[0].p, (int32_t*)s->aux[1].p, (int32_t*)s->aux[2].p, (int32_t*)s->aux[3].p,
+                               (uint8_t*)s->aux[4].p);
+        v.aux_lane = (const int32_t*)s->aux[0].p; v.aux_tile = (const int32_t*)s->aux[1].p;
+        v.aux_x = (const int32_t*)s->aux[2].p; v.aux_y = (const int32_t*)s->aux[3].p; v.aux_ok = (const uint8_t*)s->aux[4].p;
+    }
     s->view = v;
     s->n = n;
     s->paired = paired;
@@ -765,6 +777,7 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
             if ((rc = canonicalize_dev(c, *s, n, bytes[1], v.seq2, v.qual2, v.off2, v.qoff2, v.len2, s->cseq2, s->cqual2, s->co2, d_tot + 3))) return rc;
             f.seq2 = (const uint8_t*)s->cseq2.p; f.qual2 = (const uint8_t*)s->cqual2.p; f.o2 = (const uint32_t*)s->co2.p; f.len2 = v.len2;
         }
+        f.aux_lane = v.aux_lane; f.aux_tile = v.aux_tile; f.aux_x = v.aux_x; f.aux_y = v.aux_y; f.aux_ok = v.aux_ok;
         s->fview = f;
         s->has_canonical = true;
     }
@@ -794,10 +807,12 @@ int aqc_format(aqc_ctx* c, int slot, uint64_t n, uint64_t bytes_out[4]) {
     if (!s->framed) return fail(AQC_ERR_STATE, "aqc_format needs a slot filled by aqc_frame");
     if (!s->ran) return fail(AQC_ERR_STATE, "aqc_format before aqc_run");
     if (n > s->n) return fail(AQC_ERR_ARG, "aqc_format: n exceeds the slot's records");
-    if (c->cfg.barcode) return fail(AQC_ERR_UNSUPPORTED, "aqc_format: barcode name rewriting is done on the host");
     FormatView v{};
     v.paired = s->paired ? 1 : 0;
     v.results = (const aqc_result*)s->results.p;
+    v.barcode = c->cfg.barcode ? 1 : 0;
+    v.barcode_length = c->cfg.barcode_length;
+    const DevBuf* sl[2] = {&s->len1, &s->len2};
     const DevBuf* arena[2] = {&s->seq1, &s->seq2};
     const DevBuf* so[2] = {&s->off1, &s->off2};
     const DevBuf* qo[2] = {&s->qoff1, &s->qoff2};
@@ -805,6 +820,7 @@ int aqc_format(aqc_ctx* c, int slot, uint64_t n, uint64_t bytes_out[4]) {
         v.f[k].text = (const uint8_t*)arena[k]->p;
         v.f[k].seq_off = (const uint64_t*)so[k]->p;
         v.f[k].qual_off = (const uint64_t*)qo[k]->p;
+        v.f[k].seq_len = (const uint32_t*)sl[k]->p;
         v.f[k].name_off = (const uint32_t*)s->t_name_off[k].p;
         v.f[k].name_len = (const uint32_t*)s->t_name_len[k].p;
         v.f[k].plus_off = (const uint32_t*)s->t_plus_off[k].p;

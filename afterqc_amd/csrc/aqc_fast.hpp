@@ -333,7 +333,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         // ---- bubble (preprocesser.py:469-473)
         if (cfg.debubble && circ.n > 0 && fb.aux_ok) {
             bool hit = false;
-            if (valid && flag < 0 && fb.aux_ok[rec]) {
+            if (valid && flag < 0 && fb.aux_ok[rec] == 2) atomicCAS(st.status, 0, AQC_ERR_ARG);     // int() raises upstream
+            else if (valid && flag < 0 && fb.aux_ok[rec]) {
                 const int ln = fb.aux_lane[rec], tl = fb.aux_tile[rec], x = fb.aux_x[rec], y = fb.aux_y[rec];
                 for (int i = 0; i < circ.n; ++i) {
                     if (circ.tile[i] == tl && circ.lane[i] == ln) {

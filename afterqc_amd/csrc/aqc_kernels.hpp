@@ -410,7 +410,8 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
         }
         // ---- bubble (preprocesser.py:469-473)
         if (flag < 0 && cfg.debubble && b.aux_ok && b.aux_ok[rec]) {
-            if (in_bubble_wave(b.aux_lane[rec], b.aux_tile[rec], b.aux_x[rec], b.aux_y[rec], circ)) flag = AQC_BADBBL;
+            if (b.aux_ok[rec] == 2) atomicCAS(st.status, 0, AQC_ERR_ARG);     // int() raises upstream (preprocesser.py:187-192)
+            else if (in_bubble_wave(b.aux_lane[rec], b.aux_tile[rec], b.aux_x[rec], b.aux_y[rec], circ)) flag = AQC_BADBBL;
         }
         // ---- length (preprocesser.py:476-479)
         if (flag < 0 && len1 < cfg.seq_len_req) flag = AQC_BADLEN;

@@ -191,6 +191,83 @@ __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t*
     atomicMax(&meta->max_len, l[1]);
 }
 
+// ---- Illumina read names for the bubble filter (preprocesser.py:155,176-192) ---------------------------------------
+// re.search(r'\S+\:\d+\:\S+\:\d+\:\d+\:\d+\:\d+', name), then items = match.split(':'), lane = int(items[3]),
+// tile = int(items[4][1:]), x = int(items[5]), y = int(items[6]).  The search is reproduced with the regex engine's
+// own order: leftmost start; first \S+ greedy (longest first, backing off to the previous ':'); \d+ runs are maximal
+// (a shorter run is followed by a digit, never by ':'); second \S+ greedy.  ok = 0 no match, 1 parsed, 2 the
+// reference would raise (a non-numeric items[k], e.g. more than seven fields, or an empty items[4][1:]) — the
+// kernels turn 2 into AQC_ERR_ARG only if the record actually reaches the bubble stage, like the exception upstream.
+__device__ __forceinline__ bool is_digit(uint8_t c) { return c >= '0' && c <= '9'; }
+
+// int() of name[a:b): digits only; returns false for anything else; values beyond int32 saturate (no circle can
+// match such a lane / tile, and such a coordinate is outside every circle)
+__device__ __forceinline__ bool parse_uint(const uint8_t* name, int a, int b, int32_t& out) {
+    if (b <= a) return false;
+    unsigned long long v = 0;
+    for (int i = a; i < b; ++i) {
+        if (!is_digit(name[i])) return false;
+        v = v * 10ull + (unsigned long long)(name[i] - '0');
+        if (v > 0x7fffffffull) v = 0x7fffffffull;
+    }
+    out = (int32_t)v;
+    return true;
+}
+
+__global__ __launch_bounds__(TXT_BLOCK) void parse_names_kernel(const uint8_t* __restrict__ text, const uint32_t* __restrict__ name_off,
+                                                                const uint32_t* __restrict__ name_len, uint64_t n,
+                                                                int32_t* __restrict__ lane_out, int32_t* __restrict__ tile_out,
+                                                                int32_t* __restrict__ x_out, int32_t* __restrict__ y_out,
+                                                                uint8_t* __restrict__ ok_out) {
+    const uint64_t r = (uint64_t)blockIdx.x * TXT_BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const uint8_t* name = text + name_off[r];
+    const int len = (int)name_len[r];
+    int m_s = -1, m_e = -1;
+    for (int s = 0; s < len && m_s < 0; ++s) {
+        if (is_space(name[s])) continue;
+        int E = s;
+        while (E < len && !is_space(name[E])) ++E;           // the match stays inside this blank-delimited token
+        for (int e1 = E - 1; e1 > s && m_s < 0; --e1) {
+            if (name[e1] != ':') continue;
+            int p = e1 + 1;
+            while (p < E && is_digit(name[p])) ++p;
+            if (p == e1 + 1 || p >= E || name[p] != ':') continue;
+            const int s3 = p + 1;
+            for (int e3 = E - 1; e3 > s3 && m_s < 0; --e3) {
+                if (name[e3] != ':') continue;
+                int q = e3 + 1;
+                bool good = true;
+                for (int g = 0; g < 3 && good; ++g) {
+                    const int a = q;
+                    while (q < E && is_digit(name[q])) ++q;
+                    if (q == a || q >= E || name[q] != ':') good = false;
+                    else ++q;
+                }
+                if (good) {
+                    const int a = q;
+                    while (q < E && is_digit(name[q])) ++q;
+                    if (q > a) { m_s = s; m_e = q; }
+                }
+            }
+        }
+    }
+    int32_t lane = 0, tile = 0, x = 0, y = 0;
+    uint8_t ok = 0;
+    if (m_s >= 0) {
+        // items = match.split(':') : the 4th..7th field from the LEFT
+        int fs[8], fe[8], nf = 0, a = m_s;
+        for (int i = m_s; i <= m_e && nf < 8; ++i) {
+            if (i == m_e || name[i] == ':') { fs[nf] = a; fe[nf] = i; ++nf; a = i + 1; }
+        }
+        ok = 1;
+        if (!parse_uint(name, fs[3], fe[3], lane) || !parse_uint(name, fs[4] + 1, fe[4], tile) || !parse_uint(name, fs[5], fe[5], x) ||
+            !parse_uint(name, fs[6], fe[6], y))
+            ok = 2;
+    }
+    lane_out[r] = lane; tile_out[r] = tile; x_out[r] = x; y_out[r] = y; ok_out[r] = ok;
+}
+
 // ---- canonical offsets on the device ------------------------------------------------------------------------------
 struct ChunksOf {      // 16-byte chunks a read occupies in the canonical layout
     const uint32_t* len;
@@ -205,6 +282,7 @@ __device__ __constant__ int FLAG_TEXT_LEN[AQC_N_FLAGS] = {4, 7, 7, 8, 8, 6, 6, 6
 struct TextFile {
     const uint8_t* text;
     const uint64_t *seq_off, *qual_off;
+    const uint32_t *seq_len;
     const uint32_t *name_off, *name_len, *plus_off, *plus_len;
 };
 
@@ -212,7 +290,19 @@ struct FormatView {
     TextFile f[2];
     const aqc_result* results;
     int paired;
+    int barcode;          // options.barcode: moveBarcodeToName (barcodeprocesser.py:34-45) rewrites the names
+    int barcode_length;
 };
+
+// moveBarcodeToName for one read: the name becomes '@' + bases[0:b] + name[first ':' :]; b is the detected barcode
+// length for pairs (preprocesser.py:452), the design length for single-end input (:444).  Records flagged
+// BADBCD1 / BADBCD2 keep their names.  Returns b (bases moved, clipped to the read) or -1 when the name stays.
+__device__ __forceinline__ int moved_barcode_len(const FormatView& v, int file, int flag, uint32_t barcode_byte, uint32_t seq_len) {
+    if (!v.barcode || flag == AQC_BADBCD1 || flag == AQC_BADBCD2) return -1;
+    const int code = file == 0 ? (int)(barcode_byte & 15u) : (int)(barcode_byte >> 4);
+    const int b = v.paired ? code - 2 + v.barcode_length : v.barcode_length;
+    return min(max(b, 0), (int)seq_len);
+}
 
 // bytes record r contributes to (file, stream); stream 0 = good, 1 = bad
 struct OutSize {
@@ -224,7 +314,20 @@ struct OutSize {
         if ((flag == AQC_GOOD ? 0 : 1) != stream) return 0u;
         const uint32_t len = file == 0 ? (w0.y & 0xffffu) : (w0.z & 0xffffu);
         const TextFile& t = v.f[file];
-        return t.name_len[r] + (flag == AQC_GOOD ? 0u : (uint32_t)FLAG_TEXT_LEN[flag]) + 2u * len + t.plus_len[r] + 4u;
+        uint32_t nlen = t.name_len[r];
+        if (v.barcode) {
+            const uint32_t bc = reinterpret_cast<const uint8_t*>(v.results + r)[31];
+            const int b = moved_barcode_len(v, file, flag, bc, t.seq_len[r]);
+            if (b >= 0) {
+                // name[str.find(':'):] — find() == -1 slices the last character
+                const uint8_t* name = t.text + t.name_off[r];
+                uint32_t cpos = nlen - 1;
+                for (uint32_t i = 0; i < nlen; ++i)
+                    if (name[i] == ':') { cpos = i; break; }
+                nlen = 1u + (uint32_t)b + (nlen - cpos);
+            }
+        }
+        return nlen + (flag == AQC_GOOD ? 0u : (uint32_t)FLAG_TEXT_LEN[flag]) + 2u * len + t.plus_len[r] + 4u;
     }
 };
 
@@ -268,8 +371,19 @@ __global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, u
     const uint8_t* qual = t.text + t.qual_off[r] + st;
     const int nlen = (int)t.name_len[r], plen = (int)t.plus_len[r];
     const int flen = stream ? FLAG_TEXT_LEN[flag] : 0;
+    // barcode moved into the name: '@' + [FLAG] + bases[0:mb] + name[cpos:]
+    const int mb = v.barcode ? moved_barcode_len(v, file, flag, w1.w >> 24, t.seq_len[r]) : -1;
+    int cpos = nlen - 1;
+    if (mb >= 0) {
+        for (int i0 = 0; i0 < nlen; i0 += WAVE) {
+            const unsigned long long hit = __ballot(i0 + lane < nlen && name[i0 + lane] == ':');
+            if (hit) { cpos = i0 + __builtin_ctzll(hit); break; }
+        }
+    }
+    const uint8_t* seq0 = t.text + t.seq_off[r];          // the read as sequenced (barcode source)
+    const int nlen_out = mb >= 0 ? 1 + mb + (nlen - cpos) : nlen;
     // segment boundaries in the output record
-    const int b_name = nlen + flen;            // name' then '\n'
+    const int b_name = nlen_out + flen;        // name' then '\n'
     const int b_seq = b_name + 1 + len;        // bases then '\n'
     const int b_plus = b_seq + 1 + plen;       // strand line then '\n'
     const int b_qual = b_plus + 1 + len;       // qualities then '\n'
@@ -279,10 +393,18 @@ __global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, u
     for (int j = lane; j < total; j += WAVE) {
         uint8_t c;
         if (j < b_name) {
-            // "@" + FLAG + name[1:] for a bad record (preprocesser.py:213-219), the name itself for a good one
-            if (j == 0 || !stream) c = stream ? (uint8_t)'@' : name[j];
-            else if (j <= flen) c = (uint8_t)FLAG_TEXT[flag][j - 1];
-            else c = name[j - flen];
+            // "@" + FLAG + name[1:] for a bad record (preprocesser.py:213-219), the name itself for a good one;
+            // with a moved barcode the name is '@' + barcode + name[cpos:] before that rule applies
+            if (mb < 0) {
+                if (j == 0 || !stream) c = stream ? (uint8_t)'@' : name[j];
+                else if (j <= flen) c = (uint8_t)FLAG_TEXT[flag][j - 1];
+                else c = name[j - flen];
+            } else {
+                if (j == 0) c = (uint8_t)'@';
+                else if (j <= flen) c = (uint8_t)FLAG_TEXT[flag][j - 1];
+                else if (j <= flen + mb) c = seq0[j - flen - 1];
+                else c = name[cpos + (j - flen - mb - 1)];
+            }
         } else if (j == b_name || j == b_seq || j == b_plus || j == b_qual) {
             c = (uint8_t)'\n';
         } else if (j < b_seq) {

@@ -393,10 +393,9 @@ class seqFilter:
         # the per-read settings now include the resolved trim values
         eng.set_config(build_config(opt, paired, has_i2))
         # text in / text out on the device (aqc_frame / aqc_format) whenever the run needs nothing of the host per
-        # record; barcode name rewriting, index files, --store_overlap, --debubble (name parsing) and --qc_only keep
+        # record; index files, --store_overlap and --qc_only keep
         # the host-side framing and writer below
-        self.text_path = (self.use_text_path and not opt.barcode and not opt.store_overlap and not opt.debubble
-                          and not opt.qc_only and not has_i1 and not has_i2)
+        self.text_path = (self.use_text_path and not opt.store_overlap and not opt.qc_only and not has_i1 and not has_i2)
         t_p2 = time.perf_counter()
         if self.text_path:
             extra_bases = self._run_text(eng, opt, outs, paired)

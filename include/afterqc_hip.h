@@ -253,7 +253,8 @@ int aqc_get_kmers(aqc_ctx* ctx, int which, uint64_t* keys, int64_t* counts, uint
  * `final` (nothing follows: an unterminated last line counts as a line, a partial group is dropped).
  * Mate files are read in lock step (preprocesser.py:412-429): n = min(avail1, avail2, max_records).
  * After aqc_frame the slot holds the n records exactly as after aqc_upload (the text is the arena), so
- * aqc_run / aqc_qc_stat / aqc_fetch_results apply.  Chunks must be < 4 GiB. */
+ * aqc_run / aqc_qc_stat / aqc_fetch_results apply.  With cfg.debubble (aqc_set_config before aqc_frame) the
+ * lane / tile / x / y of preprocesser.py:180-192 are parsed out of the R1 names on the device.  Chunks must be < 4 GiB. */
 typedef struct aqc_text_chunk {
     const uint8_t* text1;
     uint64_t bytes1;
@@ -279,8 +280,9 @@ int aqc_frame(aqc_ctx* ctx, int slot, const aqc_text_chunk* chunk, aqc_frame_inf
 /* seqFilter.writeReads (preprocesser.py:206-232) + fastq.Writer.writeLines (fastq.py:87-93) for records
  * [0, n) of a framed slot after aqc_run: builds, in record order, the text of the good and of the bad output
  * of each file (name / bases / strand line / qualities + "\n"; bad names "@" + FLAG + name[1:]; trimmed
- * slices with the walk's edits applied).  bytes_out = {good R1, bad R1, good R2, bad R2}.  Barcode name
- * rewriting, index files and --store_overlap are not handled here (AQC_ERR_UNSUPPORTED / host side). */
+ * slices with the walk's edits applied; with cfg.barcode the names carry the moved barcode,
+ * barcodeprocesser.py:34-45).  bytes_out = {good R1, bad R1, good R2, bad R2}.  Index files and --store_overlap
+ * are not handled here (host side). */
 int aqc_format(aqc_ctx* ctx, int slot, uint64_t n, uint64_t bytes_out[4]);
 /* copy one formatted stream (file 0/1, stream 0 good / 1 bad) to host memory and wait for it */
 int aqc_fetch_text(aqc_ctx* ctx, int slot, int file, int stream, uint8_t* dst, uint64_t cap);

@@ -349,6 +349,17 @@ def _oracle_frame(self, slot, text1, bytes1, final1, text2=None, bytes2=0, final
             info.avail2, info.eof2, info.consumed2 = avail, int(eof), consumed
         lines.append((buf, records))
     info.max_len = mx
+    if self.cfg is not None and self.cfg.debubble:
+        # the host half of isInBubble (preprocesser.py:180-192) with Python's own regex engine
+        from afterqc_amd import fastq
+        buf, records = lines[0]
+        try:
+            aux = [fastq.parse_illumina_name(buf[records[r][0][0]:records[r][0][0] + records[r][0][1]]) for r in range(n)]
+        except ValueError as e:
+            raise capi.AqcError(-2, "read name: %s" % e)
+        if n:
+            ok, lane, tile, x, y = zip(*aux)
+            b.set_aux(lane, tile, x, y, ok)
     self.upload(slot, b)
     self._text = getattr(self, "_text", {})
     self._text[slot] = lines
@@ -358,7 +369,7 @@ def _oracle_frame(self, slot, text1, bytes1, final1, text2=None, bytes2=0, final
 
 
 def _oracle_format(self, slot, n):
-    """seqFilter.writeReads (preprocesser.py:206-232) + Writer.writeLines (fastq.py:87-93) without barcode/overlap"""
+    """seqFilter.writeReads (preprocesser.py:206-232) + Writer.writeLines (fastq.py:87-93), index files / overlap store aside"""
     res = self.results[slot]
     b = self.slots[slot]
     out = [bytearray(), bytearray(), bytearray(), bytearray()]
@@ -369,6 +380,11 @@ def _oracle_format(self, slot, n):
             rr = res[r]
             seq, qual = final_read(buf[so:so + sl], buf[qo:qo + ql], rr, k + 1)
             flag = int(rr["flag"])
+            if self.cfg.barcode and flag not in (capi.BADBCD1, capi.BADBCD2):
+                # moveBarcodeToName (barcodeprocesser.py:34-45): detected length for pairs, design length single-end
+                code = (int(rr["barcode"]) & 15) if k == 0 else (int(rr["barcode"]) >> 4)
+                blen = code - 2 + self.cfg.barcode_length if self.cfg.paired else self.cfg.barcode_length
+                name = b"@" + buf[so:so + sl][0:max(blen, 0)] + name[name.find(b":"):]
             stream = 0 if flag == capi.GOOD else 1
             if stream:
                 name = b"@" + FLAG_NAMES_B[flag] + name[1:]
