@@ -27,13 +27,24 @@ def main():
     ap.add_argument("--single", action="store_true")
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--gz", action="store_true", help="gzip input (and therefore, like upstream, gzip output)")
+    ap.add_argument("--config5", action="store_true", help="config-5 flavour: 2x250 bp + 17 bp barcode/verify prefix, file names with 'barcode', --debubble with a circles.csv")
     args = ap.parse_args()
     from afterqc_amd import after, preprocesser, synth
     os.makedirs(args.dir, exist_ok=True)
     ext = ".fq.gz" if args.gz else ".fq"
-    r1, r2 = os.path.join(args.dir, "R1" + ext), os.path.join(args.dir, "R2" + ext)
+    stem = "barcode_" if args.config5 else ""
+    r1, r2 = os.path.join(args.dir, stem + "R1" + ext), os.path.join(args.dir, stem + "R2" + ext)
     t = time.perf_counter()
-    d = synth.make_pairs(args.pairs, 150, seed=1003, workers=max(1, (os.cpu_count() or 8) // 2))
+    d = synth.make_pairs(args.pairs, 250 if args.config5 else 150, seed=1005 if args.config5 else 1003,
+                         workers=max(1, (os.cpu_count() or 8) // 2))
+    if args.config5:
+        d = synth.add_barcodes(d, 1005 + 7)
+        os.makedirs(os.path.join(args.dir, "D"), exist_ok=True)
+        with open(os.path.join(args.dir, "D", "circles.csv"), "w") as f:
+            # names carry tile 1101 -> int(tile[1:]) = 101, lane 1, x = record index, y = index * 7919 % 100000
+            f.write("x,y,radius,lane,tile\n")
+            for k in range(8):
+                f.write("%r,%r,%r,1,101\n" % (250000.0 * (k + 1), 50000.0, 3000.0 + 100.0 * k))
     synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
     if not args.single:
         synth.write_fastq_fixed(r2, d["seq2"], d["qual2"], 2)
@@ -41,9 +52,13 @@ def main():
     gen_s = time.perf_counter() - t
     argv = ["-1", r1] + ([] if args.single else ["-2", r2]) + ["-f", "0", "-t", "0", "-g", os.path.join(args.dir, "good"),
                                                               "-b", os.path.join(args.dir, "bad"), "-r", os.path.join(args.dir, "QC")]
+    if args.config5:
+        argv += ["--debubble", "--debubble_dir", os.path.join(args.dir, "D")]
     options, _ = after.parseCommand(argv)
     after.finalize_options(options)
-    options.barcode = False
+    options.barcode = bool(args.config5)       # what after.py:215-221 decides from the file name
+    if args.config5:
+        options.trim_front = options.trim_front2 = 0
     flt = preprocesser.seqFilter(options, use_text_path=args.mode == "text", chunk_bytes=args.chunk_mb << 20)
     t = time.perf_counter()
     stat = flt.run()
@@ -55,7 +70,7 @@ def main():
            "wall_s": round(wall, 3), "pass1_s": round(flt.timing["pass1_s"], 3), "pass2_s": round(flt.timing["pass2_s"], 3),
            "e2e_mreads_s": round(reads / wall / 1e6, 3), "pass2_mreads_s": round(reads / flt.timing["pass2_s"] / 1e6, 3),
            "pass2_input_gb_s": round(in_bytes / flt.timing["pass2_s"] / 1e9, 3),
-           "good_reads": s["good_reads"], "bad_reads": s["bad_reads"], "text_path": flt.text_path}
+           "good_reads": s["good_reads"], "bad_reads": s["bad_reads"], "text_path": flt.text_path, "config5": args.config5}
     print(json.dumps(out))
     if not args.keep:
         shutil.rmtree(args.dir, ignore_errors=True)
