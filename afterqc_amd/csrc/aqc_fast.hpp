@@ -149,7 +149,6 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                                                                     uint64_t accum_limit, uint32_t* __restrict__ deferred,
                                                                     unsigned int* __restrict__ n_deferred) {
     using WL = FastWaveLds<NW, PAIRED>;
-    constexpr int STRIDE = WL::STRIDE;
     constexpr int PPW = WL::PPW;
     constexpr int ITERS = PPW * NW / WAVE;        // 16-byte chunk tasks per lane and string kind
     static_assert(PPW * NW % WAVE == 0, "chunk tasks must tile the wave");
@@ -278,10 +277,6 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         __builtin_amdgcn_wave_barrier();
         PROF(0);
 
-#if defined(AQC_ABLATE) && AQC_ABLATE == 1   /* phase 1 only */
-        if (valid && role == 0) results[rec].flag = (uint8_t)(L.planes[p][0] + L.lq[p] + L.exo[p]);
-        continue;
-#endif
         // ------------------------------------------------------------------ phase 2: lane per read
         const int L1 = (int)L.l1[p];
         const int L2 = PAIRED ? (int)L.l2[p] : 0;
@@ -347,21 +342,10 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         }
         // ---- length (preprocesser.py:476-479)
         if (flag < 0 && len1 < cfg.seq_len_req) flag = AQC_BADLEN;
-#ifdef AQC_DEBUG_POLY
-        uint8_t dbg_byte = 0;
-#endif
         // ---- polyX (preprocesser.py:482-490): run-length screen per read, exact check by the wave for the few hits
-#if defined(AQC_ABLATE) && AQC_ABLATE == 4   /* no polyX */
-        if (false) {
-#else
         if (cfg.poly_size_limit > 0) {
-#endif
             bool sus = false;
-#if defined(AQC_ABLATE) && AQC_ABLATE == 11
-            if (true) sus = len_own >= cfg.poly_size_limit;
-#else
             if (run_req < 2) sus = len_own >= cfg.poly_size_limit;
-#endif
             else {
                 uint32_t r[NW + 1], Wlo[NW + 1], We[NW + 1];
 #pragma unroll
@@ -405,9 +389,6 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             // (the exchange must run on all lanes: a DPP read from a masked-off partner returns 0)
             const bool poly_par = PAIRED ? xchg_pred(poly) : false;
             const bool poly_pair = poly || poly_par;
-#ifdef AQC_DEBUG_POLY
-            dbg_byte = (uint8_t)((sus ? 1 : 0) | (poly ? 2 : 0) | (poly_par ? 4 : 0) | (flag < 0 ? 8 : 0) | (defer ? 16 : 0) | 128);
-#endif
             if (flag < 0 && poly_pair) flag = AQC_BADPOL;
         }
         PROF(2);
@@ -429,9 +410,6 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         int em0 = -1, em1 = -1, em2 = -1, walk_a = 0;
         unsigned long long E0 = 0, E1 = 0, E2 = 0;
         bool walk_pair = false, walker = false;
-#ifdef AQC_DEBUG_POLY
-        if (valid) reinterpret_cast<volatile uint8_t*>(results + rec)[28 + role] = dbg_byte;
-#endif
         if (PAIRED && !cfg.no_overlap) {
             // own candidates: offsets c = 0 .. len_own - 31, the own stream moving over the partner's prefix
             const int n_own = len_own > 30 ? len_own - 30 : 0;
@@ -442,9 +420,6 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const bool short16_par = xchg_pred(short16);
                 if (short16 || short16_par) { defer = true; scan = false; }
             }
-#if defined(AQC_ABLATE) && AQC_ABLATE == 3   /* no scan */
-            scan = false;
-#endif
             bool i_found_it = false;    // this lane's stream moves on the accepted diagonal
             int from = 0;               // first own candidate still to be examined
             bool found = false;
@@ -559,11 +534,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             //      b2 = complement(r2[-o-1]).  Whenever overlap_len == len1 - offset (always after an adapter cut) those
             //      are exactly the columns of the accepted diagonal, whose first three mismatches the verification
             //      already located; otherwise (read 2 shorter than the rest of read 1) the pair is deferred.
-#if defined(AQC_ABLATE) && AQC_ABLATE == 5   /* no correction walk */
-            walk_pair = false;
-#else
             walk_pair = reached && !defer && flag < 0 && c_overlapped && dist > 0;
-#endif
             if (walk_pair && !c_adapter_read && ovl != len1 - offset) { defer = true; walk_pair = false; }
             walker = walk_pair && i_found_it;
             if (__ballot(walker)) {

@@ -286,28 +286,6 @@ __device__ __forceinline__ void stage(uint8_t* dst, const uint8_t* src, int len)
     for (int i = lane_id(); i < len; i += WAVE) dst[i] = src[i];
 }
 
-// stage two strings of the same length at once: all loads are issued before the first LDS store, so a read of up
-// to 256 bytes costs ONE memory round trip instead of one per 64 bytes and string
-__device__ __forceinline__ void stage2(uint8_t* d0, const uint8_t* s0, uint8_t* d1, const uint8_t* s1, int len) {
-    const int lane = lane_id();
-    if (len <= 4 * WAVE) {
-        uint8_t a[4], b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = lane + WAVE * j;
-            a[j] = i < len ? s0[i] : (uint8_t)0;
-            b[j] = i < len ? s1[i] : (uint8_t)0;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = lane + WAVE * j;
-            if (i < len) { d0[i] = a[j]; d1[i] = b[j]; }
-        }
-    } else {
-        for (int i = lane; i < len; i += WAVE) { d0[i] = s0[i]; d1[i] = s1[i]; }
-    }
-}
-
 struct BlockAcc {
     unsigned long long counters[AQC_N_COUNTERS];
     unsigned int ovl_hist[AQC_QC_COLS];
