@@ -237,7 +237,7 @@ int aqc_create(int device, int n_slots, aqc_ctx** out) {
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char* fg = getenv("AQC_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
-    HIP_TRY(hipFuncSetAttribute((const void*)kmer_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KMER_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute((const void*)kmer_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KMER_FUSED_LDS_BYTES));
     for (auto& s : c->slots) {
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         for (int k = 0; k < AQC_N_KERNELS; k++)
@@ -609,14 +609,19 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
     if (g0 < q.last_end) q.epoch++;
     q.last_end = g0 + count;
     const unsigned long long order_base = (q.epoch << 34) | g0;
-    hipLaunchKernelGGL(qc_stat_kernel, dim3((unsigned)blocks), dim3(QC_BLOCK), lds, s->stream, s->view, mate, first, count, post,
-                       (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, c->status, cols);
+    // Reads of <= 256 bases: ONE kernel does both halves of statRead (per-cycle rows ride along with the k-mer
+    // counting, see kmer_count_kernel); longer reads: the per-cycle kernel runs on its own.
+    const uint32_t per_read = mx > (uint32_t)c->cfg.qc_kmer ? mx - (uint32_t)c->cfg.qc_kmer : 1;
+    uint32_t rpr_max = 65535u / per_read;
+    if (rpr_max < 1) rpr_max = 1;
+    const uint64_t max_rounds = 512;                       // 64 MiB of slices at most per launch
+    const uint64_t rounds_per_block = (max_rounds + c->n_cu - 1) / c->n_cu;
+    const bool fused = cols <= KMER_FUSED_MAX_COLS && rounds_per_block * rpr_max <= (uint64_t)QC_MAX_READS_PER_BLOCK;
+    if (!fused)
+        hipLaunchKernelGGL(qc_stat_kernel, dim3((unsigned)blocks), dim3(QC_BLOCK), lds, s->stream, s->view, mate, first, count, post,
+                           (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, c->status, cols);
     // k-mer dictionary: LDS-resident u16 counters, rounds of <= 65535 k-mers per workgroup, slices reduced afterwards
     {
-        const uint32_t per_read = mx > (uint32_t)c->cfg.qc_kmer ? mx - (uint32_t)c->cfg.qc_kmer : 1;
-        uint32_t rpr_max = 65535u / per_read;
-        if (rpr_max < 1) rpr_max = 1;
-        const uint64_t max_rounds = 512;                       // 64 MiB of slices at most per launch
         uint64_t done = 0;
         while (done < count) {
             uint64_t chunk = count - done;
@@ -631,9 +636,10 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
             const uint32_t n_rounds = (uint32_t)((chunk + rpr - 1) / rpr);
             if (c->kmer_partial.reserve((size_t)n_rounds * DENSE_ENTRIES * sizeof(uint16_t))) return fail(AQC_ERR_HIP, "hipMalloc failed");
             unsigned kb = n_rounds < (unsigned)c->n_cu ? n_rounds : (unsigned)c->n_cu;
-            hipLaunchKernelGGL(kmer_count_kernel, dim3(kb), dim3(KMER_BLOCK), KMER_LDS_BYTES, s->stream, s->view, mate, first + done,
-                               chunk, post, (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.kt, order_base + done,
-                               (uint16_t*)c->kmer_partial.p, rpr, n_rounds, c->status);
+            hipLaunchKernelGGL(kmer_count_kernel, dim3(kb), dim3(KMER_BLOCK), fused ? KMER_FUSED_LDS_BYTES : KMER_LDS_BYTES, s->stream, s->view,
+                               mate, first + done, chunk, post, (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.kt, order_base + done,
+                               (uint16_t*)c->kmer_partial.p, rpr, n_rounds, c->status, fused ? q.acc : (unsigned long long*)nullptr,
+                               fused ? cols : 0);
             hipLaunchKernelGGL(kmer_reduce_kernel, dim3(DENSE_ENTRIES / KRED_ENTRIES), dim3(KRED_BLOCK), 0, s->stream,
                                (const uint16_t*)c->kmer_partial.p, n_rounds, q.kt, c->cfg.qc_kmer);
             done += chunk;

@@ -794,6 +794,72 @@ constexpr int QC_WPB = QC_BLOCK / WAVE;
 constexpr int QC_LDS_ROWS = 6;            // A T C G other | discontinuity   (+ gc histogram)
 constexpr int QC_MAX_READS_PER_BLOCK = 4095;
 
+struct QcLds {
+    unsigned int* accs;          // [QC_LDS_ROWS][cols], columns permuted (see qc_accumulate_read)
+    unsigned int* gch;           // [cols] GC histogram
+    unsigned long long* scal;    // [0] totalKmer, [1] reads
+    int cols;
+};
+
+// statRead's per-cycle part for ONE read (wave-wide).  ws / wq: the lane's dword of bases / qualities of pass 0
+// (bytes 4*lane .. 4*lane+3, zero beyond the read), without the walk's edits.
+// Column i lives at word (i & 3) * (cols / 4) + (i >> 2): the four cycles a lane owns are cols/4 words apart and
+// neighbouring lanes hit neighbouring banks (the natural layout would be a 4-way bank conflict on every add).
+__device__ __forceinline__ void qc_accumulate_read(const ReadDesc& cur, uint32_t ws, uint32_t wq, const QcLds& L, int kmer_len) {
+    const int lane = lane_id();
+    const int len = cur.len;
+    const int cols = L.cols, cq = L.cols >> 2;
+    unsigned int* const accs = L.accs;
+    unsigned int* const gch = L.gch;
+    unsigned long long* const scal = L.scal;
+    const uint8_t* gs = reinterpret_cast<const uint8_t*>(cur.s);
+    const uint8_t* gq = reinterpret_cast<const uint8_t*>(cur.q);
+    int gc = 0;
+    unsigned int d_head = 0, d_tail = 0;      // discontinuity of cycle 2 / cycle len-3: the clamped windows
+    for (int base0 = 0; base0 < len; base0 += 4 * WAVE) {
+        const int x = base0 + 4 * lane;
+        if (base0 > 0) { ws = load4(gs, x, len, 0); wq = load4(gq, x, len, 0); }
+        apply_edits(cur, x, ws, wq);
+        uint32_t prev = __shfl_up(ws, 1), next = __shfl_down(ws, 1);
+        if (base0 > 0 && lane == 0) { uint32_t dq = 0; prev = load4(gs, x - 4, len, 0); apply_edits(cur, x - 4, prev, dq); }
+        if (base0 + 4 * WAVE < len && lane == WAVE - 1) { uint32_t dq = 0; next = load4(gs, x + 4, len, 0); apply_edits(cur, x + 4, next, dq); }
+        // bytes x-2 .. x+5 ; byte k of (v ^ v >> 8) is non-zero iff bases x-2+k and x-1+k differ
+        const uint32_t vlo = __builtin_amdgcn_alignbit(ws, prev, 16), vhi = __builtin_amdgcn_alignbit(next, ws, 16);
+        const uint32_t tlo = nonzero_bytes(vlo ^ __builtin_amdgcn_alignbit(vhi, vlo, 8));
+        const uint32_t thi = nonzero_bytes(vhi ^ (vhi >> 8));
+        unsigned int dpk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dpk |= (unsigned int)__popc(__builtin_amdgcn_alignbit(thi, tlo, 8 * j)) << (3 * j);
+        if (base0 == 0) d_head = ((unsigned int)__builtin_amdgcn_readlane((int)dpk, 0) >> 6) & 7u;
+        const int tl = len - 3 - base0;                 // cycle len-3 relative to this pass (uniform)
+        if (tl >= 0 && tl < 4 * WAVE)
+            d_tail = ((unsigned int)__builtin_amdgcn_readlane((int)dpk, tl >> 2) >> (3 * (tl & 3))) & 7u;
+        const uint32_t codes = (ws >> 1) & 0x03030303u;
+        const uint32_t bad = __builtin_amdgcn_perm(0u, CODE_TO_BASE, codes) ^ ws;       // 0 where the byte is A/C/G/T
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = x + j;
+            const bool in = i < len;
+            const unsigned int code = (codes >> (8 * j)) & 3u;
+            const bool acgt = ((bad >> (8 * j)) & 0xffu) == 0u;
+            if (in) {
+                const unsigned int row = acgt ? (0x3120u >> (4 * code)) & 0xfu : 4u;     // rows A T C G, other
+                const unsigned int qn = ((wq >> (8 * j)) & 0xffu) - 33u;
+                atomicAdd(&accs[row * cols + j * cq + (i >> 2)], (1u << 20) + qn);
+                // discontinuity over the 5-wide window clamped to the read (qualitycontrol.py:97-109)
+                const unsigned int d = i < 2 ? d_head : (i > len - 3 ? d_tail : (dpk >> (3 * j)) & 7u);
+                if (d) atomicAdd(&accs[5 * cols + j * cq + (i >> 2)], d);
+            }
+            gc += __popcll(__ballot(in && acgt && (code & 1u)));                         // C = 1, G = 3
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&gch[gc], 1u);
+        atomicAdd(&scal[1], 1ull);
+        if (len > kmer_len) atomicAdd(&scal[0], (unsigned long long)(len - kmer_len));
+    }
+}
+
 __global__ __launch_bounds__(QC_BLOCK) void qc_stat_kernel(DevBatch b, int mate, uint64_t first, uint64_t count, int post,
                                                            const aqc_result* __restrict__ results, int kmer_len,
                                                            unsigned long long* __restrict__ qc /* [QC_ROWS*QC_COLS] */,
@@ -808,8 +874,6 @@ __global__ __launch_bounds__(QC_BLOCK) void qc_stat_kernel(DevBatch b, int mate,
     for (int i = threadIdx.x; i < (QC_LDS_ROWS + 1) * cols; i += QC_BLOCK) qc_smem[i] = 0;
     if (threadIdx.x < 2) scal[threadIdx.x] = 0;
     __syncthreads();
-    // column i lives at word (i & 3) * (cols / 4) + (i >> 2): the four cycles a lane owns are cols/4 words apart and
-    // neighbouring lanes hit neighbouring banks (the natural layout would be a 4-way bank conflict on every add)
     const int cq = cols >> 2;
     const uint64_t nwaves = (uint64_t)gridDim.x * QC_WPB;
     if ((count + nwaves - 1) / nwaves * QC_WPB > (uint64_t)QC_MAX_READS_PER_BLOCK) {      // host sizes the grid; never silently overflow
@@ -840,54 +904,7 @@ __global__ __launch_bounds__(QC_BLOCK) void qc_stat_kernel(DevBatch b, int mate,
             const int len = cur.len;
             if (len > AQC_MAX_READ_LEN || len > cols) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_READ_TOO_LONG); }
             else if (len < 5 && len > 0) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_ARG); }   // IndexError upstream (:106-107)
-            if (usable(cur)) {
-                const uint8_t* gs = reinterpret_cast<const uint8_t*>(cur.s);
-                const uint8_t* gq = reinterpret_cast<const uint8_t*>(cur.q);
-                int gc = 0;
-                unsigned int d_head = 0, d_tail = 0;      // discontinuity of cycle 2 / cycle len-3: the clamped windows
-                for (int base0 = 0; base0 < len; base0 += 4 * WAVE) {
-                    const int x = base0 + 4 * lane;
-                    if (base0 > 0) { ws = load4(gs, x, len, 0); wq = load4(gq, x, len, 0); }
-                    apply_edits(cur, x, ws, wq);
-                    uint32_t prev = __shfl_up(ws, 1), next = __shfl_down(ws, 1);
-                    if (base0 > 0 && lane == 0) { uint32_t dq = 0; prev = load4(gs, x - 4, len, 0); apply_edits(cur, x - 4, prev, dq); }
-                    if (base0 + 4 * WAVE < len && lane == WAVE - 1) { uint32_t dq = 0; next = load4(gs, x + 4, len, 0); apply_edits(cur, x + 4, next, dq); }
-                    // bytes x-2 .. x+5 ; byte k of (v ^ v >> 8) is non-zero iff bases x-2+k and x-1+k differ
-                    const uint32_t vlo = __builtin_amdgcn_alignbit(ws, prev, 16), vhi = __builtin_amdgcn_alignbit(next, ws, 16);
-                    const uint32_t tlo = nonzero_bytes(vlo ^ __builtin_amdgcn_alignbit(vhi, vlo, 8));
-                    const uint32_t thi = nonzero_bytes(vhi ^ (vhi >> 8));
-                    unsigned int dpk = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) dpk |= (unsigned int)__popc(__builtin_amdgcn_alignbit(thi, tlo, 8 * j)) << (3 * j);
-                    if (base0 == 0) d_head = ((unsigned int)__builtin_amdgcn_readlane((int)dpk, 0) >> 6) & 7u;
-                    const int tl = len - 3 - base0;                 // cycle len-3 relative to this pass (uniform)
-                    if (tl >= 0 && tl < 4 * WAVE)
-                        d_tail = ((unsigned int)__builtin_amdgcn_readlane((int)dpk, tl >> 2) >> (3 * (tl & 3))) & 7u;
-                    const uint32_t codes = (ws >> 1) & 0x03030303u;
-                    const uint32_t bad = __builtin_amdgcn_perm(0u, CODE_TO_BASE, codes) ^ ws;       // 0 where the byte is A/C/G/T
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i = x + j;
-                        const bool in = i < len;
-                        const unsigned int code = (codes >> (8 * j)) & 3u;
-                        const bool acgt = ((bad >> (8 * j)) & 0xffu) == 0u;
-                        if (in) {
-                            const unsigned int row = acgt ? (0x3120u >> (4 * code)) & 0xfu : 4u;     // rows A T C G, other
-                            const unsigned int qn = ((wq >> (8 * j)) & 0xffu) - 33u;
-                            atomicAdd(&accs[row * cols + j * cq + (i >> 2)], (1u << 20) + qn);
-                            // discontinuity over the 5-wide window clamped to the read (qualitycontrol.py:97-109)
-                            const unsigned int d = i < 2 ? d_head : (i > len - 3 ? d_tail : (dpk >> (3 * j)) & 7u);
-                            if (d) atomicAdd(&accs[5 * cols + j * cq + (i >> 2)], d);
-                        }
-                        gc += __popcll(__ballot(in && acgt && (code & 1u)));                         // C = 1, G = 3
-                    }
-                }
-                if (lane == 0) {
-                    atomicAdd(&gch[gc], 1u);
-                    atomicAdd(&scal[1], 1ull);
-                    if (len > kmer_len) atomicAdd(&scal[0], (unsigned long long)(len - kmer_len));
-                }
-            }
+            if (usable(cur)) qc_accumulate_read(cur, ws, wq, QcLds{accs, gch, scal, cols}, kmer_len);
             cur = nxt;
         }
     }
@@ -944,19 +961,34 @@ constexpr int KMER_BLOCK = 1024;
 constexpr int KMER_WPB = KMER_BLOCK / WAVE;
 constexpr int KMER_EXQ = 1536;                  // LDS queue of k-mers bound for the open-addressing table (24 KiB)
 constexpr size_t KMER_LDS_BYTES = DENSE_ENTRIES * 2 + (size_t)KMER_EXQ * 16 + 16;
+constexpr int KMER_FUSED_MAX_COLS = 256;         // widest QC accumulator block that still fits behind the table (160 KiB LDS)
+constexpr size_t KMER_FUSED_LDS_BYTES = KMER_LDS_BYTES + sizeof(unsigned int) * (QC_LDS_ROWS + 1) * KMER_FUSED_MAX_COLS + 16;
 constexpr int KMER_PASS_LANES = WAVE - 2;        // the last two lanes of a pass only supply bases to their neighbours
 
 __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int mate, uint64_t first, uint64_t count, int post,
                                                                 const aqc_result* __restrict__ results, int kmer_len,
                                                                 KmerTable kt, unsigned long long order_base,
                                                                 uint16_t* __restrict__ partial, uint32_t reads_per_round,
-                                                                uint32_t n_rounds, int* status) {
+                                                                uint32_t n_rounds, int* status,
+                                                                unsigned long long* __restrict__ qc /* [QC_ROWS*QC_COLS] or null */,
+                                                                int cols) {
     extern __shared__ __attribute__((aligned(16))) unsigned int ktab[];     // 32768 words = 65536 u16 counters
     unsigned long long* const exq_key = reinterpret_cast<unsigned long long*>(ktab + DENSE_ENTRIES / 2);   // parked exotic k-mers
     unsigned long long* const exq_t = exq_key + KMER_EXQ;
     unsigned int* const exq_n = reinterpret_cast<unsigned int*>(exq_t + KMER_EXQ);
+    // fused mode (qc != null, reads <= 256 bases): the per-cycle accumulators of statRead ride along — same descriptor,
+    // same dword of bases — in the LDS left over behind the k-mer table, and fill the issue slots this kernel idles in
+    const bool fused = qc != nullptr;
+    unsigned int* const q_accs = exq_n + 4;
+    unsigned int* const q_gch = q_accs + QC_LDS_ROWS * cols;
+    unsigned long long* const q_scal = reinterpret_cast<unsigned long long*>(q_gch + cols);
+    const QcLds qlds{q_accs, q_gch, q_scal, cols};
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
+    if (fused) {
+        for (int i = threadIdx.x; i < (QC_LDS_ROWS + 1) * cols; i += KMER_BLOCK) q_accs[i] = 0;
+        if (threadIdx.x < 2) q_scal[threadIdx.x] = 0;
+    }
     const unsigned long long kmask = kmer_len >= 8 ? ~0ull : (1ull << (8 * kmer_len)) - 1ull;
     // k-mer with a symbol outside A/C/G/T -> open-addressing table, keyed by its bytes (first seen at time t)
     auto exotic_insert = [&](unsigned long long key, unsigned long long t) {
@@ -977,6 +1009,7 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
     const uint32_t imask = (1u << (2 * kmer_len)) - 1u, kbits = (1u << kmer_len) - 1u;
     unsigned long long* const my_first = kt.dense_first + (size_t)xcc_id() * DENSE_ENTRIES;
     auto usable = [&](const ReadDesc& d) { return d.len >= 5 && d.len <= AQC_MAX_READ_LEN && d.len > kmer_len; };
+    auto qc_usable = [&](const ReadDesc& d) { return fused && d.len >= 5 && d.len <= AQC_MAX_READ_LEN && d.len <= cols; };
     KPROF_DECL
     // every dense k-mer already has a first-seen time from an earlier launch: nothing this launch sees can be earlier
     const bool complete = __syncthreads_and(threadIdx.x < (int)(DENSE_ENTRIES / KRED_ENTRIES) ? (int)kt.complete[threadIdx.x] : 1) != 0;
@@ -993,15 +1026,31 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
             const ReadDesc mine = lane_desc(b, mate, first + myk, myk < r_hi, post, results);
             const int nr = (int)min((uint64_t)WAVE, (r_hi - kb + KMER_WPB - 1) / KMER_WPB);
             ReadDesc cur = bcast_desc(mine, 0);
-            uint32_t pre = PAD;
-            if (usable(cur)) pre = load4(reinterpret_cast<const uint8_t*>(cur.s), 4 * lane, cur.len, PAD);
+            uint32_t pre = PAD, pre_q = 0;
+            if (qc_usable(cur) || usable(cur)) {
+                pre = load4(reinterpret_cast<const uint8_t*>(cur.s), 4 * lane, cur.len, PAD);
+                if (fused) pre_q = load4(reinterpret_cast<const uint8_t*>(cur.q), 4 * lane, cur.len, 0);
+            }
             KPROF(1);
             for (int r = 0; r < nr; ++r) {
                 uint32_t ws = pre;
+                const uint32_t wq0 = pre_q;
                 ReadDesc nxt = cur;
                 if (r + 1 < nr) {
                     nxt = bcast_desc(mine, r + 1);
-                    if (usable(nxt)) pre = load4(reinterpret_cast<const uint8_t*>(nxt.s), 4 * lane, nxt.len, PAD);
+                    if (qc_usable(nxt) || usable(nxt)) {
+                        pre = load4(reinterpret_cast<const uint8_t*>(nxt.s), 4 * lane, nxt.len, PAD);
+                        if (fused) pre_q = load4(reinterpret_cast<const uint8_t*>(nxt.q), 4 * lane, nxt.len, 0);
+                    }
+                }
+                if (fused) {
+                    const int len = cur.len;
+                    if (len > AQC_MAX_READ_LEN || len > cols) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_READ_TOO_LONG); }
+                    else if (len < 5 && len > 0) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_ARG); }   // IndexError upstream (:106-107)
+                    if (qc_usable(cur)) {
+                        // (the bases beyond the read are 'A' here, 0 in qc_stat_kernel: neither is ever looked at)
+                        qc_accumulate_read(cur, ws, wq0, qlds, kmer_len);
+                    }
                 }
                 if (usable(cur)) {
                     const int len = cur.len;
@@ -1086,6 +1135,32 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_s_barrier();
         KPROF(7);
+    }
+    if (fused) {
+        __syncthreads();
+        const int cq = cols >> 2;
+        for (int i = threadIdx.x; i < cols; i += KMER_BLOCK) {
+            const int ci = (i & 3) * cq + (i >> 2);
+            unsigned long long tn = 0, tq = 0;
+#pragma unroll
+            for (int row = 0; row < 5; ++row) {
+                const unsigned int v = q_accs[row * cols + ci];
+                const unsigned long long cnt = v >> 20, qs = v & 0xfffffu;
+                if (row < 4 && v) {
+                    atomicAdd(&qc[(AQC_QC_BASE_COUNT_A + row) * AQC_QC_COLS + i], cnt);
+                    atomicAdd(&qc[(AQC_QC_BASE_QUAL_A + row) * AQC_QC_COLS + i], qs);
+                }
+                tn += cnt; tq += qs;
+            }
+            if (tn) {
+                atomicAdd(&qc[AQC_QC_TOTAL_NUM * AQC_QC_COLS + i], tn);
+                atomicAdd(&qc[AQC_QC_TOTAL_QUAL * AQC_QC_COLS + i], tq);
+            }
+            const unsigned int dv = q_accs[5 * cols + ci];
+            if (dv) atomicAdd(&qc[AQC_QC_DISCONTINUITY * AQC_QC_COLS + i], (unsigned long long)dv);
+            if (q_gch[i]) atomicAdd(&qc[AQC_QC_GC_HIST * AQC_QC_COLS + i], (unsigned long long)q_gch[i]);
+        }
+        if (threadIdx.x < 2 && q_scal[threadIdx.x]) atomicAdd(&qc[AQC_QC_SCALARS * AQC_QC_COLS + threadIdx.x], q_scal[threadIdx.x]);
     }
     KPROF_FLUSH;
 }
