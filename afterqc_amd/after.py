@@ -130,18 +130,46 @@ def processOptions(options, engine=None, device=0):
     return flt.run()
 
 
-def processDir(folder, options):
-    """after.processDir (after.py:101-171): upstream forks one process per file; here the files are
-    handed round-robin to the visible GPUs, one context each, sequentially per GPU."""
-    from . import capi
+def processDir(folder, options, engine_factory=None, n_workers=None):
+    """after.processDir (after.py:101-171): upstream forks one process per file pair; here one worker thread per
+    visible GPU (one context each) takes the file pairs off a shared queue, so N GPUs filter N pairs at a time.
+    `engine_factory(device)` lets the tests inject an engine."""
+    import queue
+    import threading
     jobs = collect_dir_jobs(folder, options)
     if not jobs:
         print("no read files to run with, do you call the program correctly?")
         print("see -h for help")
-        return
-    ngpu = max(1, capi.load_library().aqc_device_count())
+        return []
+    if n_workers is None:
+        from . import capi
+        n_workers = max(1, capi.load_library().aqc_device_count())
+    n_workers = max(1, min(n_workers, len(jobs)))
+    todo = queue.Queue()
     for k, opt in enumerate(jobs):
-        processOptions(opt, device=k % ngpu)
+        todo.put((k, opt))
+    stats = [None] * len(jobs)
+    errors = []
+
+    def worker(device):
+        while True:
+            try:
+                k, opt = todo.get_nowait()
+            except queue.Empty:
+                return
+            try:
+                stats[k] = processOptions(opt, engine=engine_factory(device) if engine_factory else None, device=device)
+            except BaseException as e:          # report after every worker has finished its files
+                errors.append((opt.read1_file, e))
+
+    threads = [threading.Thread(target=worker, args=(d,)) for d in range(n_workers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise RuntimeError("; ".join("%s: %s" % (f, e) for f, e in errors))
+    return stats
 
 
 def main(argv=None):

@@ -379,14 +379,13 @@ class seqFilter:
         overlap_dir = opt.overlap_output_folder if opt.overlap_output_folder is not None else os.path.join(parent, "overlap")
         qc_dir = opt.report_output_folder if opt.report_output_folder is not None else os.path.join(parent, "QC")
         for d in (qc_dir, good_dir, bad_dir):
-            if not os.path.exists(d):
-                os.makedirs(d)
-        if opt.store_overlap and paired and not os.path.exists(overlap_dir):
-            os.makedirs(overlap_dir)
+            os.makedirs(d, exist_ok=True)          # (directory mode runs several files at once)
+        if opt.store_overlap and paired:
+            os.makedirs(overlap_dir, exist_ok=True)
         gzip_out = bool(opt.gzip) or opt.read1_file.endswith(".gz")
         files = [opt.read1_file, opt.read2_file, opt.index1_file, opt.index2_file]
-        if opt.store_overlap and not opt.qc_only and not os.path.exists(overlap_dir):
-            os.makedirs(overlap_dir)   # single-end + store_overlap: upstream opens the writer without the dir
+        if opt.store_overlap and not opt.qc_only:
+            os.makedirs(overlap_dir, exist_ok=True)   # single-end + store_overlap: upstream opens the writer without the dir
         outs = _Outputs(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, opt.compression)
 
         # ---- pass 2: the main loop (preprocesser.py:411-631), one batch at a time

@@ -120,3 +120,32 @@ def test_text_driver_on_gpu(shape, tmp_path, gpu_engine):
             if key != "command":
                 assert json.dumps(stat[key], sort_keys=True) == json.dumps(ref_stat[key], sort_keys=True), (shape, mode, key)
         assert files == ref_files
+
+
+def test_directory_mode_runs_pairs_concurrently(tmp_path):
+    """after.py -d DIR: every R1/R2 pair of the folder, one worker per (here: injected) engine; outputs equal to
+    running each pair on its own"""
+    from oracle import oracle
+    work = str(tmp_path / "in")
+    os.makedirs(work)
+    pairs = []
+    for k in range(3):
+        sub = os.path.join(work, "s%d" % k)
+        os.makedirs(sub)
+        p1, p2 = write_pair(sub, 80 + 10 * k, 80 + 10 * k, seed=100 + k)
+        q1, q2 = os.path.join(work, "sample%d_R1.fq" % k), os.path.join(work, "sample%d_R2.fq" % k)
+        os.rename(p1, q1); os.rename(p2, q2)
+        pairs.append((q1, q2))
+    argv = ["-d", work, "-f", "0", "-t", "0", "-g", os.path.join(work, "good"), "-b", os.path.join(work, "bad"),
+            "-r", os.path.join(work, "QC")]
+    options, _ = after.parseCommand(argv)
+    after.finalize_options(options)
+    stats = after.processDir(work, options, engine_factory=lambda dev: oracle.OracleEngine(), n_workers=2)
+    assert len(stats) == 3 and all(s is not None for s in stats)
+    for k, (q1, q2) in enumerate(pairs):
+        ref_stat, ref_files = run(str(tmp_path), q1, q2, "text", "solo%d" % k)
+        for sub_dir in ("good", "bad"):
+            for fn, data in ref_files.items():
+                if fn.startswith(sub_dir + "/"):
+                    with open(os.path.join(work, fn), "rb") as f:
+                        assert f.read() == data, fn
