@@ -33,6 +33,8 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(capi.Config) == 18 * 4 + 32 + 2 * 4
     assert ctypes.sizeof(capi.BatchStruct) == 8 * 2 + 8 * 7 * 2 + 8 * 5
     assert capi.N_COUNTERS == 4 + 12 + 10 + 16
+    assert ctypes.sizeof(capi.TextChunk) == 8 * 4 + 4 * 2 + 8 * 2          # struct aqc_text_chunk
+    assert ctypes.sizeof(capi.FrameInfo) == 8 * 5 + 4 * 4                  # struct aqc_frame_info
 
 
 def test_no_gpu_means_loud_failure():
