@@ -304,7 +304,7 @@ def load_library():
     lib.aqc_read_stats.argtypes = [P, C.POINTER(BatchStruct), C.c_int32, C.c_int32, C.c_int32, P, P, P]
     lib.aqc_edit_distance.argtypes = [P, C.POINTER(BatchStruct), P]
     lib.aqc_frame.argtypes = [P, C.c_int, C.POINTER(TextChunk), C.POINTER(FrameInfo)]
-    lib.aqc_format.argtypes = [P, C.c_int, C.c_uint64, P]
+    lib.aqc_format.argtypes = [P, C.c_int, C.c_uint64, C.c_int32, P]
     lib.aqc_fetch_text.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.c_uint64]
     lib.aqc_host_alloc.argtypes = [C.c_uint64]
     lib.aqc_host_alloc.restype = C.c_void_p
@@ -453,9 +453,10 @@ class Engine:
         self.slot_n[slot] = info.n
         return info
 
-    def format(self, slot, n):
-        sizes = np.zeros(4, dtype=np.uint64)
-        self._check(self.lib.aqc_format(self.h, slot, int(n), _ptr(sizes)))
+    def format(self, slot, n, store_overlap=False):
+        """sizes[file * 3 + stream], stream 0 good / 1 bad / 2 overlap"""
+        sizes = np.zeros(6, dtype=np.uint64)
+        self._check(self.lib.aqc_format(self.h, slot, int(n), 1 if store_overlap else 0, _ptr(sizes)))
         return [int(x) for x in sizes]
 
     def fetch_text(self, slot, file, stream, dst, cap):

@@ -69,8 +69,8 @@ struct Slot {
     // text in / text out (aqc_frame, aqc_format): per file the line table and the name / strand-line descriptors
     DevBuf t_line_end[2], t_tile[2], t_name_off[2], t_name_len[2], t_plus_off[2], t_plus_len[2], t_qual_len[2];
     DevBuf t_scratch;              // FrameMeta[2] + scan totals
-    DevBuf f_pos, f_tile, f_out[4];
-    uint64_t f_bytes[4] = {0, 0, 0, 0};
+    DevBuf f_pos, f_tile, f_out[6];
+    uint64_t f_bytes[6] = {0, 0, 0, 0, 0, 0};
     bool framed = false, formatted = false;
     FastBatch fview{};
     bool has_canonical = false;
@@ -264,7 +264,7 @@ void aqc_destroy(aqc_ctx* c) {
                           &s.t_line_end[0], &s.t_line_end[1], &s.t_tile[0], &s.t_tile[1], &s.t_name_off[0], &s.t_name_off[1],
                           &s.t_name_len[0], &s.t_name_len[1], &s.t_plus_off[0], &s.t_plus_off[1], &s.t_plus_len[0], &s.t_plus_len[1],
                           &s.t_qual_len[0], &s.t_qual_len[1], &s.t_scratch, &s.f_pos, &s.f_tile, &s.f_out[0], &s.f_out[1], &s.f_out[2],
-                          &s.f_out[3]};
+                          &s.f_out[3], &s.f_out[4], &s.f_out[5]};
         for (DevBuf* b : bufs) b->release();
         for (int k = 0; k < 2; k++)
             if (s.h_o16[k]) (void)hipHostFree(s.h_o16[k]);
@@ -805,7 +805,7 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
     return 0;
 }
 
-int aqc_format(aqc_ctx* c, int slot, uint64_t n, uint64_t bytes_out[4]) {
+int aqc_format(aqc_ctx* c, int slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]) {
     Slot* s;
     int rc = get_slot(c, slot, &s);
     if (rc) return rc;
@@ -818,6 +818,7 @@ int aqc_format(aqc_ctx* c, int slot, uint64_t n, uint64_t bytes_out[4]) {
     v.results = (const aqc_result*)s->results.p;
     v.barcode = c->cfg.barcode ? 1 : 0;
     v.barcode_length = c->cfg.barcode_length;
+    v.store_overlap = (store_overlap && s->paired) ? 1 : 0;
     const DevBuf* sl[2] = {&s->len1, &s->len2};
     const DevBuf* arena[2] = {&s->seq1, &s->seq2};
     const DevBuf* so[2] = {&s->off1, &s->off2};
@@ -832,28 +833,35 @@ int aqc_format(aqc_ctx* c, int slot, uint64_t n, uint64_t bytes_out[4]) {
         v.f[k].plus_off = (const uint32_t*)s->t_plus_off[k].p;
         v.f[k].plus_len = (const uint32_t*)s->t_plus_len[k].p;
     }
-    const int nstreams = s->paired ? 4 : 2;
-    if (s->f_pos.reserve(sizeof(unsigned long long) * 4 * (n ? n : 1)) || s->t_scratch.reserve(256))
+    // streams q = file * 3 + {0 good, 1 bad, 2 overlap}
+    if (s->f_pos.reserve(sizeof(unsigned long long) * 6 * (n ? n : 1)) || s->t_scratch.reserve(256))
         return fail(AQC_ERR_HIP, "hipMalloc failed");
     unsigned long long* d_tot = (unsigned long long*)((uint8_t*)s->t_scratch.p + 128);
-    for (int q = 0; q < nstreams; q++) {
-        OutSize f{v, q >> 1, q & 1};
+    bool live[6];
+    for (int q = 0; q < 6; q++) {
+        live[q] = (q < 3 || s->paired) && (q % 3 != 2 || v.store_overlap);
+        if (!live[q]) continue;
+        OutSize f{v, q / 3, q % 3};
         if ((rc = device_scan(*s, f, n, s->f_tile, (unsigned long long*)s->f_pos.p + (uint64_t)q * n, 0ull, d_tot + q))) return rc;
     }
-    unsigned long long h_tot[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long) * nstreams, hipMemcpyDeviceToHost, s->stream));
+    unsigned long long h_tot[6] = {0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(h_tot), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    for (int q = 0; q < 4; q++) {
-        s->f_bytes[q] = q < nstreams ? h_tot[q] : 0;
+    FormatOut outs{};
+    for (int q = 0; q < 6; q++) {
+        s->f_bytes[q] = live[q] ? h_tot[q] : 0;
         bytes_out[q] = s->f_bytes[q];
         if (s->f_out[q].reserve(s->f_bytes[q] + 64)) return fail(AQC_ERR_HIP, "hipMalloc failed");
+        outs.p[q] = (uint8_t*)s->f_out[q].p;
     }
     if (n) {
         const uint64_t waves = n * (s->paired ? 2 : 1);
         const uint64_t blocks = (waves * WAVE + TXT_BLOCK - 1) / TXT_BLOCK;
         hipLaunchKernelGGL(format_write_kernel, dim3((unsigned)blocks), dim3(TXT_BLOCK), 0, s->stream, v, n,
-                           (const unsigned long long*)s->f_pos.p, (uint8_t*)s->f_out[0].p, (uint8_t*)s->f_out[1].p, (uint8_t*)s->f_out[2].p,
-                           (uint8_t*)s->f_out[3].p);
+                           (const unsigned long long*)s->f_pos.p, outs, 0);
+        if (v.store_overlap)
+            hipLaunchKernelGGL(format_write_kernel, dim3((unsigned)blocks), dim3(TXT_BLOCK), 0, s->stream, v, n,
+                               (const unsigned long long*)s->f_pos.p, outs, 1);
         HIP_TRY(hipGetLastError());
     }
     s->formatted = true;
@@ -865,8 +873,8 @@ int aqc_fetch_text(aqc_ctx* c, int slot, int file, int stream, uint8_t* dst, uin
     int rc = get_slot(c, slot, &s);
     if (rc) return rc;
     if (!s->formatted) return fail(AQC_ERR_STATE, "aqc_fetch_text before aqc_format");
-    if (file < 0 || file > 1 || stream < 0 || stream > 1) return fail(AQC_ERR_ARG, "aqc_fetch_text: bad file/stream");
-    const int q = file * 2 + stream;
+    if (file < 0 || file > 1 || stream < 0 || stream > 2) return fail(AQC_ERR_ARG, "aqc_fetch_text: bad file/stream");
+    const int q = file * 3 + stream;
     if (s->f_bytes[q] > cap) return fail(AQC_ERR_ARG, "aqc_fetch_text: %llu bytes do not fit %llu", (unsigned long long)s->f_bytes[q], (unsigned long long)cap);
     if (s->f_bytes[q]) {
         if (!dst) return fail(AQC_ERR_ARG, "aqc_fetch_text: null destination");

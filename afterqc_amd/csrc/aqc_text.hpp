@@ -292,7 +292,28 @@ struct FormatView {
     int paired;
     int barcode;          // options.barcode: moveBarcodeToName (barcodeprocesser.py:34-45) rewrites the names
     int barcode_length;
+    int store_overlap;    // --store_overlap: third stream with the overlapped tails of good pairs (preprocesser.py:78-84,614-616)
 };
+
+// does record r go to the overlap stream?  paired, GOOD, overlap_len > 30 and every mismatch of the overlap was
+// corrected (distance == 0 or distance == corrected bases, preprocesser.py:614)
+__device__ __forceinline__ bool in_overlap_stream(const FormatView& v, const uint4& w0, const uint4& w1) {
+    if (!v.store_overlap || !v.paired || (int)(w0.x & 0xffu) != AQC_GOOD) return false;
+    const int ovl = (int)(w0.w & 0xffffu), dist = (int)(w0.w >> 16), n_edits = (int)((w0.x >> 8) & 0xffu);
+    if (ovl <= 30) return false;
+    const unsigned long long e_lo = ((unsigned long long)w1.y << 32) | w1.x, e_hi = ((unsigned long long)w1.w << 32) | w1.z;
+    int corrected = 0;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        if (e < n_edits) {
+            const int bit = 40 * e + 16;                       // the edit's kind byte
+            const unsigned int kind = (unsigned int)((bit < 64 ? e_lo >> bit : e_hi >> (bit - 64)) & 0xffu);
+            corrected += (kind == AQC_EDIT_FIX_R1 || kind == AQC_EDIT_FIX_R2) ? 1 : 0;
+        }
+    }
+    return dist == 0 || dist == corrected;
+}
+
 
 // moveBarcodeToName for one read: the name becomes '@' + bases[0:b] + name[first ':' :]; b is the detected barcode
 // length for pairs (preprocesser.py:452), the design length for single-end input (:444).  Records flagged
@@ -304,15 +325,19 @@ __device__ __forceinline__ int moved_barcode_len(const FormatView& v, int file, 
     return min(max(b, 0), (int)seq_len);
 }
 
-// bytes record r contributes to (file, stream); stream 0 = good, 1 = bad
+// bytes record r contributes to (file, stream); stream 0 = good, 1 = bad, 2 = overlap
 struct OutSize {
     FormatView v;
     int file, stream;
     __device__ uint32_t operator()(uint64_t r) const {
         const uint4 w0 = *reinterpret_cast<const uint4*>(v.results + r);
         const int flag = (int)(w0.x & 0xffu);
-        if ((flag == AQC_GOOD ? 0 : 1) != stream) return 0u;
-        const uint32_t len = file == 0 ? (w0.y & 0xffffu) : (w0.z & 0xffffu);
+        uint32_t len = file == 0 ? (w0.y & 0xffffu) : (w0.z & 0xffffu);
+        if (stream == 2) {
+            const uint4 w1 = *(reinterpret_cast<const uint4*>(v.results + r) + 1);
+            if (!in_overlap_stream(v, w0, w1)) return 0u;
+            len = w0.w & 0xffffu;                               // getOverlap: the last overlap_len bases
+        } else if ((flag == AQC_GOOD ? 0 : 1) != stream) return 0u;
         const TextFile& t = v.f[file];
         uint32_t nlen = t.name_len[r];
         if (v.barcode) {
@@ -332,8 +357,12 @@ struct OutSize {
 };
 
 // one wavefront per (record, file): the output record is assembled byte by byte, 64 bytes per step
-__global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, uint64_t n, const unsigned long long* __restrict__ pos /* [2 files][2 streams][n] */,
-                                                                 uint8_t* out00, uint8_t* out01, uint8_t* out10, uint8_t* out11) {
+struct FormatOut {
+    uint8_t* p[6];        // [file * 3 + stream]
+};
+
+__global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, uint64_t n, const unsigned long long* __restrict__ pos /* [2 files][3 streams][n] */,
+                                                                 FormatOut outs, int overlap_pass) {
     const int lane = lane_id();
     const uint64_t wid = ((uint64_t)blockIdx.x * TXT_BLOCK + threadIdx.x) / WAVE;
     const int nfiles = v.paired ? 2 : 1;
@@ -343,10 +372,13 @@ __global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, u
     const uint4 w0 = *reinterpret_cast<const uint4*>(v.results + r);
     const uint4 w1 = *(reinterpret_cast<const uint4*>(v.results + r) + 1);
     const int flag = (int)(w0.x & 0xffu), n_edits = (int)((w0.x >> 8) & 0xffu);
-    const int stream = flag == AQC_GOOD ? 0 : 1;
+    if (overlap_pass && !in_overlap_stream(v, w0, w1)) return;
+    const int stream = overlap_pass ? 2 : (flag == AQC_GOOD ? 0 : 1);
     const int len1 = (int)(w0.y & 0xffffu), len2 = (int)(w0.z & 0xffffu), ovl = (int)(w0.w & 0xffffu);
-    const int st = file == 0 ? (int)(w0.x >> 16) : (int)(w0.y >> 16);
-    const int len = file == 0 ? len1 : len2;
+    // the slice of the original read that is written: the final read, or its last overlap_len bases (getOverlap)
+    const int cut = overlap_pass ? (file == 0 ? len1 : len2) - ovl : 0;
+    const int st = (file == 0 ? (int)(w0.x >> 16) : (int)(w0.y >> 16)) + cut;
+    const int len = overlap_pass ? ovl : (file == 0 ? len1 : len2);
     // the walk's edits in this mate's final coordinates: position, new base (0 = keep), new quality
     int e_pos[3] = {-1, -1, -1};
     uint32_t e_val[3] = {0, 0, 0};
@@ -359,7 +391,7 @@ __global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, u
             if (bit + 40 > 64) x |= bit < 64 ? e_hi << (64 - bit) : e_hi >> (bit - 64);
             const int o = (int)(x & 0xffffu);
             const uint32_t kind = (uint32_t)(x >> 16) & 0xffu, base = (uint32_t)(x >> 24) & 0xffu, qual = (uint32_t)(x >> 32) & 0xffu;
-            const int p = file == 0 ? len1 - ovl + o : len2 - 1 - o;
+            const int p = (file == 0 ? len1 - ovl + o : len2 - 1 - o) - cut;
             if (kind == AQC_EDIT_MASK) { e_pos[e] = p; e_val[e] = (uint32_t)'!'; }
             else if ((kind == AQC_EDIT_FIX_R1 && file == 0) || (kind == AQC_EDIT_FIX_R2 && file == 1)) { e_pos[e] = p; e_val[e] = (base << 8) | qual; }
         }
@@ -370,7 +402,7 @@ __global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, u
     const uint8_t* plus = t.text + t.plus_off[r];
     const uint8_t* qual = t.text + t.qual_off[r] + st;
     const int nlen = (int)t.name_len[r], plen = (int)t.plus_len[r];
-    const int flen = stream ? FLAG_TEXT_LEN[flag] : 0;
+    const int flen = stream == 1 ? FLAG_TEXT_LEN[flag] : 0;
     // barcode moved into the name: '@' + [FLAG] + bases[0:mb] + name[cpos:]
     const int mb = v.barcode ? moved_barcode_len(v, file, flag, w1.w >> 24, t.seq_len[r]) : -1;
     int cpos = nlen - 1;
@@ -388,15 +420,14 @@ __global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, u
     const int b_plus = b_seq + 1 + plen;       // strand line then '\n'
     const int b_qual = b_plus + 1 + len;       // qualities then '\n'
     const int total = b_qual + 1;
-    uint8_t* const outs[4] = {out00, out01, out10, out11};
-    uint8_t* dst = outs[file * 2 + stream] + pos[(uint64_t)(file * 2 + stream) * n + r];
+    uint8_t* dst = outs.p[file * 3 + stream] + pos[(uint64_t)(file * 3 + stream) * n + r];
     for (int j = lane; j < total; j += WAVE) {
         uint8_t c;
         if (j < b_name) {
             // "@" + FLAG + name[1:] for a bad record (preprocesser.py:213-219), the name itself for a good one;
             // with a moved barcode the name is '@' + barcode + name[cpos:] before that rule applies
             if (mb < 0) {
-                if (j == 0 || !stream) c = stream ? (uint8_t)'@' : name[j];
+                if (j == 0 || stream != 1) c = stream == 1 ? (uint8_t)'@' : name[j];
                 else if (j <= flen) c = (uint8_t)FLAG_TEXT[flag][j - 1];
                 else c = name[j - flen];
             } else {

@@ -200,8 +200,8 @@ class _TextSink:
 
     def __init__(self, eng, writers, n_slots):
         self.eng = eng
-        self.writers = writers                       # per file (good, bad)
-        self.sets = [[None] * 4 for _ in range(self.N_SETS)]
+        self.writers = writers                       # per file (good, bad, overlap); None = not written
+        self.sets = [[None] * 6 for _ in range(self.N_SETS)]
         self.set_free = [threading.Semaphore(1) for _ in range(self.N_SETS)]
         self.slot_free = [threading.Semaphore(1) for _ in range(n_slots)]
         self.fq = queue.Queue()
@@ -223,15 +223,15 @@ class _TextSink:
             try:
                 self.set_free[which].acquire()           # the writer is done with this buffer set
                 if self.err is None:
-                    for q4, nbytes in enumerate(sizes):
-                        if q4 // 2 >= len(self.writers) or nbytes == 0:
+                    for q, nbytes in enumerate(sizes):
+                        if q // 3 >= len(self.writers) or nbytes == 0 or self.writers[q // 3][q % 3] is None:
                             continue
-                        buf = self.sets[which][q4]
+                        buf = self.sets[which][q]
                         if buf is None or buf.nbytes < nbytes:
                             if buf is not None:
                                 buf.free()
-                            buf = self.sets[which][q4] = self.eng.host_buffer(nbytes + nbytes // 4 + 4096)
-                        self.eng.fetch_text(slot, q4 // 2, q4 % 2, buf.array, buf.nbytes)
+                            buf = self.sets[which][q] = self.eng.host_buffer(nbytes + nbytes // 4 + 4096)
+                        self.eng.fetch_text(slot, q // 3, q % 3, buf.array, buf.nbytes)
             except BaseException as e:
                 self.err = e
             finally:
@@ -247,9 +247,9 @@ class _TextSink:
             which, sizes = job
             try:
                 if self.err is None:
-                    for q4, nbytes in enumerate(sizes):
-                        if nbytes and q4 // 2 < len(self.writers):
-                            self.writers[q4 // 2][q4 % 2].write_bytes(self.sets[which][q4].view[:nbytes])
+                    for q, nbytes in enumerate(sizes):
+                        if nbytes and q // 3 < len(self.writers) and self.writers[q // 3][q % 3] is not None:
+                            self.writers[q // 3][q % 3].write_bytes(self.sets[which][q].view[:nbytes])
             except BaseException as e:
                 self.err = e
             finally:
@@ -392,9 +392,8 @@ class seqFilter:
         # the per-read settings now include the resolved trim values
         eng.set_config(build_config(opt, paired, has_i2))
         # text in / text out on the device (aqc_frame / aqc_format) whenever the run needs nothing of the host per
-        # record; index files, --store_overlap and --qc_only keep
-        # the host-side framing and writer below
-        self.text_path = (self.use_text_path and not opt.store_overlap and not opt.qc_only and not has_i1 and not has_i2)
+        # record; runs with index files (-7 / -5) keep the host-side framing and writer below
+        self.text_path = self.use_text_path and not has_i1 and not has_i2
         t_p2 = time.perf_counter()
         if self.text_path:
             extra_bases = self._run_text(eng, opt, outs, paired)
@@ -480,7 +479,7 @@ class seqFilter:
         files = [opt.read1_file] + ([opt.read2_file] if paired else [])
         inputs = [_TextInput(eng, f, self.chunk_bytes) for f in files]
         n_slots = min(2, getattr(eng, "n_slots", 1))
-        sink = _TextSink(eng, [(outs.good[k], outs.bad[k]) for k in range(len(files))], n_slots)
+        sink = _TextSink(eng, [(outs.good[k], outs.bad[k], outs.overlap[k]) for k in range(len(files))], n_slots)
         total = 0
         extra_bases = 0
         slot = 0
@@ -515,7 +514,18 @@ class seqFilter:
                             inp.grow(cur)                                  # not even one record fits the buffer
                         inp.carry(cur, consumed[k], fills[k][0], fills[k][1], eofs[k] or (k == 1 and done2))
                 if n:
-                    eng.run(slot)
+                    limit = capi.UINT64_MAX
+                    if opt.qc_only:
+                        # --qc_only stops at the first good record whose 1-based index reaches qc_sample (:630-631):
+                        # verdicts first (nothing accumulated), then the accumulating run up to that record
+                        eng.run(slot, 0)
+                        flags = eng.fetch_results(slot)[:n]["flag"]
+                        hit = np.flatnonzero((flags == capi.GOOD) & (total + 1 + np.arange(n) >= opt.qc_sample))
+                        if len(hit):
+                            n = int(hit[0]) + 1
+                            stop = True
+                        limit = n
+                    eng.run(slot, limit)
                     # post-filter QC on good records while TOTAL_READS < qc_sample (preprocesser.py:624-627)
                     n_qc = n if opt.qc_sample <= 0 else max(0, min(n, opt.qc_sample - 1 - total))
                     if n_qc > 0:
@@ -523,8 +533,12 @@ class seqFilter:
                         if paired:
                             eng.qc_stat(slot, capi.QC_R2_POST, 1, 0, n_qc, 1)
                         eng.sync(slot)       # the sampling kernels share per-context scratch: never two chunks at once
-                    sizes = eng.format(slot, n)
-                    sink.emit(slot, sizes)   # (the fetch thread releases the slot)
+                    if opt.qc_only:
+                        eng.sync(slot)
+                        sink.release_slot(slot)
+                    else:
+                        sizes = eng.format(slot, n, bool(opt.store_overlap))
+                        sink.emit(slot, sizes)   # (the fetch thread releases the slot)
                     total += n
                 else:
                     sink.release_slot(slot)

@@ -281,10 +281,12 @@ int aqc_frame(aqc_ctx* ctx, int slot, const aqc_text_chunk* chunk, aqc_frame_inf
  * [0, n) of a framed slot after aqc_run: builds, in record order, the text of the good and of the bad output
  * of each file (name / bases / strand line / qualities + "\n"; bad names "@" + FLAG + name[1:]; trimmed
  * slices with the walk's edits applied; with cfg.barcode the names carry the moved barcode,
- * barcodeprocesser.py:34-45).  bytes_out = {good R1, bad R1, good R2, bad R2}.  Index files and --store_overlap
- * are not handled here (host side). */
-int aqc_format(aqc_ctx* ctx, int slot, uint64_t n, uint64_t bytes_out[4]);
-/* copy one formatted stream (file 0/1, stream 0 good / 1 bad) to host memory and wait for it */
+ * barcodeprocesser.py:34-45).  store_overlap != 0 (--store_overlap, pairs only) adds the third stream: name / last
+ * overlap_len bases / strand line / last overlap_len qualities of every good pair with overlap_len > 30 whose
+ * mismatches were all corrected (getOverlap, preprocesser.py:78-84,614-616).
+ * bytes_out[file * 3 + stream], stream 0 good / 1 bad / 2 overlap.  Index files are not handled here (host side). */
+int aqc_format(aqc_ctx* ctx, int slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]);
+/* copy one formatted stream (file 0/1, stream 0 good / 1 bad / 2 overlap) to host memory and wait for it */
 int aqc_fetch_text(aqc_ctx* ctx, int slot, int file, int stream, uint8_t* dst, uint64_t cap);
 /* page-locked host memory for text chunks and fetched streams (hipHostMalloc): full-rate DMA */
 void* aqc_host_alloc(uint64_t bytes);

@@ -368,11 +368,12 @@ def _oracle_frame(self, slot, text1, bytes1, final1, text2=None, bytes2=0, final
     return info
 
 
-def _oracle_format(self, slot, n):
-    """seqFilter.writeReads (preprocesser.py:206-232) + Writer.writeLines (fastq.py:87-93), index files / overlap store aside"""
+def _oracle_format(self, slot, n, store_overlap=False):
+    """seqFilter.writeReads (preprocesser.py:206-232) + Writer.writeLines (fastq.py:87-93) + getOverlap (:78-84);
+    index files aside.  Streams [file * 3 + stream], stream 0 good / 1 bad / 2 overlap"""
     res = self.results[slot]
-    b = self.slots[slot]
-    out = [bytearray(), bytearray(), bytearray(), bytearray()]
+    out = [bytearray() for _ in range(6)]
+    paired = len(self._text[slot]) == 2
     for k, (buf, records) in enumerate(self._text[slot]):
         for r in range(n):
             (no, nl), (so, sl), (po, pl), (qo, ql) = records[r]
@@ -385,16 +386,21 @@ def _oracle_format(self, slot, n):
                 code = (int(rr["barcode"]) & 15) if k == 0 else (int(rr["barcode"]) >> 4)
                 blen = code - 2 + self.cfg.barcode_length if self.cfg.paired else self.cfg.barcode_length
                 name = b"@" + buf[so:so + sl][0:max(blen, 0)] + name[name.find(b":"):]
+            ov, dist = int(rr["overlap_len"]), int(rr["distance"])
+            if store_overlap and paired and flag == capi.GOOD and ov > 30:
+                corrected = sum(1 for e in range(int(rr["n_edits"])) if int(rr["edits"][e]["kind"]) in (capi.EDIT_FIX_R1, capi.EDIT_FIX_R2))
+                if dist == 0 or dist == corrected:               # preprocesser.py:614-616
+                    out[3 * k + 2] += name + b"\n" + seq[len(seq) - ov:] + b"\n" + plus + b"\n" + qual[len(qual) - ov:] + b"\n"
             stream = 0 if flag == capi.GOOD else 1
             if stream:
                 name = b"@" + FLAG_NAMES_B[flag] + name[1:]
-            out[2 * k + stream] += name + b"\n" + seq + b"\n" + plus + b"\n" + qual + b"\n"
+            out[3 * k + stream] += name + b"\n" + seq + b"\n" + plus + b"\n" + qual + b"\n"
     self._fmt[slot] = [bytes(o) for o in out]
     return [len(o) for o in out]
 
 
 def _oracle_fetch_text(self, slot, file, stream, dst, cap):
-    data = self._fmt[slot][2 * file + stream]
+    data = self._fmt[slot][3 * file + stream]
     if len(data) > cap:
         raise capi.AqcError(-2, "fetch_text: destination too small")
     if data:

@@ -1,7 +1,7 @@
 """Randomised parity of the whole text path (-m gpu): for random option sets and dirty / ragged synthetic pairs the
 device pipeline aqc_frame -> aqc_run -> aqc_qc_stat -> aqc_format must reproduce, byte for byte, what the oracle
 engine (scalar restatement of fastq.Reader / the per-read loop / writeReads) makes of the same text chunks:
-verdict records, counters, histograms, QC accumulators, k-mer dictionaries and the four output streams."""
+verdict records, counters, histograms, QC accumulators, k-mer dictionaries and the six output streams."""
 import numpy as np
 import pytest
 
@@ -50,7 +50,7 @@ def pad(data):
     return a
 
 
-def run_text(eng, cfg, t1, t2, chunk):
+def run_text(eng, cfg, t1, t2, chunk, store_overlap=False):
     """feed the texts in chunks (lock step, carry-over) exactly like preprocesser._run_text; collect everything"""
     eng.set_config(cfg)
     eng.set_circles([])
@@ -60,7 +60,7 @@ def run_text(eng, cfg, t1, t2, chunk):
     pos = [0] * len(texts)
     left = [b""] * len(texts)
     done = [False] * len(texts)
-    streams = [b"", b"", b"", b""]
+    streams = [b""] * 6
     results = []
     total = 0
     while True:
@@ -81,12 +81,12 @@ def run_text(eng, cfg, t1, t2, chunk):
             if paired:
                 eng.qc_stat(0, capi.QC_R2_POST, 1, 0, n, 1)
             results.append(eng.fetch_results(0)[:n].copy())
-            sizes = eng.format(0, n)
-            for q4, nb in enumerate(sizes):
+            sizes = eng.format(0, n, store_overlap)
+            for q, nb in enumerate(sizes):
                 if nb:
                     out = np.zeros(nb, dtype=np.uint8)
-                    eng.fetch_text(0, q4 // 2, q4 % 2, out, nb)
-                    streams[q4] += out.tobytes()
+                    eng.fetch_text(0, q // 3, q % 3, out, nb)
+                    streams[q] += out.tobytes()
             total += n
         done1 = (info.eof1 or finals[0]) and info.avail1 == n
         done2 = paired and (info.eof2 or finals[1]) and info.avail2 == n
@@ -121,12 +121,15 @@ def test_text_path_random_options(gpu_engine, seed):
     t2 = render(d, "2", rng, crlf) if paired else None
     cfg = random_cfg(rng, paired)
     chunk = int(rng.choice([7000, 50_000, 10_000_000]))
-    g = run_text(gpu_engine, cfg, t1, t2, chunk)
-    o = run_text(oracle.OracleEngine(), cfg, t1, t2, chunk)
+    store = bool(seed % 2)
+    g = run_text(gpu_engine, cfg, t1, t2, chunk, store)
+    o = run_text(oracle.OracleEngine(), cfg, t1, t2, chunk, store)
     assert len(g["res"]) == len(o["res"]) == n
     assert np.array_equal(g["res"].view(np.uint8), o["res"].view(np.uint8))
-    for q4 in range(4):
-        assert g["streams"][q4] == o["streams"][q4], "stream %d" % q4
+    for q in range(6):
+        assert g["streams"][q] == o["streams"][q], "stream %d" % q
+    if store and paired and not cfg.no_overlap:
+        assert len(o["streams"][2]) > 0 and len(o["streams"][5]) > 0
     assert g["counters"] == o["counters"]
     assert g["hist"] == o["hist"]
     assert g["qc"] == o["qc"]
