@@ -208,6 +208,21 @@ def main():
                                                 "sample": "%d threads x %d pairs, %.2f s" % (T, per, ta)}
         except Exception as e:      # the 1-core figure above is the contract; this one is extra
             out["cpu_baseline"]["all_cores"] = {"error": str(e)}
+        # and the reference's own kind of speed: the same loop as pure Python (strings, per-base loops), 1 core —
+        # the stand-in for "CPython running after.py", which cannot travel to this box
+        try:
+            from oracle import pyloop
+            mp = min(20_000, m)
+            tp = time.perf_counter()
+            py = pyloop.run_batch(sub, cfg, 0, mp)
+            tp = time.perf_counter() - tp
+            gflags = eng.fetch_results(0)[:mp]["flag"]
+            out["cpu_baseline"]["cpython_standin"] = {
+                "value": round(2 * mp / tp / 1e6, 5), "unit": "Mreads/s", "cores": 1,
+                "sample": "first %d pairs, oracle/pyloop.py (pure-Python restatement of the reference loop), %.1f s" % (mp, tp),
+                "matches_gpu": bool(all(int(p["flag"]) == int(f) for p, f in zip(py, gflags)))}
+        except Exception as e:
+            out["cpu_baseline"]["cpython_standin"] = {"error": str(e)}
     if rank == 0:
         print(json.dumps(out))
     eng.close()
