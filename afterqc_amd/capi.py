@@ -305,6 +305,7 @@ def load_library():
     lib.aqc_edit_distance.argtypes = [P, C.POINTER(BatchStruct), P]
     lib.aqc_frame.argtypes = [P, C.c_int, C.POINTER(TextChunk), C.POINTER(FrameInfo)]
     lib.aqc_format.argtypes = [P, C.c_int, C.c_uint64, C.c_int32, P]
+    lib.aqc_format_plain.argtypes = [P, C.c_int, C.c_int, C.c_uint64, C.c_int32, P]
     lib.aqc_fetch_text.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.c_uint64]
     lib.aqc_host_alloc.argtypes = [C.c_uint64]
     lib.aqc_host_alloc.restype = C.c_void_p
@@ -313,7 +314,8 @@ def load_library():
     for name in ("aqc_create", "aqc_device_name", "aqc_set_config", "aqc_set_circles", "aqc_reset_stats", "aqc_upload",
                  "aqc_run", "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_timing_reset",
                  "aqc_timing_mean", "aqc_get_counters", "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers",
-                 "aqc_overlap", "aqc_read_stats", "aqc_edit_distance", "aqc_frame", "aqc_format", "aqc_fetch_text"):
+                 "aqc_overlap", "aqc_read_stats", "aqc_edit_distance", "aqc_frame", "aqc_format", "aqc_format_plain",
+                 "aqc_fetch_text"):
         getattr(lib, name).restype = C.c_int
     if lib.aqc_abi_version() != 1:
         raise RuntimeError("libafterqc_hip.so ABI version mismatch")
@@ -326,7 +328,8 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_last_error", "aq
                     "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_timing_reset",
                     "aqc_timing_mean", "aqc_get_counters",
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
-                    "aqc_edit_distance", "aqc_frame", "aqc_format", "aqc_fetch_text", "aqc_host_alloc", "aqc_host_free"]
+                    "aqc_edit_distance", "aqc_frame", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_host_alloc",
+                    "aqc_host_free"]
 
 
 class Engine:
@@ -457,6 +460,12 @@ class Engine:
         """sizes[file * 3 + stream], stream 0 good / 1 bad / 2 overlap"""
         sizes = np.zeros(6, dtype=np.uint64)
         self._check(self.lib.aqc_format(self.h, slot, int(n), 1 if store_overlap else 0, _ptr(sizes)))
+        return [int(x) for x in sizes]
+
+    def format_plain(self, slot, verdict_slot, n, store_overlap=False):
+        """index files: whole records of `slot`, routed / renamed by the verdicts of `verdict_slot`"""
+        sizes = np.zeros(6, dtype=np.uint64)
+        self._check(self.lib.aqc_format_plain(self.h, slot, verdict_slot, int(n), 1 if store_overlap else 0, _ptr(sizes)))
         return [int(x) for x in sizes]
 
     def fetch_text(self, slot, file, stream, dst, cap):

@@ -805,20 +805,26 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
     return 0;
 }
 
-int aqc_format(aqc_ctx* c, int slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]) {
+static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]) {
     Slot* s;
     int rc = get_slot(c, slot, &s);
     if (rc) return rc;
+    const bool plain = verdict_slot != slot;
+    Slot* vs = s;
+    if (plain && (rc = get_slot(c, verdict_slot, &vs))) return rc;
     if (!bytes_out) return fail(AQC_ERR_ARG, "aqc_format: null argument");
     if (!s->framed) return fail(AQC_ERR_STATE, "aqc_format needs a slot filled by aqc_frame");
-    if (!s->ran) return fail(AQC_ERR_STATE, "aqc_format before aqc_run");
-    if (n > s->n) return fail(AQC_ERR_ARG, "aqc_format: n exceeds the slot's records");
+    if (!vs->ran) return fail(AQC_ERR_STATE, "aqc_format before aqc_run");
+    if (n > s->n || n > vs->n) return fail(AQC_ERR_ARG, "aqc_format: n exceeds the slot's records");
+    if (plain) HIP_TRY(hipStreamSynchronize(vs->stream));      // the verdicts come from another slot's stream
     FormatView v{};
     v.paired = s->paired ? 1 : 0;
-    v.results = (const aqc_result*)s->results.p;
+    v.results = (const aqc_result*)vs->results.p;
+    v.plain = plain ? 1 : 0;
+    v.verdict_paired = vs->paired ? 1 : 0;
     v.barcode = c->cfg.barcode ? 1 : 0;
     v.barcode_length = c->cfg.barcode_length;
-    v.store_overlap = (store_overlap && s->paired) ? 1 : 0;
+    v.store_overlap = (store_overlap && vs->paired) ? 1 : 0;
     const DevBuf* sl[2] = {&s->len1, &s->len2};
     const DevBuf* arena[2] = {&s->seq1, &s->seq2};
     const DevBuf* so[2] = {&s->off1, &s->off2};
@@ -866,6 +872,15 @@ int aqc_format(aqc_ctx* c, int slot, uint64_t n, int32_t store_overlap, uint64_t
     }
     s->formatted = true;
     return 0;
+}
+
+int aqc_format(aqc_ctx* c, int slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]) {
+    return format_impl(c, slot, slot, n, store_overlap, bytes_out);
+}
+
+int aqc_format_plain(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]) {
+    if (slot == verdict_slot) return fail(AQC_ERR_ARG, "aqc_format_plain: the verdicts must come from another slot");
+    return format_impl(c, slot, verdict_slot, n, store_overlap, bytes_out);
 }
 
 int aqc_fetch_text(aqc_ctx* c, int slot, int file, int stream, uint8_t* dst, uint64_t cap) {

@@ -293,12 +293,15 @@ struct FormatView {
     int barcode;          // options.barcode: moveBarcodeToName (barcodeprocesser.py:34-45) rewrites the names
     int barcode_length;
     int store_overlap;    // --store_overlap: third stream with the overlapped tails of good pairs (preprocesser.py:78-84,614-616)
+    int plain;            // index files (-7 / -5): records are written whole (no trim, no edits, no barcode move); only
+                          // the verdicts — of the read pairs in `results` — route them and rename the bad ones
+    int verdict_paired;   // the verdicts belong to read PAIRS (overlap stream exists)
 };
 
 // does record r go to the overlap stream?  paired, GOOD, overlap_len > 30 and every mismatch of the overlap was
 // corrected (distance == 0 or distance == corrected bases, preprocesser.py:614)
 __device__ __forceinline__ bool in_overlap_stream(const FormatView& v, const uint4& w0, const uint4& w1) {
-    if (!v.store_overlap || !v.paired || (int)(w0.x & 0xffu) != AQC_GOOD) return false;
+    if (!v.store_overlap || !v.verdict_paired || (int)(w0.x & 0xffu) != AQC_GOOD) return false;
     const int ovl = (int)(w0.w & 0xffffu), dist = (int)(w0.w >> 16), n_edits = (int)((w0.x >> 8) & 0xffu);
     if (ovl <= 30) return false;
     const unsigned long long e_lo = ((unsigned long long)w1.y << 32) | w1.x, e_hi = ((unsigned long long)w1.w << 32) | w1.z;
@@ -338,9 +341,10 @@ struct OutSize {
             if (!in_overlap_stream(v, w0, w1)) return 0u;
             len = w0.w & 0xffffu;                               // getOverlap: the last overlap_len bases
         } else if ((flag == AQC_GOOD ? 0 : 1) != stream) return 0u;
+        if (v.plain) len = v.f[file].seq_len[r];                // index records go out whole
         const TextFile& t = v.f[file];
         uint32_t nlen = t.name_len[r];
-        if (v.barcode) {
+        if (v.barcode && !v.plain) {
             const uint32_t bc = reinterpret_cast<const uint8_t*>(v.results + r)[31];
             const int b = moved_barcode_len(v, file, flag, bc, t.seq_len[r]);
             if (b >= 0) {
@@ -376,16 +380,17 @@ __global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, u
     const int stream = overlap_pass ? 2 : (flag == AQC_GOOD ? 0 : 1);
     const int len1 = (int)(w0.y & 0xffffu), len2 = (int)(w0.z & 0xffffu), ovl = (int)(w0.w & 0xffffu);
     // the slice of the original read that is written: the final read, or its last overlap_len bases (getOverlap)
-    const int cut = overlap_pass ? (file == 0 ? len1 : len2) - ovl : 0;
-    const int st = (file == 0 ? (int)(w0.x >> 16) : (int)(w0.y >> 16)) + cut;
-    const int len = overlap_pass ? ovl : (file == 0 ? len1 : len2);
+    const TextFile& t = v.f[file];
+    const int cut = v.plain ? 0 : (overlap_pass ? (file == 0 ? len1 : len2) - ovl : 0);
+    const int st = v.plain ? 0 : (file == 0 ? (int)(w0.x >> 16) : (int)(w0.y >> 16)) + cut;
+    const int len = v.plain ? (int)t.seq_len[r] : (overlap_pass ? ovl : (file == 0 ? len1 : len2));
     // the walk's edits in this mate's final coordinates: position, new base (0 = keep), new quality
     int e_pos[3] = {-1, -1, -1};
     uint32_t e_val[3] = {0, 0, 0};
     const unsigned long long e_lo = ((unsigned long long)w1.y << 32) | w1.x, e_hi = ((unsigned long long)w1.w << 32) | w1.z;
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
-        if (e < n_edits) {
+        if (e < n_edits && !v.plain) {
             const int bit = 40 * e;
             unsigned long long x = bit < 64 ? e_lo >> bit : 0ull;
             if (bit + 40 > 64) x |= bit < 64 ? e_hi << (64 - bit) : e_hi >> (bit - 64);
@@ -396,7 +401,6 @@ __global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, u
             else if ((kind == AQC_EDIT_FIX_R1 && file == 0) || (kind == AQC_EDIT_FIX_R2 && file == 1)) { e_pos[e] = p; e_val[e] = (base << 8) | qual; }
         }
     }
-    const TextFile& t = v.f[file];
     const uint8_t* name = t.text + t.name_off[r];
     const uint8_t* seq = t.text + t.seq_off[r] + st;
     const uint8_t* plus = t.text + t.plus_off[r];
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, u
     const int nlen = (int)t.name_len[r], plen = (int)t.plus_len[r];
     const int flen = stream == 1 ? FLAG_TEXT_LEN[flag] : 0;
     // barcode moved into the name: '@' + [FLAG] + bases[0:mb] + name[cpos:]
-    const int mb = v.barcode ? moved_barcode_len(v, file, flag, w1.w >> 24, t.seq_len[r]) : -1;
+    const int mb = (v.barcode && !v.plain) ? moved_barcode_len(v, file, flag, w1.w >> 24, t.seq_len[r]) : -1;
     int cpos = nlen - 1;
     if (mb >= 0) {
         for (int i0 = 0; i0 < nlen; i0 += WAVE) {

@@ -392,10 +392,13 @@ class seqFilter:
         # the per-read settings now include the resolved trim values
         eng.set_config(build_config(opt, paired, has_i2))
         # text in / text out on the device (aqc_frame / aqc_format) whenever the run needs nothing of the host per
-        # record; runs with index files (-7 / -5) keep the host-side framing and writer below
-        self.text_path = self.use_text_path and not has_i1 and not has_i2
+        # record (use_text_path=False keeps the host-side framing and writer below as a cross-check)
+        self.text_path = self.use_text_path
         t_p2 = time.perf_counter()
-        if self.text_path:
+        if self.text_path and (has_i1 or has_i2):
+            extra_bases = self._run_text_indexed(eng, opt, outs, paired)
+            readers = []
+        elif self.text_path:
             extra_bases = self._run_text(eng, opt, outs, paired)
             readers = []
         else:
@@ -419,6 +422,107 @@ class seqFilter:
             eng.close()
             self.engine = None
         return self.stat
+
+    # ---- pass 2, text path with index files (-7 / -5): four lock-stepped inputs, two device slots ---------------------
+    def _run_text_indexed(self, eng, opt, outs, paired):
+        """Like _run_text, for runs with index files: the reads are framed into slot 0, the index reads into slot 1 (capped
+        at the reads' record count), the index records are formatted whole under the reads' verdicts
+        (aqc_format_plain).  Rare in practice, so this variant is kept simple: one chunk at a time, fetch and write inline."""
+        files = [opt.read1_file, opt.read2_file, opt.index1_file, opt.index2_file]
+        present = [k for k in range(4) if files[k] is not None]
+        groups = [[k for k in present if k < 2], [k for k in present if k >= 2]]
+        inputs = dict((k, _TextInput(eng, files[k], self.chunk_bytes)) for k in present)
+        writers = dict((k, (outs.good[k], outs.bad[k], outs.overlap[k])) for k in present)
+        hold = {}
+        total = 0
+        extra_bases = 0
+        cur = 0
+        UNLIMITED = capi.UINT64_MAX
+
+        def frame_group(slot, g, fills, cap):
+            a = g[0]
+            if len(g) > 1:
+                b = g[1]
+                return eng.frame(slot, inputs[a].bufs[cur].array, fills[a][0], fills[a][1], inputs[b].bufs[cur].array, fills[b][0],
+                                 fills[b][1], max_records=cap, first_index=total)
+            return eng.frame(slot, inputs[a].bufs[cur].array, fills[a][0], fills[a][1], max_records=cap, first_index=total)
+
+        def per_file(info, g):
+            d = {g[0]: (int(info.avail1), bool(info.eof1), int(info.consumed1))}
+            if len(g) > 1:
+                d[g[1]] = (int(info.avail2), bool(info.eof2), int(info.consumed2))
+            return d
+
+        def write_streams(slot, g, sizes):
+            for q, nbytes in enumerate(sizes):
+                if nbytes == 0 or q // 3 >= len(g):
+                    continue
+                w = writers[g[q // 3]][q % 3]
+                if w is None:
+                    continue
+                buf = hold.get(q)
+                if buf is None or buf.nbytes < nbytes:
+                    if buf is not None:
+                        buf.free()
+                    buf = hold[q] = eng.host_buffer(nbytes + nbytes // 4 + 4096)
+                eng.fetch_text(slot, q // 3, q % 3, buf.array, buf.nbytes)
+                w.write_bytes(buf.view[:nbytes])
+
+        try:
+            for k in present:
+                inputs[k].start_fill(cur, 0)
+            while True:
+                fills = dict((k, inputs[k].wait_fill()) for k in present)
+                info_a = frame_group(0, groups[0], fills, UNLIMITED)
+                info_b = frame_group(1, groups[1], fills, int(info_a.n))
+                if int(info_b.n) < int(info_a.n):
+                    info_a = frame_group(0, groups[0], fills, int(info_b.n))     # the index chunk holds fewer records
+                n = int(info_b.n)
+                state = per_file(info_a, groups[0])
+                state.update(per_file(info_b, groups[1]))
+                done = dict((k, (state[k][1] or fills[k][1]) and state[k][0] == n) for k in present)
+                stop = False
+                if done[0]:
+                    stop = True
+                elif any(done[k] for k in present if k != 0) and state[0][0] > n:
+                    # R1's next record was read (and counted into TOTAL_BASES) before another reader ran dry (:416-429)
+                    extra_bases = int(info_a.next_len1)
+                    stop = True
+                if not stop:
+                    for k in present:
+                        if n == 0 and not fills[k][1] and not state[k][1] and state[k][0] == 0:
+                            inputs[k].grow(cur)
+                        inputs[k].carry(cur, state[k][2], fills[k][0], fills[k][1], state[k][1] or (k != 0 and done[k]))
+                if n:
+                    limit = UNLIMITED
+                    if opt.qc_only:
+                        eng.run(0, 0)
+                        flags = eng.fetch_results(0)[:n]["flag"]
+                        hit = np.flatnonzero((flags == capi.GOOD) & (total + 1 + np.arange(n) >= opt.qc_sample))
+                        if len(hit):
+                            n = int(hit[0]) + 1
+                            stop = True
+                        limit = n
+                    eng.run(0, limit)
+                    n_qc = n if opt.qc_sample <= 0 else max(0, min(n, opt.qc_sample - 1 - total))
+                    if n_qc > 0:
+                        eng.qc_stat(0, capi.QC_R1_POST, 0, 0, n_qc, 1)
+                        if paired:
+                            eng.qc_stat(0, capi.QC_R2_POST, 1, 0, n_qc, 1)
+                    eng.sync(0)
+                    if not opt.qc_only:
+                        write_streams(0, groups[0], eng.format(0, n, bool(opt.store_overlap)))
+                        write_streams(1, groups[1], eng.format_plain(1, 0, n, bool(opt.store_overlap)))
+                    total += n
+                if stop:
+                    break
+                cur = 1 - cur
+        finally:
+            for k in present:
+                inputs[k].close()
+            for b in hold.values():
+                b.free()
+        return extra_bases
 
     # ---- pass 2 with host-side framing / formatting (general: barcodes, index files, overlap store, bubbles) ------
     def _run_host(self, eng, opt, outs, paired, files):

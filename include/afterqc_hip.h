@@ -286,6 +286,10 @@ int aqc_frame(aqc_ctx* ctx, int slot, const aqc_text_chunk* chunk, aqc_frame_inf
  * mismatches were all corrected (getOverlap, preprocesser.py:78-84,614-616).
  * bytes_out[file * 3 + stream], stream 0 good / 1 bad / 2 overlap.  Index files are not handled here (host side). */
 int aqc_format(aqc_ctx* ctx, int slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]);
+/* index files (-7 / -5, preprocesser.py:222-232): the n records framed into `slot` are written WHOLE, routed and (when
+ * bad) renamed by the verdicts of the read records of `verdict_slot` (same chunk, same n); the overlap stream takes
+ * the whole record wherever the reads' overlap record is written (preprocesser.py:616). */
+int aqc_format_plain(aqc_ctx* ctx, int slot, int verdict_slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]);
 /* copy one formatted stream (file 0/1, stream 0 good / 1 bad / 2 overlap) to host memory and wait for it */
 int aqc_fetch_text(aqc_ctx* ctx, int slot, int file, int stream, uint8_t* dst, uint64_t cap);
 /* page-locked host memory for text chunks and fetched streams (hipHostMalloc): full-rate DMA */

@@ -399,6 +399,29 @@ def _oracle_format(self, slot, n, store_overlap=False):
     return [len(o) for o in out]
 
 
+def _oracle_format_plain(self, slot, verdict_slot, n, store_overlap=False):
+    """writeReads for the index files (preprocesser.py:222-232,616): whole records, bad ones renamed, overlap copies"""
+    res = self.results[verdict_slot]
+    paired = self.slots[verdict_slot].seq2 is not None
+    out = [bytearray() for _ in range(6)]
+    for k, (buf, records) in enumerate(self._text[slot]):
+        for r in range(n):
+            rec = [buf[o:o + l] for (o, l) in records[r]]
+            rr = res[r]
+            flag = int(rr["flag"])
+            ov, dist = int(rr["overlap_len"]), int(rr["distance"])
+            if store_overlap and paired and flag == capi.GOOD and ov > 30:
+                corrected = sum(1 for e in range(int(rr["n_edits"])) if int(rr["edits"][e]["kind"]) in (capi.EDIT_FIX_R1, capi.EDIT_FIX_R2))
+                if dist == 0 or dist == corrected:
+                    out[3 * k + 2] += b"\n".join(rec) + b"\n"
+            stream = 0 if flag == capi.GOOD else 1
+            if stream:
+                rec[0] = b"@" + FLAG_NAMES_B[flag] + rec[0][1:]
+            out[3 * k + stream] += b"\n".join(rec) + b"\n"
+    self._fmt[slot] = [bytes(o) for o in out]
+    return [len(o) for o in out]
+
+
 def _oracle_fetch_text(self, slot, file, stream, dst, cap):
     data = self._fmt[slot][3 * file + stream]
     if len(data) > cap:
@@ -429,4 +452,5 @@ def final_read(seq, qual, r, which):
 OracleEngine.host_buffer = lambda self, nbytes: _HostBuffer(nbytes)
 OracleEngine.frame = _oracle_frame
 OracleEngine.format = _oracle_format
+OracleEngine.format_plain = _oracle_format_plain
 OracleEngine.fetch_text = _oracle_fetch_text
