@@ -834,23 +834,36 @@ __device__ __forceinline__ void qc_accumulate_read(const ReadDesc& cur, uint32_t
         const int tl = len - 3 - base0;                 // cycle len-3 relative to this pass (uniform)
         if (tl >= 0 && tl < 4 * WAVE)
             d_tail = ((unsigned int)__builtin_amdgcn_readlane((int)dpk, tl >> 2) >> (3 * (tl & 3))) & 7u;
+        // the lane's four cycles at once: accumulator row per base (A T C G = 0..3, anything else 4), quality - 33 per
+        // byte, the clamped discontinuity windows patched into the packed fields; then per cycle only two field
+        // extractions, one multiply-add for the address and the atomics remain
         const uint32_t codes = (ws >> 1) & 0x03030303u;
         const uint32_t bad = __builtin_amdgcn_perm(0u, CODE_TO_BASE, codes) ^ ws;       // 0 where the byte is A/C/G/T
+        const uint32_t nz = nonzero_bytes(bad);                                         // 0x80 per foreign byte
+        const uint32_t foreign = nz | (nz - (nz >> 7));                                 // 0xff per foreign byte
+        // code (A0 C1 T2 G3) -> row (A0 T1 C2 G3); foreign -> 4
+        const uint32_t rows4 = (__builtin_amdgcn_perm(0u, 0x03010200u, codes) & ~foreign) | (0x04040404u & foreign);
+        const uint32_t qn4 = wq - 0x21212121u;                                          // (qualities are >= '!' in FASTQ)
+        const int nin = min(max(len - x, 0), 4);                                        // cycles of this lane inside the read
+        if (base0 == 0 && lane == 0) dpk = (dpk & ~0x3fu) | d_head | (d_head << 3);     // cycles 0, 1: window [0, 5)
+        {
+            const int over = min(max(x + 3 - (len - 3), 0), 4);                         // cycles beyond len-3: window [len-5, len)
+            const unsigned int m = over ? (0xfffu << (3 * (4 - over))) & 0xfffu : 0u;
+            dpk = (dpk & ~m) | ((d_tail * 0x249u) & m);
+        }
+        const unsigned int col0 = (unsigned int)lane + (unsigned int)(base0 >> 2);
+        // G / C among the lane's cycles inside the read (C = code 1, G = code 3: low code bit), not foreign
+        const uint32_t gcm = codes & 0x01010101u & ~foreign & (nin >= 4 ? 0x01010101u : ((1u << (8 * nin)) - 1u));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int i = x + j;
-            const bool in = i < len;
-            const unsigned int code = (codes >> (8 * j)) & 3u;
-            const bool acgt = ((bad >> (8 * j)) & 0xffu) == 0u;
-            if (in) {
-                const unsigned int row = acgt ? (0x3120u >> (4 * code)) & 0xfu : 4u;     // rows A T C G, other
-                const unsigned int qn = ((wq >> (8 * j)) & 0xffu) - 33u;
-                atomicAdd(&accs[row * cols + j * cq + (i >> 2)], (1u << 20) + qn);
+            if (j < nin) {
+                const unsigned int row = (rows4 >> (8 * j)) & 0xffu;
+                atomicAdd(&accs[row * (unsigned int)cols + (unsigned int)(j * cq) + col0], (1u << 20) + ((qn4 >> (8 * j)) & 0xffu));
                 // discontinuity over the 5-wide window clamped to the read (qualitycontrol.py:97-109)
-                const unsigned int d = i < 2 ? d_head : (i > len - 3 ? d_tail : (dpk >> (3 * j)) & 7u);
-                if (d) atomicAdd(&accs[5 * cols + j * cq + (i >> 2)], d);
+                const unsigned int d = (dpk >> (3 * j)) & 7u;
+                if (d) atomicAdd(&accs[5u * (unsigned int)cols + (unsigned int)(j * cq) + col0], d);
             }
-            gc += __popcll(__ballot(in && acgt && (code & 1u)));                         // C = 1, G = 3
+            gc += __popcll(__ballot((gcm >> (8 * j)) & 1u));
         }
     }
     if (lane == 0) {
