@@ -97,7 +97,7 @@ def assert_same(g, o):
 
 
 @pytest.mark.parametrize("case", ["default", "trim", "nocorr", "mask", "nocorr_mask", "nooverlap", "strict", "ragged",
-                                  "short", "lowercase", "l250", "l100", "index2", "l400", "l700_ragged"])
+                                  "short", "lowercase", "l250", "l100", "index2", "l400", "l700_ragged", "l1000_max"])
 def test_pairs_vs_oracle(gpu_engine, case):
     kw = dict(n=6000, L=150, seed=4242, dirty=True)
     cfgkw = {}
@@ -130,6 +130,9 @@ def test_pairs_vs_oracle(gpu_engine, case):
     elif case == "l400":
         # beyond the lane-per-read kernel's 256 bases: general kernel, multi-pass QC / k-mer kernels (unfused)
         kw.update(L=400, n=1200)
+    elif case == "l1000_max":
+        # AQC_MAX_READ_LEN: the longest read the ABI takes
+        kw.update(L=1000, n=300)
     elif case == "l700_ragged":
         kw.update(L=700, n=600, ragged=True)
         cfgkw = dict(seq_len_req=20, trim_front=2, trim_tail=1, trim_front2=3, trim_tail2=2)
