@@ -227,3 +227,23 @@ def test_errors_are_loud(gpu_engine):
     bad.qc_kmer = 12
     with pytest.raises(capi.AqcError):
         gpu_engine.set_config(bad)
+
+
+def test_empty_inputs(gpu_engine):
+    """zero records through every entry point of the path: nothing is counted, nothing is written, nothing fails"""
+    cfg = default_cfg(True)
+    gpu_engine.set_config(cfg)
+    gpu_engine.reset_stats()
+    empty = np.zeros((0, 150), dtype=np.uint8)
+    lens = np.zeros(0, dtype=np.uint32)
+    b = capi.Batch.from_matrices(empty, empty, lens, empty, empty, lens)
+    gpu_engine.upload(0, b)
+    gpu_engine.run(0)
+    assert len(gpu_engine.fetch_results(0)) == 0
+    assert not gpu_engine.counters().any()
+    text = np.zeros(64, dtype=np.uint8)
+    info = gpu_engine.frame(0, text, 0, True, text, 0, True)
+    assert int(info.n) == 0 and int(info.avail1) == 0 and not info.eof1
+    gpu_engine.run(0)
+    assert gpu_engine.format(0, 0, True) == [0] * 6
+    assert not gpu_engine.counters().any()
