@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "aqc_kernels.hpp"
@@ -544,7 +545,7 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
         if (s->deferred.reserve(sizeof(uint32_t) * (s->n + 1)) || s->n_deferred.reserve(sizeof(unsigned int)))
             return fail(AQC_ERR_HIP, "hipMalloc failed");
         if (s->max_len <= 160) {
-            if (cfg.paired) launch_fast<10, true, 4>(c, s, cfg, st, accum_limit);
+            if (cfg.paired) launch_fast<10, true, 16>(c, s, cfg, st, accum_limit);
             else launch_fast<10, false, 4>(c, s, cfg, st, accum_limit);
         } else {
             if (cfg.paired) launch_fast<16, true, 4>(c, s, cfg, st, accum_limit);
@@ -988,6 +989,36 @@ int aqc_get_counters(aqc_ctx* c, int64_t* out) {
         for (int k = 0; k < 10; k++) tot += pr[k];
         static const char* nm[10] = {"phase1", "normalise", "bubble+len+polyX", "lowq+N", "scan", "verify", "post+walk", "results+counters", "deferred", "-"};
         for (int k = 0; k < 9; k++) fprintf(stderr, "PROF %-18s %6.2f %%\n", nm[k], tot ? 100.0 * pr[k] / tot : 0.0);
+        // load balance of the last fast-kernel launch of slot 0: spread of the waves' end stamps
+        {
+            Slot& s0 = c->slots[0];
+            if (s0.has_canonical && s0.n > (1u << 16) && s0.deferred.p) {
+                const size_t nw = 4096;
+                std::vector<uint32_t> st(2 * nw);
+                (void)hipMemcpy(st.data(), (uint32_t*)s0.deferred.p + (s0.n - 2 * nw), sizeof(uint32_t) * 2 * nw, hipMemcpyDeviceToHost);
+                // (s_memtime runs on the shader clock and is not synchronised across XCDs: only lifetimes are meaningful)
+                std::vector<uint32_t> life;
+                double sum_life = 0;
+                for (size_t w = 0; w < nw; ++w) { const uint32_t d = st[2 * w + 1] - st[2 * w]; life.push_back(d); sum_life += d; }
+                {
+                    // by XCD (workgroups are dealt round-robin to the 8 XCDs) and by position in the grid
+                    double xs[8] = {0}, qs[4] = {0};
+                    for (size_t w = 0; w < nw; ++w) {
+                        const size_t gw = nw - 1 - w;          // stamps are stored from the tail backwards
+                        xs[(gw / 4) % 8] += life[w];
+                        qs[gw * 4 / nw] += life[w];
+                    }
+                    fprintf(stderr, "WAVES mean lifetime by XCD:");
+                    for (int x = 0; x < 8; ++x) fprintf(stderr, " %.0f", xs[x] / (nw / 8));
+                    fprintf(stderr, "  by grid quarter:");
+                    for (int q = 0; q < 4; ++q) fprintf(stderr, " %.0f", qs[q] / (nw / 4));
+                    fprintf(stderr, "\n");
+                }
+                std::sort(life.begin(), life.end());
+                fprintf(stderr, "WAVES lifetime in shader clocks: min %u p10 %u median %u p90 %u max %u mean %.0f\n", life.front(), life[nw / 10],
+                        life[nw / 2], life[nw * 9 / 10], life.back(), sum_life / nw);
+            }
+        }
         unsigned long long kp[16];
         (void)hipMemcpyFromSymbol(kp, HIP_SYMBOL(g_kprof), sizeof(kp));
         tot = 0;

@@ -131,7 +131,7 @@ __device__ __forceinline__ uint32_t mm_word(uint32_t mlo0, uint32_t mlo1, uint32
 }
 
 #ifdef AQC_PROFILE
-#define PROF_DECL unsigned long long prof_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_amdgcn_s_memtime();
+#define PROF_DECL unsigned long long prof_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_amdgcn_s_memtime(); const unsigned long long prof_t0 = prof_last;
 #define PROF(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof_t[k] += now_ - prof_last; prof_last = now_; } while (0)
 #define PROF_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 10; ++k_) atomicAdd(&st.counters[AQC_N_COUNTERS + k_], prof_t[k_]); } while (0)
 #else
@@ -154,9 +154,11 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     static_assert(PPW * NW % WAVE == 0, "chunk tasks must tile the wave");
     __shared__ WL wls[WPBT];
     __shared__ BlockAcc acc;
+    __shared__ unsigned int batch_ticket;
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
     for (int i = threadIdx.x; i < (int)(sizeof(BlockAcc) / 4); i += WPBT * WAVE) ((unsigned int*)&acc)[i] = 0;
+    if (threadIdx.x == 0) batch_ticket = WPBT;      // tickets 0 .. WPBT-1 are the waves' first batches
     __syncthreads();
     WL& L = wls[wave];
     const int p = PAIRED ? lane >> 1 : lane;      // record of this lane within the batch
@@ -175,15 +177,31 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     uint32_t r_n = 0, r_good = 0, r_tb = 0, r_gb = 0, r_ab = 0, r_ar = 0, r_ov = 0, r_ol = 0, r_od = 0, r_rc = 0, r_bc = 0, r_mk = 0, r_sk = 0;
 
     PROF_DECL
-    const uint64_t stride = (uint64_t)gridDim.x * WPBT * PPW;
-    const uint64_t base0 = ((uint64_t)blockIdx.x * WPBT + wave) * PPW;
+    // Wave batches (PPW consecutive records) are NOT dealt statically: a saturated SIMD serves its resident waves by age,
+    // the oldest wave of four runs ~35 % faster than the youngest, and with equal shares the SIMD idles while the
+    // stragglers finish alone (measured: mean wave lifetime 79 % of the kernel).  The workgroup owns one batch of every
+    // group of gridDim.x batches (batch_of(t)) and its waves draw the tickets t from an LDS counter — one LDS atomic per batch, drawn a
+    // batch ahead so that neither it nor the descriptor prefetch is ever waited for.
+    const uint32_t n_batches = (uint32_t)((fb.n + PPW - 1) / PPW);
+    auto draw = [&]() -> uint32_t {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&batch_ticket, 1u);
+        return t;                                      // (lane 0 holds it; broadcast when consumed)
+    };
+    // (the workgroup's column rotates with t, so that its batches are spread over all memory channels)
+    auto batch_of = [&](uint32_t t) -> uint64_t { return (uint64_t)gridDim.x * t + (blockIdx.x + 61u * t) % gridDim.x; };
+    uint64_t cur = batch_of((uint32_t)wave);
+    uint64_t nxt = batch_of((uint32_t)__builtin_amdgcn_readfirstlane((int)draw()));
     // the descriptor of this lane's read in the NEXT batch is fetched one iteration ahead
     uint32_t m_o = 0, m_l = 0;
-    if (base0 + p < fb.n) {
-        m_o = role ? fb.o2[base0 + p] : fb.o1[base0 + p];
-        m_l = role ? fb.len2[base0 + p] : fb.len1[base0 + p];
+    if (cur < n_batches && cur * PPW + p < fb.n) {
+        const uint64_t r0 = cur * PPW + p;
+        m_o = role ? fb.o2[r0] : fb.o1[r0];
+        m_l = role ? fb.len2[r0] : fb.len1[r0];
     }
-    for (uint64_t base = base0; base < fb.n; base += stride) {
+    while (cur < n_batches) {
+        const uint64_t base = cur * PPW;
+        const uint32_t nxt2_l0 = draw();
         const uint64_t rec = base + p;
         const bool valid = rec < fb.n;
         // ------------------------------------------------------------------ phase 1: load + pack
@@ -192,9 +210,9 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         else { L.o2[p] = m_o & ~EXOTIC_BIT; L.l2[p] = m_l; }
         if (role && (m_o >> 31)) L.exo[p] = 1;
         {
-            const uint64_t nrec = rec + stride;
+            const uint64_t nrec = nxt * PPW + p;
             m_o = m_l = 0;
-            if (nrec < fb.n) {
+            if (nxt < n_batches && nrec < fb.n) {
                 m_o = role ? fb.o2[nrec] : fb.o1[nrec];
                 m_l = role ? fb.len2[nrec] : fb.len1[nrec];
             }
@@ -647,6 +665,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         }
         __builtin_amdgcn_wave_barrier();
         PROF(8);
+        cur = nxt;
+        nxt = batch_of((uint32_t)__builtin_amdgcn_readfirstlane((int)nxt2_l0));
     }
     // ---- reduce the per-lane running totals once
     {
@@ -676,6 +696,14 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         }
     }
     PROF_FLUSH;
+#ifdef AQC_PROFILE
+    // per-wave start / end stamps (100 MHz reference clock) at the tail of the deferral queue buffer: load balance
+    if (lane == 0) {
+        const uint64_t gw = (uint64_t)blockIdx.x * WPBT + wave;
+        deferred[fb.n - 2 * (gw + 1)] = (uint32_t)prof_t0;
+        deferred[fb.n - 2 * (gw + 1) + 1] = (uint32_t)__builtin_amdgcn_s_memtime();
+    }
+#endif
     __syncthreads();
     flush_block_acc(acc, st);
 }
