@@ -546,10 +546,10 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
             return fail(AQC_ERR_HIP, "hipMalloc failed");
         if (s->max_len <= 160) {
             if (cfg.paired) launch_fast<10, true, 16>(c, s, cfg, st, accum_limit);
-            else launch_fast<10, false, 4>(c, s, cfg, st, accum_limit);
+            else launch_fast<10, false, 12>(c, s, cfg, st, accum_limit);
         } else {
-            if (cfg.paired) launch_fast<16, true, 4>(c, s, cfg, st, accum_limit);
-            else launch_fast<16, false, 4>(c, s, cfg, st, accum_limit);
+            if (cfg.paired) launch_fast<16, true, 12>(c, s, cfg, st, accum_limit);
+            else launch_fast<16, false, 12>(c, s, cfg, st, accum_limit);
         }
         hipLaunchKernelGGL(filter_overlap_list_kernel, dim3((unsigned)c->n_cu), dim3(BLOCK), 0, s->stream, s->view, cfg, c->circles,
                            (aqc_result*)s->results.p, st, accum_limit, (const uint32_t*)s->deferred.p,
