@@ -180,8 +180,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     // Wave batches (PPW consecutive records) are NOT dealt statically: a saturated SIMD serves its resident waves by age,
     // the oldest wave of four runs ~35 % faster than the youngest, and with equal shares the SIMD idles while the
     // stragglers finish alone (measured: mean wave lifetime 79 % of the kernel).  The workgroup owns one batch of every
-    // group of gridDim.x batches (batch_of(t)) and its waves draw the tickets t from an LDS counter — one LDS atomic per batch, drawn a
-    // batch ahead so that neither it nor the descriptor prefetch is ever waited for.
+    // group of gridDim.x batches (batch_of(t)) and its waves draw the tickets t from an LDS counter — one LDS atomic per batch.
     const uint32_t n_batches = (uint32_t)((fb.n + PPW - 1) / PPW);
     auto draw = [&]() -> uint32_t {
         uint32_t t = 0;
@@ -191,7 +190,6 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     // (the workgroup's column rotates with t, so that its batches are spread over all memory channels)
     auto batch_of = [&](uint32_t t) -> uint64_t { return (uint64_t)gridDim.x * t + (blockIdx.x + 61u * t) % gridDim.x; };
     uint64_t cur = batch_of((uint32_t)wave);
-    uint64_t nxt = batch_of((uint32_t)__builtin_amdgcn_readfirstlane((int)draw()));
     // the descriptor of this lane's read in the NEXT batch is fetched one iteration ahead
     uint32_t m_o = 0, m_l = 0;
     if (cur < n_batches && cur * PPW + p < fb.n) {
@@ -201,7 +199,9 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     }
     while (cur < n_batches) {
         const uint64_t base = cur * PPW;
-        const uint32_t nxt2_l0 = draw();
+        // exactly ONE batch of lookahead (its descriptors travel while this batch is processed): a slow wave never sits
+        // on more than one batch the faster waves could have taken
+        const uint64_t nxt = batch_of((uint32_t)__builtin_amdgcn_readfirstlane((int)draw()));
         const uint64_t rec = base + p;
         const bool valid = rec < fb.n;
         // ------------------------------------------------------------------ phase 1: load + pack
@@ -666,7 +666,6 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         __builtin_amdgcn_wave_barrier();
         PROF(8);
         cur = nxt;
-        nxt = batch_of((uint32_t)__builtin_amdgcn_readfirstlane((int)nxt2_l0));
     }
     // ---- reduce the per-lane running totals once
     {
