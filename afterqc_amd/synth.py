@@ -194,9 +194,12 @@ def make_pairs(n, L=150, seed=1003, ragged=False, chunk=250_000, lowercase=0.0, 
     return res
 
 
-def add_barcodes(d, seed, barcode_len=12, verify=b"CAGTA"):
+def add_barcodes(d, seed, barcode_len=12, verify=b"CAGTA", tail_frac=0.0):
     """Config 5 flavour: prepend <barcode><verify> to both mates; 10 % of R1 verify sequences get
-    one mismatch, 3 % are destroyed (-> BADBCD1); a few R2 are destroyed too (-> BADBCD2)."""
+    one mismatch, 3 % are destroyed (-> BADBCD1); a few R2 are destroyed too (-> BADBCD2).
+    tail_frac > 0: that fraction of the pairs reads through into the mate's barcode (the last k bases of each mate are
+    the reverse complement of the other mate's first k bases, k = 1 .. barcode + verify + 2, with an occasional
+    substitution / deletion), which is what cleanBarcodeTail (barcodeprocesser.py:47-75) exists to cut."""
     rng = np.random.Generator(np.random.PCG64(seed))
     n, L = d["seq1"].shape
     ver = np.frombuffer(verify, dtype=np.uint8)
@@ -222,6 +225,29 @@ def add_barcodes(d, seed, barcode_len=12, verify=b"CAGTA"):
         d["seq" + k] = seq
         d["qual" + k] = qual
         d["len" + k] = (d["len" + k] + P).astype(np.uint32)
+    if tail_frac > 0:
+        # (drawn after everything else so that tail_frac = 0 reproduces the older fixtures bit for bit)
+        comp = np.zeros(256, dtype=np.uint8)
+        comp[:] = ord("N")
+        for a, b in zip(b"ACGTacgt", b"TGCAtgca"):
+            comp[a] = b
+        s1, s2 = d["seq1"], d["seq2"]
+        for r in np.nonzero(rng.random(n) < tail_frac)[0]:
+            k = int(rng.integers(1, P + 3))
+            l1, l2 = int(d["len1"][r]), int(d["len2"][r])
+            if k + 2 >= min(l1, l2):
+                continue
+            t1 = comp[s2[r, :k]][::-1].copy()
+            t2 = comp[s1[r, :k]][::-1].copy()
+            for t in (t1, t2):
+                u = rng.random()
+                if u < 0.25:
+                    t[int(rng.integers(0, k))] = BASES[int(rng.integers(0, 4))]
+                elif u < 0.35 and k > 3:
+                    j = int(rng.integers(0, k - 1))
+                    t[j:-1] = t[j + 1:].copy()
+            s1[r, l1 - k:l1] = t1
+            s2[r, l2 - k:l2] = t2
     return d
 
 

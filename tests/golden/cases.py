@@ -18,9 +18,9 @@ CIRCLES = [(5000.0, 6000.0, 1500.0, 1, 101), (12000.5, 9000.25, 2500.75, 2, 405)
 
 
 def pe(seed, n=2000, L=150, ragged=False, r1="R1.fq", r2="R2.fq", lowercase=0.0, barcode=False, index=False,
-       circles=False, dirty=True, short_frac=0.03):
+       circles=False, dirty=True, short_frac=0.03, tail_frac=0.0):
     return dict(kind="pe", seed=seed, n=n, L=L, ragged=ragged, r1=r1, r2=r2, lowercase=lowercase, barcode=barcode,
-                index=index, circles=circles, dirty=dirty, short_frac=short_frac)
+                index=index, circles=circles, dirty=dirty, short_frac=short_frac, tail_frac=tail_frac)
 
 
 def se(seed, n=3000, L=150):
@@ -75,6 +75,12 @@ CASES = [
     ("pe_l250", PE + F0, pe(1213, n=800, L=250), False),
     ("pe_outdirs", PE + F0 + ["-g", "gout", "-b", "bout", "-r", "rout"], pe(1223, n=300), False),
     ("pe_qc_kmer5", PE + F0 + ["--qc_kmer", "5"], pe(1233, n=600), False),
+    # BASELINE.json config 5 in one piece: 2x250 + 17-base barcode/verify prefix on both mates, "barcode" in the file
+    # names (after.py:215-221), gzip in, -z out, --debubble with a circles.csv, default (auto) tail trim
+    ("pe_cfg5", ["-1", "barcode_R1.fq.gz", "-2", "barcode_R2.fq.gz", "--debubble", "--debubble_dir", "D", "-z"],
+     pe(1305, n=1200, L=250, r1="barcode_R1.fq.gz", r2="barcode_R2.fq.gz", barcode=True, circles=True, tail_frac=0.12), False),
+    ("pe_barcode_tails", ["-1", "barcode_R1.fq", "-2", "barcode_R2.fq", "-t", "0"],
+     pe(1306, n=1500, L=100, r1="barcode_R1.fq", r2="barcode_R2.fq", barcode=True, tail_frac=0.3), False),
 ]
 
 
@@ -97,7 +103,7 @@ def materialize(spec, work):
     d = synth.make_pairs(n, spec["L"], seed, ragged=spec["ragged"], lowercase=spec["lowercase"],
                          dirty=spec["dirty"], short_frac=spec["short_frac"])
     if spec["barcode"]:
-        d = synth.add_barcodes(d, seed + 7)
+        d = synth.add_barcodes(d, seed + 7, tail_frac=spec.get("tail_frac", 0.0))
     lane, tile, x, y = d["meta"]
     if spec["circles"]:
         # put the clusters on the circles' lanes/tiles so that BADBBL actually fires
