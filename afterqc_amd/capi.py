@@ -293,6 +293,8 @@ def load_library():
     lib.aqc_qc_stat.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int]
     lib.aqc_fetch_results.argtypes = [P, C.c_int, P, C.c_uint64]
     lib.aqc_sync.argtypes = [P, C.c_int]
+    lib.aqc_last_deferred.argtypes = [P, C.c_int, P, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.aqc_last_deferred.restype = C.c_int
     lib.aqc_kernel_ms.argtypes = [P, C.c_int, P]
     lib.aqc_timing_reset.argtypes = [P, C.c_int]
     lib.aqc_timing_mean.argtypes = [P, C.c_int, P, P]
@@ -325,11 +327,13 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_last_error", "aqc_create", "aqc_destroy",
                     "aqc_device_name", "aqc_set_config", "aqc_set_circles", "aqc_reset_stats", "aqc_upload", "aqc_run",
-                    "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_timing_reset",
+                    "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_last_deferred", "aqc_kernel_ms", "aqc_timing_reset",
                     "aqc_timing_mean", "aqc_get_counters",
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
                     "aqc_edit_distance", "aqc_frame", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_host_alloc",
-                    "aqc_host_free"]
+                    "aqc_host_free",
+                    # the reference's own native seam (editdistance/_editdistance.h:16,23), same names and signatures
+                    "edit_distance", "seek_overlap"]
 
 
 class Engine:
@@ -400,6 +404,14 @@ class Engine:
 
     def sync(self, slot):
         self._check(self.lib.aqc_sync(self.h, slot))
+
+    def last_deferred(self, slot, want_indices=False):
+        """records of the slot's last run() that the lane-per-read kernel handed to the general kernel"""
+        n = C.c_uint64(0)
+        cap = self.slot_n[slot] if want_indices else 0
+        idx = np.zeros(max(cap, 1), dtype=np.uint32)
+        self._check(self.lib.aqc_last_deferred(self.h, slot, _ptr(idx), cap, C.byref(n)))
+        return (int(n.value), idx[:min(int(n.value), cap)]) if want_indices else int(n.value)
 
     def kernel_ms(self, slot):
         ms = np.zeros(N_KERNELS, dtype=np.float32)

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "aqc_kernels.hpp"
@@ -61,25 +62,19 @@ struct DevBuf {
 struct Slot {
     hipStream_t stream = nullptr;
     DevBuf seq1, qual1, off1, qoff1, len1, seq2, qual2, off2, qoff2, len2, aux[5], results;
-    // canonical layout for the lane-per-pair kernel: 16-byte aligned records, offsets in 16-byte units
-    DevBuf cseq1, cqual1, cseq2, cqual2, co1, co2, deferred, n_deferred, walk_q, n_walk;
-    unsigned int walk_segs = 0;
-    uint64_t walk_seg_cap = 0;
-    uint32_t* h_o16[2] = {nullptr, nullptr};   // pinned staging for the canonical offsets
-    size_t h_o16_cap[2] = {0, 0};
+    DevBuf deferred, n_deferred;     // records the lane-per-read kernel hands to the general kernel
+    DevBuf off_stage;                // the caller's 64-bit offsets on their way to the 32-bit device form
     // text in / text out (aqc_frame, aqc_format): per file the line table and the name / strand-line descriptors
     DevBuf t_line_end[2], t_tile[2], t_name_off[2], t_name_len[2], t_plus_off[2], t_plus_len[2], t_qual_len[2];
     DevBuf t_scratch;              // FrameMeta[2] + scan totals
     DevBuf f_pos, f_tile, f_out[6];
     uint64_t f_bytes[6] = {0, 0, 0, 0, 0, 0};
     bool framed = false, formatted = false;
-    FastBatch fview{};
-    bool has_canonical = false;
     uint32_t max_len = 0;
     uint32_t raw_max_len = 0;      // longest read of the slot (both mates), 0 = unknown
     DevBatch view{};
     uint64_t n = 0;
-    bool paired = false, ran = false, same_arena1 = false, same_arena2 = false;
+    bool paired = false, ran = false, used_fast = false, same_arena1 = false, same_arena2 = false;
     hipEvent_t ev[AQC_N_KERNELS][2] = {};
     bool timed[AQC_N_KERNELS] = {};
     // timing region (aqc_timing_reset / aqc_timing_mean): one event pair per launch
@@ -152,12 +147,12 @@ static int check_status(aqc_ctx* c) {
     return 0;
 }
 
-template <int NW, bool PAIRED, int WPBT>
+template <int NW, bool PAIRED, int WPBT, bool BARCODE>
 static void launch_fast(aqc_ctx* c, Slot* s, const aqc_config& cfg, const DevStats& st, uint64_t accum_limit) {
     constexpr uint64_t per_block = (uint64_t)WPBT * FastWaveLds<NW, PAIRED>::PPW;
     uint64_t blocks = (s->n + per_block - 1) / per_block;
     // persistent grid: as many workgroups as the LDS footprint lets a CU hold; batches are grid-strided
-    const size_t lds = sizeof(FastWaveLds<NW, PAIRED>) * WPBT + sizeof(BlockAcc) + 64;
+    const size_t lds = sizeof(FastWaveLds<NW, PAIRED>) * WPBT + sizeof(BlockAcc) + 64 + 17 * 16;
     uint64_t per_cu = (160 * 1024) / lds;
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
@@ -166,8 +161,8 @@ static void launch_fast(aqc_ctx* c, Slot* s, const aqc_config& cfg, const DevSta
     // pairs the fast kernel cannot decide exactly (exotic bytes, very short reads, ...) are queued and
     // finished by the general wave-per-record pipeline right behind it on the same stream
     (void)hipMemsetAsync(s->n_deferred.p, 0, sizeof(unsigned int), s->stream);
-    hipLaunchKernelGGL((fast_filter_overlap_kernel<NW, PAIRED, WPBT>), dim3((unsigned)blocks), dim3(WPBT * WAVE), 0, s->stream,
-                       s->fview, cfg, c->circles, (aqc_result*)s->results.p, st, accum_limit, (uint32_t*)s->deferred.p,
+    hipLaunchKernelGGL((fast_filter_overlap_kernel<NW, PAIRED, WPBT, BARCODE>), dim3((unsigned)blocks), dim3(WPBT * WAVE), 0, s->stream,
+                       s->view, cfg, c->circles, (aqc_result*)s->results.p, st, accum_limit, (uint32_t*)s->deferred.p,
                        (unsigned int*)s->n_deferred.p);
 }
 
@@ -182,31 +177,6 @@ static int device_scan(Slot& s, F f, uint64_t n, DevBuf& tile, OutT* out, unsign
     hipLaunchKernelGGL(scan_tile_bases_kernel, dim3(1), dim3(TXT_BLOCK), 0, s.stream, t, tiles, d_total);
     if (n) hipLaunchKernelGGL((scan_apply_kernel<F, OutT>), dim3((unsigned)tiles), dim3(TXT_BLOCK), 0, s.stream, f, n, t, out, add);
     HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// device half of the canonical layout when the lengths only exist on the device (framed text)
-static int canonicalize_dev(aqc_ctx* c, Slot& s, uint64_t n, uint64_t text_bytes, const uint8_t* d_seq, const uint8_t* d_qual,
-                            const uint64_t* d_off, const uint64_t* d_qoff, const uint32_t* d_len, DevBuf& cseq, DevBuf& cqual,
-                            DevBuf& co, unsigned long long* d_total) {
-    const uint64_t max_chunks = 4 + text_bytes / 16 + n;              // upper bound of 4 + sum ceil(len / 16)
-    if (max_chunks >= (1ull << 32)) return fail(AQC_ERR_ARG, "chunk too large for 32-bit chunk offsets");
-    const size_t bytes = (size_t)max_chunks * 16 + 16 * 64 + 256;
-    if (cseq.reserve(bytes) || cqual.reserve(bytes) || co.reserve(sizeof(uint32_t) * (n ? n : 1)))
-        return fail(AQC_ERR_HIP, "hipMalloc failed");
-    // padding everywhere first ('A' / 0x7f): front pad, chunk tails and the slack behind the last record
-    HIP_TRY(hipMemsetAsync(cseq.p, 'A', bytes, s.stream));
-    HIP_TRY(hipMemsetAsync(cqual.p, 0x7f, bytes, s.stream));
-    int rc = device_scan(s, ChunksOf{d_len}, n, s.f_tile, (uint32_t*)co.p, 4ull, d_total);
-    if (rc) return rc;
-    if (n) {
-        const unsigned blocks = (unsigned)((n * 16 + 255) / 256);
-        hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_seq, d_off, d_len, (uint32_t*)co.p, n,
-                           (uint8_t*)cseq.p, (uint8_t)'A', 0);
-        hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_qual, d_qoff, d_len, (uint32_t*)co.p, n,
-                           (uint8_t*)cqual.p, (uint8_t)0x7f, 1);
-        HIP_TRY(hipGetLastError());
-    }
     return 0;
 }
 
@@ -261,14 +231,12 @@ void aqc_destroy(aqc_ctx* c) {
     for (auto& s : c->slots) {
         DevBuf* bufs[] = {&s.seq1, &s.qual1, &s.off1, &s.qoff1, &s.len1, &s.seq2, &s.qual2, &s.off2, &s.qoff2, &s.len2,
                           &s.aux[0], &s.aux[1], &s.aux[2], &s.aux[3], &s.aux[4], &s.results,
-                          &s.cseq1, &s.cqual1, &s.cseq2, &s.cqual2, &s.co1, &s.co2, &s.deferred, &s.n_deferred, &s.walk_q, &s.n_walk,
+                          &s.deferred, &s.n_deferred, &s.off_stage,
                           &s.t_line_end[0], &s.t_line_end[1], &s.t_tile[0], &s.t_tile[1], &s.t_name_off[0], &s.t_name_off[1],
                           &s.t_name_len[0], &s.t_name_len[1], &s.t_plus_off[0], &s.t_plus_off[1], &s.t_plus_len[0], &s.t_plus_len[1],
                           &s.t_qual_len[0], &s.t_qual_len[1], &s.t_scratch, &s.f_pos, &s.f_tile, &s.f_out[0], &s.f_out[1], &s.f_out[2],
                           &s.f_out[3], &s.f_out[4], &s.f_out[5]};
         for (DevBuf* b : bufs) b->release();
-        for (int k = 0; k < 2; k++)
-            if (s.h_o16[k]) (void)hipHostFree(s.h_o16[k]);
         for (int k = 0; k < AQC_N_KERNELS; k++)
             for (int j = 0; j < 2; j++) {
                 if (s.ev[k][j]) (void)hipEventDestroy(s.ev[k][j]);
@@ -357,10 +325,26 @@ int aqc_reset_stats(aqc_ctx* c) {
     return 0;
 }
 
+// (ARENA_SLACK readable bytes behind every arena: the lane-per-read kernel always loads whole 16-byte chunks, up to
+// 256 bytes from the start of a read whatever its length)
+constexpr size_t ARENA_SLACK = 1024;
+
 static int up(DevBuf& d, const void* src, size_t bytes, hipStream_t st) {
-    if (d.reserve(bytes)) return fail(AQC_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
+    if (d.reserve(bytes + ARENA_SLACK)) return fail(AQC_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
     if (bytes == 0) return 0;
     HIP_TRY(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+// 64-bit host offsets -> 32-bit device offsets (through the slot's staging buffer, in stream order)
+static int up_offsets(Slot& s, DevBuf& d, const uint64_t* src, uint64_t n) {
+    if (d.reserve(sizeof(uint32_t) * (n ? n : 1)) || s.off_stage.reserve(sizeof(uint64_t) * (n ? n : 1)))
+        return fail(AQC_ERR_HIP, "hipMalloc failed");
+    if (n == 0) return 0;
+    HIP_TRY(hipMemcpyAsync(s.off_stage.p, src, sizeof(uint64_t) * n, hipMemcpyHostToDevice, s.stream));
+    hipLaunchKernelGGL(narrow_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s.stream, (const uint64_t*)s.off_stage.p,
+                       (uint32_t*)d.p, n);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -370,6 +354,7 @@ static int fill_slot(aqc_ctx* c, Slot& s, const aqc_batch* b, bool need_qual, bo
     const bool paired = b->seq2 != nullptr;
     if (need_pair && !paired) return fail(AQC_ERR_ARG, "batch: this call needs seq2/off2/len2");
     if (paired && (!b->off2 || !b->len2)) return fail(AQC_ERR_ARG, "batch: off2/len2 missing");
+    if ((b->bytes1 | b->qbytes1 | b->bytes2 | b->qbytes2) >> 32) return fail(AQC_ERR_ARG, "batch: an arena must be smaller than 4 GiB (split the batch)");
     // make sure earlier work on this slot has drained before its buffers are overwritten / regrown
     HIP_TRY(hipStreamSynchronize(s.stream));
     int rc;
@@ -385,11 +370,11 @@ static int fill_slot(aqc_ctx* c, Slot& s, const aqc_batch* b, bool need_qual, bo
             v.qual1 = (const uint8_t*)s.qual1.p;
         }
     } else if (need_qual) return fail(AQC_ERR_ARG, "batch: qual1 is required");
-    if ((rc = up(s.off1, b->off1, sizeof(uint64_t) * n, s.stream))) return rc;
-    v.off1 = (const uint64_t*)s.off1.p;
+    if ((rc = up_offsets(s, s.off1, b->off1, n))) return rc;
+    v.off1 = (const uint32_t*)s.off1.p;
     if (b->qoff1) {
-        if ((rc = up(s.qoff1, b->qoff1, sizeof(uint64_t) * n, s.stream))) return rc;
-        v.qoff1 = (const uint64_t*)s.qoff1.p;
+        if ((rc = up_offsets(s, s.qoff1, b->qoff1, n))) return rc;
+        v.qoff1 = (const uint32_t*)s.qoff1.p;
     }
     if ((rc = up(s.len1, b->len1, sizeof(uint32_t) * n, s.stream))) return rc;
     v.len1 = (const uint32_t*)s.len1.p;
@@ -403,11 +388,11 @@ static int fill_slot(aqc_ctx* c, Slot& s, const aqc_batch* b, bool need_qual, bo
                 v.qual2 = (const uint8_t*)s.qual2.p;
             }
         } else if (need_qual) return fail(AQC_ERR_ARG, "batch: qual2 is required");
-        if ((rc = up(s.off2, b->off2, sizeof(uint64_t) * n, s.stream))) return rc;
-        v.off2 = (const uint64_t*)s.off2.p;
+        if ((rc = up_offsets(s, s.off2, b->off2, n))) return rc;
+        v.off2 = (const uint32_t*)s.off2.p;
         if (b->qoff2) {
-            if ((rc = up(s.qoff2, b->qoff2, sizeof(uint64_t) * n, s.stream))) return rc;
-            v.qoff2 = (const uint64_t*)s.qoff2.p;
+            if ((rc = up_offsets(s, s.qoff2, b->qoff2, n))) return rc;
+            v.qoff2 = (const uint32_t*)s.qoff2.p;
         }
         if ((rc = up(s.len2, b->len2, sizeof(uint32_t) * n, s.stream))) return rc;
         v.len2 = (const uint32_t*)s.len2.p;
@@ -444,48 +429,6 @@ static int get_slot(aqc_ctx* c, int slot, Slot** out) {
     return 0;
 }
 
-// Build the canonical device layout of one mate: offsets / 16 on the host (prefix sum of ceil(len/16)),
-// then a device-side copy of every record to its aligned slot ('A' / 0xff padding of the last chunk).
-static int canonicalize(aqc_ctx* c, Slot& s, int mate, const uint32_t* len, uint64_t n, const uint8_t* d_seq,
-                        const uint8_t* d_qual, const uint64_t* d_off, const uint64_t* d_qoff, const uint32_t* d_len,
-                        DevBuf& cseq, DevBuf& cqual, DevBuf& co, uint32_t* max_len) {
-    if (s.h_o16_cap[mate] < n + 1) {
-        if (s.h_o16[mate]) (void)hipHostFree(s.h_o16[mate]);
-        s.h_o16[mate] = nullptr;
-        s.h_o16_cap[mate] = 0;
-        size_t want = (size_t)(n + n / 8 + 64);
-        HIP_TRY(hipHostMalloc((void**)&s.h_o16[mate], want * sizeof(uint32_t), hipHostMallocDefault));
-        s.h_o16_cap[mate] = want;
-    }
-    uint32_t* o = s.h_o16[mate];
-    uint64_t acc = 4;     // 64 bytes of front padding: the correction walk reads up to 15 bytes before a read
-    uint32_t mx = 0;
-    for (uint64_t i = 0; i < n; i++) {
-        o[i] = (uint32_t)acc;
-        acc += (len[i] + 15u) >> 4;
-        if (len[i] > mx) mx = len[i];
-    }
-    if (acc >= (1ull << 32)) return fail(AQC_ERR_ARG, "batch too large for 32-bit chunk offsets (>64 GiB of bases)");
-    if (mx > *max_len) *max_len = mx;
-    const size_t bytes = (size_t)acc * 16 + 16 * 64 + 256;   // tail slack: the kernel always loads NW chunks per record
-    if (cseq.reserve(bytes) || cqual.reserve(bytes) || co.reserve(sizeof(uint32_t) * (n ? n : 1)))
-        return fail(AQC_ERR_HIP, "hipMalloc failed");
-    HIP_TRY(hipMemcpyAsync(co.p, o, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s.stream));
-    HIP_TRY(hipMemsetAsync((uint8_t*)cseq.p, 'A', 64, s.stream));
-    HIP_TRY(hipMemsetAsync((uint8_t*)cqual.p, 0x7f, 64, s.stream));
-    HIP_TRY(hipMemsetAsync((uint8_t*)cseq.p + (size_t)acc * 16, 'A', bytes - (size_t)acc * 16, s.stream));
-    HIP_TRY(hipMemsetAsync((uint8_t*)cqual.p + (size_t)acc * 16, 0x7f, bytes - (size_t)acc * 16, s.stream));
-    if (n) {
-        const unsigned blocks = (unsigned)((n * 16 + 255) / 256);
-        hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_seq, d_off, d_len,
-                           (uint32_t*)co.p, n, (uint8_t*)cseq.p, (uint8_t)'A', 0);
-        hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, s.stream, d_qual, d_qoff ? d_qoff : d_off, d_len,
-                           (uint32_t*)co.p, n, (uint8_t*)cqual.p, (uint8_t)0x7f, 1);
-        HIP_TRY(hipGetLastError());
-    }
-    return 0;
-}
-
 int aqc_upload(aqc_ctx* c, int slot, const aqc_batch* b) {
     Slot* s;
     int rc = get_slot(c, slot, &s);
@@ -493,24 +436,7 @@ int aqc_upload(aqc_ctx* c, int slot, const aqc_batch* b) {
     if (!b) return fail(AQC_ERR_ARG, "null batch");
     if ((rc = fill_slot(c, *s, b, true, false))) return rc;
     s->framed = s->formatted = false;
-    s->has_canonical = false;
-    s->max_len = 0;
-    if (c->force_generic) return 0;
-    FastBatch f{};
-    f.n = b->n;
-    if ((rc = canonicalize(c, *s, 0, b->len1, b->n, s->view.seq1, s->view.qual1, s->view.off1, s->view.qoff1, s->view.len1,
-                           s->cseq1, s->cqual1, s->co1, &s->max_len)))
-        return rc;
-    f.seq1 = (const uint8_t*)s->cseq1.p; f.qual1 = (const uint8_t*)s->cqual1.p; f.o1 = (const uint32_t*)s->co1.p; f.len1 = s->view.len1;
-    if (s->paired) {
-        if ((rc = canonicalize(c, *s, 1, b->len2, b->n, s->view.seq2, s->view.qual2, s->view.off2, s->view.qoff2, s->view.len2,
-                               s->cseq2, s->cqual2, s->co2, &s->max_len)))
-            return rc;
-        f.seq2 = (const uint8_t*)s->cseq2.p; f.qual2 = (const uint8_t*)s->cqual2.p; f.o2 = (const uint32_t*)s->co2.p; f.len2 = s->view.len2;
-    }
-    f.aux_lane = s->view.aux_lane; f.aux_tile = s->view.aux_tile; f.aux_x = s->view.aux_x; f.aux_y = s->view.aux_y; f.aux_ok = s->view.aux_ok;
-    s->fview = f;
-    s->has_canonical = true;
+    s->max_len = s->raw_max_len;
     return 0;
 }
 
@@ -537,7 +463,18 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_FILTER_OVERLAP, 0), s->stream));
     // lane-per-pair kernel whenever its preconditions hold; the general wave-per-record kernel otherwise
     const int thr = cfg.qualified_quality_phred + 33;
-    const bool fast_ok = s->has_canonical && !cfg.barcode && thr >= 0 && thr <= 127 && s->max_len <= 256;
+    // barcodes on that kernel: detectBarcode's three windows must lie in the first 32 bases and the verify sequence must
+    // be plain A/C/G/T (2-bit codes); anything else takes the general kernel
+    bool barcode_ok = true;
+    if (cfg.barcode) {
+        barcode_ok = cfg.barcode_verify_len >= 1 && cfg.barcode_length + 1 + cfg.barcode_verify_len <= 31;
+        for (int j = 0; j < cfg.barcode_verify_len && barcode_ok; ++j) {
+            const uint8_t ch = cfg.barcode_verify[j];
+            barcode_ok = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+        }
+    }
+    const bool fast_ok = !c->force_generic && barcode_ok && thr >= 0 && thr <= 127 && s->max_len <= 256 && s->max_len > 0;
+    s->used_fast = fast_ok;
     if (!fast_ok) {
         hipLaunchKernelGGL(filter_overlap_kernel, dim3(grid_for(c, s->n)), dim3(BLOCK), 0, s->stream, s->view, cfg, c->circles,
                            (aqc_result*)s->results.p, st, accum_limit);
@@ -545,11 +482,11 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
         if (s->deferred.reserve(sizeof(uint32_t) * (s->n + 1)) || s->n_deferred.reserve(sizeof(unsigned int)))
             return fail(AQC_ERR_HIP, "hipMalloc failed");
         if (s->max_len <= 160) {
-            if (cfg.paired) launch_fast<10, true, 16>(c, s, cfg, st, accum_limit);
-            else launch_fast<10, false, 12>(c, s, cfg, st, accum_limit);
+            if (cfg.paired) { if (cfg.barcode) launch_fast<10, true, 16, true>(c, s, cfg, st, accum_limit); else launch_fast<10, true, 16, false>(c, s, cfg, st, accum_limit); }
+            else { if (cfg.barcode) launch_fast<10, false, 12, true>(c, s, cfg, st, accum_limit); else launch_fast<10, false, 12, false>(c, s, cfg, st, accum_limit); }
         } else {
-            if (cfg.paired) launch_fast<16, true, 12>(c, s, cfg, st, accum_limit);
-            else launch_fast<16, false, 12>(c, s, cfg, st, accum_limit);
+            if (cfg.paired) { if (cfg.barcode) launch_fast<16, true, 12, true>(c, s, cfg, st, accum_limit); else launch_fast<16, true, 12, false>(c, s, cfg, st, accum_limit); }
+            else { if (cfg.barcode) launch_fast<16, false, 11, true>(c, s, cfg, st, accum_limit); else launch_fast<16, false, 11, false>(c, s, cfg, st, accum_limit); }
         }
         hipLaunchKernelGGL(filter_overlap_list_kernel, dim3((unsigned)c->n_cu), dim3(BLOCK), 0, s->stream, s->view, cfg, c->circles,
                            (aqc_result*)s->results.p, st, accum_limit, (const uint32_t*)s->deferred.p,
@@ -667,13 +604,12 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
         if (bytes[k] >= (1ull << 32) - TXT_TILE) return fail(AQC_ERR_ARG, "aqc_frame: chunks must be < 4 GiB");
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->framed = s->formatted = false;
-    s->has_canonical = false;
     s->ran = false;
     DevBuf* arena[2] = {&s->seq1, &s->seq2};
     DevBuf* seq_off[2] = {&s->off1, &s->off2};
     DevBuf* qual_off[2] = {&s->qoff1, &s->qoff2};
     DevBuf* seq_len[2] = {&s->len1, &s->len2};
-    // scratch: FrameMeta[2] | line totals[2] | canonical totals[2] | tail values[4]
+    // scratch: FrameMeta[2] | line totals[2] | tail values[4]
     if (s->t_scratch.reserve(256)) return fail(AQC_ERR_HIP, "hipMalloc failed");
     FrameMeta* d_meta = (FrameMeta*)s->t_scratch.p;
     unsigned long long* d_tot = (unsigned long long*)((uint8_t*)s->t_scratch.p + 64);
@@ -715,12 +651,12 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
         }
         nrec[k] = lines[k] / 4;
         const uint64_t m = nrec[k] ? nrec[k] : 1;
-        if (seq_off[k]->reserve(8 * m) || qual_off[k]->reserve(8 * m) || seq_len[k]->reserve(4 * m) || s->t_name_off[k].reserve(4 * m) ||
+        if (seq_off[k]->reserve(4 * m) || qual_off[k]->reserve(4 * m) || seq_len[k]->reserve(4 * m) || s->t_name_off[k].reserve(4 * m) ||
             s->t_name_len[k].reserve(4 * m) || s->t_plus_off[k].reserve(4 * m) || s->t_plus_len[k].reserve(4 * m) ||
             s->t_qual_len[k].reserve(4 * m))
             return fail(AQC_ERR_HIP, "hipMalloc failed");
         if (nrec[k]) {
-            FramedFile ff{(uint64_t*)seq_off[k]->p, (uint64_t*)qual_off[k]->p, (uint32_t*)seq_len[k]->p, (uint32_t*)s->t_name_off[k].p,
+            FramedFile ff{(uint32_t*)seq_off[k]->p, (uint32_t*)qual_off[k]->p, (uint32_t*)seq_len[k]->p, (uint32_t*)s->t_name_off[k].p,
                           (uint32_t*)s->t_name_len[k].p, (uint32_t*)s->t_plus_off[k].p, (uint32_t*)s->t_plus_len[k].p,
                           (uint32_t*)s->t_qual_len[k].p};
             hipLaunchKernelGGL(frame_records_kernel, dim3((unsigned)((nrec[k] + TXT_BLOCK - 1) / TXT_BLOCK)), dim3(TXT_BLOCK), 0, s->stream,
@@ -747,15 +683,15 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
     info->eof1 = h_meta[0].first_empty < nrec[0];
     info->eof2 = paired && h_meta[1].first_empty < nrec[1];
     info->max_len = h_meta[0].max_len > h_meta[1].max_len ? h_meta[0].max_len : h_meta[1].max_len;
-    // 4. slot view (the text is the arena) + canonical layout for the lane-per-read kernel
+    // 4. slot view: the text IS the arena, every kernel reads the records in place
     DevBatch v{};
     v.n = n;
     v.first_index = ch->first_index;
     v.seq1 = v.qual1 = (const uint8_t*)s->seq1.p;
-    v.off1 = (const uint64_t*)s->off1.p; v.qoff1 = (const uint64_t*)s->qoff1.p; v.len1 = (const uint32_t*)s->len1.p;
+    v.off1 = (const uint32_t*)s->off1.p; v.qoff1 = (const uint32_t*)s->qoff1.p; v.len1 = (const uint32_t*)s->len1.p;
     if (paired) {
         v.seq2 = v.qual2 = (const uint8_t*)s->seq2.p;
-        v.off2 = (const uint64_t*)s->off2.p; v.qoff2 = (const uint64_t*)s->qoff2.p; v.len2 = (const uint32_t*)s->len2.p;
+        v.off2 = (const uint32_t*)s->off2.p; v.qoff2 = (const uint32_t*)s->qoff2.p; v.len2 = (const uint32_t*)s->len2.p;
     }
     if (s->results.reserve(sizeof(aqc_result) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
     if (c->has_cfg && c->cfg.debubble) {
@@ -775,19 +711,6 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
     s->paired = paired;
     s->raw_max_len = info->max_len;
     s->max_len = info->max_len;
-    if (!c->force_generic) {
-        FastBatch f{};
-        f.n = n;
-        if ((rc = canonicalize_dev(c, *s, n, bytes[0], v.seq1, v.qual1, v.off1, v.qoff1, v.len1, s->cseq1, s->cqual1, s->co1, d_tot + 2))) return rc;
-        f.seq1 = (const uint8_t*)s->cseq1.p; f.qual1 = (const uint8_t*)s->cqual1.p; f.o1 = (const uint32_t*)s->co1.p; f.len1 = v.len1;
-        if (paired) {
-            if ((rc = canonicalize_dev(c, *s, n, bytes[1], v.seq2, v.qual2, v.off2, v.qoff2, v.len2, s->cseq2, s->cqual2, s->co2, d_tot + 3))) return rc;
-            f.seq2 = (const uint8_t*)s->cseq2.p; f.qual2 = (const uint8_t*)s->cqual2.p; f.o2 = (const uint32_t*)s->co2.p; f.len2 = v.len2;
-        }
-        f.aux_lane = v.aux_lane; f.aux_tile = v.aux_tile; f.aux_x = v.aux_x; f.aux_y = v.aux_y; f.aux_ok = v.aux_ok;
-        s->fview = f;
-        s->has_canonical = true;
-    }
     // 5. bytes consumed by the n records (+ R1's next sequence length for the TOTAL_BASES quirk)
     uint32_t h_end[2] = {0, 0}, h_next = 0;
     if (n) {
@@ -832,8 +755,8 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
     const DevBuf* qo[2] = {&s->qoff1, &s->qoff2};
     for (int k = 0; k < (s->paired ? 2 : 1); k++) {
         v.f[k].text = (const uint8_t*)arena[k]->p;
-        v.f[k].seq_off = (const uint64_t*)so[k]->p;
-        v.f[k].qual_off = (const uint64_t*)qo[k]->p;
+        v.f[k].seq_off = (const uint32_t*)so[k]->p;
+        v.f[k].qual_off = (const uint32_t*)qo[k]->p;
         v.f[k].seq_len = (const uint32_t*)sl[k]->p;
         v.f[k].name_off = (const uint32_t*)s->t_name_off[k].p;
         v.f[k].name_len = (const uint32_t*)s->t_name_len[k].p;
@@ -929,6 +852,23 @@ int aqc_fetch_results(aqc_ctx* c, int slot, aqc_result* out, uint64_t n) {
     return check_status(c);
 }
 
+int aqc_last_deferred(aqc_ctx* c, int slot, uint32_t* idx, uint64_t cap, uint64_t* n) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!n) return fail(AQC_ERR_ARG, "aqc_last_deferred: null argument");
+    if (!s->ran) return fail(AQC_ERR_STATE, "aqc_last_deferred before aqc_run");
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    *n = 0;
+    if (!s->used_fast || !s->n_deferred.p) return 0;
+    unsigned int m = 0;
+    HIP_TRY(hipMemcpy(&m, s->n_deferred.p, sizeof(m), hipMemcpyDeviceToHost));
+    *n = m;
+    const uint64_t w = m < cap ? m : cap;
+    if (idx && w) HIP_TRY(hipMemcpy(idx, s->deferred.p, sizeof(uint32_t) * w, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int aqc_kernel_ms(aqc_ctx* c, int slot, float* ms) {
     Slot* s;
     int rc = get_slot(c, slot, &s);
@@ -992,7 +932,7 @@ int aqc_get_counters(aqc_ctx* c, int64_t* out) {
         // load balance of the last fast-kernel launch of slot 0: spread of the waves' end stamps
         {
             Slot& s0 = c->slots[0];
-            if (s0.has_canonical && s0.n > (1u << 16) && s0.deferred.p) {
+            if (s0.used_fast && s0.n > (1u << 16) && s0.deferred.p) {
                 const size_t nw = 4096;
                 std::vector<uint32_t> st(2 * nw);
                 (void)hipMemcpy(st.data(), (uint32_t*)s0.deferred.p + (s0.n - 2 * nw), sizeof(uint32_t) * 2 * nw, hipMemcpyDeviceToHost);
@@ -1152,6 +1092,58 @@ int aqc_edit_distance(aqc_ctx* c, const aqc_batch* b, int32_t* dist) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     o.release();
     return check_status(c);
+}
+
+// ---- the reference's existing native seam: libed.so (editdistance/_editdistance.h:16,23, loaded by util.py:16-24) ----
+// Same two symbols, same signatures, so that `cdll.LoadLibrary(<this library>)` serves util.editDistance (util.py:70) and
+// util.overlap_hm_cpp (util.py:223).  Device-backed like everything else here (one lazily created context on GPU 0, one
+// small launch per call); no error channel exists in these signatures, so a failure is printed and the "none" value
+// of the interface comes back (0xFFFFFFFF / 0x7FFFFFFF).
+static std::mutex g_compat_mu;
+static aqc_ctx* g_compat = nullptr;
+static DevBuf g_compat_buf[4];
+
+static int compat_prepare(const char* a, size_t la, const char* b, size_t lb, size_t row_bytes) {
+    if (!g_compat) {
+        int rc = aqc_create(0, 1, &g_compat);
+        if (rc) { g_compat = nullptr; return rc; }
+    }
+    HIP_TRY(hipSetDevice(g_compat->device));
+    if (g_compat_buf[0].reserve(la + 16) || g_compat_buf[1].reserve(lb + 16) || g_compat_buf[2].reserve(row_bytes + 16) ||
+        g_compat_buf[3].reserve(16))
+        return fail(AQC_ERR_HIP, "hipMalloc failed");
+    if (la) HIP_TRY(hipMemcpy(g_compat_buf[0].p, a, la, hipMemcpyHostToDevice));
+    if (lb) HIP_TRY(hipMemcpy(g_compat_buf[1].p, b, lb, hipMemcpyHostToDevice));
+    return 0;
+}
+
+unsigned int edit_distance(const char* a, const unsigned int asize, const char* b, const unsigned int bsize) {
+    if (asize == 0) return bsize;                    // (_editdistance.cpp:101-102)
+    if (bsize == 0) return asize;
+    std::lock_guard<std::mutex> g(g_compat_mu);
+    int out = -1;
+    if (compat_prepare(a, asize, b, bsize, sizeof(int) * ((size_t)bsize + 1)) == 0) {
+        hipLaunchKernelGGL(edit_distance_any_kernel, dim3(1), dim3(WAVE), 0, 0, (const uint8_t*)g_compat_buf[0].p, (int)asize,
+                           (const uint8_t*)g_compat_buf[1].p, (int)bsize, (int*)g_compat_buf[2].p, (int*)g_compat_buf[3].p);
+        if (hipMemcpy(&out, g_compat_buf[3].p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) out = -1;
+    }
+    if (out < 0) fprintf(stderr, "libafterqc_hip: edit_distance failed: %s\n", g_err);
+    return (unsigned int)out;
+}
+
+int seek_overlap(const char* r1, const int len1, const char* r2, const int len2, const int limit_distance,
+                 const int complete_compare_require, const int overlap_require) {
+    std::lock_guard<std::mutex> g(g_compat_mu);
+    int out = 0x7FFFFFFF;
+    bool ok = len1 >= 0 && len2 >= 0 && compat_prepare(r1, (size_t)len1, r2, (size_t)len2, 0) == 0;
+    if (ok) {
+        hipLaunchKernelGGL(seek_overlap_kernel, dim3(1), dim3(WAVE), 0, 0, (const uint8_t*)g_compat_buf[0].p, len1,
+                           (const uint8_t*)g_compat_buf[1].p, len2, limit_distance, complete_compare_require, overlap_require,
+                           (int*)g_compat_buf[3].p);
+        ok = hipMemcpy(&out, g_compat_buf[3].p, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (!ok) { fprintf(stderr, "libafterqc_hip: seek_overlap failed: %s\n", g_err); out = 0x7FFFFFFF; }
+    return out;
 }
 
 }  // extern "C"

@@ -31,25 +31,34 @@
 //       pipeline (process_record_wave) for it afterwards, in the same launch.  Results are
 //       bit-identical either way; only the speed differs.
 //
-// Input is the engine's canonical device layout (built by aqc_upload): records 16-byte aligned,
-// offsets in 16-byte units, the unused bytes of a sequence's last chunk filled with 'A'.
+// Input is the batch exactly as it sits in HBM (DevBatch): byte arenas + 32-bit byte offsets + lengths — the raw FASTQ
+// text chunk addressed in place, or the caller's packed SoA arenas.  Nothing is copied or re-laid-out first: a lane loads
+// its 16-byte chunk with ONE global_load_dwordx4 at whatever alignment the read happens to have (gfx950 serves unaligned
+// vector loads; the ten lanes of a read still cover 160 contiguous bytes), replaces the bytes beyond the read's length
+// by the pad symbol with one v_bfi per dword (mask from a 17-entry LDS table) and validates the alphabet on the fly
+// (v_perm round trip; a record with any other byte is deferred).  Generation 2 needed a separate canonicalisation pass
+// (read 3.0 GB + write 3.2 GB per 5 M pairs, 2.8x the time of this kernel) for the same effect.
 #pragma once
 #include "aqc_kernels.hpp"
 
 namespace aqc {
 
-struct FastBatch {
-    const uint8_t *seq1, *qual1, *seq2, *qual2;
-    const uint32_t *o1, *o2;       // record offsets / 16
-    const uint32_t *len1, *len2;
-    const int32_t *aux_lane, *aux_tile, *aux_x, *aux_y;
-    const uint8_t* aux_ok;
-    uint64_t n;
-};
-
 constexpr uint32_t ODD = 0xAAAAAAAAu;
-constexpr uint32_t EXOTIC_BIT = 0x80000000u;   // in a canonical chunk offset: the record holds bytes the packed arithmetic cannot take
 constexpr int NONE_CAND = 0x7fffffff;
+
+// 16 bytes from an arbitrarily aligned address: one global_load_dwordx4
+__device__ __forceinline__ uint4 load16u(const uint8_t* p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+// (mask & a) | (~mask & b): v_bfi_b32
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+// bytes of d that are none of A C G T N come back non-zero: table round trip through the 3-bit code (c >> 1) & 7
+// (A0 C1 T2 G3 N7; codes 4..6 map to 0x00, which no text byte equals)
+__device__ __forceinline__ uint32_t not_acgtn(uint32_t d) {
+    return d ^ __builtin_amdgcn_perm(0x4e000000u, 0x47544341u, (d >> 1) & 0x07070707u);
+}
 
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
@@ -68,7 +77,6 @@ __device__ __forceinline__ void pack_dword(uint32_t d, uint32_t& lo8, uint32_t& 
     e8 = udot4((d >> 3) & 0x01010101u, 0x80200802u, 0u);
 }
 
-// (the bytes are known to be A C G T N: canonicalize_kernel flags every other record as exotic)
 __device__ __forceinline__ void pack_chunk(const uint4 v, uint32_t& lo, uint32_t& e) {
     uint32_t l0, l1, l2, l3, e0, e1, e2, e3;
     pack_dword(v.x, l0, e0);
@@ -95,13 +103,38 @@ __device__ __forceinline__ void trim_view(int len, int front, int tail, int& st,
 template <int NW, bool PAIRED>
 struct FastWaveLds {
     static constexpr int PPW = PAIRED ? 32 : 64;               // records per wave batch
-    static constexpr int STRIDE = (PAIRED ? 4 : 2) * NW + 5;   // odd: conflict-free lane-strided access
+    static constexpr int GUARD = (PAIRED ? 4 : 2) * NW;        // 5 zero words behind the planes
+    static constexpr int LQ0 = GUARD + 5;                      // read 1's low-quality bit plane: 16 bits per chunk
+    static constexpr int STRIDE = (LQ0 + (NW + 1) / 2) | 1;    // odd: conflict-free lane-strided access
     uint32_t planes[PPW][STRIDE];
-    uint32_t o1[PPW], o2[PPW], l1[PPW], l2[PPW];
+    uint32_t o1[PPW], o2[PPW], q1[PPW], l1[PPW], l2[PPW];
     uint32_t lq[PPW];
     uint32_t exo[PPW];
     uint8_t stage[16 * NW + 16];
 };
+
+// reverse the order of the thirty-two 2-bit fields of a 64-bit value given as (w0 = fields 0..15, w1 = fields 16..31)
+__device__ __forceinline__ void rev2_64(uint32_t& w0, uint32_t& w1) {
+    const uint32_t a = rev2(w1), b = rev2(w0);
+    w0 = a; w1 = b;
+}
+// the 32 fields [start, start + 32) of a plane (16 fields per word); reads plane[start / 16 .. + 2]
+__device__ __forceinline__ void win64(const uint32_t* plane, int start, uint32_t& w0, uint32_t& w1) {
+    const int k = start >> 4;
+    const uint32_t s = (uint32_t)(start & 15) * 2;
+    const uint32_t a = plane[k], b = plane[k + 1], c = plane[k + 2];
+    w0 = alignbit(b, a, s);
+    w1 = alignbit(c, b, s);
+}
+// the sixteen even bits of w, compacted into the low half
+__device__ __forceinline__ uint32_t even_bits16(uint32_t w) {
+    uint32_t x = w & 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0f0f0f0fu;
+    x = (x | (x >> 4)) & 0x00ff00ffu;
+    x = (x | (x >> 8)) & 0x0000ffffu;
+    return x;
+}
 
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 
@@ -143,8 +176,15 @@ __device__ __forceinline__ uint32_t mm_word(uint32_t mlo0, uint32_t mlo1, uint32
 #ifndef AQC_MIN_WAVES
 #define AQC_MIN_WAVES 4
 #endif
-template <int NW, bool PAIRED, int WPBT>
-__global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overlap_kernel(FastBatch fb, aqc_config cfg, DevCircles circ,
+
+// what the barcode stage needs of aqc_config, decoded once per kernel (uniform): verify as 2-bit codes
+struct BarcodeCodes {
+    uint32_t v0, v1;      // verify, field j = (verify[j] >> 1) & 3, fields 0..15 / 16..31
+    uint32_t m0, m1;      // even-bit mask of the verify's fields
+};
+
+template <int NW, bool PAIRED, int WPBT, bool BARCODE>
+__global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overlap_kernel(DevBatch fb, aqc_config cfg, DevCircles circ,
                                                                     aqc_result* __restrict__ results, DevStats st,
                                                                     uint64_t accum_limit, uint32_t* __restrict__ deferred,
                                                                     unsigned int* __restrict__ n_deferred) {
@@ -155,10 +195,21 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     __shared__ WL wls[WPBT];
     __shared__ BlockAcc acc;
     __shared__ unsigned int batch_ticket;
+    __shared__ uint4 mtab[17];                    // mtab[nb]: byte mask of the first nb bytes of a 16-byte chunk
     const int lane = lane_id();
     const int wave = threadIdx.x / WAVE;
     for (int i = threadIdx.x; i < (int)(sizeof(BlockAcc) / 4); i += WPBT * WAVE) ((unsigned int*)&acc)[i] = 0;
     if (threadIdx.x == 0) batch_ticket = WPBT;      // tickets 0 .. WPBT-1 are the waves' first batches
+    if (threadIdx.x < 17) {
+        const int nb = threadIdx.x;
+        uint32_t m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int vb = min(max(nb - 4 * k, 0), 4);
+            m[k] = vb >= 4 ? 0xffffffffu : ((1u << (8 * vb)) - 1u);
+        }
+        mtab[nb] = make_uint4(m[0], m[1], m[2], m[3]);
+    }
     __syncthreads();
     WL& L = wls[wave];
     const int p = PAIRED ? lane >> 1 : lane;      // record of this lane within the batch
@@ -166,12 +217,25 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     uint32_t* const pr = L.planes[p];
     uint32_t* const own = pr + (role ? 2 * NW : 0);         // own stream: lo at own[j], e at own[NW + j]
     const uint32_t* const par = pr + (role ? 0 : 2 * NW);   // partner stream
+    const uint32_t* const qo1 = fb.qoff1 ? fb.qoff1 : fb.off1;
+    const uint32_t* const qo2 = PAIRED ? (fb.qoff2 ? fb.qoff2 : fb.off2) : nullptr;
     const int thr4 = (cfg.qualified_quality_phred + 33) * 0x01010101;
     const bool do_trim = cfg.trim_front > 0 || cfg.trim_tail > 0;
+    // read 1's low-quality count: with a view that is only known per read (trim, barcode) phase 1 leaves one bit per base
+    // and the owner counts inside its view; otherwise the chunks are simply summed
+    const bool lq_plane = BARCODE || do_trim;
     // longest run of identical bases any firing polyX window must contain (pigeonhole over the mismatches)
     const int need = cfg.poly_size_limit - cfg.allow_mismatch_in_poly;
     const int run_req = cfg.allow_mismatch_in_poly >= 0 ? (need + cfg.allow_mismatch_in_poly) / (cfg.allow_mismatch_in_poly + 1) : 0;
     const int r2b = (PAIRED && cfg.count_r2_bases) ? 1 : 0;
+    BarcodeCodes bc{0, 0, 0, 0};
+    if (BARCODE) {
+        for (int j = 0; j < cfg.barcode_verify_len && j < 32; ++j) {
+            const uint32_t code = ((uint32_t)cfg.barcode_verify[j] >> 1) & 3u;
+            if (j < 16) { bc.v0 |= code << (2 * j); bc.m0 |= 1u << (2 * j); }
+            else { bc.v1 |= code << (2 * (j - 16)); bc.m1 |= 1u << (2 * (j - 16)); }
+        }
+    }
 
     // per-lane running totals, reduced once at the end of the kernel
     uint32_t r_n = 0, r_good = 0, r_tb = 0, r_gb = 0, r_ab = 0, r_ar = 0, r_ov = 0, r_ol = 0, r_od = 0, r_rc = 0, r_bc = 0, r_mk = 0, r_sk = 0;
@@ -191,11 +255,12 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     auto batch_of = [&](uint32_t t) -> uint64_t { return (uint64_t)gridDim.x * t + (blockIdx.x + 61u * t) % gridDim.x; };
     uint64_t cur = batch_of((uint32_t)wave);
     // the descriptor of this lane's read in the NEXT batch is fetched one iteration ahead
-    uint32_t m_o = 0, m_l = 0;
+    uint32_t m_o = 0, m_l = 0, m_q = 0;
     if (cur < n_batches && cur * PPW + p < fb.n) {
         const uint64_t r0 = cur * PPW + p;
-        m_o = role ? fb.o2[r0] : fb.o1[r0];
+        m_o = role ? fb.off2[r0] : fb.off1[r0];
         m_l = role ? fb.len2[r0] : fb.len1[r0];
+        if (role == 0) m_q = qo1[r0];
     }
     while (cur < n_batches) {
         const uint64_t base = cur * PPW;
@@ -205,20 +270,21 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         const uint64_t rec = base + p;
         const bool valid = rec < fb.n;
         // ------------------------------------------------------------------ phase 1: load + pack
-        // bit 31 of the chunk offset: canonicalize_kernel met a byte the packed arithmetic cannot take (exotic pair)
-        if (role == 0) { L.o1[p] = m_o & ~EXOTIC_BIT; L.l1[p] = m_l; L.lq[p] = 0; L.exo[p] = m_o >> 31; }
-        else { L.o2[p] = m_o & ~EXOTIC_BIT; L.l2[p] = m_l; }
-        if (role && (m_o >> 31)) L.exo[p] = 1;
+        if (role == 0) { L.o1[p] = m_o; L.l1[p] = m_l; L.q1[p] = m_q; L.lq[p] = 0; L.exo[p] = 0; }
+        else { L.o2[p] = m_o; L.l2[p] = m_l; }
         {
             const uint64_t nrec = nxt * PPW + p;
-            m_o = m_l = 0;
+            m_o = m_l = m_q = 0;
             if (nxt < n_batches && nrec < fb.n) {
-                m_o = role ? fb.o2[nrec] : fb.o1[nrec];
+                m_o = role ? fb.off2[nrec] : fb.off1[nrec];
                 m_l = role ? fb.len2[nrec] : fb.len1[nrec];
+                if (role == 0) m_q = qo1[nrec];
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // each pass: descriptors from LDS, then all 16-byte loads of the pass in flight at once, then the packing
+        // each pass: descriptors from LDS, then all 16-byte loads of the pass in flight at once, then the packing.
+        // Bytes behind the end of a read (the rest of the text line, the next record) become the pad symbol; every byte
+        // that is kept is checked against the alphabet the packed arithmetic takes (A C G T N; qualities < 0x80).
         {
             uint4 v[ITERS];
             int sp[ITERS], len[ITERS];
@@ -227,13 +293,18 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const int t = it * WAVE + lane;
                 sp[it] = t / NW;
                 len[it] = (int)L.l1[sp[it]];
-                v[it] = *reinterpret_cast<const uint4*>(fb.seq1 + ((uint64_t)(L.o1[sp[it]] + (t - sp[it] * NW)) << 4));
+                v[it] = load16u(fb.seq1 + ((uint64_t)L.o1[sp[it]] + (uint32_t)((t - sp[it] * NW) << 4)));
             }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 const int c = it * WAVE + lane - sp[it] * NW;
+                const uint4 m = mtab[min(max(len[it] - 16 * c, 0), 16)];
+                uint4 d;
+                d.x = bfi(m.x, v[it].x, 0x41414141u); d.y = bfi(m.y, v[it].y, 0x41414141u);
+                d.z = bfi(m.z, v[it].z, 0x41414141u); d.w = bfi(m.w, v[it].w, 0x41414141u);
+                if ((not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w))) L.exo[sp[it]] = 1;
                 uint32_t lo, e;
-                pack_chunk(v[it], lo, e);
+                pack_chunk(d, lo, e);
                 L.planes[sp[it]][c] = lo;
                 L.planes[sp[it]][NW + c] = e;
             }
@@ -246,13 +317,18 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const int t = it * WAVE + lane;
                 sp[it] = t / NW;
                 len[it] = (int)L.l2[sp[it]];
-                v[it] = *reinterpret_cast<const uint4*>(fb.seq2 + ((uint64_t)(L.o2[sp[it]] + (t - sp[it] * NW)) << 4));
+                v[it] = load16u(fb.seq2 + ((uint64_t)L.o2[sp[it]] + (uint32_t)((t - sp[it] * NW) << 4)));
             }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 const int c = it * WAVE + lane - sp[it] * NW;
+                const uint4 m = mtab[min(max(len[it] - 16 * c, 0), 16)];
+                uint4 d;
+                d.x = bfi(m.x, v[it].x, 0x41414141u); d.y = bfi(m.y, v[it].y, 0x41414141u);
+                d.z = bfi(m.z, v[it].z, 0x41414141u); d.w = bfi(m.w, v[it].w, 0x41414141u);
+                if ((not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w))) L.exo[sp[it]] = 1;
                 uint32_t lo, e;
-                pack_chunk(v[it], lo, e);
+                pack_chunk(d, lo, e);
                 // complement (A<->T, C<->G: flip the high bit of the field), keep N at code 3, then reverse the chunk
                 lo = (lo ^ ODD) | e | (e >> 1);
                 L.planes[sp[it]][2 * NW + (NW - 1 - c)] = rev2(lo);
@@ -267,29 +343,28 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const int t = it * WAVE + lane;
                 sp[it] = t / NW;
                 len[it] = (int)L.l1[sp[it]];
-                v[it] = *reinterpret_cast<const uint4*>(fb.qual1 + ((uint64_t)(L.o1[sp[it]] + (t - sp[it] * NW)) << 4));
+                v[it] = load16u(fb.qual1 + ((uint64_t)L.q1[sp[it]] + (uint32_t)((t - sp[it] * NW) << 4)));
             }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 const int c = it * WAVE + lane - sp[it] * NW;
+                const uint4 m = mtab[min(max(len[it] - 16 * c, 0), 16)];
+                uint4 d;
+                d.x = bfi(m.x, v[it].x, 0x7f7f7f7fu); d.y = bfi(m.y, v[it].y, 0x7f7f7f7fu);
+                d.z = bfi(m.z, v[it].z, 0x7f7f7f7fu); d.w = bfi(m.w, v[it].w, 0x7f7f7f7fu);
+                if (((d.x | d.y) | (d.z | d.w)) & 0x80808080u) L.exo[sp[it]] = 1;
                 // byte >= thr  <=>  high bit of ((byte | 0x80) - thr) set   (bytes < 0x80, thr <= 0x7f)
-                const uint32_t g0 = ((v[it].x | 0x80808080u) - thr4) & 0x80808080u, g1 = ((v[it].y | 0x80808080u) - thr4) & 0x80808080u;
-                const uint32_t g2 = ((v[it].z | 0x80808080u) - thr4) & 0x80808080u, g3 = ((v[it].w | 0x80808080u) - thr4) & 0x80808080u;
-                int cnt;
-                if (!do_trim) {
-                    // untrimmed: the 0x7f padding of the read's last chunk counts as "qualified", so no position mask is
-                    // needed; chunks wholly behind the read belong to the next record
-                    cnt = 16 * c < len[it] ? 16 - (__popc(g0) + __popc(g1) + __popc(g2) + __popc(g3)) : 0;
+                const uint32_t g0 = ((d.x | 0x80808080u) - thr4) & 0x80808080u, g1 = ((d.y | 0x80808080u) - thr4) & 0x80808080u;
+                const uint32_t g2 = ((d.z | 0x80808080u) - thr4) & 0x80808080u, g3 = ((d.w | 0x80808080u) - thr4) & 0x80808080u;
+                if (!lq_plane) {
+                    // the whole read counts: the 0x7f padding is "qualified", chunks wholly behind the read are all padding
+                    const int cnt = 16 - (__popc(g0) + __popc(g1) + __popc(g2) + __popc(g3));
+                    if (cnt) atomicAdd(&L.lq[sp[it]], (uint32_t)cnt);
                 } else {
-                    int a = 0, nl = len[it];
-                    trim_view(len[it], cfg.trim_front, cfg.trim_tail, a, nl);
                     const uint32_t f16 = udot4((g0 ^ 0x80808080u) >> 7, 0x08040201u, 0u) | (udot4((g1 ^ 0x80808080u) >> 7, 0x08040201u, 0u) << 4) |
                                          (udot4((g2 ^ 0x80808080u) >> 7, 0x08040201u, 0u) << 8) | (udot4((g3 ^ 0x80808080u) >> 7, 0x08040201u, 0u) << 12);
-                    const int lo_b = min(max(a - 16 * c, 0), 16), hi_b = min(max(a + nl - 16 * c, 0), 16);
-                    const uint32_t m16 = ((1u << hi_b) - 1u) & ~((1u << lo_b) - 1u);
-                    cnt = __popc(f16 & m16);
+                    reinterpret_cast<uint16_t*>(&L.planes[sp[it]][WL::LQ0])[c] = (uint16_t)f16;
                 }
-                if (cnt) atomicAdd(&L.lq[sp[it]], (uint32_t)cnt);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -300,18 +375,156 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         const int L2 = PAIRED ? (int)L.l2[p] : 0;
         const bool accum = valid && rec < accum_limit;
         bool defer = valid && (L.exo[p] != 0 || L1 > 16 * NW || L2 > 16 * NW || L1 == 0 || (PAIRED && L2 == 0));
-        // trim (preprocesser.py:455-466): every lane trims its own read
         const int Lown = role ? L2 : L1;
         int a_own = 0, len_own = Lown;
-        if (do_trim) trim_view(Lown, role ? cfg.trim_front2 : cfg.trim_front, role ? cfg.trim_tail2 : cfg.trim_tail, a_own, len_own);
+        int flag = -1;
+        uint32_t bcode = 0;
+        // ---- barcode (preprocesser.py:436-452, barcodeprocesser.py): detectBarcode on the packed first 32 bases of the own
+        //      read, moveBarcodeToName as a front shift of the view, cleanBarcodeTail with ONE bit-vector Levenshtein
+        //      pass per lane (see below)
+        if (BARCODE) {
+            const int bl = cfg.barcode_length, vl = cfg.barcode_verify_len;
+            // the own read's first 32 bases, forward and as sequenced (read 2's stream is stored reversed + complemented)
+            uint32_t f0, f1, g0, g1;
+            if (role == 0) { f0 = own[0]; f1 = own[1]; g0 = own[NW]; g1 = own[NW + 1]; }
+            else {
+                f0 = rev2(own[NW - 1]) ^ ODD; f1 = rev2(own[NW - 2]) ^ ODD;      // (an N comes out as code 1; its flag below decides)
+                g0 = rev2(own[2 * NW - 1]);   g1 = rev2(own[2 * NW - 2]);
+            }
+            const unsigned long long F = ((unsigned long long)f1 << 32) | f0, G = ((unsigned long long)g1 << 32) | g0;
+            const unsigned long long V = ((unsigned long long)bc.v1 << 32) | bc.v0, VM = ((unsigned long long)bc.m1 << 32) | bc.m0;
+            // diffNumber(seq[s : s + len(verify)], verify) (barcodeprocesser.py:9-14): differing codes or an N
+            auto ndiff = [&](int s) -> int {
+                const unsigned long long x = (F >> (2 * s)) ^ V;
+                return __popcll(((x | (x >> 1)) | (G >> (2 * s + 1))) & VM);
+            };
+            int b_own = 0;
+            if (Lown > vl + bl + 1) {
+                if (ndiff(bl) <= 1) b_own = bl;
+                else if (ndiff(bl - 1) == 0) b_own = bl - 1;
+                else if (ndiff(bl + 1) == 0) b_own = bl + 1;
+            }
+            if (!PAIRED) {
+                if (b_own == 0) flag = AQC_BADBCD1;
+                else {
+                    bcode = (uint32_t)(b_own - bl + 2);
+                    const int rm = vl + bl;                 // single-end moves the design length (preprocesser.py:444)
+                    a_own = min(rm, Lown); len_own = max(Lown - rm, 0);
+                }
+            } else {
+                const int b_par = xchg(b_own);
+                const int b1 = role ? b_par : b_own, b2 = role ? b_own : b_par;
+                if (b1 == 0) flag = AQC_BADBCD1;
+                else if (b2 == 0) { flag = AQC_BADBCD2; bcode = (uint32_t)(b1 - bl + 2); }
+                else bcode = (uint32_t)(b1 - bl + 2) | ((uint32_t)(b2 - bl + 2) << 4);
+                const bool moved = b1 != 0 && b2 != 0;
+                if (moved) { a_own = vl + b_own; len_own = Lown - a_own; }
+                const int len_par = xchg(len_own);
+                // ---- cleanBarcodeTail (barcodeprocesser.py:47-75).  For compLen = bsl .. 1 upstream computes
+                //      d = editDistance(own[-compLen:], rc(readStart_partner)[bsl - compLen:]) for both mates and cuts compLen
+                //      from both tails at the first compLen where both d <= compLen / 5.  Reversing both strings and
+                //      complementing both leaves d unchanged, and turns "drop the first i characters of both" into "take
+                //      prefixes": with P = rc(own read)[0 .. bsl) (the tail read backwards, complemented) and
+                //      T = readStart_partner (its barcode + the verify sequence, forward), d(compLen) is the cell
+                //      D[compLen][n_par - bsl + compLen] of ONE Levenshtein matrix of P against T — a diagonal that the
+                //      bit-vector recurrence (Myers / Hyyro, as in edit_distance_lane) yields column by column:
+                //      D[x][y] = y + popc(Pv & low(x)) - popc(Mv & low(x)).
+                const int n_own = b_own + vl, n_par = b_par + vl, bsl = min(n_own, n_par);
+                // readStart of the own read: first b_own bases + verify, as fields; handed to the partner
+                const unsigned long long keep = b_own >= 32 ? ~0ull : ((1ull << (2 * b_own)) - 1ull);
+                const unsigned long long RS = (F & keep) | (b_own >= 32 ? 0ull : (V << (2 * b_own)));
+                const unsigned long long RE = G & keep;
+                uint32_t t0 = (uint32_t)xchg((int)(uint32_t)RS), t1 = (uint32_t)xchg((int)(uint32_t)(RS >> 32));
+                uint32_t u0 = (uint32_t)xchg((int)(uint32_t)RE), u1 = (uint32_t)xchg((int)(uint32_t)(RE >> 32));
+                // the pattern P: rc(own read) from its start.  Read 2's stream already is rc(read 2); read 1's tail is
+                // fetched, reversed and complemented.
+                uint32_t p_lo0, p_lo1, p_e0, p_e1;
+                {
+                    const int tl = Lown - 1;
+                    const int start = role ? 16 * (NW - 1 - (tl >> 4)) + 15 - (tl & 15) : max(Lown - 32, 0);
+                    win64(own, start, p_lo0, p_lo1);
+                    win64(own + NW, start, p_e0, p_e1);
+                    if (role == 0) {
+                        rev2_64(p_lo0, p_lo1);
+                        rev2_64(p_e0, p_e1);
+                        p_lo0 ^= ODD; p_lo1 ^= ODD;
+                        const uint32_t sh = (uint32_t)(2 * (start + 32 - Lown));          // > 0 only for reads under 32 bases
+                        if (sh) {
+                            const unsigned long long a = (((unsigned long long)p_lo1 << 32) | p_lo0) >> sh;
+                            const unsigned long long b = (((unsigned long long)p_e1 << 32) | p_e0) >> sh;
+                            p_lo0 = (uint32_t)a; p_lo1 = (uint32_t)(a >> 32); p_e0 = (uint32_t)b; p_e1 = (uint32_t)(b >> 32);
+                        }
+                    }
+                }
+                // bit planes of the pattern: code bit 0, code bit 1, N flag; position j at bit j
+                const uint32_t P0 = even_bits16(p_lo0) | (even_bits16(p_lo1) << 16);
+                const uint32_t P1 = even_bits16(p_lo0 >> 1) | (even_bits16(p_lo1 >> 1) << 16);
+                const uint32_t PN = even_bits16(p_e0 >> 1) | (even_bits16(p_e1 >> 1) << 16);
+                uint32_t Pv = 0xffffffffu, Mv = 0u, pass = 0u;
+                const int delta = n_par - bsl;
+                const int ymax = bl + 1 + vl;                     // longest readStart
+                for (int y = 0; y < ymax; ++y) {
+                    const uint32_t tc = t0 & 3u, tn = (u0 >> 1) & 1u;
+                    t0 = alignbit(t1, t0, 2); t1 >>= 2;
+                    u0 = alignbit(u1, u0, 2); u1 >>= 2;
+                    const uint32_t s0 = 0u - (tc & 1u), s1 = 0u - (tc >> 1);
+                    const uint32_t Eq = tn ? PN : (~(P0 ^ s0) & ~(P1 ^ s1) & ~PN);
+                    const uint32_t Xv = Eq | Mv;
+                    const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                    uint32_t Ph = Mv | ~(Xh | Pv);
+                    uint32_t Mh = Pv & Xh;
+                    Ph = (Ph << 1) | 1u;
+                    Mh <<= 1;
+                    const uint32_t nPv = Mh | ~(Xv | Ph), nMv = Ph & Xv;
+                    if (y < n_par) { Pv = nPv; Mv = nMv; }
+                    const int x = y + 1 - delta;                  // compLen whose cell sits in this column
+                    if (y < n_par && x >= 1 && x <= bsl) {
+                        const uint32_t lowx = x >= 32 ? 0xffffffffu : ((1u << x) - 1u);
+                        const int d = y + 1 + __popc(Pv & lowx) - __popc(Mv & lowx);
+                        if (d * 5 <= x && x < len_own && x < len_par) pass |= 1u << (x & 31);
+                    }
+                }
+                const uint32_t both = pass & (uint32_t)xchg((int)pass);
+                const int cut = (moved && both) ? 31 - __clz((int)both) : 0;
+                len_own -= cut;
+            }
+        }
+        // trim (preprocesser.py:455-466): every lane trims its own read
+        const int a_pre = a_own, len_pre = len_own;
+        if (do_trim && flag < 0) {
+            int st_ = 0, nl_ = 0;
+            trim_view(len_own, role ? cfg.trim_front2 : cfg.trim_front, role ? cfg.trim_tail2 : cfg.trim_tail, st_, nl_);
+            a_own += st_; len_own = nl_;
+        }
         int a_par = 0, len_par = 0;
         if (PAIRED) { a_par = xchg(a_own); len_par = xchg(len_own); }
         int a1 = role ? a_par : a_own, len1 = role ? len_par : len_own;
         int a2 = role ? a_own : a_par, len2 = role ? len_own : len_par;
-        int flag = -1;
         if (do_trim) {
-            if (len1 < 5) { flag = AQC_BADTRIM1; a2 = 0; len2 = L2; }       // read 2 is not trimmed in this case
-            else if (PAIRED && len2 < 5) flag = AQC_BADTRIM2;
+            // (every exchange runs on all lanes: a DPP read from a masked-off partner returns 0)
+            const int xa_pre = PAIRED ? xchg(a_pre) : 0, xl_pre = PAIRED ? xchg(len_pre) : 0;
+            if (flag < 0) {
+                if (len1 < 5) { flag = AQC_BADTRIM1; a2 = role ? a_pre : xa_pre; len2 = role ? len_pre : xl_pre; }   // read 2 is not trimmed in this case
+                else if (PAIRED && len2 < 5) flag = AQC_BADTRIM2;
+            }
+        }
+        // ---- read 1's low-quality count inside its final view
+        int lq_cnt = 0;
+        if (cfg.unqualified_base_limit > 0) {
+            if (!lq_plane) lq_cnt = (int)L.lq[p];
+            else {
+                int cnt = 0;
+                if (role == 0) {
+#pragma unroll
+                    for (int j = 0; j < (NW + 1) / 2; ++j) {
+                        const int lo_b = min(max(a_own - 32 * j, 0), 32), hi_b = min(max(a_own + len_own - 32 * j, 0), 32);
+                        const uint32_t mh = hi_b >= 32 ? 0xffffffffu : ((1u << hi_b) - 1u), ml = lo_b >= 32 ? 0xffffffffu : ((1u << lo_b) - 1u);
+                        cnt += __popc(pr[WL::LQ0 + j] & mh & ~ml);
+                    }
+                }
+                const int xc = PAIRED ? xchg(cnt) : 0;
+                lq_cnt = role ? xc : cnt;
+            }
         }
         // ---- normalise the own stream IN PLACE in LDS: afterwards own[j] / own[NW + j] hold bases 16j..16j+15 of
         //      read 1 (role 0) or of reverse_r2 (role 1); everything beyond the read's length is zero.  Later
@@ -338,7 +551,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         }
         if (role == 0) {
 #pragma unroll
-            for (int j = 0; j < 5; ++j) pr[(PAIRED ? 4 : 2) * NW + j] = 0;
+            for (int j = 0; j < 5; ++j) pr[WL::GUARD + j] = 0;
         }
         __builtin_amdgcn_wave_barrier();
         PROF(1);
@@ -397,7 +610,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const int lp = PAIRED ? l >> 1 : l, lr = PAIRED ? l & 1 : 0;
                 const int ta = __shfl(a_own, l, WAVE), tl = __shfl(len_own, l, WAVE);
                 // hasPolyX runs on the read as sequenced (read 2 is NOT reverse-complemented)
-                const uint8_t* src = (lr ? fb.seq2 + ((uint64_t)L.o2[lp] << 4) : fb.seq1 + ((uint64_t)L.o1[lp] << 4)) + ta;
+                const uint8_t* src = (lr ? fb.seq2 + L.o2[lp] : fb.seq1 + L.o1[lp]) + ta;
                 stage(L.stage, src, tl);
                 __builtin_amdgcn_wave_barrier();
                 const int px = has_polyx_wave(L.stage, tl, cfg.poly_size_limit, cfg.allow_mismatch_in_poly);
@@ -411,7 +624,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         }
         PROF(2);
         // ---- low quality: read 1 only (preprocesser.py:498)
-        if (flag < 0 && cfg.unqualified_base_limit > 0 && (int)L.lq[p] > cfg.unqualified_base_limit) flag = AQC_BADLQC;
+        if (flag < 0 && cfg.unqualified_base_limit > 0 && lq_cnt > cfg.unqualified_base_limit) flag = AQC_BADLQC;
         // ---- N (preprocesser.py:504-512)
         if (cfg.n_base_limit > 0) {
             int n_own = 0;
@@ -421,7 +634,6 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             if (flag < 0 && (n_own > cfg.n_base_limit || n_par > cfg.n_base_limit)) flag = AQC_BADNCT;
         }
         PROF(3);
-
         // ---- overlap (util.py:158-212) --------------------------------------------------------------
         int offset = 0, ovl = 0, dist = 0, ovl0 = -1, dist_final = -1, n_edits = 0;
         int c_adapter_base = 0, c_adapter_read = 0, c_overlapped = 0, c_corrected = 0, c_masked = 0, c_skipped = 0, c_read_corrected = 0;
@@ -562,8 +774,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const uint32_t* s1w = pr;                                  // read-1 stream
                 const uint32_t* s2w = pr + 2 * NW;                         // reverse_r2 stream
                 // (lanes that do not walk still execute the loads below: keep their addresses inside the arenas)
-                const uint8_t* h1 = fb.qual1 + (walker ? ((uint64_t)L.o1[p] << 4) + a1 + (len1 - ovl) : 0);
-                const uint8_t* h2 = fb.qual2 + (walker ? ((uint64_t)L.o2[p] << 4) + a2 + (len2 - 1) : 64);
+                const uint8_t* h1 = fb.qual1 + (walker ? (uint64_t)L.q1[p] + a1 + (len1 - ovl) : 0);
+                const uint8_t* h2 = fb.qual2 + (walker ? (uint64_t)qo2[rec] + a2 + (len2 - 1) : 0);
                 int wq1[3], wq2[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -619,8 +831,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             lo.y = (uint32_t)(len1 & 0xffff) | ((uint32_t)(a2 & 0xffff) << 16);
             lo.z = (uint32_t)(len2 & 0xffff) | ((uint32_t)(offset & 0xffff) << 16);
             lo.w = (uint32_t)(ovl & 0xffff) | ((uint32_t)(dist & 0xffff) << 16);
-            const unsigned long long q0 = E0 | (E1 << 40), q1 = (E1 >> 24) | (E2 << 16);   // byte 31 (barcode) = 0
-            hi.x = (uint32_t)q0; hi.y = (uint32_t)(q0 >> 32); hi.z = (uint32_t)q1; hi.w = (uint32_t)(q1 >> 32);
+            const unsigned long long q0 = E0 | (E1 << 40), q1 = (E1 >> 24) | (E2 << 16);
+            hi.x = (uint32_t)q0; hi.y = (uint32_t)(q0 >> 32); hi.z = (uint32_t)q1; hi.w = (uint32_t)(q1 >> 32) | (bcode << 24);   // byte 31: barcode nibbles
             uint4* out = reinterpret_cast<uint4*>(results + rec);
             out[0] = lo;
             out[1] = hi;
@@ -705,53 +917,6 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
 #endif
     __syncthreads();
     flush_block_acc(acc, st);
-}
-
-// ------------------------------------------------------------------------------------------------
-// canonicalisation (part of aqc_upload, not of the hot path): copy every record of a raw arena
-// (arbitrary alignment, e.g. FASTQ text addressed in place) to a 16-byte aligned slot and fill the
-// rest of the slot's last 16-byte chunk with `pad`.
-// ------------------------------------------------------------------------------------------------
-// While the bytes pass through, the kernel also validates them — bases must be one of A C G T N, quality bytes
-// below 0x80 (what the lane-per-read kernel's SWAR arithmetic assumes) — and sets bit 31 of the record's chunk
-// offset otherwise ("exotic": the pair is decided by the general kernel).  The hot kernel therefore does not spend
-// instructions re-checking every dword it packs.
-__global__ void canonicalize_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ off,
-                                    const uint32_t* __restrict__ len, uint32_t* __restrict__ o16, uint64_t n,
-                                    uint8_t* __restrict__ dst, uint8_t pad, int is_quality) {
-    // 16 lanes per record, lane = 16-byte chunk of the record (looping for reads longer than 256 bytes)
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t rec = gid >> 4;
-    const bool in = rec < n;
-    const int l = in ? (int)len[rec] : 0;
-    const uint32_t o = in ? o16[rec] : 0u;
-    const uint8_t* s = src + (in ? off[rec] : 0);
-    uint8_t* d = dst + ((uint64_t)(o & ~EXOTIC_BIT) << 4);
-    const int nchunks = (l + 15) >> 4;
-    const uint32_t pad4 = (uint32_t)pad * 0x01010101u;
-    uint32_t bad = 0;
-    for (int c = (int)(gid & 15); c < nchunks; c += 16) {
-        uint32_t w[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = 16 * c + 4 * k;
-            uint32_t v = pad4;
-            if (i + 4 <= l) __builtin_memcpy(&v, s + i, 4);            // unaligned dword load
-            else {
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    if (i + j < l) v = (v & ~(0xffu << (8 * j))) | ((uint32_t)s[i + j] << (8 * j));
-            }
-            // (the pad bytes are valid symbols themselves)
-            bad |= is_quality ? (v & 0x80808080u) : (v ^ __builtin_amdgcn_perm(0x4e000000u, 0x47544341u, (v >> 1) & 0x07070707u));
-            w[k] = v;
-        }
-        *reinterpret_cast<uint4*>(d + 16 * c) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    // the record's 16 lanes sit in one wavefront
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) bad |= (uint32_t)__shfl_xor((int)bad, m, WAVE);
-    if (in && bad && (gid & 15) == 0) o16[rec] = o | EXOTIC_BIT;
 }
 
 }  // namespace aqc

@@ -20,7 +20,7 @@ constexpr int LSTR = 1024;             // LDS bytes per staged string (AQC_MAX_R
 
 struct DevBatch {
     const uint8_t *seq1, *qual1, *seq2, *qual2;
-    const uint64_t *off1, *qoff1, *off2, *qoff2;
+    const uint32_t *off1, *qoff1, *off2, *qoff2;   // byte offsets into the arenas (a chunk / batch arena is < 4 GiB); qoff NULL = off
     const uint32_t *len1, *len2;
     const int32_t *aux_lane, *aux_tile, *aux_x, *aux_y;
     const uint8_t* aux_ok;
@@ -1290,6 +1290,77 @@ __global__ void edit_distance_seam_kernel(DevBatch b, int32_t* dist, int* status
     if (la <= 64) dist[rec] = edit_distance_lane(fa, la, fc, lb);
     else if (lb <= 64) dist[rec] = edit_distance_lane(fc, lb, fa, la);
     else { dist[rec] = -1; atomicCAS(status, 0, AQC_ERR_UNSUPPORTED); }
+}
+
+// the caller's 64-bit byte offsets (struct aqc_batch) -> the 32-bit device form
+__global__ void narrow_offsets_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)in[i];
+}
+
+// ---- libed.so-compatible seams (editdistance/_editdistance.h:16,23): one call = one tiny launch ----------------
+// Levenshtein distance of two strings of any length: one workgroup, the DP row of util.py:72-83 in global scratch
+// (`row`, lb + 1 ints), anti-dependencies resolved by walking the row in order on lane 0 — a compatibility seam, not a
+// hot path (the hot path's Levenshtein is edit_distance_lane above).
+__global__ void edit_distance_any_kernel(const uint8_t* a, int la, const uint8_t* b, int lb, int* row, int* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (la <= 64 || lb <= 64) {
+        auto fa = [&](int i) { return a[i]; };
+        auto fb = [&](int i) { return b[i]; };
+        *out = la <= 64 ? edit_distance_lane(fa, la, fb, lb) : edit_distance_lane(fb, lb, fa, la);
+        return;
+    }
+    for (int j = 0; j <= lb; ++j) row[j] = j;
+    for (int i = 1; i <= la; ++i) {
+        int diag = row[0];
+        row[0] = i;
+        const uint8_t ca = a[i - 1];
+        for (int j = 1; j <= lb; ++j) {
+            const int up = row[j];
+            const int v = min(min(up + 1, row[j - 1] + 1), diag + (ca != b[j - 1] ? 1 : 0));
+            diag = up;
+            row[j] = v;
+        }
+    }
+    *out = row[lb];
+}
+
+// seek_overlap(r1, len1, reverse_r2, len2, limit_distance, complete_compare_require, overlap_require) with the semantics of
+// the LIVE scan util.overlap_hm (util.py:158-212), parameters made explicit: per offset the loop counts mismatches and
+// breaks at the limit-th one if it falls at a column < complete_compare_require; the offset is accepted iff diff < limit,
+// or the loop ran to the end (no break) and its last column L-1 is > complete_compare_require.  In closed form:
+// tot < limit, or (mismatches among the first `ccr` columns < limit and L - 1 > ccr).  One candidate per lane, 64 per
+// step, in the reference's order (forward offsets, then reverse).  Result (offset << 8) + diff, 0x7FFFFFFF for none
+// (_editdistance.cpp:150,177,181).
+__global__ void seek_overlap_kernel(const uint8_t* r1, int len1, const uint8_t* rr2, int len2, int limit, int ccr, int ovr, int* out) {
+    const int lane = lane_id();
+    const int nf = len1 > ovr ? len1 - ovr : 0;
+    const int nr = len2 > ovr ? len2 - ovr : 0;
+    for (int base = 0; base < nf + nr; base += WAVE) {
+        const int c = base + lane;
+        bool ok = false;
+        int tot = 0;
+        if (c < nf + nr) {
+            const int p1 = c < nf ? c : 0, p2 = c < nf ? 0 : c - nf;
+            const int L = c < nf ? min(len1 - c, len2) : min(len1, len2 - p2);
+            int early = 0;
+            for (int i = 0; i < L; ++i) {
+                const int mm = r1[p1 + i] != rr2[p2 + i] ? 1 : 0;
+                tot += mm;
+                if (i < ccr) early += mm;
+            }
+            ok = tot < limit || (early < limit && L - 1 > ccr);
+        }
+        const unsigned long long b = __ballot(ok);
+        if (b) {
+            const int l = __ffsll((long long)b) - 1;
+            const int cand = base + l;
+            const int t = __shfl(tot, l, WAVE);
+            if (lane == 0) *out = (int)((unsigned int)(cand < nf ? cand : -(cand - nf)) << 8) + t;
+            return;
+        }
+    }
+    if (lane == 0) *out = 0x7FFFFFFF;
 }
 
 }  // namespace aqc

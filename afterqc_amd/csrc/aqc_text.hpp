@@ -157,8 +157,8 @@ struct FrameMeta {
 
 // the four lines of every complete group of the chunk (fastq.py:37-49); thread per record
 struct FramedFile {
-    uint64_t* seq_off;
-    uint64_t* qual_off;
+    uint32_t* seq_off;
+    uint32_t* qual_off;
     uint32_t* seq_len;
     uint32_t* name_off;
     uint32_t* name_len;
@@ -268,12 +268,6 @@ __global__ __launch_bounds__(TXT_BLOCK) void parse_names_kernel(const uint8_t* _
     lane_out[r] = lane; tile_out[r] = tile; x_out[r] = x; y_out[r] = y; ok_out[r] = ok;
 }
 
-// ---- canonical offsets on the device ------------------------------------------------------------------------------
-struct ChunksOf {      // 16-byte chunks a read occupies in the canonical layout
-    const uint32_t* len;
-    __device__ uint32_t operator()(uint64_t i) const { return (len[i] + 15u) >> 4; }
-};
-
 // ---- formatting -----------------------------------------------------------------------------------------------------
 __device__ __constant__ char FLAG_TEXT[AQC_N_FLAGS][12] = {"GOOD", "BADBCD1", "BADBCD2", "BADTRIM1", "BADTRIM2", "BADBBL",
                                                             "BADLEN", "BADPOL", "BADLQC", "BADNCT", "BADDIFF", "BADMISMATCH"};
@@ -281,7 +275,7 @@ __device__ __constant__ int FLAG_TEXT_LEN[AQC_N_FLAGS] = {4, 7, 7, 8, 8, 6, 6, 6
 
 struct TextFile {
     const uint8_t* text;
-    const uint64_t *seq_off, *qual_off;
+    const uint32_t *seq_off, *qual_off;
     const uint32_t *seq_len;
     const uint32_t *name_off, *name_len, *plus_off, *plus_len;
 };

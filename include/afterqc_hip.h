@@ -13,8 +13,9 @@
  *   - every function returns 0 on success or a negative AQC_ERR_* code; aqc_last_error() returns a
  *     thread-local human readable message for the last failure;
  *   - one aqc_ctx per GPU, used from one host thread at a time; contexts are independent;
- *   - host buffers are borrowed for the duration of the call only (aqc_upload copies them through
- *     pinned staging with hipMemcpyAsync on the slot's stream);
+ *   - host buffers are borrowed for the duration of the call only (aqc_upload / aqc_frame DMA them with hipMemcpyAsync on
+ *     the slot's stream straight from the caller's pointer: pass page-locked memory from aqc_host_alloc for full-rate,
+ *     truly asynchronous copies; pageable memory works but is staged by the runtime);
  *   - a "record" is one read (single-end) or one read pair; reads are byte strings exactly as in the
  *     FASTQ file (no recoding), addressed by (offset, length) into a packed arena (SoA);
  *   - all integer results are bit-exact restatements of the reference's arithmetic.
@@ -212,7 +213,7 @@ int aqc_set_circles(aqc_ctx* ctx, const double* cx, const double* cy, const doub
 int aqc_reset_stats(aqc_ctx* ctx);
 
 /* ---- the hot path: preprocesser.py:411-631 over a batch --------------------------------------- */
-/* copy a batch into slot `slot` (async on the slot's stream, pinned staging inside) */
+/* copy a batch into slot `slot` (async on the slot's stream; see the note on host buffers above) */
 int aqc_upload(aqc_ctx* ctx, int slot, const aqc_batch* batch);
 /* run filter / trim / overlap / correction over the slot's records (async).  Records with batch
  * index >= accum_limit still get a result but do not enter counters / histograms (used for the
@@ -223,6 +224,10 @@ int aqc_run(aqc_ctx* ctx, int slot, uint64_t accum_limit);
  * post != 0: stat the FINAL reads (trim + edits from the slot's results applied) and only records
  * whose verdict is AQC_GOOD (preprocesser.py:624-627). */
 int aqc_qc_stat(aqc_ctx* ctx, int slot, int which, int mate, uint64_t first, uint64_t count, int post);
+/* diagnostics: the records of the slot's last aqc_run that the lane-per-read kernel did NOT decide itself but handed to the
+ * general wave-per-record kernel (bytes outside A C G T N, reads under 16 bases, the second-scan corner of the adapter
+ * cut, ...).  *n = their number; up to `cap` record indices go to idx (may be NULL).  Results are identical either way. */
+int aqc_last_deferred(aqc_ctx* ctx, int slot, uint32_t* idx, uint64_t cap, uint64_t* n);
 /* wait for the slot and copy its n result records to `out` */
 int aqc_fetch_results(aqc_ctx* ctx, int slot, aqc_result* out, uint64_t n);
 int aqc_sync(aqc_ctx* ctx, int slot);
@@ -306,6 +311,16 @@ int aqc_read_stats(aqc_ctx* ctx, const aqc_batch* reads, int32_t max_poly, int32
 /* util.editDistance(a, b) (util.py:65-83; native twin editdistance/_editdistance.h:16) for n string pairs
  * given as seq1 (a) / seq2 (b) of a batch; strings up to 64 bytes on the device path */
 int aqc_edit_distance(aqc_ctx* ctx, const aqc_batch* pairs, int32_t* dist);
+
+/* ---- the reference's EXISTING native seam (libed.so), for ABI compatibility ------------------------ */
+/* editdistance/_editdistance.h:16 — Levenshtein distance; util.editDistance binds it at util.py:70 */
+unsigned int edit_distance(const char* a, const unsigned int asize, const char* b, const unsigned int bsize);
+/* editdistance/_editdistance.h:23 — bound by util.overlap_hm_cpp (util.py:223).  r2 is ALREADY reverse-complemented.
+ * Implemented with the semantics of the live scan util.overlap_hm (util.py:158-212; the vendored C++ differs from it, see
+ * SURVEY.md App. B-7): returns (offset << 8) + diff of the first accepted offset, 0x7FFFFFFF for none.  With
+ * (limit_distance, complete_compare_require, overlap_require) = (3, 50, 30) it is util.overlap. */
+int seek_overlap(const char* r1, const int len1, const char* r2_revcomp, const int len2, const int limit_distance,
+                 const int complete_compare_require, const int overlap_require);
 
 #ifdef __cplusplus
 }

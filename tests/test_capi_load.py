@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     txt = open(os.path.join(ROOT, "include", "afterqc_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(aqc_[a-z_0-9]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(aqc_[a-z_0-9]+|edit_distance|seek_overlap)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -26,6 +26,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "missing export " + s
     assert sorted(capi.EXPORTED_SYMBOLS) == syms
     assert lib.aqc_abi_version() == 1
+
+
+def test_loads_the_way_the_reference_loads_libed():
+    """util.py:16-24 does `ed_ctypes = cdll.LoadLibrary(<path>)` and then calls ed_ctypes.edit_distance(a, len(a), b, len(b))
+    (util.py:70) / ed_ctypes.seek_overlap(r1, len1, reverse_r2, len2, 3, 30, 50) (util.py:223) with default (int) restype:
+    the two symbols must resolve on this library with exactly those names (no compute here: no GPU)."""
+    from ctypes import cdll
+    ed_ctypes = cdll.LoadLibrary(capi.LIB_PATH)
+    assert ed_ctypes.edit_distance is not None and ed_ctypes.seek_overlap is not None
+    hdr = open(os.path.join(ROOT, "include", "afterqc_hip.h")).read()
+    assert "unsigned int edit_distance(const char* a, const unsigned int asize, const char* b, const unsigned int bsize);" in hdr
+    assert re.search(r"int seek_overlap\(const char\* r1, const int len1, const char\* r2_revcomp, const int len2, const int limit_distance,\s*"
+                     r"const int complete_compare_require, const int overlap_require\);", hdr)
 
 
 def test_struct_layouts_match_header():

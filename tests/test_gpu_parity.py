@@ -54,6 +54,68 @@ def test_edit_distance_golden(gpu_engine, fvec):
     assert d.tolist() == [v[2] for v in vec]
 
 
+def test_libed_compatible_symbols(fvec):
+    """The reference's own native seam (editdistance/_editdistance.h:16,23), loaded the way util.py:16-24 loads libed.so:
+    edit_distance against the reference's editDistance vectors (any length), seek_overlap(r1, reverse_r2, 3, 50, 30)
+    against the reference's util.overlap vectors."""
+    from ctypes import cdll
+    ed_ctypes = cdll.LoadLibrary(capi.LIB_PATH)
+    for a, b, d in fvec["editdistance"]:
+        assert ed_ctypes.edit_distance(a.encode(), len(a), b.encode(), len(b)) == d
+    comp = {"A": "T", "T": "A", "C": "G", "G": "C", "a": "t", "t": "a", "c": "g", "g": "c", "N": "N"}
+    vec = fvec["overlap"]
+    for r1, r2, exp in vec[:400] + vec[5200:]:
+        rr2 = "".join(comp.get(c, "N") for c in reversed(r2))
+        ret = ed_ctypes.seek_overlap(r1.encode("latin-1"), len(r1), rr2.encode("latin-1"), len(r2), 3, 50, 30)
+        if ret == 0x7FFFFFFF:
+            got = [0, 0, 0]
+        else:
+            offset, diff = ret >> 8, ret & 0xFF                      # decoded like util.py:224-225
+            ol = min(len(r1) - offset, len(r2)) if offset >= 0 else min(len(r1), len(r2) - abs(offset))
+            got = [offset, ol, diff]
+        assert got == exp, (r1, r2, exp, got)
+
+
+def test_overlap_golden_through_the_production_kernel(gpu_engine, fvec):
+    """The reference's util.overlap vectors (incl. the i = 49/50/51 and L = 51/52 boundary set, util.py:183,206) through
+    aqc_run — i.e. through the lane-per-read kernel and its closed form, not the function seam: every filter off, no trim,
+    the result record's (offset, overlap_len, distance) must be the golden triple unless the adapter cut re-ran the scan
+    (offset < 0 and overlap_len > 30, preprocesser.py:520-534), in which case the record holds the second call's triple,
+    which is util.overlap of the two reads cut to overlap_len — also a golden-checkable value via the seam's semantics."""
+    comp_keys = set("ATCGatcgN")          # util.COMP (util.py:27): anything else raises KeyError in the walk upstream
+    vec = [v for v in fvec["overlap"] if len(v[0]) > 0 and len(v[1]) > 0 and set(v[0] + v[1]) <= comp_keys]
+    b = capi.Batch.from_strings([v[0] for v in vec], None, [v[1] for v in vec], None)
+    cfg = default_cfg(True, seq_len_req=0, poly_size_limit=0, unqualified_base_limit=0, n_base_limit=0, no_correction=1)
+    gpu_engine.set_config(cfg)
+    gpu_engine.reset_stats()
+    gpu_engine.upload(0, b)
+    gpu_engine.run(0)
+    res = gpu_engine.fetch_results(0)
+    n_def, deferred = gpu_engine.last_deferred(0, want_indices=True)
+    from oracle import oracle
+    checked = 0
+    for i, (r1, r2, exp) in enumerate(vec):
+        r = res[i]
+        got = [int(r["offset"]), int(r["overlap_len"]), int(r["distance"])]
+        if exp[0] < 0 and exp[1] > 30:
+            # adapter cut: both reads := [0:overlap_len], util.overlap again (preprocesser.py:520-534); the second call is
+            # checked against the (golden-pinned) oracle
+            assert int(r["len1"]) == exp[1] and int(r["len2"]) == exp[1]
+            assert got == list(oracle.overlap(r1[:exp[1]], r2[:exp[1]])), (i, r1, r2, exp, got)
+        else:
+            assert got == exp, (i, r1, r2, exp, got)
+        checked += 1
+    assert checked > 5000
+    # the lane-per-read kernel must really have decided them: of the pairs it is built for (A C G T N only, both reads at
+    # least 16 bases) it may hand on only the rare second-scan / walk corners
+    plain = set("ACGTN")
+    eligible = np.array([set(v[0]) <= plain and set(v[1]) <= plain and min(len(v[0]), len(v[1])) >= 16 for v in vec])
+    was_deferred = np.zeros(len(vec), dtype=bool)
+    was_deferred[deferred] = True
+    assert eligible.sum() > 4000
+    assert was_deferred[eligible].mean() < 0.05, was_deferred[eligible].mean()
+
+
 # ---- whole batches vs the oracle ---------------------------------------------------------------------------
 def run_both(gpu_engine, cfg, batch, circles=(), qc=True, accum_limit=capi.UINT64_MAX):
     from oracle import oracle
