@@ -354,7 +354,8 @@ static int fill_slot(aqc_ctx* c, Slot& s, const aqc_batch* b, bool need_qual, bo
     const bool paired = b->seq2 != nullptr;
     if (need_pair && !paired) return fail(AQC_ERR_ARG, "batch: this call needs seq2/off2/len2");
     if (paired && (!b->off2 || !b->len2)) return fail(AQC_ERR_ARG, "batch: off2/len2 missing");
-    if ((b->bytes1 | b->qbytes1 | b->bytes2 | b->qbytes2) >> 32) return fail(AQC_ERR_ARG, "batch: an arena must be smaller than 4 GiB (split the batch)");
+    const uint64_t lim = (1ull << 32) - 4096;      // 32-bit byte offsets on the device, chunk loads may run 288 bytes past a read's start
+    if (b->bytes1 >= lim || b->qbytes1 >= lim || b->bytes2 >= lim || b->qbytes2 >= lim) return fail(AQC_ERR_ARG, "batch: an arena must be smaller than 4 GiB (split the batch)");
     // make sure earlier work on this slot has drained before its buffers are overwritten / regrown
     HIP_TRY(hipStreamSynchronize(s.stream));
     int rc;
@@ -473,7 +474,7 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
             barcode_ok = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
         }
     }
-    const bool fast_ok = !c->force_generic && barcode_ok && thr >= 0 && thr <= 127 && s->max_len <= 256 && s->max_len > 0;
+    const bool fast_ok = !c->force_generic && barcode_ok && thr >= 0 && thr <= 127 && s->max_len <= 288 && s->max_len > 0;
     s->used_fast = fast_ok;
     if (!fast_ok) {
         hipLaunchKernelGGL(filter_overlap_kernel, dim3(grid_for(c, s->n)), dim3(BLOCK), 0, s->stream, s->view, cfg, c->circles,
@@ -484,9 +485,13 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
         if (s->max_len <= 160) {
             if (cfg.paired) { if (cfg.barcode) launch_fast<10, true, 16, true>(c, s, cfg, st, accum_limit); else launch_fast<10, true, 16, false>(c, s, cfg, st, accum_limit); }
             else { if (cfg.barcode) launch_fast<10, false, 12, true>(c, s, cfg, st, accum_limit); else launch_fast<10, false, 12, false>(c, s, cfg, st, accum_limit); }
-        } else {
+        } else if (s->max_len <= 256) {
             if (cfg.paired) { if (cfg.barcode) launch_fast<16, true, 12, true>(c, s, cfg, st, accum_limit); else launch_fast<16, true, 12, false>(c, s, cfg, st, accum_limit); }
             else { if (cfg.barcode) launch_fast<16, false, 11, true>(c, s, cfg, st, accum_limit); else launch_fast<16, false, 11, false>(c, s, cfg, st, accum_limit); }
+        } else {
+            // 257 .. 288 bases: 2x250 reads that still carry a barcode + verify prefix (BASELINE config 5: 267 bases)
+            if (cfg.paired) { if (cfg.barcode) launch_fast<18, true, 12, true>(c, s, cfg, st, accum_limit); else launch_fast<18, true, 12, false>(c, s, cfg, st, accum_limit); }
+            else { if (cfg.barcode) launch_fast<18, false, 10, true>(c, s, cfg, st, accum_limit); else launch_fast<18, false, 10, false>(c, s, cfg, st, accum_limit); }
         }
         hipLaunchKernelGGL(filter_overlap_list_kernel, dim3((unsigned)c->n_cu), dim3(BLOCK), 0, s->stream, s->view, cfg, c->circles,
                            (aqc_result*)s->results.p, st, accum_limit, (const uint32_t*)s->deferred.p,

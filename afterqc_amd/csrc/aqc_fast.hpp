@@ -107,7 +107,7 @@ struct FastWaveLds {
     static constexpr int LQ0 = GUARD + 5;                      // read 1's low-quality bit plane: 16 bits per chunk
     static constexpr int STRIDE = (LQ0 + (NW + 1) / 2) | 1;    // odd: conflict-free lane-strided access
     uint32_t planes[PPW][STRIDE];
-    uint32_t o1[PPW], o2[PPW], q1[PPW], l1[PPW], l2[PPW];
+    uint32_t o1[PPW], o2[PPW], q1[PPW], q2[PAIRED ? PPW : 1], l1[PPW], l2[PPW];
     uint32_t lq[PPW];
     uint32_t exo[PPW];
     uint8_t stage[16 * NW + 16];
@@ -176,6 +176,9 @@ __device__ __forceinline__ uint32_t mm_word(uint32_t mlo0, uint32_t mlo1, uint32
 #ifndef AQC_MIN_WAVES
 #define AQC_MIN_WAVES 4
 #endif
+#ifndef AQC_ABL
+#define AQC_ABL 0      // ablation builds only (tools/gpu_ablate.sh): 1 = no alphabet validation, 2 = no length masks
+#endif
 
 // what the barcode stage needs of aqc_config, decoded once per kernel (uniform): verify as 2-bit codes
 struct BarcodeCodes {
@@ -238,7 +241,37 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     }
 
     // per-lane running totals, reduced once at the end of the kernel
-    uint32_t r_n = 0, r_good = 0, r_tb = 0, r_gb = 0, r_ab = 0, r_ar = 0, r_ov = 0, r_ol = 0, r_od = 0, r_rc = 0, r_bc = 0, r_mk = 0, r_sk = 0;
+    // (packed: R0 = records | good | adapter reads | overlapped, 8 bits each; R1 = total bases | good bases, R2 = adapter bases |
+    //  overlap length, 16 bits each; R3 = distance | corrected reads | corrected bases | masked, R4 = skipped, 8 bits each.  A
+    //  lane adds at most 1 / 576 / 3 to a field per batch, so the wave flushes every 64 batches — five live registers, not 13)
+    uint32_t R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0;
+    int since_flush = 0;
+    auto flush_totals = [&]() {
+        unsigned long long* C = acc.counters;
+        auto fld = [&](uint32_t r, int sh, uint32_t mask) -> unsigned long long { return (unsigned long long)(uint32_t)wave_sum((int)((r >> sh) & mask)); };
+        const unsigned long long t_n = fld(R0, 0, 0xff), t_good = fld(R0, 8, 0xff), t_ar = fld(R0, 16, 0xff), t_ov = fld(R0, 24, 0xff);
+        const unsigned long long t_tb = fld(R1, 0, 0xffff), t_gb = fld(R1, 16, 0xffff), t_ab = fld(R2, 0, 0xffff), t_ol = fld(R2, 16, 0xffff);
+        const unsigned long long t_od = fld(R3, 0, 0xff), t_rc = fld(R3, 8, 0xff), t_bc = fld(R3, 16, 0xff), t_mk = fld(R3, 24, 0xff), t_sk = fld(R4, 0, 0xff);
+        if (lane == 0) {
+            atomicAdd(&C[AQC_C_TOTAL_READS], t_n);
+            atomicAdd(&C[AQC_C_TOTAL_BASES], t_tb);
+            atomicAdd(&C[AQC_C_GOOD_READS], t_good);
+            atomicAdd(&C[AQC_C_GOOD_BASES], t_gb);
+            atomicAdd(&C[AQC_C_FLAG0 + AQC_GOOD], t_good);
+            atomicAdd(&C[AQC_C_TRIMMED_ADAPTER_BASE], t_ab);
+            atomicAdd(&C[AQC_C_TRIMMED_ADAPTER_READ], t_ar);
+            atomicAdd(&C[AQC_C_OVERLAPPED], t_ov);
+            atomicAdd(&C[AQC_C_OVERLAP_LEN_SUM], t_ol);
+            atomicAdd(&C[AQC_C_OVERLAP_BASE_SUM], 2ull * t_ol);
+            atomicAdd(&C[AQC_C_OVERLAP_BASE_ERR], t_od);
+            atomicAdd(&C[AQC_C_READ_CORRECTED], t_rc);
+            atomicAdd(&C[AQC_C_BASE_CORRECTED], t_bc);
+            atomicAdd(&C[AQC_C_BASE_ZERO_QUAL_MASKED], 2ull * t_mk);
+            atomicAdd(&C[AQC_C_BASE_SKIPPED_CORRECTION], 2ull * t_sk);
+        }
+        R0 = R1 = R2 = R3 = R4 = 0;
+        since_flush = 0;
+    };
 
     PROF_DECL
     // Wave batches (PPW consecutive records) are NOT dealt statically: a saturated SIMD serves its resident waves by age,
@@ -254,13 +287,22 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     // (the workgroup's column rotates with t, so that its batches are spread over all memory channels)
     auto batch_of = [&](uint32_t t) -> uint64_t { return (uint64_t)gridDim.x * t + (blockIdx.x + 61u * t) % gridDim.x; };
     uint64_t cur = batch_of((uint32_t)wave);
+    // chunk task `it` of this lane: record (low byte) and chunk within the record — loop invariants, kept PACKED and
+    // re-opened inside the loop behind an opaque barrier: left to itself the compiler hoists every derived address
+    // (15 64-bit values per lane), runs out of registers and reloads them from scratch in every iteration
+    uint32_t task[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int t = it * WAVE + lane;
+        task[it] = (uint32_t)(t / NW) | ((uint32_t)(t % NW) << 8);
+    }
     // the descriptor of this lane's read in the NEXT batch is fetched one iteration ahead
     uint32_t m_o = 0, m_l = 0, m_q = 0;
     if (cur < n_batches && cur * PPW + p < fb.n) {
         const uint64_t r0 = cur * PPW + p;
         m_o = role ? fb.off2[r0] : fb.off1[r0];
         m_l = role ? fb.len2[r0] : fb.len1[r0];
-        if (role == 0) m_q = qo1[r0];
+        m_q = role ? qo2[r0] : qo1[r0];
     }
     while (cur < n_batches) {
         const uint64_t base = cur * PPW;
@@ -271,99 +313,103 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         const bool valid = rec < fb.n;
         // ------------------------------------------------------------------ phase 1: load + pack
         if (role == 0) { L.o1[p] = m_o; L.l1[p] = m_l; L.q1[p] = m_q; L.lq[p] = 0; L.exo[p] = 0; }
-        else { L.o2[p] = m_o; L.l2[p] = m_l; }
+        else { L.o2[p] = m_o; L.l2[p] = m_l; L.q2[p] = m_q; }
         {
             const uint64_t nrec = nxt * PPW + p;
             m_o = m_l = m_q = 0;
             if (nxt < n_batches && nrec < fb.n) {
                 m_o = role ? fb.off2[nrec] : fb.off1[nrec];
                 m_l = role ? fb.len2[nrec] : fb.len1[nrec];
-                if (role == 0) m_q = qo1[nrec];
+                m_q = role ? qo2[nrec] : qo1[nrec];
             }
         }
         __builtin_amdgcn_wave_barrier();
         // each pass: descriptors from LDS, then all 16-byte loads of the pass in flight at once, then the packing.
         // Bytes behind the end of a read (the rest of the text line, the next record) become the pad symbol; every byte
-        // that is kept is checked against the alphabet the packed arithmetic takes (A C G T N; qualities < 0x80).
+        // that is kept is checked against the alphabet the packed arithmetic takes (A C G T N; qualities < 0x80).  The
+        // verdict goes to the record's flag word with one LDS OR per chunk (no compare, no branch).
         {
             uint4 v[ITERS];
-            int sp[ITERS], len[ITERS];
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                const int t = it * WAVE + lane;
-                sp[it] = t / NW;
-                len[it] = (int)L.l1[sp[it]];
-                v[it] = load16u(fb.seq1 + ((uint64_t)L.o1[sp[it]] + (uint32_t)((t - sp[it] * NW) << 4)));
+                uint32_t q = task[it];
+                asm volatile("" : "+v"(q));
+                v[it] = load16u(fb.seq1 + (uint32_t)(L.o1[q & 0xffu] + ((q >> 8) << 4)));
             }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                const int c = it * WAVE + lane - sp[it] * NW;
-                const uint4 m = mtab[min(max(len[it] - 16 * c, 0), 16)];
+                uint32_t q = task[it];
+                asm volatile("" : "+v"(q));
+                const int spi = (int)(q & 0xffu), c = (int)(q >> 8), leni = (int)L.l1[spi];
+                const uint4 m = mtab[min(max(leni - 16 * c, 0), 16)];
                 uint4 d;
                 d.x = bfi(m.x, v[it].x, 0x41414141u); d.y = bfi(m.y, v[it].y, 0x41414141u);
                 d.z = bfi(m.z, v[it].z, 0x41414141u); d.w = bfi(m.w, v[it].w, 0x41414141u);
-                if ((not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w))) L.exo[sp[it]] = 1;
+                if (AQC_ABL & 2) d = v[it];
+                if (!(AQC_ABL & 1)) atomicOr(&L.exo[spi], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
                 uint32_t lo, e;
                 pack_chunk(d, lo, e);
-                L.planes[sp[it]][c] = lo;
-                L.planes[sp[it]][NW + c] = e;
+                L.planes[spi][c] = lo;
+                L.planes[spi][NW + c] = e;
             }
         }
         if (PAIRED) {
             uint4 v[ITERS];
-            int sp[ITERS], len[ITERS];
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                const int t = it * WAVE + lane;
-                sp[it] = t / NW;
-                len[it] = (int)L.l2[sp[it]];
-                v[it] = load16u(fb.seq2 + ((uint64_t)L.o2[sp[it]] + (uint32_t)((t - sp[it] * NW) << 4)));
+                uint32_t q = task[it];
+                asm volatile("" : "+v"(q));
+                v[it] = load16u(fb.seq2 + (uint32_t)(L.o2[q & 0xffu] + ((q >> 8) << 4)));
             }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                const int c = it * WAVE + lane - sp[it] * NW;
-                const uint4 m = mtab[min(max(len[it] - 16 * c, 0), 16)];
+                uint32_t q = task[it];
+                asm volatile("" : "+v"(q));
+                const int spi = (int)(q & 0xffu), c = (int)(q >> 8), leni = (int)L.l2[spi];
+                const uint4 m = mtab[min(max(leni - 16 * c, 0), 16)];
                 uint4 d;
                 d.x = bfi(m.x, v[it].x, 0x41414141u); d.y = bfi(m.y, v[it].y, 0x41414141u);
                 d.z = bfi(m.z, v[it].z, 0x41414141u); d.w = bfi(m.w, v[it].w, 0x41414141u);
-                if ((not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w))) L.exo[sp[it]] = 1;
+                if (AQC_ABL & 2) d = v[it];
+                if (!(AQC_ABL & 1)) atomicOr(&L.exo[spi], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
                 uint32_t lo, e;
                 pack_chunk(d, lo, e);
                 // complement (A<->T, C<->G: flip the high bit of the field), keep N at code 3, then reverse the chunk
                 lo = (lo ^ ODD) | e | (e >> 1);
-                L.planes[sp[it]][2 * NW + (NW - 1 - c)] = rev2(lo);
-                L.planes[sp[it]][3 * NW + (NW - 1 - c)] = __builtin_bitreverse32(e) << 1;
+                L.planes[spi][2 * NW + (NW - 1 - c)] = rev2(lo);
+                L.planes[spi][3 * NW + (NW - 1 - c)] = __builtin_bitreverse32(e) << 1;
             }
         }
         if (cfg.unqualified_base_limit > 0) {
             uint4 v[ITERS];
-            int sp[ITERS], len[ITERS];
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                const int t = it * WAVE + lane;
-                sp[it] = t / NW;
-                len[it] = (int)L.l1[sp[it]];
-                v[it] = load16u(fb.qual1 + ((uint64_t)L.q1[sp[it]] + (uint32_t)((t - sp[it] * NW) << 4)));
+                uint32_t q = task[it];
+                asm volatile("" : "+v"(q));
+                v[it] = load16u(fb.qual1 + (uint32_t)(L.q1[q & 0xffu] + ((q >> 8) << 4)));
             }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
-                const int c = it * WAVE + lane - sp[it] * NW;
-                const uint4 m = mtab[min(max(len[it] - 16 * c, 0), 16)];
+                uint32_t q = task[it];
+                asm volatile("" : "+v"(q));
+                const int spi = (int)(q & 0xffu), c = (int)(q >> 8), leni = (int)L.l1[spi];
+                const uint4 m = mtab[min(max(leni - 16 * c, 0), 16)];
                 uint4 d;
                 d.x = bfi(m.x, v[it].x, 0x7f7f7f7fu); d.y = bfi(m.y, v[it].y, 0x7f7f7f7fu);
                 d.z = bfi(m.z, v[it].z, 0x7f7f7f7fu); d.w = bfi(m.w, v[it].w, 0x7f7f7f7fu);
-                if (((d.x | d.y) | (d.z | d.w)) & 0x80808080u) L.exo[sp[it]] = 1;
+                if (AQC_ABL & 2) d = v[it];
+                if (!(AQC_ABL & 1)) atomicOr(&L.exo[spi], ((d.x | d.y) | (d.z | d.w)) & 0x80808080u);
                 // byte >= thr  <=>  high bit of ((byte | 0x80) - thr) set   (bytes < 0x80, thr <= 0x7f)
                 const uint32_t g0 = ((d.x | 0x80808080u) - thr4) & 0x80808080u, g1 = ((d.y | 0x80808080u) - thr4) & 0x80808080u;
                 const uint32_t g2 = ((d.z | 0x80808080u) - thr4) & 0x80808080u, g3 = ((d.w | 0x80808080u) - thr4) & 0x80808080u;
                 if (!lq_plane) {
                     // the whole read counts: the 0x7f padding is "qualified", chunks wholly behind the read are all padding
                     const int cnt = 16 - (__popc(g0) + __popc(g1) + __popc(g2) + __popc(g3));
-                    if (cnt) atomicAdd(&L.lq[sp[it]], (uint32_t)cnt);
+                    if (cnt) atomicAdd(&L.lq[spi], (uint32_t)cnt);
                 } else {
                     const uint32_t f16 = udot4((g0 ^ 0x80808080u) >> 7, 0x08040201u, 0u) | (udot4((g1 ^ 0x80808080u) >> 7, 0x08040201u, 0u) << 4) |
                                          (udot4((g2 ^ 0x80808080u) >> 7, 0x08040201u, 0u) << 8) | (udot4((g3 ^ 0x80808080u) >> 7, 0x08040201u, 0u) << 12);
-                    reinterpret_cast<uint16_t*>(&L.planes[sp[it]][WL::LQ0])[c] = (uint16_t)f16;
+                    reinterpret_cast<uint16_t*>(&L.planes[spi][WL::LQ0])[c] = (uint16_t)f16;
                 }
             }
         }
@@ -463,6 +509,11 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 uint32_t Pv = 0xffffffffu, Mv = 0u, pass = 0u;
                 const int delta = n_par - bsl;
                 const int ymax = bl + 1 + vl;                     // longest readStart
+                // the diagonal's score is carried from cell to cell: D[x][y+1] = D[x-1][y] + 1 - D0[x-1], D0 = Xh | Mv the
+                // "diagonal delta is zero" vector of the recurrence; it starts at D[0][delta] = delta.  Columns behind the
+                // partner's readStart (y >= n_par) only ever reach x > bsl, which the bound below excludes.
+                int dsc = delta;
+                const int xmax = min(bsl, min(len_own, len_par) - 1);        // compLen < both reads' lengths
                 for (int y = 0; y < ymax; ++y) {
                     const uint32_t tc = t0 & 3u, tn = (u0 >> 1) & 1u;
                     t0 = alignbit(t1, t0, 2); t1 >>= 2;
@@ -471,17 +522,17 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                     const uint32_t Eq = tn ? PN : (~(P0 ^ s0) & ~(P1 ^ s1) & ~PN);
                     const uint32_t Xv = Eq | Mv;
                     const uint32_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                    const uint32_t D0 = Xh | Mv;
                     uint32_t Ph = Mv | ~(Xh | Pv);
                     uint32_t Mh = Pv & Xh;
                     Ph = (Ph << 1) | 1u;
                     Mh <<= 1;
-                    const uint32_t nPv = Mh | ~(Xv | Ph), nMv = Ph & Xv;
-                    if (y < n_par) { Pv = nPv; Mv = nMv; }
+                    Pv = Mh | ~(Xv | Ph);
+                    Mv = Ph & Xv;
                     const int x = y + 1 - delta;                  // compLen whose cell sits in this column
-                    if (y < n_par && x >= 1 && x <= bsl) {
-                        const uint32_t lowx = x >= 32 ? 0xffffffffu : ((1u << x) - 1u);
-                        const int d = y + 1 + __popc(Pv & lowx) - __popc(Mv & lowx);
-                        if (d * 5 <= x && x < len_own && x < len_par) pass |= 1u << (x & 31);
+                    if (x >= 1) {
+                        dsc += 1 - (int)((D0 >> (x - 1)) & 1u);
+                        if (dsc * 5 <= x && x <= xmax) pass |= 1u << x;
                     }
                 }
                 const uint32_t both = pass & (uint32_t)xchg((int)pass);
@@ -775,7 +826,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const uint32_t* s2w = pr + 2 * NW;                         // reverse_r2 stream
                 // (lanes that do not walk still execute the loads below: keep their addresses inside the arenas)
                 const uint8_t* h1 = fb.qual1 + (walker ? (uint64_t)L.q1[p] + a1 + (len1 - ovl) : 0);
-                const uint8_t* h2 = fb.qual2 + (walker ? (uint64_t)qo2[rec] + a2 + (len2 - 1) : 0);
+                const uint8_t* h2 = fb.qual2 + (walker ? (uint64_t)L.q2[p] + a2 + (len2 - 1) : 0);
                 int wq1[3], wq2[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -839,14 +890,14 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         }
         const bool cnt = mine && accum;
         if (cnt) {
-            r_n += 1;
-            r_tb += (uint32_t)(L1 + r2b * L2);
-            if (flag == AQC_GOOD) { r_good += 1; r_gb += (uint32_t)(len1 + r2b * len2); }
+            R0 += 1u;
+            R1 += (uint32_t)(L1 + r2b * L2);
+            if (flag == AQC_GOOD) { R0 += 1u << 8; R1 += (uint32_t)(len1 + r2b * len2) << 16; }
             else atomicAdd(&acc.counters[AQC_C_FLAG0 + flag], 1ull);
             if (PAIRED) {
-                r_ab += (uint32_t)c_adapter_base; r_ar += (uint32_t)c_adapter_read;
-                if (c_overlapped) { r_ov += 1; r_ol += (uint32_t)ovl; r_od += (uint32_t)dist; }
-                r_rc += (uint32_t)c_read_corrected; r_bc += (uint32_t)c_corrected; r_mk += (uint32_t)c_masked; r_sk += (uint32_t)c_skipped;
+                R2 += (uint32_t)c_adapter_base; R0 += (uint32_t)c_adapter_read << 16;
+                if (c_overlapped) { R0 += 1u << 24; R2 += (uint32_t)ovl << 16; R3 += (uint32_t)dist; }
+                R3 += ((uint32_t)c_read_corrected << 8) + ((uint32_t)c_corrected << 16) + ((uint32_t)c_masked << 24); R4 += (uint32_t)c_skipped;
                 if (em0 >= 0) atomicAdd(&acc.counters[AQC_C_ERR_MATRIX0 + em0], 1ull);
                 if (em1 >= 0) atomicAdd(&acc.counters[AQC_C_ERR_MATRIX0 + em1], 1ull);
                 if (em2 >= 0) atomicAdd(&acc.counters[AQC_C_ERR_MATRIX0 + em2], 1ull);
@@ -877,34 +928,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         }
         __builtin_amdgcn_wave_barrier();
         PROF(8);
+        if (++since_flush == 64 || nxt >= n_batches) flush_totals();     // (also the wave's last batch: the only copy of the flush)
         cur = nxt;
-    }
-    // ---- reduce the per-lane running totals once
-    {
-        unsigned long long* C = acc.counters;
-        const uint32_t t_n = (uint32_t)wave_sum((int)r_n), t_good = (uint32_t)wave_sum((int)r_good);
-        const uint32_t t_tb = (uint32_t)wave_sum((int)r_tb), t_gb = (uint32_t)wave_sum((int)r_gb);
-        const uint32_t t_ab = (uint32_t)wave_sum((int)r_ab), t_ar = (uint32_t)wave_sum((int)r_ar);
-        const uint32_t t_ov = (uint32_t)wave_sum((int)r_ov), t_ol = (uint32_t)wave_sum((int)r_ol), t_od = (uint32_t)wave_sum((int)r_od);
-        const uint32_t t_rc = (uint32_t)wave_sum((int)r_rc), t_bc = (uint32_t)wave_sum((int)r_bc);
-        const uint32_t t_mk = (uint32_t)wave_sum((int)r_mk), t_sk = (uint32_t)wave_sum((int)r_sk);
-        if (lane == 0) {
-            atomicAdd(&C[AQC_C_TOTAL_READS], (unsigned long long)t_n);
-            atomicAdd(&C[AQC_C_TOTAL_BASES], (unsigned long long)t_tb);
-            atomicAdd(&C[AQC_C_GOOD_READS], (unsigned long long)t_good);
-            atomicAdd(&C[AQC_C_GOOD_BASES], (unsigned long long)t_gb);
-            atomicAdd(&C[AQC_C_FLAG0 + AQC_GOOD], (unsigned long long)t_good);
-            atomicAdd(&C[AQC_C_TRIMMED_ADAPTER_BASE], (unsigned long long)t_ab);
-            atomicAdd(&C[AQC_C_TRIMMED_ADAPTER_READ], (unsigned long long)t_ar);
-            atomicAdd(&C[AQC_C_OVERLAPPED], (unsigned long long)t_ov);
-            atomicAdd(&C[AQC_C_OVERLAP_LEN_SUM], (unsigned long long)t_ol);
-            atomicAdd(&C[AQC_C_OVERLAP_BASE_SUM], 2ull * t_ol);
-            atomicAdd(&C[AQC_C_OVERLAP_BASE_ERR], (unsigned long long)t_od);
-            atomicAdd(&C[AQC_C_READ_CORRECTED], (unsigned long long)t_rc);
-            atomicAdd(&C[AQC_C_BASE_CORRECTED], (unsigned long long)t_bc);
-            atomicAdd(&C[AQC_C_BASE_ZERO_QUAL_MASKED], 2ull * t_mk);
-            atomicAdd(&C[AQC_C_BASE_SKIPPED_CORRECTION], 2ull * t_sk);
-        }
     }
     PROF_FLUSH;
 #ifdef AQC_PROFILE

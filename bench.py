@@ -60,6 +60,8 @@ def main():
     RL = 250 if args.workload == "config5" else L
     if paired:
         d = synth.make_pairs(args.pairs, RL, seed=(1003 if RL == L else 1005) + rank, workers=nworkers)
+        if args.workload == "config5":
+            d = synth.add_barcodes(d, 1005 + 7 + rank)      # 17-base barcode + verify prefix on both mates
         batch = capi.Batch.from_matrices(d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
     else:
         d = synth.make_single(2 * args.pairs, RL, seed=1002 + rank, workers=nworkers)
@@ -88,6 +90,8 @@ def main():
     cfg.barcode_length = 12
     cfg.set_verify("CAGTA")
     cfg.qc_kmer = 8
+    if args.workload == "config5":
+        cfg.barcode = 1
 
     eng = capi.Engine(device_index, 1)
     eng.set_config(cfg)

@@ -213,10 +213,13 @@ def test_single_end_vs_oracle(gpu_engine):
     assert_same(g, o)
 
 
-def test_barcode_and_bubble_vs_oracle(gpu_engine):
+@pytest.mark.parametrize("L,ragged", [(120, False), (250, False), (239, False), (100, True)])
+def test_barcode_and_bubble_vs_oracle(gpu_engine, L, ragged):
+    """barcode mode on the lane-per-read kernel (detectBarcode / moveAndTrimPair / cleanBarcodeTail incl. mates that read
+    into each other's barcode), at 137, 267 (BASELINE config 5: the 18-word variant), 256 and ragged lengths"""
     import cases
-    d = synth.make_pairs(5000, 120, seed=515, dirty=True)
-    d = synth.add_barcodes(d, 516)
+    d = synth.make_pairs(5000 if L < 200 else 2500, L, seed=515 + L, dirty=True, ragged=ragged)
+    d = synth.add_barcodes(d, 516, tail_frac=0.25)
     batch = capi.Batch.from_matrices(d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
     lane, tile, x, y = d["meta"]
     which = tile % len(cases.CIRCLES)
@@ -224,11 +227,18 @@ def test_barcode_and_bubble_vs_oracle(gpu_engine):
     tile = np.array([c[4] for c in cases.CIRCLES])[which]
     ok = (x % 7 != 0).astype(np.uint8)
     batch.set_aux(lane, tile, x, y, ok)
-    cfg = default_cfg(True, barcode=1, debubble=1)
-    g, o = run_both(gpu_engine, cfg, batch, circles=cases.CIRCLES)
+    cfg = default_cfg(True, barcode=1, debubble=1, trim_tail=3 if L == 239 else 0, trim_tail2=2 if L == 239 else 0, seq_len_req=20 if ragged else 35)
+    # (ragged: reads that are shorter than 5 bases once the barcode is gone make statRead raise upstream, so no QC there)
+    g, o = run_both(gpu_engine, cfg, batch, circles=cases.CIRCLES, qc=not ragged)
     assert_same(g, o)
     flags = np.bincount(g["res"]["flag"], minlength=12)
     assert flags[capi.BADBCD1] > 0 and flags[capi.BADBCD2] > 0 and flags[capi.BADBBL] > 0
+    # the lane-per-read kernel decided (nearly) all of them, and barcode tails were cut
+    assert gpu_engine.last_deferred(0) < 0.05 * batch.n
+    r = g["res"]
+    moved = (r["flag"] != capi.BADBCD1) & (r["flag"] != capi.BADBCD2)
+    cut = d["len1"].astype(np.int64) - r["start1"] - r["len1"]
+    assert (cut[moved & (r["flag"] != capi.BADLEN)] > 4).sum() > 50 or cfg.trim_tail
     # single-end barcode
     b1 = capi.Batch.from_matrices(d["seq1"], d["qual1"], d["len1"])
     g, o = run_both(gpu_engine, default_cfg(False, barcode=1), b1)
