@@ -606,7 +606,7 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
     const uint64_t bytes[2] = {ch->bytes1, paired ? ch->bytes2 : 0};
     const int final_[2] = {ch->final1, ch->final2};
     for (int k = 0; k < nf; k++)
-        if (bytes[k] >= (1ull << 32) - TXT_TILE) return fail(AQC_ERR_ARG, "aqc_frame: chunks must be < 4 GiB");
+        if (bytes[k] >= (1ull << 31) - IDX_TILE) return fail(AQC_ERR_ARG, "aqc_frame: chunks must be < 2 GiB");
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->framed = s->formatted = false;
     s->ran = false;
@@ -618,25 +618,45 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
     if (s->t_scratch.reserve(256)) return fail(AQC_ERR_HIP, "hipMalloc failed");
     FrameMeta* d_meta = (FrameMeta*)s->t_scratch.p;
     unsigned long long* d_tot = (unsigned long long*)((uint8_t*)s->t_scratch.p + 64);
-    // 1. text to the device, newline census
-    uint64_t tiles[2] = {0, 0};
+    // 1. text to the device; line index in one pass (text_index_kernel): both files in one launch
+    uint64_t tiles[2] = {0, 0}, cap[2] = {0, 0};
     for (int k = 0; k < nf; k++) {
-        const size_t slack = TXT_TILE + 64;
+        const size_t slack = IDX_TILE + 64;
         if (arena[k]->reserve(bytes[k] + slack)) return fail(AQC_ERR_HIP, "hipMalloc of %llu bytes failed", (unsigned long long)bytes[k]);
         if (bytes[k]) HIP_TRY(hipMemcpyAsync(arena[k]->p, text[k], bytes[k], hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemsetAsync((uint8_t*)arena[k]->p + bytes[k], 0, slack, s->stream));
-        tiles[k] = bytes[k] ? (bytes[k] + TXT_TILE - 1) / TXT_TILE : 1;
-        if (s->t_tile[k].reserve(sizeof(unsigned long long) * tiles[k])) return fail(AQC_ERR_HIP, "hipMalloc failed");
-        hipLaunchKernelGGL(newline_count_kernel, dim3((unsigned)tiles[k]), dim3(TXT_BLOCK), 0, s->stream, (const uint8_t*)arena[k]->p,
-                           bytes[k], (unsigned long long*)s->t_tile[k].p);
-        hipLaunchKernelGGL(scan_tile_bases_kernel, dim3(1), dim3(TXT_BLOCK), 0, s->stream, (unsigned long long*)s->t_tile[k].p, tiles[k],
-                           d_tot + k);
+        tiles[k] = bytes[k] ? (bytes[k] + IDX_TILE - 1) / IDX_TILE : 1;
+        // FASTQ lines average ~90 bytes; a chunk with more lines than this guess is indexed again with the exact size
+        const uint64_t guess = bytes[k] / 16 + 4096;
+        cap[k] = s->t_line_end[k].cap / sizeof(uint32_t) > guess + 2 ? s->t_line_end[k].cap / sizeof(uint32_t) - 2 : guess;
+        if (s->t_line_end[k].reserve(sizeof(uint32_t) * (cap[k] + 2))) return fail(AQC_ERR_HIP, "hipMalloc failed");
     }
-    HIP_TRY(hipGetLastError());
+    const uint64_t all_tiles = tiles[0] + (paired ? tiles[1] : 0);
+    if (s->t_tile[0].reserve(sizeof(unsigned long long) * (all_tiles + 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
     unsigned long long h_tot[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long) * nf, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    // 2. line table, then the four lines of every complete group
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(hipMemsetAsync(s->t_tile[0].p, 0, sizeof(unsigned long long) * (all_tiles + 1), s->stream));
+        IndexFile f[2] = {};
+        uint32_t t0 = 0;
+        for (int k = 0; k < nf; k++) {
+            f[k] = IndexFile{(const uint8_t*)arena[k]->p, bytes[k], (uint32_t*)s->t_line_end[k].p, cap[k], d_tot + k, t0, (uint32_t)tiles[k]};
+            t0 += (uint32_t)tiles[k];
+        }
+        hipLaunchKernelGGL(text_index_kernel, dim3((unsigned)all_tiles), dim3(TXT_BLOCK), 0, s->stream, f[0], f[1],
+                           (unsigned long long*)s->t_tile[0].p, (unsigned int*)((unsigned long long*)s->t_tile[0].p + all_tiles));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long) * nf, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        bool fits = true;
+        for (int k = 0; k < nf; k++)
+            if (h_tot[k] > cap[k]) {
+                fits = false;
+                cap[k] = h_tot[k];
+                if (s->t_line_end[k].reserve(sizeof(uint32_t) * (cap[k] + 2))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+            }
+        if (fits) break;
+    }
+    // 2. the four lines of every complete group
     uint64_t lines[2] = {0, 0}, nrec[2] = {0, 0};
     const FrameMeta init{0xffffffffu, 0u, 0xffffffffu, 0u};
     FrameMeta h_meta[2] = {init, init};
@@ -645,11 +665,8 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
         lines[k] = h_tot[k];
         // an unterminated last line of the file is a line (readline() returns it)
         const bool virt = final_[k] && bytes[k] > 0 && text[k][bytes[k] - 1] != '\n';
-        if (s->t_line_end[k].reserve(sizeof(uint32_t) * (lines[k] + 2))) return fail(AQC_ERR_HIP, "hipMalloc failed");
-        hipLaunchKernelGGL(newline_emit_kernel, dim3((unsigned)tiles[k]), dim3(TXT_BLOCK), 0, s->stream, (const uint8_t*)arena[k]->p,
-                           bytes[k], (const unsigned long long*)s->t_tile[k].p, (uint32_t*)s->t_line_end[k].p);
         if (virt) {
-            const uint32_t end = (uint32_t)bytes[k];
+            const uint32_t end = (uint32_t)bytes[k] | LINE_WS;          // (may end in blanks: let the framing kernel look)
             HIP_TRY(hipMemcpyAsync((uint32_t*)s->t_line_end[k].p + lines[k], &end, sizeof(end), hipMemcpyHostToDevice, s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));      // `end` lives on this stack frame
             lines[k] += 1;
@@ -726,7 +743,7 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
     HIP_TRY(hipStreamSynchronize(s->stream));
     uint64_t consumed[2] = {0, 0};
     for (int k = 0; k < nf; k++)
-        if (n) consumed[k] = (uint64_t)h_end[k] + 1 < bytes[k] ? (uint64_t)h_end[k] + 1 : bytes[k];
+        if (n) consumed[k] = (uint64_t)(h_end[k] & LINE_POS) + 1 < bytes[k] ? (uint64_t)(h_end[k] & LINE_POS) + 1 : bytes[k];
     info->consumed1 = consumed[0];
     info->consumed2 = consumed[1];
     info->next_len1 = h_next;

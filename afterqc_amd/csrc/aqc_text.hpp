@@ -120,28 +120,122 @@ __device__ __forceinline__ unsigned long long newline_mask64(const uint8_t* p, u
     return mask;
 }
 
-__global__ __launch_bounds__(TXT_BLOCK) void newline_count_kernel(const uint8_t* __restrict__ text, uint64_t bytes,
-                                                                  unsigned long long* __restrict__ tile_sum) {
-    __shared__ unsigned long long lds[4];
-    const uint64_t pos = (uint64_t)blockIdx.x * TXT_TILE + (uint64_t)threadIdx.x * TXT_BYTES_PER_THREAD;
-    const unsigned long long m = pos < bytes ? newline_mask64(text + pos, pos, bytes) : 0ull;
-    unsigned long long total;
-    (void)block_excl_scan((unsigned long long)__popcll(m), lds, total);
-    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+// ---- line index of a text chunk in ONE pass over the bytes ----------------------------------------------------------
+// line_end[i] = byte position of the i-th '\n' (bit 31: the byte before it is a blank or control character, i.e. the
+// line MAY end in whitespace that readline().rstrip() removes — the framing kernel looks at the text only then).
+// Tiles of 32 KiB are claimed in arrival order (ticket) and chained with a decoupled look-back: a tile publishes its
+// newline count (flag A), adds up its predecessors' counts until it meets one that already knows its inclusive prefix
+// (flag P), publishes its own prefix and emits.  The text is read once; the old count / scan / emit trio read it twice
+// and needed three launches per file.
+constexpr int IDX_BYTES_PER_THREAD = 128;
+constexpr int IDX_TILE = TXT_BLOCK * IDX_BYTES_PER_THREAD;     // 32 KiB
+constexpr unsigned long long IDX_FLAG_A = 1ull << 62, IDX_FLAG_P = 2ull << 62, IDX_VAL = (1ull << 62) - 1ull;
+constexpr uint32_t LINE_WS = 0x80000000u, LINE_POS = 0x7fffffffu;
+
+struct IndexFile {
+    const uint8_t* text;
+    uint64_t bytes;
+    uint32_t* line_end;
+    uint64_t cap;              // entries line_end can take (more are counted, not written)
+    unsigned long long* total; // out: number of '\n' in the chunk
+    uint32_t tile0, tiles;     // this file's tiles are [tile0, tile0 + tiles) of the launch
+};
+
+// 64-bit mask of the bytes < 0x21 (blanks and control characters, '\n' included) among the 64 bytes at p
+__device__ __forceinline__ unsigned long long blank_mask64(const uint8_t* p) {
+    unsigned long long mask = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint4 v = reinterpret_cast<const uint4*>(p)[k];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t t = (w[d] & 0x7f7f7f7fu) + 0x5f5f5f5fu;              // bit 7 set where the low 7 bits are >= 0x21
+            const uint32_t z = ~(t | w[d]) & 0x80808080u;
+            const uint32_t nib = ((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xfu;
+            mask |= (unsigned long long)nib << (16 * k + 4 * d);
+        }
+    }
+    return mask;
 }
 
-// line_end[i] = byte position of the i-th '\n'
-__global__ __launch_bounds__(TXT_BLOCK) void newline_emit_kernel(const uint8_t* __restrict__ text, uint64_t bytes,
-                                                                 const unsigned long long* __restrict__ tile_base,
-                                                                 uint32_t* __restrict__ line_end) {
+__global__ __launch_bounds__(TXT_BLOCK) void text_index_kernel(IndexFile f0, IndexFile f1, unsigned long long* __restrict__ state,
+                                                               unsigned int* __restrict__ ticket) {
     __shared__ unsigned long long lds[4];
-    const uint64_t pos = (uint64_t)blockIdx.x * TXT_TILE + (uint64_t)threadIdx.x * TXT_BYTES_PER_THREAD;
-    unsigned long long m = pos < bytes ? newline_mask64(text + pos, pos, bytes) : 0ull;
+    __shared__ unsigned int s_tile;
+    __shared__ unsigned long long s_base;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const IndexFile& f = tile >= f1.tile0 && f1.tiles ? f1 : f0;
+    const uint32_t lt = tile - f.tile0;                                   // tile within the file
+    const uint64_t pos = (uint64_t)lt * IDX_TILE + (uint64_t)threadIdx.x * IDX_BYTES_PER_THREAD;
+    unsigned long long nl[2] = {0, 0}, ws[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint64_t q = pos + 64 * h;
+        if (q < f.bytes) {
+            nl[h] = newline_mask64(f.text + q, q, f.bytes);
+            ws[h] = blank_mask64(f.text + q);
+        }
+    }
+    // "the byte before is blank": shift the blank mask up by one position, the byte before the span comes from memory
+    const unsigned long long carry0 = (pos > 0 && pos <= f.bytes && f.text[pos - 1] < 0x21) ? 1ull : 0ull;
+    const unsigned long long pw0 = (ws[0] << 1) | carry0, pw1 = (ws[1] << 1) | (ws[0] >> 63);
+    const unsigned int cnt = (unsigned int)(__popcll(nl[0]) + __popcll(nl[1]));
     unsigned long long total;
-    unsigned long long i = tile_base[blockIdx.x] + block_excl_scan((unsigned long long)__popcll(m), lds, total);
-    while (m) {
-        line_end[i++] = (uint32_t)(pos + (uint64_t)__builtin_ctzll(m));
-        m &= m - 1;
+    const unsigned long long excl = block_excl_scan((unsigned long long)cnt, lds, total);
+    if (threadIdx.x < WAVE) {
+        const int lane = threadIdx.x;
+        unsigned long long base = 0;
+        if (lt == 0) {
+            if (lane == 0) __hip_atomic_store(&state[tile], IDX_FLAG_P | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&state[tile], IDX_FLAG_A | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long j = (long long)tile - 1;                            // look back from the predecessor
+            const long long first = (long long)f.tile0;
+            while (true) {
+                const long long idx = j - lane;
+                unsigned long long v = IDX_FLAG_P;                        // before the file's first tile: prefix 0
+                if (idx >= first) v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int flag = (unsigned int)(v >> 62);
+                const unsigned long long pend = __ballot(flag == 0), pfx = __ballot(flag == 2);
+                if (pfx) {
+                    const int fp = __ffsll((long long)pfx) - 1;
+                    const unsigned long long upto = fp == 63 ? ~0ull : ((2ull << fp) - 1ull);
+                    if (pend & upto) { __builtin_amdgcn_s_sleep(1); continue; }
+                    unsigned long long part = lane <= fp ? (v & IDX_VAL) : 0ull;
+#pragma unroll
+                    for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft, WAVE);
+                    base += part;
+                    break;
+                }
+                if (pend) { __builtin_amdgcn_s_sleep(1); continue; }
+                unsigned long long part = v & IDX_VAL;
+#pragma unroll
+                for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft, WAVE);
+                base += part;
+                j -= WAVE;
+            }
+            if (lane == 0) __hip_atomic_store(&state[tile], IDX_FLAG_P | (base + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_base = base;
+            if (lt + 1 == f.tiles) *f.total = base + total;
+        }
+    }
+    __syncthreads();
+    unsigned long long i = s_base + excl;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned long long m = nl[h];
+        const unsigned long long pw = h ? pw1 : pw0;
+        while (m) {
+            const int bit = __builtin_ctzll(m);
+            if (i < f.cap) f.line_end[i] = (uint32_t)(pos + 64 * h + (uint64_t)bit) | (((pw >> bit) & 1ull) ? LINE_WS : 0u);
+            ++i;
+            m &= m - 1;
+        }
     }
 }
 
@@ -176,9 +270,11 @@ __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t*
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint64_t li = 4 * r + k;
-        const uint32_t b = li == 0 ? 0u : line_end[li - 1] + 1u;
-        uint32_t e = line_end[li];
-        while (e > b && is_space(text[e - 1])) --e;
+        const uint32_t b = li == 0 ? 0u : (line_end[li - 1] & LINE_POS) + 1u;
+        const uint32_t le = line_end[li];
+        uint32_t e = le & LINE_POS;
+        if (le & LINE_WS)                                   // only lines that may end in whitespace touch the text
+            while (e > b && is_space(text[e - 1])) --e;
         s[k] = b;
         l[k] = e - b;
     }

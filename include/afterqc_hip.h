@@ -259,7 +259,7 @@ int aqc_get_kmers(aqc_ctx* ctx, int which, uint64_t* keys, int64_t* counts, uint
  * Mate files are read in lock step (preprocesser.py:412-429): n = min(avail1, avail2, max_records).
  * After aqc_frame the slot holds the n records exactly as after aqc_upload (the text is the arena), so
  * aqc_run / aqc_qc_stat / aqc_fetch_results apply.  With cfg.debubble (aqc_set_config before aqc_frame) the
- * lane / tile / x / y of preprocesser.py:180-192 are parsed out of the R1 names on the device.  Chunks must be < 4 GiB. */
+ * lane / tile / x / y of preprocesser.py:180-192 are parsed out of the R1 names on the device.  Chunks must be < 2 GiB. */
 typedef struct aqc_text_chunk {
     const uint8_t* text1;
     uint64_t bytes1;
