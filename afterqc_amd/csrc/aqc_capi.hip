@@ -166,20 +166,6 @@ static void launch_fast(aqc_ctx* c, Slot* s, const aqc_config& cfg, const DevSta
                        (unsigned int*)s->n_deferred.p);
 }
 
-// ---- text in / text out -----------------------------------------------------------------------------------------
-// exclusive scan of f(0..n) into out (+add); the grand total lands in *d_total (device)
-template <class F, class OutT>
-static int device_scan(Slot& s, F f, uint64_t n, DevBuf& tile, OutT* out, unsigned long long add, unsigned long long* d_total) {
-    const uint64_t tiles = n ? (n + SCAN_TILE - 1) / SCAN_TILE : 1;
-    if (tile.reserve(sizeof(unsigned long long) * tiles)) return fail(AQC_ERR_HIP, "hipMalloc failed");
-    unsigned long long* t = (unsigned long long*)tile.p;
-    hipLaunchKernelGGL((scan_tile_sums_kernel<F>), dim3((unsigned)tiles), dim3(TXT_BLOCK), 0, s.stream, f, n, t);
-    hipLaunchKernelGGL(scan_tile_bases_kernel, dim3(1), dim3(TXT_BLOCK), 0, s.stream, t, tiles, d_total);
-    if (n) hipLaunchKernelGGL((scan_apply_kernel<F, OutT>), dim3((unsigned)tiles), dim3(TXT_BLOCK), 0, s.stream, f, n, t, out, add);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 extern "C" {
 
 int aqc_abi_version(void) { return AQC_ABI_VERSION; }
@@ -328,6 +314,7 @@ int aqc_reset_stats(aqc_ctx* c) {
 // (ARENA_SLACK readable bytes behind every arena: the lane-per-read kernel always loads whole 16-byte chunks, up to
 // 256 bytes from the start of a read whatever its length)
 constexpr size_t ARENA_SLACK = 1024;
+constexpr size_t TEXT_FRONT = 64;
 
 static int up(DevBuf& d, const void* src, size_t bytes, hipStream_t st) {
     if (d.reserve(bytes + ARENA_SLACK)) return fail(AQC_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
@@ -618,13 +605,16 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
     if (s->t_scratch.reserve(256)) return fail(AQC_ERR_HIP, "hipMalloc failed");
     FrameMeta* d_meta = (FrameMeta*)s->t_scratch.p;
     unsigned long long* d_tot = (unsigned long long*)((uint8_t*)s->t_scratch.p + 64);
-    // 1. text to the device; line index in one pass (text_index_kernel): both files in one launch
+    // 1. text to the device; line index in one pass (text_index_kernel): both files in one launch.  The text sits
+    //    TEXT_FRONT bytes into its buffer: the writer's 16-byte windows may start a few bytes before a piece's source.
     uint64_t tiles[2] = {0, 0}, cap[2] = {0, 0};
+    uint8_t* tbase[2] = {nullptr, nullptr};
     for (int k = 0; k < nf; k++) {
         const size_t slack = IDX_TILE + 64;
-        if (arena[k]->reserve(bytes[k] + slack)) return fail(AQC_ERR_HIP, "hipMalloc of %llu bytes failed", (unsigned long long)bytes[k]);
-        if (bytes[k]) HIP_TRY(hipMemcpyAsync(arena[k]->p, text[k], bytes[k], hipMemcpyHostToDevice, s->stream));
-        HIP_TRY(hipMemsetAsync((uint8_t*)arena[k]->p + bytes[k], 0, slack, s->stream));
+        if (arena[k]->reserve(TEXT_FRONT + bytes[k] + slack)) return fail(AQC_ERR_HIP, "hipMalloc of %llu bytes failed", (unsigned long long)bytes[k]);
+        tbase[k] = (uint8_t*)arena[k]->p + TEXT_FRONT;
+        if (bytes[k]) HIP_TRY(hipMemcpyAsync(tbase[k], text[k], bytes[k], hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemsetAsync(tbase[k] + bytes[k], 0, slack, s->stream));
         tiles[k] = bytes[k] ? (bytes[k] + IDX_TILE - 1) / IDX_TILE : 1;
         // FASTQ lines average ~90 bytes; a chunk with more lines than this guess is indexed again with the exact size
         const uint64_t guess = bytes[k] / 16 + 4096;
@@ -639,7 +629,7 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
         IndexFile f[2] = {};
         uint32_t t0 = 0;
         for (int k = 0; k < nf; k++) {
-            f[k] = IndexFile{(const uint8_t*)arena[k]->p, bytes[k], (uint32_t*)s->t_line_end[k].p, cap[k], d_tot + k, t0, (uint32_t)tiles[k]};
+            f[k] = IndexFile{(const uint8_t*)tbase[k], bytes[k], (uint32_t*)s->t_line_end[k].p, cap[k], d_tot + k, t0, (uint32_t)tiles[k]};
             t0 += (uint32_t)tiles[k];
         }
         hipLaunchKernelGGL(text_index_kernel, dim3((unsigned)all_tiles), dim3(TXT_BLOCK), 0, s->stream, f[0], f[1],
@@ -682,7 +672,7 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
                           (uint32_t*)s->t_name_len[k].p, (uint32_t*)s->t_plus_off[k].p, (uint32_t*)s->t_plus_len[k].p,
                           (uint32_t*)s->t_qual_len[k].p};
             hipLaunchKernelGGL(frame_records_kernel, dim3((unsigned)((nrec[k] + TXT_BLOCK - 1) / TXT_BLOCK)), dim3(TXT_BLOCK), 0, s->stream,
-                               (const uint8_t*)arena[k]->p, (const uint32_t*)s->t_line_end[k].p, nrec[k], ff, d_meta + k);
+                               (const uint8_t*)tbase[k], (const uint32_t*)s->t_line_end[k].p, nrec[k], ff, d_meta + k);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -709,10 +699,10 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
     DevBatch v{};
     v.n = n;
     v.first_index = ch->first_index;
-    v.seq1 = v.qual1 = (const uint8_t*)s->seq1.p;
+    v.seq1 = v.qual1 = (const uint8_t*)tbase[0];
     v.off1 = (const uint32_t*)s->off1.p; v.qoff1 = (const uint32_t*)s->qoff1.p; v.len1 = (const uint32_t*)s->len1.p;
     if (paired) {
-        v.seq2 = v.qual2 = (const uint8_t*)s->seq2.p;
+        v.seq2 = v.qual2 = (const uint8_t*)tbase[1];
         v.off2 = (const uint32_t*)s->off2.p; v.qoff2 = (const uint32_t*)s->qoff2.p; v.len2 = (const uint32_t*)s->len2.p;
     }
     if (s->results.reserve(sizeof(aqc_result) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
@@ -722,7 +712,7 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
             if (s->aux[k].reserve((k < 4 ? sizeof(int32_t) : 1) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
         if (n)
             hipLaunchKernelGGL(parse_names_kernel, dim3((unsigned)((n + TXT_BLOCK - 1) / TXT_BLOCK)), dim3(TXT_BLOCK), 0, s->stream,
-                               (const uint8_t*)s->seq1.p, (const uint32_t*)s->t_name_off[0].p, (const uint32_t*)s->t_name_len[0].p, n,
+                               (const uint8_t*)tbase[0], (const uint32_t*)s->t_name_off[0].p, (const uint32_t*)s->t_name_len[0].p, n,
                                (int32_t*)s->aux[0].p, (int32_t*)s->aux[1].p, (int32_t*)s->aux[2].p, (int32_t*)s->aux[3].p,
                                (uint8_t*)s->aux[4].p);
         v.aux_lane = (const int32_t*)s->aux[0].p; v.aux_tile = (const int32_t*)s->aux[1].p;
@@ -776,7 +766,7 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
     const DevBuf* so[2] = {&s->off1, &s->off2};
     const DevBuf* qo[2] = {&s->qoff1, &s->qoff2};
     for (int k = 0; k < (s->paired ? 2 : 1); k++) {
-        v.f[k].text = (const uint8_t*)arena[k]->p;
+        v.f[k].text = (const uint8_t*)arena[k]->p + TEXT_FRONT;
         v.f[k].seq_off = (const uint32_t*)so[k]->p;
         v.f[k].qual_off = (const uint32_t*)qo[k]->p;
         v.f[k].seq_len = (const uint32_t*)sl[k]->p;
@@ -785,17 +775,18 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
         v.f[k].plus_off = (const uint32_t*)s->t_plus_off[k].p;
         v.f[k].plus_len = (const uint32_t*)s->t_plus_len[k].p;
     }
-    // streams q = file * 3 + {0 good, 1 bad, 2 overlap}
-    if (s->f_pos.reserve(sizeof(unsigned long long) * 6 * (n ? n : 1)) || s->t_scratch.reserve(256))
+    // streams q = file * 3 + {0 good, 1 bad, 2 overlap}: per-tile byte sums -> tile bases (one launch each), the
+    // per-record offsets are formed inside the writer
+    const uint64_t n_tiles = n ? (n + FMT_TILE - 1) / FMT_TILE : 1;
+    if (s->f_tile.reserve(sizeof(unsigned long long) * 6 * n_tiles) || s->t_scratch.reserve(256))
         return fail(AQC_ERR_HIP, "hipMalloc failed");
     unsigned long long* d_tot = (unsigned long long*)((uint8_t*)s->t_scratch.p + 128);
+    HIP_TRY(hipMemsetAsync(s->f_tile.p, 0, sizeof(unsigned long long) * 6 * n_tiles, s->stream));
+    if (n) hipLaunchKernelGGL(fmt_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles, (unsigned long long*)s->f_tile.p);
+    hipLaunchKernelGGL(fmt_tile_bases_kernel, dim3(6), dim3(TXT_BLOCK), 0, s->stream, (unsigned long long*)s->f_tile.p, n_tiles, d_tot);
+    HIP_TRY(hipGetLastError());
     bool live[6];
-    for (int q = 0; q < 6; q++) {
-        live[q] = (q < 3 || s->paired) && (q % 3 != 2 || v.store_overlap);
-        if (!live[q]) continue;
-        OutSize f{v, q / 3, q % 3};
-        if ((rc = device_scan(*s, f, n, s->f_tile, (unsigned long long*)s->f_pos.p + (uint64_t)q * n, 0ull, d_tot + q))) return rc;
-    }
+    for (int q = 0; q < 6; q++) live[q] = (q < 3 || s->paired) && (q % 3 != 2 || v.store_overlap);
     unsigned long long h_tot[6] = {0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(h_tot), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -807,13 +798,11 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
         outs.p[q] = (uint8_t*)s->f_out[q].p;
     }
     if (n) {
-        const uint64_t waves = n * (s->paired ? 2 : 1);
-        const uint64_t blocks = (waves * WAVE + TXT_BLOCK - 1) / TXT_BLOCK;
-        hipLaunchKernelGGL(format_write_kernel, dim3((unsigned)blocks), dim3(TXT_BLOCK), 0, s->stream, v, n,
-                           (const unsigned long long*)s->f_pos.p, outs, 0);
+        hipLaunchKernelGGL(fmt_write_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles,
+                           (const unsigned long long*)s->f_tile.p, outs, 0);
         if (v.store_overlap)
-            hipLaunchKernelGGL(format_write_kernel, dim3((unsigned)blocks), dim3(TXT_BLOCK), 0, s->stream, v, n,
-                               (const unsigned long long*)s->f_pos.p, outs, 1);
+            hipLaunchKernelGGL(fmt_write_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles,
+                               (const unsigned long long*)s->f_tile.p, outs, 1);
         HIP_TRY(hipGetLastError());
     }
     s->formatted = true;

@@ -418,136 +418,295 @@ __device__ __forceinline__ int moved_barcode_len(const FormatView& v, int file, 
     return min(max(b, 0), (int)seq_len);
 }
 
-// bytes record r contributes to (file, stream); stream 0 = good, 1 = bad, 2 = overlap
-struct OutSize {
-    FormatView v;
-    int file, stream;
-    __device__ uint32_t operator()(uint64_t r) const {
-        const uint4 w0 = *reinterpret_cast<const uint4*>(v.results + r);
-        const int flag = (int)(w0.x & 0xffu);
-        uint32_t len = file == 0 ? (w0.y & 0xffffu) : (w0.z & 0xffffu);
-        if (stream == 2) {
-            const uint4 w1 = *(reinterpret_cast<const uint4*>(v.results + r) + 1);
-            if (!in_overlap_stream(v, w0, w1)) return 0u;
-            len = w0.w & 0xffffu;                               // getOverlap: the last overlap_len bases
-        } else if ((flag == AQC_GOOD ? 0 : 1) != stream) return 0u;
-        if (v.plain) len = v.f[file].seq_len[r];                // index records go out whole
-        const TextFile& t = v.f[file];
-        uint32_t nlen = t.name_len[r];
-        if (v.barcode && !v.plain) {
-            const uint32_t bc = reinterpret_cast<const uint8_t*>(v.results + r)[31];
-            const int b = moved_barcode_len(v, file, flag, bc, t.seq_len[r]);
-            if (b >= 0) {
-                // name[str.find(':'):] — find() == -1 slices the last character
-                const uint8_t* name = t.text + t.name_off[r];
-                uint32_t cpos = nlen - 1;
-                for (uint32_t i = 0; i < nlen; ++i)
-                    if (name[i] == ':') { cpos = i; break; }
-                nlen = 1u + (uint32_t)b + (nlen - cpos);
-            }
+// ---- one record of one file, as the writer sees it --------------------------------------------------------------------
+// The output record is a sequence of pieces
+//     '@' | FLAG | barcode bases | name tail | \n | bases | \n | strand line | \n | qualities | \n
+// of which the flag text, the barcode bases, the name tail, the bases, the strand line and the qualities are copied from a
+// source (SEGMENTS: output offset, length, source pointer) and '@' / the four newlines are literals.
+constexpr int FMT_NSEG = 6;
+struct FmtRec {
+    int stream;                 // 0 good / 1 bad / 2 overlap; -1: this record does not go to the pass's stream
+    int total;                  // bytes of the output record
+    int seg_dst[FMT_NSEG], seg_len[FMT_NSEG];
+    const uint8_t* seg_src[FMT_NSEG];
+    int at;                     // 1: byte 0 is a literal '@'
+    int nl[4];                  // positions of the four newlines
+    int e_pos[3];               // the walk's edits in this mate's slice coordinates (-1 none)
+    uint32_t e_val[3];          //   new base << 8 | new quality  (base 0 = keep)
+    int n_edits;
+};
+
+// flag texts behind 16 bytes of slack (the writer loads 16-byte windows that may start before a piece's source)
+__device__ uint8_t FLAG_SRC[AQC_N_FLAGS + 1][48] = {
+    "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0GOOD",     "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADBCD1",  "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADBCD2",
+    "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADTRIM1", "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADTRIM2", "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADBBL",
+    "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADLEN",   "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADPOL",   "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADLQC",
+    "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADNCT",   "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADDIFF",  "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADMISMATCH"};
+
+// bytes of (file, stream) that record r contributes: the sizes of all three streams of one file at once
+// (sz[0] good, sz[1] bad, sz[2] overlap); the name's first ':' is only searched when a barcode was moved
+__device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int file, uint32_t sz[3]) {
+    const uint4 w0 = *reinterpret_cast<const uint4*>(v.results + r);
+    const int flag = (int)(w0.x & 0xffu);
+    const TextFile& t = v.f[file];
+    uint32_t len = file == 0 ? (w0.y & 0xffffu) : (w0.z & 0xffffu);
+    if (v.plain) len = t.seq_len[r];                        // index records go out whole
+    uint32_t nlen = t.name_len[r];
+    if (v.barcode && !v.plain) {
+        const uint32_t bc = reinterpret_cast<const uint8_t*>(v.results + r)[31];
+        const int b = moved_barcode_len(v, file, flag, bc, t.seq_len[r]);
+        if (b >= 0) {
+            // name[str.find(':'):] — find() == -1 slices the last character
+            const uint8_t* name = t.text + t.name_off[r];
+            uint32_t cpos = nlen - 1;
+            for (uint32_t i = 0; i < nlen; ++i)
+                if (name[i] == ':') { cpos = i; break; }
+            nlen = 1u + (uint32_t)b + (nlen - cpos);
         }
-        return nlen + (flag == AQC_GOOD ? 0u : (uint32_t)FLAG_TEXT_LEN[flag]) + 2u * len + t.plus_len[r] + 4u;
     }
-};
+    const uint32_t body = nlen + t.plus_len[r] + 4u;
+    sz[0] = flag == AQC_GOOD ? body + 2u * len : 0u;
+    sz[1] = flag == AQC_GOOD ? 0u : body + (uint32_t)FLAG_TEXT_LEN[flag] + 2u * len;
+    sz[2] = 0u;
+    if (v.store_overlap) {
+        const uint4 w1 = *(reinterpret_cast<const uint4*>(v.results + r) + 1);
+        if (in_overlap_stream(v, w0, w1)) sz[2] = body + 2u * (v.plain ? len : (w0.w & 0xffffu));   // getOverlap: the last overlap_len bases
+    }
+}
 
-// one wavefront per (record, file): the output record is assembled byte by byte, 64 bytes per step
-struct FormatOut {
-    uint8_t* p[6];        // [file * 3 + stream]
-};
+constexpr int FMT_TILE = 256;           // records per workgroup (one thread per record in the sizing phase)
 
-__global__ __launch_bounds__(TXT_BLOCK) void format_write_kernel(FormatView v, uint64_t n, const unsigned long long* __restrict__ pos /* [2 files][3 streams][n] */,
-                                                                 FormatOut outs, int overlap_pass) {
-    const int lane = lane_id();
-    const uint64_t wid = ((uint64_t)blockIdx.x * TXT_BLOCK + threadIdx.x) / WAVE;
+// per-tile byte sums of the six streams (file * 3 + stream): tile_sum[q * n_tiles + tile]
+__global__ __launch_bounds__(FMT_TILE) void fmt_tile_sums_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
+                                                                 unsigned long long* __restrict__ tile_sum) {
+    __shared__ unsigned long long lds[4];
+    const uint64_t r = (uint64_t)blockIdx.x * FMT_TILE + threadIdx.x;
     const int nfiles = v.paired ? 2 : 1;
-    if (wid >= n * nfiles) return;
-    const uint64_t r = wid / nfiles;
-    const int file = (int)(wid % nfiles);
+    for (int file = 0; file < nfiles; ++file) {
+        uint32_t sz[3] = {0, 0, 0};
+        if (r < n) fmt_sizes(v, r, file, sz);
+        for (int st = 0; st < (v.store_overlap ? 3 : 2); ++st) {
+            unsigned long long total;
+            (void)block_excl_scan((unsigned long long)sz[st], lds, total);
+            if (threadIdx.x == 0) tile_sum[(uint64_t)(file * 3 + st) * n_tiles + blockIdx.x] = total;
+        }
+    }
+}
+
+// exclusive scan of each stream's tile sums (workgroup q handles stream q); totals to total_out[q]
+__global__ __launch_bounds__(TXT_BLOCK) void fmt_tile_bases_kernel(unsigned long long* __restrict__ tile_sum, uint64_t n_tiles,
+                                                                   unsigned long long* __restrict__ total_out) {
+    __shared__ unsigned long long lds[4];
+    unsigned long long* ts = tile_sum + (uint64_t)blockIdx.x * n_tiles;
+    unsigned long long carry = 0;
+    for (uint64_t t0 = 0; t0 < n_tiles; t0 += TXT_BLOCK) {
+        const uint64_t t = t0 + threadIdx.x;
+        const unsigned long long val = t < n_tiles ? ts[t] : 0ull;
+        unsigned long long total;
+        const unsigned long long ex = block_excl_scan(val, lds, total);
+        if (t < n_tiles) ts[t] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) total_out[blockIdx.x] = carry;
+}
+
+__device__ __forceinline__ void fmt_record(const FormatView& v, uint64_t r, int file, int overlap_pass, int lane32, FmtRec& o) {
     const uint4 w0 = *reinterpret_cast<const uint4*>(v.results + r);
     const uint4 w1 = *(reinterpret_cast<const uint4*>(v.results + r) + 1);
-    const int flag = (int)(w0.x & 0xffu), n_edits = (int)((w0.x >> 8) & 0xffu);
-    if (overlap_pass && !in_overlap_stream(v, w0, w1)) return;
-    const int stream = overlap_pass ? 2 : (flag == AQC_GOOD ? 0 : 1);
+    const int flag = (int)(w0.x & 0xffu);
+    o.n_edits = v.plain ? 0 : (int)((w0.x >> 8) & 0xffu);
+    o.stream = overlap_pass ? (in_overlap_stream(v, w0, w1) ? 2 : -1) : (flag == AQC_GOOD ? 0 : 1);
     const int len1 = (int)(w0.y & 0xffffu), len2 = (int)(w0.z & 0xffffu), ovl = (int)(w0.w & 0xffffu);
-    // the slice of the original read that is written: the final read, or its last overlap_len bases (getOverlap)
     const TextFile& t = v.f[file];
+    // the slice of the original read that is written: the final read, or its last overlap_len bases (getOverlap)
     const int cut = v.plain ? 0 : (overlap_pass ? (file == 0 ? len1 : len2) - ovl : 0);
     const int st = v.plain ? 0 : (file == 0 ? (int)(w0.x >> 16) : (int)(w0.y >> 16)) + cut;
     const int len = v.plain ? (int)t.seq_len[r] : (overlap_pass ? ovl : (file == 0 ? len1 : len2));
-    // the walk's edits in this mate's final coordinates: position, new base (0 = keep), new quality
-    int e_pos[3] = {-1, -1, -1};
-    uint32_t e_val[3] = {0, 0, 0};
     const unsigned long long e_lo = ((unsigned long long)w1.y << 32) | w1.x, e_hi = ((unsigned long long)w1.w << 32) | w1.z;
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
-        if (e < n_edits && !v.plain) {
+        o.e_pos[e] = -1; o.e_val[e] = 0;
+        if (e < o.n_edits) {
             const int bit = 40 * e;
             unsigned long long x = bit < 64 ? e_lo >> bit : 0ull;
             if (bit + 40 > 64) x |= bit < 64 ? e_hi << (64 - bit) : e_hi >> (bit - 64);
-            const int o = (int)(x & 0xffffu);
+            const int oo = (int)(x & 0xffffu);
             const uint32_t kind = (uint32_t)(x >> 16) & 0xffu, base = (uint32_t)(x >> 24) & 0xffu, qual = (uint32_t)(x >> 32) & 0xffu;
-            const int p = (file == 0 ? len1 - ovl + o : len2 - 1 - o) - cut;
-            if (kind == AQC_EDIT_MASK) { e_pos[e] = p; e_val[e] = (uint32_t)'!'; }
-            else if ((kind == AQC_EDIT_FIX_R1 && file == 0) || (kind == AQC_EDIT_FIX_R2 && file == 1)) { e_pos[e] = p; e_val[e] = (base << 8) | qual; }
+            const int p = (file == 0 ? len1 - ovl + oo : len2 - 1 - oo) - cut;
+            if (kind == AQC_EDIT_MASK) { o.e_pos[e] = p; o.e_val[e] = (uint32_t)'!'; }
+            else if ((kind == AQC_EDIT_FIX_R1 && file == 0) || (kind == AQC_EDIT_FIX_R2 && file == 1)) { o.e_pos[e] = p; o.e_val[e] = (base << 8) | qual; }
         }
     }
     const uint8_t* name = t.text + t.name_off[r];
-    const uint8_t* seq = t.text + t.seq_off[r] + st;
-    const uint8_t* plus = t.text + t.plus_off[r];
-    const uint8_t* qual = t.text + t.qual_off[r] + st;
+    const uint8_t* seq0 = t.text + t.seq_off[r];           // the read as sequenced (barcode source)
     const int nlen = (int)t.name_len[r], plen = (int)t.plus_len[r];
-    const int flen = stream == 1 ? FLAG_TEXT_LEN[flag] : 0;
+    const int flen = o.stream == 1 ? FLAG_TEXT_LEN[flag] : 0;
     // barcode moved into the name: '@' + [FLAG] + bases[0:mb] + name[cpos:]
     const int mb = (v.barcode && !v.plain) ? moved_barcode_len(v, file, flag, w1.w >> 24, t.seq_len[r]) : -1;
     int cpos = nlen - 1;
     if (mb >= 0) {
-        for (int i0 = 0; i0 < nlen; i0 += WAVE) {
-            const unsigned long long hit = __ballot(i0 + lane < nlen && name[i0 + lane] == ':');
-            if (hit) { cpos = i0 + __builtin_ctzll(hit); break; }
+        // (the 32 lanes of the task search together; every lane gets the same answer)
+        for (int i0 = 0; i0 < nlen; i0 += 32) {
+            const unsigned long long hit = __ballot(i0 + lane32 < nlen && name[i0 + lane32] == ':');
+            const uint32_t mine = (uint32_t)(hit >> (32 * ((threadIdx.x >> 5) & 1)));
+            if (mine) { cpos = i0 + __builtin_ctz(mine); break; }
         }
     }
-    const uint8_t* seq0 = t.text + t.seq_off[r];          // the read as sequenced (barcode source)
-    const int nlen_out = mb >= 0 ? 1 + mb + (nlen - cpos) : nlen;
-    // segment boundaries in the output record
-    const int b_name = nlen_out + flen;        // name' then '\n'
-    const int b_seq = b_name + 1 + len;        // bases then '\n'
-    const int b_plus = b_seq + 1 + plen;       // strand line then '\n'
-    const int b_qual = b_plus + 1 + len;       // qualities then '\n'
-    const int total = b_qual + 1;
-    uint8_t* dst = outs.p[file * 3 + stream] + pos[(uint64_t)(file * 3 + stream) * n + r];
-    for (int j = lane; j < total; j += WAVE) {
-        uint8_t c;
-        if (j < b_name) {
-            // "@" + FLAG + name[1:] for a bad record (preprocesser.py:213-219), the name itself for a good one;
-            // with a moved barcode the name is '@' + barcode + name[cpos:] before that rule applies
-            if (mb < 0) {
-                if (j == 0 || stream != 1) c = stream == 1 ? (uint8_t)'@' : name[j];
-                else if (j <= flen) c = (uint8_t)FLAG_TEXT[flag][j - 1];
-                else c = name[j - flen];
-            } else {
-                if (j == 0) c = (uint8_t)'@';
-                else if (j <= flen) c = (uint8_t)FLAG_TEXT[flag][j - 1];
-                else if (j <= flen + mb) c = seq0[j - flen - 1];
-                else c = name[cpos + (j - flen - mb - 1)];
-            }
-        } else if (j == b_name || j == b_seq || j == b_plus || j == b_qual) {
-            c = (uint8_t)'\n';
-        } else if (j < b_seq) {
-            const int i = j - b_name - 1;
-            c = seq[i];
+    // "@" + FLAG + name[1:] for a bad record (preprocesser.py:213-219), the name itself for a good one; with a moved barcode
+    // the name is '@' + barcode + name[cpos:] before that rule applies
+    const bool renamed = o.stream == 1 || mb >= 0;
+    o.at = renamed ? 1 : 0;
+    o.seg_dst[0] = 1; o.seg_len[0] = flen; o.seg_src[0] = &FLAG_SRC[flag][16];
+    o.seg_dst[1] = 1 + flen; o.seg_len[1] = mb >= 0 ? mb : 0; o.seg_src[1] = seq0;
+    if (mb >= 0) { o.seg_dst[2] = 1 + flen + mb; o.seg_len[2] = nlen - cpos; o.seg_src[2] = name + cpos; }
+    else if (renamed) { o.seg_dst[2] = 1 + flen; o.seg_len[2] = max(nlen - 1, 0); o.seg_src[2] = name + 1; }
+    else { o.seg_dst[2] = 0; o.seg_len[2] = nlen; o.seg_src[2] = name; }
+    const int b_name = o.seg_dst[2] + o.seg_len[2];        // name' then '\n'
+    const int b_seq = b_name + 1 + len;                    // bases then '\n'
+    const int b_plus = b_seq + 1 + plen;                   // strand line then '\n'
+    const int b_qual = b_plus + 1 + len;                   // qualities then '\n'
+    o.seg_dst[3] = b_name + 1; o.seg_len[3] = len; o.seg_src[3] = seq0 + st;
+    o.seg_dst[4] = b_seq + 1; o.seg_len[4] = plen; o.seg_src[4] = t.text + t.plus_off[r];
+    o.seg_dst[5] = b_plus + 1; o.seg_len[5] = len; o.seg_src[5] = t.text + t.qual_off[r] + st;
+    o.nl[0] = b_name; o.nl[1] = b_seq; o.nl[2] = b_plus; o.nl[3] = b_qual;
+    o.total = b_qual + 1;
+}
+
+struct FormatOut {
+    uint8_t* p[6];        // [file * 3 + stream]
+};
+
+__device__ __forceinline__ uint4 and4(uint4 a, uint4 b) { return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w); }
+__device__ __forceinline__ uint4 andn4(uint4 a, uint4 b) { return make_uint4(a.x & ~b.x, a.y & ~b.y, a.z & ~b.z, a.w & ~b.w); }
+__device__ __forceinline__ uint4 sel4(uint4 m, uint4 a, uint4 b) {
+    return make_uint4((a.x & m.x) | (b.x & ~m.x), (a.y & m.y) | (b.y & ~m.y), (a.z & m.z) | (b.z & ~m.z), (a.w & m.w) | (b.w & ~m.w));
+}
+__device__ __forceinline__ void store16u(uint8_t* p, uint4 v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ uint4 load16u_t(const uint8_t* p) {
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+// the 16 output bytes [w, w + 16) of a record, assembled from every piece that touches the window
+__device__ __forceinline__ uint4 fmt_window(const FmtRec& o, int w, const uint4* first /* [17] */) {
+    uint4 out = make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int e = 0; e < 3; ++e)
-                if (i == e_pos[e] && (e_val[e] >> 8)) c = (uint8_t)(e_val[e] >> 8);
-        } else if (j < b_plus) {
-            c = plus[j - b_seq - 1];
-        } else {
-            const int i = j - b_plus - 1;
-            c = qual[i];
-#pragma unroll
-            for (int e = 0; e < 3; ++e)
-                if (i == e_pos[e]) c = (uint8_t)e_val[e];
+    for (int k = 0; k < FMT_NSEG; ++k) {
+        const int lo = max(o.seg_dst[k], w), hi = min(o.seg_dst[k] + o.seg_len[k], w + 16);
+        if (lo < hi) {
+            const uint4 m = andn4(first[hi - w], first[lo - w]);
+            out = sel4(m, load16u_t(o.seg_src[k] + (w - o.seg_dst[k])), out);
         }
-        dst[j] = c;
+    }
+    if (o.at && w == 0) out.x = (out.x & ~0xffu) | (uint32_t)'@';
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = o.nl[k] - w;
+        if (i >= 0 && i < 16) out = sel4(andn4(first[i + 1], first[i]), make_uint4(0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au), out);
+    }
+    return out;
+}
+
+// the walk's edits that fall into the window [w, w + 16)
+__device__ __forceinline__ uint4 fmt_edits(const FmtRec& o, int w, uint4 out, const uint4* first) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        if (o.e_pos[e] >= 0) {
+            const int ib = o.seg_dst[3] + o.e_pos[e] - w, iq = o.seg_dst[5] + o.e_pos[e] - w;
+            const uint32_t b4 = (o.e_val[e] >> 8) * 0x01010101u, q4 = (o.e_val[e] & 0xffu) * 0x01010101u;
+            if ((o.e_val[e] >> 8) && ib >= 0 && ib < 16 && o.e_pos[e] < o.seg_len[3]) out = sel4(andn4(first[ib + 1], first[ib]), make_uint4(b4, b4, b4, b4), out);
+            if (iq >= 0 && iq < 16 && o.e_pos[e] < o.seg_len[5]) out = sel4(andn4(first[iq + 1], first[iq]), make_uint4(q4, q4, q4, q4), out);
+        }
+    }
+    return out;
+}
+
+// Writer: one workgroup per tile of 256 records.  Sizing phase: thread = record, block scans give every record's offset in
+// its streams (tile bases from fmt_tile_bases_kernel).  Writing phase: 32 lanes per (record, file); a lane owns 16 output
+// bytes: windows that lie inside one piece are a 16-byte load + a 16-byte store (any alignment on both sides), the few
+// windows that straddle pieces are assembled by fmt_window; the record's last window is end-aligned, so no lane ever
+// writes a byte that is not its record's.
+__global__ __launch_bounds__(FMT_TILE) void fmt_write_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
+                                                             const unsigned long long* __restrict__ tile_base, FormatOut outs,
+                                                             int overlap_pass) {
+    __shared__ unsigned long long lds[4];
+    __shared__ unsigned int s_pos[2][FMT_TILE];
+    __shared__ unsigned long long s_base[2];
+    __shared__ uint4 first[17];
+    const int nfiles = v.paired ? 2 : 1;
+    const uint64_t r0 = (uint64_t)blockIdx.x * FMT_TILE;
+    if (threadIdx.x < 17) {
+        const int nb = threadIdx.x;
+        uint32_t m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int vb = min(max(nb - 4 * k, 0), 4);
+            m[k] = vb >= 4 ? 0xffffffffu : ((1u << (8 * vb)) - 1u);
+        }
+        first[nb] = make_uint4(m[0], m[1], m[2], m[3]);
+    }
+    // ---- sizing: this pass's stream of every record (good / bad differ per record, overlap is its own pass)
+    for (int file = 0; file < nfiles; ++file) {
+        uint32_t sz[3] = {0, 0, 0};
+        const uint64_t r = r0 + threadIdx.x;
+        if (r < n) fmt_sizes(v, r, file, sz);
+        if (!overlap_pass) {
+            // good and bad records interleave: two scans, each record keeps the offset of the stream it goes to
+            unsigned long long tg, tb;
+            const unsigned long long eg = block_excl_scan((unsigned long long)sz[0], lds, tg);
+            const unsigned long long eb = block_excl_scan((unsigned long long)sz[1], lds, tb);
+            const unsigned long long bg = tile_base[(uint64_t)(file * 3 + 0) * n_tiles + blockIdx.x];
+            const unsigned long long bb = tile_base[(uint64_t)(file * 3 + 1) * n_tiles + blockIdx.x];
+            // (offsets inside a chunk's stream fit 32 bits: chunks are < 2 GiB)
+            s_pos[file][threadIdx.x] = sz[1] ? (unsigned int)(bb + eb) : (unsigned int)(bg + eg);
+        } else {
+            unsigned long long to;
+            const unsigned long long eo = block_excl_scan((unsigned long long)sz[2], lds, to);
+            s_pos[file][threadIdx.x] = (unsigned int)(tile_base[(uint64_t)(file * 3 + 2) * n_tiles + blockIdx.x] + eo);
+        }
+    }
+    __syncthreads();
+    // ---- writing
+    const int lane32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    const int ntask = FMT_TILE * nfiles;
+    for (int task = hw; task < ntask; task += FMT_TILE / 32) {
+        const int rr = task / nfiles, file = task - rr * nfiles;
+        const uint64_t r = r0 + rr;
+        if (r >= n) break;
+        FmtRec o;
+        fmt_record(v, r, file, overlap_pass, lane32, o);
+        if (o.stream < 0) continue;
+        uint8_t* dst = outs.p[file * 3 + o.stream] + s_pos[file][rr];
+        if (o.total < 16) {
+            // (a record of fewer than 16 bytes: byte by byte)
+            const uint4 wv = fmt_edits(o, 0, fmt_window(o, 0, first), first);
+            const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
+            if (lane32 < o.total) dst[lane32] = (uint8_t)(ww[lane32 >> 2] >> (8 * (lane32 & 3)));
+            continue;
+        }
+        const int ngroups = (o.total + 15) >> 4;
+        for (int g0 = 0; g0 < ngroups; g0 += 32) {
+            const int g = g0 + lane32;
+            if (g < ngroups) {
+                const int w = min(16 * g, o.total - 16);           // the last window is aligned to the record's end
+                // inside one piece?
+                int k_in = -1;
+#pragma unroll
+                for (int k = 0; k < FMT_NSEG; ++k)
+                    if (o.seg_dst[k] <= w && w + 16 <= o.seg_dst[k] + o.seg_len[k]) k_in = k;
+                uint4 out;
+                if (k_in >= 0) {
+                    const uint8_t* src = k_in == 5 ? o.seg_src[5] : k_in == 3 ? o.seg_src[3] : k_in == 2 ? o.seg_src[2] : k_in == 4 ? o.seg_src[4] : k_in == 1 ? o.seg_src[1] : o.seg_src[0];
+                    const int d0 = k_in == 5 ? o.seg_dst[5] : k_in == 3 ? o.seg_dst[3] : k_in == 2 ? o.seg_dst[2] : k_in == 4 ? o.seg_dst[4] : k_in == 1 ? o.seg_dst[1] : o.seg_dst[0];
+                    out = load16u_t(src + (w - d0));
+                } else {
+                    out = fmt_window(o, w, first);
+                }
+                if (o.n_edits) out = fmt_edits(o, w, out, first);
+                store16u(dst + w, out);
+            }
+        }
     }
 }
 
