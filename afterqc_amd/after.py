@@ -123,11 +123,22 @@ def collect_dir_jobs(folder, options):
     return jobs
 
 
-def processOptions(options, engine=None, device=0):
-    """after.processOptions (after.py:173-175)"""
+def processOptions(options, engine=None, device=0, devices=None):
+    """after.processOptions (after.py:173-175).  `devices`: the GPUs ONE input is dealt over (chunks round robin, host-side
+    merge of the statistics); a single file pair given with -1 / -2 uses every visible GPU."""
     from . import preprocesser
-    flt = preprocesser.seqFilter(options, engine=engine, device=device)
+    flt = preprocesser.seqFilter(options, engine=engine, device=device, devices=devices)
     return flt.run()
+
+
+def visible_devices():
+    """GPUs this run may use: AQC_DEVICES=0,2,3 narrows the list (default: all that aqc_device_count() reports)"""
+    from . import capi
+    n = max(1, capi.load_library().aqc_device_count())
+    env = os.environ.get("AQC_DEVICES")
+    if env:
+        return [int(x) for x in env.split(",") if x.strip() != ""]
+    return list(range(n))
 
 
 def processDir(folder, options, engine_factory=None, n_workers=None):
@@ -188,7 +199,7 @@ def main(argv=None):
             options.trim_front2 = 0
         else:
             options.barcode = False
-        processOptions(options)
+        processOptions(options, devices=visible_devices())
     print('Time used: ' + str(time.time() - t0))
 
 

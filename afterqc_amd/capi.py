@@ -93,6 +93,24 @@ class FrameInfo(C.Structure):
                 ("next_len1", C.c_uint32)]
 
 
+class PipeIO(C.Structure):
+    """struct aqc_pipe_io"""
+    _fields_ = [("in_path", C.c_char_p * 2), ("in_mem", C.c_void_p * 2), ("in_mem_bytes", C.c_uint64 * 2),
+                ("gzip_in", C.c_int32 * 2), ("out_path", (C.c_char_p * 3) * 2), ("gzip_out", C.c_int32), ("gzip_level", C.c_int32)]
+
+
+class PipeOpts(C.Structure):
+    """struct aqc_pipe_opts"""
+    _fields_ = [("chunk_records", C.c_uint64), ("qc_sample", C.c_int64), ("store_overlap", C.c_int32), ("no_output", C.c_int32),
+                ("chunk_index0", C.c_uint64), ("chunk_index_stride", C.c_uint64)]
+
+
+class PipeResult(C.Structure):
+    """struct aqc_pipe_result"""
+    _fields_ = [("records", C.c_uint64), ("chunks", C.c_uint64), ("bytes_out", C.c_uint64 * 6), ("anomaly", C.c_int32),
+                ("pad_", C.c_int32), ("seconds", C.c_double)]
+
+
 class HostBuffer:
     """Page-locked host memory from aqc_host_alloc, exposed as a writable numpy uint8 array / memoryview."""
 
@@ -309,6 +327,13 @@ def load_library():
     lib.aqc_format.argtypes = [P, C.c_int, C.c_uint64, C.c_int32, P]
     lib.aqc_format_plain.argtypes = [P, C.c_int, C.c_int, C.c_uint64, C.c_int32, P]
     lib.aqc_fetch_text.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.c_uint64]
+    lib.aqc_pipe_create.argtypes = [C.POINTER(P), C.c_int32, C.c_int32, C.c_int32, C.POINTER(P)]
+    lib.aqc_pipe_create.restype = C.c_int
+    lib.aqc_pipe_destroy.argtypes = [P]
+    lib.aqc_pipe_destroy.restype = None
+    lib.aqc_pipe_run.argtypes = [P, C.POINTER(PipeIO), C.POINTER(PipeOpts), C.POINTER(PipeResult)]
+    lib.aqc_pipe_run.restype = C.c_int
+    lib.aqc_pipe_last_error.restype = C.c_char_p
     lib.aqc_host_alloc.argtypes = [C.c_uint64]
     lib.aqc_host_alloc.restype = C.c_void_p
     lib.aqc_host_free.argtypes = [P]
@@ -332,6 +357,7 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_last_error", "aq
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
                     "aqc_edit_distance", "aqc_frame", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_host_alloc",
                     "aqc_host_free",
+                    "aqc_pipe_create", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
                     # the reference's own native seam (editdistance/_editdistance.h:16,23), same names and signatures
                     "edit_distance", "seek_overlap"]
 
@@ -504,3 +530,99 @@ class Engine:
         s = batch.as_struct()
         self._check(self.lib.aqc_edit_distance(self.h, C.byref(s), _ptr(d)))
         return d
+
+
+class Pipe:
+    """struct aqc_pipe: the whole-input pipeline (C++ reader / slot-worker / writer threads) over one or more engines —
+    one engine per GPU; chunk i of the input goes to engine i % len(engines)."""
+
+    def __init__(self, engines, slots=3, io_threads=0):
+        self.lib = load_library()
+        self.engines = list(engines)
+        arr = (C.c_void_p * len(self.engines))(*[e.h for e in self.engines])
+        h = C.c_void_p()
+        rc = self.lib.aqc_pipe_create(arr, len(self.engines), slots, io_threads, C.byref(h))
+        if rc != 0:
+            raise AqcError(rc, "aqc_pipe_create failed")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.aqc_pipe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, inputs, outputs=None, gzip_in=(False, False), gzip_out=False, gzip_level=2, chunk_records=0, qc_sample=200000,
+            store_overlap=False, no_output=False, chunk_index0=0, chunk_index_stride=1):
+        """inputs: list of 1-2 file names, or of (numpy uint8 array / HostBuffer.array, nbytes) tuples (text in memory);
+        outputs: per input (good, bad, overlap) file names or None.  Returns a PipeResult."""
+        io = PipeIO()
+        keep = []
+        for k, src in enumerate(inputs):
+            if src is None:
+                continue
+            if isinstance(src, (str, bytes)):
+                b = src.encode() if isinstance(src, str) else src
+                keep.append(b)
+                io.in_path[k] = b
+                io.gzip_in[k] = 1 if gzip_in[k] else 0
+            else:
+                arr, nbytes = src
+                keep.append(arr)
+                io.in_mem[k] = arr.ctypes.data
+                io.in_mem_bytes[k] = int(nbytes)
+        if outputs is not None:
+            for k, trio in enumerate(outputs):
+                for st, name in enumerate(trio or ()):
+                    if name is not None:
+                        b = name.encode() if isinstance(name, str) else name
+                        keep.append(b)
+                        io.out_path[k][st] = b
+        io.gzip_out = 1 if gzip_out else 0
+        io.gzip_level = int(gzip_level)
+        opts = PipeOpts(int(chunk_records), int(qc_sample), 1 if store_overlap else 0, 1 if no_output else 0, int(chunk_index0),
+                        int(chunk_index_stride))
+        res = PipeResult()
+        rc = self.lib.aqc_pipe_run(self.h, C.byref(io), C.byref(opts), C.byref(res))
+        if rc != 0:
+            raise AqcError(rc, (self.lib.aqc_pipe_last_error() or b"").decode("utf-8", "replace"))
+        for e in self.engines:
+            e.slot_n = [0] * e.n_slots
+        return res
+
+
+class MergedEngines:
+    """Statistics of several engines seen as one (per-GPU integers are summed on the host; k-mer dictionaries
+    merge by count sum and smallest first-seen key).  Read-only: counters / histograms / qc / kmers."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+
+    def counters(self):
+        return sum(e.counters() for e in self.engines)
+
+    def histograms(self, n=AQC_QC_COLS):
+        hs = [e.histograms(n) for e in self.engines]
+        return sum(h[0] for h in hs), sum(h[1] for h in hs)
+
+    def qc(self, which):
+        return sum(e.qc(which) for e in self.engines)
+
+    def kmers(self, which, cap=1 << 22):
+        parts = [e.kmers(which, cap) for e in self.engines]
+        if len(parts) == 1:
+            return parts[0]
+        keys = np.concatenate([p[0] for p in parts])
+        counts = np.concatenate([p[1] for p in parts])
+        order = np.concatenate([p[2] for p in parts])
+        uk, inv = np.unique(keys, return_inverse=True)
+        c = np.zeros(len(uk), dtype=np.int64)
+        np.add.at(c, inv, counts)
+        o = np.full(len(uk), np.iinfo(np.uint64).max, dtype=np.uint64)
+        np.minimum.at(o, inv, order)
+        return uk, c, o

@@ -61,6 +61,8 @@ struct DevBuf {
 
 struct Slot {
     hipStream_t stream = nullptr;
+    int* status = nullptr;           // first device-side error raised by this slot's kernels (one word per slot: the slots
+                                     // of a context may be driven from different host threads)
     DevBuf seq1, qual1, off1, qoff1, len1, seq2, qual2, off2, qoff2, len2, aux[5], results;
     DevBuf deferred, n_deferred;     // records the lane-per-read kernel hands to the general kernel
     DevBuf off_stage;                // the caller's 64-bit offsets on their way to the 32-bit device form
@@ -125,18 +127,18 @@ struct aqc_ctx {
     DevBuf kmer_partial;          // per-round u16 count slices of kmer_count_kernel
     DevCircles circles{};
     unsigned long long *counters = nullptr, *ovl_hist = nullptr, *dist_hist = nullptr;
-    int* status = nullptr;
     QcDev qc[4];
     int n_cu = 256;
     char name[256] = "";
 };
 
-static int check_status(aqc_ctx* c) {
+static int check_status(Slot& sl) {
     int st = 0;
-    HIP_TRY(hipMemcpy(&st, c->status, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(&st, sl.status, sizeof(int), hipMemcpyDeviceToHost, sl.stream));
+    HIP_TRY(hipStreamSynchronize(sl.stream));
     if (st != 0) {
-        int zero = 0;
-        (void)hipMemcpy(c->status, &zero, sizeof(int), hipMemcpyHostToDevice);
+        (void)hipMemsetAsync(sl.status, 0, sizeof(int), sl.stream);
+        (void)hipStreamSynchronize(sl.stream);
         const char* what = st == AQC_ERR_ALPHABET ? "a base outside the reference's COMP table reached the correction walk (KeyError upstream)"
                          : st == AQC_ERR_READ_TOO_LONG ? "a read is longer than AQC_MAX_READ_LEN"
                          : st == AQC_ERR_ARG ? "a read shorter than 5 bases reached statRead (IndexError upstream)"
@@ -203,7 +205,10 @@ int aqc_create(int device, int n_slots, aqc_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->counters, sizeof(unsigned long long) * (AQC_N_COUNTERS + 16)));   // +16: AQC_PROFILE builds
     HIP_TRY(hipMalloc((void**)&c->ovl_hist, sizeof(unsigned long long) * AQC_QC_COLS));
     HIP_TRY(hipMalloc((void**)&c->dist_hist, sizeof(unsigned long long) * AQC_QC_COLS));
-    HIP_TRY(hipMalloc((void**)&c->status, sizeof(int)));
+    for (auto& s : c->slots) {
+        HIP_TRY(hipMalloc((void**)&s.status, sizeof(int)));
+        HIP_TRY(hipMemset(s.status, 0, sizeof(int)));
+    }
     for (int k = 0; k < 4; k++)
         HIP_TRY(hipMalloc((void**)&c->qc[k].acc, sizeof(unsigned long long) * AQC_QC_ROWS * AQC_QC_COLS));
     *out = c;
@@ -228,11 +233,12 @@ void aqc_destroy(aqc_ctx* c) {
                 if (s.ev[k][j]) (void)hipEventDestroy(s.ev[k][j]);
                 for (hipEvent_t e : s.ring[k][j]) (void)hipEventDestroy(e);
             }
+        if (s.status) (void)hipFree(s.status);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     for (auto& b : c->circ) b.release();
     c->kmer_partial.release();
-    (void)hipFree(c->counters); (void)hipFree(c->ovl_hist); (void)hipFree(c->dist_hist); (void)hipFree(c->status);
+    (void)hipFree(c->counters); (void)hipFree(c->ovl_hist); (void)hipFree(c->dist_hist);
     for (int k = 0; k < 4; k++) {
         (void)hipFree(c->qc[k].acc);
         if (c->qc[k].kt.keys) {
@@ -293,7 +299,7 @@ int aqc_reset_stats(aqc_ctx* c) {
     HIP_TRY(hipMemset(c->counters, 0, sizeof(unsigned long long) * (AQC_N_COUNTERS + 16)));
     HIP_TRY(hipMemset(c->ovl_hist, 0, sizeof(unsigned long long) * AQC_QC_COLS));
     HIP_TRY(hipMemset(c->dist_hist, 0, sizeof(unsigned long long) * AQC_QC_COLS));
-    HIP_TRY(hipMemset(c->status, 0, sizeof(int)));
+    for (auto& sl : c->slots) HIP_TRY(hipMemset(sl.status, 0, sizeof(int)));
     for (int k = 0; k < 4; k++) {
         HIP_TRY(hipMemset(c->qc[k].acc, 0, sizeof(unsigned long long) * AQC_QC_ROWS * AQC_QC_COLS));
         c->qc[k].last_end = 0;
@@ -447,7 +453,7 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
     if (s->n == 0) { s->ran = true; return 0; }
     aqc_config cfg = c->cfg;
     if (!cfg.paired) cfg.no_overlap = 1;
-    DevStats st{c->counters, c->ovl_hist, c->dist_hist, c->status};
+    DevStats st{c->counters, c->ovl_hist, c->dist_hist, s->status};
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_FILTER_OVERLAP, 0), s->stream));
     // lane-per-pair kernel whenever its preconditions hold; the general wave-per-record kernel otherwise
     const int thr = cfg.qualified_quality_phred + 33;
@@ -549,7 +555,7 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
     const bool fused = cols <= KMER_FUSED_MAX_COLS && rounds_per_block * rpr_max <= (uint64_t)QC_MAX_READS_PER_BLOCK;
     if (!fused)
         hipLaunchKernelGGL(qc_stat_kernel, dim3((unsigned)blocks), dim3(QC_BLOCK), lds, s->stream, s->view, mate, first, count, post,
-                           (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, c->status, cols);
+                           (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, s->status, cols);
     // k-mer dictionary: LDS-resident u16 counters, rounds of <= 65535 k-mers per workgroup, slices reduced afterwards
     {
         uint64_t done = 0;
@@ -568,7 +574,7 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
             unsigned kb = n_rounds < (unsigned)c->n_cu ? n_rounds : (unsigned)c->n_cu;
             hipLaunchKernelGGL(kmer_count_kernel, dim3(kb), dim3(KMER_BLOCK), fused ? KMER_FUSED_LDS_BYTES : KMER_LDS_BYTES, s->stream, s->view,
                                mate, first + done, chunk, post, (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.kt, order_base + done,
-                               (uint16_t*)c->kmer_partial.p, rpr, n_rounds, c->status, fused ? q.acc : (unsigned long long*)nullptr,
+                               (uint16_t*)c->kmer_partial.p, rpr, n_rounds, s->status, fused ? q.acc : (unsigned long long*)nullptr,
                                fused ? cols : 0);
             hipLaunchKernelGGL(kmer_reduce_kernel, dim3(DENSE_ENTRIES / KRED_ENTRIES), dim3(KRED_BLOCK), 0, s->stream,
                                (const uint16_t*)c->kmer_partial.p, n_rounds, q.kt, c->cfg.qc_kmer);
@@ -831,7 +837,7 @@ int aqc_fetch_text(aqc_ctx* c, int slot, int file, int stream, uint8_t* dst, uin
         HIP_TRY(hipMemcpyAsync(dst, s->f_out[q].p, s->f_bytes[q], hipMemcpyDeviceToHost, s->stream));
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return check_status(c);
+    return check_status(*s);
 }
 
 void* aqc_host_alloc(uint64_t bytes) {
@@ -849,7 +855,7 @@ int aqc_sync(aqc_ctx* c, int slot) {
     int rc = get_slot(c, slot, &s);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return check_status(c);
+    return check_status(*s);
 }
 
 int aqc_fetch_results(aqc_ctx* c, int slot, aqc_result* out, uint64_t n) {
@@ -860,7 +866,7 @@ int aqc_fetch_results(aqc_ctx* c, int slot, aqc_result* out, uint64_t n) {
     if (n > s->n) return fail(AQC_ERR_ARG, "aqc_fetch_results: n exceeds the slot's records");
     if (n) HIP_TRY(hipMemcpyAsync(out, s->results.p, sizeof(aqc_result) * n, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return check_status(c);
+    return check_status(*s);
 }
 
 int aqc_last_deferred(aqc_ctx* c, int slot, uint32_t* idx, uint64_t cap, uint64_t* n) {
@@ -924,8 +930,12 @@ int aqc_timing_mean(aqc_ctx* c, int slot, float* mean_ms, int32_t* launches) {
 
 static int sync_all(aqc_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
-    for (auto& s : c->slots) HIP_TRY(hipStreamSynchronize(s.stream));
-    return check_status(c);
+    for (auto& s : c->slots) {
+        HIP_TRY(hipStreamSynchronize(s.stream));
+        int rc = check_status(s);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int aqc_get_counters(aqc_ctx* c, int64_t* out) {
@@ -1097,12 +1107,12 @@ int aqc_edit_distance(aqc_ctx* c, const aqc_batch* b, int32_t* dist) {
     DevBuf o;
     if (o.reserve(4 * n)) return fail(AQC_ERR_HIP, "hipMalloc failed");
     hipLaunchKernelGGL(edit_distance_seam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->view,
-                       (int32_t*)o.p, c->status);
+                       (int32_t*)o.p, s->status);
     HIP_TRY(hipGetLastError());
     if ((rc = seam_out(s, o, dist, n))) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     o.release();
-    return check_status(c);
+    return check_status(*s);
 }
 
 // ---- the reference's existing native seam: libed.so (editdistance/_editdistance.h:16,23, loaded by util.py:16-24) ----

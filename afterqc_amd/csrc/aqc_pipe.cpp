@@ -1,0 +1,976 @@
+// aqc_pipe.cpp — whole-input pipeline above the per-chunk C ABI (include/afterqc_hip.h): the byte path of
+// seqFilter.run's main loop (preprocesser.py:411-631 with fastq.Reader / fastq.Writer around it) without Python in it.
+//
+//   reader threads (one per input)   file / gzip stream / memory -> page-locked chunk buffers holding EXACTLY
+//                                    `chunk_records` records each (the chunk boundary is the 4K-th newline, found with
+//                                    per-block newline counts made by the I/O pool right behind the reads)
+//   slot workers (per GPU x slots)   chunk pair i -> context i % n_ctx: aqc_frame -> aqc_run -> aqc_qc_stat (first
+//                                    qc_sample records only, in chunk order) -> aqc_format -> aqc_fetch_text into
+//                                    page-locked output buffers; a worker blocks only on ITS slot's stream, so the
+//                                    upload of one chunk, the kernels of another and the download of a third overlap
+//   writer thread                    commits the chunks' good / bad / overlap streams in chunk order: plain files with
+//                                    parallel pwrite, .gz as BGZF-compatible independent members deflated on the pool
+//
+// Records are independent and every statistic is additive (or min-merged by global record index), so one input is
+// dealt over any number of GPUs with no collective: chunk i carries first_index = i * chunk_records.
+//
+// The pipeline handles the REGULAR shape of an input — 4-line records, both mates with the same number of records, no
+// empty line inside.  Anything else (fastq.py:44-47's "empty line ends the file", mates of different lengths, ...)
+// is detected from the frame info and reported as `anomaly`; the caller then reruns the input through the serial
+// chunk loop, which reproduces the reference's reader semantics case by case.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+#include "../../include/afterqc_hip.h"
+
+namespace {
+
+char g_pipe_err[512] = "";
+std::mutex g_pipe_err_mu;
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// small thread pool for I/O-side work (pread pieces, newline counts, deflate / inflate of independent blocks)
+// ---------------------------------------------------------------------------------------------------------------
+class Pool {
+public:
+    explicit Pool(int n) {
+        for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    // run fn(i) for i in [0, n) on the pool and wait for all of them
+    void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
+        if (n == 0) return;
+        if (n == 1 || th_.empty()) {
+            for (size_t i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        struct Batch {
+            std::atomic<size_t> next{0}, done{0};
+            size_t n;
+            const std::function<void(size_t)>* fn;
+            std::mutex mu;
+            std::condition_variable cv;
+        };
+        auto b = std::make_shared<Batch>();
+        b->n = n;
+        b->fn = &fn;
+        const size_t helpers = std::min(n, th_.size());
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (size_t k = 0; k < helpers; ++k)
+                q_.push_back([b] {
+                    for (;;) {
+                        const size_t i = b->next.fetch_add(1);
+                        if (i >= b->n) break;
+                        (*b->fn)(i);
+                        if (b->done.fetch_add(1) + 1 == b->n) {
+                            std::lock_guard<std::mutex> g2(b->mu);
+                            b->cv.notify_all();
+                        }
+                    }
+                });
+        }
+        cv_.notify_all();
+        // the caller works too
+        for (;;) {
+            const size_t i = b->next.fetch_add(1);
+            if (i >= n) break;
+            fn(i);
+            b->done.fetch_add(1);
+        }
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->cv.wait(lk, [&] { return b->done.load() >= n; });
+    }
+
+private:
+    void loop() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (stop_ && q_.empty()) return;
+                job = std::move(q_.front());
+                q_.pop_front();
+            }
+            job();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::deque<std::function<void()>> q_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
+
+template <class T>
+class BQueue {
+public:
+    explicit BQueue(size_t cap = 0) : cap_(cap) {}
+    bool push(T v) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_space_.wait(lk, [&] { return closed_ || cap_ == 0 || q_.size() < cap_; });
+        if (closed_) return false;
+        q_.push_back(std::move(v));
+        cv_item_.notify_one();
+        return true;
+    }
+    bool pop(T& out) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_item_.wait(lk, [&] { return closed_ || !q_.empty(); });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        cv_space_.notify_one();
+        return true;
+    }
+    void close() {
+        std::lock_guard<std::mutex> g(mu_);
+        closed_ = true;
+        cv_item_.notify_all();
+        cv_space_.notify_all();
+    }
+
+private:
+    size_t cap_;
+    std::deque<T> q_;
+    std::mutex mu_;
+    std::condition_variable cv_item_, cv_space_;
+    bool closed_ = false;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// newline counting (the chunk boundary is "the 4K-th newline"): 8 bytes per step, portable; an AVX2 twin where the CPU has it
+// ---------------------------------------------------------------------------------------------------------------
+uint64_t count_nl_generic(const uint8_t* p, size_t n) {
+    uint64_t c = 0;
+    size_t i = 0;
+    for (; i < n && ((uintptr_t)(p + i) & 7); ++i) c += p[i] == '\n';
+    const uint64_t k = 0x0a0a0a0a0a0a0a0aull, lo7 = 0x7f7f7f7f7f7f7f7full;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x;
+        memcpy(&x, p + i, 8);
+        x ^= k;
+        const uint64_t z = ~(((x & lo7) + lo7) | x | lo7);      // 0x80 in every zero byte
+        c += (uint64_t)__builtin_popcountll(z);
+    }
+    for (; i < n; ++i) c += p[i] == '\n';
+    return c;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) uint64_t count_nl_avx2(const uint8_t* p, size_t n) {
+    uint64_t c = 0;
+    size_t i = 0;
+    const __m256i nl = _mm256_set1_epi8('\n');
+    for (; i + 128 <= n; i += 128) {
+        const unsigned m0 = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i)), nl));
+        const unsigned m1 = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i + 32)), nl));
+        const unsigned m2 = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i + 64)), nl));
+        const unsigned m3 = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(p + i + 96)), nl));
+        c += (uint64_t)__builtin_popcountll(((uint64_t)m1 << 32) | m0) + (uint64_t)__builtin_popcountll(((uint64_t)m3 << 32) | m2);
+    }
+    return c + count_nl_generic(p + i, n - i);
+}
+#endif
+
+uint64_t count_nl(const uint8_t* p, size_t n) {
+#if defined(__x86_64__)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx2) return count_nl_avx2(p, n);
+#endif
+    return count_nl_generic(p, n);
+}
+
+constexpr size_t SUB = 256 << 10;        // newline counts are kept per 256 KiB block
+
+// position just behind the `want`-th newline of p[0, n) (want >= 1) given the per-block counts; n if there are fewer
+size_t locate_nl(const uint8_t* p, size_t n, const std::vector<uint32_t>& cnt, uint64_t want) {
+    uint64_t seen = 0;
+    for (size_t b = 0; b < cnt.size(); ++b) {
+        if (seen + cnt[b] >= want) {
+            size_t i = b * SUB;
+            const size_t end = std::min(n, i + SUB);
+            while (i < end) {
+                const uint8_t* q = (const uint8_t*)memchr(p + i, '\n', end - i);
+                if (!q) break;
+                i = (size_t)(q - p) + 1;
+                if (++seen == want) return i;
+            }
+            return n;      // (counts and bytes disagree: cannot happen)
+        }
+        seen += cnt[b];
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// byte sources: a plain file (parallel pread), a gzip stream (zlib; BGZF / multi-member inputs are inflated
+// member-parallel), or host memory
+// ---------------------------------------------------------------------------------------------------------------
+struct Source {
+    virtual ~Source() {}
+    // fill dst[0, want) with the next bytes of the stream; returns the bytes delivered (< want only at the end)
+    virtual size_t read(uint8_t* dst, size_t want) = 0;
+    virtual bool failed() const { return false; }
+};
+
+struct FileSource : Source {
+    int fd = -1;
+    uint64_t pos = 0, size = 0;
+    Pool* pool;
+    FileSource(const char* path, Pool* p) : pool(p) {
+        fd = open(path, O_RDONLY);
+        if (fd >= 0) {
+            struct stat st;
+            if (fstat(fd, &st) == 0) size = (uint64_t)st.st_size;
+            (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+        }
+    }
+    ~FileSource() override { if (fd >= 0) close(fd); }
+    bool failed() const override { return fd < 0; }
+    size_t read(uint8_t* dst, size_t want) override {
+        const uint64_t left = size > pos ? size - pos : 0;
+        const size_t take = (size_t)std::min<uint64_t>(want, left);
+        const size_t piece = 4 << 20;
+        const size_t n = (take + piece - 1) / piece;
+        std::atomic<bool> bad{false};
+        pool->parallel_for(n, [&](size_t i) {
+            size_t off = i * piece;
+            const size_t end = std::min(take, off + piece);
+            while (off < end) {
+                const ssize_t got = pread(fd, dst + off, end - off, (off_t)(pos + off));
+                if (got <= 0) { bad = true; return; }
+                off += (size_t)got;
+            }
+        });
+        if (bad) return 0;
+        pos += take;
+        return take;
+    }
+};
+
+struct GzSource : Source {
+    // a gzip stream.  Members that carry the BGZF extra field ("BC": the member's compressed size) are located by walking
+    // the headers and inflated in parallel on the pool; anything else goes through one sequential inflate stream.
+    int fd = -1;
+    Pool* pool;
+    std::vector<uint8_t> in;        // compressed window
+    size_t in_lo = 0, in_hi = 0;
+    bool file_eof = false, stream_end = true, bgzf = false, bad = false;
+    z_stream zs{};
+    bool zs_init = false;
+    std::vector<uint8_t> spill;     // inflated bytes that did not fit the caller's buffer (BGZF path)
+    size_t spill_lo = 0;
+    GzSource(const char* path, Pool* p) : pool(p) {
+        fd = open(path, O_RDONLY);
+        in.resize(32 << 20);
+        if (fd >= 0) {
+            refill();
+            bgzf = is_bgzf_header(in.data() + in_lo, in_hi - in_lo);
+        }
+    }
+    ~GzSource() override {
+        if (zs_init) inflateEnd(&zs);
+        if (fd >= 0) close(fd);
+    }
+    bool failed() const override { return fd < 0 || bad; }
+    static bool is_bgzf_header(const uint8_t* h, size_t n) {
+        return n >= 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C' &&
+               h[14] == 2 && h[15] == 0;
+    }
+    void refill() {
+        if (in_lo > 0 && in_lo < in_hi) memmove(in.data(), in.data() + in_lo, in_hi - in_lo);
+        in_hi -= in_lo;
+        in_lo = 0;
+        while (!file_eof && in_hi < in.size()) {
+            const ssize_t got = ::read(fd, in.data() + in_hi, in.size() - in_hi);
+            if (got <= 0) { file_eof = true; break; }
+            in_hi += (size_t)got;
+        }
+    }
+    size_t read(uint8_t* dst, size_t want) override { return bgzf ? read_bgzf(dst, want) : read_stream(dst, want); }
+
+    size_t read_stream(uint8_t* dst, size_t want) {
+        size_t out = 0;
+        while (out < want && !bad) {
+            if (in_lo == in_hi) {
+                refill();
+                if (in_lo == in_hi) break;          // end of the file
+            }
+            if (stream_end) {
+                // next member (concatenated members are one gzip file)
+                if (zs_init) inflateEnd(&zs);
+                memset(&zs, 0, sizeof(zs));
+                if (inflateInit2(&zs, 15 + 16) != Z_OK) { bad = true; break; }
+                zs_init = true;
+                stream_end = false;
+            }
+            zs.next_in = in.data() + in_lo;
+            zs.avail_in = (uInt)std::min<size_t>(in_hi - in_lo, 1u << 30);
+            zs.next_out = dst + out;
+            zs.avail_out = (uInt)std::min<size_t>(want - out, 1u << 30);
+            const uInt ai = zs.avail_in, ao = zs.avail_out;
+            const int rc = inflate(&zs, Z_NO_FLUSH);
+            in_lo += ai - zs.avail_in;
+            out += ao - zs.avail_out;
+            if (rc == Z_STREAM_END) stream_end = true;
+            else if (rc != Z_OK && rc != Z_BUF_ERROR) { bad = true; break; }
+            else if (rc == Z_BUF_ERROR && ai == zs.avail_in && ao == zs.avail_out) {
+                if (file_eof && in_lo == in_hi) break;
+                refill();
+                if (in_lo == in_hi) break;
+            }
+        }
+        return out;
+    }
+
+    size_t read_bgzf(uint8_t* dst, size_t want) {
+        size_t out = 0;
+        // left-overs of the previous call first
+        if (spill_lo < spill.size()) {
+            const size_t k = std::min(want, spill.size() - spill_lo);
+            memcpy(dst, spill.data() + spill_lo, k);
+            spill_lo += k;
+            out = k;
+            if (spill_lo == spill.size()) { spill.clear(); spill_lo = 0; }
+        }
+        struct Blk { size_t coff, clen, isize, ooff; };
+        while (out < want && !bad) {
+            if (in_hi - in_lo < (64u << 10) + 32 && !file_eof) refill();
+            if (in_lo == in_hi) break;
+            // walk the members that are completely inside the window
+            std::vector<Blk> blks;
+            size_t p = in_lo, total = 0;
+            while (p + 18 <= in_hi) {
+                const uint8_t* h = in.data() + p;
+                if (!is_bgzf_header(h, in_hi - p)) { bad = true; break; }
+                const size_t bsize = (size_t)(h[16] | (h[17] << 8)) + 1;
+                if (p + bsize > in_hi) break;
+                const uint8_t* t = h + bsize - 4;
+                const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+                blks.push_back(Blk{p + 18, bsize - 18 - 8, isize, total});
+                total += isize;
+                p += bsize;
+                if (total >= (want - out) + (1u << 20)) break;
+            }
+            if (bad) break;
+            if (blks.empty()) {
+                if (file_eof) { if (in_hi - in_lo > 0) bad = true; break; }
+                refill();
+                if (in_hi - in_lo < 18) break;
+                continue;
+            }
+            // inflate in parallel: straight into dst where the block fits, into the spill buffer otherwise
+            const size_t room = want - out;
+            size_t fit_total = 0;
+            for (auto& b : blks) if (b.ooff + b.isize <= room) fit_total = b.ooff + b.isize;
+            spill.assign(total - fit_total, 0);
+            spill_lo = 0;
+            std::atomic<bool> err{false};
+            pool->parallel_for(blks.size(), [&](size_t i) {
+                const Blk& b = blks[i];
+                uint8_t* o = b.ooff + b.isize <= room ? dst + out + b.ooff : spill.data() + (b.ooff - fit_total);
+                z_stream z{};
+                if (inflateInit2(&z, -15) != Z_OK) { err = true; return; }
+                z.next_in = in.data() + b.coff;
+                z.avail_in = (uInt)b.clen;
+                z.next_out = o;
+                z.avail_out = (uInt)b.isize;
+                const int rc = b.isize ? inflate(&z, Z_FINISH) : Z_STREAM_END;
+                if (rc != Z_STREAM_END || z.avail_out != 0) err = true;
+                inflateEnd(&z);
+            });
+            if (err) { bad = true; break; }
+            in_lo = p;
+            out += fit_total;
+            if (!spill.empty()) {
+                // the caller's buffer is filled to the last byte from the spill buffer; the rest waits for the next call
+                const size_t k = std::min(want - out, spill.size());
+                memcpy(dst + out, spill.data(), k);
+                spill_lo = k;
+                out += k;
+                if (spill_lo == spill.size()) { spill.clear(); spill_lo = 0; }
+                if (out == want) break;
+            }
+        }
+        return out;
+    }
+};
+
+struct HostBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        if (p) aqc_host_free(p);
+        cap = n + n / 8 + (1 << 20);
+        p = (uint8_t*)aqc_host_alloc(cap);
+        if (!p) cap = 0;
+    }
+    void release() {
+        if (p) aqc_host_free(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct InChunk {
+    uint64_t idx = 0;
+    const uint8_t* data = nullptr;
+    uint64_t bytes = 0, lines = 0;
+    bool final = false;
+    int buf = -1;        // index into the file's buffer ring (-1: zero-copy view of a memory source)
+};
+
+struct OutChunk {
+    uint64_t idx = 0;
+    int set = -1;                // output buffer set (owned by a slot worker)
+    int worker = -1;
+    uint64_t sizes[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t n = 0;
+    bool last = false;
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+struct aqc_pipe {
+    int n_ctx = 0;
+    std::vector<aqc_ctx*> ctx;
+    int slots = 2;
+    int io_threads = 8;
+    std::unique_ptr<Pool> pool;
+    // per input file: ring of page-locked chunk buffers
+    std::vector<HostBuf> in_buf[2];
+    // per worker (ctx, slot): two sets of six output buffers
+    struct WorkerBufs { HostBuf out[2][6]; };
+    std::vector<WorkerBufs> wbufs;
+};
+
+namespace {
+
+struct Run {
+    aqc_pipe* P;
+    const aqc_pipe_io* io;
+    const aqc_pipe_opts* opt;
+    aqc_pipe_result* res;
+    int nf = 1;
+    uint64_t K = 0;
+    std::atomic<bool> abort{false}, anomaly{false};
+    std::mutex err_mu;
+    std::string err;
+    int err_code = 0;
+
+    // reader -> dispatcher
+    std::unique_ptr<BQueue<InChunk>> inq[2];
+    // input buffer rings
+    std::mutex ring_mu[2];
+    std::condition_variable ring_cv[2];
+    std::vector<char> ring_free[2];
+    // dispatcher -> workers (one queue per context)
+    struct Job { InChunk c[2]; uint64_t idx; bool last; };
+    std::vector<std::unique_ptr<BQueue<Job>>> jobq;
+    // workers -> writer
+    BQueue<OutChunk> outq{0};
+    // output set ownership
+    std::mutex set_mu;
+    std::condition_variable set_cv;
+    std::vector<char> set_free;        // [worker * 2 + set]
+    // QC turn taking (post-filter sampling must be issued in chunk order, see aqc_qc_stat's time keys)
+    std::mutex qc_mu;
+    std::condition_variable qc_cv;
+    uint64_t qc_next = 0;
+    // outputs
+    int out_fd[6] = {-1, -1, -1, -1, -1, -1};
+    uint64_t out_pos[6] = {0, 0, 0, 0, 0, 0};
+    std::atomic<uint64_t> records{0};
+    uint64_t extra_bases = 0;
+    double t_gpu = 0;
+
+    void fail(int code, const char* fmt, ...) {
+        char buf[400];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (err.empty()) { err = buf; err_code = code; }
+        }
+        stop_all();
+    }
+    void stop_all() {
+        abort = true;
+        for (int f = 0; f < 2; ++f) {
+            if (inq[f]) inq[f]->close();
+            ring_cv[f].notify_all();
+        }
+        for (auto& q : jobq) q->close();
+        outq.close();
+        set_cv.notify_all();
+        qc_cv.notify_all();
+    }
+
+    int acquire_ring(int f) {
+        std::unique_lock<std::mutex> lk(ring_mu[f]);
+        int got = -1;
+        ring_cv[f].wait(lk, [&] {
+            if (abort) return true;
+            for (size_t i = 0; i < ring_free[f].size(); ++i)
+                if (ring_free[f][i]) { got = (int)i; return true; }
+            return false;
+        });
+        if (abort || got < 0) return -1;
+        ring_free[f][got] = 0;
+        return got;
+    }
+    void release_ring(int f, int i) {
+        if (i < 0) return;
+        {
+            std::lock_guard<std::mutex> g(ring_mu[f]);
+            ring_free[f][i] = 1;
+        }
+        ring_cv[f].notify_all();
+    }
+
+    // ---- reader: chunks of exactly K records -------------------------------------------------------------------------
+    void reader(int f) {
+        const bool mem = io->in_mem[f] != nullptr;
+        std::unique_ptr<Source> src;
+        if (!mem) {
+            if (io->gzip_in[f]) src.reset(new GzSource(io->in_path[f], P->pool.get()));
+            else src.reset(new FileSource(io->in_path[f], P->pool.get()));
+            if (src->failed()) { fail(AQC_ERR_ARG, "cannot open %s", io->in_path[f]); return; }
+        }
+        const uint64_t want_lines = 4 * K;
+        double est = 360.0;                 // bytes per record, refined after the first chunk
+        uint64_t mpos = 0;
+        std::vector<uint8_t> carry;
+        bool eof = false;
+        for (uint64_t idx = 0; !abort; ++idx) {
+            InChunk c;
+            c.idx = idx;
+            if (mem) {
+                const uint8_t* base = io->in_mem[f] + mpos;
+                const uint64_t left = io->in_mem_bytes[f] - mpos;
+                uint64_t span = std::min<uint64_t>(left, (uint64_t)(est * 1.02 * (double)K) + (64 << 10));
+                std::vector<uint32_t> cnt;
+                uint64_t lines = 0;
+                for (;;) {
+                    const size_t b0 = cnt.size(), b1 = (size_t)((span + SUB - 1) / SUB);
+                    cnt.resize(b1);
+                    P->pool->parallel_for(b1 - b0, [&](size_t i) {
+                        const size_t o = (b0 + i) * SUB;
+                        cnt[b0 + i] = (uint32_t)count_nl(base + o, (size_t)std::min<uint64_t>(SUB, span - o));
+                    });
+                    lines = 0;
+                    for (auto v : cnt) lines += v;
+                    if (lines >= want_lines || span == left) break;
+                    const uint64_t nspan = std::min<uint64_t>(left, span + span / 2 + (1 << 20));
+                    // recount the (partial) last block of the old span together with the new bytes
+                    if (!cnt.empty()) cnt.pop_back();
+                    span = nspan;
+                }
+                uint64_t bytes = span;
+                if (lines >= want_lines) bytes = locate_nl(base, (size_t)span, cnt, want_lines);
+                c.data = base;
+                c.bytes = bytes;
+                c.lines = std::min<uint64_t>(lines, want_lines);
+                mpos += bytes;
+                c.final = mpos == io->in_mem_bytes[f];
+                if (c.final && bytes > 0 && base[bytes - 1] != '\n' && lines < want_lines) c.lines += 1;     // unterminated last line
+                c.buf = -1;
+            } else {
+                const int bi = acquire_ring(f);
+                if (bi < 0) return;
+                HostBuf& hb = P->in_buf[f][bi];
+                size_t cap = (size_t)(est * 1.02 * (double)K) + (256 << 10);
+                if (cap < carry.size() + (1 << 20)) cap = carry.size() + (1 << 20);
+                hb.ensure(cap);
+                if (!hb.p) { fail(AQC_ERR_HIP, "page-locked allocation of %zu bytes failed", cap); return; }
+                size_t fill = carry.size();
+                if (fill) memcpy(hb.p, carry.data(), fill);
+                carry.clear();
+                std::vector<uint32_t> cnt;
+                uint64_t lines = 0;
+                size_t counted_blocks = 0;
+                for (;;) {
+                    if (!eof && fill < hb.cap) {
+                        const size_t want = std::min(hb.cap, cap) - fill;
+                        const size_t got = want ? src->read(hb.p + fill, want) : 0;
+                        if (src->failed()) { fail(AQC_ERR_ARG, "read error on %s", io->in_path[f]); return; }
+                        if (got < want) eof = true;
+                        fill += got;
+                    }
+                    // count the new (and the previously partial) blocks
+                    const size_t nb = (fill + SUB - 1) / SUB;
+                    const size_t from = counted_blocks ? counted_blocks - 1 : 0;
+                    cnt.resize(nb);
+                    P->pool->parallel_for(nb - from, [&](size_t i) {
+                        const size_t o = (from + i) * SUB;
+                        cnt[from + i] = (uint32_t)count_nl(hb.p + o, std::min(SUB, fill - o));
+                    });
+                    counted_blocks = nb;
+                    lines = 0;
+                    for (auto v : cnt) lines += v;
+                    if (lines >= want_lines || eof) break;
+                    // the records are longer than estimated: a bigger buffer, keep what is there
+                    const size_t ncap = cap + cap / 2 + (4 << 20);
+                    if (ncap > hb.cap) {
+                        HostBuf nbuf;
+                        nbuf.ensure(ncap);
+                        if (!nbuf.p) { fail(AQC_ERR_HIP, "page-locked allocation of %zu bytes failed", ncap); return; }
+                        memcpy(nbuf.p, hb.p, fill);
+                        hb.release();
+                        hb = nbuf;
+                    }
+                    cap = ncap;
+                }
+                size_t bytes = fill;
+                if (lines >= want_lines) bytes = locate_nl(hb.p, fill, cnt, want_lines);
+                if (bytes < fill) carry.assign(hb.p + bytes, hb.p + fill);
+                c.data = hb.p;
+                c.bytes = bytes;
+                c.lines = std::min<uint64_t>(lines, want_lines);
+                c.final = eof && carry.empty();
+                if (c.final && bytes > 0 && hb.p[bytes - 1] != '\n' && lines < want_lines) c.lines += 1;
+                c.buf = bi;
+            }
+            if (c.lines >= 4 && c.bytes) est = (double)c.bytes / (double)(c.lines / 4);
+            const bool fin = c.final;
+            if (!inq[f]->push(c)) { if (c.buf >= 0) release_ring(f, c.buf); return; }
+            if (fin) break;
+        }
+        inq[f]->close();
+    }
+
+    // ---- dispatcher: pair the chunks, deal them round robin ---------------------------------------------------------------
+    void dispatcher() {
+        for (uint64_t idx = 0; !abort; ++idx) {
+            Job j;
+            j.idx = idx;
+            bool ok = inq[0]->pop(j.c[0]);
+            if (ok && nf == 2) {
+                ok = inq[1]->pop(j.c[1]);
+                if (!ok) release_ring(0, j.c[0].buf);
+            }
+            if (!ok) break;
+            // the regular shape: both mates hold the same number of complete records, and end together
+            const uint64_t r1 = j.c[0].lines / 4, r2 = nf == 2 ? j.c[1].lines / 4 : r1;
+            const bool fin1 = j.c[0].final, fin2 = nf == 2 ? j.c[1].final : fin1;
+            if (r1 != r2 || fin1 != fin2 || (!fin1 && r1 != K) || (j.c[0].lines % 4) || (nf == 2 && (j.c[1].lines % 4))) {
+                anomaly = true;
+                for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf);
+                stop_all();
+                return;
+            }
+            j.last = fin1;
+            if (!jobq[idx % jobq.size()]->push(j)) {
+                for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf);
+                break;
+            }
+            if (j.last) break;
+        }
+        for (auto& q : jobq) q->close();
+    }
+
+    // ---- slot worker ------------------------------------------------------------------------------------------------------
+    void worker(int ci, int slot) {
+        aqc_ctx* c = P->ctx[ci];
+        const int wid = ci * P->slots + slot;
+        Job j;
+        int set = 0;
+        while (!abort && jobq[ci]->pop(j)) {
+            aqc_text_chunk ch{};
+            ch.text1 = j.c[0].data; ch.bytes1 = j.c[0].bytes; ch.final1 = j.c[0].final ? 1 : 0;
+            if (nf == 2) { ch.text2 = j.c[1].data; ch.bytes2 = j.c[1].bytes; ch.final2 = j.c[1].final ? 1 : 0; }
+            ch.max_records = UINT64_MAX;
+            ch.first_index = (opt->chunk_index0 + j.idx * (opt->chunk_index_stride ? opt->chunk_index_stride : 1)) * K;
+            aqc_frame_info info{};
+            int rc = aqc_frame(c, slot, &ch, &info);
+            // the text has left the host buffers
+            for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf);
+            if (rc) { fail(rc, "aqc_frame: %s", aqc_last_error()); return; }
+            const uint64_t expect = j.c[0].lines / 4;
+            if (info.n != expect || info.eof1 || info.eof2 || info.avail1 != expect || (nf == 2 && info.avail2 != expect)) {
+                anomaly = true;           // an empty line / a blank-only line inside: the serial path knows what to do
+                stop_all();
+                return;
+            }
+            const uint64_t n = info.n;
+            if ((rc = aqc_run(c, slot, UINT64_MAX))) { fail(rc, "aqc_run: %s", aqc_last_error()); return; }
+            // post-filter QC while TOTAL_READS < qc_sample (preprocesser.py:624-627), issued in chunk order
+            const uint64_t g0 = ch.first_index;
+            uint64_t n_qc = n;
+            if (opt->qc_sample > 0) n_qc = (uint64_t)opt->qc_sample - 1 > g0 ? std::min<uint64_t>(n, (uint64_t)opt->qc_sample - 1 - g0) : 0;
+            const bool may_qc = opt->qc_sample <= 0 || g0 < (uint64_t)opt->qc_sample - 1;
+            if (may_qc) {
+                std::unique_lock<std::mutex> lk(qc_mu);
+                qc_cv.wait(lk, [&] { return abort || qc_next == j.idx; });
+                if (!abort && n_qc > 0) {
+                    rc = aqc_qc_stat(c, slot, AQC_QC_R1_POST, 0, 0, n_qc, 1);
+                    if (!rc && nf == 2) rc = aqc_qc_stat(c, slot, AQC_QC_R2_POST, 1, 0, n_qc, 1);
+                    if (!rc) rc = aqc_sync(c, slot);
+                }
+                qc_next = j.idx + 1;
+                lk.unlock();
+                qc_cv.notify_all();
+                if (rc) { fail(rc, "aqc_qc_stat: %s", aqc_last_error()); return; }
+            } else {
+                // (chunks behind the sample never wait; the turn counter is passed on by the ones before)
+                std::lock_guard<std::mutex> g(qc_mu);
+                if (qc_next == j.idx) { qc_next = j.idx + 1; qc_cv.notify_all(); }
+            }
+            OutChunk oc;
+            oc.idx = j.idx;
+            oc.n = n;
+            oc.last = j.last;
+            oc.worker = wid;
+            if (!opt->no_output) {
+                if ((rc = aqc_format(c, slot, n, opt->store_overlap, oc.sizes))) { fail(rc, "aqc_format: %s", aqc_last_error()); return; }
+                // wait for the writer to hand this buffer set back
+                {
+                    std::unique_lock<std::mutex> lk(set_mu);
+                    set_cv.wait(lk, [&] { return abort || set_free[wid * 2 + set]; });
+                    if (abort) return;
+                    set_free[wid * 2 + set] = 0;
+                }
+                for (int q = 0; q < 6; ++q) {
+                    if (!oc.sizes[q]) continue;
+                    HostBuf& hb = P->wbufs[wid].out[set][q];
+                    hb.ensure(oc.sizes[q]);
+                    if (!hb.p) { fail(AQC_ERR_HIP, "page-locked allocation failed"); return; }
+                    if ((rc = aqc_fetch_text(c, slot, q / 3, q % 3, hb.p, hb.cap))) { fail(rc, "aqc_fetch_text: %s", aqc_last_error()); return; }
+                }
+                oc.set = set;
+                set ^= 1;
+            } else {
+                if ((rc = aqc_sync(c, slot))) { fail(rc, "aqc_sync: %s", aqc_last_error()); return; }
+            }
+            records += n;
+            if (!outq.push(oc)) return;
+        }
+    }
+
+    // ---- writer: commit in chunk order ------------------------------------------------------------------------------------
+    static void bgzf_block(const uint8_t* src, size_t n, int level, std::vector<uint8_t>& out) {
+        // one gzip member with the BGZF extra field (BC: total block size - 1); members concatenate into one valid .gz
+        out.resize(18 + compressBound((uLong)n) + 8);
+        z_stream z{};
+        deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        z.next_in = const_cast<uint8_t*>(src);
+        z.avail_in = (uInt)n;
+        z.next_out = out.data() + 18;
+        z.avail_out = (uInt)(out.size() - 18 - 8);
+        deflate(&z, Z_FINISH);
+        const size_t clen = z.total_out;
+        deflateEnd(&z);
+        const size_t bsize = 18 + clen + 8;
+        static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        memcpy(out.data(), hdr, 16);
+        out[16] = (uint8_t)((bsize - 1) & 0xff);
+        out[17] = (uint8_t)((bsize - 1) >> 8);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n);
+        uint8_t* t = out.data() + 18 + clen;
+        for (int k = 0; k < 4; ++k) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)((uint32_t)n >> (8 * k)); }
+        out.resize(bsize);
+    }
+
+    bool write_all(int fd, const uint8_t* p, size_t n, uint64_t off) {
+        const size_t piece = 8 << 20;
+        const size_t k = (n + piece - 1) / piece;
+        std::atomic<bool> bad{false};
+        P->pool->parallel_for(k, [&](size_t i) {
+            size_t o = i * piece;
+            const size_t end = std::min(n, o + piece);
+            while (o < end) {
+                const ssize_t w = pwrite(fd, p + o, end - o, (off_t)(off + o));
+                if (w <= 0) { bad = true; return; }
+                o += (size_t)w;
+            }
+        });
+        return !bad;
+    }
+
+    void commit(const OutChunk& oc) {
+        if (oc.set < 0) return;
+        for (int q = 0; q < 6; ++q) {
+            res->bytes_out[q] += oc.sizes[q];
+            if (!oc.sizes[q] || out_fd[q] < 0) continue;
+            const uint8_t* p = P->wbufs[oc.worker].out[oc.set][q].p;
+            if (!io->gzip_out) {
+                if (!write_all(out_fd[q], p, oc.sizes[q], out_pos[q])) { fail(AQC_ERR_ARG, "write error on output %d", q); return; }
+                out_pos[q] += oc.sizes[q];
+            } else {
+                const size_t blk = 0xff00;                    // BGZF: at most 64 KiB of text per member
+                const size_t nb = (oc.sizes[q] + blk - 1) / blk;
+                std::vector<std::vector<uint8_t>> z(nb);
+                P->pool->parallel_for(nb, [&](size_t i) {
+                    const size_t o = i * blk;
+                    bgzf_block(p + o, std::min<size_t>(blk, oc.sizes[q] - o), io->gzip_level, z[i]);
+                });
+                size_t total = 0;
+                for (auto& b : z) total += b.size();
+                std::vector<uint8_t> cat(total);
+                size_t o = 0;
+                for (auto& b : z) { memcpy(cat.data() + o, b.data(), b.size()); o += b.size(); }
+                if (!write_all(out_fd[q], cat.data(), total, out_pos[q])) { fail(AQC_ERR_ARG, "write error on output %d", q); return; }
+                out_pos[q] += total;
+            }
+        }
+    }
+
+    void writer() {
+        std::map<uint64_t, OutChunk> pending;
+        uint64_t next = 0;
+        OutChunk oc;
+        bool done = false;
+        while (!done && outq.pop(oc)) {
+            pending[oc.idx] = oc;
+            while (!pending.empty() && pending.begin()->first == next) {
+                OutChunk cur = pending.begin()->second;
+                pending.erase(pending.begin());
+                if (!abort) commit(cur);
+                if (cur.set >= 0) {
+                    {
+                        std::lock_guard<std::mutex> g(set_mu);
+                        set_free[cur.worker * 2 + cur.set] = 1;
+                    }
+                    set_cv.notify_all();
+                }
+                res->chunks += 1;
+                ++next;
+                if (cur.last) { done = true; break; }
+            }
+        }
+        outq.close();
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* aqc_pipe_last_error(void) { return g_pipe_err; }
+
+int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_t io_threads, aqc_pipe** out) {
+    if (!ctxs || n_ctx < 1 || !out || slots_per_ctx < 1 || slots_per_ctx > 16) return AQC_ERR_ARG;
+    aqc_pipe* p = new aqc_pipe();
+    p->n_ctx = n_ctx;
+    p->ctx.assign(ctxs, ctxs + n_ctx);
+    p->slots = slots_per_ctx;
+    unsigned hc = std::thread::hardware_concurrency();
+    p->io_threads = io_threads > 0 ? io_threads : (int)std::min(32u, std::max(4u, hc / 2));
+    p->pool.reset(new Pool(p->io_threads));
+    const int ring = n_ctx * slots_per_ctx + 2;
+    for (int f = 0; f < 2; ++f) p->in_buf[f].resize(ring);
+    p->wbufs.resize((size_t)n_ctx * slots_per_ctx);
+    *out = p;
+    return 0;
+}
+
+void aqc_pipe_destroy(aqc_pipe* p) {
+    if (!p) return;
+    for (int f = 0; f < 2; ++f)
+        for (auto& b : p->in_buf[f]) b.release();
+    for (auto& w : p->wbufs)
+        for (int s = 0; s < 2; ++s)
+            for (int q = 0; q < 6; ++q) w.out[s][q].release();
+    delete p;
+}
+
+int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, aqc_pipe_result* res) {
+    if (!P || !io || !opt || !res) return AQC_ERR_ARG;
+    memset(res, 0, sizeof(*res));
+    if (!io->in_path[0] && !io->in_mem[0]) return AQC_ERR_ARG;
+    const double t0 = now_s();
+    Run R;
+    R.P = P;
+    R.io = io;
+    R.opt = opt;
+    R.res = res;
+    R.nf = (io->in_path[1] || io->in_mem[1]) ? 2 : 1;
+    R.K = opt->chunk_records ? opt->chunk_records : (1u << 17);
+    for (int f = 0; f < R.nf; ++f) {
+        R.inq[f].reset(new BQueue<InChunk>(2));
+        R.ring_free[f].assign(P->in_buf[f].size(), 1);
+    }
+    for (int i = 0; i < P->n_ctx; ++i) R.jobq.emplace_back(new BQueue<Run::Job>((size_t)P->slots));
+    R.set_free.assign(P->wbufs.size() * 2, 1);
+    if (!opt->no_output) {
+        for (int q = 0; q < 6; ++q) {
+            const char* path = io->out_path[q / 3][q % 3];
+            if (!path) continue;
+            R.out_fd[q] = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (R.out_fd[q] < 0) {
+                snprintf(g_pipe_err, sizeof(g_pipe_err), "cannot open %s for writing", path);
+                for (int k = 0; k < q; ++k) if (R.out_fd[k] >= 0) close(R.out_fd[k]);
+                return AQC_ERR_ARG;
+            }
+        }
+    }
+    std::vector<std::thread> th;
+    for (int f = 0; f < R.nf; ++f) th.emplace_back([&R, f] { R.reader(f); });
+    th.emplace_back([&R] { R.dispatcher(); });
+    for (int ci = 0; ci < P->n_ctx; ++ci)
+        for (int s = 0; s < P->slots; ++s) th.emplace_back([&R, ci, s] { R.worker(ci, s); });
+    std::thread wr([&R] { R.writer(); });
+    for (auto& t : th) t.join();
+    // all producers are done: if the last chunk never arrived (abort / anomaly) the writer must not wait for it
+    R.outq.close();
+    wr.join();
+    for (int q = 0; q < 6; ++q) {
+        if (R.out_fd[q] >= 0) {
+            if (io->gzip_out && !R.abort) {
+                // an empty BGZF member terminates the file (and makes an output with no records a valid .gz)
+                std::vector<uint8_t> e;
+                Run::bgzf_block((const uint8_t*)"", 0, io->gzip_level, e);
+                (void)!pwrite(R.out_fd[q], e.data(), e.size(), (off_t)R.out_pos[q]);
+            }
+            close(R.out_fd[q]);
+        }
+    }
+    res->records = R.records.load();
+    res->anomaly = R.anomaly ? 1 : 0;
+    res->seconds = now_s() - t0;
+    if (!R.err.empty()) {
+        std::lock_guard<std::mutex> g(g_pipe_err_mu);
+        snprintf(g_pipe_err, sizeof(g_pipe_err), "%s", R.err.c_str());
+        return R.err_code ? R.err_code : AQC_ERR_HIP;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -632,7 +632,6 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_write_kernel(FormatView v, uint6
                                                              int overlap_pass) {
     __shared__ unsigned long long lds[4];
     __shared__ unsigned int s_pos[2][FMT_TILE];
-    __shared__ unsigned long long s_base[2];
     __shared__ uint4 first[17];
     const int nfiles = v.paired ? 2 : 1;
     const uint64_t r0 = (uint64_t)blockIdx.x * FMT_TILE;

@@ -6,10 +6,15 @@ batches, judged by the HIP kernels behind the C ABI (afterqc_amd.capi.Engine) an
 verdict records come back.  This module is I/O and bookkeeping:
 
   pass 1  pre-filter QC sampling + auto-trim            (preprocesser.py:247-280)
-  pass 2  text path (default): raw text chunk -> aqc_frame -> aqc_run -> aqc_qc_stat(post) -> aqc_format ->
-          good/bad text back -> files; framing and formatting happen on the device, the host moves bytes
-          host path (barcodes, index files, --store_overlap, --debubble, --qc_only): host framing ->
-          upload -> aqc_run -> aqc_qc_stat(post) -> fetch verdicts -> host writer
+  pass 2  every run takes the text path: raw text chunk -> aqc_frame -> aqc_run -> aqc_qc_stat(post) -> aqc_format ->
+          good / bad / overlap text back -> files; framing and formatting happen on the device.
+            * whole-input pipe (aqc_pipe_run, C++ reader / slot-worker / writer threads; the default for read files
+              without index files and without --qc_only): chunks of exactly `chunk_records` records, dealt round robin
+              over every engine (= GPU) the filter was given, outputs stitched in chunk order, statistics summed on
+              the host (SURVEY.md §8e);
+            * serial chunk loop in this file (_run_text / _run_text_indexed): index files, --qc_only, inputs of
+              irregular shape (the pipe reports them), injected engines;
+          the host path (_run_host: numpy framing, Python writer) only exists as a cross-check (use_text_path=False)
   stats   counters -> JSON with the reference's schema  (preprocesser.py:660-778)
 
 There is no CPU compute path: `engine` defaults to the HIP engine, which raises if the library or
@@ -283,13 +288,22 @@ class _TextSink:
 class seqFilter:
     """seqFilter(options).run() — preprocesser.py:141-155,234-783."""
 
-    def __init__(self, opt, engine=None, batch_records=1 << 20, device=0, chunk_bytes=8 << 20, use_text_path=True):
+    def __init__(self, opt, engine=None, batch_records=1 << 20, device=0, chunk_bytes=64 << 20, use_text_path=True,
+                 devices=None, use_pipe=True, chunk_records=1 << 17, pipe_slots=3, io_threads=0):
         self.options = opt
         self.chunk_bytes = chunk_bytes
         self.use_text_path = use_text_path
         self.text_path = False
         self.engine = engine
         self.device = device
+        # devices: the GPUs one input is dealt over (default: just `device`); engines[0] is self.engine
+        self.devices = list(devices) if devices else [device]
+        self.extra_engines = []
+        self.use_pipe = use_pipe
+        self.used_pipe = False
+        self.chunk_records = int(chunk_records)
+        self.pipe_slots = int(pipe_slots)
+        self.io_threads = int(io_threads)
         self.own_engine = False
         self.batch_records = max(int(batch_records), 1000)
         self.paired = opt.read2_file is not None
@@ -299,9 +313,13 @@ class seqFilter:
     # ---- helpers ---------------------------------------------------------------------------------
     def _engine(self):
         if self.engine is None:
-            self.engine = capi.Engine(self.device, 2)
+            self.engine = capi.Engine(self.devices[0], max(2, self.pipe_slots))
             self.own_engine = True
+            self.extra_engines = [capi.Engine(d, max(2, self.pipe_slots)) for d in self.devices[1:]]
         return self.engine
+
+    def _engines(self):
+        return [self._engine()] + self.extra_engines
 
     def _aux(self, batch, rb1):
         """Parse lane/tile/x/y out of the R1 names for the bubble filter (preprocesser.py:180-192)."""
@@ -328,9 +346,10 @@ class seqFilter:
         t_run = time.perf_counter()
         has_i1 = opt.index1_file is not None
         has_i2 = opt.index2_file is not None
-        eng.set_config(build_config(opt, paired, has_i2))
-        eng.set_circles(self.bubbleCircles)
-        eng.reset_stats()
+        for e in self._engines():
+            e.set_config(build_config(opt, paired, has_i2))
+            e.set_circles(self.bubbleCircles)
+            e.reset_stats()
 
         # ---- pass 1: pre-filter QC on a sample of each file (preprocesser.py:247-251)
         r1pre = QualityControl(opt.qc_sample, opt.qc_kmer, eng, capi.QC_R1_PRE)
@@ -386,42 +405,87 @@ class seqFilter:
         files = [opt.read1_file, opt.read2_file, opt.index1_file, opt.index2_file]
         if opt.store_overlap and not opt.qc_only:
             os.makedirs(overlap_dir, exist_ok=True)   # single-end + store_overlap: upstream opens the writer without the dir
-        outs = _Outputs(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, opt.compression)
-
-        # ---- pass 2: the main loop (preprocesser.py:411-631), one batch at a time
+        # ---- pass 2: the main loop (preprocesser.py:411-631)
         # the per-read settings now include the resolved trim values
-        eng.set_config(build_config(opt, paired, has_i2))
-        # text in / text out on the device (aqc_frame / aqc_format) whenever the run needs nothing of the host per
-        # record (use_text_path=False keeps the host-side framing and writer below as a cross-check)
-        self.text_path = self.use_text_path
+        for e in self._engines():
+            e.set_config(build_config(opt, paired, has_i2))
+        # text in / text out on the device (aqc_frame / aqc_format); use_text_path=False keeps the host-side framing and
+        # writer below as a cross-check.  An injected engine without the text calls takes the host path.
+        self.text_path = self.use_text_path and hasattr(eng, "frame")
         t_p2 = time.perf_counter()
-        if self.text_path and (has_i1 or has_i2):
+        outs = None
+        extra_bases = None
+        readers = []
+        if (self.text_path and self.use_pipe and not (has_i1 or has_i2) and not opt.qc_only and isinstance(eng, capi.Engine)
+                and not any(f is not None and f.endswith(".bz2") for f in files)):
+            extra_bases = self._run_pipe(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, paired)
+            if extra_bases is None:
+                # not the regular shape (empty line inside, mates of different lengths, ...): start over, chunk by chunk
+                for e in self._engines():
+                    e.reset_stats()
+        if extra_bases is not None:
+            pass
+        elif self.text_path and (has_i1 or has_i2):
+            outs = _Outputs(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, opt.compression)
             extra_bases = self._run_text_indexed(eng, opt, outs, paired)
-            readers = []
         elif self.text_path:
+            outs = _Outputs(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, opt.compression)
             extra_bases = self._run_text(eng, opt, outs, paired)
-            readers = []
         else:
+            outs = _Outputs(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, opt.compression)
             readers, extra_bases = self._run_host(eng, opt, outs, paired, files)
         for r in readers:
             if r is not None:
                 r.close()
-        outs.close()
+        if outs is not None:
+            outs.close()
         self.timing["pass2_s"] = time.perf_counter() - t_p2
 
+        # statistics: per-GPU integers summed on the host (only the pipe spreads a run over several engines)
+        stat_eng = capi.MergedEngines(self._engines()) if self.extra_engines else eng
+        r1post.engine = r2post.engine = stat_eng
         r1post.qc()
         if paired:
             r2post.qc()
 
-        self.stat = self._stats(eng, r1pre, r2pre, r1post, r2post, readLen, extra_bases)
+        self.stat = self._stats(stat_eng, r1pre, r2pre, r1post, r2post, readLen, extra_bases)
         stat_path = os.path.join(qc_dir, os.path.basename(opt.read1_file) + ".json")
         with open(stat_path, "w") as f:
             f.write(json.dumps(self.stat, sort_keys=True, indent=4, separators=(',', ': ')))
         self.timing["total_s"] = time.perf_counter() - t_run
         if self.own_engine:
-            eng.close()
+            for e in self._engines():
+                e.close()
             self.engine = None
+            self.extra_engines = []
         return self.stat
+
+    # ---- pass 2 through the whole-input pipe (aqc_pipe_run) ---------------------------------------------------------------
+    def _run_pipe(self, opt, files, good_dir, bad_dir, overlap_dir, gzip_out, paired):
+        """Hands the read file(s) to the C++ pipe: chunks of `chunk_records` records dealt over every engine, outputs written
+        in chunk order by its writer thread.  Returns the extra-bases quirk value (always 0 for the regular inputs the pipe
+        accepts) or None when the pipe met an input of irregular shape (the caller falls back to the serial chunk loop)."""
+        nfiles = 2 if paired else 1
+        outputs = []
+        for k in range(nfiles):
+            main = getMainName(files[k])
+            ext = ".gz" if gzip_out else ""
+            # upstream opens the R1 overlap writer whenever store_overlap is on, the others only when paired (_Outputs)
+            want_ovl = (opt.store_overlap and k == 0) or (opt.store_overlap and paired)
+            outputs.append((os.path.join(good_dir, main + ".good.fq" + ext), os.path.join(bad_dir, main + ".bad.fq" + ext),
+                            os.path.join(overlap_dir, main + ".overlap.fq" + ext) if want_ovl else None))
+        pipe = capi.Pipe(self._engines(), slots=min([self.pipe_slots] + [e.n_slots for e in self._engines()]), io_threads=self.io_threads)
+        try:
+            res = pipe.run(files[:nfiles], outputs, gzip_in=[f.endswith(".gz") for f in files[:nfiles]], gzip_out=gzip_out,
+                           gzip_level=opt.compression, chunk_records=self.chunk_records, qc_sample=opt.qc_sample,
+                           store_overlap=bool(opt.store_overlap) and paired)
+        finally:
+            pipe.close()
+        self.used_pipe = not res.anomaly
+        if res.anomaly:
+            return None
+        self.timing["pipe_s"] = res.seconds
+        return 0
 
     # ---- pass 2, text path with index files (-7 / -5): four lock-stepped inputs, two device slots ---------------------
     def _run_text_indexed(self, eng, opt, outs, paired):

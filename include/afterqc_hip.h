@@ -312,6 +312,53 @@ int aqc_read_stats(aqc_ctx* ctx, const aqc_batch* reads, int32_t max_poly, int32
  * given as seq1 (a) / seq2 (b) of a batch; strings up to 64 bytes on the device path */
 int aqc_edit_distance(aqc_ctx* ctx, const aqc_batch* pairs, int32_t* dist);
 
+/* ---- whole-input pipeline: the byte path of seqFilter.run's main loop (preprocesser.py:411-631) --------------------- */
+/* Reads one input (a read file, or a pair of mate files; plain, .gz, or text already in host memory), cuts it into chunks
+ * of exactly chunk_records records, deals chunk i to context i % n_ctx (first_index = i * chunk_records, so the sampling
+ * rules of preprocesser.py:624 / qualitycontrol.py:343-350 stay exact; no collective), runs aqc_frame ->
+ * aqc_run -> aqc_qc_stat(post, first qc_sample records) -> aqc_format -> aqc_fetch_text per chunk on side threads and
+ * writes the good / bad / overlap streams in chunk order (fastq.Writer, fastq.py:63-93; .gz output as independent
+ * BGZF-compatible members).  The contexts must be configured (aqc_set_config / aqc_set_circles) by the caller, who also
+ * merges their statistics afterwards (plain sums).  While a pipe runs, its contexts belong to it.
+ * The pipe covers the regular shape of an input (4-line records, mates with equal record counts, no empty line inside);
+ * for anything else it stops and sets result->anomaly: rerun the input through the per-chunk calls, which reproduce
+ * fastq.Reader's end-of-file rules case by case (fastq.py:37-49, preprocesser.py:412-429). */
+typedef struct aqc_pipe aqc_pipe;
+
+typedef struct aqc_pipe_io {
+    const char* in_path[2];        /* read 1 / read 2 file (NULL: in_mem, or single-end for index 1) */
+    const uint8_t* in_mem[2];      /* alternative to a path: the FASTQ text in host memory (page-locked memory from
+                                      aqc_host_alloc is used in place, zero copy) */
+    uint64_t in_mem_bytes[2];
+    int32_t gzip_in[2];            /* the file is a gzip stream (fastq.py:23-24) */
+    const char* out_path[2][3];    /* per input: good / bad / overlap output file, NULL = that stream is dropped */
+    int32_t gzip_out;              /* write .gz (preprocesser.py:318-321) */
+    int32_t gzip_level;            /* --compression */
+} aqc_pipe_io;
+
+typedef struct aqc_pipe_opts {
+    uint64_t chunk_records;        /* records per chunk (0: 131072) */
+    int64_t qc_sample;             /* --qc_sample: post-filter QC while TOTAL_READS < qc_sample (<= 0: every record) */
+    int32_t store_overlap;         /* --store_overlap */
+    int32_t no_output;             /* 1: verdicts and statistics only, no text is formatted or fetched (--qc_only style) */
+    uint64_t chunk_index0;         /* this input holds chunks chunk_index0, chunk_index0 + stride, ... of a larger one: */
+    uint64_t chunk_index_stride;   /*   first_index = (chunk_index0 + i * stride) * chunk_records   (0 = 1) */
+} aqc_pipe_opts;
+
+typedef struct aqc_pipe_result {
+    uint64_t records;              /* records processed */
+    uint64_t chunks;
+    uint64_t bytes_out[6];         /* [file * 3 + stream] */
+    int32_t anomaly;               /* the input is not of the regular shape: outputs and statistics are incomplete */
+    int32_t pad_;
+    double seconds;
+} aqc_pipe_result;
+
+int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_t io_threads, aqc_pipe** out);
+void aqc_pipe_destroy(aqc_pipe* p);
+int aqc_pipe_run(aqc_pipe* p, const aqc_pipe_io* io, const aqc_pipe_opts* opts, aqc_pipe_result* result);
+const char* aqc_pipe_last_error(void);
+
 /* ---- the reference's EXISTING native seam (libed.so), for ABI compatibility ------------------------ */
 /* editdistance/_editdistance.h:16 — Levenshtein distance; util.editDistance binds it at util.py:70 */
 unsigned int edit_distance(const char* a, const unsigned int asize, const char* b, const unsigned int bsize);

@@ -34,6 +34,6 @@ def e2e():
 def gpu_engine():
     """One HIP context for the whole session; fails loudly if the library or the GPU is missing."""
     from afterqc_amd import capi
-    eng = capi.Engine(0, 2)
+    eng = capi.Engine(0, 3)
     yield eng
     eng.close()

@@ -1,0 +1,118 @@
+"""-m gpu: ONE input dealt over several contexts by the whole-input pipe gives byte-identical outputs and
+an identical stats JSON to the serial single-context chunk loop — chunk i carries first_index = i * chunk_records, so the
+post-filter sampling rule (TOTAL_READS < qc_sample, preprocesser.py:624) and the k-mer dictionary's insertion order survive
+the sharding; counters / histograms / QC rows are plain sums, k-mers merge by (count sum, min first-seen key)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from afterqc_amd import after, preprocesser, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def run(work, r1, r2, extra, **kw):
+    out = os.path.join(work, kw.pop("tag"))
+    argv = ["-1", r1] + (["-2", r2] if r2 else []) + ["-g", os.path.join(out, "good"), "-b", os.path.join(out, "bad"),
+                                                       "-r", os.path.join(out, "QC")] + extra
+    options, _ = after.parseCommand(argv)
+    after.finalize_options(options)
+    options.barcode = False
+    flt = preprocesser.seqFilter(options, **kw)
+    stat = flt.run()
+    files = {}
+    for sub in ("good", "bad"):
+        for fn in sorted(os.listdir(os.path.join(out, sub))):
+            with open(os.path.join(out, sub, fn), "rb") as f:
+                files[sub + "/" + fn] = hashlib.sha256(f.read()).hexdigest()
+    stat = json.loads(json.dumps(stat))
+    for k in ("good_output_folder", "bad_output_folder", "report_output_folder"):
+        stat["command"].pop(k, None)
+    return files, stat, flt
+
+
+@pytest.mark.parametrize("paired", [True, False])
+def test_one_input_over_two_contexts(tmp_path, paired):
+    work = str(tmp_path)
+    n = 60000
+    d = synth.make_pairs(n, 150, seed=8801, dirty=True)
+    r1, r2 = os.path.join(work, "R1.fq"), os.path.join(work, "R2.fq")
+    synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
+    synth.write_fastq_fixed(r2, d["seq2"], d["qual2"], 2)
+    extra = ["-f", "2", "-t", "3", "--qc_sample", "30000"]        # the sample ends inside a chunk, several chunks behind it
+    a_files, a_stat, a = run(work, r1, r2 if paired else None, extra, tag="serial", use_pipe=False, devices=[0])
+    b_files, b_stat, b = run(work, r1, r2 if paired else None, extra, tag="two", use_pipe=True, devices=[0, 0], chunk_records=4096, pipe_slots=3)
+    c_files, c_stat, c = run(work, r1, r2 if paired else None, extra, tag="one", use_pipe=True, devices=[0], chunk_records=7000, pipe_slots=2)
+    assert b.used_pipe and c.used_pipe and not a.used_pipe
+    assert a_files == b_files == c_files
+    assert a_stat == b_stat == c_stat
+    assert a_stat["afterqc_main_summary"]["total_reads"] == n
+
+
+def test_pipe_gzip_in_and_out(tmp_path):
+    """.gz in (our own BGZF-style multi-member files: inflated member-parallel; and a single-member stream) -> .gz out"""
+    import gzip
+    work = str(tmp_path)
+    d = synth.make_pairs(20000, 150, seed=8802, dirty=True)
+    r1, r2 = os.path.join(work, "R1.fq"), os.path.join(work, "R2.fq")
+    synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
+    synth.write_fastq_fixed(r2, d["seq2"], d["qual2"], 2)
+    ref_files, ref_stat, _ = run(work, r1, r2, ["-f", "0", "-t", "0"], tag="plain", use_pipe=False, devices=[0])
+    # single-member gzip inputs -> BGZF outputs; then those outputs' siblings as BGZF inputs
+    for p in (r1, r2):
+        with open(p, "rb") as f, gzip.open(p + ".gz", "wb", compresslevel=1) as g:
+            g.write(f.read())
+    out = os.path.join(work, "gz1")
+    argv = ["-1", r1 + ".gz", "-2", r2 + ".gz", "-f", "0", "-t", "0", "-g", os.path.join(out, "good"), "-b", os.path.join(out, "bad"), "-r", os.path.join(out, "QC")]
+    options, _ = after.parseCommand(argv)
+    after.finalize_options(options)
+    options.barcode = False
+    flt = preprocesser.seqFilter(options, use_pipe=True, devices=[0], chunk_records=3000)
+    flt.run()
+    assert flt.used_pipe
+    good1 = os.path.join(out, "good", "R1.good.fq.gz")
+    with gzip.open(good1, "rb") as f:
+        data = f.read()
+    assert hashlib.sha256(data).hexdigest() == ref_files["good/R1.good.fq"]
+    with open(good1, "rb") as f:
+        head = f.read(16)
+    assert head[:4] == b"\x1f\x8b\x08\x04" and head[12:14] == b"BC"       # BGZF members
+    # BGZF in: feed the good outputs back in (every read is good again or at least the pipe must frame them all)
+    out2 = os.path.join(work, "gz2")
+    argv = ["-1", good1, "-2", os.path.join(out, "good", "R2.good.fq.gz"), "-f", "0", "-t", "0", "-g", os.path.join(out2, "good"),
+            "-b", os.path.join(out2, "bad"), "-r", os.path.join(out2, "QC")]
+    options, _ = after.parseCommand(argv)
+    after.finalize_options(options)
+    options.barcode = False
+    flt2 = preprocesser.seqFilter(options, use_pipe=True, devices=[0], chunk_records=2500)
+    st2 = flt2.run()
+    assert flt2.used_pipe
+    assert st2["afterqc_main_summary"]["total_reads"] == ref_stat["afterqc_main_summary"]["good_reads"]
+    flt3 = preprocesser.seqFilter(options, use_pipe=False, devices=[0])
+    options.good_output_folder = os.path.join(work, "gz3", "good")
+    options.bad_output_folder = os.path.join(work, "gz3", "bad")
+    options.report_output_folder = os.path.join(work, "gz3", "QC")
+    st3 = flt3.run()
+    for k in ("good_output_folder", "bad_output_folder", "report_output_folder"):
+        st2["command"].pop(k, None); st3["command"].pop(k, None)
+    assert json.dumps(st2, sort_keys=True) == json.dumps(st3, sort_keys=True)
+    for sub, fn in (("good", "R1.good.good.fq.gz"), ("bad", "R2.good.bad.fq.gz")):
+        with gzip.open(os.path.join(out2, sub, fn), "rb") as f, gzip.open(os.path.join(work, "gz3", sub, fn), "rb") as g:
+            assert f.read() == g.read()
+
+
+def test_pipe_reports_irregular_inputs(tmp_path):
+    """mates of different lengths / an empty line inside: the pipe steps aside, the serial loop reproduces the reference"""
+    work = str(tmp_path)
+    d = synth.make_pairs(3000, 100, seed=8803)
+    r1, r2 = os.path.join(work, "R1.fq"), os.path.join(work, "R2.fq")
+    synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
+    synth.write_fastq_fixed(r2, d["seq2"][:2500], d["qual2"][:2500], 2)
+    files, stat, flt = run(work, r1, r2, ["-f", "0", "-t", "0"], tag="short", use_pipe=True, devices=[0], chunk_records=512)
+    assert not flt.used_pipe
+    assert stat["afterqc_main_summary"]["total_reads"] == 2500
+    files2, stat2, _ = run(work, r1, r2, ["-f", "0", "-t", "0"], tag="short_serial", use_pipe=False, devices=[0])
+    assert files == files2 and stat == stat2

@@ -22,8 +22,14 @@ CASE_TABLE = {c[0]: c for c in cases.CASES}
 
 # how pass 2 is driven: device-side framing/formatting with production-size chunks, the same with chunks of a few
 # records (every carry-over / lock-step corner is hit many times per file), and the host-side framing / writer
-MODES = {"text": dict(use_text_path=True), "text_tiny_chunks": dict(use_text_path=True, chunk_bytes=1500),
+MODES = {"text": dict(use_text_path=True, use_pipe=False), "text_tiny_chunks": dict(use_text_path=True, use_pipe=False, chunk_bytes=1500),
          "host": dict(use_text_path=False)}
+# GPU only (tests/test_gpu_e2e.py): the whole-input pipe (C++ threads), with production-size chunks, with chunks of a few
+# hundred records over three slots, and with ONE input dealt over two contexts (here: two contexts on GPU 0) whose
+# statistics are summed on the host
+PIPE_MODES = {"pipe": dict(use_text_path=True, use_pipe=True),
+              "pipe_small_chunks": dict(use_text_path=True, use_pipe=True, chunk_records=257, pipe_slots=3),
+              "pipe_two_contexts": dict(use_text_path=True, use_pipe=True, chunk_records=300, devices=[0, 0], own_engines=True)}
 
 
 def run_case(name, tmp_path, engine, mode="text", info=None):
@@ -42,10 +48,14 @@ def run_case(name, tmp_path, engine, mode="text", info=None):
             options.trim_front2 = 0
         else:
             options.barcode = False
-        flt = preprocesser.seqFilter(options, engine=engine, **MODES[mode])     # what after.processOptions does
+        kw = dict(MODES[mode] if mode in MODES else PIPE_MODES[mode])
+        if kw.pop("own_engines", False):
+            engine = None                                                        # the filter creates one engine per device
+        flt = preprocesser.seqFilter(options, engine=engine, **kw)              # what after.processOptions does
         stat = flt.run()
         if info is not None:
             info["text_path"] = flt.text_path
+            info["used_pipe"] = flt.used_pipe
     finally:
         os.chdir(cwd)
     return work, stat
