@@ -324,6 +324,8 @@ def load_library():
     lib.aqc_read_stats.argtypes = [P, C.POINTER(BatchStruct), C.c_int32, C.c_int32, C.c_int32, P, P, P]
     lib.aqc_edit_distance.argtypes = [P, C.POINTER(BatchStruct), P]
     lib.aqc_frame.argtypes = [P, C.c_int, C.POINTER(TextChunk), C.POINTER(FrameInfo)]
+    lib.aqc_reframe.argtypes = [P, C.c_int, C.POINTER(FrameInfo)]
+    lib.aqc_reframe.restype = C.c_int
     lib.aqc_format.argtypes = [P, C.c_int, C.c_uint64, C.c_int32, P]
     lib.aqc_format_plain.argtypes = [P, C.c_int, C.c_int, C.c_uint64, C.c_int32, P]
     lib.aqc_fetch_text.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.c_uint64]
@@ -341,7 +343,7 @@ def load_library():
     for name in ("aqc_create", "aqc_device_name", "aqc_set_config", "aqc_set_circles", "aqc_reset_stats", "aqc_upload",
                  "aqc_run", "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_timing_reset",
                  "aqc_timing_mean", "aqc_get_counters", "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers",
-                 "aqc_overlap", "aqc_read_stats", "aqc_edit_distance", "aqc_frame", "aqc_format", "aqc_format_plain",
+                 "aqc_overlap", "aqc_read_stats", "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain",
                  "aqc_fetch_text"):
         getattr(lib, name).restype = C.c_int
     if lib.aqc_abi_version() != 1:
@@ -355,7 +357,7 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_last_error", "aq
                     "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_last_deferred", "aqc_kernel_ms", "aqc_timing_reset",
                     "aqc_timing_mean", "aqc_get_counters",
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
-                    "aqc_edit_distance", "aqc_frame", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_host_alloc",
+                    "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_host_alloc",
                     "aqc_host_free",
                     "aqc_pipe_create", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
                     # the reference's own native seam (editdistance/_editdistance.h:16,23), same names and signatures
@@ -491,6 +493,13 @@ class Engine:
         ch.max_records, ch.first_index = int(max_records), int(first_index)
         info = FrameInfo()
         self._check(self.lib.aqc_frame(self.h, slot, C.byref(ch), C.byref(info)))
+        self.slot_n[slot] = info.n
+        return info
+
+    def reframe(self, slot):
+        """aqc_reframe: frame the text the slot already holds in HBM again (no host copy)"""
+        info = FrameInfo()
+        self._check(self.lib.aqc_reframe(self.h, slot, C.byref(info)))
         self.slot_n[slot] = info.n
         return info
 

@@ -72,6 +72,8 @@ struct Slot {
     DevBuf f_pos, f_tile, f_out[6];
     uint64_t f_bytes[6] = {0, 0, 0, 0, 0, 0};
     bool framed = false, formatted = false;
+    aqc_text_chunk last_chunk{};   // what the slot's arenas hold (aqc_reframe)
+    uint8_t last_byte[2] = {'\n', '\n'};
     uint32_t max_len = 0;
     uint32_t raw_max_len = 0;      // longest read of the slot (both mates), 0 = unknown
     DevBatch view{};
@@ -588,7 +590,7 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
 }
 
 // ---- text in / text out -----------------------------------------------------------------------------------------
-int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* info) {
+static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* info, bool resident) {
     Slot* s;
     int rc = get_slot(c, slot, &s);
     if (rc) return rc;
@@ -619,8 +621,11 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
         const size_t slack = IDX_TILE + 64;
         if (arena[k]->reserve(TEXT_FRONT + bytes[k] + slack)) return fail(AQC_ERR_HIP, "hipMalloc of %llu bytes failed", (unsigned long long)bytes[k]);
         tbase[k] = (uint8_t*)arena[k]->p + TEXT_FRONT;
-        if (bytes[k]) HIP_TRY(hipMemcpyAsync(tbase[k], text[k], bytes[k], hipMemcpyHostToDevice, s->stream));
-        HIP_TRY(hipMemsetAsync(tbase[k] + bytes[k], 0, slack, s->stream));
+        if (!resident) {
+            if (bytes[k]) HIP_TRY(hipMemcpyAsync(tbase[k], text[k], bytes[k], hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(hipMemsetAsync(tbase[k] + bytes[k], 0, slack, s->stream));
+            s->last_byte[k] = bytes[k] ? text[k][bytes[k] - 1] : (uint8_t)'\n';
+        }
         tiles[k] = bytes[k] ? (bytes[k] + IDX_TILE - 1) / IDX_TILE : 1;
         // FASTQ lines average ~90 bytes; a chunk with more lines than this guess is indexed again with the exact size
         const uint64_t guess = bytes[k] / 16 + 4096;
@@ -660,7 +665,7 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
     for (int k = 0; k < nf; k++) {
         lines[k] = h_tot[k];
         // an unterminated last line of the file is a line (readline() returns it)
-        const bool virt = final_[k] && bytes[k] > 0 && text[k][bytes[k] - 1] != '\n';
+        const bool virt = final_[k] && bytes[k] > 0 && s->last_byte[k] != '\n';
         if (virt) {
             const uint32_t end = (uint32_t)bytes[k] | LINE_WS;          // (may end in blanks: let the framing kernel look)
             HIP_TRY(hipMemcpyAsync((uint32_t*)s->t_line_end[k].p + lines[k], &end, sizeof(end), hipMemcpyHostToDevice, s->stream));
@@ -744,7 +749,19 @@ int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* in
     info->consumed2 = consumed[1];
     info->next_len1 = h_next;
     s->framed = true;
+    s->last_chunk = *ch;
     return 0;
+}
+
+int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* info) { return frame_impl(c, slot, ch, info, false); }
+
+int aqc_reframe(aqc_ctx* c, int slot, aqc_frame_info* info) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!s->framed) return fail(AQC_ERR_STATE, "aqc_reframe needs a slot filled by aqc_frame");
+    const aqc_text_chunk ch = s->last_chunk;
+    return frame_impl(c, slot, &ch, info, true);
 }
 
 static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]) {
@@ -805,10 +822,10 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
     }
     if (n) {
         hipLaunchKernelGGL(fmt_write_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles,
-                           (const unsigned long long*)s->f_tile.p, outs, 0);
+                           (const unsigned long long*)s->f_tile.p, outs, 0, s->status);
         if (v.store_overlap)
             hipLaunchKernelGGL(fmt_write_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles,
-                               (const unsigned long long*)s->f_tile.p, outs, 1);
+                               (const unsigned long long*)s->f_tile.p, outs, 1, s->status);
         HIP_TRY(hipGetLastError());
     }
     s->formatted = true;

@@ -42,6 +42,7 @@ __device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long
     total = 0;
 #pragma unroll
     for (int w = 0; w < TXT_BLOCK / WAVE; ++w) {
+        if (w >= (int)(blockDim.x / WAVE)) break;            // (workgroups of 64 .. 256 threads)
         const unsigned long long t = lds[w];
         if (w < wave) base += t;
         total += t;
@@ -265,10 +266,10 @@ __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t*
                                                                   const uint32_t* __restrict__ line_end, uint64_t n_rec,
                                                                   FramedFile out, FrameMeta* __restrict__ meta) {
     const uint64_t r = (uint64_t)blockIdx.x * TXT_BLOCK + threadIdx.x;
-    if (r >= n_rec) return;
-    uint32_t s[4], l[4];
+    const bool in = r < n_rec;
+    uint32_t s[4] = {0, 0, 0, 0}, l[4] = {1, 1, 1, 1};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 4 && in; ++k) {
         const uint64_t li = 4 * r + k;
         const uint32_t b = li == 0 ? 0u : (line_end[li - 1] & LINE_POS) + 1u;
         const uint32_t le = line_end[li];
@@ -278,13 +279,26 @@ __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t*
         s[k] = b;
         l[k] = e - b;
     }
-    out.name_off[r] = s[0]; out.name_len[r] = l[0];
-    out.seq_off[r] = s[1];  out.seq_len[r] = l[1];
-    out.plus_off[r] = s[2]; out.plus_len[r] = l[2];
-    out.qual_off[r] = s[3]; out.qual_len[r] = l[3];
-    if (l[0] == 0 || l[1] == 0 || l[2] == 0 || l[3] == 0) atomicMin(&meta->first_empty, (unsigned int)r);
-    else if (l[1] != l[3]) atomicMin(&meta->first_mismatch, (unsigned int)r);
-    atomicMax(&meta->max_len, l[1]);
+    if (in) {
+        out.name_off[r] = s[0]; out.name_len[r] = l[0];
+        out.seq_off[r] = s[1];  out.seq_len[r] = l[1];
+        out.plus_off[r] = s[2]; out.plus_len[r] = l[2];
+        out.qual_off[r] = s[3]; out.qual_len[r] = l[3];
+    }
+    // chunk-wide reductions: one atomic per WAVE and only when it has something to say (5 M same-address atomics would
+    // serialise in L2 and cost more than the framing itself)
+    const bool empty = in && (l[0] == 0 || l[1] == 0 || l[2] == 0 || l[3] == 0);
+    const bool mism = in && !empty && l[1] != l[3];
+    const unsigned long long be = __ballot(empty), bm = __ballot(mism);
+    unsigned int mx = in ? l[1] : 0u;
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, sft, WAVE));
+    if (lane_id() == 0) {
+        const uint64_t rw = r;                                     // first record of this wave
+        if (be) atomicMin(&meta->first_empty, (unsigned int)(rw + (uint64_t)__builtin_ctzll(be)));
+        if (bm) atomicMin(&meta->first_mismatch, (unsigned int)(rw + (uint64_t)__builtin_ctzll(bm)));
+        if (mx > meta->max_len) atomicMax(&meta->max_len, mx);
+    }
 }
 
 // ---- Illumina read names for the bubble filter (preprocesser.py:155,176-192) ---------------------------------------
@@ -418,31 +432,6 @@ __device__ __forceinline__ int moved_barcode_len(const FormatView& v, int file, 
     return min(max(b, 0), (int)seq_len);
 }
 
-// ---- one record of one file, as the writer sees it --------------------------------------------------------------------
-// The output record is a sequence of pieces
-//     '@' | FLAG | barcode bases | name tail | \n | bases | \n | strand line | \n | qualities | \n
-// of which the flag text, the barcode bases, the name tail, the bases, the strand line and the qualities are copied from a
-// source (SEGMENTS: output offset, length, source pointer) and '@' / the four newlines are literals.
-constexpr int FMT_NSEG = 6;
-struct FmtRec {
-    int stream;                 // 0 good / 1 bad / 2 overlap; -1: this record does not go to the pass's stream
-    int total;                  // bytes of the output record
-    int seg_dst[FMT_NSEG], seg_len[FMT_NSEG];
-    const uint8_t* seg_src[FMT_NSEG];
-    int at;                     // 1: byte 0 is a literal '@'
-    int nl[4];                  // positions of the four newlines
-    int e_pos[3];               // the walk's edits in this mate's slice coordinates (-1 none)
-    uint32_t e_val[3];          //   new base << 8 | new quality  (base 0 = keep)
-    int n_edits;
-};
-
-// flag texts behind 16 bytes of slack (the writer loads 16-byte windows that may start before a piece's source)
-__device__ uint8_t FLAG_SRC[AQC_N_FLAGS + 1][48] = {
-    "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0GOOD",     "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADBCD1",  "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADBCD2",
-    "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADTRIM1", "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADTRIM2", "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADBBL",
-    "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADLEN",   "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADPOL",   "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADLQC",
-    "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADNCT",   "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADDIFF",  "\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0\0BADMISMATCH"};
-
 // bytes of (file, stream) that record r contributes: the sizes of all three streams of one file at once
 // (sz[0] good, sz[1] bad, sz[2] overlap); the name's first ':' is only searched when a barcode was moved
 __device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int file, uint32_t sz[3]) {
@@ -474,7 +463,7 @@ __device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int f
     }
 }
 
-constexpr int FMT_TILE = 256;           // records per workgroup (one thread per record in the sizing phase)
+constexpr int FMT_TILE = 128;           // records per workgroup (one thread per record in the sizing phase)
 
 // per-tile byte sums of the six streams (file * 3 + stream): tile_sum[q * n_tiles + tile]
 __global__ __launch_bounds__(FMT_TILE) void fmt_tile_sums_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
@@ -510,77 +499,6 @@ __global__ __launch_bounds__(TXT_BLOCK) void fmt_tile_bases_kernel(unsigned long
     if (threadIdx.x == 0) total_out[blockIdx.x] = carry;
 }
 
-__device__ __forceinline__ void fmt_record(const FormatView& v, uint64_t r, int file, int overlap_pass, int lane32, FmtRec& o) {
-    const uint4 w0 = *reinterpret_cast<const uint4*>(v.results + r);
-    const uint4 w1 = *(reinterpret_cast<const uint4*>(v.results + r) + 1);
-    const int flag = (int)(w0.x & 0xffu);
-    o.n_edits = v.plain ? 0 : (int)((w0.x >> 8) & 0xffu);
-    o.stream = overlap_pass ? (in_overlap_stream(v, w0, w1) ? 2 : -1) : (flag == AQC_GOOD ? 0 : 1);
-    const int len1 = (int)(w0.y & 0xffffu), len2 = (int)(w0.z & 0xffffu), ovl = (int)(w0.w & 0xffffu);
-    const TextFile& t = v.f[file];
-    // the slice of the original read that is written: the final read, or its last overlap_len bases (getOverlap)
-    const int cut = v.plain ? 0 : (overlap_pass ? (file == 0 ? len1 : len2) - ovl : 0);
-    const int st = v.plain ? 0 : (file == 0 ? (int)(w0.x >> 16) : (int)(w0.y >> 16)) + cut;
-    const int len = v.plain ? (int)t.seq_len[r] : (overlap_pass ? ovl : (file == 0 ? len1 : len2));
-    const unsigned long long e_lo = ((unsigned long long)w1.y << 32) | w1.x, e_hi = ((unsigned long long)w1.w << 32) | w1.z;
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-        o.e_pos[e] = -1; o.e_val[e] = 0;
-        if (e < o.n_edits) {
-            const int bit = 40 * e;
-            unsigned long long x = bit < 64 ? e_lo >> bit : 0ull;
-            if (bit + 40 > 64) x |= bit < 64 ? e_hi << (64 - bit) : e_hi >> (bit - 64);
-            const int oo = (int)(x & 0xffffu);
-            const uint32_t kind = (uint32_t)(x >> 16) & 0xffu, base = (uint32_t)(x >> 24) & 0xffu, qual = (uint32_t)(x >> 32) & 0xffu;
-            const int p = (file == 0 ? len1 - ovl + oo : len2 - 1 - oo) - cut;
-            if (kind == AQC_EDIT_MASK) { o.e_pos[e] = p; o.e_val[e] = (uint32_t)'!'; }
-            else if ((kind == AQC_EDIT_FIX_R1 && file == 0) || (kind == AQC_EDIT_FIX_R2 && file == 1)) { o.e_pos[e] = p; o.e_val[e] = (base << 8) | qual; }
-        }
-    }
-    const uint8_t* name = t.text + t.name_off[r];
-    const uint8_t* seq0 = t.text + t.seq_off[r];           // the read as sequenced (barcode source)
-    const int nlen = (int)t.name_len[r], plen = (int)t.plus_len[r];
-    const int flen = o.stream == 1 ? FLAG_TEXT_LEN[flag] : 0;
-    // barcode moved into the name: '@' + [FLAG] + bases[0:mb] + name[cpos:]
-    const int mb = (v.barcode && !v.plain) ? moved_barcode_len(v, file, flag, w1.w >> 24, t.seq_len[r]) : -1;
-    int cpos = nlen - 1;
-    if (mb >= 0) {
-        // (the 32 lanes of the task search together; every lane gets the same answer)
-        for (int i0 = 0; i0 < nlen; i0 += 32) {
-            const unsigned long long hit = __ballot(i0 + lane32 < nlen && name[i0 + lane32] == ':');
-            const uint32_t mine = (uint32_t)(hit >> (32 * ((threadIdx.x >> 5) & 1)));
-            if (mine) { cpos = i0 + __builtin_ctz(mine); break; }
-        }
-    }
-    // "@" + FLAG + name[1:] for a bad record (preprocesser.py:213-219), the name itself for a good one; with a moved barcode
-    // the name is '@' + barcode + name[cpos:] before that rule applies
-    const bool renamed = o.stream == 1 || mb >= 0;
-    o.at = renamed ? 1 : 0;
-    o.seg_dst[0] = 1; o.seg_len[0] = flen; o.seg_src[0] = &FLAG_SRC[flag][16];
-    o.seg_dst[1] = 1 + flen; o.seg_len[1] = mb >= 0 ? mb : 0; o.seg_src[1] = seq0;
-    if (mb >= 0) { o.seg_dst[2] = 1 + flen + mb; o.seg_len[2] = nlen - cpos; o.seg_src[2] = name + cpos; }
-    else if (renamed) { o.seg_dst[2] = 1 + flen; o.seg_len[2] = max(nlen - 1, 0); o.seg_src[2] = name + 1; }
-    else { o.seg_dst[2] = 0; o.seg_len[2] = nlen; o.seg_src[2] = name; }
-    const int b_name = o.seg_dst[2] + o.seg_len[2];        // name' then '\n'
-    const int b_seq = b_name + 1 + len;                    // bases then '\n'
-    const int b_plus = b_seq + 1 + plen;                   // strand line then '\n'
-    const int b_qual = b_plus + 1 + len;                   // qualities then '\n'
-    o.seg_dst[3] = b_name + 1; o.seg_len[3] = len; o.seg_src[3] = seq0 + st;
-    o.seg_dst[4] = b_seq + 1; o.seg_len[4] = plen; o.seg_src[4] = t.text + t.plus_off[r];
-    o.seg_dst[5] = b_plus + 1; o.seg_len[5] = len; o.seg_src[5] = t.text + t.qual_off[r] + st;
-    o.nl[0] = b_name; o.nl[1] = b_seq; o.nl[2] = b_plus; o.nl[3] = b_qual;
-    o.total = b_qual + 1;
-}
-
-struct FormatOut {
-    uint8_t* p[6];        // [file * 3 + stream]
-};
-
-__device__ __forceinline__ uint4 and4(uint4 a, uint4 b) { return make_uint4(a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w); }
-__device__ __forceinline__ uint4 andn4(uint4 a, uint4 b) { return make_uint4(a.x & ~b.x, a.y & ~b.y, a.z & ~b.z, a.w & ~b.w); }
-__device__ __forceinline__ uint4 sel4(uint4 m, uint4 a, uint4 b) {
-    return make_uint4((a.x & m.x) | (b.x & ~m.x), (a.y & m.y) | (b.y & ~m.y), (a.z & m.z) | (b.z & ~m.z), (a.w & m.w) | (b.w & ~m.w));
-}
 __device__ __forceinline__ void store16u(uint8_t* p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 __device__ __forceinline__ uint4 load16u_t(const uint8_t* p) {
     uint4 v;
@@ -588,68 +506,149 @@ __device__ __forceinline__ uint4 load16u_t(const uint8_t* p) {
     return v;
 }
 
-// the 16 output bytes [w, w + 16) of a record, assembled from every piece that touches the window
-__device__ __forceinline__ uint4 fmt_window(const FmtRec& o, int w, const uint4* first /* [17] */) {
-    uint4 out = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int k = 0; k < FMT_NSEG; ++k) {
-        const int lo = max(o.seg_dst[k], w), hi = min(o.seg_dst[k] + o.seg_len[k], w + 16);
-        if (lo < hi) {
-            const uint4 m = andn4(first[hi - w], first[lo - w]);
-            out = sel4(m, load16u_t(o.seg_src[k] + (w - o.seg_dst[k])), out);
+// ---- one record of one file, as the writer sees it --------------------------------------------------------------------
+// The output record is a sequence of pieces
+//     '@' FLAG | barcode bases | name tail | \n | bases | \n | strand line | \n | qualities | \n
+// each copied from a source: the chunk's text, or a small table of literals ("@BADPOL", "\n", "@").  Neighbouring pieces
+// that are neighbours in the text as well are merged while the list is built, so an untrimmed good record is ONE piece
+// (the record's own bytes), a tail-trimmed one three, a renamed (bad) one two more.
+constexpr int FMT_MAXP = 10;
+constexpr uint32_t FMT_LIT_BIT = 0x80000000u;
+struct FmtPiece {
+    uint32_t src;          // byte offset from the file's text base; FMT_LIT_BIT: offset into FMT_LIT instead
+    uint16_t dst, len;     // position in the output record, bytes
+};
+struct FmtTask {
+    uint32_t pos;          // offset of the record in its output stream
+    uint8_t stream;        // 0 good / 1 bad / 2 overlap, 0xff: not written in this pass
+    uint8_t np, n_patch, pad_;
+    uint16_t total, items; // bytes of the output record; work items (16-byte windows + short pieces)
+    uint32_t patch[6];     // the walk's edits: output position | new byte << 16
+    FmtPiece p[FMT_MAXP];
+};
+
+// literals: row f < 12 = "@" + FLAG text, row 12 = "\n", row 13 = "@"
+__device__ uint8_t FMT_LIT[16][16] = {"@GOOD", "@BADBCD1", "@BADBCD2", "@BADTRIM1", "@BADTRIM2", "@BADBBL", "@BADLEN", "@BADPOL", "@BADLQC",
+                                      "@BADNCT", "@BADDIFF", "@BADMISMATCH", "\n", "@", "", ""};
+
+__device__ __forceinline__ void fmt_add(FmtTask& t, int& o, int len, uint32_t src) {
+    if (len <= 0) return;
+    if (t.np > 0) {
+        FmtPiece& q = t.p[t.np - 1];
+        if (!((q.src | src) & FMT_LIT_BIT) && q.src + q.len == src && (int)q.len + len <= 0xffff) {       // neighbours in the text too
+            q.len = (uint16_t)(q.len + len);
+            o += len;
+            return;
         }
     }
-    if (o.at && w == 0) out.x = (out.x & ~0xffu) | (uint32_t)'@';
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = o.nl[k] - w;
-        if (i >= 0 && i < 16) out = sel4(andn4(first[i + 1], first[i]), make_uint4(0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au, 0x0a0a0a0au), out);
+    if (t.np < FMT_MAXP) {
+        t.p[t.np].src = src; t.p[t.np].dst = (uint16_t)o; t.p[t.np].len = (uint16_t)len;
+        t.np++;
     }
-    return out;
+    o += len;
 }
 
-// the walk's edits that fall into the window [w, w + 16)
-__device__ __forceinline__ uint4 fmt_edits(const FmtRec& o, int w, uint4 out, const uint4* first) {
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-        if (o.e_pos[e] >= 0) {
-            const int ib = o.seg_dst[3] + o.e_pos[e] - w, iq = o.seg_dst[5] + o.e_pos[e] - w;
-            const uint32_t b4 = (o.e_val[e] >> 8) * 0x01010101u, q4 = (o.e_val[e] & 0xffu) * 0x01010101u;
-            if ((o.e_val[e] >> 8) && ib >= 0 && ib < 16 && o.e_pos[e] < o.seg_len[3]) out = sel4(andn4(first[ib + 1], first[ib]), make_uint4(b4, b4, b4, b4), out);
-            if (iq >= 0 && iq < 16 && o.e_pos[e] < o.seg_len[5]) out = sel4(andn4(first[iq + 1], first[iq]), make_uint4(q4, q4, q4, q4), out);
+// the piece list of record r of `file` for this pass (main: good / bad, overlap_pass: the overlap stream)
+__device__ inline void fmt_build(const FormatView& v, uint64_t r, int file, int overlap_pass, FmtTask& t, int* status) {
+    const uint4 w0 = *reinterpret_cast<const uint4*>(v.results + r);
+    const uint4 w1 = *(reinterpret_cast<const uint4*>(v.results + r) + 1);
+    const int flag = (int)(w0.x & 0xffu);
+    const int n_edits = v.plain ? 0 : (int)((w0.x >> 8) & 0xffu);
+    t.np = 0; t.n_patch = 0; t.pad_ = 0; t.items = 0; t.total = 0;
+    if (overlap_pass) t.stream = in_overlap_stream(v, w0, w1) ? 2 : 0xff;
+    else t.stream = flag == AQC_GOOD ? 0 : 1;
+    if (t.stream == 0xff) return;
+    const int len1 = (int)(w0.y & 0xffffu), len2 = (int)(w0.z & 0xffffu), ovl = (int)(w0.w & 0xffffu);
+    const TextFile& tf = v.f[file];
+    const uint32_t name_off = tf.name_off[r], seq_off = tf.seq_off[r], plus_off = tf.plus_off[r], qual_off = tf.qual_off[r];
+    const int nlen = (int)tf.name_len[r], plen = (int)tf.plus_len[r], slen = (int)tf.seq_len[r];
+    // the slice of the original read that is written: the final read, or its last overlap_len bases (getOverlap)
+    const int cut = v.plain ? 0 : (overlap_pass ? (file == 0 ? len1 : len2) - ovl : 0);
+    const int st = v.plain ? 0 : (file == 0 ? (int)(w0.x >> 16) : (int)(w0.y >> 16)) + cut;
+    const int len = v.plain ? slen : (overlap_pass ? ovl : (file == 0 ? len1 : len2));
+    const int flen = t.stream == 1 ? FLAG_TEXT_LEN[flag] : 0;
+    // barcode moved into the name: '@' + [FLAG] + bases[0:mb] + name[cpos:]  (name[str.find(':'):]; find() == -1 slices the last character)
+    const int mb = (v.barcode && !v.plain) ? moved_barcode_len(v, file, flag, w1.w >> 24, (uint32_t)slen) : -1;
+    int cpos = nlen - 1;
+    if (mb >= 0) {
+        const uint8_t* name = tf.text + name_off;
+        for (int i = 0; i < nlen; ++i)
+            if (name[i] == ':') { cpos = i; break; }
+    }
+    const uint32_t NL = FMT_LIT_BIT | (12 * 16);
+    int o = 0;
+    // "@" + FLAG + name[1:] for a bad record (preprocesser.py:213-219), the name itself for a good one
+    const bool renamed = t.stream == 1 || mb >= 0;
+    if (renamed) fmt_add(t, o, 1 + flen, FMT_LIT_BIT | (uint32_t)((t.stream == 1 ? flag : 13) * 16));
+    if (mb >= 0) { fmt_add(t, o, mb, seq_off); fmt_add(t, o, nlen - cpos, name_off + (uint32_t)cpos); }
+    else if (renamed) fmt_add(t, o, nlen - 1, name_off + 1);
+    else fmt_add(t, o, nlen, name_off);
+    // the newlines come from the text where the text has them right there (no stripped whitespace), else from the table
+    fmt_add(t, o, 1, seq_off == name_off + (uint32_t)nlen + 1 ? name_off + (uint32_t)nlen : NL);
+    const int seq_dst = o;
+    fmt_add(t, o, len, seq_off + (uint32_t)st);
+    fmt_add(t, o, 1, plus_off == seq_off + (uint32_t)slen + 1 ? seq_off + (uint32_t)slen : NL);
+    fmt_add(t, o, plen, plus_off);
+    fmt_add(t, o, 1, qual_off == plus_off + (uint32_t)plen + 1 ? plus_off + (uint32_t)plen : NL);
+    const int qual_dst = o;
+    fmt_add(t, o, len, qual_off + (uint32_t)st);
+    fmt_add(t, o, 1, (st + len == slen && tf.text[qual_off + (uint32_t)slen] == '\n') ? qual_off + (uint32_t)slen : NL);
+    if (o > 0xffff) { atomicCAS(status, 0, AQC_ERR_UNSUPPORTED); t.stream = 0xff; return; }      // (a 64 KiB FASTQ record)
+    t.total = (uint16_t)o;
+    int items = 0;
+    for (int k = 0; k < t.np; ++k) items += t.p[k].len >= 16 ? (t.p[k].len + 15) >> 4 : 1;
+    t.items = (uint16_t)items;
+    // the walk's edits in this mate's slice coordinates -> byte patches of the output record
+    const unsigned long long e_lo = ((unsigned long long)w1.y << 32) | w1.x, e_hi = ((unsigned long long)w1.w << 32) | w1.z;
+    for (int e = 0; e < n_edits && e < 3; ++e) {
+        const int bit = 40 * e;
+        unsigned long long x = bit < 64 ? e_lo >> bit : 0ull;
+        if (bit + 40 > 64) x |= bit < 64 ? e_hi << (64 - bit) : e_hi >> (bit - 64);
+        const int oo = (int)(x & 0xffffu);
+        const uint32_t kind = (uint32_t)(x >> 16) & 0xffu, base = (uint32_t)(x >> 24) & 0xffu, qual = (uint32_t)(x >> 32) & 0xffu;
+        const int pp = (file == 0 ? len1 - ovl + oo : len2 - 1 - oo) - cut;
+        if (pp < 0 || pp >= len) continue;
+        if (kind == AQC_EDIT_MASK) t.patch[t.n_patch++] = (uint32_t)(qual_dst + pp) | ((uint32_t)'!' << 16);
+        else if ((kind == AQC_EDIT_FIX_R1 && file == 0) || (kind == AQC_EDIT_FIX_R2 && file == 1)) {
+            if (base) t.patch[t.n_patch++] = (uint32_t)(seq_dst + pp) | (base << 16);
+            t.patch[t.n_patch++] = (uint32_t)(qual_dst + pp) | (qual << 16);
         }
     }
-    return out;
 }
 
-// Writer: one workgroup per tile of 256 records.  Sizing phase: thread = record, block scans give every record's offset in
-// its streams (tile bases from fmt_tile_bases_kernel).  Writing phase: 32 lanes per (record, file); a lane owns 16 output
-// bytes: windows that lie inside one piece are a 16-byte load + a 16-byte store (any alignment on both sides), the few
-// windows that straddle pieces are assembled by fmt_window; the record's last window is end-aligned, so no lane ever
-// writes a byte that is not its record's.
+struct FormatOut {
+    uint8_t* p[6];        // [file * 3 + stream]
+};
+
+template <int N>
+__device__ __forceinline__ void copy_small(uint8_t* d, const uint8_t* s_, int len) {
+    // len in [N, 2N): two overlapping N-byte moves
+    uint8_t a[N], b[N];
+    __builtin_memcpy(a, s_, N);
+    __builtin_memcpy(b, s_ + len - N, N);
+    __builtin_memcpy(d, a, N);
+    __builtin_memcpy(d + len - N, b, N);
+}
+
+// Writer: one workgroup per tile of FMT_TILE records.  Phase A, thread = record: the record's offset in its stream (block
+// scans over the sizes, tile bases from fmt_tile_bases_kernel) and its piece list, into LDS.  Phase B, 32 lanes per
+// (record, file), four records in flight per half-wave: a lane owns one work item — a 16-byte window of a long piece
+// (16-byte load + 16-byte store at any alignment, the piece's last window end-aligned) or a whole short piece — so every
+// load of a record is independent of every other and nothing but the (LDS) piece list is on the critical path.
+constexpr int FMT_UNROLL = 4;
 __global__ __launch_bounds__(FMT_TILE) void fmt_write_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
                                                              const unsigned long long* __restrict__ tile_base, FormatOut outs,
-                                                             int overlap_pass) {
+                                                             int overlap_pass, int* __restrict__ status) {
     __shared__ unsigned long long lds[4];
-    __shared__ unsigned int s_pos[2][FMT_TILE];
-    __shared__ uint4 first[17];
+    __shared__ FmtTask tasks[FMT_TILE * 2];
     const int nfiles = v.paired ? 2 : 1;
     const uint64_t r0 = (uint64_t)blockIdx.x * FMT_TILE;
-    if (threadIdx.x < 17) {
-        const int nb = threadIdx.x;
-        uint32_t m[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int vb = min(max(nb - 4 * k, 0), 4);
-            m[k] = vb >= 4 ? 0xffffffffu : ((1u << (8 * vb)) - 1u);
-        }
-        first[nb] = make_uint4(m[0], m[1], m[2], m[3]);
-    }
-    // ---- sizing: this pass's stream of every record (good / bad differ per record, overlap is its own pass)
+    // ---- phase A
     for (int file = 0; file < nfiles; ++file) {
         uint32_t sz[3] = {0, 0, 0};
         const uint64_t r = r0 + threadIdx.x;
         if (r < n) fmt_sizes(v, r, file, sz);
+        unsigned int pos;
         if (!overlap_pass) {
             // good and bad records interleave: two scans, each record keeps the offset of the stream it goes to
             unsigned long long tg, tb;
@@ -657,53 +656,93 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_write_kernel(FormatView v, uint6
             const unsigned long long eb = block_excl_scan((unsigned long long)sz[1], lds, tb);
             const unsigned long long bg = tile_base[(uint64_t)(file * 3 + 0) * n_tiles + blockIdx.x];
             const unsigned long long bb = tile_base[(uint64_t)(file * 3 + 1) * n_tiles + blockIdx.x];
-            // (offsets inside a chunk's stream fit 32 bits: chunks are < 2 GiB)
-            s_pos[file][threadIdx.x] = sz[1] ? (unsigned int)(bb + eb) : (unsigned int)(bg + eg);
+            pos = sz[1] ? (unsigned int)(bb + eb) : (unsigned int)(bg + eg);      // (offsets inside a chunk's stream fit 32 bits)
         } else {
             unsigned long long to;
             const unsigned long long eo = block_excl_scan((unsigned long long)sz[2], lds, to);
-            s_pos[file][threadIdx.x] = (unsigned int)(tile_base[(uint64_t)(file * 3 + 2) * n_tiles + blockIdx.x] + eo);
+            pos = (unsigned int)(tile_base[(uint64_t)(file * 3 + 2) * n_tiles + blockIdx.x] + eo);
+        }
+        FmtTask& t = tasks[threadIdx.x * nfiles + file];
+        t.stream = 0xff;
+        if (r < n) {
+            fmt_build(v, r, file, overlap_pass, t, status);
+            t.pos = pos;
         }
     }
     __syncthreads();
-    // ---- writing
+    // ---- phase B
     const int lane32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
+    constexpr int NHW = FMT_TILE / 32;
     const int ntask = FMT_TILE * nfiles;
-    for (int task = hw; task < ntask; task += FMT_TILE / 32) {
-        const int rr = task / nfiles, file = task - rr * nfiles;
-        const uint64_t r = r0 + rr;
-        if (r >= n) break;
-        FmtRec o;
-        fmt_record(v, r, file, overlap_pass, lane32, o);
-        if (o.stream < 0) continue;
-        uint8_t* dst = outs.p[file * 3 + o.stream] + s_pos[file][rr];
-        if (o.total < 16) {
-            // (a record of fewer than 16 bytes: byte by byte)
-            const uint4 wv = fmt_edits(o, 0, fmt_window(o, 0, first), first);
-            const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w};
-            if (lane32 < o.total) dst[lane32] = (uint8_t)(ww[lane32 >> 2] >> (8 * (lane32 & 3)));
-            continue;
-        }
-        const int ngroups = (o.total + 15) >> 4;
-        for (int g0 = 0; g0 < ngroups; g0 += 32) {
-            const int g = g0 + lane32;
-            if (g < ngroups) {
-                const int w = min(16 * g, o.total - 16);           // the last window is aligned to the record's end
-                // inside one piece?
-                int k_in = -1;
+    for (int t0 = hw; t0 < ntask; t0 += NHW * FMT_UNROLL) {
+        int max_items = 0;
 #pragma unroll
-                for (int k = 0; k < FMT_NSEG; ++k)
-                    if (o.seg_dst[k] <= w && w + 16 <= o.seg_dst[k] + o.seg_len[k]) k_in = k;
-                uint4 out;
-                if (k_in >= 0) {
-                    const uint8_t* src = k_in == 5 ? o.seg_src[5] : k_in == 3 ? o.seg_src[3] : k_in == 2 ? o.seg_src[2] : k_in == 4 ? o.seg_src[4] : k_in == 1 ? o.seg_src[1] : o.seg_src[0];
-                    const int d0 = k_in == 5 ? o.seg_dst[5] : k_in == 3 ? o.seg_dst[3] : k_in == 2 ? o.seg_dst[2] : k_in == 4 ? o.seg_dst[4] : k_in == 1 ? o.seg_dst[1] : o.seg_dst[0];
-                    out = load16u_t(src + (w - d0));
-                } else {
-                    out = fmt_window(o, w, first);
+        for (int u = 0; u < FMT_UNROLL; ++u) {
+            const int ti = t0 + u * NHW;
+            if (ti < ntask && tasks[ti].stream != 0xff) max_items = max(max_items, (int)tasks[ti].items);
+        }
+        for (int i0 = 0; i0 < max_items; i0 += 32) {
+            uint4 val[FMT_UNROLL];
+            uint8_t* dptr[FMT_UNROLL];
+            const uint8_t* sptr[FMT_UNROLL];
+            int mode[FMT_UNROLL];          // 0 nothing, 16 a window, 1..15 a short piece of that many bytes
+#pragma unroll
+            for (int u = 0; u < FMT_UNROLL; ++u) {
+                const int ti = t0 + u * NHW;
+                mode[u] = 0;
+                dptr[u] = nullptr; sptr[u] = nullptr;
+                val[u] = make_uint4(0, 0, 0, 0);
+                if (ti >= ntask) continue;
+                const FmtTask& t = tasks[ti];
+                const int item = i0 + lane32;
+                if (t.stream == 0xff || item >= (int)t.items) continue;
+                // which piece does this item belong to?
+                int k = 0, first_item = 0;
+                for (; k < (int)t.np; ++k) {
+                    const int cnt = t.p[k].len >= 16 ? (t.p[k].len + 15) >> 4 : 1;
+                    if (item < first_item + cnt) break;
+                    first_item += cnt;
                 }
-                if (o.n_edits) out = fmt_edits(o, w, out, first);
-                store16u(dst + w, out);
+                const FmtPiece pc = t.p[k];
+                const int file = nfiles == 2 ? (ti & 1) : 0;
+                const uint8_t* src = (pc.src & FMT_LIT_BIT) ? &FMT_LIT[0][0] + (pc.src & ~FMT_LIT_BIT) : v.f[file].text + pc.src;
+                uint8_t* dst = outs.p[file * 3 + t.stream] + t.pos + pc.dst;
+                if (pc.len >= 16) {
+                    const int off = min(16 * (item - first_item), (int)pc.len - 16);        // the last window is aligned to the piece's end
+                    sptr[u] = src + off; dptr[u] = dst + off; mode[u] = 16;
+                    val[u] = load16u_t(sptr[u]);
+                } else {
+                    sptr[u] = src; dptr[u] = dst; mode[u] = (int)pc.len;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FMT_UNROLL; ++u) {
+                if (mode[u] == 16) store16u(dptr[u], val[u]);
+                else if (mode[u] >= 8) copy_small<8>(dptr[u], sptr[u], mode[u]);
+                else if (mode[u] >= 4) copy_small<4>(dptr[u], sptr[u], mode[u]);
+                else if (mode[u] >= 2) copy_small<2>(dptr[u], sptr[u], mode[u]);
+                else if (mode[u] == 1) dptr[u][0] = sptr[u][0];
+            }
+        }
+        // the walk's edits: byte patches on top of the copies (the copies of this wave are complete first)
+        bool any_patch = false;
+#pragma unroll
+        for (int u = 0; u < FMT_UNROLL; ++u) {
+            const int ti = t0 + u * NHW;
+            if (ti < ntask && tasks[ti].stream != 0xff && tasks[ti].n_patch) any_patch = true;
+        }
+        if (any_patch) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+            for (int u = 0; u < FMT_UNROLL; ++u) {
+                const int ti = t0 + u * NHW;
+                if (ti >= ntask) continue;
+                const FmtTask& t = tasks[ti];
+                if (t.stream == 0xff || lane32 >= (int)t.n_patch) continue;
+                const int file = nfiles == 2 ? (ti & 1) : 0;
+                const uint32_t pt = t.patch[lane32];
+                outs.p[file * 3 + t.stream][t.pos + (pt & 0xffffu)] = (uint8_t)(pt >> 16);
             }
         }
     }

@@ -265,6 +265,46 @@ def write_fastq(path, names, seq, qual, lens, plus="+"):
         f.write(b"".join(buf))
 
 
+def fixed_record_width(L, tile=1101, mate=1):
+    """bytes of one record as render_fastq_fixed / write_fastq_fixed lay it out"""
+    return len("@SIM:1:FC1:1:%d:" % tile) + 7 + 1 + 5 + len(" %d:N:0:ACGT\n" % mate) + L + 1 + 2 + L + 1
+
+
+def render_fastq_fixed(seq, qual, mate=1, tile=1101, out=None, index0=0):
+    """The text write_fastq_fixed writes, rendered into memory (numpy uint8, e.g. a page-locked HostBuffer.array): returns
+    (array, nbytes).  index0 = global index of record 0 (names carry it modulo 10^7)."""
+    n, L = seq.shape
+    w = fixed_record_width(L, tile, mate)
+    if out is None:
+        out = np.empty(n * w + 64, dtype=np.uint8)
+    assert out.size >= n * w
+    head = np.frombuffer(("@SIM:1:FC1:1:%d:" % tile).encode(), dtype=np.uint8)
+    tail = np.frombuffer((" %d:N:0:ACGT\n" % mate).encode(), dtype=np.uint8)
+    chunk = 1 << 18
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        m = out[a * w:b * w].reshape(b - a, w)
+        idx = (np.arange(a, b, dtype=np.int64) + index0)
+        c = 0
+        m[:, c:c + len(head)] = head; c += len(head)
+        x = idx % 10 ** 7
+        for d in range(7):
+            m[:, c + 6 - d] = (x // (10 ** d)) % 10 + 48
+        c += 7
+        m[:, c] = ord(":"); c += 1
+        y = (idx * 7919) % 100000
+        for d in range(5):
+            m[:, c + 4 - d] = (y // (10 ** d)) % 10 + 48
+        c += 5
+        m[:, c:c + len(tail)] = tail; c += len(tail)
+        m[:, c:c + L] = seq[a:b]; c += L
+        m[:, c] = 10; c += 1
+        m[:, c] = ord("+"); m[:, c + 1] = 10; c += 2
+        m[:, c:c + L] = qual[a:b]; c += L
+        m[:, c] = 10
+    return out, n * w
+
+
 def write_fastq_fixed(path, seq, qual, mate=1, tile=1101):
     """Fixed-length reads as FASTQ text, vectorised (benchmarks: millions of records).  Names follow SURVEY.md
     §8d: @SIM:1:FC1:1:<tile>:<x = 7-digit record index>:<y> <mate>:N:0:ACGT"""

@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py — Mreads/s of the AfterQC hot path on MI355X (BASELINE.json metric).
+"""bench.py — Mreads/s of the AfterQC hot path on MI355X (BASELINE.json metric), one process per GPU.
 
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (aqc_run: filter / trim / overlap / correction over every pair of
-the batch, plus the post-filter QC accumulation over the first qc_sample-1 records exactly as
-seqFilter.run issues it for a file's first batch) over one batch of synthetic 2x150 bp pairs that is
-already resident in HBM when the timed region starts.  Workload = BASELINE.json configs[2]
-("10M synthetic paired-end 2x150 bp reads ... full overlap-detect + base-correction, 1xMI355X",
-SURVEY.md §8d config 3, seed 1003): 5 M pairs = 10 M reads per GPU; with N GPUs every rank holds its own
-5 M pairs (independent shards, no collective on the data path -> weak scaling).
+Workload = BASELINE.json configs[2] (seed 1003): 5 M synthetic 2x150 bp pairs = 10 M reads per
+GPU, as RAW FASTQ TEXT (two mate files' worth, 1.7 GB each).  With N GPUs the ranks hold the chunks r, r+N, r+2N, ... of one
+5 M x N pair input (every chunk carries its global first_index; independent shards, no collective on the data path ->
+weak scaling; the statistics are summed on the host at the end).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event kernel time,
-algorithmic bytes 4L+56 per pair) and, at N=1, `cpu_baseline` (the oracle = scalar C port of the
-reference loop, timed on one host core over a bounded sample of the same workload).
+Three measurements of the good / bad split of that text, all in the one JSON line rank 0 prints:
+
+  value (the metric)           one STEP = the whole device pipeline over the text RESIDENT IN HBM: record framing
+                               (aqc_reframe: line index + 4-line records, fastq.py:37-49) -> verdicts (aqc_run: the loop of
+                               preprocesser.py:436-617) -> post-filter QC sampling (aqc_qc_stat, first qc_sample records) ->
+                               good / bad FASTQ text built in HBM (aqc_format, preprocesser.py:206-232).  Nothing is
+                               pre-digested: the step starts from bytes and ends with bytes.
+  pinned_to_pinned_mreads_s    the same work fed from page-locked HOST memory through the whole-input pipe (aqc_pipe_run:
+                               chunks of 131072 records, H2D / kernels / D2H of different chunks overlapped over three slots),
+                               outputs fetched into page-locked buffers — PCIe inclusive, all ranks at once
+  file_to_file_mreads_s        the pipe from two FASTQ files to the four good / bad files (page cache / tmpfs), all ranks at once
+
+`roofline` is for the dominant kernel of the step (fast_filter_overlap_kernel): HIP-event time of the aqc_run launches on
+the slot's stream, algorithmic bytes 4L+56 per pair.  `cpu_baseline` (N=1): the oracle (scalar C port of
+the reference loop) on one core over a bounded sample, checked against the GPU's verdicts.
 """
 import argparse
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,7 +39,6 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 L = 150
-BYTES_PER_PAIR = 4 * L + 56    # 2 seq + 2 qual + 2x12 B descriptors + 32 B result
 
 
 def main():
@@ -39,9 +49,12 @@ def main():
     ap.add_argument("--pairs", type=int, default=5_000_000, help="pairs per GPU (default: config 3 = 10 M reads)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs timed on the CPU baseline (0 = skip)")
     ap.add_argument("--qc-sample", type=int, default=200_000)
+    ap.add_argument("--chunk-records", type=int, default=1 << 17, help="records per chunk of the pipe measurements")
+    ap.add_argument("--pipe-runs", type=int, default=3, help="timed runs of the pinned->pinned pipe (0 = skip)")
+    ap.add_argument("--file-runs", type=int, default=1, help="timed file-to-file runs (0 = skip)")
     ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5"],
                     help="config3 (default, the metric's workload): PE 2x150; config2: SE 1x150 filter+trim only; "
-                         "config5-like: PE 2x250 (no barcode/gzip) — the non-default ones are for DESIGN.md numbers")
+                         "config5: PE 2x250 + 17-base barcode / verify prefix, barcode mode on (no gzip here: tools/e2e_bench.py)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -52,8 +65,7 @@ def main():
     import numpy as np
     from afterqc_amd import capi, synth
 
-    # ---- workload: seed 1003 (+rank: independent shards).  Generated with forked numpy workers, so it
-    # happens BEFORE torch / the HIP runtime are loaded into this process.
+    # ---- workload (generated with forked numpy workers BEFORE torch / the HIP runtime are loaded into this process)
     t_gen = time.time()
     nworkers = max(1, (os.cpu_count() or 8) // max(1, world))
     paired = args.workload != "config2"
@@ -62,10 +74,10 @@ def main():
         d = synth.make_pairs(args.pairs, RL, seed=(1003 if RL == L else 1005) + rank, workers=nworkers)
         if args.workload == "config5":
             d = synth.add_barcodes(d, 1005 + 7 + rank)      # 17-base barcode + verify prefix on both mates
-        batch = capi.Batch.from_matrices(d["seq1"], d["qual1"], d["len1"], d["seq2"], d["qual2"], d["len2"])
     else:
         d = synth.make_single(2 * args.pairs, RL, seed=1002 + rank, workers=nworkers)
-        batch = capi.Batch.from_matrices(d["seq1"], d["qual1"], d["len1"])
+    n_rec = len(d["len1"])
+    W = d["seq1"].shape[1]
     t_gen = time.time() - t_gen
 
     import torch  # plumbing only (barrier / max-over-ranks); loaded before libafterqc_hip.so so both share one HIP runtime
@@ -93,84 +105,181 @@ def main():
     if args.workload == "config5":
         cfg.barcode = 1
 
-    eng = capi.Engine(device_index, 1)
+    eng = capi.Engine(device_index, 3)
     eng.set_config(cfg)
     eng.reset_stats()
-    t_up = time.perf_counter()
-    eng.upload(0, batch)          # inputs resident in HBM before the timed region
-    eng.sync(0)
-    t_up = time.perf_counter() - t_up   # host -> HBM incl. canonicalisation; reported, never part of `value`
-    n_qc = max(0, min(batch.n, args.qc_sample - 1))
 
-    def step():
-        eng.run(0)
-        if n_qc:
-            eng.qc_stat(0, capi.QC_R1_POST, 0, 0, n_qc, 1)
-            if paired:
-                eng.qc_stat(0, capi.QC_R2_POST, 1, 0, n_qc, 1)
+    # ---- the input as raw FASTQ text in page-locked host memory (what a reader thread would have produced)
+    t_txt = time.time()
+    w = synth.fixed_record_width(W)
+    texts = []
+    for mate in ((1, 2) if paired else (1,)):
+        hb = eng.host_buffer(n_rec * w + 4096)
+        _, nbytes = synth.render_fastq_fixed(d["seq%d" % mate], d["qual%d" % mate], mate, out=hb.array, index0=rank * n_rec)
+        texts.append((hb, nbytes))
+    t_txt = time.time() - t_txt
+    K = args.chunk_records
+    # this rank's text holds the chunks rank, rank + world, ... of the N-GPU input; for the one-chunk step its records are
+    # simply numbered from rank * n_rec (the sampling rule only looks at indices below qc_sample)
+    first_index = rank * n_rec
 
     def barrier():
-        eng.sync(0)
         torch.cuda.synchronize() if torch.cuda.is_available() else None
         if dist is not None:
             dist.barrier()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ================= A. the step: text resident in HBM -> good / bad text in HBM ==========================================
+    # (a chunk is < 2 GiB of text per mate: 5 M records of 347 bytes fit one chunk, longer inputs are spread over the slots)
+    per_slot = min(n_rec, int(1.9e9 // w))
+    n_res = (n_rec + per_slot - 1) // per_slot
+    assert n_res <= eng.n_slots, "input too large to keep resident in %d slots" % eng.n_slots
+    t_up = time.perf_counter()
+    res_n = []
+    for sl in range(n_res):
+        lo, hi = sl * per_slot, min(n_rec, (sl + 1) * per_slot)
+        views = [(t[0].array[lo * w:], (hi - lo) * w) for t in texts]
+        if paired:
+            info = eng.frame(sl, views[0][0], views[0][1], True, views[1][0], views[1][1], True, first_index=first_index + lo)
+        else:
+            info = eng.frame(sl, views[0][0], views[0][1], True, first_index=first_index + lo)
+        assert int(info.n) == hi - lo, (int(info.n), hi - lo)
+        res_n.append((lo, hi))
+    for sl in range(n_res):
+        eng.sync(sl)
+    t_up = time.perf_counter() - t_up          # host -> HBM + first framing (reported, never part of `value`)
+
+    def step():
+        total = [0] * 6
+        for sl, (lo, hi) in enumerate(res_n):
+            eng.reframe(sl)
+            eng.run(sl)
+            n_qc = (hi - lo) if args.qc_sample <= 0 else max(0, min(hi - lo, args.qc_sample - 1 - (first_index + lo)))
+            if n_qc > 0:
+                eng.qc_stat(sl, capi.QC_R1_POST, 0, 0, n_qc, 1)
+                if paired:
+                    eng.qc_stat(sl, capi.QC_R2_POST, 1, 0, n_qc, 1)
+            sz = eng.format(sl, hi - lo, False)     # (returns once the sizes are known; the writer kernel is still queued)
+            total = [a + b for a, b in zip(total, sz)]
+        return total
+
+    def sync_all():
+        for sl in range(n_res):
+            eng.sync(sl)
+
     for _ in range(args.warmup):
         step()
+    sync_all()
     barrier()
-    eng.timing_reset(0)
+    for sl in range(n_res):
+        eng.timing_reset(sl)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    eng.sync(0)
+        sizes = step()
+    sync_all()
     if torch.cuda.is_available():
         torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     kms, klaunch = eng.timing_mean(0)
+    for sl in range(1, n_res):
+        k2, l2 = eng.timing_mean(sl)
+        kms = kms + k2                    # per step the kernel runs once per resident chunk: times add up
     counters = eng.counters()
+    res_gpu = eng.fetch_results(0) if (rank == 0 and world == 1 and args.cpu_sample > 0 and paired) else None
 
+    reads_per_gpu = n_rec * (2 if paired else 1)
     ms_per_step = 1000.0 * elapsed / max(1, args.steps)
-    reads_total = 2 * args.pairs * world
-    records = batch.n
+    value = reads_per_gpu * world / (elapsed / max(1, args.steps)) / 1e6
     bytes_per_record = (4 * RL + 56) if paired else (2 * RL + 20)
-    value = reads_total / (elapsed / max(1, args.steps)) / 1e6
-
     k_ms = float(kms[capi.K_FILTER_OVERLAP])
-    achieved = records * bytes_per_record / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
+    achieved = n_rec * bytes_per_record / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    text_in = sum(t[1] for t in texts)
+    text_out = int(sum(sizes))
+    good_frac = float(counters[capi.C_GOOD_READS]) / max(1.0, float(counters[capi.C_TOTAL_READS]))
+
+    # ================= B. page-locked host memory -> pipe -> page-locked host memory (PCIe inclusive) =======================
+    pipe = capi.Pipe([eng], slots=3)
+    inputs = [(t[0].array, t[1]) for t in texts]
+    pinned = None
+    if args.pipe_runs > 0:
+        ts = []
+        for it in range(args.pipe_runs + 1):            # the first run allocates the page-locked rings: not timed
+            eng.reset_stats()
+            barrier()
+            t1 = time.perf_counter()
+            pr = pipe.run(inputs, outputs=None, chunk_records=K, qc_sample=args.qc_sample, chunk_index0=rank, chunk_index_stride=world)
+            dt = max_over_ranks(time.perf_counter() - t1)
+            assert not pr.anomaly and int(pr.records) == n_rec
+            if it:
+                ts.append(dt)
+        best = min(ts)
+        pinned = {"mreads_s": round(reads_per_gpu * world / best / 1e6, 2), "seconds": round(best, 4), "runs": len(ts),
+                  "gb_s_each_way_per_gpu": round(text_in / best / 1e9, 2), "chunk_records": K}
+
+    # ================= C. file -> pipe -> file ================================================================================
+    f2f = None
+    if args.file_runs > 0:
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 3 * (text_in + text_out) * world else None
+        work = tempfile.mkdtemp(prefix="aqc_bench_%d_" % rank, dir=base)
         try:
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("pairs") == args.pairs and args.workload == "config3":
-                traffic = tj.get("bytes_per_launch")
-        except Exception:
-            traffic = None
+            paths = []
+            for k, t in enumerate(texts):
+                p = os.path.join(work, "R%d.fq" % (k + 1))
+                with open(p, "wb") as f:
+                    f.write(memoryview(t[0].array)[:t[1]])
+                paths.append(p)
+            outs = [(os.path.join(work, "R%d.good.fq" % (k + 1)), os.path.join(work, "R%d.bad.fq" % (k + 1)), None) for k in range(len(texts))]
+            ts = []
+            for it in range(args.file_runs + 1):
+                eng.reset_stats()
+                barrier()
+                t1 = time.perf_counter()
+                pr = pipe.run(paths, outs, chunk_records=K, qc_sample=args.qc_sample, chunk_index0=rank, chunk_index_stride=world)
+                dt = max_over_ranks(time.perf_counter() - t1)
+                assert not pr.anomaly and int(pr.records) == n_rec
+                if it:
+                    ts.append(dt)
+            best = min(ts)
+            f2f = {"mreads_s": round(reads_per_gpu * world / best / 1e6, 2), "seconds": round(best, 4), "runs": len(ts),
+                   "where": "tmpfs" if base else "tmp dir (page cache)", "input_gb_per_gpu": round(text_in / 1e9, 3),
+                   "output_gb_per_gpu": round(sum(int(x) for x in pr.bytes_out) / 1e9, 3)}
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+    pipe.close()
+
+    wl = {"config3": "config3: %d synthetic PE 2x150 bp pairs per GPU (%.1f M reads) as raw FASTQ text (%.2f GB), seed 1003+rank, "
+                     "overlap ~N(30,8), 3%% adapter read-through, defaults with -f 0 -t 0, qc_sample %d"
+                     % (n_rec, reads_per_gpu / 1e6, text_in / 1e9, args.qc_sample),
+          "config2": "config2: %d synthetic SE 1x150 bp reads per GPU as raw FASTQ text, -f 5 -t 5, qc_sample %d" % (n_rec, args.qc_sample),
+          "config5": "config5 (no gzip): %d synthetic PE 2x250 bp pairs + 17-base barcode/verify prefix per GPU as raw FASTQ text, barcode "
+                     "mode, qc_sample %d" % (n_rec, args.qc_sample)}[args.workload]
     out = {
         "metric": "Mreads/s (paired 2x150 bp) end-to-end good/bad split",
         "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": ("config3: %d synthetic PE 2x150 bp pairs per GPU (%.1f M reads), seed 1003+rank, overlap ~N(30,8), "
-                                "3%% adapter read-through, defaults with -f 0 -t 0, qc_sample %d; inputs resident in HBM"
-                                % (args.pairs, 2 * args.pairs / 1e6, args.qc_sample)) if args.workload == "config3" else
-                               ("%s: %d records of length %d per GPU, qc_sample %d; inputs resident in HBM" % (args.workload, records, RL, args.qc_sample)),
-                   "pairs_per_gpu": args.pairs, "read_len": RL, "parallelism": "independent shards x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "filter_overlap_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "config": {"workload": wl + "; step = FASTQ text resident in HBM -> record framing -> filter / overlap / correction verdicts -> "
+                                    "post-filter QC sampling -> good / bad FASTQ text in HBM",
+                   "pairs_per_gpu": args.pairs, "read_len": RL, "parallelism": "independent shards x%d (chunks dealt round robin, no collective)" % world,
+                   "text_in_gb_per_gpu": round(text_in / 1e9, 3), "text_out_gb_per_gpu": round(text_out / 1e9, 3)},
+        "roofline": {"bound": "hbm", "kernel": "fast_filter_overlap_kernel (+ its deferral list kernel)", "achieved": round(achieved, 2),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                     "traffic": None,    # HBM counter bytes are collected in separate rocprofv3 --pmc passes: profiles/
                      "kernel_ms": round(k_ms, 4), "launches": int(klaunch[capi.K_FILTER_OVERLAP]),
-                     "algorithmic_bytes_per_launch": records * bytes_per_record,
-                     "qc_stat_kernel_ms": round(float(kms[capi.K_QC_STAT]), 4)},
-        "good_reads_frac": round(float(counters[capi.C_GOOD_READS]) / max(1, float(counters[capi.C_TOTAL_READS])), 5),
-        "gen_s": round(t_gen, 1),
-        "upload_s": round(t_up, 3),
-        "pcie_inclusive_mreads_s": round(2 * args.pairs / (t_up + elapsed / max(1, args.steps)) / 1e6, 1),
+                     "algorithmic_bytes_per_launch": n_rec * bytes_per_record,
+                     "qc_stat_ms_per_call": round(float(kms[capi.K_QC_STAT]), 4),
+                     "step_text_gb_s": round((text_in + text_out) / (ms_per_step * 1e-3) / 1e9, 1)},
+        "pinned_to_pinned_mreads_s": pinned["mreads_s"] if pinned else None,
+        "file_to_file_mreads_s": f2f["mreads_s"] if f2f else None,
+        "pinned_to_pinned": pinned, "file_to_file": f2f,
+        "good_reads_frac": round(good_frac, 5),
+        "gen_s": round(t_gen, 1), "text_render_s": round(t_txt, 1), "first_upload_s": round(t_up, 3),
     }
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle, 1 core, bounded sample of the same workload
@@ -185,10 +294,10 @@ def main():
         oe.run(0)
         tc = time.perf_counter() - tc
         # cross-check while we are here: same verdicts as the GPU for the sample
-        same = bool(np.array_equal(oe.fetch_results(0), eng.fetch_results(0)[:m]))
+        same = bool(np.array_equal(oe.fetch_results(0), res_gpu[:m]))
         out["cpu_baseline"] = {"value": round(2 * m / tc / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
-                               "sample": "first %d pairs of the same batch, oracle/aqc_oracle.c (scalar C restatement of "
-                                         "preprocesser.py:411-631), filter+overlap+correction only, %.1f s" % (m, tc),
+                               "sample": "first %d pairs of the same input, oracle/aqc_oracle.c (scalar C restatement of "
+                                         "preprocesser.py:411-631), filter+overlap+correction only (no text framing / formatting), %.1f s" % (m, tc),
                                "matches_gpu": same, "host_cpus": os.cpu_count()}
         # the same port on every host core (independent slices, one oracle context per thread; the C call releases the
         # GIL): SURVEY.md §8d asks for the 1-core and the all-cores figure side by side
@@ -220,7 +329,7 @@ def main():
             tp = time.perf_counter()
             py = pyloop.run_batch(sub, cfg, 0, mp)
             tp = time.perf_counter() - tp
-            gflags = eng.fetch_results(0)[:mp]["flag"]
+            gflags = res_gpu[:mp]["flag"]
             out["cpu_baseline"]["cpython_standin"] = {
                 "value": round(2 * mp / tp / 1e6, 5), "unit": "Mreads/s", "cores": 1,
                 "sample": "first %d pairs, oracle/pyloop.py (pure-Python restatement of the reference loop), %.1f s" % (mp, tp),
@@ -229,6 +338,8 @@ def main():
             out["cpu_baseline"]["cpython_standin"] = {"error": str(e)}
     if rank == 0:
         print(json.dumps(out))
+    for t in texts:
+        t[0].free()
     eng.close()
     if dist is not None:
         dist.barrier()

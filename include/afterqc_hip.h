@@ -282,6 +282,9 @@ typedef struct aqc_frame_info {
 } aqc_frame_info;
 
 int aqc_frame(aqc_ctx* ctx, int slot, const aqc_text_chunk* chunk, aqc_frame_info* info);
+/* the same framing again over the text the slot already holds in HBM (no host copy): line index + record framing of the
+ * chunk of the last aqc_frame.  For measurements with the input resident in HBM (bench.py). */
+int aqc_reframe(aqc_ctx* ctx, int slot, aqc_frame_info* info);
 /* seqFilter.writeReads (preprocesser.py:206-232) + fastq.Writer.writeLines (fastq.py:87-93) for records
  * [0, n) of a framed slot after aqc_run: builds, in record order, the text of the good and of the bad output
  * of each file (name / bases / strand line / qualities + "\n"; bad names "@" + FLAG + name[1:]; trimmed
