@@ -19,6 +19,7 @@
 // is detected from the frame info and reported as `anomaly`; the caller then reruns the input through the serial
 // chunk loop, which reproduces the reference's reader semantics case by case.
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -51,6 +52,7 @@ char g_pipe_err[512] = "";
 std::mutex g_pipe_err_mu;
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // small thread pool for I/O-side work (pread pieces, newline counts, deflate / inflate of independent blocks)
@@ -429,6 +431,31 @@ struct GzSource : Source {
     }
 };
 
+// An output file.  Measured on the MI355X host (tools/ubench/file_write_rate.cpp): ONE thread issuing large sequential
+// write()s fills a file at 6 GB/s (tmpfs) .. 11 GB/s (page cache); several threads pwrite()-ing disjoint ranges of the same
+// file, or storing into a shared mapping of it, are 2-5x SLOWER (they fight over the file's page-cache lock).  So every
+// output file gets its own writer thread and sees nothing but big sequential writes.
+struct OutFile {
+    int fd = -1;
+    uint64_t pos = 0;
+    bool open_(const char* path) {
+        fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        return fd >= 0;
+    }
+    bool append(const uint8_t* p, size_t n) {
+        while (n) {
+            const ssize_t w = ::write(fd, p, std::min<size_t>(n, 1u << 30));
+            if (w <= 0) return false;
+            p += w; n -= (size_t)w; pos += (uint64_t)w;
+        }
+        return true;
+    }
+    void close_() {
+        if (fd >= 0) close(fd);
+        fd = -1;
+    }
+};
+
 struct HostBuf {
     uint8_t* p = nullptr;
     size_t cap = 0;
@@ -513,11 +540,9 @@ struct Run {
     std::condition_variable qc_cv;
     uint64_t qc_next = 0;
     // outputs
-    int out_fd[6] = {-1, -1, -1, -1, -1, -1};
-    uint64_t out_pos[6] = {0, 0, 0, 0, 0, 0};
+    OutFile out[6];
     std::atomic<uint64_t> records{0};
-    uint64_t extra_bases = 0;
-    double t_gpu = 0;
+    std::atomic<uint64_t> ns_read{0}, ns_count{0}, ns_frame{0}, ns_kernels{0}, ns_fetch{0}, ns_write{0}, ns_wait_set{0}, ns_wait_ring{0};
 
     void fail(int code, const char* fmt, ...) {
         char buf[400];
@@ -539,6 +564,7 @@ struct Run {
         }
         for (auto& q : jobq) q->close();
         outq.close();
+        for (int q = 0; q < 6; ++q) if (fileq[q]) fileq[q]->close();
         set_cv.notify_all();
         qc_cv.notify_all();
     }
@@ -613,7 +639,9 @@ struct Run {
                 if (c.final && bytes > 0 && base[bytes - 1] != '\n' && lines < want_lines) c.lines += 1;     // unterminated last line
                 c.buf = -1;
             } else {
+                const uint64_t tw = now_ns();
                 const int bi = acquire_ring(f);
+                ns_wait_ring += now_ns() - tw;
                 if (bi < 0) return;
                 HostBuf& hb = P->in_buf[f][bi];
                 size_t cap = (size_t)(est * 1.02 * (double)K) + (256 << 10);
@@ -629,7 +657,9 @@ struct Run {
                 for (;;) {
                     if (!eof && fill < hb.cap) {
                         const size_t want = std::min(hb.cap, cap) - fill;
+                        const uint64_t tr = now_ns();
                         const size_t got = want ? src->read(hb.p + fill, want) : 0;
+                        ns_read += now_ns() - tr;
                         if (src->failed()) { fail(AQC_ERR_ARG, "read error on %s", io->in_path[f]); return; }
                         if (got < want) eof = true;
                         fill += got;
@@ -638,10 +668,12 @@ struct Run {
                     const size_t nb = (fill + SUB - 1) / SUB;
                     const size_t from = counted_blocks ? counted_blocks - 1 : 0;
                     cnt.resize(nb);
+                    const uint64_t tcn = now_ns();
                     P->pool->parallel_for(nb - from, [&](size_t i) {
                         const size_t o = (from + i) * SUB;
                         cnt[from + i] = (uint32_t)count_nl(hb.p + o, std::min(SUB, fill - o));
                     });
+                    ns_count += now_ns() - tcn;
                     counted_blocks = nb;
                     lines = 0;
                     for (auto v : cnt) lines += v;
@@ -719,7 +751,10 @@ struct Run {
             ch.max_records = UINT64_MAX;
             ch.first_index = (opt->chunk_index0 + j.idx * (opt->chunk_index_stride ? opt->chunk_index_stride : 1)) * K;
             aqc_frame_info info{};
+            uint64_t tt = now_ns();
             int rc = aqc_frame(c, slot, &ch, &info);
+            ns_frame += now_ns() - tt;
+            tt = now_ns();
             // the text has left the host buffers
             for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf);
             if (rc) { fail(rc, "aqc_frame: %s", aqc_last_error()); return; }
@@ -760,6 +795,8 @@ struct Run {
             oc.worker = wid;
             if (!opt->no_output) {
                 if ((rc = aqc_format(c, slot, n, opt->store_overlap, oc.sizes))) { fail(rc, "aqc_format: %s", aqc_last_error()); return; }
+                ns_kernels += now_ns() - tt;
+                tt = now_ns();
                 // wait for the writer to hand this buffer set back
                 {
                     std::unique_lock<std::mutex> lk(set_mu);
@@ -767,6 +804,8 @@ struct Run {
                     if (abort) return;
                     set_free[wid * 2 + set] = 0;
                 }
+                ns_wait_set += now_ns() - tt;
+                tt = now_ns();
                 for (int q = 0; q < 6; ++q) {
                     if (!oc.sizes[q]) continue;
                     HostBuf& hb = P->wbufs[wid].out[set][q];
@@ -774,6 +813,7 @@ struct Run {
                     if (!hb.p) { fail(AQC_ERR_HIP, "page-locked allocation failed"); return; }
                     if ((rc = aqc_fetch_text(c, slot, q / 3, q % 3, hb.p, hb.cap))) { fail(rc, "aqc_fetch_text: %s", aqc_last_error()); return; }
                 }
+                ns_fetch += now_ns() - tt;
                 oc.set = set;
                 set ^= 1;
             } else {
@@ -808,47 +848,50 @@ struct Run {
         out.resize(bsize);
     }
 
-    bool write_all(int fd, const uint8_t* p, size_t n, uint64_t off) {
-        const size_t piece = 8 << 20;
-        const size_t k = (n + piece - 1) / piece;
-        std::atomic<bool> bad{false};
-        P->pool->parallel_for(k, [&](size_t i) {
-            size_t o = i * piece;
-            const size_t end = std::min(n, o + piece);
-            while (o < end) {
-                const ssize_t w = pwrite(fd, p + o, end - o, (off_t)(off + o));
-                if (w <= 0) { bad = true; return; }
-                o += (size_t)w;
-            }
-        });
-        return !bad;
+    // a committed chunk on its way through the per-file writer threads; the last one to finish hands the buffer set back
+    struct Commit {
+        OutChunk oc;
+        std::atomic<int> remaining{0};
+    };
+    std::unique_ptr<BQueue<std::shared_ptr<Commit>>> fileq[6];
+
+    void release_set(const OutChunk& oc) {
+        if (oc.set < 0) return;
+        {
+            std::lock_guard<std::mutex> g(set_mu);
+            set_free[oc.worker * 2 + oc.set] = 1;
+        }
+        set_cv.notify_all();
     }
 
-    void commit(const OutChunk& oc) {
-        if (oc.set < 0) return;
-        for (int q = 0; q < 6; ++q) {
-            res->bytes_out[q] += oc.sizes[q];
-            if (!oc.sizes[q] || out_fd[q] < 0) continue;
-            const uint8_t* p = P->wbufs[oc.worker].out[oc.set][q].p;
-            if (!io->gzip_out) {
-                if (!write_all(out_fd[q], p, oc.sizes[q], out_pos[q])) { fail(AQC_ERR_ARG, "write error on output %d", q); return; }
-                out_pos[q] += oc.sizes[q];
-            } else {
-                const size_t blk = 0xff00;                    // BGZF: at most 64 KiB of text per member
-                const size_t nb = (oc.sizes[q] + blk - 1) / blk;
-                std::vector<std::vector<uint8_t>> z(nb);
-                P->pool->parallel_for(nb, [&](size_t i) {
-                    const size_t o = i * blk;
-                    bgzf_block(p + o, std::min<size_t>(blk, oc.sizes[q] - o), io->gzip_level, z[i]);
-                });
-                size_t total = 0;
-                for (auto& b : z) total += b.size();
-                std::vector<uint8_t> cat(total);
-                size_t o = 0;
-                for (auto& b : z) { memcpy(cat.data() + o, b.data(), b.size()); o += b.size(); }
-                if (!write_all(out_fd[q], cat.data(), total, out_pos[q])) { fail(AQC_ERR_ARG, "write error on output %d", q); return; }
-                out_pos[q] += total;
+    void file_writer(int q) {
+        std::shared_ptr<Commit> cm;
+        while (fileq[q]->pop(cm)) {
+            const OutChunk& oc = cm->oc;
+            const uint64_t tw = now_ns();
+            if (!abort && oc.sizes[q]) {
+                const uint8_t* p = P->wbufs[oc.worker].out[oc.set][q].p;
+                bool ok = true;
+                if (!io->gzip_out) ok = out[q].append(p, (size_t)oc.sizes[q]);
+                else {
+                    const size_t blk = 0xff00;                    // BGZF: at most 64 KiB of text per member
+                    const size_t nb = (oc.sizes[q] + blk - 1) / blk;
+                    std::vector<std::vector<uint8_t>> z(nb);
+                    P->pool->parallel_for(nb, [&](size_t i) {
+                        const size_t o = i * blk;
+                        bgzf_block(p + o, std::min<size_t>(blk, oc.sizes[q] - o), io->gzip_level, z[i]);
+                    });
+                    size_t total = 0;
+                    for (auto& b : z) total += b.size();
+                    std::vector<uint8_t> cat(total);
+                    size_t o = 0;
+                    for (auto& b : z) { memcpy(cat.data() + o, b.data(), b.size()); o += b.size(); }
+                    ok = out[q].append(cat.data(), total);
+                }
+                if (!ok) fail(AQC_ERR_ARG, "write error on output %d (disk full?)", q);
             }
+            ns_write += now_ns() - tw;
+            if (cm->remaining.fetch_sub(1) == 1) release_set(oc);
         }
     }
 
@@ -862,13 +905,18 @@ struct Run {
             while (!pending.empty() && pending.begin()->first == next) {
                 OutChunk cur = pending.begin()->second;
                 pending.erase(pending.begin());
-                if (!abort) commit(cur);
-                if (cur.set >= 0) {
-                    {
-                        std::lock_guard<std::mutex> g(set_mu);
-                        set_free[cur.worker * 2 + cur.set] = 1;
-                    }
-                    set_cv.notify_all();
+                auto cm = std::make_shared<Commit>();
+                cm->oc = cur;
+                int live = 0;
+                for (int q = 0; q < 6; ++q) {
+                    res->bytes_out[q] += cur.sizes[q];
+                    if (cur.set >= 0 && cur.sizes[q] && out[q].fd >= 0) ++live;
+                }
+                if (live == 0 || abort) release_set(cur);
+                else {
+                    cm->remaining = live;
+                    for (int q = 0; q < 6; ++q)
+                        if (cur.sizes[q] && out[q].fd >= 0) fileq[q]->push(cm);
                 }
                 res->chunks += 1;
                 ++next;
@@ -876,6 +924,7 @@ struct Run {
             }
         }
         outq.close();
+        for (int q = 0; q < 6; ++q) fileq[q]->close();
     }
 };
 
@@ -892,7 +941,7 @@ int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_
     p->ctx.assign(ctxs, ctxs + n_ctx);
     p->slots = slots_per_ctx;
     unsigned hc = std::thread::hardware_concurrency();
-    p->io_threads = io_threads > 0 ? io_threads : (int)std::min(32u, std::max(4u, hc / 2));
+    p->io_threads = io_threads > 0 ? io_threads : (int)std::min(64u, std::max(4u, hc / 2));
     p->pool.reset(new Pool(p->io_threads));
     const int ring = n_ctx * slots_per_ctx + 2;
     for (int f = 0; f < 2; ++f) p->in_buf[f].resize(ring);
@@ -933,14 +982,19 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
         for (int q = 0; q < 6; ++q) {
             const char* path = io->out_path[q / 3][q % 3];
             if (!path) continue;
-            R.out_fd[q] = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-            if (R.out_fd[q] < 0) {
+            if (!R.out[q].open_(path)) {
                 snprintf(g_pipe_err, sizeof(g_pipe_err), "cannot open %s for writing", path);
-                for (int k = 0; k < q; ++k) if (R.out_fd[k] >= 0) close(R.out_fd[k]);
+                for (int k = 0; k < q; ++k) R.out[k].close_();
                 return AQC_ERR_ARG;
             }
         }
     }
+    for (int q = 0; q < 6; ++q) R.fileq[q].reset(new BQueue<std::shared_ptr<Run::Commit>>(0));
+    const bool dbg = getenv("AQC_PIPE_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "pipe: outputs open at %.4f s\n", now_s() - t0);
+    std::vector<std::thread> fw;
+    for (int q = 0; q < 6; ++q)
+        if (R.out[q].fd >= 0) fw.emplace_back([&R, q] { R.file_writer(q); });
     std::vector<std::thread> th;
     for (int f = 0; f < R.nf; ++f) th.emplace_back([&R, f] { R.reader(f); });
     th.emplace_back([&R] { R.dispatcher(); });
@@ -948,21 +1002,29 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
         for (int s = 0; s < P->slots; ++s) th.emplace_back([&R, ci, s] { R.worker(ci, s); });
     std::thread wr([&R] { R.writer(); });
     for (auto& t : th) t.join();
+    if (dbg) fprintf(stderr, "pipe: readers / workers done at %.4f s\n", now_s() - t0);
     // all producers are done: if the last chunk never arrived (abort / anomaly) the writer must not wait for it
     R.outq.close();
     wr.join();
+    for (auto& t : fw) t.join();
+    if (dbg) fprintf(stderr, "pipe: writers done at %.4f s\n", now_s() - t0);
     for (int q = 0; q < 6; ++q) {
-        if (R.out_fd[q] >= 0) {
+        if (R.out[q].fd >= 0) {
             if (io->gzip_out && !R.abort) {
                 // an empty BGZF member terminates the file (and makes an output with no records a valid .gz)
                 std::vector<uint8_t> e;
                 Run::bgzf_block((const uint8_t*)"", 0, io->gzip_level, e);
-                (void)!pwrite(R.out_fd[q], e.data(), e.size(), (off_t)R.out_pos[q]);
+                (void)R.out[q].append(e.data(), e.size());
             }
-            close(R.out_fd[q]);
+            R.out[q].close_();
         }
     }
+    if (dbg) fprintf(stderr, "pipe: files closed at %.4f s\n", now_s() - t0);
     res->records = R.records.load();
+    res->t_read = 1e-9 * (double)R.ns_read.load(); res->t_count = 1e-9 * (double)R.ns_count.load();
+    res->t_frame = 1e-9 * (double)R.ns_frame.load(); res->t_kernels = 1e-9 * (double)R.ns_kernels.load();
+    res->t_fetch = 1e-9 * (double)R.ns_fetch.load(); res->t_write = 1e-9 * (double)R.ns_write.load();
+    res->t_wait_set = 1e-9 * (double)R.ns_wait_set.load(); res->t_wait_ring = 1e-9 * (double)R.ns_wait_ring.load();
     res->anomaly = R.anomaly ? 1 : 0;
     res->seconds = now_s() - t0;
     if (!R.err.empty()) {

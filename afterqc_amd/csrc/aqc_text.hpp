@@ -635,7 +635,7 @@ __device__ __forceinline__ void copy_small(uint8_t* d, const uint8_t* s_, int le
 // (record, file), four records in flight per half-wave: a lane owns one work item — a 16-byte window of a long piece
 // (16-byte load + 16-byte store at any alignment, the piece's last window end-aligned) or a whole short piece — so every
 // load of a record is independent of every other and nothing but the (LDS) piece list is on the critical path.
-constexpr int FMT_UNROLL = 4;
+constexpr int FMT_UNROLL = 8;
 __global__ __launch_bounds__(FMT_TILE) void fmt_write_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
                                                              const unsigned long long* __restrict__ tile_base, FormatOut outs,
                                                              int overlap_pass, int* __restrict__ status) {
@@ -643,11 +643,20 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_write_kernel(FormatView v, uint6
     __shared__ FmtTask tasks[FMT_TILE * 2];
     const int nfiles = v.paired ? 2 : 1;
     const uint64_t r0 = (uint64_t)blockIdx.x * FMT_TILE;
-    // ---- phase A
+    // ---- phase A: piece list first (it knows the record's size and stream), then the offsets
     for (int file = 0; file < nfiles; ++file) {
-        uint32_t sz[3] = {0, 0, 0};
         const uint64_t r = r0 + threadIdx.x;
-        if (r < n) fmt_sizes(v, r, file, sz);
+        FmtTask& t = tasks[threadIdx.x * nfiles + file];
+        t.stream = 0xff;
+        t.total = 0;
+        uint32_t sz[3] = {0, 0, 0};
+        if (r < n) {
+            fmt_build(v, r, file, overlap_pass, t, status);
+            if (!overlap_pass) {
+                // (the size of a record that is not written in this pass cannot happen here: good or bad, one of the two)
+                sz[t.stream == 1 ? 1 : 0] = t.stream == 0xff ? 0u : (uint32_t)t.total;
+            } else sz[2] = t.stream == 2 ? (uint32_t)t.total : 0u;
+        }
         unsigned int pos;
         if (!overlap_pass) {
             // good and bad records interleave: two scans, each record keeps the offset of the stream it goes to
@@ -662,12 +671,7 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_write_kernel(FormatView v, uint6
             const unsigned long long eo = block_excl_scan((unsigned long long)sz[2], lds, to);
             pos = (unsigned int)(tile_base[(uint64_t)(file * 3 + 2) * n_tiles + blockIdx.x] + eo);
         }
-        FmtTask& t = tasks[threadIdx.x * nfiles + file];
-        t.stream = 0xff;
-        if (r < n) {
-            fmt_build(v, r, file, overlap_pass, t, status);
-            t.pos = pos;
-        }
+        if (r < n) t.pos = pos;
     }
     __syncthreads();
     // ---- phase B

@@ -225,7 +225,9 @@ def main():
     # ================= C. file -> pipe -> file ================================================================================
     f2f = None
     if args.file_runs > 0:
-        base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 3 * (text_in + text_out) * world else None
+        # files in the temp dir (page cache).  AQC_BENCH_DIR picks another place (tmpfs is SLOWER for this on the MI355X hosts:
+        # 6 GB/s per file against 11 GB/s, tools/ubench/file_write_rate.cpp)
+        base = os.environ.get("AQC_BENCH_DIR") or None
         work = tempfile.mkdtemp(prefix="aqc_bench_%d_" % rank, dir=base)
         try:
             paths = []
@@ -238,6 +240,10 @@ def main():
             ts = []
             for it in range(args.file_runs + 1):
                 eng.reset_stats()
+                for trio in outs:                      # a run writes NEW files (dropping last run's 3.4 GB is not part of it)
+                    for pth in trio:
+                        if pth and os.path.exists(pth):
+                            os.unlink(pth)
                 barrier()
                 t1 = time.perf_counter()
                 pr = pipe.run(paths, outs, chunk_records=K, qc_sample=args.qc_sample, chunk_index0=rank, chunk_index_stride=world)
@@ -247,8 +253,8 @@ def main():
                     ts.append(dt)
             best = min(ts)
             f2f = {"mreads_s": round(reads_per_gpu * world / best / 1e6, 2), "seconds": round(best, 4), "runs": len(ts),
-                   "where": "tmpfs" if base else "tmp dir (page cache)", "input_gb_per_gpu": round(text_in / 1e9, 3),
-                   "output_gb_per_gpu": round(sum(int(x) for x in pr.bytes_out) / 1e9, 3)}
+                   "where": base or tempfile.gettempdir(), "input_gb_per_gpu": round(text_in / 1e9, 3),
+                   "output_gb_per_gpu": round(sum(int(x) for x in pr.bytes_out) / 1e9, 3), "thread_seconds_last_run": pr.breakdown()}
         finally:
             shutil.rmtree(work, ignore_errors=True)
     pipe.close()

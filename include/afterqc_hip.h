@@ -355,6 +355,10 @@ typedef struct aqc_pipe_result {
     int32_t anomaly;               /* the input is not of the regular shape: outputs and statistics are incomplete */
     int32_t pad_;
     double seconds;
+    /* where the time went, summed over the threads of each kind (seconds): reader file reads / newline counts / waits for a
+     * free input buffer; slot workers in aqc_frame (upload + framing) / run + QC + format / waits for an output buffer set /
+     * aqc_fetch_text (download); writer commits */
+    double t_read, t_count, t_wait_ring, t_frame, t_kernels, t_wait_set, t_fetch, t_write;
 } aqc_pipe_result;
 
 int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_t io_threads, aqc_pipe** out);
