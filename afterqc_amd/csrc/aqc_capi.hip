@@ -69,7 +69,7 @@ struct Slot {
     // text in / text out (aqc_frame, aqc_format): per file the line table and the name / strand-line descriptors
     DevBuf t_line_end[2], t_tile[2], t_name_off[2], t_name_len[2], t_plus_off[2], t_plus_len[2], t_qual_len[2];
     DevBuf t_scratch;              // FrameMeta[2] + scan totals
-    DevBuf f_pos, f_tile, f_out[6];
+    DevBuf f_pos, f_tile, f_plan, f_over, f_out[6];
     uint64_t f_bytes[6] = {0, 0, 0, 0, 0, 0};
     bool framed = false, formatted = false;
     aqc_text_chunk last_chunk{};   // what the slot's arenas hold (aqc_reframe)
@@ -227,7 +227,7 @@ void aqc_destroy(aqc_ctx* c) {
                           &s.deferred, &s.n_deferred, &s.off_stage,
                           &s.t_line_end[0], &s.t_line_end[1], &s.t_tile[0], &s.t_tile[1], &s.t_name_off[0], &s.t_name_off[1],
                           &s.t_name_len[0], &s.t_name_len[1], &s.t_plus_off[0], &s.t_plus_off[1], &s.t_plus_len[0], &s.t_plus_len[1],
-                          &s.t_qual_len[0], &s.t_qual_len[1], &s.t_scratch, &s.f_pos, &s.f_tile, &s.f_out[0], &s.f_out[1], &s.f_out[2],
+                          &s.t_qual_len[0], &s.t_qual_len[1], &s.t_scratch, &s.f_pos, &s.f_tile, &s.f_plan, &s.f_over, &s.f_out[0], &s.f_out[1], &s.f_out[2],
                           &s.f_out[3], &s.f_out[4], &s.f_out[5]};
         for (DevBuf* b : bufs) b->release();
         for (int k = 0; k < AQC_N_KERNELS; k++)
@@ -821,11 +821,16 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
         outs.p[q] = (uint8_t*)s->f_out[q].p;
     }
     if (n) {
-        hipLaunchKernelGGL(fmt_write_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles,
-                           (const unsigned long long*)s->f_tile.p, outs, 0, s->status);
-        if (v.store_overlap)
-            hipLaunchKernelGGL(fmt_write_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles,
-                               (const unsigned long long*)s->f_tile.p, outs, 1, s->status);
+        const uint64_t n_tasks = n * (s->paired ? 2 : 1);
+        // 32-byte plans + (sparse) full piece lists for the records that do not fit a plan
+        if (s->f_plan.reserve(32 * n_tasks) || s->f_over.reserve(sizeof(FmtTask) * n_tasks)) return fail(AQC_ERR_HIP, "hipMalloc failed");
+        const unsigned copy_blocks = (unsigned)((n_tasks + (COPY_BLOCK / 32) * FMT_UNROLL - 1) / ((COPY_BLOCK / 32) * FMT_UNROLL));
+        for (int pass = 0; pass < (v.store_overlap ? 2 : 1); ++pass) {
+            hipLaunchKernelGGL(fmt_plan_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles,
+                               (const unsigned long long*)s->f_tile.p, pass, s->status, (uint4*)s->f_plan.p, (FmtTask*)s->f_over.p);
+            hipLaunchKernelGGL(fmt_copy_kernel, dim3(copy_blocks), dim3(COPY_BLOCK), 0, s->stream, v, n_tasks, (const uint4*)s->f_plan.p,
+                               (const FmtTask*)s->f_over.p, outs);
+        }
         HIP_TRY(hipGetLastError());
     }
     s->formatted = true;

@@ -630,32 +630,33 @@ __device__ __forceinline__ void copy_small(uint8_t* d, const uint8_t* s_, int le
     __builtin_memcpy(d + len - N, b, N);
 }
 
-// Writer: one workgroup per tile of FMT_TILE records.  Phase A, thread = record: the record's offset in its stream (block
-// scans over the sizes, tile bases from fmt_tile_bases_kernel) and its piece list, into LDS.  Phase B, 32 lanes per
-// (record, file), four records in flight per half-wave: a lane owns one work item — a 16-byte window of a long piece
-// (16-byte load + 16-byte store at any alignment, the piece's last window end-aligned) or a whole short piece — so every
-// load of a record is independent of every other and nothing but the (LDS) piece list is on the critical path.
-constexpr int FMT_UNROLL = 8;
-__global__ __launch_bounds__(FMT_TILE) void fmt_write_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
-                                                             const unsigned long long* __restrict__ tile_base, FormatOut outs,
-                                                             int overlap_pass, int* __restrict__ status) {
+// ---- the writer, two kernels ---------------------------------------------------------------------------------------------
+// fmt_plan_kernel (thread = record, workgroup = tile of FMT_TILE records): the record's offset in its stream (block scans
+// over the sizes, tile bases from fmt_tile_bases_kernel) and its piece list, written as a 32-byte PLAN per (record, file):
+//     w0 offset in the stream | w1 stream, piece count | w2..w5 sources of up to four pieces | w6, w7 their lengths
+// (the pieces follow each other in the output, so their destinations are implied).  Records with more pieces or with
+// edits of the correction walk keep their full FmtTask in an overflow array (w1 bit 31).
+// fmt_copy_kernel (32 lanes = one plan, FMT_UNROLL plans in flight per half-wave): a lane owns one work item — a 16-byte
+// window of a long piece (16-byte load + 16-byte store at any alignment, the piece's last window end-aligned) or a whole
+// short piece.  No LDS, no dependent global loads beyond the plan itself: both kernels run at full occupancy.
+constexpr uint32_t PLAN_SKIP = 0xffffffffu, PLAN_OVER = 0x80000000u;
+
+__global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
+                                                            const unsigned long long* __restrict__ tile_base, int overlap_pass,
+                                                            int* __restrict__ status, uint4* __restrict__ plan, FmtTask* __restrict__ over) {
     __shared__ unsigned long long lds[4];
-    __shared__ FmtTask tasks[FMT_TILE * 2];
+    __shared__ FmtTask tasks[FMT_TILE];
     const int nfiles = v.paired ? 2 : 1;
-    const uint64_t r0 = (uint64_t)blockIdx.x * FMT_TILE;
-    // ---- phase A: piece list first (it knows the record's size and stream), then the offsets
+    const uint64_t r = (uint64_t)blockIdx.x * FMT_TILE + threadIdx.x;
     for (int file = 0; file < nfiles; ++file) {
-        const uint64_t r = r0 + threadIdx.x;
-        FmtTask& t = tasks[threadIdx.x * nfiles + file];
+        FmtTask& t = tasks[threadIdx.x];
         t.stream = 0xff;
         t.total = 0;
         uint32_t sz[3] = {0, 0, 0};
         if (r < n) {
             fmt_build(v, r, file, overlap_pass, t, status);
-            if (!overlap_pass) {
-                // (the size of a record that is not written in this pass cannot happen here: good or bad, one of the two)
-                sz[t.stream == 1 ? 1 : 0] = t.stream == 0xff ? 0u : (uint32_t)t.total;
-            } else sz[2] = t.stream == 2 ? (uint32_t)t.total : 0u;
+            if (!overlap_pass) sz[t.stream == 1 ? 1 : 0] = t.stream == 0xff ? 0u : (uint32_t)t.total;
+            else sz[2] = t.stream == 2 ? (uint32_t)t.total : 0u;
         }
         unsigned int pos;
         if (!overlap_pass) {
@@ -671,82 +672,123 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_write_kernel(FormatView v, uint6
             const unsigned long long eo = block_excl_scan((unsigned long long)sz[2], lds, to);
             pos = (unsigned int)(tile_base[(uint64_t)(file * 3 + 2) * n_tiles + blockIdx.x] + eo);
         }
-        if (r < n) t.pos = pos;
-    }
-    __syncthreads();
-    // ---- phase B
-    const int lane32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
-    constexpr int NHW = FMT_TILE / 32;
-    const int ntask = FMT_TILE * nfiles;
-    for (int t0 = hw; t0 < ntask; t0 += NHW * FMT_UNROLL) {
-        int max_items = 0;
-#pragma unroll
-        for (int u = 0; u < FMT_UNROLL; ++u) {
-            const int ti = t0 + u * NHW;
-            if (ti < ntask && tasks[ti].stream != 0xff) max_items = max(max_items, (int)tasks[ti].items);
-        }
-        for (int i0 = 0; i0 < max_items; i0 += 32) {
-            uint4 val[FMT_UNROLL];
-            uint8_t* dptr[FMT_UNROLL];
-            const uint8_t* sptr[FMT_UNROLL];
-            int mode[FMT_UNROLL];          // 0 nothing, 16 a window, 1..15 a short piece of that many bytes
-#pragma unroll
-            for (int u = 0; u < FMT_UNROLL; ++u) {
-                const int ti = t0 + u * NHW;
-                mode[u] = 0;
-                dptr[u] = nullptr; sptr[u] = nullptr;
-                val[u] = make_uint4(0, 0, 0, 0);
-                if (ti >= ntask) continue;
-                const FmtTask& t = tasks[ti];
-                const int item = i0 + lane32;
-                if (t.stream == 0xff || item >= (int)t.items) continue;
-                // which piece does this item belong to?
-                int k = 0, first_item = 0;
-                for (; k < (int)t.np; ++k) {
-                    const int cnt = t.p[k].len >= 16 ? (t.p[k].len + 15) >> 4 : 1;
-                    if (item < first_item + cnt) break;
-                    first_item += cnt;
-                }
-                const FmtPiece pc = t.p[k];
-                const int file = nfiles == 2 ? (ti & 1) : 0;
-                const uint8_t* src = (pc.src & FMT_LIT_BIT) ? &FMT_LIT[0][0] + (pc.src & ~FMT_LIT_BIT) : v.f[file].text + pc.src;
-                uint8_t* dst = outs.p[file * 3 + t.stream] + t.pos + pc.dst;
-                if (pc.len >= 16) {
-                    const int off = min(16 * (item - first_item), (int)pc.len - 16);        // the last window is aligned to the piece's end
-                    sptr[u] = src + off; dptr[u] = dst + off; mode[u] = 16;
-                    val[u] = load16u_t(sptr[u]);
+        if (r < n) {
+            const uint64_t ti = r * nfiles + file;
+            uint4 a = make_uint4(pos, PLAN_SKIP, 0, 0), b = make_uint4(0, 0, 0, 0);
+            if (t.stream != 0xff) {
+                t.pos = pos;
+                if (t.np <= 4 && t.n_patch == 0) {
+                    a.y = (uint32_t)t.stream | ((uint32_t)t.np << 8);
+                    a.z = t.np > 0 ? t.p[0].src : 0u; a.w = t.np > 1 ? t.p[1].src : 0u;
+                    b.x = t.np > 2 ? t.p[2].src : 0u; b.y = t.np > 3 ? t.p[3].src : 0u;
+                    b.z = (t.np > 0 ? (uint32_t)t.p[0].len : 0u) | ((t.np > 1 ? (uint32_t)t.p[1].len : 0u) << 16);
+                    b.w = (t.np > 2 ? (uint32_t)t.p[2].len : 0u) | ((t.np > 3 ? (uint32_t)t.p[3].len : 0u) << 16);
                 } else {
-                    sptr[u] = src; dptr[u] = dst; mode[u] = (int)pc.len;
+                    a.y = PLAN_OVER | (uint32_t)t.stream;
+                    over[ti] = t;
                 }
             }
-#pragma unroll
-            for (int u = 0; u < FMT_UNROLL; ++u) {
-                if (mode[u] == 16) store16u(dptr[u], val[u]);
-                else if (mode[u] >= 8) copy_small<8>(dptr[u], sptr[u], mode[u]);
-                else if (mode[u] >= 4) copy_small<4>(dptr[u], sptr[u], mode[u]);
-                else if (mode[u] >= 2) copy_small<2>(dptr[u], sptr[u], mode[u]);
-                else if (mode[u] == 1) dptr[u][0] = sptr[u][0];
-            }
+            plan[2 * ti] = a;
+            plan[2 * ti + 1] = b;
         }
-        // the walk's edits: byte patches on top of the copies (the copies of this wave are complete first)
-        bool any_patch = false;
+        __syncthreads();            // (tasks[] is reused for the second file)
+    }
+}
+
+constexpr int FMT_UNROLL = 4;
+constexpr int COPY_BLOCK = 256;
+__global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, uint64_t n_tasks, const uint4* __restrict__ plan,
+                                                             const FmtTask* __restrict__ over, FormatOut outs) {
+    const int nfiles = v.paired ? 2 : 1;
+    const int lane32 = threadIdx.x & 31;
+    const uint64_t hw = ((uint64_t)blockIdx.x * COPY_BLOCK + threadIdx.x) >> 5;          // half-wave index over the grid
+    const uint64_t t_first = hw * FMT_UNROLL;
+    uint4 val[FMT_UNROLL];
+    uint8_t* dptr[FMT_UNROLL];
+    const uint8_t* sptr[FMT_UNROLL];
+    int mode[FMT_UNROLL];              // 0 nothing, 16 a window, 1..15 a short piece of that many bytes
+    uint32_t more = 0;                 // bit u: plan u has more than 32 work items, or lives in the overflow array
 #pragma unroll
+    for (int u = 0; u < FMT_UNROLL; ++u) {
+        const uint64_t ti = t_first + u;
+        mode[u] = 0; dptr[u] = nullptr; sptr[u] = nullptr; val[u] = make_uint4(0, 0, 0, 0);
+        if (ti >= n_tasks) continue;
+        const uint4 a = plan[2 * ti], b = plan[2 * ti + 1];
+        if (a.y == PLAN_SKIP) continue;
+        if (a.y & PLAN_OVER) { more |= 1u << u; continue; }
+        const int file = nfiles == 2 ? (int)(ti & 1) : 0;
+        const uint32_t srcs[4] = {a.z, a.w, b.x, b.y};
+        const int lens[4] = {(int)(b.z & 0xffffu), (int)(b.z >> 16), (int)(b.w & 0xffffu), (int)(b.w >> 16)};
+        // which piece does item `lane32` belong to?  (pieces follow each other in the output)
+        int first_item = 0, dst_off = 0, k = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cnt = lens[q] >= 16 ? (lens[q] + 15) >> 4 : (lens[q] > 0 ? 1 : 0);
+            if (k == q && lane32 >= first_item + cnt) { first_item += cnt; dst_off += lens[q]; k = q + 1; }
+        }
+        int total_items = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) total_items += lens[q] >= 16 ? (lens[q] + 15) >> 4 : (lens[q] > 0 ? 1 : 0);
+        if (total_items > 32) { more |= 1u << u; continue; }       // a long record: the general loop below
+        if (k >= 4 || lane32 >= total_items) continue;
+        const uint32_t sk = k == 0 ? srcs[0] : k == 1 ? srcs[1] : k == 2 ? srcs[2] : srcs[3];
+        const int lk = k == 0 ? lens[0] : k == 1 ? lens[1] : k == 2 ? lens[2] : lens[3];
+        const uint8_t* src = (sk & FMT_LIT_BIT) ? &FMT_LIT[0][0] + (sk & ~FMT_LIT_BIT) : v.f[file].text + sk;
+        uint8_t* dst = outs.p[file * 3 + (int)(a.y & 0xffu)] + a.x + dst_off;
+        if (lk >= 16) {
+            const int off = min(16 * (lane32 - first_item), lk - 16);           // the last window is aligned to the piece's end
+            sptr[u] = src + off; dptr[u] = dst + off; mode[u] = 16;
+            val[u] = load16u_t(sptr[u]);
+        } else {
+            sptr[u] = src; dptr[u] = dst; mode[u] = lk;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < FMT_UNROLL; ++u) {
+        if (mode[u] == 16) store16u(dptr[u], val[u]);
+        else if (mode[u] >= 8) copy_small<8>(dptr[u], sptr[u], mode[u]);
+        else if (mode[u] >= 4) copy_small<4>(dptr[u], sptr[u], mode[u]);
+        else if (mode[u] >= 2) copy_small<2>(dptr[u], sptr[u], mode[u]);
+        else if (mode[u] == 1) dptr[u][0] = sptr[u][0];
+    }
+    // ---- the general form: any number of pieces / work items, edits applied on top (rare: records with corrections,
+    //      reads of more than ~500 bytes of output, renamed records with stripped whitespace)
+    if (more) {
         for (int u = 0; u < FMT_UNROLL; ++u) {
-            const int ti = t0 + u * NHW;
-            if (ti < ntask && tasks[ti].stream != 0xff && tasks[ti].n_patch) any_patch = true;
-        }
-        if (any_patch) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_s_waitcnt(0);
-#pragma unroll
-            for (int u = 0; u < FMT_UNROLL; ++u) {
-                const int ti = t0 + u * NHW;
-                if (ti >= ntask) continue;
-                const FmtTask& t = tasks[ti];
-                if (t.stream == 0xff || lane32 >= (int)t.n_patch) continue;
-                const int file = nfiles == 2 ? (ti & 1) : 0;
-                const uint32_t pt = t.patch[lane32];
-                outs.p[file * 3 + t.stream][t.pos + (pt & 0xffffu)] = (uint8_t)(pt >> 16);
+            if (!((more >> u) & 1u)) continue;
+            const uint64_t ti = t_first + u;
+            const uint4 a = plan[2 * ti], b = plan[2 * ti + 1];
+            const int file = nfiles == 2 ? (int)(ti & 1) : 0;
+            const bool ov = (a.y & PLAN_OVER) != 0;
+            const int stream = (int)(a.y & 0xffu);
+            const int np = ov ? (int)over[ti].np : (int)((a.y >> 8) & 0xffu);
+            uint8_t* out0 = outs.p[file * 3 + stream] + a.x;
+            int dst_off = 0;
+            for (int k = 0; k < np; ++k) {
+                uint32_t sk; int lk;
+                if (ov) { sk = over[ti].p[k].src; lk = (int)over[ti].p[k].len; }
+                else {
+                    sk = k == 0 ? a.z : k == 1 ? a.w : k == 2 ? b.x : b.y;
+                    lk = k == 0 ? (int)(b.z & 0xffffu) : k == 1 ? (int)(b.z >> 16) : k == 2 ? (int)(b.w & 0xffffu) : (int)(b.w >> 16);
+                }
+                const uint8_t* src = (sk & FMT_LIT_BIT) ? &FMT_LIT[0][0] + (sk & ~FMT_LIT_BIT) : v.f[file].text + sk;
+                uint8_t* dst = out0 + dst_off;
+                if (lk >= 16) {
+                    for (int w0 = 16 * lane32; w0 < lk; w0 += 16 * 32) {
+                        const int off = min(w0, lk - 16);
+                        store16u(dst + off, load16u_t(src + off));
+                    }
+                } else if (lane32 < lk) dst[lane32] = src[lane32];
+                dst_off += lk;
+            }
+            if (ov && over[ti].n_patch) {
+                // byte patches on top of the copies (the copies of this wave are complete first)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+                if (lane32 < (int)over[ti].n_patch) {
+                    const uint32_t pt = over[ti].patch[lane32];
+                    out0[pt & 0xffffu] = (uint8_t)(pt >> 16);
+                }
             }
         }
     }
