@@ -695,7 +695,10 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
     }
 }
 
-constexpr int FMT_UNROLL = 4;
+#ifndef AQC_FMT_UNROLL
+#define AQC_FMT_UNROLL 4
+#endif
+constexpr int FMT_UNROLL = AQC_FMT_UNROLL;
 constexpr int COPY_BLOCK = 256;
 __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, uint64_t n_tasks, const uint4* __restrict__ plan,
                                                              const FmtTask* __restrict__ over, FormatOut outs) {
