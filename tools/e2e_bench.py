@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""File-to-file throughput of the drop-in CLI path (not the bench.py metric: that one is HBM-resident).
+"""File-to-file throughput of the drop-in CLI path: what `python -m afterqc_amd.after -1 R1.fq -2 R2.fq` does, timed.
 
-  python tools/e2e_bench.py --pairs 2000000 --mode text      # device framing / formatting (default path)
-  python tools/e2e_bench.py --pairs 200000 --mode host       # host framing / Python writer (general path)
+  python tools/e2e_bench.py --pairs 5000000                  # whole-input pipe (the default path)
+  python tools/e2e_bench.py --pairs 2000000 --mode text      # serial chunk loop
+  python tools/e2e_bench.py --pairs 200000 --mode host       # host framing / Python writer (cross-check path)
+  python tools/e2e_bench.py --pairs 2000000 --config5 --gz   # 2x250 + barcodes + bubbles, .gz in -> .gz out
 
 Writes config-3 style R1/R2 FASTQ files to --dir, runs afterqc_amd.preprocesser.seqFilter on them exactly as
 `python -m afterqc_amd.after -1 R1.fq -2 R2.fq -f 0 -t 0` would, and prints one JSON line with the wall time of the
@@ -21,8 +23,11 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=2_000_000)
-    ap.add_argument("--mode", default="text", choices=["text", "host"])
-    ap.add_argument("--chunk-mb", type=int, default=8)
+    ap.add_argument("--mode", default="pipe", choices=["pipe", "text", "host"],
+                    help="pipe: whole-input pipe (C++ threads, the default path); text: serial chunk loop; host: host framing / Python writer")
+    ap.add_argument("--chunk-mb", type=int, default=64)
+    ap.add_argument("--chunk-records", type=int, default=1 << 17)
+    ap.add_argument("--devices", default="0", help="GPUs the input is dealt over, e.g. 0,1,2,3")
     ap.add_argument("--dir", default="/tmp/aqc_e2e")
     ap.add_argument("--single", action="store_true")
     ap.add_argument("--keep", action="store_true")
@@ -59,7 +64,8 @@ def main():
     options.barcode = bool(args.config5)       # what after.py:215-221 decides from the file name
     if args.config5:
         options.trim_front = options.trim_front2 = 0
-    flt = preprocesser.seqFilter(options, use_text_path=args.mode == "text", chunk_bytes=args.chunk_mb << 20)
+    flt = preprocesser.seqFilter(options, use_text_path=args.mode != "host", use_pipe=args.mode == "pipe", chunk_bytes=args.chunk_mb << 20,
+                                 chunk_records=args.chunk_records, devices=[int(x) for x in args.devices.split(",")])
     t = time.perf_counter()
     stat = flt.run()
     wall = time.perf_counter() - t
@@ -70,7 +76,8 @@ def main():
            "wall_s": round(wall, 3), "pass1_s": round(flt.timing["pass1_s"], 3), "pass2_s": round(flt.timing["pass2_s"], 3),
            "e2e_mreads_s": round(reads / wall / 1e6, 3), "pass2_mreads_s": round(reads / flt.timing["pass2_s"] / 1e6, 3),
            "pass2_input_gb_s": round(in_bytes / flt.timing["pass2_s"] / 1e9, 3),
-           "good_reads": s["good_reads"], "bad_reads": s["bad_reads"], "text_path": flt.text_path, "config5": args.config5}
+           "good_reads": s["good_reads"], "bad_reads": s["bad_reads"], "text_path": flt.text_path, "used_pipe": flt.used_pipe,
+           "config5": args.config5, "devices": args.devices}
     print(json.dumps(out))
     if not args.keep:
         shutil.rmtree(args.dir, ignore_errors=True)
