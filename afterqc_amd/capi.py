@@ -341,6 +341,13 @@ def load_library():
     lib.aqc_pipe_run.argtypes = [P, C.POINTER(PipeIO), C.POINTER(PipeOpts), C.POINTER(PipeResult)]
     lib.aqc_pipe_run.restype = C.c_int
     lib.aqc_pipe_last_error.restype = C.c_char_p
+    lib.aqc_host_count_newlines.argtypes = [P, C.c_uint64]
+    lib.aqc_host_count_newlines.restype = C.c_uint64
+    lib.aqc_bgzf_compress.argtypes = [P, C.c_uint64, C.c_int32, P, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.aqc_bgzf_compress.restype = C.c_int
+    lib.aqc_pipe_split.argtypes = [C.POINTER(PipeIO), C.c_int32, C.c_uint64, C.c_int32, P, P, C.c_uint64, C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint32)]
+    lib.aqc_pipe_split.restype = C.c_int
     lib.aqc_host_alloc.argtypes = [C.c_uint64]
     lib.aqc_host_alloc.restype = C.c_void_p
     lib.aqc_host_free.argtypes = [P]
@@ -365,6 +372,7 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_last_error", "aq
                     "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_host_alloc",
                     "aqc_host_free",
                     "aqc_pipe_create", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
+                    "aqc_host_count_newlines", "aqc_bgzf_compress", "aqc_pipe_split",
                     # the reference's own native seam (editdistance/_editdistance.h:16,23), same names and signatures
                     "edit_distance", "seek_overlap"]
 
@@ -608,6 +616,46 @@ class Pipe:
         for e in self.engines:
             e.slot_n = [0] * e.n_slots
         return res
+
+
+def bgzf_compress(data, level=2):
+    """the pipe's .gz writer on a bytes object: BGZF-style members (valid gzip)"""
+    lib = load_library()
+    src = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+    cap = len(data) + len(data) // 100 + 64 * (len(data) // 0xff00 + 2)
+    dst = np.zeros(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    rc = lib.aqc_bgzf_compress(src.ctypes.data, len(data), level, dst.ctypes.data, cap, C.byref(n))
+    if rc != 0:
+        raise AqcError(rc, "aqc_bgzf_compress failed")
+    return dst[:n.value].tobytes()
+
+
+def pipe_split(source, chunk_records, gzip_in=False, io_threads=4, cap=1 << 16):
+    """the pipe's reader half alone (no GPU): (bytes per chunk, lines per chunk, crc32 of the concatenated chunks)"""
+    lib = load_library()
+    io = PipeIO()
+    keep = []
+    if isinstance(source, (str, bytes)) and not isinstance(source, bytes):
+        b = source.encode()
+        keep.append(b)
+        io.in_path[0] = b
+        io.gzip_in[0] = 1 if gzip_in else 0
+    else:
+        arr = np.frombuffer(source, dtype=np.uint8) if len(source) else np.zeros(1, dtype=np.uint8)
+        keep.append(arr)
+        io.in_mem[0] = arr.ctypes.data
+        io.in_mem_bytes[0] = len(source)
+    nbytes = np.zeros(cap, dtype=np.uint64)
+    lines = np.zeros(cap, dtype=np.uint64)
+    n = C.c_uint64(0)
+    crc = C.c_uint32(0)
+    rc = lib.aqc_pipe_split(C.byref(io), 0, int(chunk_records), io_threads, nbytes.ctypes.data, lines.ctypes.data, cap, C.byref(n),
+                            C.byref(crc))
+    if rc != 0:
+        raise AqcError(rc, (lib.aqc_pipe_last_error() or b"").decode("utf-8", "replace"))
+    k = min(int(n.value), cap)
+    return nbytes[:k].tolist(), lines[:k].tolist(), int(crc.value)
 
 
 class MergedEngines:

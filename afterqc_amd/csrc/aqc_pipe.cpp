@@ -459,15 +459,16 @@ struct OutFile {
 struct HostBuf {
     uint8_t* p = nullptr;
     size_t cap = 0;
+    bool pageable = false;       // (aqc_pipe_split only: plain memory, no GPU runtime involved)
     void ensure(size_t n) {
         if (n <= cap) return;
-        if (p) aqc_host_free(p);
+        release();
         cap = n + n / 8 + (1 << 20);
-        p = (uint8_t*)aqc_host_alloc(cap);
+        p = pageable ? (uint8_t*)malloc(cap) : (uint8_t*)aqc_host_alloc(cap);
         if (!p) cap = 0;
     }
     void release() {
-        if (p) aqc_host_free(p);
+        if (p) { if (pageable) free(p); else aqc_host_free(p); }
         p = nullptr;
         cap = 0;
     }
@@ -682,6 +683,7 @@ struct Run {
                     const size_t ncap = cap + cap / 2 + (4 << 20);
                     if (ncap > hb.cap) {
                         HostBuf nbuf;
+                        nbuf.pageable = hb.pageable;
                         nbuf.ensure(ncap);
                         if (!nbuf.p) { fail(AQC_ERR_HIP, "page-locked allocation of %zu bytes failed", ncap); return; }
                         memcpy(nbuf.p, hb.p, fill);
@@ -1031,6 +1033,71 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
         std::lock_guard<std::mutex> g(g_pipe_err_mu);
         snprintf(g_pipe_err, sizeof(g_pipe_err), "%s", R.err.c_str());
         return R.err_code ? R.err_code : AQC_ERR_HIP;
+    }
+    return 0;
+}
+
+// ---- host-only helpers (no GPU involved): used by the CPU tests of the pipe's reader / writer halves ---------------------
+uint64_t aqc_host_count_newlines(const uint8_t* p, uint64_t n) { return p ? count_nl(p, (size_t)n) : 0; }
+
+int aqc_bgzf_compress(const uint8_t* src, uint64_t n, int32_t level, uint8_t* dst, uint64_t cap, uint64_t* out_n) {
+    if ((!src && n) || !dst || !out_n) return AQC_ERR_ARG;
+    const size_t blk = 0xff00;
+    uint64_t o = 0;
+    std::vector<uint8_t> z;
+    for (uint64_t i = 0; i < n || (n == 0 && i == 0); i += blk) {
+        Run::bgzf_block(src + i, (size_t)std::min<uint64_t>(blk, n - i), level, z);
+        if (o + z.size() > cap) return AQC_ERR_ARG;
+        memcpy(dst + o, z.data(), z.size());
+        o += z.size();
+        if (n == 0) break;
+    }
+    *out_n = o;
+    return 0;
+}
+
+int aqc_pipe_split(const aqc_pipe_io* io, int32_t file_index, uint64_t chunk_records, int32_t io_threads, uint64_t* bytes,
+                   uint64_t* lines, uint64_t cap, uint64_t* n_chunks, uint32_t* crc) {
+    if (!io || file_index < 0 || file_index > 1 || !n_chunks || !crc) return AQC_ERR_ARG;
+    aqc_pipe P;
+    P.n_ctx = 0;
+    P.io_threads = io_threads > 0 ? io_threads : 4;
+    P.pool.reset(new Pool(P.io_threads));
+    for (int f = 0; f < 2; ++f) {
+        P.in_buf[f].resize(2);
+        for (auto& b : P.in_buf[f]) b.pageable = true;
+    }
+    aqc_pipe_opts opt{};
+    aqc_pipe_result res{};
+    Run R;
+    R.P = &P;
+    R.io = io;
+    R.opt = &opt;
+    R.res = &res;
+    R.nf = 1;
+    R.K = chunk_records ? chunk_records : (1u << 17);
+    const int f = file_index;
+    R.inq[f].reset(new BQueue<InChunk>(2));
+    R.ring_free[f].assign(P.in_buf[f].size(), 1);
+    std::thread rd([&R, f] { R.reader(f); });
+    uint64_t k = 0;
+    uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
+    InChunk ch;
+    while (R.inq[f]->pop(ch)) {
+        if (k < cap) { if (bytes) bytes[k] = ch.bytes; if (lines) lines[k] = ch.lines; }
+        for (uint64_t o = 0; o < ch.bytes; o += (1u << 30)) c = (uint32_t)crc32(c, ch.data + o, (uInt)std::min<uint64_t>(1u << 30, ch.bytes - o));
+        ++k;
+        R.release_ring(f, ch.buf);
+    }
+    rd.join();
+    for (int g = 0; g < 2; ++g)
+        for (auto& b : P.in_buf[g]) b.release();
+    *n_chunks = k;
+    *crc = c;
+    if (!R.err.empty()) {
+        std::lock_guard<std::mutex> g(g_pipe_err_mu);
+        snprintf(g_pipe_err, sizeof(g_pipe_err), "%s", R.err.c_str());
+        return R.err_code ? R.err_code : AQC_ERR_ARG;
     }
     return 0;
 }

@@ -365,6 +365,15 @@ int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_
 void aqc_pipe_destroy(aqc_pipe* p);
 int aqc_pipe_run(aqc_pipe* p, const aqc_pipe_io* io, const aqc_pipe_opts* opts, aqc_pipe_result* result);
 const char* aqc_pipe_last_error(void);
+/* host-only pieces of the pipe, callable without a GPU (the CPU tests use them):
+ * the newline counter the chunk boundaries are found with; BGZF-style gzip members as the pipe's writer makes them (dst must
+ * hold n + n / 200 + 64 bytes per 64 KiB block); and the reader half alone — cuts input `file_index` of `io` into chunks of
+ * chunk_records records exactly as aqc_pipe_run does (file / gzip / BGZF / memory sources, carry-over, growth) and reports
+ * each chunk's bytes and line count plus the CRC-32 of the concatenated (decompressed) chunks */
+uint64_t aqc_host_count_newlines(const uint8_t* p, uint64_t n);
+int aqc_bgzf_compress(const uint8_t* src, uint64_t n, int32_t level, uint8_t* dst, uint64_t cap, uint64_t* out_n);
+int aqc_pipe_split(const aqc_pipe_io* io, int32_t file_index, uint64_t chunk_records, int32_t io_threads, uint64_t* bytes,
+                   uint64_t* lines, uint64_t cap, uint64_t* n_chunks, uint32_t* crc);
 
 /* ---- the reference's EXISTING native seam (libed.so), for ABI compatibility ------------------------ */
 /* editdistance/_editdistance.h:16 — Levenshtein distance; util.editDistance binds it at util.py:70 */
