@@ -341,6 +341,12 @@ def load_library():
     lib.aqc_pipe_run.argtypes = [P, C.POINTER(PipeIO), C.POINTER(PipeOpts), C.POINTER(PipeResult)]
     lib.aqc_pipe_run.restype = C.c_int
     lib.aqc_pipe_last_error.restype = C.c_char_p
+    lib.aqc_source_open.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
+    lib.aqc_source_open.restype = P
+    lib.aqc_source_read.argtypes = [P, P, C.c_uint64]
+    lib.aqc_source_read.restype = C.c_int64
+    lib.aqc_source_close.argtypes = [P]
+    lib.aqc_source_close.restype = None
     lib.aqc_host_count_newlines.argtypes = [P, C.c_uint64]
     lib.aqc_host_count_newlines.restype = C.c_uint64
     lib.aqc_bgzf_compress.argtypes = [P, C.c_uint64, C.c_int32, P, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -373,6 +379,7 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_last_error", "aq
                     "aqc_host_free",
                     "aqc_pipe_create", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
                     "aqc_host_count_newlines", "aqc_bgzf_compress", "aqc_pipe_split",
+                    "aqc_source_open", "aqc_source_read", "aqc_source_close",
                     # the reference's own native seam (editdistance/_editdistance.h:16,23), same names and signatures
                     "edit_distance", "seek_overlap"]
 
@@ -616,6 +623,50 @@ class Pipe:
         for e in self.engines:
             e.slot_n = [0] * e.n_slots
         return res
+
+
+class NativeSource:
+    """A read file as a binary stream with readinto() — the pipe's readers behind Python's file protocol (parallel pread,
+    member-parallel BGZF inflate): what afterqc_amd.fastq.open_binary hands out for plain and .gz files."""
+
+    def __init__(self, path, gzip_in):
+        self.lib = load_library()
+        self.h = self.lib.aqc_source_open(path.encode() if isinstance(path, str) else path, 1 if gzip_in else 0, 0)
+        if not self.h:
+            raise IOError("cannot open " + str(path))
+
+    def readinto(self, view):
+        mv = memoryview(view)
+        n = mv.nbytes
+        if n == 0:
+            return 0
+        arr = np.frombuffer(mv, dtype=np.uint8)
+        got = self.lib.aqc_source_read(self.h, arr.ctypes.data, n)
+        if got < 0:
+            raise IOError("read error (corrupt gzip data?)")
+        return int(got)
+
+    def read(self, n=-1):
+        out = bytearray()
+        step = n if n is not None and n >= 0 else (8 << 20)
+        while True:
+            buf = bytearray(step)
+            got = self.readinto(buf)
+            out += buf[:got]
+            if got < step or (n is not None and n >= 0):
+                break
+        return bytes(out)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.aqc_source_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def bgzf_compress(data, level=2):

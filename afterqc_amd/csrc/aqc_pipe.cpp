@@ -943,7 +943,11 @@ int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_
     p->ctx.assign(ctxs, ctxs + n_ctx);
     p->slots = slots_per_ctx;
     unsigned hc = std::thread::hardware_concurrency();
-    p->io_threads = io_threads > 0 ? io_threads : (int)std::min(64u, std::max(4u, hc / 2));
+    // default pool: a quarter of the machine's hardware threads, shared fairly when several ranks run on one node (torchrun
+    // exports LOCAL_WORLD_SIZE); gzip work (inflate / deflate of independent members) is what scales with it
+    unsigned share = 1;
+    if (const char* lw = getenv("LOCAL_WORLD_SIZE")) share = (unsigned)std::max(1, atoi(lw));
+    p->io_threads = io_threads > 0 ? io_threads : (int)std::min(64u, std::max(4u, hc / 4 / share));
     p->pool.reset(new Pool(p->io_threads));
     const int ring = n_ctx * slots_per_ctx + 2;
     for (int f = 0; f < 2; ++f) p->in_buf[f].resize(ring);
@@ -1036,6 +1040,33 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
     }
     return 0;
 }
+
+// ---- byte sources on their own: what fastq.Reader's file object is upstream (fastq.py:23-28), with the pipe's readers behind
+//      it (parallel pread; BGZF members inflated in parallel; other gzip data through one zlib stream)
+struct aqc_source {
+    std::unique_ptr<Pool> pool;
+    std::unique_ptr<Source> src;
+};
+
+aqc_source* aqc_source_open(const char* path, int32_t gzip, int32_t io_threads) {
+    if (!path) return nullptr;
+    aqc_source* s = new aqc_source();
+    unsigned hc = std::thread::hardware_concurrency();
+    s->pool.reset(new Pool(io_threads > 0 ? io_threads : (int)std::min(16u, std::max(2u, hc / 4))));
+    if (gzip) s->src.reset(new GzSource(path, s->pool.get()));
+    else s->src.reset(new FileSource(path, s->pool.get()));
+    if (s->src->failed()) { delete s; return nullptr; }
+    return s;
+}
+
+int64_t aqc_source_read(aqc_source* s, uint8_t* dst, uint64_t want) {
+    if (!s || (!dst && want)) return -1;
+    const size_t got = want ? s->src->read(dst, (size_t)want) : 0;
+    if (s->src->failed()) return -1;
+    return (int64_t)got;
+}
+
+void aqc_source_close(aqc_source* s) { delete s; }
 
 // ---- host-only helpers (no GPU involved): used by the CPU tests of the pipe's reader / writer halves ---------------------
 uint64_t aqc_host_count_newlines(const uint8_t* p, uint64_t n) { return p ? count_nl(p, (size_t)n) : 0; }

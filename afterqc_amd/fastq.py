@@ -35,10 +35,16 @@ def isFastq(f):
 def open_binary(fname):
     """the byte stream fastq.Reader reads (fastq.py:23-28): .gz / .bz2 decoded transparently"""
     try:
-        if fname.endswith(".gz"):
-            return gzip.open(fname, "rb")
         if fname.endswith(".bz2"):
             return bz2.BZ2File(fname)
+        try:
+            # the native readers (parallel pread; BGZF members inflated in parallel, other gzip data as one zlib stream)
+            from . import capi
+            return capi.NativeSource(fname, fname.endswith(".gz"))
+        except (ImportError, RuntimeError, AttributeError):
+            pass
+        if fname.endswith(".gz"):
+            return gzip.open(fname, "rb")
         return open(fname, "rb", buffering=0)
     except (IOError, OSError):
         print("Failed to open file " + fname)
@@ -192,8 +198,14 @@ def _pool():
 
 
 def _gzip_member(data, level):
-    c = zlib.compressobj(level, zlib.DEFLATED, 31)       # wbits 31: a complete gzip member (header + CRC trailer)
-    return c.compress(data) + c.flush()
+    """one block of text as gzip members.  With the native library present: BGZF-style 64 KiB members (the pipe's writer,
+    aqc_bgzf_compress — a reader can inflate them in parallel); else one plain member from Python's zlib."""
+    try:
+        from . import capi
+        return capi.bgzf_compress(bytes(data), level)
+    except Exception:
+        c = zlib.compressobj(level, zlib.DEFLATED, 31)       # wbits 31: a complete gzip member (header + CRC trailer)
+        return c.compress(data) + c.flush()
 
 
 class ParallelGzipFile:

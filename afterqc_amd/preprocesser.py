@@ -485,6 +485,7 @@ class seqFilter:
         if res.anomaly:
             return None
         self.timing["pipe_s"] = res.seconds
+        self.timing["pipe_threads"] = res.breakdown()
         return 0
 
     # ---- pass 2, text path with index files (-7 / -5): four lock-stepped inputs, two device slots ---------------------

@@ -365,6 +365,15 @@ int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_
 void aqc_pipe_destroy(aqc_pipe* p);
 int aqc_pipe_run(aqc_pipe* p, const aqc_pipe_io* io, const aqc_pipe_opts* opts, aqc_pipe_result* result);
 const char* aqc_pipe_last_error(void);
+/* a read file as a byte stream (fastq.Reader's `self.__file`, fastq.py:23-28), served by the pipe's readers: parallel pread
+ * for plain files; for .gz, BGZF members inflated in parallel and any other gzip data through one zlib stream.
+ * aqc_source_read fills dst with the next `want` decompressed bytes and returns their number (< want only at the end of
+ * the stream, -1 on a read / format error). */
+typedef struct aqc_source aqc_source;
+aqc_source* aqc_source_open(const char* path, int32_t gzip, int32_t io_threads);
+int64_t aqc_source_read(aqc_source* s, uint8_t* dst, uint64_t want);
+void aqc_source_close(aqc_source* s);
+
 /* host-only pieces of the pipe, callable without a GPU (the CPU tests use them):
  * the newline counter the chunk boundaries are found with; BGZF-style gzip members as the pipe's writer makes them (dst must
  * hold n + n / 200 + 64 bytes per 64 KiB block); and the reader half alone — cuts input `file_index` of `io` into chunks of

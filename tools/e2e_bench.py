@@ -77,7 +77,7 @@ def main():
            "e2e_mreads_s": round(reads / wall / 1e6, 3), "pass2_mreads_s": round(reads / flt.timing["pass2_s"] / 1e6, 3),
            "pass2_input_gb_s": round(in_bytes / flt.timing["pass2_s"] / 1e9, 3),
            "good_reads": s["good_reads"], "bad_reads": s["bad_reads"], "text_path": flt.text_path, "used_pipe": flt.used_pipe,
-           "config5": args.config5, "devices": args.devices}
+           "config5": args.config5, "devices": args.devices, "pipe_threads": flt.timing.get("pipe_threads")}
     print(json.dumps(out))
     if not args.keep:
         shutil.rmtree(args.dir, ignore_errors=True)
