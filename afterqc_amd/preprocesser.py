@@ -452,6 +452,12 @@ class seqFilter:
         stat_path = os.path.join(qc_dir, os.path.basename(opt.read1_file) + ".json")
         with open(stat_path, "w") as f:
             f.write(json.dumps(self.stat, sort_keys=True, indent=4, separators=(',', ': ')))
+        # the HTML report next to it (preprocesser.py:780-783, qcreporter.py)
+        from . import qcreporter
+        ovl_hist, _ = stat_eng.histograms(capi.AQC_QC_COLS)
+        figures = qcreporter.build_figures(self.stat, opt, r1pre, r2pre, r1post, r2post, ovl_hist, readLen)
+        with open(os.path.join(qc_dir, os.path.basename(opt.read1_file) + ".html"), "w") as f:
+            f.write(qcreporter.render(self.stat, figures, getattr(opt, "version", "")))
         self.timing["total_s"] = time.perf_counter() - t_run
         if self.own_engine:
             for e in self._engines():
