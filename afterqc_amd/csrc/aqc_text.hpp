@@ -142,52 +142,92 @@ struct IndexFile {
     uint32_t tile0, tiles;     // this file's tiles are [tile0, tile0 + tiles) of the launch
 };
 
-// 64-bit mask of the bytes < 0x21 (blanks and control characters, '\n' included) among the 64 bytes at p
-__device__ __forceinline__ unsigned long long blank_mask64(const uint8_t* p) {
-    unsigned long long mask = 0;
+// newline flags and "< 0x21" flags of the 16 bytes of v, one bit per byte
+__device__ __forceinline__ void piece_masks(const uint4 v, uint32_t& nl16, uint32_t& bl16) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    nl16 = 0; bl16 = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint4 v = reinterpret_cast<const uint4*>(p)[k];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            const uint32_t t = (w[d] & 0x7f7f7f7fu) + 0x5f5f5f5fu;              // bit 7 set where the low 7 bits are >= 0x21
-            const uint32_t z = ~(t | w[d]) & 0x80808080u;
-            const uint32_t nib = ((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xfu;
-            mask |= (unsigned long long)nib << (16 * k + 4 * d);
-        }
+    for (int d = 0; d < 4; ++d) {
+        const uint32_t x = w[d] ^ 0x0a0a0a0au;
+        const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;        // 0x80 where the byte is '\n'
+        const uint32_t t = (w[d] & 0x7f7f7f7fu) + 0x5f5f5f5fu;                            // bit 7 where the low 7 bits are >= 0x21
+        const uint32_t zb = ~(t | w[d]) & 0x80808080u;
+        nl16 |= __builtin_amdgcn_udot4(z >> 7, 0x08040201u, 0u, false) << (4 * d);
+        bl16 |= __builtin_amdgcn_udot4(zb >> 7, 0x08040201u, 0u, false) << (4 * d);
     }
-    return mask;
 }
 
+// Layout inside a tile: a wave owns 8 KiB; its lane i reads the 16-byte pieces at  wave base + k * 1024 + i * 16,
+// k = 0..7 — every load instruction of the wave is one contiguous KiB (the earlier "128 contiguous bytes per thread" made
+// each instruction touch 64 different cache lines and ran at 2.3 TB/s whatever the arithmetic cost).  The text order of the
+// pieces is (k, lane), so the rank of a piece's first newline is  tile prefix + waves before + pieces (k' < k) + lanes before
+// within k: eight lane scans (two counts per register), no data transposed.
+constexpr int IDX_K = IDX_BYTES_PER_THREAD / 16;      // pieces per lane
 __global__ __launch_bounds__(TXT_BLOCK) void text_index_kernel(IndexFile f0, IndexFile f1, unsigned long long* __restrict__ state,
                                                                unsigned int* __restrict__ ticket) {
-    __shared__ unsigned long long lds[4];
     __shared__ unsigned int s_tile;
+    __shared__ unsigned int s_wave_tot[TXT_BLOCK / WAVE];
     __shared__ unsigned long long s_base;
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t tile = s_tile;
     const IndexFile& f = tile >= f1.tile0 && f1.tiles ? f1 : f0;
     const uint32_t lt = tile - f.tile0;                                   // tile within the file
-    const uint64_t pos = (uint64_t)lt * IDX_TILE + (uint64_t)threadIdx.x * IDX_BYTES_PER_THREAD;
-    unsigned long long nl[2] = {0, 0}, ws[2] = {0, 0};
+    const int lane = lane_id(), wave = threadIdx.x / WAVE;
+    const uint64_t wbase = (uint64_t)lt * IDX_TILE + (uint64_t)wave * (WAVE * IDX_BYTES_PER_THREAD);
+    // (the buffer is zero-filled for more than a tile behind the text: no bounds checks, zeros are no newlines)
+    uint4 v[IDX_K];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const uint64_t q = pos + 64 * h;
-        if (q < f.bytes) {
-            nl[h] = newline_mask64(f.text + q, q, f.bytes);
-            ws[h] = blank_mask64(f.text + q);
-        }
+    for (int k = 0; k < IDX_K; ++k) {
+        const uint64_t q = wbase + (uint64_t)k * (WAVE * 16) + (uint64_t)lane * 16;
+        v[k] = q < f.bytes ? *reinterpret_cast<const uint4*>(f.text + q) : make_uint4(0, 0, 0, 0);
     }
-    // "the byte before is blank": shift the blank mask up by one position, the byte before the span comes from memory
-    const unsigned long long carry0 = (pos > 0 && pos <= f.bytes && f.text[pos - 1] < 0x21) ? 1ull : 0ull;
-    const unsigned long long pw0 = (ws[0] << 1) | carry0, pw1 = (ws[1] << 1) | (ws[0] >> 63);
-    const unsigned int cnt = (unsigned int)(__popcll(nl[0]) + __popcll(nl[1]));
-    unsigned long long total;
-    const unsigned long long excl = block_excl_scan((unsigned long long)cnt, lds, total);
+    uint32_t nl[IDX_K], ws[IDX_K];
+    uint32_t carry_in = (wbase > 0 && wbase <= f.bytes && lane == 0) ? (f.text[wbase - 1] < 0x21 ? 1u : 0u) : 0u;
+#pragma unroll
+    for (int k = 0; k < IDX_K; ++k) {
+        uint32_t bl;
+        piece_masks(v[k], nl[k], bl);
+        // mask the bytes behind the end of the text (the last piece may be partial)
+        const uint64_t q = wbase + (uint64_t)k * (WAVE * 16) + (uint64_t)lane * 16;
+        if (q + 16 > f.bytes) { const uint32_t keep = q >= f.bytes ? 0u : ((1u << (f.bytes - q)) - 1u); nl[k] &= keep; }
+        // "the byte before is blank": this piece's flags moved up one byte; the byte before the piece is the last byte of
+        // the piece of the lane before (same k), for lane 0 of the last lane's piece of k - 1
+        const uint32_t top = bl >> 15;
+        uint32_t prev = (uint32_t)__shfl_up((int)top, 1, WAVE);
+        if (lane == 0) prev = carry_in;
+        carry_in = (uint32_t)__builtin_amdgcn_readlane((int)top, WAVE - 1);          // (only lane 0 uses it)
+        ws[k] = ((bl << 1) | prev) & 0xffffu;
+    }
+    // ranks: inclusive lane scans of the per-piece counts, two pieces per register
+    uint32_t inc[IDX_K / 2];
+#pragma unroll
+    for (int j = 0; j < IDX_K / 2; ++j) {
+        uint32_t c = (uint32_t)__popc(nl[2 * j]) | ((uint32_t)__popc(nl[2 * j + 1]) << 16);
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)c, d, WAVE);
+            if (lane >= d) c += o;
+        }
+        inc[j] = c;
+    }
+    uint32_t koff[IDX_K];          // newlines of the wave's pieces k' < k
+    uint32_t wtot = 0;
+#pragma unroll
+    for (int k = 0; k < IDX_K; ++k) {
+        koff[k] = wtot;
+        const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)inc[k / 2], WAVE - 1);
+        wtot += (k & 1) ? (last >> 16) : (last & 0xffffu);
+    }
+    if (lane == 0) s_wave_tot[wave] = wtot;
+    __syncthreads();
+    unsigned long long total = 0, wave_off = 0;
+#pragma unroll
+    for (int w = 0; w < TXT_BLOCK / WAVE; ++w) {
+        if (w < wave) wave_off += s_wave_tot[w];
+        total += s_wave_tot[w];
+    }
     if (threadIdx.x < WAVE) {
-        const int lane = threadIdx.x;
         unsigned long long base = 0;
         if (lt == 0) {
             if (lane == 0) __hip_atomic_store(&state[tile], IDX_FLAG_P | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -197,22 +237,22 @@ __global__ __launch_bounds__(TXT_BLOCK) void text_index_kernel(IndexFile f0, Ind
             const long long first = (long long)f.tile0;
             while (true) {
                 const long long idx = j - lane;
-                unsigned long long v = IDX_FLAG_P;                        // before the file's first tile: prefix 0
-                if (idx >= first) v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned int flag = (unsigned int)(v >> 62);
+                unsigned long long sv = IDX_FLAG_P;                       // before the file's first tile: prefix 0
+                if (idx >= first) sv = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int flag = (unsigned int)(sv >> 62);
                 const unsigned long long pend = __ballot(flag == 0), pfx = __ballot(flag == 2);
                 if (pfx) {
                     const int fp = __ffsll((long long)pfx) - 1;
                     const unsigned long long upto = fp == 63 ? ~0ull : ((2ull << fp) - 1ull);
                     if (pend & upto) { __builtin_amdgcn_s_sleep(1); continue; }
-                    unsigned long long part = lane <= fp ? (v & IDX_VAL) : 0ull;
+                    unsigned long long part = lane <= fp ? (sv & IDX_VAL) : 0ull;
 #pragma unroll
                     for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft, WAVE);
                     base += part;
                     break;
                 }
                 if (pend) { __builtin_amdgcn_s_sleep(1); continue; }
-                unsigned long long part = v & IDX_VAL;
+                unsigned long long part = sv & IDX_VAL;
 #pragma unroll
                 for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft, WAVE);
                 base += part;
@@ -226,14 +266,16 @@ __global__ __launch_bounds__(TXT_BLOCK) void text_index_kernel(IndexFile f0, Ind
         }
     }
     __syncthreads();
-    unsigned long long i = s_base + excl;
+    const unsigned long long rank0 = s_base + wave_off;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        unsigned long long m = nl[h];
-        const unsigned long long pw = h ? pw1 : pw0;
+    for (int k = 0; k < IDX_K; ++k) {
+        const uint32_t incl = (k & 1) ? (inc[k / 2] >> 16) : (inc[k / 2] & 0xffffu);
+        uint32_t m = nl[k];
+        unsigned long long i = rank0 + koff[k] + (incl - (uint32_t)__popc(m));
+        const uint64_t q = wbase + (uint64_t)k * (WAVE * 16) + (uint64_t)lane * 16;
         while (m) {
-            const int bit = __builtin_ctzll(m);
-            if (i < f.cap) f.line_end[i] = (uint32_t)(pos + 64 * h + (uint64_t)bit) | (((pw >> bit) & 1ull) ? LINE_WS : 0u);
+            const int bit = __builtin_ctz(m);
+            if (i < f.cap) f.line_end[i] = (uint32_t)(q + (uint64_t)bit) | (((ws[k] >> bit) & 1u) ? LINE_WS : 0u);
             ++i;
             m &= m - 1;
         }
