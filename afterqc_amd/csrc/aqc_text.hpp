@@ -675,17 +675,26 @@ __device__ __forceinline__ void copy_small(uint8_t* d, const uint8_t* s_, int le
 // ---- the writer, two kernels ---------------------------------------------------------------------------------------------
 // fmt_plan_kernel (thread = record, workgroup = tile of FMT_TILE records): the record's offset in its stream (block scans
 // over the sizes, tile bases from fmt_tile_bases_kernel) and its piece list, written as a 32-byte PLAN per (record, file):
-//     w0 offset in the stream | w1 stream, piece count | w2..w5 sources of up to four pieces | w6, w7 their lengths
-// (the pieces follow each other in the output, so their destinations are implied).  Records with more pieces or with
-// edits of the correction walk keep their full FmtTask in an overflow array (w1 bit 31).
+//     w0 offset in the stream | w1 stream, piece count, patch count | w2..w5 sources of up to four pieces | w6, w7 their
+//     lengths | w8..w11 up to four byte patches of the correction walk (output position | byte << 16)
+// (the pieces follow each other in the output, so their destinations are implied; 48 bytes).  Records with more pieces or
+// patches keep their full FmtTask in an overflow array (w1 bit 31).
 // fmt_copy_kernel (32 lanes = one plan, FMT_UNROLL plans in flight per half-wave): a lane owns one work item — a 16-byte
 // window of a long piece (16-byte load + 16-byte store at any alignment, the piece's last window end-aligned) or a whole
 // short piece.  No LDS, no dependent global loads beyond the plan itself: both kernels run at full occupancy.
 constexpr uint32_t PLAN_SKIP = 0xffffffffu, PLAN_OVER = 0x80000000u;
+constexpr unsigned int GEN_LISTS = 256;      // lists of "general" records (capacity gen_cap each), see fmt_plan_kernel
+
+// the plans fmt_copy_whole_kernel takes: one piece of 16..512 bytes, no patches — a record that goes out as its own bytes
+__device__ __forceinline__ bool plan_is_whole(const uint4& a, const uint4& b) {
+    return (a.y & 0xffffff00u) == 0x100u && !(a.z & FMT_LIT_BIT) && (b.z & 0xffffu) >= 16u && (b.z & 0xffffu) <= 512u;
+}
+
 
 __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
                                                             const unsigned long long* __restrict__ tile_base, int overlap_pass,
-                                                            int* __restrict__ status, uint4* __restrict__ plan, FmtTask* __restrict__ over) {
+                                                            int* __restrict__ status, uint4* __restrict__ plan, FmtTask* __restrict__ over,
+                                                            uint32_t* __restrict__ gen_list, unsigned int* __restrict__ n_gen, uint64_t gen_cap) {
     __shared__ unsigned long long lds[4];
     __shared__ FmtTask tasks[FMT_TILE];
     const int nfiles = v.paired ? 2 : 1;
@@ -701,6 +710,7 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
             else sz[2] = t.stream == 2 ? (uint32_t)t.total : 0u;
         }
         unsigned int pos;
+        bool general = false;
         if (!overlap_pass) {
             // good and bad records interleave: two scans, each record keeps the offset of the stream it goes to
             unsigned long long tg, tb;
@@ -716,22 +726,49 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
         }
         if (r < n) {
             const uint64_t ti = r * nfiles + file;
-            uint4 a = make_uint4(pos, PLAN_SKIP, 0, 0), b = make_uint4(0, 0, 0, 0);
+            uint4 a = make_uint4(pos, PLAN_SKIP, 0, 0), b = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
             if (t.stream != 0xff) {
                 t.pos = pos;
-                if (t.np <= 4 && t.n_patch == 0) {
-                    a.y = (uint32_t)t.stream | ((uint32_t)t.np << 8);
+                // inline: up to four pieces and up to four byte patches, every patch inside a piece of >= 16 bytes
+                bool inline_ok = t.np <= 4 && t.n_patch <= 4 && (t.n_patch == 0 || t.items <= 32);     // (the copy kernel's general loop patches overflow records only)
+                for (int q = 0; q < (int)t.n_patch && inline_ok; ++q) {
+                    const int pp = (int)(t.patch[q] & 0xffffu);
+                    int o = 0;
+                    for (int k = 0; k < (int)t.np; ++k) {
+                        if (pp >= o && pp < o + (int)t.p[k].len && t.p[k].len < 16) inline_ok = false;
+                        o += t.p[k].len;
+                    }
+                }
+                if (inline_ok) {
+                    a.y = (uint32_t)t.stream | ((uint32_t)t.np << 8) | ((uint32_t)t.n_patch << 16);
                     a.z = t.np > 0 ? t.p[0].src : 0u; a.w = t.np > 1 ? t.p[1].src : 0u;
                     b.x = t.np > 2 ? t.p[2].src : 0u; b.y = t.np > 3 ? t.p[3].src : 0u;
                     b.z = (t.np > 0 ? (uint32_t)t.p[0].len : 0u) | ((t.np > 1 ? (uint32_t)t.p[1].len : 0u) << 16);
                     b.w = (t.np > 2 ? (uint32_t)t.p[2].len : 0u) | ((t.np > 3 ? (uint32_t)t.p[3].len : 0u) << 16);
+                    c.x = t.n_patch > 0 ? t.patch[0] : 0u; c.y = t.n_patch > 1 ? t.patch[1] : 0u;
+                    c.z = t.n_patch > 2 ? t.patch[2] : 0u; c.w = t.n_patch > 3 ? t.patch[3] : 0u;
                 } else {
                     a.y = PLAN_OVER | (uint32_t)t.stream;
                     over[ti] = t;
                 }
             }
-            plan[2 * ti] = a;
-            plan[2 * ti + 1] = b;
+            plan[3 * ti] = a;
+            plan[3 * ti + 1] = b;
+            plan[3 * ti + 2] = c;
+            general = a.y != PLAN_SKIP && !plan_is_whole(a, b);
+        }
+        // the records fmt_copy_whole_kernel does not take are listed (one atomic per wave) for the general copy kernel
+        {
+            const unsigned long long gm = __ballot(general);
+            if (gm) {
+                unsigned int base = 0;
+                // (GEN_LISTS separate lists, tile t appends to list t % GEN_LISTS: one shared counter would serialise
+                //  ~10^5 same-address atomics in L2 — that alone cost 1.3 ms)
+                const unsigned int lj = blockIdx.x % GEN_LISTS;
+                if (lane_id() == 0) base = atomicAdd(&n_gen[lj], (unsigned int)__popcll(gm));
+                base = (unsigned int)__shfl((int)base, 0, WAVE);
+                if (general) gen_list[(uint64_t)lj * gen_cap + base + (unsigned int)__popcll(gm & ((1ull << lane_id()) - 1ull))] = (uint32_t)(r * nfiles + file);
+            }
         }
         __syncthreads();            // (tasks[] is reused for the second file)
     }
@@ -742,12 +779,63 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
 #endif
 constexpr int FMT_UNROLL = AQC_FMT_UNROLL;
 constexpr int COPY_BLOCK = 256;
-__global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, uint64_t n_tasks, const uint4* __restrict__ plan,
-                                                             const FmtTask* __restrict__ over, FormatOut outs) {
+// Records that are ONE piece (untrimmed, unedited, not renamed: the bulk of a -f 0 -t 0 run) need none of the piece
+// search below: 32 lanes, window min(16 * lane, len - 16), load, store — as lean as a copy gets.  The general kernel skips them.
+__global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_kernel(FormatView v, uint64_t n_tasks, const uint4* __restrict__ plan,
+                                                                   FormatOut outs) {
     const int nfiles = v.paired ? 2 : 1;
     const int lane32 = threadIdx.x & 31;
-    const uint64_t hw = ((uint64_t)blockIdx.x * COPY_BLOCK + threadIdx.x) >> 5;          // half-wave index over the grid
+    const uint64_t hw = ((uint64_t)blockIdx.x * COPY_BLOCK + threadIdx.x) >> 5;
     const uint64_t t_first = hw * FMT_UNROLL;
+    uint4 pa[FMT_UNROLL], pb[FMT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < FMT_UNROLL; ++u) {
+        const uint64_t ti = t_first + u;
+        pa[u] = make_uint4(0, PLAN_SKIP, 0, 0); pb[u] = make_uint4(0, 0, 0, 0);
+        if (ti < n_tasks) { pa[u] = plan[3 * ti]; pb[u] = plan[3 * ti + 1]; }
+    }
+    uint4 val[FMT_UNROLL];
+    uint8_t* dptr[FMT_UNROLL];
+    bool on[FMT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < FMT_UNROLL; ++u) {
+        const int file = nfiles == 2 ? (int)((t_first + u) & 1) : 0;
+        const int len = (int)(pb[u].z & 0xffffu);
+        on[u] = plan_is_whole(pa[u], pb[u]) && lane32 < ((len + 15) >> 4);
+        const int off = min(16 * lane32, len - 16);
+        dptr[u] = outs.p[file * 3 + (int)(pa[u].y & 0xffu)] + pa[u].x + off;
+        if (on[u]) val[u] = load16u_t(v.f[file].text + pa[u].z + off);
+    }
+#pragma unroll
+    for (int u = 0; u < FMT_UNROLL; ++u)
+        if (on[u]) store16u(dptr[u], val[u]);
+}
+
+__global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, const uint4* __restrict__ plan, const FmtTask* __restrict__ over,
+                                                             FormatOut outs, const uint32_t* __restrict__ gen_lists,
+                                                             const unsigned int* __restrict__ n_gen, uint64_t gen_cap) {
+    const int nfiles = v.paired ? 2 : 1;
+    const int lane32 = threadIdx.x & 31;
+    // workgroup b works on list b % GEN_LISTS together with the other workgroups of that list
+    const unsigned int lj = blockIdx.x % GEN_LISTS;
+    const uint32_t* gen_list = gen_lists + (uint64_t)lj * gen_cap;
+    const uint64_t n_list = n_gen[lj];
+    const uint64_t n_hw = ((uint64_t)(gridDim.x / GEN_LISTS) * COPY_BLOCK) >> 5;
+  for (uint64_t hw = ((uint64_t)(blockIdx.x / GEN_LISTS) * COPY_BLOCK + threadIdx.x) >> 5; hw * FMT_UNROLL < n_list; hw += n_hw) {
+    const uint64_t l_first = hw * FMT_UNROLL;
+    // stages, each over all the plans in flight, so that the loads of a stage travel together: list, plans, (decode), data,
+    // stores.  (Interleaved per plan, every plan's data load waited for the next plan's plan load: eight serial round trips.)
+    uint64_t tis[FMT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < FMT_UNROLL; ++u) tis[u] = l_first + u < n_list ? (uint64_t)gen_list[l_first + u] : ~0ull;
+    uint4 pa[FMT_UNROLL], pb[FMT_UNROLL], pc[FMT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < FMT_UNROLL; ++u) {
+        const uint64_t ti = tis[u];
+        pa[u] = make_uint4(0, PLAN_SKIP, 0, 0); pb[u] = make_uint4(0, 0, 0, 0); pc[u] = make_uint4(0, 0, 0, 0);
+        if (ti != ~0ull) { pa[u] = plan[3 * ti]; pb[u] = plan[3 * ti + 1]; pc[u] = plan[3 * ti + 2]; }
+    }
+    int wpos[FMT_UNROLL];              // position of the lane's window in its output record
     uint4 val[FMT_UNROLL];
     uint8_t* dptr[FMT_UNROLL];
     const uint8_t* sptr[FMT_UNROLL];
@@ -755,10 +843,9 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, uint
     uint32_t more = 0;                 // bit u: plan u has more than 32 work items, or lives in the overflow array
 #pragma unroll
     for (int u = 0; u < FMT_UNROLL; ++u) {
-        const uint64_t ti = t_first + u;
-        mode[u] = 0; dptr[u] = nullptr; sptr[u] = nullptr; val[u] = make_uint4(0, 0, 0, 0);
-        if (ti >= n_tasks) continue;
-        const uint4 a = plan[2 * ti], b = plan[2 * ti + 1];
+        const uint64_t ti = tis[u];
+        const uint4 a = pa[u], b = pb[u];
+        mode[u] = 0; dptr[u] = nullptr; sptr[u] = nullptr; val[u] = make_uint4(0, 0, 0, 0); wpos[u] = 0;
         if (a.y == PLAN_SKIP) continue;
         if (a.y & PLAN_OVER) { more |= 1u << u; continue; }
         const int file = nfiles == 2 ? (int)(ti & 1) : 0;
@@ -782,10 +869,31 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, uint
         uint8_t* dst = outs.p[file * 3 + (int)(a.y & 0xffu)] + a.x + dst_off;
         if (lk >= 16) {
             const int off = min(16 * (lane32 - first_item), lk - 16);           // the last window is aligned to the piece's end
-            sptr[u] = src + off; dptr[u] = dst + off; mode[u] = 16;
-            val[u] = load16u_t(sptr[u]);
+            sptr[u] = src + off; dptr[u] = dst + off; mode[u] = 16; wpos[u] = dst_off + off;
         } else {
             sptr[u] = src; dptr[u] = dst; mode[u] = lk;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < FMT_UNROLL; ++u)
+        if (mode[u] == 16) val[u] = load16u_t(sptr[u]);
+    // the correction walk's edits: byte patches applied in registers (windows that overlap carry the same patch)
+#pragma unroll
+    for (int u = 0; u < FMT_UNROLL; ++u) {
+        const uint32_t np_ = (pa[u].y & PLAN_OVER) || pa[u].y == PLAN_SKIP ? 0u : (pa[u].y >> 16) & 0xffu;
+        if (np_ == 0 || mode[u] != 16) continue;
+        const uint32_t pt[4] = {pc[u].x, pc[u].y, pc[u].z, pc[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = (pt[q] & 0xffffu) - (uint32_t)wpos[u];
+            if ((uint32_t)q < np_ && i < 16u) {
+                const uint32_t sh = (i & 3u) * 8u, m = 0xffu << sh, cb = ((pt[q] >> 16) & 0xffu) << sh;
+                const uint32_t wd = i >> 2;
+                val[u].x = wd == 0 ? (val[u].x & ~m) | cb : val[u].x;
+                val[u].y = wd == 1 ? (val[u].y & ~m) | cb : val[u].y;
+                val[u].z = wd == 2 ? (val[u].z & ~m) | cb : val[u].z;
+                val[u].w = wd == 3 ? (val[u].w & ~m) | cb : val[u].w;
+            }
         }
     }
 #pragma unroll
@@ -801,8 +909,8 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, uint
     if (more) {
         for (int u = 0; u < FMT_UNROLL; ++u) {
             if (!((more >> u) & 1u)) continue;
-            const uint64_t ti = t_first + u;
-            const uint4 a = plan[2 * ti], b = plan[2 * ti + 1];
+            const uint64_t ti = tis[u];
+            const uint4 a = plan[3 * ti], b = plan[3 * ti + 1];
             const int file = nfiles == 2 ? (int)(ti & 1) : 0;
             const bool ov = (a.y & PLAN_OVER) != 0;
             const int stream = (int)(a.y & 0xffu);
@@ -837,6 +945,7 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, uint
             }
         }
     }
+  }
 }
 
 }  // namespace aqc
