@@ -534,6 +534,9 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                         dsc += 1 - (int)((D0 >> (x - 1)) & 1u);
                         if (dsc * 5 <= x && x <= xmax) pass |= 1u << x;
                     }
+                    // the score never falls along a diagonal: once 5 * score > xmax on every lane (unrelated tails get there
+                    // within a handful of columns) no later compLen can pass
+                    if (!__ballot(dsc * 5 <= xmax && x < xmax)) break;
                 }
                 const uint32_t both = pass & (uint32_t)xchg((int)pass);
                 const int cut = (moved && both) ? 31 - __clz((int)both) : 0;

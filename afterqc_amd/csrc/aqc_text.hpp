@@ -672,24 +672,28 @@ __device__ __forceinline__ void copy_small(uint8_t* d, const uint8_t* s_, int le
     __builtin_memcpy(d + len - N, b, N);
 }
 
-// ---- the writer, two kernels ---------------------------------------------------------------------------------------------
+// ---- the writer: plan, then copy ------------------------------------------------------------------------------------------
 // fmt_plan_kernel (thread = record, workgroup = tile of FMT_TILE records): the record's offset in its stream (block scans
-// over the sizes, tile bases from fmt_tile_bases_kernel) and its piece list, written as a 32-byte PLAN per (record, file):
-//     w0 offset in the stream | w1 stream, piece count, patch count | w2..w5 sources of up to four pieces | w6, w7 their
-//     lengths | w8..w11 up to four byte patches of the correction walk (output position | byte << 16)
-// (the pieces follow each other in the output, so their destinations are implied; 48 bytes).  Records with more pieces or
-// patches keep their full FmtTask in an overflow array (w1 bit 31).
-// fmt_copy_kernel (32 lanes = one plan, FMT_UNROLL plans in flight per half-wave): a lane owns one work item — a 16-byte
-// window of a long piece (16-byte load + 16-byte store at any alignment, the piece's last window end-aligned) or a whole
-// short piece.  No LDS, no dependent global loads beyond the plan itself: both kernels run at full occupancy.
+// over the sizes, tile bases from fmt_tile_bases_kernel) and its piece list, written as a PLAN of six 16-byte words per
+// (record, file):
+//     q0  offset in the stream | stream, piece count, patch count | source of piece 0 | lengths of pieces 0, 1
+//     q1  sources of pieces 1..4          q2  sources of pieces 5..7 | lengths of pieces 2, 3
+//     q3  lengths of pieces 4..7 | cumulative work items of pieces 0..7 (a byte each)
+//     q4  output offsets of pieces 1..7 (16 bits each) | total work items      q5  up to four byte patches (position | byte << 16)
+// The search a copy lane would otherwise repeat (which piece is my work item in, where does that piece start in the
+// output) is done here once per record.  Records with more than eight pieces / four patches / 32 work items keep their
+// full FmtTask in an overflow array (q0.y bit 31).  A record that goes out as ONE piece — its own bytes — needs q0 only.
+// fmt_copy_whole_kernel takes those, fmt_copy_kernel everything else (listed by the plan kernel).
 constexpr uint32_t PLAN_SKIP = 0xffffffffu, PLAN_OVER = 0x80000000u;
 constexpr unsigned int GEN_LISTS = 256;      // lists of "general" records (capacity gen_cap each), see fmt_plan_kernel
+constexpr int PLAN_Q = 6;                    // 16-byte words per plan
+constexpr int PLAN_MAXP = 8;
+constexpr int GEN_PASSES = 2;                // work items per lane of the general copy kernel (32 lanes per record)
 
-// the plans fmt_copy_whole_kernel takes: one piece of 16..512 bytes, no patches — a record that goes out as its own bytes
-__device__ __forceinline__ bool plan_is_whole(const uint4& a, const uint4& b) {
-    return (a.y & 0xffffff00u) == 0x100u && !(a.z & FMT_LIT_BIT) && (b.z & 0xffffu) >= 16u && (b.z & 0xffffu) <= 512u;
+// the plans fmt_copy_whole_kernel takes: one piece of 16..512 bytes from the text, no patches
+__device__ __forceinline__ bool plan_is_whole(const uint4& q0) {
+    return (q0.y & 0xffffff00u) == 0x100u && !(q0.z & FMT_LIT_BIT) && (q0.w & 0xffffu) >= 16u && (q0.w & 0xffffu) <= 512u;
 }
-
 
 __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
                                                             const unsigned long long* __restrict__ tile_base, int overlap_pass,
@@ -726,13 +730,16 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
         }
         if (r < n) {
             const uint64_t ti = r * nfiles + file;
-            uint4 a = make_uint4(pos, PLAN_SKIP, 0, 0), b = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
+            uint4 q[PLAN_Q];
+#pragma unroll
+            for (int k = 0; k < PLAN_Q; ++k) q[k] = make_uint4(0, 0, 0, 0);
+            q[0] = make_uint4(pos, PLAN_SKIP, 0, 0);
             if (t.stream != 0xff) {
                 t.pos = pos;
-                // inline: up to four pieces and up to four byte patches, every patch inside a piece of >= 16 bytes
-                bool inline_ok = t.np <= 4 && t.n_patch <= 4 && (t.n_patch == 0 || t.items <= 32);     // (the copy kernel's general loop patches overflow records only)
-                for (int q = 0; q < (int)t.n_patch && inline_ok; ++q) {
-                    const int pp = (int)(t.patch[q] & 0xffffu);
+                // inline: up to eight pieces, four byte patches (each inside a piece of >= 16 bytes), 64 work items (1 KiB)
+                bool inline_ok = t.np <= PLAN_MAXP && t.n_patch <= 4 && t.items <= 32 * GEN_PASSES;
+                for (int e = 0; e < (int)t.n_patch && inline_ok; ++e) {
+                    const int pp = (int)(t.patch[e] & 0xffffu);
                     int o = 0;
                     for (int k = 0; k < (int)t.np; ++k) {
                         if (pp >= o && pp < o + (int)t.p[k].len && t.p[k].len < 16) inline_ok = false;
@@ -740,22 +747,37 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
                     }
                 }
                 if (inline_ok) {
-                    a.y = (uint32_t)t.stream | ((uint32_t)t.np << 8) | ((uint32_t)t.n_patch << 16);
-                    a.z = t.np > 0 ? t.p[0].src : 0u; a.w = t.np > 1 ? t.p[1].src : 0u;
-                    b.x = t.np > 2 ? t.p[2].src : 0u; b.y = t.np > 3 ? t.p[3].src : 0u;
-                    b.z = (t.np > 0 ? (uint32_t)t.p[0].len : 0u) | ((t.np > 1 ? (uint32_t)t.p[1].len : 0u) << 16);
-                    b.w = (t.np > 2 ? (uint32_t)t.p[2].len : 0u) | ((t.np > 3 ? (uint32_t)t.p[3].len : 0u) << 16);
-                    c.x = t.n_patch > 0 ? t.patch[0] : 0u; c.y = t.n_patch > 1 ? t.patch[1] : 0u;
-                    c.z = t.n_patch > 2 ? t.patch[2] : 0u; c.w = t.n_patch > 3 ? t.patch[3] : 0u;
+                    uint32_t src[PLAN_MAXP], len[PLAN_MAXP], cum[PLAN_MAXP], off[PLAN_MAXP];
+                    uint32_t ci = 0, doff = 0;
+                    for (int k = 0; k < PLAN_MAXP; ++k) {
+                        const bool in = k < (int)t.np;
+                        src[k] = in ? t.p[k].src : 0u;
+                        len[k] = in ? (uint32_t)t.p[k].len : 0u;
+                        off[k] = doff;
+                        ci += len[k] >= 16 ? (len[k] + 15) >> 4 : (len[k] > 0 ? 1u : 0u);
+                        cum[k] = ci;
+                        doff += len[k];
+                    }
+                    q[0] = make_uint4(pos, (uint32_t)t.stream | ((uint32_t)t.np << 8) | ((uint32_t)t.n_patch << 16), src[0], len[0] | (len[1] << 16));
+                    q[1] = make_uint4(src[1], src[2], src[3], src[4]);
+                    q[2] = make_uint4(src[5], src[6], src[7], len[2] | (len[3] << 16));
+                    q[3] = make_uint4(len[4] | (len[5] << 16), len[6] | (len[7] << 16), cum[0] | (cum[1] << 8) | (cum[2] << 16) | (cum[3] << 24),
+                                      cum[4] | (cum[5] << 8) | (cum[6] << 16) | (cum[7] << 24));
+                    q[4] = make_uint4(off[1] | (off[2] << 16), off[3] | (off[4] << 16), off[5] | (off[6] << 16), off[7] | (ci << 16));
+                    q[5] = make_uint4(t.n_patch > 0 ? t.patch[0] : 0u, t.n_patch > 1 ? t.patch[1] : 0u, t.n_patch > 2 ? t.patch[2] : 0u,
+                                      t.n_patch > 3 ? t.patch[3] : 0u);
                 } else {
-                    a.y = PLAN_OVER | (uint32_t)t.stream;
+                    q[0].y = PLAN_OVER | (uint32_t)t.stream;
                     over[ti] = t;
                 }
             }
-            plan[3 * ti] = a;
-            plan[3 * ti + 1] = b;
-            plan[3 * ti + 2] = c;
-            general = a.y != PLAN_SKIP && !plan_is_whole(a, b);
+            const bool whole = plan_is_whole(q[0]);
+            plan[PLAN_Q * ti] = q[0];
+            if (!whole && q[0].y != PLAN_SKIP && !(q[0].y & PLAN_OVER)) {
+#pragma unroll
+                for (int k = 1; k < PLAN_Q; ++k) plan[PLAN_Q * ti + k] = q[k];
+            }
+            general = q[0].y != PLAN_SKIP && !whole;
         }
         // the records fmt_copy_whole_kernel does not take are listed (one atomic per wave) for the general copy kernel
         {
@@ -779,20 +801,22 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
 #endif
 constexpr int FMT_UNROLL = AQC_FMT_UNROLL;
 constexpr int COPY_BLOCK = 256;
-// Records that are ONE piece (untrimmed, unedited, not renamed: the bulk of a -f 0 -t 0 run) need none of the piece
-// search below: 32 lanes, window min(16 * lane, len - 16), load, store — as lean as a copy gets.  The general kernel skips them.
+
+// Records that are ONE piece (untrimmed, unedited, not renamed: the bulk of a -f 0 -t 0 run): 32 lanes, window
+// min(16 * lane, len - 16), load, store — as lean as a copy gets (tools/ubench/copy_rate.hip: this shape moves 6.9 GB in
+// 1.4 ms without the plan read, 1.6 ms with it).
 __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_kernel(FormatView v, uint64_t n_tasks, const uint4* __restrict__ plan,
                                                                    FormatOut outs) {
     const int nfiles = v.paired ? 2 : 1;
     const int lane32 = threadIdx.x & 31;
     const uint64_t hw = ((uint64_t)blockIdx.x * COPY_BLOCK + threadIdx.x) >> 5;
     const uint64_t t_first = hw * FMT_UNROLL;
-    uint4 pa[FMT_UNROLL], pb[FMT_UNROLL];
+    uint4 pa[FMT_UNROLL];
 #pragma unroll
     for (int u = 0; u < FMT_UNROLL; ++u) {
         const uint64_t ti = t_first + u;
-        pa[u] = make_uint4(0, PLAN_SKIP, 0, 0); pb[u] = make_uint4(0, 0, 0, 0);
-        if (ti < n_tasks) { pa[u] = plan[3 * ti]; pb[u] = plan[3 * ti + 1]; }
+        pa[u] = make_uint4(0, PLAN_SKIP, 0, 0);
+        if (ti < n_tasks) pa[u] = plan[PLAN_Q * ti];
     }
     uint4 val[FMT_UNROLL];
     uint8_t* dptr[FMT_UNROLL];
@@ -800,8 +824,8 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_kernel(FormatView v
 #pragma unroll
     for (int u = 0; u < FMT_UNROLL; ++u) {
         const int file = nfiles == 2 ? (int)((t_first + u) & 1) : 0;
-        const int len = (int)(pb[u].z & 0xffffu);
-        on[u] = plan_is_whole(pa[u], pb[u]) && lane32 < ((len + 15) >> 4);
+        const int len = (int)(pa[u].w & 0xffffu);
+        on[u] = plan_is_whole(pa[u]) && lane32 < ((len + 15) >> 4);
         const int off = min(16 * lane32, len - 16);
         dptr[u] = outs.p[file * 3 + (int)(pa[u].y & 0xffu)] + pa[u].x + off;
         if (on[u]) val[u] = load16u_t(v.f[file].text + pa[u].z + off);
@@ -811,6 +835,11 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_kernel(FormatView v
         if (on[u]) store16u(dptr[u], val[u]);
 }
 
+// Everything else, from the plan kernel's lists: 32 lanes per plan, two plans in flight per half-wave, a lane owns one work
+// item — a 16-byte window of a long piece (16-byte load + 16-byte store at any alignment, the piece's last window
+// end-aligned) or a whole short piece.  Stages (list, plans, decode, loads, patches, stores) run over both plans so that
+// each stage's memory operations travel together.
+constexpr int GEN_UNROLL = 2;
 __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, const uint4* __restrict__ plan, const FmtTask* __restrict__ over,
                                                              FormatOut outs, const uint32_t* __restrict__ gen_lists,
                                                              const unsigned int* __restrict__ n_gen, uint64_t gen_cap) {
@@ -821,131 +850,131 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
     const uint32_t* gen_list = gen_lists + (uint64_t)lj * gen_cap;
     const uint64_t n_list = n_gen[lj];
     const uint64_t n_hw = ((uint64_t)(gridDim.x / GEN_LISTS) * COPY_BLOCK) >> 5;
-  for (uint64_t hw = ((uint64_t)(blockIdx.x / GEN_LISTS) * COPY_BLOCK + threadIdx.x) >> 5; hw * FMT_UNROLL < n_list; hw += n_hw) {
-    const uint64_t l_first = hw * FMT_UNROLL;
-    // stages, each over all the plans in flight, so that the loads of a stage travel together: list, plans, (decode), data,
-    // stores.  (Interleaved per plan, every plan's data load waited for the next plan's plan load: eight serial round trips.)
-    uint64_t tis[FMT_UNROLL];
+    for (uint64_t hw = ((uint64_t)(blockIdx.x / GEN_LISTS) * COPY_BLOCK + threadIdx.x) >> 5; hw * GEN_UNROLL < n_list; hw += n_hw) {
+        const uint64_t l_first = hw * GEN_UNROLL;
+        uint64_t tis[GEN_UNROLL];
 #pragma unroll
-    for (int u = 0; u < FMT_UNROLL; ++u) tis[u] = l_first + u < n_list ? (uint64_t)gen_list[l_first + u] : ~0ull;
-    uint4 pa[FMT_UNROLL], pb[FMT_UNROLL], pc[FMT_UNROLL];
+        for (int u = 0; u < GEN_UNROLL; ++u) tis[u] = l_first + u < n_list ? (uint64_t)gen_list[l_first + u] : ~0ull;
+        uint4 q[GEN_UNROLL][PLAN_Q];
 #pragma unroll
-    for (int u = 0; u < FMT_UNROLL; ++u) {
-        const uint64_t ti = tis[u];
-        pa[u] = make_uint4(0, PLAN_SKIP, 0, 0); pb[u] = make_uint4(0, 0, 0, 0); pc[u] = make_uint4(0, 0, 0, 0);
-        if (ti != ~0ull) { pa[u] = plan[3 * ti]; pb[u] = plan[3 * ti + 1]; pc[u] = plan[3 * ti + 2]; }
-    }
-    int wpos[FMT_UNROLL];              // position of the lane's window in its output record
-    uint4 val[FMT_UNROLL];
-    uint8_t* dptr[FMT_UNROLL];
-    const uint8_t* sptr[FMT_UNROLL];
-    int mode[FMT_UNROLL];              // 0 nothing, 16 a window, 1..15 a short piece of that many bytes
-    uint32_t more = 0;                 // bit u: plan u has more than 32 work items, or lives in the overflow array
+        for (int u = 0; u < GEN_UNROLL; ++u) {
 #pragma unroll
-    for (int u = 0; u < FMT_UNROLL; ++u) {
-        const uint64_t ti = tis[u];
-        const uint4 a = pa[u], b = pb[u];
-        mode[u] = 0; dptr[u] = nullptr; sptr[u] = nullptr; val[u] = make_uint4(0, 0, 0, 0); wpos[u] = 0;
-        if (a.y == PLAN_SKIP) continue;
-        if (a.y & PLAN_OVER) { more |= 1u << u; continue; }
-        const int file = nfiles == 2 ? (int)(ti & 1) : 0;
-        const uint32_t srcs[4] = {a.z, a.w, b.x, b.y};
-        const int lens[4] = {(int)(b.z & 0xffffu), (int)(b.z >> 16), (int)(b.w & 0xffffu), (int)(b.w >> 16)};
-        // which piece does item `lane32` belong to?  (pieces follow each other in the output)
-        int first_item = 0, dst_off = 0, k = 0;
+            for (int k = 0; k < PLAN_Q; ++k) q[u][k] = make_uint4(0, 0, 0, 0);
+            q[u][0].y = PLAN_SKIP;
+            if (tis[u] != ~0ull) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cnt = lens[q] >= 16 ? (lens[q] + 15) >> 4 : (lens[q] > 0 ? 1 : 0);
-            if (k == q && lane32 >= first_item + cnt) { first_item += cnt; dst_off += lens[q]; k = q + 1; }
-        }
-        int total_items = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) total_items += lens[q] >= 16 ? (lens[q] + 15) >> 4 : (lens[q] > 0 ? 1 : 0);
-        if (total_items > 32) { more |= 1u << u; continue; }       // a long record: the general loop below
-        if (k >= 4 || lane32 >= total_items) continue;
-        const uint32_t sk = k == 0 ? srcs[0] : k == 1 ? srcs[1] : k == 2 ? srcs[2] : srcs[3];
-        const int lk = k == 0 ? lens[0] : k == 1 ? lens[1] : k == 2 ? lens[2] : lens[3];
-        const uint8_t* src = (sk & FMT_LIT_BIT) ? &FMT_LIT[0][0] + (sk & ~FMT_LIT_BIT) : v.f[file].text + sk;
-        uint8_t* dst = outs.p[file * 3 + (int)(a.y & 0xffu)] + a.x + dst_off;
-        if (lk >= 16) {
-            const int off = min(16 * (lane32 - first_item), lk - 16);           // the last window is aligned to the piece's end
-            sptr[u] = src + off; dptr[u] = dst + off; mode[u] = 16; wpos[u] = dst_off + off;
-        } else {
-            sptr[u] = src; dptr[u] = dst; mode[u] = lk;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < FMT_UNROLL; ++u)
-        if (mode[u] == 16) val[u] = load16u_t(sptr[u]);
-    // the correction walk's edits: byte patches applied in registers (windows that overlap carry the same patch)
-#pragma unroll
-    for (int u = 0; u < FMT_UNROLL; ++u) {
-        const uint32_t np_ = (pa[u].y & PLAN_OVER) || pa[u].y == PLAN_SKIP ? 0u : (pa[u].y >> 16) & 0xffu;
-        if (np_ == 0 || mode[u] != 16) continue;
-        const uint32_t pt[4] = {pc[u].x, pc[u].y, pc[u].z, pc[u].w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t i = (pt[q] & 0xffffu) - (uint32_t)wpos[u];
-            if ((uint32_t)q < np_ && i < 16u) {
-                const uint32_t sh = (i & 3u) * 8u, m = 0xffu << sh, cb = ((pt[q] >> 16) & 0xffu) << sh;
-                const uint32_t wd = i >> 2;
-                val[u].x = wd == 0 ? (val[u].x & ~m) | cb : val[u].x;
-                val[u].y = wd == 1 ? (val[u].y & ~m) | cb : val[u].y;
-                val[u].z = wd == 2 ? (val[u].z & ~m) | cb : val[u].z;
-                val[u].w = wd == 3 ? (val[u].w & ~m) | cb : val[u].w;
+                for (int k = 0; k < PLAN_Q; ++k) q[u][k] = plan[PLAN_Q * tis[u] + k];     // (q1.. of an overflow plan are never used)
             }
         }
-    }
+        constexpr int NWIN = GEN_UNROLL * GEN_PASSES;     // windows in flight per lane: plan u, pass j -> slot u * GEN_PASSES + j
+        uint4 val[NWIN];
+        uint8_t* dptr[NWIN];
+        const uint8_t* sptr[NWIN];
+        int mode[NWIN], wpos[NWIN];          // mode: 0 nothing, 16 a window, 1..15 a short piece of that many bytes
+        uint32_t more = 0;                   // bit u: plan u lives in the overflow array
 #pragma unroll
-    for (int u = 0; u < FMT_UNROLL; ++u) {
-        if (mode[u] == 16) store16u(dptr[u], val[u]);
-        else if (mode[u] >= 8) copy_small<8>(dptr[u], sptr[u], mode[u]);
-        else if (mode[u] >= 4) copy_small<4>(dptr[u], sptr[u], mode[u]);
-        else if (mode[u] >= 2) copy_small<2>(dptr[u], sptr[u], mode[u]);
-        else if (mode[u] == 1) dptr[u][0] = sptr[u][0];
-    }
-    // ---- the general form: any number of pieces / work items, edits applied on top (rare: records with corrections,
-    //      reads of more than ~500 bytes of output, renamed records with stripped whitespace)
-    if (more) {
-        for (int u = 0; u < FMT_UNROLL; ++u) {
-            if (!((more >> u) & 1u)) continue;
-            const uint64_t ti = tis[u];
-            const uint4 a = plan[3 * ti], b = plan[3 * ti + 1];
-            const int file = nfiles == 2 ? (int)(ti & 1) : 0;
-            const bool ov = (a.y & PLAN_OVER) != 0;
-            const int stream = (int)(a.y & 0xffu);
-            const int np = ov ? (int)over[ti].np : (int)((a.y >> 8) & 0xffu);
-            uint8_t* out0 = outs.p[file * 3 + stream] + a.x;
-            int dst_off = 0;
-            for (int k = 0; k < np; ++k) {
-                uint32_t sk; int lk;
-                if (ov) { sk = over[ti].p[k].src; lk = (int)over[ti].p[k].len; }
-                else {
-                    sk = k == 0 ? a.z : k == 1 ? a.w : k == 2 ? b.x : b.y;
-                    lk = k == 0 ? (int)(b.z & 0xffffu) : k == 1 ? (int)(b.z >> 16) : k == 2 ? (int)(b.w & 0xffffu) : (int)(b.w >> 16);
-                }
+        for (int u = 0; u < GEN_UNROLL; ++u) {
+            const uint4 q0 = q[u][0], q1 = q[u][1], q2 = q[u][2], q3 = q[u][3], q4 = q[u][4];
+#pragma unroll
+            for (int j = 0; j < GEN_PASSES; ++j) {
+                const int w = u * GEN_PASSES + j;
+                mode[w] = 0; dptr[w] = nullptr; sptr[w] = nullptr; val[w] = make_uint4(0, 0, 0, 0); wpos[w] = 0;
+            }
+            if (q0.y == PLAN_SKIP) continue;
+            if (q0.y & PLAN_OVER) { more |= 1u << u; continue; }
+            const int file = nfiles == 2 ? (int)(tis[u] & 1) : 0;
+            const uint32_t items = q4.w >> 16;
+            const unsigned long long cum = ((unsigned long long)q3.w << 32) | q3.z;
+#pragma unroll
+            for (int j = 0; j < GEN_PASSES; ++j) {
+                const int w = u * GEN_PASSES + j;
+                const uint32_t item = (uint32_t)lane32 + 32u * j;
+                if (item >= items) continue;
+                // my piece: count the pieces whose cumulative item count I am at or beyond
+                int k = 0;
+#pragma unroll
+                for (int jj = 0; jj < PLAN_MAXP - 1; ++jj) k += item >= (uint32_t)((cum >> (8 * jj)) & 0xffu) ? 1 : 0;
+                const int first_item = (int)(((cum << 8) >> (8 * k)) & 0xffu);
+                const uint32_t lw = k < 2 ? q0.w : k < 4 ? q2.w : k < 6 ? q3.x : q3.y;                  // lengths, two per word
+                const int lk = (int)((lw >> (16 * (k & 1))) & 0xffffu);
+                const uint32_t ow = k < 1 ? 0u : k < 3 ? q4.x : k < 5 ? q4.y : k < 7 ? q4.z : q4.w;     // output offsets of pieces 1..7
+                const int dst_off = k == 0 ? 0 : (int)((ow >> (16 * ((k - 1) & 1))) & 0xffffu);
+                const uint32_t sk = k == 0 ? q0.z : k == 1 ? q1.x : k == 2 ? q1.y : k == 3 ? q1.z : k == 4 ? q1.w : k == 5 ? q2.x : k == 6 ? q2.y : q2.z;
                 const uint8_t* src = (sk & FMT_LIT_BIT) ? &FMT_LIT[0][0] + (sk & ~FMT_LIT_BIT) : v.f[file].text + sk;
-                uint8_t* dst = out0 + dst_off;
+                uint8_t* dst = outs.p[file * 3 + (int)(q0.y & 0xffu)] + q0.x + dst_off;
                 if (lk >= 16) {
-                    for (int w0 = 16 * lane32; w0 < lk; w0 += 16 * 32) {
-                        const int off = min(w0, lk - 16);
-                        store16u(dst + off, load16u_t(src + off));
-                    }
-                } else if (lane32 < lk) dst[lane32] = src[lane32];
-                dst_off += lk;
+                    const int off = min(16 * ((int)item - first_item), lk - 16);       // the last window is aligned to the piece's end
+                    sptr[w] = src + off; dptr[w] = dst + off; mode[w] = 16; wpos[w] = dst_off + off;
+                } else {
+                    sptr[w] = src; dptr[w] = dst; mode[w] = lk;
+                }
             }
-            if (ov && over[ti].n_patch) {
-                // byte patches on top of the copies (the copies of this wave are complete first)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_s_waitcnt(0);
-                if (lane32 < (int)over[ti].n_patch) {
-                    const uint32_t pt = over[ti].patch[lane32];
-                    out0[pt & 0xffffu] = (uint8_t)(pt >> 16);
+        }
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w)
+            if (mode[w] == 16) val[w] = load16u_t(sptr[w]);
+        // the correction walk's edits: byte patches applied in registers (windows that overlap carry the same patch)
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+            const int u = w / GEN_PASSES;
+            const uint32_t np_ = (q[u][0].y & PLAN_OVER) || q[u][0].y == PLAN_SKIP ? 0u : (q[u][0].y >> 16) & 0xffu;
+            if (np_ == 0 || mode[w] != 16) continue;
+            const uint32_t pt[4] = {q[u][5].x, q[u][5].y, q[u][5].z, q[u][5].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t i = (pt[e] & 0xffffu) - (uint32_t)wpos[w];
+                if ((uint32_t)e < np_ && i < 16u) {
+                    const uint32_t sh = (i & 3u) * 8u, m = 0xffu << sh, cb = ((pt[e] >> 16) & 0xffu) << sh;
+                    const uint32_t wd = i >> 2;
+                    val[w].x = wd == 0 ? (val[w].x & ~m) | cb : val[w].x;
+                    val[w].y = wd == 1 ? (val[w].y & ~m) | cb : val[w].y;
+                    val[w].z = wd == 2 ? (val[w].z & ~m) | cb : val[w].z;
+                    val[w].w = wd == 3 ? (val[w].w & ~m) | cb : val[w].w;
+                }
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < NWIN; ++w) {
+            if (mode[w] == 16) store16u(dptr[w], val[w]);
+            else if (mode[w] >= 8) copy_small<8>(dptr[w], sptr[w], mode[w]);
+            else if (mode[w] >= 4) copy_small<4>(dptr[w], sptr[w], mode[w]);
+            else if (mode[w] >= 2) copy_small<2>(dptr[w], sptr[w], mode[w]);
+            else if (mode[w] == 1) dptr[w][0] = sptr[w][0];
+        }
+        // ---- overflow records: any number of pieces / work items, piece by piece (records of more than ~500 bytes, more
+        //      than eight pieces or four patches)
+        if (more) {
+            for (int u = 0; u < GEN_UNROLL; ++u) {
+                if (!((more >> u) & 1u)) continue;
+                const uint64_t ti = tis[u];
+                const FmtTask& t = over[ti];
+                const int file = nfiles == 2 ? (int)(ti & 1) : 0;
+                uint8_t* out0 = outs.p[file * 3 + (int)t.stream] + t.pos;
+                const int np = (int)t.np;
+                for (int k = 0; k < np; ++k) {
+                    const uint32_t sk = t.p[k].src;
+                    const int lk = (int)t.p[k].len;
+                    const uint8_t* src = (sk & FMT_LIT_BIT) ? &FMT_LIT[0][0] + (sk & ~FMT_LIT_BIT) : v.f[file].text + sk;
+                    uint8_t* dst = out0 + t.p[k].dst;
+                    if (lk >= 16) {
+                        for (int w0 = 16 * lane32; w0 < lk; w0 += 16 * 32) {
+                            const int off = min(w0, lk - 16);
+                            store16u(dst + off, load16u_t(src + off));
+                        }
+                    } else if (lane32 < lk) dst[lane32] = src[lane32];
+                }
+                if (t.n_patch) {
+                    // byte patches on top of the copies (the copies of this wave are complete first)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_s_waitcnt(0);
+                    if (lane32 < (int)t.n_patch) {
+                        const uint32_t pt = t.patch[lane32];
+                        out0[pt & 0xffffu] = (uint8_t)(pt >> 16);
+                    }
                 }
             }
         }
     }
-  }
 }
 
 }  // namespace aqc
