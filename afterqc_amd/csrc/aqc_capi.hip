@@ -165,9 +165,10 @@ static void launch_fast(aqc_ctx* c, Slot* s, const aqc_config& cfg, const DevSta
     // pairs the fast kernel cannot decide exactly (exotic bytes, very short reads, ...) are queued and
     // finished by the general wave-per-record pipeline right behind it on the same stream
     (void)hipMemsetAsync(s->n_deferred.p, 0, sizeof(unsigned int), s->stream);
-    hipLaunchKernelGGL((fast_filter_overlap_kernel<NW, PAIRED, WPBT, BARCODE>), dim3((unsigned)blocks), dim3(WPBT * WAVE), 0, s->stream,
-                       s->view, cfg, c->circles, (aqc_result*)s->results.p, st, accum_limit, (uint32_t*)s->deferred.p,
-                       (unsigned int*)s->n_deferred.p);
+    FastArgs K;
+    K.fb = s->view; K.cfg = cfg; K.circ = c->circles; K.results = (aqc_result*)s->results.p; K.st = st; K.accum_limit = accum_limit;
+    K.deferred = (uint32_t*)s->deferred.p; K.n_deferred = (unsigned int*)s->n_deferred.p;
+    hipLaunchKernelGGL((fast_filter_overlap_kernel<NW, PAIRED, WPBT, BARCODE>), dim3((unsigned)blocks), dim3(WPBT * WAVE), 0, s->stream, K);
 }
 
 extern "C" {
@@ -797,6 +798,7 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
         v.f[k].name_len = (const uint32_t*)s->t_name_len[k].p;
         v.f[k].plus_off = (const uint32_t*)s->t_plus_off[k].p;
         v.f[k].plus_len = (const uint32_t*)s->t_plus_len[k].p;
+        v.f[k].qual_len = (const uint32_t*)s->t_qual_len[k].p;
     }
     // streams q = file * 3 + {0 good, 1 bad, 2 overlap}: per-tile byte sums -> tile bases (one launch each), the
     // per-record offsets are formed inside the writer

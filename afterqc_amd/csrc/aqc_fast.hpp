@@ -65,10 +65,26 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { 
 // mask with the low 2*nb bits set, nb in 0..16
 __device__ __forceinline__ uint32_t base_mask(int nb) { return nb >= 16 ? 0xffffffffu : ((1u << (2 * nb)) - 1u); }
 
+// Wave-wide max / sum of a lane value, in uniform control flow (all 64 lanes active), as a wave-uniform result: four DPP
+// steps inside the rows of 16 lanes (lane ^ 1, lane ^ 2, half-row mirror, row mirror), then the four row results through
+// v_readlane and scalar arithmetic.  The __shfl_xor form goes through the LDS crossbar (six ds_bpermute round trips) and
+// keeps its six lane-address registers alive for the whole kernel.
+template <int CTRL>
+__device__ __forceinline__ int dpp_move(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v = max(v, __shfl_xor(v, s, WAVE));
-    return v;
+    v = max(v, dpp_move<0xB1>(v));       // quad_perm [1,0,3,2]
+    v = max(v, dpp_move<0x4E>(v));       // quad_perm [2,3,0,1]
+    v = max(v, dpp_move<0x141>(v));      // row_half_mirror
+    v = max(v, dpp_move<0x140>(v));      // row_mirror
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_sum_u(int v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 
 // 16 sequence bytes -> lo plane (2 bits/base: (c >> 1) & 3), e plane ('N' flag, bit 3 of the byte, on the odd bit)
@@ -105,11 +121,11 @@ struct FastWaveLds {
     static constexpr int PPW = PAIRED ? 32 : 64;               // records per wave batch
     static constexpr int GUARD = (PAIRED ? 4 : 2) * NW;        // 5 zero words behind the planes
     static constexpr int LQ0 = GUARD + 5;                      // read 1's low-quality bit plane: 16 bits per chunk
-    static constexpr int STRIDE = (LQ0 + (NW + 1) / 2) | 1;    // odd: conflict-free lane-strided access
+    // the record's descriptor lives in its row too: one row address serves the planes and these (immediate offsets)
+    static constexpr int D_O1 = LQ0 + (NW + 1) / 2, D_L1 = D_O1 + 1, D_Q1 = D_O1 + 2, D_O2 = D_O1 + 3, D_L2 = D_O1 + 4, D_Q2 = D_O1 + 5;
+    static constexpr int D_EXO = D_O1 + 6, D_LQ = D_O1 + 7;    // alphabet verdict (non-zero: defer), read 1's low-quality count
+    static constexpr int STRIDE = (D_O1 + 8) | 1;              // odd: conflict-free lane-strided access
     uint32_t planes[PPW][STRIDE];
-    uint32_t o1[PPW], o2[PPW], q1[PPW], q2[PAIRED ? PPW : 1], l1[PPW], l2[PPW];
-    uint32_t lq[PPW];
-    uint32_t exo[PPW];
     uint8_t stage[16 * NW + 16];
 };
 
@@ -147,8 +163,13 @@ __device__ __forceinline__ int base_idx_acgt(uint32_t c) { return (int)((0x3120u
 
 // exchange a value with the partner lane (lane ^ 1): DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ int xchg(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true); }
-// the partner lane's predicate, through a ballot (all lanes must call it)
-__device__ __forceinline__ bool xchg_pred(bool b) { return ((__ballot(b) >> (lane_id() ^ 1)) & 1ull) != 0; }
+// the partner lane's predicate (all lanes must call it).  One DPP move: the ballot form needs the lane's 64-bit bit mask,
+// a loop invariant the compiler keeps in two registers for the whole kernel
+__device__ __forceinline__ bool xchg_pred(bool b) { return xchg(b ? 1 : 0) != 0; }
+// number of set bits of m below this lane
+__device__ __forceinline__ unsigned int rank_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
 
 // mismatch word j of a diagonal: moving stream (lo/e at word index k+j, sub-word shift s) against the
 // fixed stream's word j; returns one flag per base on the ODD bits, limited to the first nb bases.
@@ -166,7 +187,7 @@ __device__ __forceinline__ uint32_t mm_word(uint32_t mlo0, uint32_t mlo1, uint32
 #ifdef AQC_PROFILE
 #define PROF_DECL unsigned long long prof_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_amdgcn_s_memtime(); const unsigned long long prof_t0 = prof_last;
 #define PROF(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof_t[k] += now_ - prof_last; prof_last = now_; } while (0)
-#define PROF_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 10; ++k_) atomicAdd(&st.counters[AQC_N_COUNTERS + k_], prof_t[k_]); } while (0)
+#define PROF_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 10; ++k_) atomicAdd(&R->st.counters[AQC_N_COUNTERS + k_], prof_t[k_]); } while (0)
 #else
 #define PROF_DECL
 #define PROF(k)
@@ -186,21 +207,42 @@ struct BarcodeCodes {
     uint32_t m0, m1;      // even-bit mask of the verify's fields
 };
 
+// The kernel's arguments, one struct.  The hot loop keeps what it uses in every batch in scalar registers (K.field); what
+// only rare branches need — the bubble circles and name fields, the trim amounts, the deferral queue, the device status
+// word, the statistics arrays — is read from the kernarg segment where it is used (R->field, an s_load): held in SGPRs
+// across the loop those ~40 values pushed the kernel past the 102 it has, and the spill code (v_writelane / v_readlane
+// + hazard nops) was ~6 % of all vector instructions issued.
+struct FastArgs {
+    DevBatch fb;
+    aqc_config cfg;
+    DevCircles circ;
+    aqc_result* results;
+    DevStats st;
+    uint64_t accum_limit;
+    uint32_t* deferred;
+    unsigned int* n_deferred;
+};
+typedef const FastArgs __attribute__((address_space(4))) * FastArgsRare;
+
 template <int NW, bool PAIRED, int WPBT, bool BARCODE>
-__global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overlap_kernel(DevBatch fb, aqc_config cfg, DevCircles circ,
-                                                                    aqc_result* __restrict__ results, DevStats st,
-                                                                    uint64_t accum_limit, uint32_t* __restrict__ deferred,
-                                                                    unsigned int* __restrict__ n_deferred) {
+__global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overlap_kernel(FastArgs K) {
+    const DevBatch& fb = K.fb;
+    const aqc_config& cfg = K.cfg;
+    aqc_result* __restrict__ const results = K.results;
+    const uint64_t accum_limit = K.accum_limit;
+    FastArgsRare R = (FastArgsRare)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(R));                   // opaque: nothing read through R is hoisted out of its branch
     using WL = FastWaveLds<NW, PAIRED>;
     constexpr int PPW = WL::PPW;
     constexpr int ITERS = PPW * NW / WAVE;        // 16-byte chunk tasks per lane and string kind
-    static_assert(PPW * NW % WAVE == 0, "chunk tasks must tile the wave");
+    static_assert(PPW * NW % WAVE == 0 && (!PAIRED || NW % 2 == 0), "chunk tasks must tile the wave");
     __shared__ WL wls[WPBT];
     __shared__ BlockAcc acc;
     __shared__ unsigned int batch_ticket;
     __shared__ uint4 mtab[17];                    // mtab[nb]: byte mask of the first nb bytes of a 16-byte chunk
-    const int lane = lane_id();
-    const int wave = threadIdx.x / WAVE;
+    // (lane from mbcnt, wave in a scalar register: nothing derived from the work-item id has to survive the main loop)
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     for (int i = threadIdx.x; i < (int)(sizeof(BlockAcc) / 4); i += WPBT * WAVE) ((unsigned int*)&acc)[i] = 0;
     if (threadIdx.x == 0) batch_ticket = WPBT;      // tickets 0 .. WPBT-1 are the waves' first batches
     if (threadIdx.x < 17) {
@@ -222,15 +264,15 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     const uint32_t* const par = pr + (role ? 0 : 2 * NW);   // partner stream
     const uint32_t* const qo1 = fb.qoff1 ? fb.qoff1 : fb.off1;
     const uint32_t* const qo2 = PAIRED ? (fb.qoff2 ? fb.qoff2 : fb.off2) : nullptr;
-    const int thr4 = (cfg.qualified_quality_phred + 33) * 0x01010101;
-    const bool do_trim = cfg.trim_front > 0 || cfg.trim_tail > 0;
+    const int thr4 = __builtin_amdgcn_readfirstlane((cfg.qualified_quality_phred + 33) * 0x01010101);
+    const int do_trim = __builtin_amdgcn_readfirstlane((cfg.trim_front > 0 || cfg.trim_tail > 0) ? 1 : 0);
     // read 1's low-quality count: with a view that is only known per read (trim, barcode) phase 1 leaves one bit per base
     // and the owner counts inside its view; otherwise the chunks are simply summed
-    const bool lq_plane = BARCODE || do_trim;
     // longest run of identical bases any firing polyX window must contain (pigeonhole over the mismatches)
     const int need = cfg.poly_size_limit - cfg.allow_mismatch_in_poly;
-    const int run_req = cfg.allow_mismatch_in_poly >= 0 ? (need + cfg.allow_mismatch_in_poly) / (cfg.allow_mismatch_in_poly + 1) : 0;
-    const int r2b = (PAIRED && cfg.count_r2_bases) ? 1 : 0;
+    // (the division runs on the vector unit: bring the result back to a scalar register once)
+    const int run_req = __builtin_amdgcn_readfirstlane(cfg.allow_mismatch_in_poly >= 0 ? (need + cfg.allow_mismatch_in_poly) / (cfg.allow_mismatch_in_poly + 1) : 0);
+    const int r2b = __builtin_amdgcn_readfirstlane((PAIRED && cfg.count_r2_bases) ? 1 : 0);
     BarcodeCodes bc{0, 0, 0, 0};
     if (BARCODE) {
         for (int j = 0; j < cfg.barcode_verify_len && j < 32; ++j) {
@@ -248,7 +290,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     int since_flush = 0;
     auto flush_totals = [&]() {
         unsigned long long* C = acc.counters;
-        auto fld = [&](uint32_t r, int sh, uint32_t mask) -> unsigned long long { return (unsigned long long)(uint32_t)wave_sum((int)((r >> sh) & mask)); };
+        auto fld = [&](uint32_t r, int sh, uint32_t mask) -> unsigned long long { return (unsigned long long)(uint32_t)wave_sum_u((int)((r >> sh) & mask)); };
         const unsigned long long t_n = fld(R0, 0, 0xff), t_good = fld(R0, 8, 0xff), t_ar = fld(R0, 16, 0xff), t_ov = fld(R0, 24, 0xff);
         const unsigned long long t_tb = fld(R1, 0, 0xffff), t_gb = fld(R1, 16, 0xffff), t_ab = fld(R2, 0, 0xffff), t_ol = fld(R2, 16, 0xffff);
         const unsigned long long t_od = fld(R3, 0, 0xff), t_rc = fld(R3, 8, 0xff), t_bc = fld(R3, 16, 0xff), t_mk = fld(R3, 24, 0xff), t_sk = fld(R4, 0, 0xff);
@@ -287,14 +329,17 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     // (the workgroup's column rotates with t, so that its batches are spread over all memory channels)
     auto batch_of = [&](uint32_t t) -> uint64_t { return (uint64_t)gridDim.x * t + (blockIdx.x + 61u * t) % gridDim.x; };
     uint64_t cur = batch_of((uint32_t)wave);
-    // chunk task `it` of this lane: record (low byte) and chunk within the record — loop invariants, kept PACKED and
-    // re-opened inside the loop behind an opaque barrier: left to itself the compiler hoists every derived address
-    // (15 64-bit values per lane), runs out of registers and reloads them from scratch in every iteration
+    // chunk task `it` of this lane: chunk t = it * 64 + lane of the batch, i.e. chunk t % NW of record t / NW — ten
+    // neighbouring lanes cover one read, every load instruction of the wave reads 6.4 whole reads (dense in memory: dealing
+    // each lane the chunks of its OWN pair costs a third fewer instructions and runs slower, its loads touch 32 lines
+    // each).  Kept as ONE packed word per task — byte offset of the record's LDS row | chunk << 16 — and re-opened inside
+    // the loop behind an opaque barrier: left to itself the compiler hoists every derived address (15 64-bit values per
+    // lane), runs out of registers and reloads them from scratch in every iteration.
     uint32_t task[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int t = it * WAVE + lane;
-        task[it] = (uint32_t)(t / NW) | ((uint32_t)(t % NW) << 8);
+        task[it] = (uint32_t)((t / NW) * (WL::STRIDE * 4)) | ((uint32_t)(t % NW) << 16);
     }
     // the descriptor of this lane's read in the NEXT batch is fetched one iteration ahead
     uint32_t m_o = 0, m_l = 0, m_q = 0;
@@ -305,6 +350,13 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         m_q = role ? qo2[r0] : qo1[r0];
     }
     while (cur < n_batches) {
+        // The options are read where they are used, from the kernarg segment through a pointer that is opaque per batch
+        // (Rb->cfg.x: an s_load next to the vector work).  As loop invariants the compiler turns every "option > 0" into a
+        // 64-bit lane mask held across the loop (two SGPRs per condition, ~15 conditions), runs out of scalar registers and
+        // spills them to VGPR lanes — v_writelane / v_readlane + hazard nops were ~6 % of the vector instructions issued.
+        FastArgsRare Rb = R;
+        asm volatile("" : "+s"(Rb));
+        const int o_do_trim = do_trim, o_run_req = run_req, o_r2b = r2b, o_thr4 = thr4;
         const uint64_t base = cur * PPW;
         // exactly ONE batch of lookahead (its descriptors travel while this batch is processed): a slow wave never sits
         // on more than one batch the faster waves could have taken
@@ -312,8 +364,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         const uint64_t rec = base + p;
         const bool valid = rec < fb.n;
         // ------------------------------------------------------------------ phase 1: load + pack
-        if (role == 0) { L.o1[p] = m_o; L.l1[p] = m_l; L.q1[p] = m_q; L.lq[p] = 0; L.exo[p] = 0; }
-        else { L.o2[p] = m_o; L.l2[p] = m_l; L.q2[p] = m_q; }
+        if (role == 0) { pr[WL::D_O1] = m_o; pr[WL::D_L1] = m_l; pr[WL::D_Q1] = m_q; pr[WL::D_EXO] = 0; pr[WL::D_LQ] = 0; }
+        else { pr[WL::D_O2] = m_o; pr[WL::D_L2] = m_l; pr[WL::D_Q2] = m_q; }
         {
             const uint64_t nrec = nxt * PPW + p;
             m_o = m_l = m_q = 0;
@@ -328,29 +380,32 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         // Bytes behind the end of a read (the rest of the text line, the next record) become the pad symbol; every byte
         // that is kept is checked against the alphabet the packed arithmetic takes (A C G T N; qualities < 0x80).  The
         // verdict goes to the record's flag word with one LDS OR per chunk (no compare, no branch).
+        uint8_t* const rows = reinterpret_cast<uint8_t*>(&L.planes[0][0]);
+#define AQC_TASK_ROW(q) reinterpret_cast<uint32_t*>(rows + ((q) & 0xffffu))
         {
             uint4 v[ITERS];
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
                 asm volatile("" : "+v"(q));
-                v[it] = load16u(fb.seq1 + (uint32_t)(L.o1[q & 0xffu] + ((q >> 8) << 4)));
+                v[it] = load16u(fb.seq1 + (uint32_t)(AQC_TASK_ROW(q)[WL::D_O1] + ((q >> 16) << 4)));
             }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
                 asm volatile("" : "+v"(q));
-                const int spi = (int)(q & 0xffu), c = (int)(q >> 8), leni = (int)L.l1[spi];
-                const uint4 m = mtab[min(max(leni - 16 * c, 0), 16)];
+                uint32_t* const row = AQC_TASK_ROW(q);
+                const int c = (int)(q >> 16);
+                const uint4 m = mtab[min(max((int)row[WL::D_L1] - 16 * c, 0), 16)];
                 uint4 d;
                 d.x = bfi(m.x, v[it].x, 0x41414141u); d.y = bfi(m.y, v[it].y, 0x41414141u);
                 d.z = bfi(m.z, v[it].z, 0x41414141u); d.w = bfi(m.w, v[it].w, 0x41414141u);
                 if (AQC_ABL & 2) d = v[it];
-                if (!(AQC_ABL & 1)) atomicOr(&L.exo[spi], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
+                if (!(AQC_ABL & 1)) atomicOr(&row[WL::D_EXO], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
                 uint32_t lo, e;
                 pack_chunk(d, lo, e);
-                L.planes[spi][c] = lo;
-                L.planes[spi][NW + c] = e;
+                row[c] = lo;
+                row[NW + c] = e;
             }
         }
         if (PAIRED) {
@@ -359,68 +414,71 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
                 asm volatile("" : "+v"(q));
-                v[it] = load16u(fb.seq2 + (uint32_t)(L.o2[q & 0xffu] + ((q >> 8) << 4)));
+                v[it] = load16u(fb.seq2 + (uint32_t)(AQC_TASK_ROW(q)[WL::D_O2] + ((q >> 16) << 4)));
             }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
                 asm volatile("" : "+v"(q));
-                const int spi = (int)(q & 0xffu), c = (int)(q >> 8), leni = (int)L.l2[spi];
-                const uint4 m = mtab[min(max(leni - 16 * c, 0), 16)];
+                uint32_t* const row = AQC_TASK_ROW(q);
+                const int c = (int)(q >> 16);
+                const uint4 m = mtab[min(max((int)row[WL::D_L2] - 16 * c, 0), 16)];
                 uint4 d;
                 d.x = bfi(m.x, v[it].x, 0x41414141u); d.y = bfi(m.y, v[it].y, 0x41414141u);
                 d.z = bfi(m.z, v[it].z, 0x41414141u); d.w = bfi(m.w, v[it].w, 0x41414141u);
                 if (AQC_ABL & 2) d = v[it];
-                if (!(AQC_ABL & 1)) atomicOr(&L.exo[spi], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
+                if (!(AQC_ABL & 1)) atomicOr(&row[WL::D_EXO], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
                 uint32_t lo, e;
                 pack_chunk(d, lo, e);
                 // complement (A<->T, C<->G: flip the high bit of the field), keep N at code 3, then reverse the chunk
                 lo = (lo ^ ODD) | e | (e >> 1);
-                L.planes[spi][2 * NW + (NW - 1 - c)] = rev2(lo);
-                L.planes[spi][3 * NW + (NW - 1 - c)] = __builtin_bitreverse32(e) << 1;
+                row[3 * NW - 1 - c] = rev2(lo);
+                row[4 * NW - 1 - c] = __builtin_bitreverse32(e) << 1;
             }
         }
-        if (cfg.unqualified_base_limit > 0) {
+        if (Rb->cfg.unqualified_base_limit > 0) {
             uint4 v[ITERS];
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
                 asm volatile("" : "+v"(q));
-                v[it] = load16u(fb.qual1 + (uint32_t)(L.q1[q & 0xffu] + ((q >> 8) << 4)));
+                v[it] = load16u(fb.qual1 + (uint32_t)(AQC_TASK_ROW(q)[WL::D_Q1] + ((q >> 16) << 4)));
             }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
                 asm volatile("" : "+v"(q));
-                const int spi = (int)(q & 0xffu), c = (int)(q >> 8), leni = (int)L.l1[spi];
-                const uint4 m = mtab[min(max(leni - 16 * c, 0), 16)];
+                uint32_t* const row = AQC_TASK_ROW(q);
+                const int c = (int)(q >> 16);
+                const uint4 m = mtab[min(max((int)row[WL::D_L1] - 16 * c, 0), 16)];
                 uint4 d;
                 d.x = bfi(m.x, v[it].x, 0x7f7f7f7fu); d.y = bfi(m.y, v[it].y, 0x7f7f7f7fu);
                 d.z = bfi(m.z, v[it].z, 0x7f7f7f7fu); d.w = bfi(m.w, v[it].w, 0x7f7f7f7fu);
                 if (AQC_ABL & 2) d = v[it];
-                if (!(AQC_ABL & 1)) atomicOr(&L.exo[spi], ((d.x | d.y) | (d.z | d.w)) & 0x80808080u);
+                if (!(AQC_ABL & 1)) atomicOr(&row[WL::D_EXO], ((d.x | d.y) | (d.z | d.w)) & 0x80808080u);
                 // byte >= thr  <=>  high bit of ((byte | 0x80) - thr) set   (bytes < 0x80, thr <= 0x7f)
-                const uint32_t g0 = ((d.x | 0x80808080u) - thr4) & 0x80808080u, g1 = ((d.y | 0x80808080u) - thr4) & 0x80808080u;
-                const uint32_t g2 = ((d.z | 0x80808080u) - thr4) & 0x80808080u, g3 = ((d.w | 0x80808080u) - thr4) & 0x80808080u;
-                if (!lq_plane) {
+                const uint32_t g0 = ((d.x | 0x80808080u) - o_thr4) & 0x80808080u, g1 = ((d.y | 0x80808080u) - o_thr4) & 0x80808080u;
+                const uint32_t g2 = ((d.z | 0x80808080u) - o_thr4) & 0x80808080u, g3 = ((d.w | 0x80808080u) - o_thr4) & 0x80808080u;
+                if (!(BARCODE || o_do_trim)) {
                     // the whole read counts: the 0x7f padding is "qualified", chunks wholly behind the read are all padding
                     const int cnt = 16 - (__popc(g0) + __popc(g1) + __popc(g2) + __popc(g3));
-                    if (cnt) atomicAdd(&L.lq[spi], (uint32_t)cnt);
+                    if (cnt) atomicAdd(&row[WL::D_LQ], (uint32_t)cnt);
                 } else {
                     const uint32_t f16 = udot4((g0 ^ 0x80808080u) >> 7, 0x08040201u, 0u) | (udot4((g1 ^ 0x80808080u) >> 7, 0x08040201u, 0u) << 4) |
                                          (udot4((g2 ^ 0x80808080u) >> 7, 0x08040201u, 0u) << 8) | (udot4((g3 ^ 0x80808080u) >> 7, 0x08040201u, 0u) << 12);
-                    reinterpret_cast<uint16_t*>(&L.planes[spi][WL::LQ0])[c] = (uint16_t)f16;
+                    reinterpret_cast<uint16_t*>(row + WL::LQ0)[c] = (uint16_t)f16;
                 }
             }
         }
+#undef AQC_TASK_ROW
         __builtin_amdgcn_wave_barrier();
         PROF(0);
 
         // ------------------------------------------------------------------ phase 2: lane per read
-        const int L1 = (int)L.l1[p];
-        const int L2 = PAIRED ? (int)L.l2[p] : 0;
+        const int L1 = (int)pr[WL::D_L1];
+        const int L2 = PAIRED ? (int)pr[WL::D_L2] : 0;
         const bool accum = valid && rec < accum_limit;
-        bool defer = valid && (L.exo[p] != 0 || L1 > 16 * NW || L2 > 16 * NW || L1 == 0 || (PAIRED && L2 == 0));
+        bool defer = valid && (pr[WL::D_EXO] != 0 || L1 > 16 * NW || L2 > 16 * NW || L1 == 0 || (PAIRED && L2 == 0));
         const int Lown = role ? L2 : L1;
         int a_own = 0, len_own = Lown;
         int flag = -1;
@@ -545,16 +603,16 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         }
         // trim (preprocesser.py:455-466): every lane trims its own read
         const int a_pre = a_own, len_pre = len_own;
-        if (do_trim && flag < 0) {
+        if (o_do_trim && flag < 0) {
             int st_ = 0, nl_ = 0;
-            trim_view(len_own, role ? cfg.trim_front2 : cfg.trim_front, role ? cfg.trim_tail2 : cfg.trim_tail, st_, nl_);
+            trim_view(len_own, role ? R->cfg.trim_front2 : R->cfg.trim_front, role ? R->cfg.trim_tail2 : R->cfg.trim_tail, st_, nl_);
             a_own += st_; len_own = nl_;
         }
         int a_par = 0, len_par = 0;
         if (PAIRED) { a_par = xchg(a_own); len_par = xchg(len_own); }
         int a1 = role ? a_par : a_own, len1 = role ? len_par : len_own;
         int a2 = role ? a_own : a_par, len2 = role ? len_own : len_par;
-        if (do_trim) {
+        if (o_do_trim) {
             // (every exchange runs on all lanes: a DPP read from a masked-off partner returns 0)
             const int xa_pre = PAIRED ? xchg(a_pre) : 0, xl_pre = PAIRED ? xchg(len_pre) : 0;
             if (flag < 0) {
@@ -564,8 +622,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         }
         // ---- read 1's low-quality count inside its final view
         int lq_cnt = 0;
-        if (cfg.unqualified_base_limit > 0) {
-            if (!lq_plane) lq_cnt = (int)L.lq[p];
+        if (Rb->cfg.unqualified_base_limit > 0) {
+            if (!(BARCODE || o_do_trim)) lq_cnt = (int)pr[WL::D_LQ];
             else {
                 int cnt = 0;
                 if (role == 0) {
@@ -611,42 +669,51 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         PROF(1);
 
         // ---- bubble (preprocesser.py:469-473)
-        if (cfg.debubble && circ.n > 0 && fb.aux_ok) {
+        if (Rb->cfg.debubble && R->circ.n > 0 && R->fb.aux_ok) {
             bool hit = false;
-            if (valid && flag < 0 && fb.aux_ok[rec] == 2) atomicCAS(st.status, 0, AQC_ERR_ARG);     // int() raises upstream
-            else if (valid && flag < 0 && fb.aux_ok[rec]) {
-                const int ln = fb.aux_lane[rec], tl = fb.aux_tile[rec], x = fb.aux_x[rec], y = fb.aux_y[rec];
-                for (int i = 0; i < circ.n; ++i) {
-                    if (circ.tile[i] == tl && circ.lane[i] == ln) {
-                        const double dx = __dsub_rn(circ.cx[i], (double)x), dy = __dsub_rn(circ.cy[i], (double)y);
-                        if (__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)) < __dmul_rn(circ.cr[i], circ.cr[i])) hit = true;
+            const uint8_t* const aux_ok = R->fb.aux_ok;
+            const uint8_t ok = valid && flag < 0 ? aux_ok[rec] : (uint8_t)0;
+            if (ok == 2) {                                          // int() raises upstream
+                int code = AQC_ERR_ARG;
+                asm volatile("" : "+v"(code));                      // (built here, not hoisted out of the loop as a register pair)
+                atomicCAS(R->st.status, 0, code);
+            }
+            else if (ok) {
+                const int ln = R->fb.aux_lane[rec], tl = R->fb.aux_tile[rec], x = R->fb.aux_x[rec], y = R->fb.aux_y[rec];
+                const int n_circ = R->circ.n;
+                const int32_t *c_tile = R->circ.tile, *c_lane = R->circ.lane;
+                const double *c_x = R->circ.cx, *c_y = R->circ.cy, *c_r = R->circ.cr;
+                for (int i = 0; i < n_circ; ++i) {
+                    if (c_tile[i] == tl && c_lane[i] == ln) {
+                        const double dx = __dsub_rn(c_x[i], (double)x), dy = __dsub_rn(c_y[i], (double)y);
+                        if (__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)) < __dmul_rn(c_r[i], c_r[i])) hit = true;
                     }
                 }
             }
             if (hit) flag = AQC_BADBBL;
         }
         // ---- length (preprocesser.py:476-479)
-        if (flag < 0 && len1 < cfg.seq_len_req) flag = AQC_BADLEN;
+        if (flag < 0 && len1 < Rb->cfg.seq_len_req) flag = AQC_BADLEN;
         // ---- polyX (preprocesser.py:482-490): run-length screen per read, exact check by the wave for the few hits
-        if (cfg.poly_size_limit > 0) {
+        if (Rb->cfg.poly_size_limit > 0) {
             bool sus = false;
-            if (run_req < 2) sus = len_own >= cfg.poly_size_limit;
+            if (o_run_req < 2) sus = len_own >= Rb->cfg.poly_size_limit;
             else {
-                uint32_t r[NW + 1], Wlo[NW + 1], We[NW + 1];
-#pragma unroll
-                for (int j = 0; j < NW; ++j) { Wlo[j] = own[j]; We[j] = own[NW + j]; }
-                Wlo[NW] = 0; We[NW] = 0;
+                uint32_t r[NW + 1];
+                uint32_t lo0 = own[0], e0 = own[NW];
 #pragma unroll
                 for (int j = 0; j < NW; ++j) {
-                    const uint32_t x = Wlo[j] ^ alignbit(Wlo[j + 1], Wlo[j], 2);
-                    const uint32_t ex = We[j] ^ alignbit(We[j + 1], We[j], 2);
+                    const uint32_t lo1 = j + 1 < NW ? own[j + 1] : 0u, e1 = j + 1 < NW ? own[NW + j + 1] : 0u;
+                    const uint32_t x = lo0 ^ alignbit(lo1, lo0, 2);
+                    const uint32_t ex = e0 ^ alignbit(e1, e0, 2);
                     // base i equals base i+1, only for i <= len-2
                     r[j] = ~(((x << 1) | x | ex)) & ODD & base_mask(min(max(len_own - 1 - 16 * j, 0), 16));
+                    lo0 = lo1; e0 = e1;
                 }
                 r[NW] = 0;
                 int covered = 1;
-                while (covered < run_req - 1) {
-                    const int step = min(min(covered, run_req - 1 - covered), 15);
+                while (covered < o_run_req - 1) {
+                    const int step = min(min(covered, o_run_req - 1 - covered), 15);
 #pragma unroll
                     for (int j = 0; j < NW; ++j) r[j] &= alignbit(r[j + 1], r[j], 2 * step);
                     covered += step;
@@ -654,7 +721,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 uint32_t any = 0;
 #pragma unroll
                 for (int j = 0; j < NW; ++j) any |= r[j];
-                sus = any != 0 && len_own >= cfg.poly_size_limit;
+                sus = any != 0 && len_own >= Rb->cfg.poly_size_limit;
             }
             bool poly = false;
             unsigned long long todo = __ballot(valid && !defer && flag < 0 && sus);
@@ -662,12 +729,12 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const int l = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 const int lp = PAIRED ? l >> 1 : l, lr = PAIRED ? l & 1 : 0;
-                const int ta = __shfl(a_own, l, WAVE), tl = __shfl(len_own, l, WAVE);
+                const int ta = __builtin_amdgcn_readlane(a_own, l), tl = __builtin_amdgcn_readlane(len_own, l);
                 // hasPolyX runs on the read as sequenced (read 2 is NOT reverse-complemented)
-                const uint8_t* src = (lr ? fb.seq2 + L.o2[lp] : fb.seq1 + L.o1[lp]) + ta;
+                const uint8_t* src = (lr ? fb.seq2 + L.planes[lp][WL::D_O2] : fb.seq1 + L.planes[lp][WL::D_O1]) + ta;
                 stage(L.stage, src, tl);
                 __builtin_amdgcn_wave_barrier();
-                const int px = has_polyx_wave(L.stage, tl, cfg.poly_size_limit, cfg.allow_mismatch_in_poly);
+                const int px = has_polyx_wave(L.stage, tl, Rb->cfg.poly_size_limit, Rb->cfg.allow_mismatch_in_poly);
                 __builtin_amdgcn_wave_barrier();
                 if (px != 0 && lane == l) poly = true;
             }
@@ -678,14 +745,14 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         }
         PROF(2);
         // ---- low quality: read 1 only (preprocesser.py:498)
-        if (flag < 0 && cfg.unqualified_base_limit > 0 && lq_cnt > cfg.unqualified_base_limit) flag = AQC_BADLQC;
+        if (flag < 0 && Rb->cfg.unqualified_base_limit > 0 && lq_cnt > Rb->cfg.unqualified_base_limit) flag = AQC_BADLQC;
         // ---- N (preprocesser.py:504-512)
-        if (cfg.n_base_limit > 0) {
+        if (Rb->cfg.n_base_limit > 0) {
             int n_own = 0;
 #pragma unroll
             for (int j = 0; j < NW; ++j) n_own += __popc(own[NW + j]);
             const int n_par = PAIRED ? xchg(n_own) : 0;
-            if (flag < 0 && (n_own > cfg.n_base_limit || n_par > cfg.n_base_limit)) flag = AQC_BADNCT;
+            if (flag < 0 && (n_own > Rb->cfg.n_base_limit || n_par > Rb->cfg.n_base_limit)) flag = AQC_BADNCT;
         }
         PROF(3);
         // ---- overlap (util.py:158-212) --------------------------------------------------------------
@@ -694,7 +761,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         int em0 = -1, em1 = -1, em2 = -1, walk_a = 0;
         unsigned long long E0 = 0, E1 = 0, E2 = 0;
         bool walk_pair = false, walker = false;
-        if (PAIRED && !cfg.no_overlap) {
+        if (PAIRED && !Rb->cfg.no_overlap) {
             // own candidates: offsets c = 0 .. len_own - 31, the own stream moving over the partner's prefix
             const int n_own = len_own > 30 ? len_own - 30 : 0;
             bool scan = valid && !defer && flag < 0;
@@ -805,7 +872,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                         c_adapter_base = -2 * offset; c_adapter_read = 1;
                         walk_a = -offset;
                         len1 = ovl; len2 = ovl; offset = 0;
-                        if (len1 < cfg.seq_len_req) { flag = AQC_BADLEN; ovl = 0; dist = 0; }
+                        if (len1 < Rb->cfg.seq_len_req) { flag = AQC_BADLEN; ovl = 0; dist = 0; }
                     }
                 }
             }
@@ -828,8 +895,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const uint32_t* s1w = pr;                                  // read-1 stream
                 const uint32_t* s2w = pr + 2 * NW;                         // reverse_r2 stream
                 // (lanes that do not walk still execute the loads below: keep their addresses inside the arenas)
-                const uint8_t* h1 = fb.qual1 + (walker ? (uint64_t)L.q1[p] + a1 + (len1 - ovl) : 0);
-                const uint8_t* h2 = fb.qual2 + (walker ? (uint64_t)L.q2[p] + a2 + (len2 - 1) : 0);
+                const uint8_t* h1 = fb.qual1 + (walker ? (uint64_t)pr[WL::D_Q1] + a1 + (len1 - ovl) : 0);
+                const uint8_t* h2 = fb.qual2 + (walker ? (uint64_t)pr[WL::D_Q2] + a2 + (len2 - 1) : 0);
                 int wq1[3], wq2[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -853,8 +920,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                         int em = -1;
                         if (r2_wrong && both_acgt) em = base_idx_acgt(comp_acgtn(bA)) * 4 + base_idx_acgt(r2o);
                         if (r1_wrong && both_acgt) em = base_idx_acgt(bB) * 4 + base_idx_acgt(bA);
-                        const bool fix = (r2_wrong || r1_wrong) && !cfg.no_correction;
-                        const bool mask = !fix && cfg.mask_mismatch;
+                        const bool fix = (r2_wrong || r1_wrong) && !Rb->cfg.no_correction;
+                        const bool mask = !fix && Rb->cfg.mask_mismatch;
                         const unsigned long long kind = fix ? (r2_wrong ? AQC_EDIT_FIX_R2 : AQC_EDIT_FIX_R1) : AQC_EDIT_MASK;
                         const unsigned long long base = fix ? (r2_wrong ? comp_acgtn(bA) : bB) : 0u;
                         const unsigned long long qual = fix ? (unsigned long long)(r2_wrong ? qa : qb) : (unsigned long long)'!';
@@ -894,8 +961,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         const bool cnt = mine && accum;
         if (cnt) {
             R0 += 1u;
-            R1 += (uint32_t)(L1 + r2b * L2);
-            if (flag == AQC_GOOD) { R0 += 1u << 8; R1 += (uint32_t)(len1 + r2b * len2) << 16; }
+            R1 += (uint32_t)(L1 + o_r2b * L2);
+            if (flag == AQC_GOOD) { R0 += 1u << 8; R1 += (uint32_t)(len1 + o_r2b * len2) << 16; }
             else atomicAdd(&acc.counters[AQC_C_FLAG0 + flag], 1ull);
             if (PAIRED) {
                 R2 += (uint32_t)c_adapter_base; R0 += (uint32_t)c_adapter_read << 16;
@@ -923,10 +990,10 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             const unsigned long long dmask = __ballot(valid && defer && role == 0);
             if (dmask) {
                 unsigned int slot0 = 0;
-                if (lane == 0) slot0 = atomicAdd(n_deferred, (unsigned int)__popcll(dmask));
-                slot0 = (unsigned int)__shfl((int)slot0, 0, WAVE);
+                if (lane == 0) slot0 = atomicAdd(R->n_deferred, (unsigned int)__popcll(dmask));
+                slot0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)slot0);
                 if (valid && defer && role == 0)
-                    deferred[slot0 + (unsigned int)__popcll(dmask & ((1ull << lane) - 1ull))] = (uint32_t)(rec - 0);
+                    R->deferred[slot0 + rank_below(dmask)] = (uint32_t)(rec - 0);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -939,12 +1006,14 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     // per-wave start / end stamps (100 MHz reference clock) at the tail of the deferral queue buffer: load balance
     if (lane == 0) {
         const uint64_t gw = (uint64_t)blockIdx.x * WPBT + wave;
-        deferred[fb.n - 2 * (gw + 1)] = (uint32_t)prof_t0;
-        deferred[fb.n - 2 * (gw + 1) + 1] = (uint32_t)__builtin_amdgcn_s_memtime();
+        R->deferred[fb.n - 2 * (gw + 1)] = (uint32_t)prof_t0;
+        R->deferred[fb.n - 2 * (gw + 1) + 1] = (uint32_t)__builtin_amdgcn_s_memtime();
     }
 #endif
     __syncthreads();
-    flush_block_acc(acc, st);
+    DevStats st;
+    st.counters = R->st.counters; st.ovl_hist = R->st.ovl_hist; st.dist_hist = R->st.dist_hist; st.status = R->st.status;
+    flush_block_acc(acc, st, wave * WAVE + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
 }
 
 }  // namespace aqc

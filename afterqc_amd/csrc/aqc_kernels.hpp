@@ -546,10 +546,11 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
 // ------------------------------------------------------------------------------------------------
 // Generic kernel: grid-stride over records, one wave per record, block-private counters flushed once.
 // ------------------------------------------------------------------------------------------------
-__device__ inline void flush_block_acc(BlockAcc& acc, const DevStats& st) {
-    for (int i = threadIdx.x; i < AQC_N_COUNTERS; i += blockDim.x)
+__device__ inline void flush_block_acc(BlockAcc& acc, const DevStats& st, int tid = -1) {
+    if (tid < 0) tid = (int)threadIdx.x;
+    for (int i = tid; i < AQC_N_COUNTERS; i += blockDim.x)
         if (acc.counters[i]) atomicAdd(&st.counters[i], acc.counters[i]);
-    for (int i = threadIdx.x; i < AQC_QC_COLS; i += blockDim.x) {
+    for (int i = tid; i < AQC_QC_COLS; i += blockDim.x) {
         if (acc.ovl_hist[i]) atomicAdd(&st.ovl_hist[i], (unsigned long long)acc.ovl_hist[i]);
         if (acc.dist_hist[i]) atomicAdd(&st.dist_hist[i], (unsigned long long)acc.dist_hist[i]);
     }

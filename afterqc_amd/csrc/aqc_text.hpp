@@ -128,8 +128,14 @@ __device__ __forceinline__ unsigned long long newline_mask64(const uint8_t* p, u
 // newline count (flag A), adds up its predecessors' counts until it meets one that already knows its inclusive prefix
 // (flag P), publishes its own prefix and emits.  The text is read once; the old count / scan / emit trio read it twice
 // and needed three launches per file.
-constexpr int IDX_BYTES_PER_THREAD = 128;
-constexpr int IDX_TILE = TXT_BLOCK * IDX_BYTES_PER_THREAD;     // 32 KiB
+#ifndef AQC_IDX_SUB
+#define AQC_IDX_SUB 4
+#endif
+constexpr int IDX_K = 8;                              // 16-byte pieces a lane loads at a time (one sub-tile)
+constexpr int IDX_SUB = AQC_IDX_SUB;                  // sub-tiles per tile
+constexpr int IDX_P = IDX_K * IDX_SUB;                // pieces per lane per tile
+constexpr int IDX_TILE = TXT_BLOCK * 16 * IDX_P;      // 128 KiB: one ticket and one look-back per tile (same-address atomics
+                                                      // serialise in L2 at ~8 ns each, so 32 KiB tiles capped the kernel near 4 TB/s)
 constexpr unsigned long long IDX_FLAG_A = 1ull << 62, IDX_FLAG_P = 2ull << 62, IDX_VAL = (1ull << 62) - 1ull;
 constexpr uint32_t LINE_WS = 0x80000000u, LINE_POS = 0x7fffffffu;
 
@@ -145,80 +151,90 @@ struct IndexFile {
 // newline flags and "< 0x21" flags of the 16 bytes of v, one bit per byte
 __device__ __forceinline__ void piece_masks(const uint4 v, uint32_t& nl16, uint32_t& bl16) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    nl16 = 0; bl16 = 0;
+    uint32_t zb[4], zn[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const uint32_t x = w[d] ^ 0x0a0a0a0au;
-        const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;        // 0x80 where the byte is '\n'
         const uint32_t t = (w[d] & 0x7f7f7f7fu) + 0x5f5f5f5fu;                            // bit 7 where the low 7 bits are >= 0x21
-        const uint32_t zb = ~(t | w[d]) & 0x80808080u;
-        nl16 |= __builtin_amdgcn_udot4(z >> 7, 0x08040201u, 0u, false) << (4 * d);
-        bl16 |= __builtin_amdgcn_udot4(zb >> 7, 0x08040201u, 0u, false) << (4 * d);
+        zb[d] = ~(t | w[d]) & 0x80808080u;                                                 // 0x80 where the byte is < 0x21
+        // '\n' is one of those bytes, and they all have bit 7 clear: byte ^ 0x0a is zero iff adding 0x7f does not reach bit 7
+        const uint32_t x = w[d] ^ 0x0a0a0a0au;
+        zn[d] = ~((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) & zb[d];                          // 0x80 where the byte is '\n'
     }
+    // gather the bit 7s: dot products with weights 1, 2, 4, ... (0x80 * mask), two words per chain
+    const uint32_t n_lo = __builtin_amdgcn_udot4(zn[1], 0x80402010u, __builtin_amdgcn_udot4(zn[0], 0x08040201u, 0u, false), false);
+    const uint32_t n_hi = __builtin_amdgcn_udot4(zn[3], 0x80402010u, __builtin_amdgcn_udot4(zn[2], 0x08040201u, 0u, false), false);
+    const uint32_t b_lo = __builtin_amdgcn_udot4(zb[1], 0x80402010u, __builtin_amdgcn_udot4(zb[0], 0x08040201u, 0u, false), false);
+    const uint32_t b_hi = __builtin_amdgcn_udot4(zb[3], 0x80402010u, __builtin_amdgcn_udot4(zb[2], 0x08040201u, 0u, false), false);
+    nl16 = (n_lo >> 7) | (n_hi << 1);
+    bl16 = (b_lo >> 7) | (b_hi << 1);
 }
 
-// Layout inside a tile: a wave owns 8 KiB; its lane i reads the 16-byte pieces at  wave base + k * 1024 + i * 16,
-// k = 0..7 — every load instruction of the wave is one contiguous KiB (the earlier "128 contiguous bytes per thread" made
-// each instruction touch 64 different cache lines and ran at 2.3 TB/s whatever the arithmetic cost).  The text order of the
-// pieces is (k, lane), so the rank of a piece's first newline is  tile prefix + waves before + pieces (k' < k) + lanes before
-// within k: eight lane scans (two counts per register), no data transposed.
-constexpr int IDX_K = IDX_BYTES_PER_THREAD / 16;      // pieces per lane
+// Layout inside a tile: a wave owns IDX_SUB * 8 KiB; its lane i reads the 16-byte pieces at  wave base + p * 1024 + i * 16,
+// p = 0..IDX_P-1, eight at a time — every load instruction of the wave is one contiguous KiB (the earlier "contiguous bytes
+// per thread" made each instruction touch 64 different cache lines and ran at 2.3 TB/s whatever the arithmetic cost).  The
+// text order of the pieces is (p, lane), so the rank of a piece's first newline is  tile prefix + waves before + pieces
+// (p' < p) + lanes before within p.  Between the load and the emit only the 16-bit newline / blank masks of a piece are
+// kept, in LDS (32 KiB per workgroup); the emit pass rebuilds the lane ranks from them with one packed lane scan per two
+// pieces.  Both passes are rolled loops: fully unrolled, the compiler kept the whole tile's state live (300 registers).
 __global__ __launch_bounds__(TXT_BLOCK) void text_index_kernel(IndexFile f0, IndexFile f1, unsigned long long* __restrict__ state,
                                                                unsigned int* __restrict__ ticket) {
     __shared__ unsigned int s_tile;
     __shared__ unsigned int s_wave_tot[TXT_BLOCK / WAVE];
     __shared__ unsigned long long s_base;
+    __shared__ uint32_t s_nl[IDX_P / 2][TXT_BLOCK], s_ws[IDX_P / 2][TXT_BLOCK];     // two pieces per word
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t tile = s_tile;
     const IndexFile& f = tile >= f1.tile0 && f1.tiles ? f1 : f0;
     const uint32_t lt = tile - f.tile0;                                   // tile within the file
     const int lane = lane_id(), wave = threadIdx.x / WAVE;
-    const uint64_t wbase = (uint64_t)lt * IDX_TILE + (uint64_t)wave * (WAVE * IDX_BYTES_PER_THREAD);
-    // (the buffer is zero-filled for more than a tile behind the text: no bounds checks, zeros are no newlines)
+    const uint64_t wbase = (uint64_t)lt * IDX_TILE + (uint64_t)wave * (WAVE * 16 * IDX_P);
+    const uint64_t lbase = wbase + (uint64_t)lane * 16;
+    // (the buffer is zero-filled for more than a tile behind the text; loads are still bounded by the text's end)
+    uint32_t carry_in = (wbase > 0 && wbase <= f.bytes && lane == 0) ? (f.text[wbase - 1] < 0x21 ? 1u : 0u) : 0u;
+    uint32_t mine = 0;                            // newlines in this lane's pieces
     uint4 v[IDX_K];
 #pragma unroll
     for (int k = 0; k < IDX_K; ++k) {
-        const uint64_t q = wbase + (uint64_t)k * (WAVE * 16) + (uint64_t)lane * 16;
+        const uint64_t q = lbase + (uint64_t)k * (WAVE * 16);
         v[k] = q < f.bytes ? *reinterpret_cast<const uint4*>(f.text + q) : make_uint4(0, 0, 0, 0);
     }
-    uint32_t nl[IDX_K], ws[IDX_K];
-    uint32_t carry_in = (wbase > 0 && wbase <= f.bytes && lane == 0) ? (f.text[wbase - 1] < 0x21 ? 1u : 0u) : 0u;
+#pragma unroll 1
+    for (int sub = 0; sub < IDX_SUB; ++sub) {
+        uint4 nx[IDX_K];
 #pragma unroll
-    for (int k = 0; k < IDX_K; ++k) {
-        uint32_t bl;
-        piece_masks(v[k], nl[k], bl);
-        // mask the bytes behind the end of the text (the last piece may be partial)
-        const uint64_t q = wbase + (uint64_t)k * (WAVE * 16) + (uint64_t)lane * 16;
-        if (q + 16 > f.bytes) { const uint32_t keep = q >= f.bytes ? 0u : ((1u << (f.bytes - q)) - 1u); nl[k] &= keep; }
-        // "the byte before is blank": this piece's flags moved up one byte; the byte before the piece is the last byte of
-        // the piece of the lane before (same k), for lane 0 of the last lane's piece of k - 1
-        const uint32_t top = bl >> 15;
-        uint32_t prev = (uint32_t)__shfl_up((int)top, 1, WAVE);
-        if (lane == 0) prev = carry_in;
-        carry_in = (uint32_t)__builtin_amdgcn_readlane((int)top, WAVE - 1);          // (only lane 0 uses it)
-        ws[k] = ((bl << 1) | prev) & 0xffffu;
-    }
-    // ranks: inclusive lane scans of the per-piece counts, two pieces per register
-    uint32_t inc[IDX_K / 2];
-#pragma unroll
-    for (int j = 0; j < IDX_K / 2; ++j) {
-        uint32_t c = (uint32_t)__popc(nl[2 * j]) | ((uint32_t)__popc(nl[2 * j + 1]) << 16);
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)c, d, WAVE);
-            if (lane >= d) c += o;
+        for (int k = 0; k < IDX_K; ++k) {         // the next sub-tile is on its way while this one is worked on
+            const uint64_t q = lbase + (uint64_t)((sub + 1) * IDX_K + k) * (WAVE * 16);
+            nx[k] = (sub + 1 < IDX_SUB && q < f.bytes) ? *reinterpret_cast<const uint4*>(f.text + q) : make_uint4(0, 0, 0, 0);
         }
-        inc[j] = c;
-    }
-    uint32_t koff[IDX_K];          // newlines of the wave's pieces k' < k
-    uint32_t wtot = 0;
+        uint32_t nlp = 0, wsp = 0;
 #pragma unroll
-    for (int k = 0; k < IDX_K; ++k) {
-        koff[k] = wtot;
-        const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)inc[k / 2], WAVE - 1);
-        wtot += (k & 1) ? (last >> 16) : (last & 0xffffu);
+        for (int k = 0; k < IDX_K; ++k) {
+            const int p = sub * IDX_K + k;
+            uint32_t nl, bl;
+            piece_masks(v[k], nl, bl);
+            // mask the bytes behind the end of the text (the last piece may be partial)
+            const uint64_t q = lbase + (uint64_t)p * (WAVE * 16);
+            if (q + 16 > f.bytes) { const uint32_t keep = q >= f.bytes ? 0u : ((1u << (f.bytes - q)) - 1u); nl &= keep; }
+            // "the byte before is blank": this piece's flags moved up one byte; the byte before the piece is the last byte
+            // of the piece of the lane before (same p), for lane 0 of the last lane's piece of p - 1
+            const uint32_t top = bl >> 15;
+            uint32_t prev = (uint32_t)__shfl_up((int)top, 1, WAVE);
+            if (lane == 0) prev = carry_in;
+            carry_in = (uint32_t)__builtin_amdgcn_readlane((int)top, WAVE - 1);          // (only lane 0 uses it)
+            const uint32_t ws = ((bl << 1) | prev) & 0xffffu;
+            mine += (uint32_t)__popc(nl);
+            if (k & 1) {
+                s_nl[p / 2][threadIdx.x] = nlp | (nl << 16);
+                s_ws[p / 2][threadIdx.x] = wsp | (ws << 16);
+            } else { nlp = nl; wsp = ws; }
+        }
+#pragma unroll
+        for (int k = 0; k < IDX_K; ++k) v[k] = nx[k];
     }
+    uint32_t wtot = mine;
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) wtot += (uint32_t)__shfl_xor((int)wtot, sft, WAVE);
     if (lane == 0) s_wave_tot[wave] = wtot;
     __syncthreads();
     unsigned long long total = 0, wave_off = 0;
@@ -266,18 +282,32 @@ __global__ __launch_bounds__(TXT_BLOCK) void text_index_kernel(IndexFile f0, Ind
         }
     }
     __syncthreads();
-    const unsigned long long rank0 = s_base + wave_off;
+    unsigned long long run = s_base + wave_off;      // rank of the first newline of the wave's pieces in row p (wave-uniform)
+#pragma unroll 2
+    for (int j = 0; j < IDX_P / 2; ++j) {
+        const uint32_t nlp = s_nl[j][threadIdx.x], wsp = s_ws[j][threadIdx.x];
+        const uint32_t own = (uint32_t)__popc(nlp & 0xffffu) | ((uint32_t)__popc(nlp >> 16) << 16);
+        uint32_t c = own;                             // inclusive lane scan, two rows at once
 #pragma unroll
-    for (int k = 0; k < IDX_K; ++k) {
-        const uint32_t incl = (k & 1) ? (inc[k / 2] >> 16) : (inc[k / 2] & 0xffffu);
-        uint32_t m = nl[k];
-        unsigned long long i = rank0 + koff[k] + (incl - (uint32_t)__popc(m));
-        const uint64_t q = wbase + (uint64_t)k * (WAVE * 16) + (uint64_t)lane * 16;
-        while (m) {
-            const int bit = __builtin_ctz(m);
-            if (i < f.cap) f.line_end[i] = (uint32_t)(q + (uint64_t)bit) | (((ws[k] >> bit) & 1u) ? LINE_WS : 0u);
-            ++i;
-            m &= m - 1;
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)c, d, WAVE);
+            if (lane >= d) c += o;
+        }
+        const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)c, WAVE - 1);
+        const uint32_t ex = c - own;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t m = h ? (nlp >> 16) : (nlp & 0xffffu);
+            const uint32_t ws = h ? (wsp >> 16) : (wsp & 0xffffu);
+            unsigned long long i = run + (h ? (ex >> 16) : (ex & 0xffffu));
+            const uint32_t q = (uint32_t)lbase + (uint32_t)(2 * j + h) * (WAVE * 16);      // (chunks are < 2 GiB)
+            while (m) {
+                const int bit = __builtin_ctz(m);
+                if (i < f.cap) f.line_end[i] = (q + (uint32_t)bit) | (((ws >> bit) & 1u) ? LINE_WS : 0u);
+                ++i;
+                m &= m - 1;
+            }
+            run += h ? (last >> 16) : (last & 0xffffu);
         }
     }
 }
@@ -301,7 +331,7 @@ struct FramedFile {
     uint32_t* name_len;
     uint32_t* plus_off;
     uint32_t* plus_len;
-    uint32_t* qual_len;
+    uint32_t* qual_len;      // bit 31: the byte behind the (stripped) quality line is its '\n'
 };
 
 __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t* __restrict__ text,
@@ -309,37 +339,57 @@ __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t*
                                                                   FramedFile out, FrameMeta* __restrict__ meta) {
     const uint64_t r = (uint64_t)blockIdx.x * TXT_BLOCK + threadIdx.x;
     const bool in = r < n_rec;
+    const int lane = lane_id();
+    // the record's four line ends in one 16-byte load; the end of the line before it is the neighbour lane's fourth
+    uint4 le4 = make_uint4(0, 0, 0, 0);
+    if (in) le4 = reinterpret_cast<const uint4*>(line_end)[r];
+    uint32_t before = (uint32_t)__shfl_up((int)le4.w, 1, WAVE);
+    if (lane == 0) before = (in && r > 0) ? line_end[4 * r - 1] : 0u;
+    const uint32_t le[4] = {le4.x, le4.y, le4.z, le4.w};
     uint32_t s[4] = {0, 0, 0, 0}, l[4] = {1, 1, 1, 1};
-#pragma unroll
-    for (int k = 0; k < 4 && in; ++k) {
-        const uint64_t li = 4 * r + k;
-        const uint32_t b = li == 0 ? 0u : (line_end[li - 1] & LINE_POS) + 1u;
-        const uint32_t le = line_end[li];
-        uint32_t e = le & LINE_POS;
-        if (le & LINE_WS)                                   // only lines that may end in whitespace touch the text
-            while (e > b && is_space(text[e - 1])) --e;
-        s[k] = b;
-        l[k] = e - b;
-    }
+    uint32_t tail_nl = 0;                                   // the quality line ends right at its '\n' (nothing stripped)
     if (in) {
+        uint32_t b = r == 0 ? 0u : (before & LINE_POS) + 1u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t e = le[k] & LINE_POS;
+            const uint32_t nl_at = e;
+            bool at_nl = true;
+            if (le[k] & LINE_WS) {                          // only lines that may end in whitespace touch the text
+                while (e > b && is_space(text[e - 1])) --e;
+                at_nl = e == nl_at && text[nl_at] == '\n';   // (the file's unterminated last line ends at a virtual '\n')
+            }
+            s[k] = b;
+            l[k] = e - b;
+            if (k == 3) tail_nl = at_nl ? 0x80000000u : 0u;
+            b = nl_at + 1u;
+        }
         out.name_off[r] = s[0]; out.name_len[r] = l[0];
         out.seq_off[r] = s[1];  out.seq_len[r] = l[1];
         out.plus_off[r] = s[2]; out.plus_len[r] = l[2];
-        out.qual_off[r] = s[3]; out.qual_len[r] = l[3];
+        out.qual_off[r] = s[3]; out.qual_len[r] = l[3] | tail_nl;
     }
-    // chunk-wide reductions: one atomic per WAVE and only when it has something to say (5 M same-address atomics would
-    // serialise in L2 and cost more than the framing itself)
+    // chunk-wide reductions: at most one atomic per workgroup and only when it has something to say.  (Same-address
+    // atomics serialise in L2 at ~8 ns each; the running maximum is read with an L2-coherent load — a plain load is served
+    // from the CU's L1, which kept saying 0 for most of the kernel and let nearly every wave through to the atomic.)
+    __shared__ unsigned int s_mx[TXT_BLOCK / WAVE];
     const bool empty = in && (l[0] == 0 || l[1] == 0 || l[2] == 0 || l[3] == 0);
     const bool mism = in && !empty && l[1] != l[3];
     const unsigned long long be = __ballot(empty), bm = __ballot(mism);
     unsigned int mx = in ? l[1] : 0u;
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, sft, WAVE));
-    if (lane_id() == 0) {
+    if (lane == 0) {
         const uint64_t rw = r;                                     // first record of this wave
         if (be) atomicMin(&meta->first_empty, (unsigned int)(rw + (uint64_t)__builtin_ctzll(be)));
         if (bm) atomicMin(&meta->first_mismatch, (unsigned int)(rw + (uint64_t)__builtin_ctzll(bm)));
-        if (mx > meta->max_len) atomicMax(&meta->max_len, mx);
+        s_mx[threadIdx.x / WAVE] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < TXT_BLOCK / WAVE; ++w) mx = max(mx, s_mx[w]);
+        if (mx > __hip_atomic_load(&meta->max_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&meta->max_len, mx);
     }
 }
 
@@ -430,6 +480,7 @@ struct TextFile {
     const uint32_t *seq_off, *qual_off;
     const uint32_t *seq_len;
     const uint32_t *name_off, *name_len, *plus_off, *plus_len;
+    const uint32_t *qual_len;     // bit 31: the quality line's '\n' follows it directly (frame_records_kernel)
 };
 
 struct FormatView {
@@ -524,18 +575,28 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_tile_sums_kernel(FormatView v, u
     }
 }
 
-// exclusive scan of each stream's tile sums (workgroup q handles stream q); totals to total_out[q]
+// exclusive scan of each stream's tile sums (workgroup q handles stream q, eight tiles per thread per round); totals to total_out[q]
 __global__ __launch_bounds__(TXT_BLOCK) void fmt_tile_bases_kernel(unsigned long long* __restrict__ tile_sum, uint64_t n_tiles,
                                                                    unsigned long long* __restrict__ total_out) {
     __shared__ unsigned long long lds[4];
+    constexpr int PER = 8;
     unsigned long long* ts = tile_sum + (uint64_t)blockIdx.x * n_tiles;
     unsigned long long carry = 0;
-    for (uint64_t t0 = 0; t0 < n_tiles; t0 += TXT_BLOCK) {
-        const uint64_t t = t0 + threadIdx.x;
-        const unsigned long long val = t < n_tiles ? ts[t] : 0ull;
+    for (uint64_t t0 = 0; t0 < n_tiles; t0 += (uint64_t)TXT_BLOCK * PER) {
+        const uint64_t t = t0 + (uint64_t)threadIdx.x * PER;
+        unsigned long long val[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            val[k] = t + k < n_tiles ? ts[t + k] : 0ull;
+            sum += val[k];
+        }
         unsigned long long total;
-        const unsigned long long ex = block_excl_scan(val, lds, total);
-        if (t < n_tiles) ts[t] = carry + ex;
+        unsigned long long run = carry + block_excl_scan(sum, lds, total);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (t + k < n_tiles) ts[t + k] = run;
+            run += val[k];
+        }
         carry += total;
     }
     if (threadIdx.x == 0) total_out[blockIdx.x] = carry;
@@ -634,7 +695,7 @@ __device__ inline void fmt_build(const FormatView& v, uint64_t r, int file, int 
     fmt_add(t, o, 1, qual_off == plus_off + (uint32_t)plen + 1 ? plus_off + (uint32_t)plen : NL);
     const int qual_dst = o;
     fmt_add(t, o, len, qual_off + (uint32_t)st);
-    fmt_add(t, o, 1, (st + len == slen && tf.text[qual_off + (uint32_t)slen] == '\n') ? qual_off + (uint32_t)slen : NL);
+    fmt_add(t, o, 1, (st + len == slen && (tf.qual_len[r] >> 31)) ? qual_off + (uint32_t)slen : NL);
     if (o > 0xffff) { atomicCAS(status, 0, AQC_ERR_UNSUPPORTED); t.stream = 0xff; return; }      // (a 64 KiB FASTQ record)
     t.total = (uint16_t)o;
     int items = 0;
