@@ -325,10 +325,12 @@ int aqc_reset_stats(aqc_ctx* c) {
 constexpr size_t ARENA_SLACK = 1024;
 constexpr size_t TEXT_FRONT = 64;
 
-static int up(DevBuf& d, const void* src, size_t bytes, hipStream_t st) {
-    if (d.reserve(bytes + ARENA_SLACK)) return fail(AQC_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
+// (`front` readable bytes before the data as well: read 2 is loaded in 16-byte chunks counted from its END, the chunk
+// with a read's first bases may begin up to 16 bytes before the read)
+static int up(DevBuf& d, const void* src, size_t bytes, hipStream_t st, size_t front = 0) {
+    if (d.reserve(front + bytes + ARENA_SLACK)) return fail(AQC_ERR_HIP, "hipMalloc of %zu bytes failed", bytes);
     if (bytes == 0) return 0;
-    HIP_TRY(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync((uint8_t*)d.p + front, src, bytes, hipMemcpyHostToDevice, st));
     return 0;
 }
 
@@ -376,8 +378,8 @@ static int fill_slot(aqc_ctx* c, Slot& s, const aqc_batch* b, bool need_qual, bo
     if ((rc = up(s.len1, b->len1, sizeof(uint32_t) * n, s.stream))) return rc;
     v.len1 = (const uint32_t*)s.len1.p;
     if (paired) {
-        if ((rc = up(s.seq2, b->seq2, b->bytes2, s.stream))) return rc;
-        v.seq2 = (const uint8_t*)s.seq2.p;
+        if ((rc = up(s.seq2, b->seq2, b->bytes2, s.stream, TEXT_FRONT))) return rc;
+        v.seq2 = (const uint8_t*)s.seq2.p + TEXT_FRONT;
         if (b->qual2 && need_qual) {
             if (b->qual2 == b->seq2) v.qual2 = v.seq2;
             else {

@@ -409,12 +409,20 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             }
         }
         if (PAIRED) {
+            // Read 2 is cut into chunks from its END: chunk c holds the bases [L2 - 16 (c + 1), L2 - 16 c), so that reversed
+            // (and complemented) it IS word c of reverse_r2 — the stream starts at bit 0 of word 0 whatever the length,
+            // and an untrimmed pair needs no alignment pass in phase 2.  (Unaligned 16-byte loads cost the same as aligned
+            // ones; the chunk of the read's first bases may begin up to 15 bytes before the read, chunks wholly before it
+            // are clamped to 16 bytes before: hence the 64-byte bias, every arena has that much readable space in front.)
             uint4 v[ITERS];
+            const uint8_t* const seq2b = fb.seq2 - 64;
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
                 asm volatile("" : "+v"(q));
-                v[it] = load16u(fb.seq2 + (uint32_t)(AQC_TASK_ROW(q)[WL::D_O2] + ((q >> 16) << 4)));
+                const uint32_t* const row = AQC_TASK_ROW(q);
+                const int st = max((int)row[WL::D_L2] - 16 * ((int)(q >> 16) + 1), -16);
+                v[it] = load16u(seq2b + (uint32_t)((int)row[WL::D_O2] + st + 64));
             }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
@@ -422,18 +430,20 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 asm volatile("" : "+v"(q));
                 uint32_t* const row = AQC_TASK_ROW(q);
                 const int c = (int)(q >> 16);
-                const uint4 m = mtab[min(max((int)row[WL::D_L2] - 16 * c, 0), 16)];
+                // the chunk's LAST nb bytes belong to the read: the first 16 - nb become the pad symbol ('T': complemented it
+                // is code 0, like the 'A' padding of read 1)
+                const uint4 m = mtab[16 - min(max((int)row[WL::D_L2] - 16 * c, 0), 16)];
                 uint4 d;
-                d.x = bfi(m.x, v[it].x, 0x41414141u); d.y = bfi(m.y, v[it].y, 0x41414141u);
-                d.z = bfi(m.z, v[it].z, 0x41414141u); d.w = bfi(m.w, v[it].w, 0x41414141u);
+                d.x = bfi(m.x, 0x54545454u, v[it].x); d.y = bfi(m.y, 0x54545454u, v[it].y);
+                d.z = bfi(m.z, 0x54545454u, v[it].z); d.w = bfi(m.w, 0x54545454u, v[it].w);
                 if (AQC_ABL & 2) d = v[it];
                 if (!(AQC_ABL & 1)) atomicOr(&row[WL::D_EXO], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
                 uint32_t lo, e;
                 pack_chunk(d, lo, e);
                 // complement (A<->T, C<->G: flip the high bit of the field), keep N at code 3, then reverse the chunk
                 lo = (lo ^ ODD) | e | (e >> 1);
-                row[3 * NW - 1 - c] = rev2(lo);
-                row[4 * NW - 1 - c] = __builtin_bitreverse32(e) << 1;
+                row[2 * NW + c] = rev2(lo);
+                row[3 * NW + c] = __builtin_bitreverse32(e) << 1;
             }
         }
         if (Rb->cfg.unqualified_base_limit > 0) {
@@ -488,13 +498,27 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         //      pass per lane (see below)
         if (BARCODE) {
             const int bl = cfg.barcode_length, vl = cfg.barcode_verify_len;
-            // the own read's first 32 bases, forward and as sequenced (read 2's stream is stored reversed + complemented)
-            uint32_t f0, f1, g0, g1;
-            if (role == 0) { f0 = own[0]; f1 = own[1]; g0 = own[NW]; g1 = own[NW + 1]; }
-            else {
-                f0 = rev2(own[NW - 1]) ^ ODD; f1 = rev2(own[NW - 2]) ^ ODD;      // (an N comes out as code 1; its flag below decides)
-                g0 = rev2(own[2 * NW - 1]);   g1 = rev2(own[2 * NW - 2]);
+            // Two 32-base windows of the own stream serve both mates: its head A (fields [0, 32)) and its tail B, reversed
+            // and complemented (fields [Lown - 32, Lown) read backwards; for reads under 32 bases what lies before the
+            // stream is shifted out).  Read 1's stream is the read: its first bases are A, rc(read 1) starts with B.  Read
+            // 2's stream is rc(read 2): its first bases as sequenced are B, rc(read 2) starts with A.
+            uint32_t a_lo0 = own[0], a_lo1 = own[1], a_e0 = own[NW], a_e1 = own[NW + 1];
+            uint32_t b_lo0, b_lo1, b_e0, b_e1;
+            {
+                const int start = max(Lown - 32, 0);
+                win64(own, start, b_lo0, b_lo1);
+                win64(own + NW, start, b_e0, b_e1);
+                rev2_64(b_lo0, b_lo1);
+                rev2_64(b_e0, b_e1);
+                b_lo0 ^= ODD; b_lo1 ^= ODD;                 // (an N comes out as code 1; its flag decides)
+                const uint32_t sh = (uint32_t)(2 * (start + 32 - Lown));          // > 0 only for reads under 32 bases
+                if (sh) {
+                    const unsigned long long x = (((unsigned long long)b_lo1 << 32) | b_lo0) >> sh;
+                    const unsigned long long y = (((unsigned long long)b_e1 << 32) | b_e0) >> sh;
+                    b_lo0 = (uint32_t)x; b_lo1 = (uint32_t)(x >> 32); b_e0 = (uint32_t)y; b_e1 = (uint32_t)(y >> 32);
+                }
             }
+            const uint32_t f0 = role ? b_lo0 : a_lo0, f1 = role ? b_lo1 : a_lo1, g0 = role ? b_e0 : a_e0, g1 = role ? b_e1 : a_e1;
             const unsigned long long F = ((unsigned long long)f1 << 32) | f0, G = ((unsigned long long)g1 << 32) | g0;
             const unsigned long long V = ((unsigned long long)bc.v1 << 32) | bc.v0, VM = ((unsigned long long)bc.m1 << 32) | bc.m0;
             // diffNumber(seq[s : s + len(verify)], verify) (barcodeprocesser.py:9-14): differing codes or an N
@@ -542,24 +566,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 uint32_t u0 = (uint32_t)xchg((int)(uint32_t)RE), u1 = (uint32_t)xchg((int)(uint32_t)(RE >> 32));
                 // the pattern P: rc(own read) from its start.  Read 2's stream already is rc(read 2); read 1's tail is
                 // fetched, reversed and complemented.
-                uint32_t p_lo0, p_lo1, p_e0, p_e1;
-                {
-                    const int tl = Lown - 1;
-                    const int start = role ? 16 * (NW - 1 - (tl >> 4)) + 15 - (tl & 15) : max(Lown - 32, 0);
-                    win64(own, start, p_lo0, p_lo1);
-                    win64(own + NW, start, p_e0, p_e1);
-                    if (role == 0) {
-                        rev2_64(p_lo0, p_lo1);
-                        rev2_64(p_e0, p_e1);
-                        p_lo0 ^= ODD; p_lo1 ^= ODD;
-                        const uint32_t sh = (uint32_t)(2 * (start + 32 - Lown));          // > 0 only for reads under 32 bases
-                        if (sh) {
-                            const unsigned long long a = (((unsigned long long)p_lo1 << 32) | p_lo0) >> sh;
-                            const unsigned long long b = (((unsigned long long)p_e1 << 32) | p_e0) >> sh;
-                            p_lo0 = (uint32_t)a; p_lo1 = (uint32_t)(a >> 32); p_e0 = (uint32_t)b; p_e1 = (uint32_t)(b >> 32);
-                        }
-                    }
-                }
+                const uint32_t p_lo0 = role ? a_lo0 : b_lo0, p_lo1 = role ? a_lo1 : b_lo1, p_e0 = role ? a_e0 : b_e0, p_e1 = role ? a_e1 : b_e1;
                 // bit planes of the pattern: code bit 0, code bit 1, N flag; position j at bit j
                 const uint32_t P0 = even_bits16(p_lo0) | (even_bits16(p_lo1) << 16);
                 const uint32_t P1 = even_bits16(p_lo0 >> 1) | (even_bits16(p_lo1 >> 1) << 16);
@@ -641,24 +648,24 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         // ---- normalise the own stream IN PLACE in LDS: afterwards own[j] / own[NW + j] hold bases 16j..16j+15 of
         //      read 1 (role 0) or of reverse_r2 (role 1); everything beyond the read's length is zero.  Later
         //      stages fetch the few words they need from LDS instead of pinning 2 x NW registers per lane.
+        //      Phase 1 leaves both streams starting at bit 0 and zero behind the full read, so there is nothing to do
+        //      unless a trim / barcode stage moved this read's view: read 1's stream starts a_own bases in, reverse_r2
+        //      starts as many bases in as were cut from read 2's tail.
         {
-            int b0 = a_own;
-            if (role) {
-                // reverse_r2[i] sits at stream position p0 + i of the reversed chunk sequence
-                const int tl = a_own + len_own - 1;                     // last base of the current read 2
-                b0 = 16 * (NW - 1 - (tl >> 4)) + 15 - (tl & 15);
-            }
-            const int k0 = b0 >> 4;
-            const uint32_t s = (uint32_t)(b0 & 15) * 2;
-            uint32_t lo0 = k0 < NW ? own[k0] : 0u, e0 = k0 < NW ? own[NW + k0] : 0u;
+            const int b0 = role ? Lown - (a_own + len_own) : a_own;
+            if (__ballot(b0 != 0 || len_own != Lown)) {
+                const int k0 = b0 >> 4;
+                const uint32_t s = (uint32_t)(b0 & 15) * 2;
+                uint32_t lo0 = k0 < NW ? own[k0] : 0u, e0 = k0 < NW ? own[NW + k0] : 0u;
 #pragma nounroll
-            for (int j = 0; j < NW; ++j) {
-                const int i1 = k0 + j + 1;
-                const uint32_t lo1 = i1 < NW ? own[i1] : 0u, e1 = i1 < NW ? own[NW + i1] : 0u;
-                const uint32_t m = base_mask(min(max(len_own - 16 * j, 0), 16));
-                own[j] = alignbit(lo1, lo0, s) & m;          // index j <= k0 + j: never overwrites a word still to be read
-                own[NW + j] = alignbit(e1, e0, s) & m;
-                lo0 = lo1; e0 = e1;
+                for (int j = 0; j < NW; ++j) {
+                    const int i1 = k0 + j + 1;
+                    const uint32_t lo1 = i1 < NW ? own[i1] : 0u, e1 = i1 < NW ? own[NW + i1] : 0u;
+                    const uint32_t m = base_mask(min(max(len_own - 16 * j, 0), 16));
+                    own[j] = alignbit(lo1, lo0, s) & m;          // index j <= k0 + j: never overwrites a word still to be read
+                    own[NW + j] = alignbit(e1, e0, s) & m;
+                    lo0 = lo1; e0 = e1;
+                }
             }
         }
         if (role == 0) {
