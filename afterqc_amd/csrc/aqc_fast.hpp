@@ -44,6 +44,10 @@
 namespace aqc {
 
 constexpr uint32_t ODD = 0xAAAAAAAAu;
+// What stands behind a read in its 2-bit stream: A C A C ... by stream position (no two neighbours equal, so the padding
+// never looks like a homopolymer run to the polyX screen and that screen needs no length masks).  PAD1 / PAD2 are the text
+// bytes that pack to it: "ACAC" for read 1, "GTGT" for read 2 (complemented and reversed: position p comes from byte 15 - p).
+constexpr uint32_t PADLO = 0x44444444u, PAD1 = 0x43414341u, PAD2 = 0x54475447u;
 constexpr int NONE_CAND = 0x7fffffff;
 
 // 16 bytes from an arbitrarily aligned address: one global_load_dwordx4
@@ -398,8 +402,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const int c = (int)(q >> 16);
                 const uint4 m = mtab[min(max((int)row[WL::D_L1] - 16 * c, 0), 16)];
                 uint4 d;
-                d.x = bfi(m.x, v[it].x, 0x41414141u); d.y = bfi(m.y, v[it].y, 0x41414141u);
-                d.z = bfi(m.z, v[it].z, 0x41414141u); d.w = bfi(m.w, v[it].w, 0x41414141u);
+                d.x = bfi(m.x, v[it].x, PAD1); d.y = bfi(m.y, v[it].y, PAD1);
+                d.z = bfi(m.z, v[it].z, PAD1); d.w = bfi(m.w, v[it].w, PAD1);
                 if (AQC_ABL & 2) d = v[it];
                 if (!(AQC_ABL & 1)) atomicOr(&row[WL::D_EXO], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
                 uint32_t lo, e;
@@ -434,8 +438,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 // is code 0, like the 'A' padding of read 1)
                 const uint4 m = mtab[16 - min(max((int)row[WL::D_L2] - 16 * c, 0), 16)];
                 uint4 d;
-                d.x = bfi(m.x, 0x54545454u, v[it].x); d.y = bfi(m.y, 0x54545454u, v[it].y);
-                d.z = bfi(m.z, 0x54545454u, v[it].z); d.w = bfi(m.w, 0x54545454u, v[it].w);
+                d.x = bfi(m.x, PAD2, v[it].x); d.y = bfi(m.y, PAD2, v[it].y);
+                d.z = bfi(m.z, PAD2, v[it].z); d.w = bfi(m.w, PAD2, v[it].w);
                 if (AQC_ABL & 2) d = v[it];
                 if (!(AQC_ABL & 1)) atomicOr(&row[WL::D_EXO], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
                 uint32_t lo, e;
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             }
         }
         // ---- normalise the own stream IN PLACE in LDS: afterwards own[j] / own[NW + j] hold bases 16j..16j+15 of
-        //      read 1 (role 0) or of reverse_r2 (role 1); everything beyond the read's length is zero.  Later
+        //      read 1 (role 0) or of reverse_r2 (role 1); everything beyond the read's length is the padding (A C A C ..., N flags zero).  Later
         //      stages fetch the few words they need from LDS instead of pinning 2 x NW registers per lane.
         //      Phase 1 leaves both streams starting at bit 0 and zero behind the full read, so there is nothing to do
         //      unless a trim / barcode stage moved this read's view: read 1's stream starts a_own bases in, reverse_r2
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                     const int i1 = k0 + j + 1;
                     const uint32_t lo1 = i1 < NW ? own[i1] : 0u, e1 = i1 < NW ? own[NW + i1] : 0u;
                     const uint32_t m = base_mask(min(max(len_own - 16 * j, 0), 16));
-                    own[j] = alignbit(lo1, lo0, s) & m;          // index j <= k0 + j: never overwrites a word still to be read
+                    own[j] = bfi(m, alignbit(lo1, lo0, s), PADLO);   // index j <= k0 + j: never overwrites a word still to be read
                     own[NW + j] = alignbit(e1, e0, s) & m;
                     lo0 = lo1; e0 = e1;
                 }
@@ -713,8 +717,9 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                     const uint32_t lo1 = j + 1 < NW ? own[j + 1] : 0u, e1 = j + 1 < NW ? own[NW + j + 1] : 0u;
                     const uint32_t x = lo0 ^ alignbit(lo1, lo0, 2);
                     const uint32_t ex = e0 ^ alignbit(e1, e0, 2);
-                    // base i equals base i+1, only for i <= len-2
-                    r[j] = ~(((x << 1) | x | ex)) & ODD & base_mask(min(max(len_own - 1 - 16 * j, 0), 16));
+                    // base i equals base i+1 (behind the read the stream alternates: at most the read's last base pairs
+                    // with the padding, which lengthens a run by one — the exact check decides)
+                    r[j] = ~(((x << 1) | x | ex)) & ODD;
                     lo0 = lo1; e0 = e1;
                 }
                 r[NW] = 0;
@@ -766,7 +771,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         int offset = 0, ovl = 0, dist = 0, ovl0 = -1, dist_final = -1, n_edits = 0;
         int c_adapter_base = 0, c_adapter_read = 0, c_overlapped = 0, c_corrected = 0, c_masked = 0, c_skipped = 0, c_read_corrected = 0;
         int em0 = -1, em1 = -1, em2 = -1, walk_a = 0;
-        unsigned long long E0 = 0, E1 = 0, E2 = 0;
+        uint32_t EW0 = 0, EW1 = 0, EW2 = 0, EW3 = 0;       // the walk's edits as they go into the result (bytes 16..30)
         bool walk_pair = false, walker = false;
         if (PAIRED && !Rb->cfg.no_overlap) {
             // own candidates: offsets c = 0 .. len_own - 31, the own stream moving over the partner's prefix
@@ -897,53 +902,61 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             walker = walk_pair && i_found_it;
             if (__ballot(walker)) {
                 // (<= 3 mismatches, all handled: the walk can never end short here, so BADMISMATCH cannot arise)
+                // Straight-line and in the streams' 2-bit codes (A 0, C 1, T 2, G 3; complement = code ^ 2): lanes that do not
+                // walk run along with column 0 and switch their results off.
                 const int shift1 = c_adapter_read ? 0 : len1 - ovl;        // read-1 position of walk column o: shift1 + o
                 const int shift2 = c_adapter_read ? walk_a : 0;            // reverse_r2 position of column o
                 const uint32_t* s1w = pr;                                  // read-1 stream
                 const uint32_t* s2w = pr + 2 * NW;                         // reverse_r2 stream
-                // (lanes that do not walk still execute the loads below: keep their addresses inside the arenas)
-                const uint8_t* h1 = fb.qual1 + (walker ? (uint64_t)pr[WL::D_Q1] + a1 + (len1 - ovl) : 0);
-                const uint8_t* h2 = fb.qual2 + (walker ? (uint64_t)pr[WL::D_Q2] + a2 + (len2 - 1) : 0);
-                int wq1[3], wq2[3];
+                const bool no_corr = Rb->cfg.no_correction != 0, mask_mm = Rb->cfg.mask_mismatch != 0;
+                // byte offsets of column 0's qualities (32-bit, from the arenas' bases: one add per load, no 64-bit address math)
+                const uint32_t qa0 = walker ? pr[WL::D_Q1] + (uint32_t)(a1 + (len1 - ovl)) : 0u;
+                const uint32_t qb0 = walker ? pr[WL::D_Q2] + (uint32_t)(a2 + (len2 - 1)) : 0u;
+                int wcol[3];
+                uint32_t wq1[3], wq2[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    const int oo = walker && q < dist ? (q == 0 ? f_p0 : q == 1 ? f_p1 : f_p2) : 0;
-                    wq1[q] = h1[oo]; wq2[q] = h2[-oo];
+                    wcol[q] = walker && q < dist ? (q == 0 ? f_p0 : q == 1 ? f_p1 : f_p2) : 0;
+                    wq1[q] = fb.qual1[qa0 + (uint32_t)wcol[q]];
+                    wq2[q] = fb.qual2[qb0 - (uint32_t)wcol[q]];
                 }
+                uint32_t El0 = 0, El1 = 0, El2 = 0, Eh0 = 0, Eh1 = 0, Eh2 = 0;      // edits: column | kind << 16 | base << 24, quality
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    if (walker && q < dist) {
-                        const int oo = q == 0 ? f_p0 : q == 1 ? f_p1 : f_p2;
-                        const int x1 = shift1 + oo, x2 = shift2 + oo;
-                        const uint32_t c1 = (s1w[x1 >> 4] >> (2 * (x1 & 15))) & 3u, n1 = (s1w[NW + (x1 >> 4)] >> (2 * (x1 & 15) + 1)) & 1u;
-                        const uint32_t c2 = (s2w[x2 >> 4] >> (2 * (x2 & 15))) & 3u, n2 = (s2w[NW + (x2 >> 4)] >> (2 * (x2 & 15) + 1)) & 1u;
-                        const uint32_t bA = n1 ? (uint32_t)'N' : ((0x47544341u >> (8 * c1)) & 0xffu);      // code -> A C T G
-                        const uint32_t bB = n2 ? (uint32_t)'N' : ((0x47544341u >> (8 * c2)) & 0xffu);      // = complement(r2 base)
-                        const uint32_t r2o = comp_acgtn(bB);
-                        const int qa = wq1[q], qb = wq2[q];
-                        const bool r2_wrong = qa - 33 >= 30 && qb - 33 <= 14;     // trust read 1 (preprocesser.py:571)
-                        const bool r1_wrong = !r2_wrong && qb - 33 >= 30 && qa - 33 <= 14;   // trust read 2 (:579)
-                        const bool both_acgt = bA != 'N' && bB != 'N';
-                        int em = -1;
-                        if (r2_wrong && both_acgt) em = base_idx_acgt(comp_acgtn(bA)) * 4 + base_idx_acgt(r2o);
-                        if (r1_wrong && both_acgt) em = base_idx_acgt(bB) * 4 + base_idx_acgt(bA);
-                        const bool fix = (r2_wrong || r1_wrong) && !Rb->cfg.no_correction;
-                        const bool mask = !fix && Rb->cfg.mask_mismatch;
-                        const unsigned long long kind = fix ? (r2_wrong ? AQC_EDIT_FIX_R2 : AQC_EDIT_FIX_R1) : AQC_EDIT_MASK;
-                        const unsigned long long base = fix ? (r2_wrong ? comp_acgtn(bA) : bB) : 0u;
-                        const unsigned long long qual = fix ? (unsigned long long)(r2_wrong ? qa : qb) : (unsigned long long)'!';
-                        const unsigned long long e40 = (unsigned long long)oo | (kind << 16) | (base << 24) | (qual << 32);
-                        c_corrected += fix ? 1 : 0;
-                        c_masked += mask ? 1 : 0;
-                        c_skipped += (!fix && !mask) ? 1 : 0;
-                        if (q == 0) em0 = em; else if (q == 1) em1 = em; else em2 = em;
-                        if (fix || mask) {
-                            if (n_edits == 0) E0 = e40; else if (n_edits == 1) E1 = e40; else E2 = e40;
-                            n_edits++;
-                        }
-                    }
+                    const bool on = walker && q < dist;
+                    const int oo = wcol[q];
+                    const int x1 = on ? shift1 + oo : 0, x2 = on ? shift2 + oo : 0;
+                    const uint32_t h1 = (uint32_t)(x1 & 15) * 2u, h2 = (uint32_t)(x2 & 15) * 2u;
+                    const uint32_t c1 = (s1w[x1 >> 4] >> h1) & 3u, n1 = (s1w[NW + (x1 >> 4)] >> (h1 + 1u)) & 1u;
+                    const uint32_t c2 = (s2w[x2 >> 4] >> h2) & 3u, n2 = (s2w[NW + (x2 >> 4)] >> (h2 + 1u)) & 1u;      // c2: complement(r2 base)
+                    const uint32_t qa = wq1[q], qb = wq2[q];
+                    const bool r2_wrong = qa >= 63u && qb <= 47u;                   // trust read 1 (preprocesser.py:571: q1 >= 30, q2 <= 14)
+                    const bool r1_wrong = !r2_wrong && qb >= 63u && qa <= 47u;      // trust read 2 (:579)
+                    const bool trust = on && (r2_wrong || r1_wrong);
+                    // the base that is written (and its N flag) / the base it replaces, as codes:
+                    // read 2 wrong: r2 := complement(b1), was complement(b2');  read 1 wrong: r1 := b2', was b1
+                    const uint32_t X = r2_wrong ? (c1 ^ 2u) : c2, Y = r2_wrong ? (c2 ^ 2u) : c1, nX = r2_wrong ? n1 : n2;
+                    // error matrix cell (preprocesser.py:573,581): ALL_BASES index A T C G = 0 1 2 3 of either base
+                    const int em = (trust && !(n1 | n2)) ? (int)((((0xD8u >> (2u * X)) & 3u) << 2) | ((0xD8u >> (2u * Y)) & 3u)) : -1;
+                    const bool fix = trust && !no_corr;
+                    const bool mask = on && !fix && mask_mm;
+                    const uint32_t kind = fix ? (r2_wrong ? (uint32_t)AQC_EDIT_FIX_R2 : (uint32_t)AQC_EDIT_FIX_R1) : (uint32_t)AQC_EDIT_MASK;
+                    const uint32_t base = fix ? (nX ? (uint32_t)'N' : ((0x47544341u >> (8u * X)) & 0xffu)) : 0u;       // code -> A C T G
+                    const uint32_t el = (uint32_t)oo | (kind << 16) | (base << 24);
+                    const uint32_t eh = fix ? (r2_wrong ? qa : qb) : (uint32_t)'!';
+                    c_corrected += fix ? 1 : 0;
+                    c_masked += mask ? 1 : 0;
+                    c_skipped += (on && !fix && !mask) ? 1 : 0;
+                    if (q == 0) em0 = em; else if (q == 1) em1 = em; else em2 = em;
+                    const bool put = fix || mask;
+                    if (put && n_edits == 0) { El0 = el; Eh0 = eh; }
+                    if (put && n_edits == 1) { El1 = el; Eh1 = eh; }
+                    if (put && n_edits == 2) { El2 = el; Eh2 = eh; }
+                    n_edits += put ? 1 : 0;
                 }
                 if (walker && c_corrected > 0) c_read_corrected = 1;
+                // the three 40-bit edits, packed into the result's upper 16 bytes
+                EW0 = El0; EW1 = Eh0 | (El1 << 8); EW2 = (El1 >> 24) | (Eh1 << 8) | (El2 << 16); EW3 = (El2 >> 16) | (Eh2 << 16);
             }
         }
         if (flag < 0) flag = AQC_GOOD;
@@ -959,8 +972,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             lo.y = (uint32_t)(len1 & 0xffff) | ((uint32_t)(a2 & 0xffff) << 16);
             lo.z = (uint32_t)(len2 & 0xffff) | ((uint32_t)(offset & 0xffff) << 16);
             lo.w = (uint32_t)(ovl & 0xffff) | ((uint32_t)(dist & 0xffff) << 16);
-            const unsigned long long q0 = E0 | (E1 << 40), q1 = (E1 >> 24) | (E2 << 16);
-            hi.x = (uint32_t)q0; hi.y = (uint32_t)(q0 >> 32); hi.z = (uint32_t)q1; hi.w = (uint32_t)(q1 >> 32) | (bcode << 24);   // byte 31: barcode nibbles
+            hi.x = EW0; hi.y = EW1; hi.z = EW2; hi.w = EW3 | (bcode << 24);   // byte 31: barcode nibbles
             uint4* out = reinterpret_cast<uint4*>(results + rec);
             out[0] = lo;
             out[1] = hi;
