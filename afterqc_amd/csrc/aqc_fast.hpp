@@ -386,14 +386,46 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         // verdict goes to the record's flag word with one LDS OR per chunk (no compare, no branch).
         uint8_t* const rows = reinterpret_cast<uint8_t*>(&L.planes[0][0]);
 #define AQC_TASK_ROW(q) reinterpret_cast<uint32_t*>(rows + ((q) & 0xffffu))
-        {
-            uint4 v[ITERS];
+        // Where the registers allow it (2 x 150: 15 loads, 60 registers that nothing else needs at this point) ALL the
+        // 16-byte loads of the batch are issued first — read 1, read 2, read 1's qualities: one memory latency per batch
+        // instead of three, the wave has only three neighbours on its SIMD to hide them behind.  Each pass then packs its
+        // chunks as they arrive.  The longer / single-end variants load pass by pass.
+        constexpr bool ALL_UP = (PAIRED ? 3 : 2) * ITERS * 4 <= 64;
+        uint4 v1[ITERS], v2[PAIRED ? ITERS : 1], v3[ITERS];
+        const bool want_qual = Rb->cfg.unqualified_base_limit > 0;
+        auto issue1 = [&]() {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
                 asm volatile("" : "+v"(q));
-                v[it] = load16u(fb.seq1 + (uint32_t)(AQC_TASK_ROW(q)[WL::D_O1] + ((q >> 16) << 4)));
+                v1[it] = load16u(fb.seq1 + (uint32_t)(AQC_TASK_ROW(q)[WL::D_O1] + ((q >> 16) << 4)));
             }
+        };
+        auto issue2 = [&]() {
+            const uint8_t* const seq2b = fb.seq2 - 64;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                uint32_t q = task[it];
+                asm volatile("" : "+v"(q));
+                const uint32_t* const row = AQC_TASK_ROW(q);
+                const int st = max((int)row[WL::D_L2] - 16 * ((int)(q >> 16) + 1), -16);
+                v2[PAIRED ? it : 0] = load16u(seq2b + (uint32_t)((int)row[WL::D_O2] + st + 64));
+            }
+        };
+        auto issue3 = [&]() {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                uint32_t q = task[it];
+                asm volatile("" : "+v"(q));
+                v3[it] = load16u(fb.qual1 + (uint32_t)(AQC_TASK_ROW(q)[WL::D_Q1] + ((q >> 16) << 4)));
+            }
+        };
+        issue1();
+        if (ALL_UP) {
+            if (PAIRED) issue2();
+            if (want_qual) issue3();
+        }
+        {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
@@ -402,9 +434,9 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const int c = (int)(q >> 16);
                 const uint4 m = mtab[min(max((int)row[WL::D_L1] - 16 * c, 0), 16)];
                 uint4 d;
-                d.x = bfi(m.x, v[it].x, PAD1); d.y = bfi(m.y, v[it].y, PAD1);
-                d.z = bfi(m.z, v[it].z, PAD1); d.w = bfi(m.w, v[it].w, PAD1);
-                if (AQC_ABL & 2) d = v[it];
+                d.x = bfi(m.x, v1[it].x, PAD1); d.y = bfi(m.y, v1[it].y, PAD1);
+                d.z = bfi(m.z, v1[it].z, PAD1); d.w = bfi(m.w, v1[it].w, PAD1);
+                if (AQC_ABL & 2) d = v1[it];
                 if (!(AQC_ABL & 1)) atomicOr(&row[WL::D_EXO], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
                 uint32_t lo, e;
                 pack_chunk(d, lo, e);
@@ -413,21 +445,12 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             }
         }
         if (PAIRED) {
+            if (!ALL_UP) issue2();
             // Read 2 is cut into chunks from its END: chunk c holds the bases [L2 - 16 (c + 1), L2 - 16 c), so that reversed
             // (and complemented) it IS word c of reverse_r2 — the stream starts at bit 0 of word 0 whatever the length,
             // and an untrimmed pair needs no alignment pass in phase 2.  (Unaligned 16-byte loads cost the same as aligned
             // ones; the chunk of the read's first bases may begin up to 15 bytes before the read, chunks wholly before it
             // are clamped to 16 bytes before: hence the 64-byte bias, every arena has that much readable space in front.)
-            uint4 v[ITERS];
-            const uint8_t* const seq2b = fb.seq2 - 64;
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                uint32_t q = task[it];
-                asm volatile("" : "+v"(q));
-                const uint32_t* const row = AQC_TASK_ROW(q);
-                const int st = max((int)row[WL::D_L2] - 16 * ((int)(q >> 16) + 1), -16);
-                v[it] = load16u(seq2b + (uint32_t)((int)row[WL::D_O2] + st + 64));
-            }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
@@ -438,9 +461,9 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 // is code 0, like the 'A' padding of read 1)
                 const uint4 m = mtab[16 - min(max((int)row[WL::D_L2] - 16 * c, 0), 16)];
                 uint4 d;
-                d.x = bfi(m.x, PAD2, v[it].x); d.y = bfi(m.y, PAD2, v[it].y);
-                d.z = bfi(m.z, PAD2, v[it].z); d.w = bfi(m.w, PAD2, v[it].w);
-                if (AQC_ABL & 2) d = v[it];
+                d.x = bfi(m.x, PAD2, v2[it].x); d.y = bfi(m.y, PAD2, v2[it].y);
+                d.z = bfi(m.z, PAD2, v2[it].z); d.w = bfi(m.w, PAD2, v2[it].w);
+                if (AQC_ABL & 2) d = v2[it];
                 if (!(AQC_ABL & 1)) atomicOr(&row[WL::D_EXO], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
                 uint32_t lo, e;
                 pack_chunk(d, lo, e);
@@ -450,14 +473,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 row[3 * NW + c] = __builtin_bitreverse32(e) << 1;
             }
         }
-        if (Rb->cfg.unqualified_base_limit > 0) {
-            uint4 v[ITERS];
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                uint32_t q = task[it];
-                asm volatile("" : "+v"(q));
-                v[it] = load16u(fb.qual1 + (uint32_t)(AQC_TASK_ROW(q)[WL::D_Q1] + ((q >> 16) << 4)));
-            }
+        if (want_qual) {
+            if (!ALL_UP) issue3();
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
@@ -466,9 +483,9 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 const int c = (int)(q >> 16);
                 const uint4 m = mtab[min(max((int)row[WL::D_L1] - 16 * c, 0), 16)];
                 uint4 d;
-                d.x = bfi(m.x, v[it].x, 0x7f7f7f7fu); d.y = bfi(m.y, v[it].y, 0x7f7f7f7fu);
-                d.z = bfi(m.z, v[it].z, 0x7f7f7f7fu); d.w = bfi(m.w, v[it].w, 0x7f7f7f7fu);
-                if (AQC_ABL & 2) d = v[it];
+                d.x = bfi(m.x, v3[it].x, 0x7f7f7f7fu); d.y = bfi(m.y, v3[it].y, 0x7f7f7f7fu);
+                d.z = bfi(m.z, v3[it].z, 0x7f7f7f7fu); d.w = bfi(m.w, v3[it].w, 0x7f7f7f7fu);
+                if (AQC_ABL & 2) d = v3[it];
                 if (!(AQC_ABL & 1)) atomicOr(&row[WL::D_EXO], ((d.x | d.y) | (d.z | d.w)) & 0x80808080u);
                 // byte >= thr  <=>  high bit of ((byte | 0x80) - thr) set   (bytes < 0x80, thr <= 0x7f)
                 const uint32_t g0 = ((d.x | 0x80808080u) - o_thr4) & 0x80808080u, g1 = ((d.y | 0x80808080u) - o_thr4) & 0x80808080u;
