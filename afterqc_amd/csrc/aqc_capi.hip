@@ -352,6 +352,7 @@ static int fill_slot(aqc_ctx* c, Slot& s, const aqc_batch* b, bool need_qual, bo
     const bool paired = b->seq2 != nullptr;
     if (need_pair && !paired) return fail(AQC_ERR_ARG, "batch: this call needs seq2/off2/len2");
     if (paired && (!b->off2 || !b->len2)) return fail(AQC_ERR_ARG, "batch: off2/len2 missing");
+    if (n >= (1ull << 31)) return fail(AQC_ERR_ARG, "batch: more than 2^31 records (split the batch)");
     const uint64_t lim = (1ull << 32) - 4096;      // 32-bit byte offsets on the device, chunk loads may run 288 bytes past a read's start
     if (b->bytes1 >= lim || b->qbytes1 >= lim || b->bytes2 >= lim || b->qbytes2 >= lim) return fail(AQC_ERR_ARG, "batch: an arena must be smaller than 4 GiB (split the batch)");
     // make sure earlier work on this slot has drained before its buffers are overwritten / regrown

@@ -103,8 +103,9 @@ __device__ __forceinline__ void pack_chunk(const uint4 v, uint32_t& lo, uint32_t
     pack_dword(v.y, l1, e1);
     pack_dword(v.z, l2, e2);
     pack_dword(v.w, l3, e3);
-    lo = l0 | (l1 << 8) | (l2 << 16) | (l3 << 24);
-    e = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24);
+    // (three shift-or steps each; written as a chain so that it stays one)
+    lo = (((((l3 << 8) | l2) << 8) | l1) << 8) | l0;
+    e = (((((e3 << 8) | e2) << 8) | e1) << 8) | e0;
 }
 
 // reverse the order of the sixteen 2-bit fields of a word
@@ -331,8 +332,10 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         return t;                                      // (lane 0 holds it; broadcast when consumed)
     };
     // (the workgroup's column rotates with t, so that its batches are spread over all memory channels)
-    auto batch_of = [&](uint32_t t) -> uint64_t { return (uint64_t)gridDim.x * t + (blockIdx.x + 61u * t) % gridDim.x; };
-    uint64_t cur = batch_of((uint32_t)wave);
+    // (record and batch numbers are 32-bit: a batch's byte offsets are, so it has fewer than 2^32 records)
+    auto batch_of = [&](uint32_t t) -> uint32_t { return gridDim.x * t + (blockIdx.x + 61u * t) % gridDim.x; };
+    const uint32_t n_rec = (uint32_t)fb.n;
+    uint32_t cur = batch_of((uint32_t)wave);
     // chunk task `it` of this lane: chunk t = it * 64 + lane of the batch, i.e. chunk t % NW of record t / NW — ten
     // neighbouring lanes cover one read, every load instruction of the wave reads 6.4 whole reads (dense in memory: dealing
     // each lane the chunks of its OWN pair costs a third fewer instructions and runs slower, its loads touch 32 lines
@@ -347,8 +350,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     }
     // the descriptor of this lane's read in the NEXT batch is fetched one iteration ahead
     uint32_t m_o = 0, m_l = 0, m_q = 0;
-    if (cur < n_batches && cur * PPW + p < fb.n) {
-        const uint64_t r0 = cur * PPW + p;
+    if (cur < n_batches && cur * PPW + p < n_rec) {
+        const uint32_t r0 = cur * PPW + p;
         m_o = role ? fb.off2[r0] : fb.off1[r0];
         m_l = role ? fb.len2[r0] : fb.len1[r0];
         m_q = role ? qo2[r0] : qo1[r0];
@@ -361,19 +364,19 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         FastArgsRare Rb = R;
         asm volatile("" : "+s"(Rb));
         const int o_do_trim = do_trim, o_run_req = run_req, o_r2b = r2b, o_thr4 = thr4;
-        const uint64_t base = cur * PPW;
+        const uint32_t base = cur * PPW;
         // exactly ONE batch of lookahead (its descriptors travel while this batch is processed): a slow wave never sits
         // on more than one batch the faster waves could have taken
-        const uint64_t nxt = batch_of((uint32_t)__builtin_amdgcn_readfirstlane((int)draw()));
-        const uint64_t rec = base + p;
-        const bool valid = rec < fb.n;
+        const uint32_t nxt = batch_of((uint32_t)__builtin_amdgcn_readfirstlane((int)draw()));
+        const uint32_t rec = base + p;
+        const bool valid = rec < n_rec;
         // ------------------------------------------------------------------ phase 1: load + pack
         if (role == 0) { pr[WL::D_O1] = m_o; pr[WL::D_L1] = m_l; pr[WL::D_Q1] = m_q; pr[WL::D_EXO] = 0; pr[WL::D_LQ] = 0; }
         else { pr[WL::D_O2] = m_o; pr[WL::D_L2] = m_l; pr[WL::D_Q2] = m_q; }
         {
-            const uint64_t nrec = nxt * PPW + p;
+            const uint32_t nrec = nxt * PPW + p;
             m_o = m_l = m_q = 0;
-            if (nxt < n_batches && nrec < fb.n) {
+            if (nxt < n_batches && nrec < n_rec) {
                 m_o = role ? fb.off2[nrec] : fb.off1[nrec];
                 m_l = role ? fb.len2[nrec] : fb.len1[nrec];
                 m_q = role ? qo2[nrec] : qo1[nrec];
@@ -437,6 +440,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 d.x = bfi(m.x, v1[it].x, PAD1); d.y = bfi(m.y, v1[it].y, PAD1);
                 d.z = bfi(m.z, v1[it].z, PAD1); d.w = bfi(m.w, v1[it].w, PAD1);
                 if (AQC_ABL & 2) d = v1[it];
+                asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));      // (the padded chunk itself feeds both uses below)
                 if (!(AQC_ABL & 1)) atomicOr(&row[WL::D_EXO], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
                 uint32_t lo, e;
                 pack_chunk(d, lo, e);
@@ -464,6 +468,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 d.x = bfi(m.x, PAD2, v2[it].x); d.y = bfi(m.y, PAD2, v2[it].y);
                 d.z = bfi(m.z, PAD2, v2[it].z); d.w = bfi(m.w, PAD2, v2[it].w);
                 if (AQC_ABL & 2) d = v2[it];
+                asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
                 if (!(AQC_ABL & 1)) atomicOr(&row[WL::D_EXO], (not_acgtn(d.x) | not_acgtn(d.y)) | (not_acgtn(d.z) | not_acgtn(d.w)));
                 uint32_t lo, e;
                 pack_chunk(d, lo, e);
