@@ -388,19 +388,26 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         // that is kept is checked against the alphabet the packed arithmetic takes (A C G T N; qualities < 0x80).  The
         // verdict goes to the record's flag word with one LDS OR per chunk (no compare, no branch).
         uint8_t* const rows = reinterpret_cast<uint8_t*>(&L.planes[0][0]);
+        // the task words are re-opened once per batch where five of them fit the registers with what is derived from them
+        // (the 2 x 150 variant), else once per use
+        constexpr bool TASK_ONCE = ITERS <= 5;
+        if (TASK_ONCE) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) asm volatile("" : "+v"(task[it]));
+        }
 #define AQC_TASK_ROW(q) reinterpret_cast<uint32_t*>(rows + ((q) & 0xffffu))
         // Where the registers allow it (2 x 150: 15 loads, 60 registers that nothing else needs at this point) ALL the
         // 16-byte loads of the batch are issued first — read 1, read 2, read 1's qualities: one memory latency per batch
         // instead of three, the wave has only three neighbours on its SIMD to hide them behind.  Each pass then packs its
         // chunks as they arrive.  The longer / single-end variants load pass by pass.
-        constexpr bool ALL_UP = (PAIRED ? 3 : 2) * ITERS * 4 <= 64;
+        constexpr bool ALL_UP = (PAIRED ? 3 : 2) * ITERS * 4 <= (WPBT >= 16 ? 64 : 108);      // (three waves per SIMD have 168 registers each)
         uint4 v1[ITERS], v2[PAIRED ? ITERS : 1], v3[ITERS];
         const bool want_qual = Rb->cfg.unqualified_base_limit > 0;
         auto issue1 = [&]() {
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
-                asm volatile("" : "+v"(q));
+                if (!TASK_ONCE) asm volatile("" : "+v"(q));
                 v1[it] = load16u(fb.seq1 + (uint32_t)(AQC_TASK_ROW(q)[WL::D_O1] + ((q >> 16) << 4)));
             }
         };
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
-                asm volatile("" : "+v"(q));
+                if (!TASK_ONCE) asm volatile("" : "+v"(q));
                 const uint32_t* const row = AQC_TASK_ROW(q);
                 const int st = max((int)row[WL::D_L2] - 16 * ((int)(q >> 16) + 1), -16);
                 v2[PAIRED ? it : 0] = load16u(seq2b + (uint32_t)((int)row[WL::D_O2] + st + 64));
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
-                asm volatile("" : "+v"(q));
+                if (!TASK_ONCE) asm volatile("" : "+v"(q));
                 v3[it] = load16u(fb.qual1 + (uint32_t)(AQC_TASK_ROW(q)[WL::D_Q1] + ((q >> 16) << 4)));
             }
         };
@@ -432,7 +439,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
-                asm volatile("" : "+v"(q));
+                if (!TASK_ONCE) asm volatile("" : "+v"(q));
                 uint32_t* const row = AQC_TASK_ROW(q);
                 const int c = (int)(q >> 16);
                 const uint4 m = mtab[min(max((int)row[WL::D_L1] - 16 * c, 0), 16)];
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
-                asm volatile("" : "+v"(q));
+                if (!TASK_ONCE) asm volatile("" : "+v"(q));
                 uint32_t* const row = AQC_TASK_ROW(q);
                 const int c = (int)(q >> 16);
                 // the chunk's LAST nb bytes belong to the read: the first 16 - nb become the pad symbol ('T': complemented it
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 uint32_t q = task[it];
-                asm volatile("" : "+v"(q));
+                if (!TASK_ONCE) asm volatile("" : "+v"(q));
                 uint32_t* const row = AQC_TASK_ROW(q);
                 const int c = (int)(q >> 16);
                 const uint4 m = mtab[min(max((int)row[WL::D_L1] - 16 * c, 0), 16)];
@@ -823,11 +830,13 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                     const uint32_t w1 = (k + 1 < NW) ? own[k + 1] : 0u;
 #pragma unroll
                     for (int r0 = 0; r0 < 16; r0 += 8) {
-                        uint32_t cnt[8];
+                        // popcount - 5 (the popcount instruction adds its second operand): negative for a survivor, and the
+                        // OR of the eight keeps a sign bit — three v_or3 instead of a seven-deep min tree
+                        int32_t cnt[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) cnt[q] = __popc(alignbit(w1, w0, 2 * (r0 + q)) ^ F);
-                        const uint32_t best = min(min(min(cnt[0], cnt[1]), min(cnt[2], cnt[3])), min(min(cnt[4], cnt[5]), min(cnt[6], cnt[7])));
-                        if (__ballot(best < 5)) {
+                        for (int q = 0; q < 8; ++q) cnt[q] = (int32_t)__popc(alignbit(w1, w0, 2 * (r0 + q)) ^ F) - 5;
+                        const int32_t any = ((cnt[0] | cnt[1] | cnt[2]) | (cnt[3] | cnt[4] | cnt[5])) | (cnt[6] | cnt[7]);
+                        if (__ballot(any < 0)) {
                             // rare: re-derive the eight counts in a rolled loop, keeping this path out of the hot code
 #pragma nounroll
                             for (int q = 0; q < 8; ++q) {
@@ -852,12 +861,11 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                     const int k = c >> 4;
                     const uint32_t s = (uint32_t)(c & 15) * 2;
                     int tot = 0, c50 = 0, vp0 = 0, vp1 = 0, vp2 = 0;
-                    const int jmax = (wave_max_i(check ? QL : 0) + 15) >> 4;
                     if (check) {
                         uint32_t lo0 = own[k], e0 = own[NW + k];
                         int rem = QL;
 #pragma nounroll
-                        for (int j = 0; j < jmax; ++j) {
+                        for (int j = 0; 16 * j < QL; ++j) {
                             const bool in = k + j + 1 < NW;
                             const uint32_t lo1 = in ? own[k + j + 1] : 0u, e1 = in ? own[NW + k + j + 1] : 0u;
                             uint32_t mm = mm_word(lo0, lo1, e0, e1, s, par[j], par[NW + j], rem);
