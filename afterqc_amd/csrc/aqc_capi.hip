@@ -989,6 +989,7 @@ int aqc_get_counters(aqc_ctx* c, int64_t* out) {
         for (int k = 0; k < 10; k++) tot += pr[k];
         static const char* nm[10] = {"phase1", "normalise", "bubble+len+polyX", "lowq+N", "scan", "verify", "post+walk", "results+counters", "deferred", "-"};
         for (int k = 0; k < 9; k++) fprintf(stderr, "PROF %-18s %6.2f %%\n", nm[k], tot ? 100.0 * pr[k] / tot : 0.0);
+        fprintf(stderr, "DEFER alphabet/length %llu  short-partner %llu  adapter-second-scan %llu  walk-anchor %llu\n", pr[10], pr[11], pr[12], pr[13]);
         // load balance of the last fast-kernel launch of slot 0: spread of the waves' end stamps
         {
             Slot& s0 = c->slots[0];

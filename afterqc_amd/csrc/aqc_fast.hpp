@@ -190,10 +190,12 @@ __device__ __forceinline__ uint32_t mm_word(uint32_t mlo0, uint32_t mlo1, uint32
 }
 
 #ifdef AQC_PROFILE
+#define PROF_DEFER(k, cond) do { if (cond) atomicAdd(&R->st.counters[AQC_N_COUNTERS + 10 + (k)], 1ull); } while (0)
 #define PROF_DECL unsigned long long prof_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_last = __builtin_amdgcn_s_memtime(); const unsigned long long prof_t0 = prof_last;
 #define PROF(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof_t[k] += now_ - prof_last; prof_last = now_; } while (0)
 #define PROF_FLUSH do { if (lane == 0) for (int k_ = 0; k_ < 10; ++k_) atomicAdd(&R->st.counters[AQC_N_COUNTERS + k_], prof_t[k_]); } while (0)
 #else
+#define PROF_DEFER(k, cond)
 #define PROF_DECL
 #define PROF(k)
 #define PROF_FLUSH
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         const int L2 = PAIRED ? (int)pr[WL::D_L2] : 0;
         const bool accum = valid && rec < accum_limit;
         bool defer = valid && (pr[WL::D_EXO] != 0 || L1 > 16 * NW || L2 > 16 * NW || L1 == 0 || (PAIRED && L2 == 0));
+        PROF_DEFER(0, defer && role == 0);
         const int Lown = role ? L2 : L1;
         int a_own = 0, len_own = Lown;
         int flag = -1;
@@ -810,6 +813,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 // the 16-base prefix test needs 16 columns on every diagonal
                 const bool short16 = scan && n_own > 0 && len_par < 16;
                 const bool short16_par = xchg_pred(short16);
+                PROF_DEFER(1, (short16 || short16_par) && !defer && role == 0);
                 if (short16 || short16_par) { defer = true; scan = false; }
             }
             bool i_found_it = false;    // this lane's stream moves on the accepted diagonal
@@ -909,6 +913,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                     // adapter read-through: both reads are cut to overlap_len and util.overlap runs again.  When
                     // overlap_len == len2 - |offset| the second call's first candidate (offset 0) is exactly the
                     // diagonal just accepted, so it returns (0, overlap_len, diff) again; otherwise defer.
+                    PROF_DEFER(2, reached && offset < 0 && ovl > 30 && ovl != len2 + offset && role == 0);
                     if (ovl != len2 + offset) defer = true;
                     else {
                         c_adapter_base = -2 * offset; c_adapter_read = 1;
@@ -928,6 +933,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             //      are exactly the columns of the accepted diagonal, whose first three mismatches the verification
             //      already located; otherwise (read 2 shorter than the rest of read 1) the pair is deferred.
             walk_pair = reached && !defer && flag < 0 && c_overlapped && dist > 0;
+            PROF_DEFER(3, walk_pair && !c_adapter_read && ovl != len1 - offset && role == 0);
             if (walk_pair && !c_adapter_read && ovl != len1 - offset) { defer = true; walk_pair = false; }
             walker = walk_pair && i_found_it;
             if (__ballot(walker)) {

@@ -206,6 +206,30 @@ def test_pairs_vs_oracle(gpu_engine, case):
     assert_same(g, o)
 
 
+def test_every_length_pairs_vs_oracle(gpu_engine):
+    """Read 2 is packed in 16-byte chunks counted from its END (and both mates are padded behind their last base): every
+    length 1..70 for either mate, the shortest ones first so that the first record's leading chunk begins BEFORE the
+    arena, with overlapping tails so that the scan / verification / correction walk see the stream ends."""
+    rng = np.random.default_rng(20260927)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    seqs1, quals1, seqs2, quals2 = [], [], [], []
+    for l1 in list(range(1, 71)) + [150, 160]:
+        for l2 in (1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 70, 150, 160, l1):
+            ins = "".join(rng.choice(list("ACGT"), size=max(l1, l2) + 7))
+            r1 = list(ins[:l1])
+            r2 = [comp[c] for c in reversed(ins[max(0, len(ins) - l2 - 7):len(ins) - 7])][:l2]
+            r2 += list(rng.choice(list("ACGT"), size=l2 - len(r2)))
+            for r in (r1, r2):                           # a few mismatches / N
+                for k in rng.integers(0, len(r), size=len(r) // 25):
+                    r[k] = "ACGTN"[rng.integers(0, 5)]
+            seqs1.append("".join(r1)); seqs2.append("".join(r2))
+            quals1.append("".join(rng.choice(list("#/5?I"), size=l1))); quals2.append("".join(rng.choice(list("#/5?I"), size=l2)))
+    batch = capi.Batch.from_strings(seqs1, quals1, seqs2, quals2)
+    for cfgkw in (dict(seq_len_req=1), dict(seq_len_req=1, trim_front=1, trim_tail=2, trim_front2=2, trim_tail2=1)):
+        g, o = run_both(gpu_engine, default_cfg(True, **cfgkw), batch, qc=False)
+        assert_same(g, o)
+
+
 def test_single_end_vs_oracle(gpu_engine):
     d = synth.make_single(8000, 150, seed=99)
     batch = capi.Batch.from_matrices(d["seq1"], d["qual1"], d["len1"])
