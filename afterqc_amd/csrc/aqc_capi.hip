@@ -830,7 +830,9 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
         // 48-byte plans, (sparse) full piece lists for the records that do not fit a plan, and the list of the records the
         // general copy kernel takes (+ its length)
         const uint64_t gen_cap = ((n_tiles + GEN_LISTS - 1) / GEN_LISTS) * FMT_TILE * (s->paired ? 2 : 1);     // worst case: every record
-        if (s->f_plan.reserve(16 * PLAN_Q * n_tasks) || s->f_over.reserve(sizeof(FmtTask) * n_tasks) ||
+        // plans: one 16-byte word per (record, file), dense; the six words of the records the general kernel takes, in list order
+        const uint64_t plan0_bytes = (16 * n_tasks + 255) / 256 * 256;
+        if (s->f_plan.reserve(plan0_bytes + 16 * PLAN_Q * gen_cap * GEN_LISTS) || s->f_over.reserve(sizeof(FmtTask) * n_tasks) ||
             s->f_pos.reserve(4 * gen_cap * GEN_LISTS + sizeof(unsigned int) * GEN_LISTS + 64))
             return fail(AQC_ERR_HIP, "hipMalloc failed");
         unsigned int* d_ngen = (unsigned int*)((uint8_t*)s->f_pos.p + 4 * gen_cap * GEN_LISTS);
@@ -838,15 +840,16 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
         for (int pass = 0; pass < (v.store_overlap ? 2 : 1); ++pass) {
             HIP_TRY(hipMemsetAsync(d_ngen, 0, sizeof(unsigned int) * GEN_LISTS, s->stream));
             hipLaunchKernelGGL(fmt_plan_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles,
-                               (const unsigned long long*)s->f_tile.p, pass, s->status, (uint4*)s->f_plan.p, (FmtTask*)s->f_over.p,
-                               (uint32_t*)s->f_pos.p, d_ngen, gen_cap);
+                               (const unsigned long long*)s->f_tile.p, pass, s->status, (uint4*)s->f_plan.p,
+                               (uint4*)((uint8_t*)s->f_plan.p + plan0_bytes), (FmtTask*)s->f_over.p, (uint32_t*)s->f_pos.p, d_ngen, gen_cap);
             hipLaunchKernelGGL(fmt_copy_whole_kernel, dim3(copy_blocks), dim3(COPY_BLOCK), 0, s->stream, v, n_tasks, (const uint4*)s->f_plan.p, outs);
             // GEN_LISTS x k workgroups; k from the worst case, at most 32 per list
-            uint64_t per_list = (gen_cap + (COPY_BLOCK / 32) * GEN_UNROLL - 1) / ((COPY_BLOCK / 32) * GEN_UNROLL);
+            uint64_t per_list = (gen_cap + GEN_ROUND - 1) / GEN_ROUND;
             if (per_list > 32) per_list = 32;
             if (per_list < 1) per_list = 1;
-            hipLaunchKernelGGL(fmt_copy_kernel, dim3((unsigned)(GEN_LISTS * per_list)), dim3(COPY_BLOCK), 0, s->stream, v, (const uint4*)s->f_plan.p,
-                               (const FmtTask*)s->f_over.p, outs, (const uint32_t*)s->f_pos.p, (const unsigned int*)d_ngen, gen_cap);
+            hipLaunchKernelGGL(fmt_copy_kernel, dim3((unsigned)(GEN_LISTS * per_list)), dim3(COPY_BLOCK), 0, s->stream, v,
+                               (const uint4*)((uint8_t*)s->f_plan.p + plan0_bytes), (const FmtTask*)s->f_over.p, outs, (const uint32_t*)s->f_pos.p,
+                               (const unsigned int*)d_ngen, gen_cap);
         }
         HIP_TRY(hipGetLastError());
     }

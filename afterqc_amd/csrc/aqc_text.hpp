@@ -758,8 +758,9 @@ __device__ __forceinline__ bool plan_is_whole(const uint4& q0) {
 
 __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
                                                             const unsigned long long* __restrict__ tile_base, int overlap_pass,
-                                                            int* __restrict__ status, uint4* __restrict__ plan, FmtTask* __restrict__ over,
-                                                            uint32_t* __restrict__ gen_list, unsigned int* __restrict__ n_gen, uint64_t gen_cap) {
+                                                            int* __restrict__ status, uint4* __restrict__ plan0, uint4* __restrict__ plan_gen,
+                                                            FmtTask* __restrict__ over, uint32_t* __restrict__ gen_list,
+                                                            unsigned int* __restrict__ n_gen, uint64_t gen_cap) {
     __shared__ unsigned long long lds[4];
     __shared__ FmtTask tasks[FMT_TILE];
     const int nfiles = v.paired ? 2 : 1;
@@ -776,6 +777,9 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
         }
         unsigned int pos;
         bool general = false;
+        uint4 q[PLAN_Q];
+#pragma unroll
+        for (int k = 0; k < PLAN_Q; ++k) q[k] = make_uint4(0, 0, 0, 0);
         if (!overlap_pass) {
             // good and bad records interleave: two scans, each record keeps the offset of the stream it goes to
             unsigned long long tg, tb;
@@ -791,9 +795,6 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
         }
         if (r < n) {
             const uint64_t ti = r * nfiles + file;
-            uint4 q[PLAN_Q];
-#pragma unroll
-            for (int k = 0; k < PLAN_Q; ++k) q[k] = make_uint4(0, 0, 0, 0);
             q[0] = make_uint4(pos, PLAN_SKIP, 0, 0);
             if (t.stream != 0xff) {
                 t.pos = pos;
@@ -833,11 +834,7 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
                 }
             }
             const bool whole = plan_is_whole(q[0]);
-            plan[PLAN_Q * ti] = q[0];
-            if (!whole && q[0].y != PLAN_SKIP && !(q[0].y & PLAN_OVER)) {
-#pragma unroll
-                for (int k = 1; k < PLAN_Q; ++k) plan[PLAN_Q * ti + k] = q[k];
-            }
+            plan0[ti] = q[0];
             general = q[0].y != PLAN_SKIP && !whole;
         }
         // the records fmt_copy_whole_kernel does not take are listed (one atomic per wave) for the general copy kernel
@@ -850,7 +847,13 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
                 const unsigned int lj = blockIdx.x % GEN_LISTS;
                 if (lane_id() == 0) base = atomicAdd(&n_gen[lj], (unsigned int)__popcll(gm));
                 base = (unsigned int)__shfl((int)base, 0, WAVE);
-                if (general) gen_list[(uint64_t)lj * gen_cap + base + (unsigned int)__popcll(gm & ((1ull << lane_id()) - 1ull))] = (uint32_t)(r * nfiles + file);
+                if (general) {
+                    // the general kernel reads its plans in list order: all six words go where the record is listed
+                    const uint64_t slot = (uint64_t)lj * gen_cap + base + (unsigned int)__popcll(gm & ((1ull << lane_id()) - 1ull));
+                    gen_list[slot] = (uint32_t)(r * nfiles + file);
+#pragma unroll
+                    for (int k = 0; k < PLAN_Q; ++k) plan_gen[slot * PLAN_Q + k] = q[k];
+                }
             }
         }
         __syncthreads();            // (tasks[] is reused for the second file)
@@ -877,7 +880,7 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_kernel(FormatView v
     for (int u = 0; u < FMT_UNROLL; ++u) {
         const uint64_t ti = t_first + u;
         pa[u] = make_uint4(0, PLAN_SKIP, 0, 0);
-        if (ti < n_tasks) pa[u] = plan[PLAN_Q * ti];
+        if (ti < n_tasks) pa[u] = plan[ti];
     }
     uint4 val[FMT_UNROLL];
     uint8_t* dptr[FMT_UNROLL];
@@ -900,50 +903,55 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_kernel(FormatView v
 // item — a 16-byte window of a long piece (16-byte load + 16-byte store at any alignment, the piece's last window
 // end-aligned) or a whole short piece.  Stages (list, plans, decode, loads, patches, stores) run over both plans so that
 // each stage's memory operations travel together.
-constexpr int GEN_UNROLL = 2;
-__global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, const uint4* __restrict__ plan, const FmtTask* __restrict__ over,
+constexpr int GEN_U = 4;                                   // plans per half-wave per round
+constexpr int GEN_ROUND = (COPY_BLOCK / 32) * GEN_U;       // plans per workgroup per round
+static_assert(GEN_ROUND * PLAN_Q <= COPY_BLOCK, "one 16-byte word per thread stages a round's plans");
+
+// Everything that is not "one piece": the plans arrive in list order (fmt_plan_kernel), so a workgroup stages the 32 plans
+// of a round with ONE coalesced load into LDS (3 KB) and its eight half-waves take four plans each: per lane up to eight
+// 16-byte windows in flight (32 lanes x 2 work items per plan), held as 32-bit offsets — the earlier version kept the
+// plans in registers (48 of them), had two records in flight per half-wave and three dependent memory round trips per
+// iteration (list -> plan -> data): 1.6 TB/s.
+__global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, const uint4* __restrict__ plan_gen, const FmtTask* __restrict__ over,
                                                              FormatOut outs, const uint32_t* __restrict__ gen_lists,
                                                              const unsigned int* __restrict__ n_gen, uint64_t gen_cap) {
+    __shared__ uint4 s_plan[GEN_ROUND * PLAN_Q];
+    __shared__ uint32_t s_ti[GEN_ROUND];
+    __shared__ const uint8_t* s_ptr[8];                       // [0..5] output streams (file * 3 + stream), [6..7] the files' texts
     const int nfiles = v.paired ? 2 : 1;
-    const int lane32 = threadIdx.x & 31;
+    const int lane32 = threadIdx.x & 31, hwi = threadIdx.x >> 5;
+    if (threadIdx.x < 6) s_ptr[threadIdx.x] = outs.p[threadIdx.x];
+    if (threadIdx.x >= 6 && threadIdx.x < 8) s_ptr[threadIdx.x] = v.f[threadIdx.x - 6].text;
     // workgroup b works on list b % GEN_LISTS together with the other workgroups of that list
     const unsigned int lj = blockIdx.x % GEN_LISTS;
     const uint32_t* gen_list = gen_lists + (uint64_t)lj * gen_cap;
-    const uint64_t n_list = n_gen[lj];
-    const uint64_t n_hw = ((uint64_t)(gridDim.x / GEN_LISTS) * COPY_BLOCK) >> 5;
-    for (uint64_t hw = ((uint64_t)(blockIdx.x / GEN_LISTS) * COPY_BLOCK + threadIdx.x) >> 5; hw * GEN_UNROLL < n_list; hw += n_hw) {
-        const uint64_t l_first = hw * GEN_UNROLL;
-        uint64_t tis[GEN_UNROLL];
-#pragma unroll
-        for (int u = 0; u < GEN_UNROLL; ++u) tis[u] = l_first + u < n_list ? (uint64_t)gen_list[l_first + u] : ~0ull;
-        uint4 q[GEN_UNROLL][PLAN_Q];
-#pragma unroll
-        for (int u = 0; u < GEN_UNROLL; ++u) {
-#pragma unroll
-            for (int k = 0; k < PLAN_Q; ++k) q[u][k] = make_uint4(0, 0, 0, 0);
-            q[u][0].y = PLAN_SKIP;
-            if (tis[u] != ~0ull) {
-#pragma unroll
-                for (int k = 0; k < PLAN_Q; ++k) q[u][k] = plan[PLAN_Q * tis[u] + k];     // (q1.. of an overflow plan are never used)
-            }
-        }
-        constexpr int NWIN = GEN_UNROLL * GEN_PASSES;     // windows in flight per lane: plan u, pass j -> slot u * GEN_PASSES + j
+    const uint4* pg = plan_gen + (uint64_t)lj * gen_cap * PLAN_Q;
+    const uint32_t n_list = n_gen[lj];
+    const uint32_t stride = (gridDim.x / GEN_LISTS) * GEN_ROUND;
+    for (uint32_t r0 = (blockIdx.x / GEN_LISTS) * GEN_ROUND; r0 < n_list; r0 += stride) {
+        const uint32_t cnt = min((uint32_t)GEN_ROUND, n_list - r0);
+        __syncthreads();                                     // (the previous round's plans are no longer read)
+        if (threadIdx.x < cnt * PLAN_Q) s_plan[threadIdx.x] = pg[(uint64_t)r0 * PLAN_Q + threadIdx.x];
+        if (threadIdx.x < cnt) s_ti[threadIdx.x] = gen_list[r0 + threadIdx.x];
+        __syncthreads();
+        constexpr int NWIN = GEN_U * GEN_PASSES;          // windows in flight per lane: plan u, pass j -> slot u * GEN_PASSES + j
         uint4 val[NWIN];
-        uint8_t* dptr[NWIN];
-        const uint8_t* sptr[NWIN];
-        int mode[NWIN], wpos[NWIN];          // mode: 0 nothing, 16 a window, 1..15 a short piece of that many bytes
-        uint32_t more = 0;                   // bit u: plan u lives in the overflow array
+        uint32_t so[NWIN], dof[NWIN], mw[NWIN];           // source offset (FMT_LIT_BIT: literal table), offset in the output stream,
+                                                          // mode | position in the record << 5 | file * 3 + stream << 21
+                                                          // (mode: 0 nothing, 16 a window, 1..15 a short piece of that many bytes)
+        uint32_t more = 0;                                // bit u: plan u lives in the overflow array
 #pragma unroll
-        for (int u = 0; u < GEN_UNROLL; ++u) {
-            const uint4 q0 = q[u][0], q1 = q[u][1], q2 = q[u][2], q3 = q[u][3], q4 = q[u][4];
+        for (int u = 0; u < GEN_U; ++u) {
 #pragma unroll
-            for (int j = 0; j < GEN_PASSES; ++j) {
-                const int w = u * GEN_PASSES + j;
-                mode[w] = 0; dptr[w] = nullptr; sptr[w] = nullptr; val[w] = make_uint4(0, 0, 0, 0); wpos[w] = 0;
-            }
-            if (q0.y == PLAN_SKIP) continue;
+            for (int j = 0; j < GEN_PASSES; ++j) { so[u * GEN_PASSES + j] = 0; dof[u * GEN_PASSES + j] = 0; mw[u * GEN_PASSES + j] = 0; }
+            const uint32_t idx = (uint32_t)(hwi * GEN_U + u);
+            if (idx >= cnt) continue;
+            const uint4* P = s_plan + idx * PLAN_Q;
+            const uint4 q0 = P[0];
             if (q0.y & PLAN_OVER) { more |= 1u << u; continue; }
-            const int file = nfiles == 2 ? (int)(tis[u] & 1) : 0;
+            const uint4 q1 = P[1], q2 = P[2], q3 = P[3], q4 = P[4];
+            const uint32_t file = nfiles == 2 ? (s_ti[idx] & 1u) : 0u;
+            const uint32_t fs = file * 3u + (q0.y & 0xffu);
             const uint32_t items = q4.w >> 16;
             const unsigned long long cum = ((unsigned long long)q3.w << 32) | q3.z;
 #pragma unroll
@@ -961,53 +969,65 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
                 const uint32_t ow = k < 1 ? 0u : k < 3 ? q4.x : k < 5 ? q4.y : k < 7 ? q4.z : q4.w;     // output offsets of pieces 1..7
                 const int dst_off = k == 0 ? 0 : (int)((ow >> (16 * ((k - 1) & 1))) & 0xffffu);
                 const uint32_t sk = k == 0 ? q0.z : k == 1 ? q1.x : k == 2 ? q1.y : k == 3 ? q1.z : k == 4 ? q1.w : k == 5 ? q2.x : k == 6 ? q2.y : q2.z;
-                const uint8_t* src = (sk & FMT_LIT_BIT) ? &FMT_LIT[0][0] + (sk & ~FMT_LIT_BIT) : v.f[file].text + sk;
-                uint8_t* dst = outs.p[file * 3 + (int)(q0.y & 0xffu)] + q0.x + dst_off;
-                if (lk >= 16) {
-                    const int off = min(16 * ((int)item - first_item), lk - 16);       // the last window is aligned to the piece's end
-                    sptr[w] = src + off; dptr[w] = dst + off; mode[w] = 16; wpos[w] = dst_off + off;
-                } else {
-                    sptr[w] = src; dptr[w] = dst; mode[w] = lk;
-                }
+                // a long piece: my 16-byte window of it, the last one aligned to the piece's end; a short piece: all of it
+                const int off = lk >= 16 ? min(16 * ((int)item - first_item), lk - 16) : 0;
+                so[w] = sk + (uint32_t)off;
+                dof[w] = q0.x + (uint32_t)(dst_off + off);
+                mw[w] = (uint32_t)min(lk, 16) | ((uint32_t)(dst_off + off) << 5) | (fs << 21);
             }
         }
+        auto src_of = [&](int w) -> const uint8_t* {
+            return (so[w] & FMT_LIT_BIT) ? &FMT_LIT[0][0] + (so[w] & ~FMT_LIT_BIT) : s_ptr[6 + (mw[w] >> 21) / 3u] + so[w];
+        };
+        auto dst_of = [&](int w) -> uint8_t* { return const_cast<uint8_t*>(s_ptr[mw[w] >> 21]) + dof[w]; };
 #pragma unroll
-        for (int w = 0; w < NWIN; ++w)
-            if (mode[w] == 16) val[w] = load16u_t(sptr[w]);
+        for (int w = 0; w < NWIN; ++w) {
+            val[w] = make_uint4(0, 0, 0, 0);
+            if ((mw[w] & 31u) == 16u) val[w] = load16u_t(src_of(w));
+        }
         // the correction walk's edits: byte patches applied in registers (windows that overlap carry the same patch)
 #pragma unroll
-        for (int w = 0; w < NWIN; ++w) {
-            const int u = w / GEN_PASSES;
-            const uint32_t np_ = (q[u][0].y & PLAN_OVER) || q[u][0].y == PLAN_SKIP ? 0u : (q[u][0].y >> 16) & 0xffu;
-            if (np_ == 0 || mode[w] != 16) continue;
-            const uint32_t pt[4] = {q[u][5].x, q[u][5].y, q[u][5].z, q[u][5].w};
+        for (int u = 0; u < GEN_U; ++u) {
+            const uint32_t idx = (uint32_t)(hwi * GEN_U + u);
+            if (idx >= cnt || ((more >> u) & 1u)) continue;
+            const uint32_t np_ = (s_plan[idx * PLAN_Q].y >> 16) & 0xffu;
+            if (np_ == 0) continue;
+            const uint4 q5 = s_plan[idx * PLAN_Q + 5];
+            const uint32_t pt[4] = {q5.x, q5.y, q5.z, q5.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t i = (pt[e] & 0xffffu) - (uint32_t)wpos[w];
-                if ((uint32_t)e < np_ && i < 16u) {
-                    const uint32_t sh = (i & 3u) * 8u, m = 0xffu << sh, cb = ((pt[e] >> 16) & 0xffu) << sh;
-                    const uint32_t wd = i >> 2;
-                    val[w].x = wd == 0 ? (val[w].x & ~m) | cb : val[w].x;
-                    val[w].y = wd == 1 ? (val[w].y & ~m) | cb : val[w].y;
-                    val[w].z = wd == 2 ? (val[w].z & ~m) | cb : val[w].z;
-                    val[w].w = wd == 3 ? (val[w].w & ~m) | cb : val[w].w;
+            for (int j = 0; j < GEN_PASSES; ++j) {
+                const int w = u * GEN_PASSES + j;
+                if ((mw[w] & 31u) != 16u) continue;
+                const uint32_t wpos = (mw[w] >> 5) & 0xffffu;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t i = (pt[e] & 0xffffu) - wpos;
+                    if ((uint32_t)e < np_ && i < 16u) {
+                        const uint32_t sh = (i & 3u) * 8u, m = 0xffu << sh, cb = ((pt[e] >> 16) & 0xffu) << sh;
+                        const uint32_t wd = i >> 2;
+                        val[w].x = wd == 0 ? (val[w].x & ~m) | cb : val[w].x;
+                        val[w].y = wd == 1 ? (val[w].y & ~m) | cb : val[w].y;
+                        val[w].z = wd == 2 ? (val[w].z & ~m) | cb : val[w].z;
+                        val[w].w = wd == 3 ? (val[w].w & ~m) | cb : val[w].w;
+                    }
                 }
             }
         }
 #pragma unroll
         for (int w = 0; w < NWIN; ++w) {
-            if (mode[w] == 16) store16u(dptr[w], val[w]);
-            else if (mode[w] >= 8) copy_small<8>(dptr[w], sptr[w], mode[w]);
-            else if (mode[w] >= 4) copy_small<4>(dptr[w], sptr[w], mode[w]);
-            else if (mode[w] >= 2) copy_small<2>(dptr[w], sptr[w], mode[w]);
-            else if (mode[w] == 1) dptr[w][0] = sptr[w][0];
+            const int md = (int)(mw[w] & 31u);
+            if (md == 16) store16u(dst_of(w), val[w]);
+            else if (md >= 8) copy_small<8>(dst_of(w), src_of(w), md);
+            else if (md >= 4) copy_small<4>(dst_of(w), src_of(w), md);
+            else if (md >= 2) copy_small<2>(dst_of(w), src_of(w), md);
+            else if (md == 1) dst_of(w)[0] = src_of(w)[0];
         }
-        // ---- overflow records: any number of pieces / work items, piece by piece (records of more than ~500 bytes, more
-        //      than eight pieces or four patches)
+        // ---- overflow records: any number of pieces / work items, piece by piece (records of more than 1 KiB, more than
+        //      eight pieces or four patches)
         if (more) {
-            for (int u = 0; u < GEN_UNROLL; ++u) {
+            for (int u = 0; u < GEN_U; ++u) {
                 if (!((more >> u) & 1u)) continue;
-                const uint64_t ti = tis[u];
+                const uint64_t ti = s_ti[hwi * GEN_U + u];
                 const FmtTask& t = over[ti];
                 const int file = nfiles == 2 ? (int)(ti & 1) : 0;
                 uint8_t* out0 = outs.p[file * 3 + (int)t.stream] + t.pos;
