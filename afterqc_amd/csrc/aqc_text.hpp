@@ -937,32 +937,33 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
         constexpr int NWIN = GEN_U * GEN_PASSES;          // windows in flight per lane: plan u, pass j -> slot u * GEN_PASSES + j
         uint4 val[NWIN];
         uint32_t so[NWIN], dof[NWIN], mw[NWIN];           // source offset (FMT_LIT_BIT: literal table), offset in the output stream,
-                                                          // mode | position in the record << 5 | file * 3 + stream << 21
+                                                          // mode | position in the record << 5 | file * 3 + stream << 21 | file << 24
                                                           // (mode: 0 nothing, 16 a window, 1..15 a short piece of that many bytes)
         uint32_t more = 0;                                // bit u: plan u lives in the overflow array
+        // (straight-line on purpose: with a branch per plan / window the instruction stream was one saveexec - branch - nop
+        //  sequence after the other and the kernel spent its time on instruction latency)
 #pragma unroll
         for (int u = 0; u < GEN_U; ++u) {
-#pragma unroll
-            for (int j = 0; j < GEN_PASSES; ++j) { so[u * GEN_PASSES + j] = 0; dof[u * GEN_PASSES + j] = 0; mw[u * GEN_PASSES + j] = 0; }
             const uint32_t idx = (uint32_t)(hwi * GEN_U + u);
-            if (idx >= cnt) continue;
-            const uint4* P = s_plan + idx * PLAN_Q;
-            const uint4 q0 = P[0];
-            if (q0.y & PLAN_OVER) { more |= 1u << u; continue; }
-            const uint4 q1 = P[1], q2 = P[2], q3 = P[3], q4 = P[4];
-            const uint32_t file = nfiles == 2 ? (s_ti[idx] & 1u) : 0u;
+            const bool live = idx < cnt;
+            const uint4* P = s_plan + (live ? idx : 0u) * PLAN_Q;
+            const uint4 q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3], q4 = P[4];
+            const bool ovf = live && (q0.y & PLAN_OVER) != 0;
+            more |= ovf ? 1u << u : 0u;
+            const uint32_t file = nfiles == 2 ? (s_ti[live ? idx : 0u] & 1u) : 0u;
             const uint32_t fs = file * 3u + (q0.y & 0xffu);
-            const uint32_t items = q4.w >> 16;
+            const uint32_t items = (live && !ovf) ? q4.w >> 16 : 0u;
             const unsigned long long cum = ((unsigned long long)q3.w << 32) | q3.z;
 #pragma unroll
             for (int j = 0; j < GEN_PASSES; ++j) {
                 const int w = u * GEN_PASSES + j;
                 const uint32_t item = (uint32_t)lane32 + 32u * j;
-                if (item >= items) continue;
+                const bool on = item < items;
                 // my piece: count the pieces whose cumulative item count I am at or beyond
                 int k = 0;
 #pragma unroll
                 for (int jj = 0; jj < PLAN_MAXP - 1; ++jj) k += item >= (uint32_t)((cum >> (8 * jj)) & 0xffu) ? 1 : 0;
+                k = on ? k : 0;
                 const int first_item = (int)(((cum << 8) >> (8 * k)) & 0xffu);
                 const uint32_t lw = k < 2 ? q0.w : k < 4 ? q2.w : k < 6 ? q3.x : q3.y;                  // lengths, two per word
                 const int lk = (int)((lw >> (16 * (k & 1))) & 0xffffu);
@@ -973,54 +974,75 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
                 const int off = lk >= 16 ? min(16 * ((int)item - first_item), lk - 16) : 0;
                 so[w] = sk + (uint32_t)off;
                 dof[w] = q0.x + (uint32_t)(dst_off + off);
-                mw[w] = (uint32_t)min(lk, 16) | ((uint32_t)(dst_off + off) << 5) | (fs << 21);
+                mw[w] = on ? ((uint32_t)min(lk, 16) | ((uint32_t)(dst_off + off) << 5) | (fs << 21) | (file << 24)) : 0u;
             }
         }
+        const uint8_t* const lit = &FMT_LIT[0][0];
+        const uint8_t* const tp0 = s_ptr[6];
+        const uint8_t* const tp1 = s_ptr[7];
         auto src_of = [&](int w) -> const uint8_t* {
-            return (so[w] & FMT_LIT_BIT) ? &FMT_LIT[0][0] + (so[w] & ~FMT_LIT_BIT) : s_ptr[6 + (mw[w] >> 21) / 3u] + so[w];
+            const uint8_t* base = ((mw[w] >> 24) & 1u) ? tp1 : tp0;
+            base = (so[w] & FMT_LIT_BIT) ? lit : base;
+            return base + (so[w] & ~FMT_LIT_BIT);
         };
-        auto dst_of = [&](int w) -> uint8_t* { return const_cast<uint8_t*>(s_ptr[mw[w] >> 21]) + dof[w]; };
+        auto dst_of = [&](int w) -> uint8_t* { return const_cast<uint8_t*>(s_ptr[(mw[w] >> 21) & 7u]) + dof[w]; };
+        // every lane loads (a lane without a window reads the first bytes of the text: harmless, and no branch)
+        uint32_t any_small = 0;
 #pragma unroll
         for (int w = 0; w < NWIN; ++w) {
-            val[w] = make_uint4(0, 0, 0, 0);
-            if ((mw[w] & 31u) == 16u) val[w] = load16u_t(src_of(w));
+            const uint32_t md = mw[w] & 31u;
+            val[w] = load16u_t(md == 16u ? src_of(w) : tp0);
+            any_small |= (md - 1u) < 15u ? 1u : 0u;
         }
         // the correction walk's edits: byte patches applied in registers (windows that overlap carry the same patch)
+        {
+            uint32_t np_[GEN_U];
+            uint32_t any_patch = 0;
 #pragma unroll
-        for (int u = 0; u < GEN_U; ++u) {
-            const uint32_t idx = (uint32_t)(hwi * GEN_U + u);
-            if (idx >= cnt || ((more >> u) & 1u)) continue;
-            const uint32_t np_ = (s_plan[idx * PLAN_Q].y >> 16) & 0xffu;
-            if (np_ == 0) continue;
-            const uint4 q5 = s_plan[idx * PLAN_Q + 5];
-            const uint32_t pt[4] = {q5.x, q5.y, q5.z, q5.w};
+            for (int u = 0; u < GEN_U; ++u) {
+                const uint32_t idx = (uint32_t)(hwi * GEN_U + u);
+                np_[u] = (idx < cnt && !((more >> u) & 1u)) ? (s_plan[idx * PLAN_Q].y >> 16) & 0xffu : 0u;
+                any_patch |= np_[u];
+            }
+            if (__ballot(any_patch != 0)) {
 #pragma unroll
-            for (int j = 0; j < GEN_PASSES; ++j) {
-                const int w = u * GEN_PASSES + j;
-                if ((mw[w] & 31u) != 16u) continue;
-                const uint32_t wpos = (mw[w] >> 5) & 0xffffu;
+                for (int u = 0; u < GEN_U; ++u) {
+                    const uint32_t idx = min((uint32_t)(hwi * GEN_U + u), cnt - 1u);
+                    const uint4 q5 = s_plan[idx * PLAN_Q + 5];
+                    const uint32_t pt[4] = {q5.x, q5.y, q5.z, q5.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t i = (pt[e] & 0xffffu) - wpos;
-                    if ((uint32_t)e < np_ && i < 16u) {
-                        const uint32_t sh = (i & 3u) * 8u, m = 0xffu << sh, cb = ((pt[e] >> 16) & 0xffu) << sh;
-                        const uint32_t wd = i >> 2;
-                        val[w].x = wd == 0 ? (val[w].x & ~m) | cb : val[w].x;
-                        val[w].y = wd == 1 ? (val[w].y & ~m) | cb : val[w].y;
-                        val[w].z = wd == 2 ? (val[w].z & ~m) | cb : val[w].z;
-                        val[w].w = wd == 3 ? (val[w].w & ~m) | cb : val[w].w;
+                    for (int j = 0; j < GEN_PASSES; ++j) {
+                        const int w = u * GEN_PASSES + j;
+                        const bool win = (mw[w] & 31u) == 16u;
+                        const uint32_t wpos = (mw[w] >> 5) & 0xffffu;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t i = (pt[e] & 0xffffu) - wpos;
+                            const bool hit = win && (uint32_t)e < np_[u] && i < 16u;
+                            const uint32_t sh = (i & 3u) * 8u, m = hit ? 0xffu << sh : 0u, cb = hit ? ((pt[e] >> 16) & 0xffu) << sh : 0u;
+                            const uint32_t wd = i >> 2;
+                            val[w].x = wd == 0 ? (val[w].x & ~m) | cb : val[w].x;
+                            val[w].y = wd == 1 ? (val[w].y & ~m) | cb : val[w].y;
+                            val[w].z = wd == 2 ? (val[w].z & ~m) | cb : val[w].z;
+                            val[w].w = wd == 3 ? (val[w].w & ~m) | cb : val[w].w;
+                        }
                     }
                 }
             }
         }
 #pragma unroll
-        for (int w = 0; w < NWIN; ++w) {
-            const int md = (int)(mw[w] & 31u);
-            if (md == 16) store16u(dst_of(w), val[w]);
-            else if (md >= 8) copy_small<8>(dst_of(w), src_of(w), md);
-            else if (md >= 4) copy_small<4>(dst_of(w), src_of(w), md);
-            else if (md >= 2) copy_small<2>(dst_of(w), src_of(w), md);
-            else if (md == 1) dst_of(w)[0] = src_of(w)[0];
+        for (int w = 0; w < NWIN; ++w)
+            if ((mw[w] & 31u) == 16u) store16u(dst_of(w), val[w]);
+        if (__ballot(any_small != 0)) {                    // pieces of 1..15 bytes: a literal '@', a moved barcode, a stray newline
+#pragma unroll
+            for (int w = 0; w < NWIN; ++w) {
+                const int md = (int)(mw[w] & 31u);
+                if (md >= 16 || md == 0) continue;
+                if (md >= 8) copy_small<8>(dst_of(w), src_of(w), md);
+                else if (md >= 4) copy_small<4>(dst_of(w), src_of(w), md);
+                else if (md >= 2) copy_small<2>(dst_of(w), src_of(w), md);
+                else dst_of(w)[0] = src_of(w)[0];
+            }
         }
         // ---- overflow records: any number of pieces / work items, piece by piece (records of more than 1 KiB, more than
         //      eight pieces or four patches)
