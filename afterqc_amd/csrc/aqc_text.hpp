@@ -903,12 +903,12 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_kernel(FormatView v
 // item — a 16-byte window of a long piece (16-byte load + 16-byte store at any alignment, the piece's last window
 // end-aligned) or a whole short piece.  Stages (list, plans, decode, loads, patches, stores) run over both plans so that
 // each stage's memory operations travel together.
-constexpr int GEN_U = 4;                                   // plans per half-wave per round
+constexpr int GEN_U = 2;                                   // plans per half-wave per round
 constexpr int GEN_ROUND = (COPY_BLOCK / 32) * GEN_U;       // plans per workgroup per round
 static_assert(GEN_ROUND * PLAN_Q <= COPY_BLOCK, "one 16-byte word per thread stages a round's plans");
 
-// Everything that is not "one piece": the plans arrive in list order (fmt_plan_kernel), so a workgroup stages the 32 plans
-// of a round with ONE coalesced load into LDS (3 KB) and its eight half-waves take four plans each: per lane up to eight
+// Everything that is not "one piece": the plans arrive in list order (fmt_plan_kernel), so a workgroup stages the 16 plans
+// of a round with ONE coalesced load into LDS (1.5 KB) and its eight half-waves take two plans each: per lane up to four
 // 16-byte windows in flight (32 lanes x 2 work items per plan), held as 32-bit offsets — the earlier version kept the
 // plans in registers (48 of them), had two records in flight per half-wave and three dependent memory round trips per
 // iteration (list -> plan -> data): 1.6 TB/s.
