@@ -1,43 +1,40 @@
-// aqc_fast.hpp — generation 2/3 of the hot kernel: "one LANE per READ" (two lanes per pair).
+// aqc_fast.hpp — the hot kernel: "one LANE per READ" (two lanes per pair), generation 5.
 //
 // Why: the wave-per-record kernel (aqc_kernels.hpp) spends ~1500 wave-instructions per pair, which
 // caps it at ~1 % of the HBM roofline.  To stream pairs at a useful fraction of 8 TB/s the whole
 // pipeline must cost on the order of 100 wave-instructions per pair (256 CUs x 4 SIMDs x ~1.1 G
 // wave-instr/s / 5 G pairs/s), i.e. every lane has to do useful work all the time and byte
-// compares have to become word compares.  Design:
+// compares have to become word compares.  It is at 77 per pair now.  Design:
 //
-//   phase 1 (cooperative, coalesced)   the wave owns 32 consecutive pairs.  Each lane loads one
-//       16-byte chunk of one string per step (global_load_dwordx4: 16 lanes cover a 160-byte read,
-//       4 reads per instruction) and converts it with SWAR + v_dot4/v_perm into
+//   phase 1 (cooperative, coalesced)   the wave owns 32 consecutive pairs.  Chunk t = it * 64 + lane of the batch is
+//       chunk t % NW of record t / NW: NW neighbouring lanes cover one read.  Each lane loads its 16-byte chunk
+//       (global_load_dwordx4 at the read's own alignment) and converts it with SWAR + v_dot4/v_perm into
 //         lo  : 2 bits per base  ((c >> 1) & 3: A=0 C=1 T=2 G=3; N shares 3)            32 bits/chunk
 //         e   : 1 bit per base (odd bit of the 2-bit field) set for 'N'                32 bits/chunk
-//       Read 2 is stored complemented and reversed, so that reverse_r2 (util.py:161) is a forward
-//       2-bit stream.  Low-quality counts of read 1 are reduced per chunk.  The planes go to LDS.
-//   phase 2 (lane per read)            lanes 2p / 2p+1 own read 1 / reverse_r2 of pair p.  Each pulls the
-//       planes of ITS read into registers, normalises them (trim offsets, reverse-complement
-//       alignment) and runs the pipeline of preprocesser.py:455-617 on 32-bit words.  The two roles are
-//       symmetric: the read-1 lane scans the forward offsets of util.py:172-186 (its stream moves over the
-//       partner's 16-base prefix), the read-2 lane the reverse offsets of :194-209 — same instructions,
-//       different data, values exchanged with one DPP quad_perm.  Halving the per-lane state (22 plane
-//       registers, 5.8 KB of LDS per wave) is what lifts occupancy from 2 to 4 waves per SIMD; the
-//       VALU issue rate of this code roughly doubles with it (tools/ubench/valu_rate.hip).
+//       Read 2 is cut into chunks from its END, complemented and reversed: chunk c IS word c of reverse_r2
+//       (util.py:161), a forward 2-bit stream that starts at bit 0.  Behind a read both streams continue A C A C ...
+//       Low-quality counts of read 1 are reduced per chunk.  The planes and the record's descriptor (offsets, lengths,
+//       alphabet verdict, low-quality count) share one LDS row per record.
+//   phase 2 (lane per read)            lanes 2p / 2p+1 own read 1 / reverse_r2 of pair p and run the pipeline of
+//       preprocesser.py:455-617 on 32-bit words fetched from the row as needed (a trim / barcode stage that moves a
+//       view re-aligns the stream in place first).  The two roles are symmetric: the read-1 lane scans the forward
+//       offsets of util.py:172-186 (its stream moves over the partner's 16-base prefix), the read-2 lane the reverse
+//       offsets of :194-209 — same instructions, different data, values exchanged with one DPP quad_perm.
 //         * overlap scan: one diagonal = v_alignbit + v_xor + v_bcnt on a 16-base prefix window;
 //           >= 5 differing bits imply >= 3 mismatching bases, which util.py:180-183 can never accept;
 //         * the rare survivors are verified exactly over the full diagonal (lo and e planes);
-//         * the correction walk reads the <= 3 mismatch positions off the same words.
+//         * the correction walk reads the <= 3 mismatch positions off the same words, in 2-bit codes.
 //   exactness: bytes outside {A,C,G,T,N}, reads longer than 16*NW, reads shorter than the 16-base
-//       prefix, barcodes, and the one adapter-trim corner case that needs a second scan are not
-//       handled here: the lane DEFERS its pair and the wave runs the fully general generation-1
-//       pipeline (process_record_wave) for it afterwards, in the same launch.  Results are
+//       prefix, and the adapter-trim / walk-anchor corner cases that need a second scan are not
+//       handled here: the lane DEFERS its pair to a device queue and filter_overlap_list_kernel runs the fully
+//       general wave-per-record pipeline (process_record_wave) for it right behind this kernel.  Results are
 //       bit-identical either way; only the speed differs.
 //
 // Input is the batch exactly as it sits in HBM (DevBatch): byte arenas + 32-bit byte offsets + lengths — the raw FASTQ
-// text chunk addressed in place, or the caller's packed SoA arenas.  Nothing is copied or re-laid-out first: a lane loads
-// its 16-byte chunk with ONE global_load_dwordx4 at whatever alignment the read happens to have (gfx950 serves unaligned
-// vector loads; the ten lanes of a read still cover 160 contiguous bytes), replaces the bytes beyond the read's length
-// by the pad symbol with one v_bfi per dword (mask from a 17-entry LDS table) and validates the alphabet on the fly
-// (v_perm round trip; a record with any other byte is deferred).  Generation 2 needed a separate canonicalisation pass
-// (read 3.0 GB + write 3.2 GB per 5 M pairs, 2.8x the time of this kernel) for the same effect.
+// text chunk addressed in place, or the caller's packed SoA arenas.  Nothing is copied or re-laid-out first: a lane
+// replaces the bytes outside the read by the pad symbols with one v_bfi per dword (mask from a 17-entry LDS table) and
+// validates the alphabet on the fly (v_perm round trip; a record with any other byte is deferred).  Generation 2 needed a
+// separate canonicalisation pass (read 3.0 GB + write 3.2 GB per 5 M pairs, 2.8x the time of this kernel) for that.
 #pragma once
 #include "aqc_kernels.hpp"
 

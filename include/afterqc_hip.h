@@ -129,7 +129,7 @@ typedef struct aqc_config {
  * carry the integers the reference parses out of the R1 name (preprocesser.py:180-192);
  * aux_ok[i] == 0 means the name did not match the pattern (-> not in a bubble). */
 typedef struct aqc_batch {
-    uint64_t n;                 /* records */
+    uint64_t n;                 /* records (< 2^31 per batch) */
     uint64_t first_index;       /* 0-based global index of record 0 (TOTAL_READS - 1 of preprocesser.py:433) */
     const uint8_t* seq1;
     const uint8_t* qual1;
