@@ -347,6 +347,18 @@ def load_library():
     lib.aqc_source_read.restype = C.c_int64
     lib.aqc_source_close.argtypes = [P]
     lib.aqc_source_close.restype = None
+    lib.aqc_source_open2.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_uint64]
+    lib.aqc_source_open2.restype = P
+    lib.aqc_source_error.argtypes = [P]
+    lib.aqc_source_error.restype = C.c_char_p
+    lib.aqc_source_gz_stats.argtypes = [P, C.POINTER(C.c_uint64 * 4)]
+    lib.aqc_source_gz_stats.restype = C.c_int
+    lib.aqc_gz_deflate_block.argtypes = [P, C.c_uint64, C.c_int32, P, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.aqc_gz_deflate_block.restype = C.c_int
+    lib.aqc_gz_inflate_raw.argtypes = [P, C.c_uint64, P, C.c_uint64]
+    lib.aqc_gz_inflate_raw.restype = C.c_int64
+    lib.aqc_gz_crc32.argtypes = [C.c_uint32, P, C.c_uint64]
+    lib.aqc_gz_crc32.restype = C.c_uint32
     lib.aqc_host_count_newlines.argtypes = [P, C.c_uint64]
     lib.aqc_host_count_newlines.restype = C.c_uint64
     lib.aqc_bgzf_compress.argtypes = [P, C.c_uint64, C.c_int32, P, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -379,7 +391,8 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_last_error", "aq
                     "aqc_host_free",
                     "aqc_pipe_create", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
                     "aqc_host_count_newlines", "aqc_bgzf_compress", "aqc_pipe_split",
-                    "aqc_source_open", "aqc_source_read", "aqc_source_close",
+                    "aqc_source_open", "aqc_source_open2", "aqc_source_read", "aqc_source_error", "aqc_source_gz_stats", "aqc_source_close",
+                    "aqc_gz_deflate_block", "aqc_gz_inflate_raw", "aqc_gz_crc32",
                     # the reference's own native seam (editdistance/_editdistance.h:16,23), same names and signatures
                     "edit_distance", "seek_overlap"]
 
@@ -629,11 +642,18 @@ class NativeSource:
     """A read file as a binary stream with readinto() — the pipe's readers behind Python's file protocol (parallel pread,
     member-parallel BGZF inflate): what afterqc_amd.fastq.open_binary hands out for plain and .gz files."""
 
-    def __init__(self, path, gzip_in):
+    def __init__(self, path, gzip_in, io_threads=0, gz_section_bytes=0):
         self.lib = load_library()
-        self.h = self.lib.aqc_source_open(path.encode() if isinstance(path, str) else path, 1 if gzip_in else 0, 0)
+        self.h = self.lib.aqc_source_open2(path.encode() if isinstance(path, str) else path, 1 if gzip_in else 0, int(io_threads),
+                                           int(gz_section_bytes))
         if not self.h:
             raise IOError("cannot open " + str(path))
+
+    def gz_stats(self):
+        """(sections accepted, sections discarded, bytes decoded sequentially, bytes out) of the parallel gunzip"""
+        out = (C.c_uint64 * 4)()
+        self.lib.aqc_source_gz_stats(self.h, C.byref(out))
+        return tuple(int(x) for x in out)
 
     def readinto(self, view):
         mv = memoryview(view)
@@ -643,7 +663,7 @@ class NativeSource:
         arr = np.frombuffer(mv, dtype=np.uint8)
         got = self.lib.aqc_source_read(self.h, arr.ctypes.data, n)
         if got < 0:
-            raise IOError("read error (corrupt gzip data?)")
+            raise IOError((self.lib.aqc_source_error(self.h) or b"read error").decode("utf-8", "replace"))
         return int(got)
 
     def read(self, n=-1):

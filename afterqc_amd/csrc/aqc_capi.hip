@@ -884,7 +884,8 @@ int aqc_fetch_text(aqc_ctx* c, int slot, int file, int stream, uint8_t* dst, uin
 
 void* aqc_host_alloc(uint64_t bytes) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    // portable: the rings are filled by reader threads under whichever device is current and DMA-ed from by any context
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
     return p;
 }
 

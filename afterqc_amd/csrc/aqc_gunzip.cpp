@@ -1,0 +1,438 @@
+// aqc_gunzip.cpp — ParallelGunzip: one gzip stream decoded by many threads, exactly (see aqc_gz.hpp for the idea).
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+
+#include "aqc_gz.hpp"
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+namespace aqcgz {
+
+namespace {
+
+// symbols -> bytes: literals pass, a marker j is byte j of the (right-aligned) 32 KiB window before the section; markers
+// below valid_from point before the start of the member: corrupt data.  Returns false on such a marker.
+bool translate_generic(const uint16_t* s, size_t n, uint8_t* d, const uint8_t* win, size_t valid_from) {
+    bool ok = true;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t v = s[i];
+        if (v < MARKER) d[i] = (uint8_t)v;
+        else {
+            const uint32_t j = v & 0x7fffu;
+            if (j < valid_from) ok = false;
+            d[i] = win[j];
+        }
+    }
+    return ok;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) bool translate_avx2(const uint16_t* s, size_t n, uint8_t* d, const uint8_t* win, size_t valid_from) {
+    bool ok = true;
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const __m256i a = _mm256_loadu_si256((const __m256i*)(s + i)), b = _mm256_loadu_si256((const __m256i*)(s + i + 16));
+        if (_mm256_movemask_epi8(_mm256_or_si256(a, b)) & 0xAAAAAAAAu) {
+            ok &= translate_generic(s + i, 32, d + i, win, valid_from);
+        } else {
+            const __m256i p = _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8);
+            _mm256_storeu_si256((__m256i*)(d + i), p);
+        }
+    }
+    ok &= translate_generic(s + i, n - i, d + i, win, valid_from);
+    return ok;
+}
+#endif
+
+bool translate(const uint16_t* s, size_t n, uint8_t* d, const uint8_t* win, size_t valid_from) {
+#if defined(__x86_64__)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx2) return translate_avx2(s, n, d, win, valid_from);
+#endif
+    return translate_generic(s, n, d, win, valid_from);
+}
+
+struct Event {
+    int kind;            // 0: piece of output (crc over len bytes), 1: end of a member (expected crc / isize)
+    uint32_t crc;
+    uint64_t len;
+};
+
+constexpr size_t BRIDGE_CAP = 1u << 20;
+
+}  // namespace
+
+struct ParallelGunzip::Shared {
+    std::mutex mu;
+    std::condition_variable cv;
+    int pending = 0;                            // translation tasks in flight
+    bool marker_error = false;
+    std::vector<std::vector<uint16_t>> free_bufs;
+    std::deque<Event> events;                   // in commit order (filled by the consumer; piece CRCs by the tasks)
+    size_t events_base = 0;                     // absolute index of events.front()
+};
+
+struct ParallelGunzip::Section {
+    size_t index = 0;
+    bool known_start = false;
+    uint64_t nominal_bit = 0, start_bit = 0, stop_bit = 0;
+    bool done = false, found = false, error = false, hit_eof = false;
+    uint64_t end_bit = 0;
+    std::vector<uint16_t> buf;
+    size_t n_out = 0;
+    struct MemberEnd { size_t out_pos; uint32_t crc, isize; };
+    std::vector<MemberEnd> ends;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::shared_ptr<Shared> sh;
+    ~Section() {
+        if (sh && !buf.empty()) {
+            std::lock_guard<std::mutex> g(sh->mu);
+            if (sh->free_bufs.size() < 256) sh->free_bufs.push_back(std::move(buf));
+        }
+    }
+};
+
+namespace {
+
+void run_section(const uint8_t* data, size_t size, const std::shared_ptr<ParallelGunzip::Section>& sp);
+
+}  // namespace
+
+ParallelGunzip::ParallelGunzip(const uint8_t* data, size_t size, aqc_host::Pool* pool, int inflight, size_t section_bytes)
+    : data_(data), size_(size), pool_(pool), inflight_(inflight < 1 ? 1 : inflight), section_bytes_(section_bytes < (64u << 10) ? (64u << 10) : section_bytes),
+      sh_(new Shared()) {}
+
+ParallelGunzip::~ParallelGunzip() {
+    // speculative sections still running hold their own references; wait for them (they read data_)
+    for (auto& s : q_) {
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv.wait(lk, [&] { return s->done; });
+    }
+    std::unique_lock<std::mutex> lk(sh_->mu);
+    sh_->cv.wait(lk, [&] { return sh_->pending == 0; });
+}
+
+void ParallelGunzip::fail(const char* what) {
+    if (!bad_) snprintf(err_, sizeof(err_), "%s", what);
+    bad_ = true;
+}
+
+namespace {
+
+void section_body(const uint8_t* data, size_t size, ParallelGunzip::Section& s) {
+    uint64_t start = s.start_bit;
+    if (!s.known_start) {
+        start = find_block_start(data, size, s.nominal_bit, s.stop_bit);
+        if (start == UINT64_MAX) return;
+    }
+    s.start_bit = start;
+    s.found = true;
+    std::unique_ptr<Inflater<uint16_t>> inf(new Inflater<uint16_t>());
+    if (s.sh) {
+        std::lock_guard<std::mutex> g(s.sh->mu);
+        if (!s.sh->free_bufs.empty()) { s.buf = std::move(s.sh->free_bufs.back()); s.sh->free_bufs.pop_back(); }
+    }
+    const size_t span = (size_t)((std::min<uint64_t>(s.stop_bit, (uint64_t)size * 8) - std::min<uint64_t>(start, (uint64_t)size * 8)) >> 3);
+    size_t cap = span * 4 + (256u << 10);
+    if (s.buf.size() < WINDOW + cap + 512) {
+        const bool fresh = s.buf.size() < WINDOW;
+        s.buf.resize(WINDOW + cap + 512);
+        if (fresh) for (size_t j = 0; j < WINDOW; ++j) s.buf[j] = (uint16_t)(MARKER | j);
+    } else cap = s.buf.size() - WINDOW - 512;
+    inf->reset(data, size, start);
+    inf->out = s.buf.data() + WINDOW; inf->out_pos = 0; inf->out_cap = cap; inf->hist = WINDOW;
+    size_t base_off = 0;            // symbols of earlier members of this section (a new member has no history at all)
+    for (;;) {
+        const int rc = inf->run(s.stop_bit);
+        if (rc == GZ_NEED_OUTPUT) {
+            cap = cap + cap / 2 + (1u << 20);
+            s.buf.resize(WINDOW + cap + 512);
+            inf->out = s.buf.data() + WINDOW + base_off; inf->out_cap = cap - base_off;
+            continue;
+        }
+        if (rc == GZ_STOPPED) { s.end_bit = inf->bitpos; break; }
+        if (rc == GZ_FINAL) {
+            const size_t byte = (size_t)((inf->bitpos + 7) >> 3);
+            if (byte + 8 > size) { s.error = true; break; }
+            uint32_t crc, isz;
+            memcpy(&crc, data + byte, 4); memcpy(&isz, data + byte + 4, 4);
+            base_off += inf->out_pos;
+            s.ends.push_back({base_off, crc, isz});
+            size_t p = byte + 8;
+            while (p < size && data[p] == 0) ++p;
+            if (p >= size) { s.hit_eof = true; s.end_bit = (uint64_t)size * 8; inf->out_pos = 0; break; }
+            const size_t h = parse_gzip_header(data, size, p);
+            if (!h) { s.error = true; inf->out_pos = 0; break; }
+            // the next member starts with no history: distances reaching before it are errors, no marker can appear in it
+            inf->reset(data, size, (uint64_t)h * 8);
+            inf->out = s.buf.data() + WINDOW + base_off; inf->out_pos = 0; inf->out_cap = cap - base_off; inf->hist = 0;
+            continue;
+        }
+        s.error = true;
+        break;
+    }
+    s.n_out = base_off + inf->out_pos;
+}
+
+void run_section(const uint8_t* data, size_t size, const std::shared_ptr<ParallelGunzip::Section>& sp) {
+    section_body(data, size, *sp);
+    {
+        std::lock_guard<std::mutex> g(sp->mu);
+        sp->done = true;
+    }
+    sp->cv.notify_all();
+}
+
+}  // namespace
+
+void ParallelGunzip::top_up() {
+    while ((int)q_.size() < inflight_) {
+        std::shared_ptr<Section> s;
+        if (!started_) {
+            started_ = true;
+            s.reset(new Section());
+            s->index = 0;
+            s->known_start = true;
+            s->start_bit = cur_bit_;
+            s->nominal_bit = cur_bit_;
+            next_section_ = (size_t)((cur_bit_ >> 3) / section_bytes_) + 1;
+        } else {
+            const uint64_t nominal = (uint64_t)next_section_ * section_bytes_;
+            if (nominal + 64 >= size_) return;
+            if (nominal * 8 <= cur_bit_) { ++next_section_; continue; }
+            s.reset(new Section());
+            s->index = next_section_++;
+            s->nominal_bit = nominal * 8;
+        }
+        const uint64_t next_nominal = (uint64_t)next_section_ * section_bytes_;
+        s->stop_bit = next_nominal + 64 >= size_ ? UINT64_MAX : next_nominal * 8;
+        s->sh = sh_;
+        q_.push_back(s);
+        const uint8_t* data = data_;
+        const size_t size = size_;
+        if (pool_) pool_->submit([data, size, s] { run_section(data, size, s); }, true);
+        else run_section(data, size, s);
+    }
+}
+
+void ParallelGunzip::push_window(const uint8_t* p, size_t n) {
+    if (n >= WINDOW) { window_.assign(p + n - WINDOW, p + n); return; }
+    if (window_.size() + n > WINDOW) window_.erase(window_.begin(), window_.begin() + (window_.size() + n - WINDOW));
+    window_.insert(window_.end(), p, p + n);
+}
+
+void ParallelGunzip::emit(const uint8_t* p, size_t n, uint8_t* dst, size_t& out, size_t want) {
+    const size_t k = std::min(n, want - out);
+    if (k) memcpy(dst + out, p, k);
+    out += k;
+    if (k < n) spill_.insert(spill_.end(), p + k, p + n);
+}
+
+bool ParallelGunzip::member_end(uint64_t& bit) {
+    const size_t byte = (size_t)((bit + 7) >> 3);
+    if (byte + 8 > size_) { fail("gzip stream ends before its trailer (truncated file)"); return false; }
+    uint32_t crc, isz;
+    memcpy(&crc, data_ + byte, 4); memcpy(&isz, data_ + byte + 4, 4);
+    {
+        std::lock_guard<std::mutex> g(sh_->mu);
+        sh_->events.push_back(Event{1, crc, isz});
+    }
+    size_t p = byte + 8;
+    while (p < size_ && data_[p] == 0) ++p;
+    if (p >= size_) return false;
+    const size_t h = parse_gzip_header(data_, size_, p);
+    if (!h) { fail("data behind the gzip member is not a gzip member"); return false; }
+    bit = (uint64_t)h * 8;
+    return true;
+}
+
+// fold the finished events, in order, into the running member CRC; wait_all: wait for every translation task first
+void ParallelGunzip::drain_events(bool wait_all) {
+    std::unique_lock<std::mutex> lk(sh_->mu);
+    if (wait_all) sh_->cv.wait(lk, [&] { return sh_->pending == 0; });
+    if (sh_->pending != 0) return;
+    if (sh_->marker_error) fail("corrupt gzip data: a back-reference reaches before the start of its member");
+    while (!sh_->events.empty()) {
+        const Event e = sh_->events.front();
+        sh_->events.pop_front();
+        sh_->events_base++;
+        if (e.kind == 0) {
+            crc_ = isize_ == 0 ? e.crc : crc32_combine_fast(crc_, e.crc, e.len);
+            isize_ += e.len;
+        } else {
+            if (crc_ != e.crc || (uint32_t)isize_ != (uint32_t)e.len) fail("gzip member fails its CRC-32 / length check");
+            crc_ = 0;
+            isize_ = 0;
+        }
+    }
+}
+
+void ParallelGunzip::accept(Section& s, uint8_t* dst, size_t& out, size_t want) {
+    const uint16_t* sym = s.buf.data() + WINDOW;
+    const size_t n = s.n_out;
+    const size_t to_dst = std::min(n, want - out);
+    // (the spill buffer is empty here: read() serves it before anything else)
+    spill_.resize(n - to_dst);
+    spill_lo_ = 0;
+    uint8_t* const d0 = dst + out;
+    size_t pos = 0;
+    std::shared_ptr<Section> keep;
+    for (auto& q : q_) if (q.get() == &s) keep = q;
+    for (size_t me = 0; me <= s.ends.size(); ++me) {
+        const size_t seg_end = me < s.ends.size() ? s.ends[me].out_pos : n;
+        if (seg_end > pos) {
+            // window of this segment: the consumer's for the part that continues the member, none behind a member start
+            std::shared_ptr<std::vector<uint8_t>> win(new std::vector<uint8_t>(WINDOW, 0));
+            const size_t wl = window_.size();
+            if (wl) memcpy(win->data() + WINDOW - wl, window_.data(), wl);
+            const size_t valid_from = WINDOW - wl;
+            // the window behind this segment: its last <= 32 KiB, resolved here (cheap) so that the next section can go on
+            {
+                const size_t tail = std::min<size_t>(seg_end - pos, WINDOW);
+                uint8_t tmp[WINDOW];
+                if (!translate(sym + seg_end - tail, tail, tmp, win->data(), valid_from)) {
+                    std::lock_guard<std::mutex> g(sh_->mu);
+                    sh_->marker_error = true;
+                }
+                push_window(tmp, tail);
+            }
+            const size_t PIECE = 1u << 19;
+            for (size_t a = pos; a < seg_end;) {
+                size_t b = std::min(seg_end, a + PIECE);
+                if (a < to_dst && b > to_dst) b = to_dst;          // a piece lies wholly in dst or wholly in the spill buffer
+                uint8_t* const d = a < to_dst ? d0 + a : spill_.data() + (a - to_dst);
+                size_t ev;
+                {
+                    std::lock_guard<std::mutex> g(sh_->mu);
+                    sh_->events.push_back(Event{0, 0u, (uint64_t)(b - a)});
+                    ev = sh_->events_base + sh_->events.size() - 1;
+                    sh_->pending++;
+                }
+                std::shared_ptr<Shared> sh = sh_;
+                const uint16_t* src = sym + a;
+                const size_t len = b - a;
+                auto job = [sh, keep, win, src, len, d, valid_from, ev] {
+                    const bool ok = translate(src, len, d, win->data(), valid_from);
+                    const uint32_t c = crc32_fast(0u, d, len);
+                    std::lock_guard<std::mutex> g(sh->mu);
+                    if (!ok) sh->marker_error = true;
+                    sh->events[ev - sh->events_base].crc = c;
+                    if (--sh->pending == 0) sh->cv.notify_all();
+                };
+                if (pool_) pool_->submit(job, false);
+                else job();
+                a = b;
+            }
+        }
+        if (me < s.ends.size()) {
+            std::lock_guard<std::mutex> g(sh_->mu);
+            sh_->events.push_back(Event{1, s.ends[me].crc, (uint64_t)s.ends[me].isize});
+            window_.clear();
+        }
+        pos = seg_end;
+    }
+    out += to_dst;
+    total_out += n;
+    cur_bit_ = s.end_bit;
+    if (s.hit_eof) done_ = true;
+    sections_accepted++;
+}
+
+// sequential decoding from cur_bit_ with the window known, one buffer-full per call, until a block boundary at or behind
+// `until_bit` (what could not be taken from the speculative sections: a gap before a section's start, a section that did
+// not chain up, the whole stream when no block start is recognised)
+void ParallelGunzip::bridge(uint64_t until_bit, uint8_t* dst, size_t& out, size_t want) {
+    if (!bridge_state_) bridge_state_.reset(new BridgeState());
+    BridgeState& B = *bridge_state_;
+    if (bridge_buf_.empty()) bridge_buf_.resize(WINDOW + BRIDGE_CAP + 512);
+    uint8_t* const base = bridge_buf_.data() + WINDOW;
+    if (!B.active) {
+        const size_t wl = window_.size();
+        if (wl) memcpy(base - wl, window_.data(), wl);
+        B.inf.reset(data_, size_, cur_bit_);
+        B.inf.out = base; B.inf.out_pos = 0; B.inf.out_cap = BRIDGE_CAP; B.inf.hist = wl;
+        B.active = true;
+        B.until = until_bit;
+    }
+    const int rc = B.inf.run(B.until);
+    const size_t n = B.inf.out_pos;
+    if (n) {
+        const uint32_t c = crc32_fast(0u, base, n);
+        {
+            std::lock_guard<std::mutex> g(sh_->mu);
+            sh_->events.push_back(Event{0, c, (uint64_t)n});
+        }
+        emit(base, n, dst, out, want);
+        push_window(base, n);
+        bridged_bytes += n;
+        total_out += n;
+        // keep the last 32 KiB as history in front of the buffer
+        const size_t keep = std::min<size_t>(WINDOW, B.inf.hist + n);
+        memmove(base - keep, base + n - keep, keep);
+        B.inf.hist = keep;
+        B.inf.out_pos = 0;
+    }
+    if (rc == GZ_NEED_OUTPUT) return;
+    if (rc == GZ_STOPPED) { cur_bit_ = B.inf.bitpos; B.active = false; return; }
+    if (rc == GZ_FINAL) {
+        uint64_t bit = B.inf.bitpos;
+        B.active = false;
+        window_.clear();
+        if (!member_end(bit)) { done_ = true; return; }
+        cur_bit_ = bit;
+        return;
+    }
+    B.active = false;
+    fail("corrupt or truncated gzip data");
+}
+
+size_t ParallelGunzip::read(uint8_t* dst, size_t want) {
+    size_t out = 0;
+    if (spill_lo_ < spill_.size()) {
+        const size_t k = std::min(want, spill_.size() - spill_lo_);
+        memcpy(dst, spill_.data() + spill_lo_, k);
+        spill_lo_ += k;
+        out = k;
+        if (spill_lo_ == spill_.size()) { spill_.clear(); spill_lo_ = 0; }
+        if (out == want) return out;
+    }
+    if (!started_ && !bad_ && !done_) {
+        if (size_ == 0) done_ = true;
+        else {
+            const size_t h = parse_gzip_header(data_, size_, 0);
+            if (!h) fail("not a gzip file");
+            cur_bit_ = (uint64_t)h * 8;
+        }
+    }
+    while (out < want && !bad_ && !done_) {
+        if (bridge_state_ && bridge_state_->active) { bridge(0, dst, out, want); continue; }
+        top_up();
+        if (q_.empty()) { bridge(UINT64_MAX, dst, out, want); continue; }
+        std::shared_ptr<Section> f = q_.front();
+        {
+            std::unique_lock<std::mutex> lk(f->mu);
+            f->cv.wait(lk, [&] { return f->done; });
+        }
+        const bool usable = f->found && !f->error;
+        if (usable && f->start_bit == cur_bit_) {
+            accept(*f, dst, out, want);
+            q_.erase(q_.begin());
+        } else if (usable && f->start_bit > cur_bit_) {
+            bridge(f->start_bit, dst, out, want);
+        } else {
+            q_.erase(q_.begin());
+            sections_discarded++;
+        }
+    }
+    drain_events(true);
+    if (bad_) return 0;
+    return out;
+}
+
+}  // namespace aqcgz

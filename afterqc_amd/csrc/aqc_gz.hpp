@@ -1,0 +1,131 @@
+// aqc_gz.hpp — the pipe's own gzip codec (host code): what fastq.py:23-24,65-68 gets from Python's gzip module upstream.
+//
+//   inflate   a table-driven DEFLATE decoder (RFC 1951: 11-bit litlen / 8-bit distance root tables + subtables, 64-bit
+//             bit buffer, several literals per refill) in two output flavours: bytes (window known) and 16-bit SYMBOLS, where
+//             a value >= 0x8000 stands for "byte j of the 32 KiB window before my start" — so a thread can start in the
+//             MIDDLE of a single-member stream, at a block boundary it found by itself, long before that window is known.
+//   ParallelGunzip   cuts one gzip stream into sections, decodes them speculatively on the pool in symbol form, and commits
+//             them in order: a section counts only if it begins at the very bit its predecessor ended on (decoding is
+//             deterministic from a block boundary, so that makes the result exact); its markers are then resolved against the
+//             real window.  Anything that does not chain up is decoded again sequentially from the last good bit.
+//             Member CRC-32 / ISIZE trailers are verified; a stream that ends early or fails its CRC is an error.
+//   deflate   aqc_deflate.cpp: one-pass greedy LZ77 (cost-gated matches) + dynamic Huffman, one block per call.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "aqc_pool.hpp"
+
+namespace aqcgz {
+
+enum { GZ_OK = 0, GZ_ERR_DATA = -1, GZ_NEED_OUTPUT = 1, GZ_STOPPED = 2, GZ_FINAL = 3 };
+
+constexpr int LIT_ROOT = 11, DIST_ROOT = 8;
+constexpr int LIT_TABLE = (1 << LIT_ROOT) + 2048, DIST_TABLE = (1 << DIST_ROOT) + 1024;
+constexpr uint32_t MARKER = 0x8000u;
+constexpr size_t WINDOW = 32768;
+
+// One DEFLATE stream position + the tables of the block it is in.  OutT = uint8_t (bytes) or uint16_t (symbols, see above).
+// run() decodes whole blocks and may be resumed after GZ_NEED_OUTPUT with a bigger / emptied output buffer: out[0 .. out_pos)
+// is what has been produced, out[-hist .. 0) is readable history (the window, or the marker prefix).
+template <typename OutT>
+struct Inflater {
+    const uint8_t* in = nullptr;
+    size_t in_size = 0;
+    uint64_t bitpos = 0;          // absolute bit position in `in`
+    OutT* out = nullptr;
+    size_t out_pos = 0, out_cap = 0;
+    size_t hist = 0;              // elements readable before out[0]
+    // block state
+    int in_block = 0;             // 0 between blocks, 1 stored, 2 huffman
+    bool bfinal = false, final_done = false;
+    uint32_t stored_left = 0;
+    uint64_t blocks = 0;          // blocks completed
+    uint32_t lit[LIT_TABLE];
+    uint32_t dist[DIST_TABLE];
+
+    void reset(const uint8_t* data, size_t size, uint64_t bit) {
+        in = data; in_size = size; bitpos = bit; in_block = 0; bfinal = false; final_done = false; stored_left = 0; blocks = 0;
+    }
+    // decode until: the final block has ended (GZ_FINAL); a block boundary at or behind stop_bit is reached (GZ_STOPPED);
+    // the output is (nearly) full (GZ_NEED_OUTPUT); the data is invalid or ends early (GZ_ERR_DATA)
+    int run(uint64_t stop_bit);
+
+private:
+    int read_header();
+    int decode_huffman();
+};
+
+// gzip member header at data[pos]: returns the offset of the deflate data, 0 on a malformed / truncated header
+size_t parse_gzip_header(const uint8_t* data, size_t size, size_t pos);
+
+// first bit position in [from_bit, to_bit) at which a non-final dynamic-Huffman block plausibly begins: complete code-length
+// / litlen / distance codes, the whole block decodes, its literals are text (FASTQ is) and a sane block header follows.
+// UINT64_MAX when none.  False positives are harmless (see ParallelGunzip), they only cost time.
+uint64_t find_block_start(const uint8_t* data, size_t size, uint64_t from_bit, uint64_t to_bit);
+
+// whole raw-deflate stream with no history into exactly `cap` bytes (BGZF members): returns bytes written or -1
+int64_t inflate_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+
+uint32_t crc32_fast(uint32_t crc, const uint8_t* p, size_t n);
+uint32_t crc32_combine_fast(uint32_t crc1, uint32_t crc2, uint64_t len2);
+
+class ParallelGunzip {
+public:
+    // data: the whole compressed file (mapped); sections of `section_bytes` compressed bytes, at most `inflight` at a time
+    ParallelGunzip(const uint8_t* data, size_t size, aqc_host::Pool* pool, int inflight, size_t section_bytes);
+    ~ParallelGunzip();
+    size_t read(uint8_t* dst, size_t want);
+    bool failed() const { return bad_; }
+    const char* error() const { return err_; }
+    // statistics
+    uint64_t sections_accepted = 0, sections_discarded = 0, bridged_bytes = 0, total_out = 0;
+
+    struct Section;
+    struct Shared;
+
+private:
+    struct BridgeState {
+        Inflater<uint8_t> inf;
+        bool active = false;
+        uint64_t until = 0;
+    };
+    void top_up();
+    void accept(Section& s, uint8_t* dst, size_t& out, size_t want);
+    void bridge(uint64_t until_bit, uint8_t* dst, size_t& out, size_t want);
+    void emit(const uint8_t* p, size_t n, uint8_t* dst, size_t& out, size_t want);
+    bool member_end(uint64_t& bit);      // trailer + next header at byte-aligned `bit`; false: no further member
+    void push_window(const uint8_t* p, size_t n);
+    void drain_events(bool wait_all);
+    void fail(const char* what);
+
+    const uint8_t* data_;
+    size_t size_;
+    aqc_host::Pool* pool_;
+    int inflight_;
+    size_t section_bytes_;
+    std::shared_ptr<Shared> sh_;
+    std::vector<std::shared_ptr<Section>> q_;       // in flight, by nominal start
+    size_t next_section_ = 0;                      // next section index to launch (nominal start = index * section_bytes)
+    uint64_t cur_bit_ = 0;                         // everything before this bit is decoded and committed
+    bool started_ = false, done_ = false, bad_ = false;
+    char err_[160] = "";
+    std::vector<uint8_t> window_;                  // last <= 32 KiB of the current member's output
+    std::vector<uint8_t> spill_;
+    size_t spill_lo_ = 0;
+    std::vector<uint8_t> bridge_buf_;
+    std::unique_ptr<BridgeState> bridge_state_;
+    // running CRC-32 / size of the current member, folded in commit order
+    uint32_t crc_ = 0;
+    uint64_t isize_ = 0;
+};
+
+// ---- deflate (aqc_deflate.cpp) -------------------------------------------------------------------------------------------
+// one complete raw DEFLATE stream (a single final block, or stored blocks when that is smaller) for src[0, n), n <= 65535 * 4;
+// dst must hold deflate_bound(n) bytes; returns the bytes written.  level <= 0: stored.
+size_t deflate_bound(size_t n);
+size_t deflate_block(const uint8_t* src, size_t n, int level, uint8_t* dst);
+
+}  // namespace aqcgz

@@ -3,13 +3,16 @@
 //
 //   reader threads (one per input)   file / gzip stream / memory -> page-locked chunk buffers holding EXACTLY
 //                                    `chunk_records` records each (the chunk boundary is the 4K-th newline, found with
-//                                    per-block newline counts made by the I/O pool right behind the reads)
+//                                    per-block newline counts made by the pool thread that fetched the piece); a plain file
+//                                    is pread in parallel pieces, a .gz inflated by many threads (aqc_gunzip.cpp)
 //   slot workers (per GPU x slots)   chunk pair i -> context i % n_ctx: aqc_frame -> aqc_run -> aqc_qc_stat (first
 //                                    qc_sample records only, in chunk order) -> aqc_format -> aqc_fetch_text into
 //                                    page-locked output buffers; a worker blocks only on ITS slot's stream, so the
 //                                    upload of one chunk, the kernels of another and the download of a third overlap
-//   writer thread                    commits the chunks' good / bad / overlap streams in chunk order: plain files with
-//                                    parallel pwrite, .gz as BGZF-compatible independent members deflated on the pool
+//   orderer + one writer per file    the chunks' good / bad / overlap streams are committed in chunk order; every output
+//                                    file has its own thread issuing large sequential write()s (a file takes ~10 GB/s on the
+//                                    MI355X host whatever is done: tools/ubench/io_probe.cpp), .gz as BGZF-compatible
+//                                    independent members deflated on the pool (aqc_deflate.cpp)
 //
 // Records are independent and every statistic is additive (or min-merged by global record index), so one input is
 // dealt over any number of GPUs with no collective: chunk i carries first_index = i * chunk_records.
@@ -45,6 +48,8 @@
 #endif
 
 #include "../../include/afterqc_hip.h"
+#include "aqc_gz.hpp"
+#include "aqc_pool.hpp"
 
 namespace {
 
@@ -54,87 +59,7 @@ std::mutex g_pipe_err_mu;
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// ---------------------------------------------------------------------------------------------------------------
-// small thread pool for I/O-side work (pread pieces, newline counts, deflate / inflate of independent blocks)
-// ---------------------------------------------------------------------------------------------------------------
-class Pool {
-public:
-    explicit Pool(int n) {
-        for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
-    }
-    ~Pool() {
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto& t : th_) t.join();
-    }
-    // run fn(i) for i in [0, n) on the pool and wait for all of them
-    void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
-        if (n == 0) return;
-        if (n == 1 || th_.empty()) {
-            for (size_t i = 0; i < n; ++i) fn(i);
-            return;
-        }
-        struct Batch {
-            std::atomic<size_t> next{0}, done{0};
-            size_t n;
-            const std::function<void(size_t)>* fn;
-            std::mutex mu;
-            std::condition_variable cv;
-        };
-        auto b = std::make_shared<Batch>();
-        b->n = n;
-        b->fn = &fn;
-        const size_t helpers = std::min(n, th_.size());
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            for (size_t k = 0; k < helpers; ++k)
-                q_.push_back([b] {
-                    for (;;) {
-                        const size_t i = b->next.fetch_add(1);
-                        if (i >= b->n) break;
-                        (*b->fn)(i);
-                        if (b->done.fetch_add(1) + 1 == b->n) {
-                            std::lock_guard<std::mutex> g2(b->mu);
-                            b->cv.notify_all();
-                        }
-                    }
-                });
-        }
-        cv_.notify_all();
-        // the caller works too
-        for (;;) {
-            const size_t i = b->next.fetch_add(1);
-            if (i >= n) break;
-            fn(i);
-            b->done.fetch_add(1);
-        }
-        std::unique_lock<std::mutex> lk(b->mu);
-        b->cv.wait(lk, [&] { return b->done.load() >= n; });
-    }
-
-private:
-    void loop() {
-        for (;;) {
-            std::function<void()> job;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
-                if (stop_ && q_.empty()) return;
-                job = std::move(q_.front());
-                q_.pop_front();
-            }
-            job();
-        }
-    }
-    std::vector<std::thread> th_;
-    std::deque<std::function<void()>> q_;
-    std::mutex mu_;
-    std::condition_variable cv_;
-    bool stop_ = false;
-};
+using aqc_host::Pool;      // aqc_pool.hpp: parallel_for (front lane) + submit (background lane for speculative work)
 
 template <class T>
 class BQueue {
@@ -245,13 +170,30 @@ struct Source {
     virtual ~Source() {}
     // fill dst[0, want) with the next bytes of the stream; returns the bytes delivered (< want only at the end)
     virtual size_t read(uint8_t* dst, size_t want) = 0;
+    // the same, into base[fill, fill + want), ALSO counting the newlines of every SUB-sized block of `base` the new bytes
+    // touch (cnt[b] = newlines in base[b * SUB, min((b + 1) * SUB, fill + got)); the block the old bytes end in is recounted)
+    virtual size_t read_counted(uint8_t* base, size_t fill, size_t want, std::vector<uint32_t>& cnt, Pool* pool) {
+        const size_t got = want ? read(base + fill, want) : 0;
+        count_blocks(base, fill, fill + got, cnt, pool);
+        return got;
+    }
     virtual bool failed() const { return false; }
+    virtual const char* why() const { return "read error"; }
+    static void count_blocks(const uint8_t* base, size_t from, size_t to, std::vector<uint32_t>& cnt, Pool* pool) {
+        const size_t nb = (to + SUB - 1) / SUB, b0 = std::min(nb, from / SUB);
+        cnt.resize(nb);
+        pool->parallel_for(nb - b0, [&](size_t i) {
+            const size_t o = (b0 + i) * SUB;
+            cnt[b0 + i] = (uint32_t)count_nl(base + o, std::min(SUB, to - o));
+        });
+    }
 };
 
 struct FileSource : Source {
     int fd = -1;
     uint64_t pos = 0, size = 0;
     Pool* pool;
+    bool bad = false;            // sticky: a failed pread is an error, never "end of file"
     FileSource(const char* path, Pool* p) : pool(p) {
         fd = open(path, O_RDONLY);
         if (fd >= 0) {
@@ -261,69 +203,195 @@ struct FileSource : Source {
         }
     }
     ~FileSource() override { if (fd >= 0) close(fd); }
-    bool failed() const override { return fd < 0; }
+    bool failed() const override { return fd < 0 || bad; }
     size_t read(uint8_t* dst, size_t want) override {
+        std::vector<uint32_t> none;
+        return read_impl(dst, 0, want, nullptr);
+    }
+    // the pieces are cut at multiples of 4 * SUB of `base`, so the thread that pread a piece counts its newlines while
+    // the bytes are still in its cache: one pass, one parallel_for
+    size_t read_counted(uint8_t* base, size_t fill, size_t want, std::vector<uint32_t>& cnt, Pool*) override {
+        return read_impl(base, fill, want, &cnt);
+    }
+    size_t read_impl(uint8_t* base, size_t fill, size_t want, std::vector<uint32_t>* cnt) {
         const uint64_t left = size > pos ? size - pos : 0;
         const size_t take = (size_t)std::min<uint64_t>(want, left);
-        const size_t piece = 4 << 20;
-        const size_t n = (take + piece - 1) / piece;
-        std::atomic<bool> bad{false};
-        pool->parallel_for(n, [&](size_t i) {
-            size_t off = i * piece;
-            const size_t end = std::min(take, off + piece);
-            while (off < end) {
-                const ssize_t got = pread(fd, dst + off, end - off, (off_t)(pos + off));
-                if (got <= 0) { bad = true; return; }
+        const size_t end = fill + take;
+        const size_t PIECE = 4 * SUB;
+        const size_t p0 = fill / PIECE, p1 = (end + PIECE - 1) / PIECE;
+        if (cnt) cnt->resize((end + SUB - 1) / SUB);
+        std::atomic<bool> err{false};
+        pool->parallel_for(p1 > p0 ? p1 - p0 : 0, [&](size_t k) {
+            const size_t lo = std::max(fill, (p0 + k) * PIECE), hi = std::min(end, (p0 + k + 1) * PIECE);
+            size_t off = lo;
+            while (off < hi) {
+                const ssize_t got = pread(fd, base + off, hi - off, (off_t)(pos + (off - fill)));
+                if (got <= 0) { err = true; return; }
                 off += (size_t)got;
             }
+            if (cnt)
+                for (size_t b = lo / SUB; b * SUB < hi; ++b) (*cnt)[b] = (uint32_t)count_nl(base + b * SUB, std::min(SUB, end - b * SUB));
         });
-        if (bad) return 0;
+        if (err) { bad = true; return 0; }
         pos += take;
         return take;
     }
 };
 
+// A gzip file (fastq.py:23-24 opens it with gzip.open upstream).  The file is mapped; then
+//   * members that carry the BGZF extra field ("BC": the member's compressed size) are located by walking the headers and
+//     inflated independently, in parallel;
+//   * anything else — one big member as gzip / pigz / Python write it, or members without sizes — goes through
+//     aqcgz::ParallelGunzip: speculative sections from block boundaries found in the middle of the stream, committed in order.
+// Every member's CRC-32 and length are checked; a file that ends inside a member is an error (gzip.open raises EOFError).
 struct GzSource : Source {
-    // a gzip stream.  Members that carry the BGZF extra field ("BC": the member's compressed size) are located by walking
-    // the headers and inflated in parallel on the pool; anything else goes through one sequential inflate stream.
     int fd = -1;
     Pool* pool;
-    std::vector<uint8_t> in;        // compressed window
+    const uint8_t* map = nullptr;
+    size_t size = 0;
+    bool bgzf = false, bad = false, mapped = false;
+    char err[200] = "";
+    std::unique_ptr<aqcgz::ParallelGunzip> pg;
+    // BGZF walk
+    size_t pos = 0;
+    std::vector<uint8_t> spill;
+    size_t spill_lo = 0;
+    // fallback for files that cannot be mapped (pipes): one zlib stream
+    std::vector<uint8_t> in;
     size_t in_lo = 0, in_hi = 0;
-    bool file_eof = false, stream_end = true, bgzf = false, bad = false;
+    bool file_eof = false, stream_end = true, any_in_member = false;
     z_stream zs{};
     bool zs_init = false;
-    std::vector<uint8_t> spill;     // inflated bytes that did not fit the caller's buffer (BGZF path)
-    size_t spill_lo = 0;
-    GzSource(const char* path, Pool* p) : pool(p) {
+
+    GzSource(const char* path, Pool* p, size_t section_bytes = 0) : pool(p) {
         fd = open(path, O_RDONLY);
-        in.resize(32 << 20);
-        if (fd >= 0) {
-            refill();
-            bgzf = is_bgzf_header(in.data() + in_lo, in_hi - in_lo);
+        if (fd < 0) return;
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+            size = (size_t)st.st_size;
+            if (size == 0) { mapped = true; return; }
+            void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                map = (const uint8_t*)m;
+                mapped = true;
+                (void)madvise(m, size, MADV_SEQUENTIAL);
+                bgzf = is_bgzf_header(map, size);
+                if (!bgzf) {
+                    const int threads = std::max(1, pool->size());
+                    const int inflight = std::max(4, std::min(threads + threads / 2, 96));
+                    size_t sec = section_bytes;
+                    if (!sec) {
+                        if (const char* e = getenv("AQC_GZ_SECTION")) sec = (size_t)atoll(e);
+                    }
+                    if (!sec) sec = std::min<size_t>(4u << 20, std::max<size_t>(256u << 10, size / (size_t)(4 * inflight)));
+                    pg.reset(new aqcgz::ParallelGunzip(map, size, pool, inflight, sec));
+                }
+                return;
+            }
         }
+        in.resize(8 << 20);
     }
     ~GzSource() override {
+        pg.reset();
+        if (map) munmap((void*)map, size);
         if (zs_init) inflateEnd(&zs);
         if (fd >= 0) close(fd);
     }
     bool failed() const override { return fd < 0 || bad; }
+    const char* why() const override { return err[0] ? err : "read error"; }
+    void fail(const char* what) { if (!bad) snprintf(err, sizeof(err), "%s", what); bad = true; }
     static bool is_bgzf_header(const uint8_t* h, size_t n) {
         return n >= 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[10] == 6 && h[11] == 0 && h[12] == 'B' && h[13] == 'C' &&
                h[14] == 2 && h[15] == 0;
     }
+    size_t read(uint8_t* dst, size_t want) override {
+        if (bad) return 0;
+        if (!mapped) return read_stream(dst, want);
+        if (size == 0) return 0;
+        if (bgzf) return read_bgzf(dst, want);
+        const size_t got = pg->read(dst, want);
+        if (pg->failed()) { fail(pg->error()); return 0; }
+        return got;
+    }
+
+    size_t read_bgzf(uint8_t* dst, size_t want) {
+        size_t out = 0;
+        if (spill_lo < spill.size()) {
+            const size_t k = std::min(want, spill.size() - spill_lo);
+            memcpy(dst, spill.data() + spill_lo, k);
+            spill_lo += k;
+            out = k;
+            if (spill_lo == spill.size()) { spill.clear(); spill_lo = 0; }
+        }
+        struct Blk { size_t coff, clen, isize, ooff; uint32_t crc; };
+        while (out < want && !bad && pos < size) {
+            // walk the members until they cover what is asked for
+            std::vector<Blk> blks;
+            size_t p = pos, total = 0;
+            bool foreign = false;
+            while (p < size && total < (want - out) + (1u << 20)) {
+                if (map[p] == 0) { size_t q = p; while (q < size && map[q] == 0) ++q; if (q == size) { p = size; break; } }
+                if (!is_bgzf_header(map + p, size - p)) { foreign = true; break; }
+                const size_t bsize = (size_t)(map[p + 16] | (map[p + 17] << 8)) + 1;
+                if (bsize < 26 || p + bsize > size) { fail("truncated BGZF member"); break; }
+                const uint8_t* t = map + p + bsize - 8;
+                uint32_t crc, isz;
+                memcpy(&crc, t, 4); memcpy(&isz, t + 4, 4);
+                blks.push_back(Blk{p + 18, bsize - 18 - 8, (size_t)isz, total, crc});
+                total += isz;
+                p += bsize;
+            }
+            if (bad) break;
+            if (blks.empty()) {
+                if (foreign) {
+                    // a member without the size field behind BGZF ones (cat of different writers): the general decoder takes over
+                    pg.reset(new aqcgz::ParallelGunzip(map + pos, size - pos, pool, std::max(4, pool->size()), 1u << 20));
+                    bgzf = false;
+                    const size_t got = pg->read(dst + out, want - out);
+                    if (pg->failed()) { fail(pg->error()); return 0; }
+                    return out + got;
+                }
+                pos = p;
+                break;
+            }
+            const size_t room = want - out;
+            size_t fit_total = 0;
+            for (auto& b : blks) if (b.ooff + b.isize <= room) fit_total = b.ooff + b.isize;
+            spill.assign(total - fit_total, 0);
+            spill_lo = 0;
+            std::atomic<bool> e{false};
+            uint8_t* const d0 = dst + out;
+            pool->parallel_for(blks.size(), [&](size_t i) {
+                const Blk& b = blks[i];
+                uint8_t* o = b.ooff + b.isize <= room ? d0 + b.ooff : spill.data() + (b.ooff - fit_total);
+                const int64_t got = aqcgz::inflate_raw(map + b.coff, b.clen, o, b.isize);
+                if (got != (int64_t)b.isize || aqcgz::crc32_fast(0u, o, b.isize) != b.crc) e = true;
+            });
+            if (e) { fail("corrupt BGZF member (inflate / CRC-32 / length)"); break; }
+            pos = p;
+            out += fit_total;
+            if (!spill.empty()) {
+                const size_t k = std::min(want - out, spill.size());
+                memcpy(dst + out, spill.data(), k);
+                spill_lo = k;
+                out += k;
+                if (spill_lo == spill.size()) { spill.clear(); spill_lo = 0; }
+            }
+        }
+        return bad ? 0 : out;
+    }
+
     void refill() {
         if (in_lo > 0 && in_lo < in_hi) memmove(in.data(), in.data() + in_lo, in_hi - in_lo);
         in_hi -= in_lo;
         in_lo = 0;
         while (!file_eof && in_hi < in.size()) {
             const ssize_t got = ::read(fd, in.data() + in_hi, in.size() - in_hi);
-            if (got <= 0) { file_eof = true; break; }
+            if (got < 0) { fail("read error"); file_eof = true; break; }
+            if (got == 0) { file_eof = true; break; }
             in_hi += (size_t)got;
         }
     }
-    size_t read(uint8_t* dst, size_t want) override { return bgzf ? read_bgzf(dst, want) : read_stream(dst, want); }
-
     size_t read_stream(uint8_t* dst, size_t want) {
         size_t out = 0;
         while (out < want && !bad) {
@@ -332,10 +400,12 @@ struct GzSource : Source {
                 if (in_lo == in_hi) break;          // end of the file
             }
             if (stream_end) {
-                // next member (concatenated members are one gzip file)
+                // next member (concatenated members are one gzip file); zero padding behind the last one is ignored
+                while (in_lo < in_hi && in[in_lo] == 0) ++in_lo;
+                if (in_lo == in_hi) continue;
                 if (zs_init) inflateEnd(&zs);
                 memset(&zs, 0, sizeof(zs));
-                if (inflateInit2(&zs, 15 + 16) != Z_OK) { bad = true; break; }
+                if (inflateInit2(&zs, 15 + 16) != Z_OK) { fail("inflateInit2 failed"); break; }
                 zs_init = true;
                 stream_end = false;
             }
@@ -344,90 +414,20 @@ struct GzSource : Source {
             zs.next_out = dst + out;
             zs.avail_out = (uInt)std::min<size_t>(want - out, 1u << 30);
             const uInt ai = zs.avail_in, ao = zs.avail_out;
-            const int rc = inflate(&zs, Z_NO_FLUSH);
+            const int rc = inflate(&zs, Z_NO_FLUSH);      // (zlib checks the member's CRC-32 / length itself)
             in_lo += ai - zs.avail_in;
             out += ao - zs.avail_out;
             if (rc == Z_STREAM_END) stream_end = true;
-            else if (rc != Z_OK && rc != Z_BUF_ERROR) { bad = true; break; }
+            else if (rc != Z_OK && rc != Z_BUF_ERROR) { fail("corrupt gzip data"); break; }
             else if (rc == Z_BUF_ERROR && ai == zs.avail_in && ao == zs.avail_out) {
                 if (file_eof && in_lo == in_hi) break;
                 refill();
                 if (in_lo == in_hi) break;
             }
         }
-        return out;
-    }
-
-    size_t read_bgzf(uint8_t* dst, size_t want) {
-        size_t out = 0;
-        // left-overs of the previous call first
-        if (spill_lo < spill.size()) {
-            const size_t k = std::min(want, spill.size() - spill_lo);
-            memcpy(dst, spill.data() + spill_lo, k);
-            spill_lo += k;
-            out = k;
-            if (spill_lo == spill.size()) { spill.clear(); spill_lo = 0; }
-        }
-        struct Blk { size_t coff, clen, isize, ooff; };
-        while (out < want && !bad) {
-            if (in_hi - in_lo < (64u << 10) + 32 && !file_eof) refill();
-            if (in_lo == in_hi) break;
-            // walk the members that are completely inside the window
-            std::vector<Blk> blks;
-            size_t p = in_lo, total = 0;
-            while (p + 18 <= in_hi) {
-                const uint8_t* h = in.data() + p;
-                if (!is_bgzf_header(h, in_hi - p)) { bad = true; break; }
-                const size_t bsize = (size_t)(h[16] | (h[17] << 8)) + 1;
-                if (p + bsize > in_hi) break;
-                const uint8_t* t = h + bsize - 4;
-                const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
-                blks.push_back(Blk{p + 18, bsize - 18 - 8, isize, total});
-                total += isize;
-                p += bsize;
-                if (total >= (want - out) + (1u << 20)) break;
-            }
-            if (bad) break;
-            if (blks.empty()) {
-                if (file_eof) { if (in_hi - in_lo > 0) bad = true; break; }
-                refill();
-                if (in_hi - in_lo < 18) break;
-                continue;
-            }
-            // inflate in parallel: straight into dst where the block fits, into the spill buffer otherwise
-            const size_t room = want - out;
-            size_t fit_total = 0;
-            for (auto& b : blks) if (b.ooff + b.isize <= room) fit_total = b.ooff + b.isize;
-            spill.assign(total - fit_total, 0);
-            spill_lo = 0;
-            std::atomic<bool> err{false};
-            pool->parallel_for(blks.size(), [&](size_t i) {
-                const Blk& b = blks[i];
-                uint8_t* o = b.ooff + b.isize <= room ? dst + out + b.ooff : spill.data() + (b.ooff - fit_total);
-                z_stream z{};
-                if (inflateInit2(&z, -15) != Z_OK) { err = true; return; }
-                z.next_in = in.data() + b.coff;
-                z.avail_in = (uInt)b.clen;
-                z.next_out = o;
-                z.avail_out = (uInt)b.isize;
-                const int rc = b.isize ? inflate(&z, Z_FINISH) : Z_STREAM_END;
-                if (rc != Z_STREAM_END || z.avail_out != 0) err = true;
-                inflateEnd(&z);
-            });
-            if (err) { bad = true; break; }
-            in_lo = p;
-            out += fit_total;
-            if (!spill.empty()) {
-                // the caller's buffer is filled to the last byte from the spill buffer; the rest waits for the next call
-                const size_t k = std::min(want - out, spill.size());
-                memcpy(dst + out, spill.data(), k);
-                spill_lo = k;
-                out += k;
-                if (spill_lo == spill.size()) { spill.clear(); spill_lo = 0; }
-                if (out == want) break;
-            }
-        }
-        return out;
+        // the file ended inside a member: gzip.open raises EOFError there, so do we
+        if (out < want && !bad && !stream_end && file_eof && in_lo == in_hi) fail("gzip stream ends before its trailer (truncated file)");
+        return bad ? 0 : out;
     }
 };
 
@@ -654,28 +654,18 @@ struct Run {
                 carry.clear();
                 std::vector<uint32_t> cnt;
                 uint64_t lines = 0;
-                size_t counted_blocks = 0;
+                if (fill) Source::count_blocks(hb.p, 0, fill, cnt, P->pool.get());      // the carried-over bytes
                 for (;;) {
                     if (!eof && fill < hb.cap) {
                         const size_t want = std::min(hb.cap, cap) - fill;
                         const uint64_t tr = now_ns();
-                        const size_t got = want ? src->read(hb.p + fill, want) : 0;
+                        // (bytes and their per-block newline counts in one go: the thread that fetched a piece counts it)
+                        const size_t got = want ? src->read_counted(hb.p, fill, want, cnt, P->pool.get()) : 0;
                         ns_read += now_ns() - tr;
-                        if (src->failed()) { fail(AQC_ERR_ARG, "read error on %s", io->in_path[f]); return; }
+                        if (src->failed()) { fail(AQC_ERR_ARG, "%s: %s", io->in_path[f], src->why()); return; }
                         if (got < want) eof = true;
                         fill += got;
                     }
-                    // count the new (and the previously partial) blocks
-                    const size_t nb = (fill + SUB - 1) / SUB;
-                    const size_t from = counted_blocks ? counted_blocks - 1 : 0;
-                    cnt.resize(nb);
-                    const uint64_t tcn = now_ns();
-                    P->pool->parallel_for(nb - from, [&](size_t i) {
-                        const size_t o = (from + i) * SUB;
-                        cnt[from + i] = (uint32_t)count_nl(hb.p + o, std::min(SUB, fill - o));
-                    });
-                    ns_count += now_ns() - tcn;
-                    counted_blocks = nb;
                     lines = 0;
                     for (auto v : cnt) lines += v;
                     if (lines >= want_lines || eof) break;
@@ -828,23 +818,16 @@ struct Run {
 
     // ---- writer: commit in chunk order ------------------------------------------------------------------------------------
     static void bgzf_block(const uint8_t* src, size_t n, int level, std::vector<uint8_t>& out) {
-        // one gzip member with the BGZF extra field (BC: total block size - 1); members concatenate into one valid .gz
-        out.resize(18 + compressBound((uLong)n) + 8);
-        z_stream z{};
-        deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
-        z.next_in = const_cast<uint8_t*>(src);
-        z.avail_in = (uInt)n;
-        z.next_out = out.data() + 18;
-        z.avail_out = (uInt)(out.size() - 18 - 8);
-        deflate(&z, Z_FINISH);
-        const size_t clen = z.total_out;
-        deflateEnd(&z);
+        // one gzip member with the BGZF extra field (BC: total block size - 1); members concatenate into one valid .gz.
+        // The deflate stream is the pipe's own (aqc_deflate.cpp); `--compression 0` stores.
+        out.resize(18 + aqcgz::deflate_bound(n) + 8);
+        const size_t clen = aqcgz::deflate_block(src, n, level, out.data() + 18);
         const size_t bsize = 18 + clen + 8;
         static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
         memcpy(out.data(), hdr, 16);
         out[16] = (uint8_t)((bsize - 1) & 0xff);
         out[17] = (uint8_t)((bsize - 1) >> 8);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n);
+        const uint32_t crc = aqcgz::crc32_fast(0u, src, n);
         uint8_t* t = out.data() + 18 + clen;
         for (int k = 0; k < 4; ++k) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)((uint32_t)n >> (8 * k)); }
         out.resize(bsize);
@@ -876,7 +859,7 @@ struct Run {
                 bool ok = true;
                 if (!io->gzip_out) ok = out[q].append(p, (size_t)oc.sizes[q]);
                 else {
-                    const size_t blk = 0xff00;                    // BGZF: at most 64 KiB of text per member
+                    const size_t blk = 0xff00;                    // BGZF: at most 64 KiB per member, headers included (stored: text + 31 bytes)
                     const size_t nb = (oc.sizes[q] + blk - 1) / blk;
                     std::vector<std::vector<uint8_t>> z(nb);
                     P->pool->parallel_for(nb, [&](size_t i) {
@@ -943,11 +926,12 @@ int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_
     p->ctx.assign(ctxs, ctxs + n_ctx);
     p->slots = slots_per_ctx;
     unsigned hc = std::thread::hardware_concurrency();
-    // default pool: a quarter of the machine's hardware threads, shared fairly when several ranks run on one node (torchrun
-    // exports LOCAL_WORLD_SIZE); gzip work (inflate / deflate of independent members) is what scales with it
+    // default pool: three eighths of the machine's hardware threads (96 on the 2 x 64-core MI355X hosts), shared fairly when
+    // several ranks run on one node (torchrun exports LOCAL_WORLD_SIZE); gzip work (speculative inflate sections, deflate of
+    // independent members) is what scales with it
     unsigned share = 1;
     if (const char* lw = getenv("LOCAL_WORLD_SIZE")) share = (unsigned)std::max(1, atoi(lw));
-    p->io_threads = io_threads > 0 ? io_threads : (int)std::min(64u, std::max(4u, hc / 4 / share));
+    p->io_threads = io_threads > 0 ? io_threads : (int)std::min(96u, std::max(4u, hc * 3 / 8 / share));
     p->pool.reset(new Pool(p->io_threads));
     const int ring = n_ctx * slots_per_ctx + 2;
     for (int f = 0; f < 2; ++f) p->in_buf[f].resize(ring);
@@ -1048,16 +1032,41 @@ struct aqc_source {
     std::unique_ptr<Source> src;
 };
 
-aqc_source* aqc_source_open(const char* path, int32_t gzip, int32_t io_threads) {
+aqc_source* aqc_source_open2(const char* path, int32_t gzip, int32_t io_threads, uint64_t gz_section_bytes) {
     if (!path) return nullptr;
     aqc_source* s = new aqc_source();
     unsigned hc = std::thread::hardware_concurrency();
     s->pool.reset(new Pool(io_threads > 0 ? io_threads : (int)std::min(16u, std::max(2u, hc / 4))));
-    if (gzip) s->src.reset(new GzSource(path, s->pool.get()));
+    if (gzip) s->src.reset(new GzSource(path, s->pool.get(), (size_t)gz_section_bytes));
     else s->src.reset(new FileSource(path, s->pool.get()));
     if (s->src->failed()) { delete s; return nullptr; }
     return s;
 }
+
+aqc_source* aqc_source_open(const char* path, int32_t gzip, int32_t io_threads) { return aqc_source_open2(path, gzip, io_threads, 0); }
+
+const char* aqc_source_error(aqc_source* s) { return s && s->src->failed() ? s->src->why() : ""; }
+
+int aqc_source_gz_stats(aqc_source* s, uint64_t out[4]) {
+    if (!s || !out) return AQC_ERR_ARG;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (GzSource* g = dynamic_cast<GzSource*>(s->src.get()))
+        if (g->pg) { out[0] = g->pg->sections_accepted; out[1] = g->pg->sections_discarded; out[2] = g->pg->bridged_bytes; out[3] = g->pg->total_out; }
+    return 0;
+}
+
+int aqc_gz_deflate_block(const uint8_t* src, uint64_t n, int32_t level, uint8_t* dst, uint64_t cap, uint64_t* out_n) {
+    if ((!src && n) || !dst || !out_n || cap < aqcgz::deflate_bound((size_t)n)) return AQC_ERR_ARG;
+    *out_n = aqcgz::deflate_block(src, (size_t)n, level, dst);
+    return 0;
+}
+
+int64_t aqc_gz_inflate_raw(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) {
+    if (!src || (!dst && cap)) return -1;
+    return aqcgz::inflate_raw(src, (size_t)n, dst, (size_t)cap);
+}
+
+uint32_t aqc_gz_crc32(uint32_t crc, const uint8_t* p, uint64_t n) { return aqcgz::crc32_fast(crc, p, (size_t)n); }
 
 int64_t aqc_source_read(aqc_source* s, uint8_t* dst, uint64_t want) {
     if (!s || (!dst && want)) return -1;

@@ -1,0 +1,108 @@
+// aqc_pool.hpp — the I/O-side thread pool of the whole-input pipe (host code only): pread pieces, newline counts, inflate /
+// deflate of independent blocks, the speculative sections of the parallel gunzip.
+//   parallel_for   blocking, the caller works too; its jobs go to the FRONT lane (short, somebody waits for them)
+//   submit         fire and forget; `background` jobs (long speculative work) only run when no front-lane job waits
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace aqc_host {
+
+class Pool {
+public:
+    explicit Pool(int n) {
+        for (int i = 0; i < n; ++i) th_.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    int size() const { return (int)th_.size(); }
+
+    void submit(std::function<void()> job, bool background = false) {
+        if (th_.empty()) { job(); return; }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            (background ? bg_ : q_).push_back(std::move(job));
+        }
+        cv_.notify_one();
+    }
+
+    // run fn(i) for i in [0, n) on the pool and wait for all of them
+    void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
+        if (n == 0) return;
+        if (n == 1 || th_.empty()) {
+            for (size_t i = 0; i < n; ++i) fn(i);
+            return;
+        }
+        struct Batch {
+            std::atomic<size_t> next{0}, done{0};
+            size_t n;
+            const std::function<void(size_t)>* fn;
+            std::mutex mu;
+            std::condition_variable cv;
+        };
+        auto b = std::make_shared<Batch>();
+        b->n = n;
+        b->fn = &fn;
+        const size_t helpers = std::min(n - 1, th_.size());
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (size_t k = 0; k < helpers; ++k)
+                q_.push_back([b] {
+                    for (;;) {
+                        const size_t i = b->next.fetch_add(1);
+                        if (i >= b->n) break;
+                        (*b->fn)(i);
+                        if (b->done.fetch_add(1) + 1 == b->n) {
+                            std::lock_guard<std::mutex> g2(b->mu);
+                            b->cv.notify_all();
+                        }
+                    }
+                });
+        }
+        cv_.notify_all();
+        // the caller works too
+        for (;;) {
+            const size_t i = b->next.fetch_add(1);
+            if (i >= n) break;
+            fn(i);
+            b->done.fetch_add(1);
+        }
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->cv.wait(lk, [&] { return b->done.load() >= n; });
+    }
+
+private:
+    void loop() {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty() || !bg_.empty(); });
+                if (!q_.empty()) { job = std::move(q_.front()); q_.pop_front(); }
+                else if (!bg_.empty()) { job = std::move(bg_.front()); bg_.pop_front(); }
+                else if (stop_) return;
+                else continue;
+            }
+            job();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::deque<std::function<void()>> q_, bg_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
+
+}  // namespace aqc_host

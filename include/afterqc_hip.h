@@ -366,13 +366,26 @@ void aqc_pipe_destroy(aqc_pipe* p);
 int aqc_pipe_run(aqc_pipe* p, const aqc_pipe_io* io, const aqc_pipe_opts* opts, aqc_pipe_result* result);
 const char* aqc_pipe_last_error(void);
 /* a read file as a byte stream (fastq.Reader's `self.__file`, fastq.py:23-28), served by the pipe's readers: parallel pread
- * for plain files; for .gz, BGZF members inflated in parallel and any other gzip data through one zlib stream.
+ * for plain files; for .gz (gzip.open upstream, fastq.py:23-24) the pipe's own decoder: BGZF members inflated independently,
+ * any other gzip data — one big member included — by speculative sections on many threads, committed in order (exact:
+ * csrc/aqc_gz.hpp), member CRC-32 / length verified, a truncated or corrupt file is an error.
  * aqc_source_read fills dst with the next `want` decompressed bytes and returns their number (< want only at the end of
- * the stream, -1 on a read / format error). */
+ * the stream, -1 on a read / format error: aqc_source_error says which). */
 typedef struct aqc_source aqc_source;
 aqc_source* aqc_source_open(const char* path, int32_t gzip, int32_t io_threads);
+/* gz_section_bytes: compressed bytes per speculative section (0: chosen from the file size; AQC_GZ_SECTION overrides) */
+aqc_source* aqc_source_open2(const char* path, int32_t gzip, int32_t io_threads, uint64_t gz_section_bytes);
 int64_t aqc_source_read(aqc_source* s, uint8_t* dst, uint64_t want);
+const char* aqc_source_error(aqc_source* s);
+/* diagnostics of the parallel gunzip: sections accepted, sections discarded, bytes decoded sequentially instead, bytes out */
+int aqc_source_gz_stats(aqc_source* s, uint64_t out[4]);
 void aqc_source_close(aqc_source* s);
+/* the codec's pieces on their own (host only; the CPU tests pin them against zlib): one raw DEFLATE stream for src[0, n)
+ * (dst must hold n + n / 1000 + 400 bytes; level <= 0 stores), its inverse into exactly `cap` bytes (-1: invalid data or a
+ * different length), and the CRC-32 of gzip (crc = 0 to start) */
+int aqc_gz_deflate_block(const uint8_t* src, uint64_t n, int32_t level, uint8_t* dst, uint64_t cap, uint64_t* out_n);
+int64_t aqc_gz_inflate_raw(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap);
+uint32_t aqc_gz_crc32(uint32_t crc, const uint8_t* p, uint64_t n);
 
 /* host-only pieces of the pipe, callable without a GPU (the CPU tests use them):
  * the newline counter the chunk boundaries are found with; BGZF-style gzip members as the pipe's writer makes them (dst must

@@ -1,0 +1,141 @@
+"""The pipe's own gzip codec (csrc/aqc_inflate.cpp, aqc_gunzip.cpp, aqc_deflate.cpp) against zlib / Python's gzip module — what
+fastq.py:23-24,65-68 uses upstream.  No GPU: the codec is host code inside libafterqc_hip.so."""
+import gzip
+import os
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from afterqc_amd import capi, synth  # noqa: E402
+
+
+def _fastq_text(n_pairs, seed):
+    d = synth.make_pairs(n_pairs, 150, seed=seed, dirty=True)
+    buf, n = synth.render_fastq_fixed(d["seq1"], d["qual1"], 1)
+    return bytes(memoryview(buf)[:n])
+
+
+def test_native_selftest(tmp_path):
+    """inflate vs zlib streams of every level / strategy, deflate_block -> zlib, ParallelGunzip over single- and multi-member
+    files in small sections, truncated / corrupted / bad-CRC / trailing-garbage inputs (tests/native/gz_selftest.cpp)"""
+    exe = str(tmp_path / "gz_selftest")
+    src = [os.path.join(ROOT, "tests", "native", "gz_selftest.cpp")] + [os.path.join(ROOT, "afterqc_amd", "csrc", f) for f in
+                                                                      ("aqc_inflate.cpp", "aqc_gunzip.cpp", "aqc_deflate.cpp")]
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wno-stringop-overflow"] + src + ["-lz", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "all gz codec checks passed" in out.stdout
+
+
+def _read_all(path, section=0, threads=4, piece=1 << 20):
+    s = capi.NativeSource(path, True, io_threads=threads, gz_section_bytes=section)
+    out = bytearray()
+    buf = bytearray(piece)
+    try:
+        while True:
+            k = s.readinto(buf)
+            out += buf[:k]
+            if k < piece:
+                break
+        return bytes(out), s.gz_stats()
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("level", [1, 2, 6, 9])
+def test_python_gzip_single_member_parallel(tmp_path, level):
+    """a single-member .gz as Python's gzip module writes it (what upstream's own outputs and most inputs are): decoded by
+    speculative sections on several threads, byte-identical, and the sections really are used"""
+    text = _fastq_text(12000, 31 + level)
+    p = str(tmp_path / "a.fq.gz")
+    with gzip.open(p, "wb", compresslevel=level) as f:
+        f.write(text)
+    for section in (64 << 10, 256 << 10, 0):
+        got, st = _read_all(p, section)
+        assert got == text
+        if section == 64 << 10:
+            assert st[0] >= 8 and st[3] == len(text), st       # accepted sections, bytes out
+            assert st[2] < len(text) // 4, st                   # little was decoded sequentially
+
+
+def test_multi_member_and_bgzf_and_mixed(tmp_path):
+    a, b, c = _fastq_text(3000, 1), _fastq_text(2000, 2), _fastq_text(2500, 3)
+    # cat of three gzip files, the middle one written by the pipe's own writer (BGZF members)
+    p = str(tmp_path / "cat.gz")
+    with open(p, "wb") as f:
+        f.write(gzip.compress(a, 4))
+        f.write(capi.bgzf_compress(b, 2))
+        f.write(gzip.compress(c, 1))
+    assert _read_all(p, 64 << 10)[0] == a + b + c
+    # BGZF first (member-parallel path), a plain member behind it
+    p2 = str(tmp_path / "bgzf_first.gz")
+    with open(p2, "wb") as f:
+        f.write(capi.bgzf_compress(b, 2))
+        f.write(gzip.compress(c, 6))
+    assert _read_all(p2)[0] == b + c
+    # the pipe's writer output reads back with Python's gzip too (and levels 0 .. 9 all give valid members)
+    for level in (0, 1, 2, 6, 9):
+        assert gzip.decompress(capi.bgzf_compress(a, level)) == a
+    assert gzip.decompress(capi.bgzf_compress(b"", 2)) == b""
+
+
+def test_empty_and_tiny(tmp_path):
+    p = str(tmp_path / "e.gz")
+    open(p, "wb").close()
+    assert _read_all(p)[0] == b""
+    with gzip.open(p, "wb") as f:
+        pass
+    assert _read_all(p)[0] == b""
+    with gzip.open(p, "wb") as f:
+        f.write(b"@r\nA\n+\nI\n")
+    assert _read_all(p)[0] == b"@r\nA\n+\nI\n"
+
+
+def test_damaged_inputs_fail_loudly(tmp_path):
+    """a truncated or corrupt input must be an error (gzip.open raises upstream), never a clean end of file"""
+    text = _fastq_text(8000, 5)
+    gz = gzip.compress(text, 6)
+    cases = {"truncated": gz[:len(gz) * 2 // 3], "flipped": gz[:len(gz) // 2] + bytes([gz[len(gz) // 2] ^ 0x20]) + gz[len(gz) // 2 + 1:],
+             "bad_crc": gz[:-6] + bytes([gz[-6] ^ 1]) + gz[-5:], "garbage_behind": gz + b"junk", "not_gzip": b"@r\nACGT\n+\nIIII\n" * 100}
+    for name, data in cases.items():
+        p = str(tmp_path / (name + ".gz"))
+        with open(p, "wb") as f:
+            f.write(data)
+        with pytest.raises(IOError):
+            _read_all(p, 64 << 10)
+    # BGZF: one corrupted byte inside a member, and a member cut short
+    bg = capi.bgzf_compress(text, 2)
+    bad = bytearray(bg)
+    bad[len(bg) // 2] ^= 0x40
+    for name, data in (("bgzf_flipped", bytes(bad)), ("bgzf_truncated", bg[:len(bg) - 100])):
+        p = str(tmp_path / (name + ".gz"))
+        with open(p, "wb") as f:
+            f.write(data)
+        with pytest.raises(IOError):
+            _read_all(p)
+
+
+def test_deflate_block_and_crc_through_the_c_abi():
+    lib = capi.load_library()
+    rng = np.random.default_rng(4)
+    text = np.frombuffer(_fastq_text(3000, 8), dtype=np.uint8)
+    for n in (0, 1, 17, 4096, 0xff00, 200000):
+        src = np.ascontiguousarray(text[:n])
+        for level in (0, 1, 2, 6):
+            dst = np.zeros(n + n // 1000 + 400, dtype=np.uint8)
+            m = capi.C.c_uint64(0)
+            assert lib.aqc_gz_deflate_block(src.ctypes.data, n, level, dst.ctypes.data, dst.size, capi.C.byref(m)) == 0
+            raw = dst[:m.value].tobytes()
+            assert zlib.decompress(raw, -15) == src.tobytes()
+            back = np.zeros(n + 1, dtype=np.uint8)
+            assert lib.aqc_gz_inflate_raw(dst.ctypes.data, m.value, back.ctypes.data, n) == n
+            assert back[:n].tobytes() == src.tobytes()
+    for n in (0, 1, 15, 16, 127, 128, 129, 1000, 65536, 1 << 20):
+        b = rng.integers(0, 256, n, dtype=np.uint8)
+        c0 = int(rng.integers(0, 1 << 32))
+        assert lib.aqc_gz_crc32(c0, b.ctypes.data, n) == zlib.crc32(b.tobytes(), c0)
