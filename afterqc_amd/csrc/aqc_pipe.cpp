@@ -915,6 +915,21 @@ struct Run {
 
 }  // namespace
 
+// CPUs' worth of run time the cgroup grants (v2: cpu.max, v1: cpu.cfs_quota_us / cpu.cfs_period_us); 0 = no limit / unknown
+static double cgroup_cpu_quota() {
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long long per = 0;
+        const int k = fscanf(f, "%63s %lld", q, &per);
+        fclose(f);
+        if (k == 2 && strcmp(q, "max") != 0 && per > 0) return (double)atoll(q) / (double)per;
+        return 0;
+    }
+    long long q = -1, per = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f, "%lld", &q) != 1) q = -1; fclose(f); }
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f, "%lld", &per) != 1) per = 0; fclose(f); }
+    return (q > 0 && per > 0) ? (double)q / (double)per : 0;
+}
+
 extern "C" {
 
 const char* aqc_pipe_last_error(void) { return g_pipe_err; }
@@ -931,7 +946,12 @@ int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_
     // independent members) is what scales with it
     unsigned share = 1;
     if (const char* lw = getenv("LOCAL_WORLD_SIZE")) share = (unsigned)std::max(1, atoi(lw));
-    p->io_threads = io_threads > 0 ? io_threads : (int)std::min(96u, std::max(4u, hc * 3 / 8 / share));
+    unsigned dflt = std::min(96u, std::max(4u, hc * 3 / 8 / share));
+    // ... but never far beyond what the container may actually use: under a cgroup CPU quota (the MI355X boxes: 256 hardware
+    // threads visible, cpu.max = 16 CPUs) more runnable threads only get the whole group throttled
+    const double quota = cgroup_cpu_quota();
+    if (quota > 0) dflt = std::min(dflt, std::max(4u, (unsigned)(quota * 2.0 / share + 0.5)));
+    p->io_threads = io_threads > 0 ? io_threads : (int)dflt;
     p->pool.reset(new Pool(p->io_threads));
     const int ring = n_ctx * slots_per_ctx + 2;
     for (int f = 0; f < 2; ++f) p->in_buf[f].resize(ring);

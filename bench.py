@@ -6,25 +6,25 @@
       bench.py --gpus N --steps K --warmup W
 
 Workload = BASELINE.json configs[2] (seed 1003): 5 M synthetic 2x150 bp pairs = 10 M reads per
-GPU, as RAW FASTQ TEXT (two mate files' worth, 1.7 GB each).  With N GPUs the ranks hold the chunks r, r+N, r+2N, ... of one
-5 M x N pair input (every chunk carries its global first_index; independent shards, no collective on the data path ->
-weak scaling; the statistics are summed on the host at the end).
+GPU, as RAW FASTQ TEXT (two mate files, 1.7 GB each).
 
-Three measurements of the good / bad split of that text, all in the one JSON line rank 0 prints:
+`value` (the metric: Mreads/s END TO END, good / bad split) — one STEP = the product's whole-input pipe (aqc_pipe_run, what
+`after.py -1 R1.fq -2 R2.fq` runs) from the two FASTQ FILES to the four good / bad FILES: parallel pread into page-locked
+rings -> H2D -> record framing -> verdicts -> post-filter QC sampling -> good / bad text -> D2H -> one sequential writer
+per output file.  ONE input whatever N is: with N GPUs the chunks of an N x 5 M-pair input are dealt round robin over N
+contexts by ONE process (rank 0 drives all N devices — SURVEY.md §8e, BASELINE config 4: no collective; the other ranks
+of a torchrun launch only take part in the barriers and in the device-step measurement below).  `--contexts C` puts C
+contexts on every device (for a one-GPU box: the N-context code path on one device).
 
-  value (the metric)           one STEP = the whole device pipeline over the text RESIDENT IN HBM: record framing
-                               (aqc_reframe: line index + 4-line records, fastq.py:37-49) -> verdicts (aqc_run: the loop of
-                               preprocesser.py:436-617) -> post-filter QC sampling (aqc_qc_stat, first qc_sample records) ->
-                               good / bad FASTQ text built in HBM (aqc_format, preprocesser.py:206-232).  Nothing is
-                               pre-digested: the step starts from bytes and ends with bytes.
-  pinned_to_pinned_mreads_s    the same work fed from page-locked HOST memory through the whole-input pipe (aqc_pipe_run:
-                               chunks of 131072 records, H2D / kernels / D2H of different chunks overlapped over three slots),
-                               outputs fetched into page-locked buffers — PCIe inclusive, all ranks at once
-  file_to_file_mreads_s        the pipe from two FASTQ files to the four good / bad files (page cache / tmpfs), all ranks at once
-
-`roofline` is for the dominant kernel of the step (fast_filter_overlap_kernel): HIP-event time of the aqc_run launches on
-the slot's stream, algorithmic bytes 4L+56 per pair.  `cpu_baseline` (N=1): the oracle (scalar C port of
-the reference loop) on one core over a bounded sample, checked against the GPU's verdicts.
+Other numbers on the same JSON line (never `value`):
+  device_step_mreads_s         the same work with the text RESIDENT IN HBM: aqc_reframe -> aqc_run -> aqc_qc_stat ->
+                               aqc_format per chunk, no PCIe, no files (each rank on its own GPU; what rounds 1-2 printed as
+                               `value`).  `roofline` is for its dominant kernel (fast_filter_overlap_kernel): HIP-event time
+                               on the slot's stream, algorithmic bytes 4L+56 per pair.
+  pinned_to_pinned_mreads_s    the pipe fed from / fetched into page-locked host memory (PCIe inclusive, no files)
+  file_to_file_gz              the pipe .gz -> .gz (own codec, host threads), on request (--gz-runs)
+`cpu_baseline` (N=1): the oracle (scalar C port of the reference loop) on one core over a bounded sample, checked against the
+GPU's verdicts; plus the same port on every host core and a pure-Python stand-in.
 """
 import argparse
 import json
@@ -42,17 +42,18 @@ L = 150
 
 
 def hbm_traffic(args, n_rec):
-    """HBM bytes per launch of the dominant kernel as measured with the PMC counters (FETCH_SIZE / WRITE_SIZE, separate passes,
-    corrected as MI355X_MICROARCH.md prescribes) for exactly this workload — profiles/hbm_traffic.json, written from the
-    rocprofv3 summaries under profiles/ — or None when that measurement is of another workload."""
+    """HBM bytes per launch of the dominant kernel as measured with the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
+    rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md prescribes) for exactly this workload — profiles/hbm_traffic.json,
+    written from the rocprofv3 summaries under profiles/ — or None when that measurement is of another workload.  Counters
+    cannot be read from inside the process that is being measured; `traffic_source` in the JSON line says where it is from."""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             t = json.load(f)
         if t.get("workload", "config3") == args.workload and int(t["pairs"]) == int(n_rec):
-            return int(t["bytes_per_launch"])
+            return int(t["bytes_per_launch"]), "profiles/hbm_traffic.json (%s)" % t.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE")
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -63,12 +64,15 @@ def main():
     ap.add_argument("--pairs", type=int, default=5_000_000, help="pairs per GPU (default: config 3 = 10 M reads)")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="pairs timed on the CPU baseline (0 = skip)")
     ap.add_argument("--qc-sample", type=int, default=200_000)
-    ap.add_argument("--chunk-records", type=int, default=1 << 17, help="records per chunk of the pipe measurements")
+    ap.add_argument("--chunk-records", type=int, default=1 << 17, help="records per chunk of the pipe")
     ap.add_argument("--pipe-runs", type=int, default=3, help="timed runs of the pinned->pinned pipe (0 = skip)")
-    ap.add_argument("--file-runs", type=int, default=1, help="timed file-to-file runs (0 = skip)")
+    ap.add_argument("--device-steps", type=int, default=10, help="timed steps of the HBM-resident device pipeline (0 = skip)")
+    ap.add_argument("--gz-runs", type=int, default=0, help="timed .gz -> .gz runs of the pipe (0 = skip)")
+    ap.add_argument("--contexts", type=int, default=1, help="contexts per device for the one-input pipe runs")
+    ap.add_argument("--devices", default="", help="explicit device list for the one-input pipe runs, e.g. 0,0,0,0 (overrides --gpus / --contexts)")
     ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5"],
                     help="config3 (default, the metric's workload): PE 2x150; config2: SE 1x150 filter+trim only; "
-                         "config5: PE 2x250 + 17-base barcode / verify prefix, barcode mode on (no gzip here: tools/e2e_bench.py)")
+                         "config5: PE 2x250 + 17-base barcode / verify prefix, barcode mode on")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,9 +137,9 @@ def main():
         texts.append((hb, nbytes))
     t_txt = time.time() - t_txt
     K = args.chunk_records
-    # this rank's text holds the chunks rank, rank + world, ... of the N-GPU input; for the one-chunk step its records are
-    # simply numbered from rank * n_rec (the sampling rule only looks at indices below qc_sample)
     first_index = rank * n_rec
+    reads_per_gpu = n_rec * (2 if paired else 1)
+    text_in = sum(t[1] for t in texts)
 
     def barrier():
         torch.cuda.synchronize() if torch.cuda.is_available() else None
@@ -149,7 +153,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ================= A. the step: text resident in HBM -> good / bad text in HBM ==========================================
+    # ================= A. the device step: text resident in HBM -> good / bad text in HBM (every rank, its own GPU) =========
     # (a chunk is < 2 GiB of text per mate: 5 M records of 347 bytes fit one chunk, longer inputs are spread over the slots)
     per_slot = min(n_rec, int(1.9e9 // w))
     n_res = (n_rec + per_slot - 1) // per_slot
@@ -167,7 +171,7 @@ def main():
         res_n.append((lo, hi))
     for sl in range(n_res):
         eng.sync(sl)
-    t_up = time.perf_counter() - t_up          # host -> HBM + first framing (reported, never part of `value`)
+    t_up = time.perf_counter() - t_up          # host -> HBM + first framing (reported)
 
     def step():
         total = [0] * 6
@@ -187,19 +191,20 @@ def main():
         for sl in range(n_res):
             eng.sync(sl)
 
-    for _ in range(args.warmup):
-        step()
+    dsteps = max(1, args.device_steps)
+    for _ in range(min(3, max(1, args.warmup))):
+        sizes = step()
     sync_all()
     barrier()
     for sl in range(n_res):
         eng.timing_reset(sl)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(dsteps):
         sizes = step()
     sync_all()
     if torch.cuda.is_available():
         torch.cuda.synchronize()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    dev_elapsed = max_over_ranks(time.perf_counter() - t0)
     kms, klaunch = eng.timing_mean(0)
     for sl in range(1, n_res):
         k2, l2 = eng.timing_mean(sl)
@@ -209,10 +214,10 @@ def main():
     if n_res > 1:
         # With several chunks resident their slots' streams overlap: the dominant kernel of one chunk shares the GPU with
         # the writer kernels of another and its event time says little about the kernel.  For the roofline line the
-        # kernel is timed again alone, chunk after chunk (outside the timed region; `value` is not affected).
+        # kernel is timed again alone, chunk after chunk.
         for sl in range(n_res):
             eng.timing_reset(sl)
-        for _ in range(max(1, args.steps)):
+        for _ in range(dsteps):
             for sl in range(n_res):
                 eng.run(sl)
                 eng.sync(sl)
@@ -220,100 +225,168 @@ def main():
         for sl in range(1, n_res):
             k_alone = k_alone + eng.timing_mean(sl)[0]
         kms[capi.K_FILTER_OVERLAP] = k_alone[capi.K_FILTER_OVERLAP]
-
-    reads_per_gpu = n_rec * (2 if paired else 1)
-    ms_per_step = 1000.0 * elapsed / max(1, args.steps)
-    value = reads_per_gpu * world / (elapsed / max(1, args.steps)) / 1e6
+    dev_ms = 1000.0 * dev_elapsed / dsteps
+    dev_value = reads_per_gpu * world / (dev_elapsed / dsteps) / 1e6
     bytes_per_record = (4 * RL + 56) if paired else (2 * RL + 20)
     k_ms = float(kms[capi.K_FILTER_OVERLAP])
     achieved = n_rec * bytes_per_record / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    text_in = sum(t[1] for t in texts)
     text_out = int(sum(sizes))
     good_frac = float(counters[capi.C_GOOD_READS]) / max(1.0, float(counters[capi.C_TOTAL_READS]))
 
-    # ================= B. page-locked host memory -> pipe -> page-locked host memory (PCIe inclusive) =======================
-    pipe = capi.Pipe([eng], slots=3)
-    inputs = [(t[0].array, t[1]) for t in texts]
-    pinned = None
-    if args.pipe_runs > 0:
+    # ================= B/C. ONE input through the whole-input pipe, driven by rank 0 over every device ========================
+    if args.devices:
+        dev_list = [int(x) for x in args.devices.split(",")]
+    elif share_gpu:
+        dev_list = [0] * (world * max(1, args.contexts))
+    else:
+        dev_list = [g for g in range(world) for _ in range(max(1, args.contexts))]
+    n_ctx = len(dev_list)
+    copies = max(1, world)                      # the one input holds `world` x the per-GPU share (weak scaling, one input)
+    pinned = f2f = f2f_gz = None
+    step_times = []
+    pipe_reads = reads_per_gpu * copies
+    if rank == 0:
+        engines = [eng]
+        for g in dev_list[1:]:
+            e2 = capi.Engine(g, 3)
+            e2.set_config(cfg)
+            e2.reset_stats()
+            engines.append(e2)
+        pipe = capi.Pipe(engines, slots=3)
+    else:
+        engines, pipe = [], None
+
+    def reset_all():
+        for e in engines:
+            e.reset_stats()
+
+    # ---- B. page-locked memory -> page-locked memory (PCIe inclusive): this rank's share only
+    if args.pipe_runs > 0 and rank == 0:
+        inputs = [(t[0].array, t[1]) for t in texts]
         ts = []
         for it in range(args.pipe_runs + 1):            # the first run allocates the page-locked rings: not timed
-            eng.reset_stats()
-            barrier()
+            reset_all()
             t1 = time.perf_counter()
-            pr = pipe.run(inputs, outputs=None, chunk_records=K, qc_sample=args.qc_sample, chunk_index0=rank, chunk_index_stride=world)
-            dt = max_over_ranks(time.perf_counter() - t1)
+            pr = pipe.run(inputs, outputs=None, chunk_records=K, qc_sample=args.qc_sample)
+            dt = time.perf_counter() - t1
             assert not pr.anomaly and int(pr.records) == n_rec
             if it:
                 ts.append(dt)
         best = min(ts)
-        pinned = {"mreads_s": round(reads_per_gpu * world / best / 1e6, 2), "seconds": round(best, 4), "runs": len(ts),
-                  "gb_s_each_way_per_gpu": round(text_in / best / 1e9, 2), "chunk_records": K}
+        pinned = {"mreads_s": round(reads_per_gpu / best / 1e6, 2), "seconds": round(best, 4), "runs": len(ts), "contexts": n_ctx,
+                  "gb_s_each_way": round(text_in / best / 1e9, 2), "chunk_records": K}
 
-    # ================= C. file -> pipe -> file ================================================================================
-    f2f = None
-    if args.file_runs > 0:
-        # files in the temp dir (page cache).  AQC_BENCH_DIR picks another place (tmpfs is SLOWER for this on the MI355X hosts:
-        # 6 GB/s per file against 11 GB/s, tools/ubench/file_write_rate.cpp)
-        base = os.environ.get("AQC_BENCH_DIR") or None
-        work = tempfile.mkdtemp(prefix="aqc_bench_%d_" % rank, dir=base)
-        try:
-            paths = []
+    # ---- C. file -> pipe -> file: THE METRIC.  W warm-up runs, then K timed runs, each bracketed by a barrier + device
+    #      synchronisation on both sides; the previous run's output files are unlinked between runs (not timed: dropping
+    #      3.4 GB of page cache belongs to no run).  Files live in the temp dir (page cache); AQC_BENCH_DIR picks another place.
+    base = os.environ.get("AQC_BENCH_DIR") or None
+    work = tempfile.mkdtemp(prefix="aqc_bench_%d_" % rank, dir=base) if rank == 0 else None
+    try:
+        paths, outs = [], []
+        if rank == 0:
             for k, t in enumerate(texts):
                 p = os.path.join(work, "R%d.fq" % (k + 1))
                 with open(p, "wb") as f:
-                    f.write(memoryview(t[0].array)[:t[1]])
+                    for _ in range(copies):
+                        f.write(memoryview(t[0].array)[:t[1]])
                 paths.append(p)
             outs = [(os.path.join(work, "R%d.good.fq" % (k + 1)), os.path.join(work, "R%d.bad.fq" % (k + 1)), None) for k in range(len(texts))]
-            ts = []
-            for it in range(args.file_runs + 1):
-                eng.reset_stats()
-                for trio in outs:                      # a run writes NEW files (dropping last run's 3.4 GB is not part of it)
+        last = None
+        for it in range(args.warmup + args.steps):
+            if rank == 0:
+                reset_all()
+                for trio in outs:
                     for pth in trio:
                         if pth and os.path.exists(pth):
                             os.unlink(pth)
-                barrier()
+            barrier()
+            t1 = time.perf_counter()
+            if rank == 0:
+                last = pipe.run(paths, outs, chunk_records=K, qc_sample=args.qc_sample)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            dt = max_over_ranks(time.perf_counter() - t1)
+            if rank == 0:
+                assert not last.anomaly and int(last.records) == n_rec * copies, (last.anomaly, int(last.records))
+            if it >= args.warmup:
+                step_times.append(dt)
+        if rank == 0:
+            f2f = {"seconds_mean": round(sum(step_times) / len(step_times), 4), "seconds_min": round(min(step_times), 4),
+                   "seconds_max": round(max(step_times), 4), "where": base or tempfile.gettempdir(),
+                   "input_gb": round(text_in * copies / 1e9, 3), "output_gb": round(sum(int(x) for x in last.bytes_out) / 1e9, 3),
+                   "contexts": n_ctx, "devices": dev_list, "thread_seconds_last_run": last.breakdown()}
+        # ---- optional: the same through gzip both ways (own codec on host threads; the box's CPU quota is the bound)
+        if args.gz_runs > 0 and rank == 0:
+            import subprocess
+            gz_paths = []
+            for p in paths:
+                g = p + ".gz"
+                with open(g, "wb") as f:
+                    subprocess.check_call(["gzip", "-2", "-c", p], stdout=f)
+                gz_paths.append(g)
+            gouts = [(o[0] + ".gz", o[1] + ".gz", None) for o in outs]
+            ts = []
+            for it in range(args.gz_runs + 1):
+                reset_all()
+                for trio in gouts:
+                    for pth in trio:
+                        if pth and os.path.exists(pth):
+                            os.unlink(pth)
                 t1 = time.perf_counter()
-                pr = pipe.run(paths, outs, chunk_records=K, qc_sample=args.qc_sample, chunk_index0=rank, chunk_index_stride=world)
-                dt = max_over_ranks(time.perf_counter() - t1)
-                assert not pr.anomaly and int(pr.records) == n_rec
+                pr = pipe.run(gz_paths, gouts, gzip_in=[True] * len(gz_paths), gzip_out=True, gzip_level=2, chunk_records=K, qc_sample=args.qc_sample)
+                dt = time.perf_counter() - t1
+                assert not pr.anomaly and int(pr.records) == n_rec * copies
                 if it:
                     ts.append(dt)
-            best = min(ts)
-            f2f = {"mreads_s": round(reads_per_gpu * world / best / 1e6, 2), "seconds": round(best, 4), "runs": len(ts),
-                   "where": base or tempfile.gettempdir(), "input_gb_per_gpu": round(text_in / 1e9, 3),
-                   "output_gb_per_gpu": round(sum(int(x) for x in pr.bytes_out) / 1e9, 3), "thread_seconds_last_run": pr.breakdown()}
-        finally:
+            f2f_gz = {"mreads_s": round(pipe_reads / min(ts) / 1e6, 2), "seconds": round(min(ts), 4), "runs": len(ts),
+                      "input_gz_gb": round(sum(os.path.getsize(g) for g in gz_paths) / 1e9, 3),
+                      "output_gz_gb": round(sum(os.path.getsize(x) for trio in gouts for x in trio if x and os.path.exists(x)) / 1e9, 3),
+                      "thread_seconds_last_run": pr.breakdown(), "cpu_quota": _cpu_quota()}
+    finally:
+        if work:
             shutil.rmtree(work, ignore_errors=True)
-    pipe.close()
+    if pipe is not None:
+        pipe.close()
 
-    wl = {"config3": "config3: %d synthetic PE 2x150 bp pairs per GPU (%.1f M reads) as raw FASTQ text (%.2f GB), seed 1003+rank, "
-                     "overlap ~N(30,8), 3%% adapter read-through, defaults with -f 0 -t 0, qc_sample %d"
-                     % (n_rec, reads_per_gpu / 1e6, text_in / 1e9, args.qc_sample),
-          "config2": "config2: %d synthetic SE 1x150 bp reads per GPU as raw FASTQ text, -f 5 -t 5, qc_sample %d" % (n_rec, args.qc_sample),
-          "config5": "config5 (no gzip): %d synthetic PE 2x250 bp pairs + 17-base barcode/verify prefix per GPU as raw FASTQ text, barcode "
-                     "mode, qc_sample %d" % (n_rec, args.qc_sample)}[args.workload]
+    elapsed = sum(step_times)
+    ms_per_step = 1000.0 * elapsed / max(1, len(step_times))
+    value = pipe_reads / (elapsed / max(1, len(step_times))) / 1e6
+
+    wl = {"config3": "config3: ONE input of %d synthetic PE 2x150 bp pairs (%.1f M reads; %d x the per-GPU share of %d pairs) as two FASTQ files "
+                     "(%.2f GB) -> four good / bad FASTQ files, seed 1003, overlap ~N(30,8), 3%% adapter read-through, defaults with -f 0 -t 0, "
+                     "qc_sample %d" % (n_rec * copies, pipe_reads / 1e6, copies, n_rec, text_in * copies / 1e9, args.qc_sample),
+          "config2": "config2: ONE input of %d synthetic SE 1x150 bp reads as one FASTQ file -> good / bad files, -f 5 -t 5, qc_sample %d" % (n_rec * copies, args.qc_sample),
+          "config5": "config5 (plain text; gzip: tools/e2e_bench.py / --gz-runs): ONE input of %d synthetic PE 2x250 bp pairs + 17-base barcode/verify "
+                     "prefix as two FASTQ files -> good / bad files, barcode mode, qc_sample %d" % (n_rec * copies, args.qc_sample)}[args.workload]
+    traffic, traffic_src = hbm_traffic(args, n_rec)
     out = {
         "metric": "Mreads/s (paired 2x150 bp) end-to-end good/bad split",
         "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": wl + "; step = FASTQ text resident in HBM -> record framing -> filter / overlap / correction verdicts -> "
-                                    "post-filter QC sampling -> good / bad FASTQ text in HBM",
-                   "pairs_per_gpu": args.pairs, "read_len": RL, "parallelism": "independent shards x%d (chunks dealt round robin, no collective)" % world,
-                   "text_in_gb_per_gpu": round(text_in / 1e9, 3), "text_out_gb_per_gpu": round(text_out / 1e9, 3)},
+        "config": {"workload": wl + "; step = file -> file: aqc_pipe_run (pread -> page-locked rings -> H2D -> framing -> filter / overlap / "
+                                    "correction verdicts -> QC sampling -> good / bad text -> D2H -> one writer per output file)",
+                   "pairs_per_gpu": args.pairs, "read_len": RL,
+                   "parallelism": "one input, chunks of %d records dealt round robin over %d context(s) on device(s) %s by one process, no collective" % (K, n_ctx, dev_list),
+                   "text_in_gb": round(text_in * copies / 1e9, 3), "timing": "%d runs, each bracketed by barrier + device sync; outputs of the previous run unlinked in between (untimed)" % len(step_times)},
         "roofline": {"bound": "hbm", "kernel": "fast_filter_overlap_kernel (+ its deferral list kernel)", "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                     "traffic": hbm_traffic(args, n_rec),     # HBM counter bytes per launch, from separate rocprofv3 --pmc passes (profiles/)
+                     "traffic": traffic, "traffic_source": traffic_src,
                      "kernel_ms": round(k_ms, 4), "launches": int(klaunch[capi.K_FILTER_OVERLAP]),
                      "algorithmic_bytes_per_launch": n_rec * bytes_per_record,
                      "qc_stat_ms_per_call": round(float(kms[capi.K_QC_STAT]), 4),
-                     "step_text_gb_s": round((text_in + text_out) / (ms_per_step * 1e-3) / 1e9, 1)},
+                     "measured_in": "the device-step loop of this run (HIP events on the slot's stream)"},
+        "device_step_mreads_s": round(dev_value, 2),
+        "device_step": {"ms_per_step": round(dev_ms, 4), "steps": dsteps, "text_in_gb_per_gpu": round(text_in / 1e9, 3),
+                        "text_out_gb_per_gpu": round(text_out / 1e9, 3), "step_text_gb_s": round((text_in + text_out) / (dev_ms * 1e-3) / 1e9, 1),
+                        "what": "text resident in HBM -> aqc_reframe -> aqc_run -> aqc_qc_stat -> aqc_format (no PCIe, no files), every rank on its own GPU"},
         "pinned_to_pinned_mreads_s": pinned["mreads_s"] if pinned else None,
-        "file_to_file_mreads_s": f2f["mreads_s"] if f2f else None,
-        "pinned_to_pinned": pinned, "file_to_file": f2f,
+        "pinned_to_pinned": pinned, "file_to_file": f2f, "file_to_file_gz": f2f_gz,
         "good_reads_frac": round(good_frac, 5),
         "gen_s": round(t_gen, 1), "text_render_s": round(t_txt, 1), "first_upload_s": round(t_up, 3),
+        "host": {"cpus": os.cpu_count(), "cpu_quota": _cpu_quota()},
     }
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle, 1 core, bounded sample of the same workload
@@ -339,20 +412,20 @@ def main():
             from concurrent.futures import ThreadPoolExecutor
             T = max(1, min(os.cpu_count() or 1, 64))
             per = max(1000, min(100_000, args.pairs // T))
-            engines = []
+            engines_o = []
             for k in range(T):
                 lo, hi = k * per, (k + 1) * per
                 e = oracle.OracleEngine()
                 e.set_config(cfg)
                 e.upload(0, capi.Batch.from_matrices(d["seq1"][lo:hi], d["qual1"][lo:hi], d["len1"][lo:hi],
                                                      d["seq2"][lo:hi], d["qual2"][lo:hi], d["len2"][lo:hi]))
-                engines.append(e)
+                engines_o.append(e)
             ta = time.perf_counter()
             with ThreadPoolExecutor(max_workers=T) as ex:
-                list(ex.map(lambda e: e.run(0), engines))
+                list(ex.map(lambda e: e.run(0), engines_o))
             ta = time.perf_counter() - ta
             out["cpu_baseline"]["all_cores"] = {"value": round(2 * per * T / ta / 1e6, 3), "unit": "Mreads/s", "cores": T,
-                                                "sample": "%d threads x %d pairs, %.2f s" % (T, per, ta)}
+                                                "sample": "%d threads x %d pairs, %.2f s (cgroup CPU quota: %s)" % (T, per, ta, _cpu_quota())}
         except Exception as e:      # the 1-core figure above is the contract; this one is extra
             out["cpu_baseline"]["all_cores"] = {"error": str(e)}
         # and the reference's own kind of speed: the same loop as pure Python (strings, per-base loops), 1 core —
@@ -374,10 +447,23 @@ def main():
         print(json.dumps(out))
     for t in texts:
         t[0].free()
+    for e in engines[1:]:
+        e.close()
     eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _cpu_quota():
+    """CPUs' worth of run time the cgroup allows this container (cpu.max), or None when unlimited / unknown: the MI355X boxes
+    show 256 hardware threads but run under a quota, which is what bounds every host-side stage (gzip above all)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except (OSError, ValueError):
+        return None
 
 
 if __name__ == "__main__":
