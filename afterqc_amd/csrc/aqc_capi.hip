@@ -252,6 +252,8 @@ void aqc_destroy(aqc_ctx* c) {
     delete c;
 }
 
+int aqc_device_index(aqc_ctx* c) { return c ? c->device : -1; }
+
 int aqc_device_name(aqc_ctx* c, char* buf, int buflen) {
     if (!c || !buf || buflen <= 0) return fail(AQC_ERR_ARG, "aqc_device_name: bad arguments");
     snprintf(buf, (size_t)buflen, "%s", c->name);

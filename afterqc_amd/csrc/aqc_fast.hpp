@@ -828,6 +828,33 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             bool found = false;
             int f_off = 0, f_len = 0, f_tot = 0, f_p0 = 0, f_p1 = 0, f_p2 = 0;   // accepted candidate + its first mismatch columns
             const uint32_t F = par[0];                          // partner's first 16 bases
+            // mismatches of one diagonal — the own stream from base c on against the partner's first QL bases: their number,
+            // how many lie in columns 0..49, and the columns of the first three (the correction walk needs them)
+            // (results come back by value, packed: columns 9 bits each | total << 27 | c50 << 36 — with reference parameters the
+            //  compiler turns the three columns into an indexed private array, i.e. scratch memory)
+            auto diag_mismatches = [&](int c, int QL) __attribute__((always_inline)) -> unsigned long long {
+                const int k = c >> 4;
+                const uint32_t s = (uint32_t)(c & 15) * 2;
+                uint32_t lo0 = own[k], e0 = own[NW + k];
+                int rem = QL, tot = 0, c50 = 0, vp0 = 0, vp1 = 0, vp2 = 0;
+#pragma nounroll
+                for (int j = 0; 16 * j < QL; ++j) {
+                    const bool in = k + j + 1 < NW;
+                    const uint32_t lo1 = in ? own[k + j + 1] : 0u, e1 = in ? own[NW + k + j + 1] : 0u;
+                    uint32_t mm = mm_word(lo0, lo1, e0, e1, s, par[j], par[NW + j], rem);
+                    if (j < 4) c50 += __popc(j < 3 ? mm : (mm & 0xFu));      // columns 0..49 (wave-uniform branch)
+                    while (mm != 0 && tot < 3) {
+                        const int col = 16 * j + ((__ffs((int)mm) - 1) >> 1);
+                        if (tot == 0) vp0 = col; else if (tot == 1) vp1 = col; else vp2 = col;
+                        tot++;
+                        mm &= mm - 1;
+                    }
+                    tot += __popc(mm);
+                    rem = max(rem - 16, 0);
+                    lo0 = lo1; e0 = e1;
+                }
+                return (unsigned long long)(uint32_t)(vp0 | (vp1 << 9) | (vp2 << 18)) | ((unsigned long long)(uint32_t)tot << 27) | ((unsigned long long)(uint32_t)c50 << 36);
+            };
             while (true) {
                 const int wmax = wave_max_i(scan && !found ? n_own : 0);
                 if (wmax == 0) break;
@@ -869,30 +896,13 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                     const bool check = live && !found && c != NONE_CAND;
                     if (!__ballot(check)) break;
                     const int QL = min(len_own - c, len_par);
-                    const int k = c >> 4;
-                    const uint32_t s = (uint32_t)(c & 15) * 2;
-                    int tot = 0, c50 = 0, vp0 = 0, vp1 = 0, vp2 = 0;
                     if (check) {
-                        uint32_t lo0 = own[k], e0 = own[NW + k];
-                        int rem = QL;
-#pragma nounroll
-                        for (int j = 0; 16 * j < QL; ++j) {
-                            const bool in = k + j + 1 < NW;
-                            const uint32_t lo1 = in ? own[k + j + 1] : 0u, e1 = in ? own[NW + k + j + 1] : 0u;
-                            uint32_t mm = mm_word(lo0, lo1, e0, e1, s, par[j], par[NW + j], rem);
-                            if (j < 4) c50 += __popc(j < 3 ? mm : (mm & 0xFu));      // columns 0..49 (wave-uniform branch)
-                            // remember the columns of the first three mismatches: the correction walk needs them
-                            while (mm != 0 && tot < 3) {
-                                const int col = 16 * j + ((__ffs((int)mm) - 1) >> 1);
-                                if (tot == 0) vp0 = col; else if (tot == 1) vp1 = col; else vp2 = col;
-                                tot++;
-                                mm &= mm - 1;
-                            }
-                            tot += __popc(mm);
-                            rem = max(rem - 16, 0);
-                            lo0 = lo1; e0 = e1;
+                        const unsigned long long dm = diag_mismatches(c, QL);
+                        const int tot = (int)((dm >> 27) & 0x1ffu), c50 = (int)(dm >> 36);
+                        if (tot < 3 || (c50 < 3 && QL >= 52)) {
+                            found = true; f_off = c; f_len = QL; f_tot = tot;
+                            f_p0 = (int)(dm & 0x1ffu); f_p1 = (int)((dm >> 9) & 0x1ffu); f_p2 = (int)((dm >> 18) & 0x1ffu);
                         }
-                        if (tot < 3 || (c50 < 3 && QL >= 52)) { found = true; f_off = c; f_len = QL; f_tot = tot; f_p0 = vp0; f_p1 = vp1; f_p2 = vp2; }
                     }
                 }
                 PROF(5);
@@ -940,11 +950,25 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             //      are exactly the columns of the accepted diagonal, whose first three mismatches the verification
             //      already located; otherwise (read 2 shorter than the rest of read 1) the pair is deferred.
             walk_pair = reached && !defer && flag < 0 && c_overlapped && dist > 0;
-            PROF_DEFER(3, walk_pair && !c_adapter_read && ovl != len1 - offset && role == 0);
-            if (walk_pair && !c_adapter_read && ovl != len1 - offset) { defer = true; walk_pair = false; }
+            // Read 2 shorter than the rest of read 1 (overlap_len == len2 < len1 - offset, App. B-6): the walk then runs along
+            // ANOTHER diagonal than the one util.overlap accepted — read 1 from len1 - len2 on against all of reverse_r2 — and
+            // handles the first `distance` mismatches it meets there; fewer than that on the whole diagonal => BADMISMATCH
+            // (preprocesser.py:563-617).  The read-1 lane looks that diagonal up with the same routine as the scan.
+            int w_tot = dist;
+            {
+                const bool shifted = walk_pair && !c_adapter_read && ovl != len1 - offset;
+                PROF_DEFER(3, shifted && role == 0);
+                if (__ballot(shifted)) {
+                    if (shifted && role == 0) {
+                        const unsigned long long dm = diag_mismatches(len1 - ovl, ovl);
+                        w_tot = (int)((dm >> 27) & 0x1ffu);
+                        f_p0 = (int)(dm & 0x1ffu); f_p1 = (int)((dm >> 9) & 0x1ffu); f_p2 = (int)((dm >> 18) & 0x1ffu);      // (the accepted diagonal's columns are not needed any more)
+                    }
+                }
+            }
+            const int w_n = min(dist, w_tot);                 // mismatches the walk handles
             walker = walk_pair && i_found_it;
             if (__ballot(walker)) {
-                // (<= 3 mismatches, all handled: the walk can never end short here, so BADMISMATCH cannot arise)
                 // Straight-line and in the streams' 2-bit codes (A 0, C 1, T 2, G 3; complement = code ^ 2): lanes that do not
                 // walk run along with column 0 and switch their results off.
                 const int shift1 = c_adapter_read ? 0 : len1 - ovl;        // read-1 position of walk column o: shift1 + o
@@ -959,14 +983,14 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 uint32_t wq1[3], wq2[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    wcol[q] = walker && q < dist ? (q == 0 ? f_p0 : q == 1 ? f_p1 : f_p2) : 0;
+                    wcol[q] = walker && q < w_n ? (q == 0 ? f_p0 : q == 1 ? f_p1 : f_p2) : 0;
                     wq1[q] = fb.qual1[qa0 + (uint32_t)wcol[q]];
                     wq2[q] = fb.qual2[qb0 - (uint32_t)wcol[q]];
                 }
                 uint32_t El0 = 0, El1 = 0, El2 = 0, Eh0 = 0, Eh1 = 0, Eh2 = 0;      // edits: column | kind << 16 | base << 24, quality
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    const bool on = walker && q < dist;
+                    const bool on = walker && q < w_n;
                     const int oo = wcol[q];
                     const int x1 = on ? shift1 + oo : 0, x2 = on ? shift2 + oo : 0;
                     const uint32_t h1 = (uint32_t)(x1 & 15) * 2u, h2 = (uint32_t)(x2 & 15) * 2u;
@@ -996,6 +1020,13 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                     if (put && n_edits == 1) { El1 = el; Eh1 = eh; }
                     if (put && n_edits == 2) { El2 = el; Eh2 = eh; }
                     n_edits += put ? 1 : 0;
+                }
+                if (walker && w_tot < dist) {
+                    // the walk ran out of mismatches before it had handled `distance` of them: the pair goes to bad/ with the
+                    // edits made so far, the correction counters do not move (preprocesser.py:600-612)
+                    flag = AQC_BADMISMATCH;
+                    em0 = em1 = em2 = -1;
+                    c_corrected = c_masked = c_skipped = 0;
                 }
                 if (walker && c_corrected > 0) c_read_corrected = 1;
                 // the three 40-bit edits, packed into the result's upper 16 bytes

@@ -528,10 +528,36 @@ struct Run {
     std::condition_variable ring_cv[2];
     std::vector<char> ring_free[2];
     // dispatcher -> workers (one queue per context)
-    struct Job { InChunk c[2]; uint64_t idx; bool last; };
+    struct Job { InChunk c[2]; uint64_t idx; bool last; uint64_t ticket; };
     std::vector<std::unique_ptr<BQueue<Job>>> jobq;
     // workers -> writer
     BQueue<OutChunk> outq{0};
+    // DMA gates, one pair per physical device: the uploads (and the downloads) of the chunks dealt to ONE device start in
+    // chunk order and at most `slots` of them run at a time.  With one context per GPU that never blocks; with several
+    // contexts on one device it keeps a dozen transfers from sharing the link equally and all finishing late, which
+    // starves the in-order writers.
+    struct Gate {
+        std::mutex mu;
+        std::condition_variable cv;
+        uint64_t started = 0, finished = 0;
+    };
+    std::vector<std::unique_ptr<Gate>> up_gate, down_gate;
+    std::vector<int> group_of_ctx;
+    std::vector<uint64_t> group_tickets;
+    bool gate_enter(Gate& g, uint64_t ticket, uint64_t width) {
+        std::unique_lock<std::mutex> lk(g.mu);
+        g.cv.wait(lk, [&] { return abort.load() || (g.started == ticket && ticket < g.finished + width); });
+        if (abort) return false;
+        g.started++;
+        return true;
+    }
+    void gate_leave(Gate& g) {
+        {
+            std::lock_guard<std::mutex> lk(g.mu);
+            g.finished++;
+        }
+        g.cv.notify_all();
+    }
     // output set ownership
     std::mutex set_mu;
     std::condition_variable set_cv;
@@ -568,6 +594,8 @@ struct Run {
         for (int q = 0; q < 6; ++q) if (fileq[q]) fileq[q]->close();
         set_cv.notify_all();
         qc_cv.notify_all();
+        for (auto& g : up_gate) { std::lock_guard<std::mutex> lk(g->mu); g->cv.notify_all(); }
+        for (auto& g : down_gate) { std::lock_guard<std::mutex> lk(g->mu); g->cv.notify_all(); }
     }
 
     int acquire_ring(int f) {
@@ -721,6 +749,7 @@ struct Run {
                 return;
             }
             j.last = fin1;
+            j.ticket = group_tickets[group_of_ctx[idx % jobq.size()]]++;
             if (!jobq[idx % jobq.size()]->push(j)) {
                 for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf);
                 break;
@@ -744,7 +773,11 @@ struct Run {
             ch.first_index = (opt->chunk_index0 + j.idx * (opt->chunk_index_stride ? opt->chunk_index_stride : 1)) * K;
             aqc_frame_info info{};
             uint64_t tt = now_ns();
+            Gate& ug = *up_gate[group_of_ctx[ci]];
+            Gate& dg = *down_gate[group_of_ctx[ci]];
+            if (!gate_enter(ug, j.ticket, (uint64_t)P->slots)) { for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf); return; }
             int rc = aqc_frame(c, slot, &ch, &info);
+            gate_leave(ug);
             ns_frame += now_ns() - tt;
             tt = now_ns();
             // the text has left the host buffers
@@ -798,17 +831,21 @@ struct Run {
                 }
                 ns_wait_set += now_ns() - tt;
                 tt = now_ns();
+                if (!gate_enter(dg, j.ticket, (uint64_t)P->slots)) return;
                 for (int q = 0; q < 6; ++q) {
                     if (!oc.sizes[q]) continue;
                     HostBuf& hb = P->wbufs[wid].out[set][q];
                     hb.ensure(oc.sizes[q]);
                     if (!hb.p) { fail(AQC_ERR_HIP, "page-locked allocation failed"); return; }
-                    if ((rc = aqc_fetch_text(c, slot, q / 3, q % 3, hb.p, hb.cap))) { fail(rc, "aqc_fetch_text: %s", aqc_last_error()); return; }
+                    if ((rc = aqc_fetch_text(c, slot, q / 3, q % 3, hb.p, hb.cap))) { gate_leave(dg); fail(rc, "aqc_fetch_text: %s", aqc_last_error()); return; }
                 }
+                gate_leave(dg);
                 ns_fetch += now_ns() - tt;
                 oc.set = set;
                 set ^= 1;
             } else {
+                if (!gate_enter(dg, j.ticket, (uint64_t)P->slots)) return;
+                gate_leave(dg);
                 if ((rc = aqc_sync(c, slot))) { fail(rc, "aqc_sync: %s", aqc_last_error()); return; }
             }
             records += n;
@@ -950,7 +987,7 @@ int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_
     // ... but never far beyond what the container may actually use: under a cgroup CPU quota (the MI355X boxes: 256 hardware
     // threads visible, cpu.max = 16 CPUs) more runnable threads only get the whole group throttled
     const double quota = cgroup_cpu_quota();
-    if (quota > 0) dflt = std::min(dflt, std::max(4u, (unsigned)(quota * 2.0 / share + 0.5)));
+    if (quota > 0) dflt = std::min(dflt, std::max(4u, (unsigned)(quota * 4.0 / share + 0.5)));      // (measured: 2 .. 4 threads per granted CPU do best, profiles/r03_gz_codec_scaling.txt)
     p->io_threads = io_threads > 0 ? io_threads : (int)dflt;
     p->pool.reset(new Pool(p->io_threads));
     const int ring = n_ctx * slots_per_ctx + 2;
@@ -988,6 +1025,19 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
     }
     for (int i = 0; i < P->n_ctx; ++i) R.jobq.emplace_back(new BQueue<Run::Job>((size_t)P->slots));
     R.set_free.assign(P->wbufs.size() * 2, 1);
+    {
+        // contexts on the same physical device share one pair of DMA gates
+        std::vector<int> devs;
+        for (int i = 0; i < P->n_ctx; ++i) {
+            const int dv = aqc_device_index(P->ctx[i]);
+            int g = -1;
+            for (size_t k = 0; k < devs.size(); ++k) if (devs[k] == dv) g = (int)k;
+            if (g < 0) { g = (int)devs.size(); devs.push_back(dv); }
+            R.group_of_ctx.push_back(g);
+        }
+        for (size_t k = 0; k < devs.size(); ++k) { R.up_gate.emplace_back(new Run::Gate()); R.down_gate.emplace_back(new Run::Gate()); }
+        R.group_tickets.assign(devs.size(), 0);
+    }
     if (!opt->no_output) {
         for (int q = 0; q < 6; ++q) {
             const char* path = io->out_path[q / 3][q % 3];

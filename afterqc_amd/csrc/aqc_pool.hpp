@@ -1,7 +1,9 @@
 // aqc_pool.hpp — the I/O-side thread pool of the whole-input pipe (host code only): pread pieces, newline counts, inflate /
 // deflate of independent blocks, the speculative sections of the parallel gunzip.
 //   parallel_for   blocking, the caller works too; its jobs go to the FRONT lane (short, somebody waits for them)
-//   submit         fire and forget; `background` jobs (long speculative work) only run when no front-lane job waits
+//   submit         fire and forget; `background` jobs (long speculative work: the gunzip sections) have a lane of their own.
+//                  A free worker serves the lanes in turn — front, background, front, ... — so that neither the gzip writers'
+//                  deflate batches nor the readers' inflate sections can starve the other
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -90,8 +92,9 @@ private:
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return stop_ || !q_.empty() || !bg_.empty(); });
-                if (!q_.empty()) { job = std::move(q_.front()); q_.pop_front(); }
-                else if (!bg_.empty()) { job = std::move(bg_.front()); bg_.pop_front(); }
+                const bool take_bg = !bg_.empty() && (q_.empty() || (turn_++ & 1));
+                if (take_bg) { job = std::move(bg_.front()); bg_.pop_front(); }
+                else if (!q_.empty()) { job = std::move(q_.front()); q_.pop_front(); }
                 else if (stop_) return;
                 else continue;
             }
@@ -103,6 +106,7 @@ private:
     std::mutex mu_;
     std::condition_variable cv_;
     bool stop_ = false;
+    unsigned turn_ = 0;
 };
 
 }  // namespace aqc_host

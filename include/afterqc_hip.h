@@ -203,6 +203,7 @@ const char* aqc_last_error(void);
 int aqc_create(int device, int n_slots, aqc_ctx** out);
 void aqc_destroy(aqc_ctx* ctx);
 int aqc_device_name(aqc_ctx* ctx, char* buf, int buflen);
+int aqc_device_index(aqc_ctx* ctx); /* the HIP device the context lives on */
 
 /* ---- configuration ---------------------------------------------------------------------------- */
 int aqc_set_config(aqc_ctx* ctx, const aqc_config* cfg);
