@@ -137,7 +137,13 @@ def visible_devices():
     n = max(1, capi.load_library().aqc_device_count())
     env = os.environ.get("AQC_DEVICES")
     if env:
-        return [int(x) for x in env.split(",") if x.strip() != ""]
+        devs = [int(x) for x in env.split(",") if x.strip() != ""]
+        bad = [d for d in devs if d < 0 or d >= n]
+        if bad or not devs:
+            raise SystemExit("AQC_DEVICES=%s: device index out of range (this machine shows %d GPU%s)" % (env, n, "" if n == 1 else "s"))
+        # (an index may be listed more than once: that many contexts on the one device — how a single-GPU box exercises the
+        #  one-input-over-N-contexts path)
+        return devs
     return list(range(n))
 
 

@@ -22,6 +22,7 @@ the GPU is missing.  (Tests inject the oracle engine to exercise THIS file's hos
 """
 import json
 import os
+import sys
 import queue
 import threading
 
@@ -315,11 +316,22 @@ class seqFilter:
         if self.engine is None:
             self.engine = capi.Engine(self.devices[0], max(2, self.pipe_slots))
             self.own_engine = True
-            self.extra_engines = [capi.Engine(d, max(2, self.pipe_slots)) for d in self.devices[1:]]
         return self.engine
 
-    def _engines(self):
-        return [self._engine()] + self.extra_engines
+    def _engines(self, all_devices=False):
+        """engines[0] is the run's engine; the contexts on the other devices are only created once the whole-input pipe has
+        been chosen (all_devices=True) — a run that stays on one engine (index files, --qc_only, .bz2, the serial fallback)
+        never touches another GPU"""
+        eng = self._engine()
+        if all_devices and self.own_engine and not self.extra_engines and len(self.devices) > 1:
+            cfg, circles = self._last_cfg
+            for d in self.devices[1:]:
+                e = capi.Engine(d, max(2, self.pipe_slots))
+                e.set_config(cfg)
+                e.set_circles(circles)
+                e.reset_stats()
+                self.extra_engines.append(e)
+        return [eng] + self.extra_engines
 
     def _aux(self, batch, rb1):
         """Parse lane/tile/x/y out of the R1 names for the bubble filter (preprocesser.py:180-192)."""
@@ -346,8 +358,9 @@ class seqFilter:
         t_run = time.perf_counter()
         has_i1 = opt.index1_file is not None
         has_i2 = opt.index2_file is not None
+        self._last_cfg = (build_config(opt, paired, has_i2), self.bubbleCircles)
         for e in self._engines():
-            e.set_config(build_config(opt, paired, has_i2))
+            e.set_config(self._last_cfg[0])
             e.set_circles(self.bubbleCircles)
             e.reset_stats()
 
@@ -407,8 +420,9 @@ class seqFilter:
             os.makedirs(overlap_dir, exist_ok=True)   # single-end + store_overlap: upstream opens the writer without the dir
         # ---- pass 2: the main loop (preprocesser.py:411-631)
         # the per-read settings now include the resolved trim values
+        self._last_cfg = (build_config(opt, paired, has_i2), self.bubbleCircles)
         for e in self._engines():
-            e.set_config(build_config(opt, paired, has_i2))
+            e.set_config(self._last_cfg[0])
         # text in / text out on the device (aqc_frame / aqc_format); use_text_path=False keeps the host-side framing and
         # writer below as a cross-check.  An injected engine without the text calls takes the host path.
         self.text_path = self.use_text_path and hasattr(eng, "frame")
@@ -421,6 +435,9 @@ class seqFilter:
             extra_bases = self._run_pipe(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, paired)
             if extra_bases is None:
                 # not the regular shape (empty line inside, mates of different lengths, ...): start over, chunk by chunk
+                print("afterqc_amd: %s is not of the regular shape the whole-input pipe takes (blank line inside / mates of "
+                      "different lengths); running it again through the serial chunk loop" % opt.read1_file, file=sys.stderr)
+                self.timing["pipe_fallback"] = True
                 for e in self._engines():
                     e.reset_stats()
         if extra_bases is not None:
@@ -441,29 +458,38 @@ class seqFilter:
             outs.close()
         self.timing["pass2_s"] = time.perf_counter() - t_p2
 
-        # statistics: per-GPU integers summed on the host (only the pipe spreads a run over several engines)
-        stat_eng = capi.MergedEngines(self._engines()) if self.extra_engines else eng
-        r1post.engine = r2post.engine = stat_eng
-        r1post.qc()
-        if paired:
-            r2post.qc()
+        try:
+            # statistics: per-GPU integers summed on the host (only the pipe spreads a run over several engines)
+            stat_eng = capi.MergedEngines(self._engines()) if self.extra_engines else eng
+            r1post.engine = r2post.engine = stat_eng
+            r1post.qc()
+            if paired:
+                r2post.qc()
 
-        self.stat = self._stats(stat_eng, r1pre, r2pre, r1post, r2post, readLen, extra_bases)
-        stat_path = os.path.join(qc_dir, os.path.basename(opt.read1_file) + ".json")
-        with open(stat_path, "w") as f:
-            f.write(json.dumps(self.stat, sort_keys=True, indent=4, separators=(',', ': ')))
-        # the HTML report next to it (preprocesser.py:780-783, qcreporter.py)
-        from . import qcreporter
-        ovl_hist, _ = stat_eng.histograms(capi.AQC_QC_COLS)
-        figures = qcreporter.build_figures(self.stat, opt, r1pre, r2pre, r1post, r2post, ovl_hist, readLen)
-        with open(os.path.join(qc_dir, os.path.basename(opt.read1_file) + ".html"), "w") as f:
-            f.write(qcreporter.render(self.stat, figures, getattr(opt, "version", "")))
-        self.timing["total_s"] = time.perf_counter() - t_run
-        if self.own_engine:
-            for e in self._engines():
-                e.close()
-            self.engine = None
-            self.extra_engines = []
+            self.stat = self._stats(stat_eng, r1pre, r2pre, r1post, r2post, readLen, extra_bases)
+            stat_path = os.path.join(qc_dir, os.path.basename(opt.read1_file) + ".json")
+            with open(stat_path, "w") as f:
+                f.write(json.dumps(self.stat, sort_keys=True, indent=4, separators=(',', ': ')))
+            # the HTML report next to it (preprocesser.py:780-783, qcreporter.py).  The FASTQ outputs and the statistics are
+            # complete at this point: a problem in the report is reported, it does not fail the run
+            try:
+                from . import qcreporter
+                ovl_hist, _ = stat_eng.histograms(capi.AQC_QC_COLS)
+                figures = qcreporter.build_figures(self.stat, opt, r1pre, r2pre, r1post, r2post, ovl_hist, readLen)
+                with open(os.path.join(qc_dir, os.path.basename(opt.read1_file) + ".html"), "w") as f:
+                    f.write(qcreporter.render(self.stat, figures, getattr(opt, "version", "")))
+            except Exception as e:      # noqa: BLE001 — whatever it is, the run's results stand
+                print("afterqc_amd: the HTML report could not be written (%s: %s); outputs and %s are complete"
+                      % (type(e).__name__, e, stat_path), file=sys.stderr)
+                self.timing["report_error"] = "%s: %s" % (type(e).__name__, e)
+            self.timing["total_s"] = time.perf_counter() - t_run
+        finally:
+            if self.own_engine:
+                for e in [self.engine] + self.extra_engines:
+                    if e is not None:
+                        e.close()
+                self.engine = None
+                self.extra_engines = []
         return self.stat
 
     # ---- pass 2 through the whole-input pipe (aqc_pipe_run) ---------------------------------------------------------------
@@ -480,7 +506,8 @@ class seqFilter:
             want_ovl = (opt.store_overlap and k == 0) or (opt.store_overlap and paired)
             outputs.append((os.path.join(good_dir, main + ".good.fq" + ext), os.path.join(bad_dir, main + ".bad.fq" + ext),
                             os.path.join(overlap_dir, main + ".overlap.fq" + ext) if want_ovl else None))
-        pipe = capi.Pipe(self._engines(), slots=min([self.pipe_slots] + [e.n_slots for e in self._engines()]), io_threads=self.io_threads)
+        engines = self._engines(all_devices=True)
+        pipe = capi.Pipe(engines, slots=min([self.pipe_slots] + [e.n_slots for e in engines]), io_threads=self.io_threads)
         try:
             res = pipe.run(files[:nfiles], outputs, gzip_in=[f.endswith(".gz") for f in files[:nfiles]], gzip_out=gzip_out,
                            gzip_level=opt.compression, chunk_records=self.chunk_records, qc_sample=opt.qc_sample,

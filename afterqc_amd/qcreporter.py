@@ -68,7 +68,9 @@ def gc_figure(qc, div, title):
     if n == 0:
         return Figure(title, div, None, None)
     from . import capi
-    hist = qc.acc[capi.QC_GC_HIST, :n + 1].tolist()
+    # (squeeze(), qualitycontrol.py:59-71, has cut the histogram to readLen entries before the report is drawn —
+    #  preprocesser.py:703-708 — so upstream plots readLen + 1 x positions against readLen counts; kept)
+    hist = qc.acc[capi.QC_GC_HIST, :n].tolist()
     xs = [100.0 * float(t) / n for t in range(n + 1)]
     return Figure(title, div, [{"x": xs, "y": hist, "type": "bar"}], {"title": title, "xaxis": {"title": "percents(%)"}, "yaxis": {"title": "counts"}})
 

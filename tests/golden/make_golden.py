@@ -27,6 +27,26 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
 
+class Py2Int(int):
+    """an int whose `/` is python 2's: floor division between integers (results stay Py2Int through + - * //)"""
+    def __truediv__(self, o):
+        return Py2Int(int(self) // int(o)) if isinstance(o, int) else int(self) / o
+    def __rtruediv__(self, o):
+        return Py2Int(int(o) // int(self)) if isinstance(o, int) else o / int(self)
+    def __add__(self, o):
+        return Py2Int(int(self) + int(o)) if isinstance(o, int) else int(self) + o
+    __radd__ = __add__
+    def __sub__(self, o):
+        return Py2Int(int(self) - int(o)) if isinstance(o, int) else int(self) - o
+    def __rsub__(self, o):
+        return Py2Int(int(o) - int(self)) if isinstance(o, int) else o - int(self)
+    def __mul__(self, o):
+        return Py2Int(int(self) * int(o)) if isinstance(o, int) else int(self) * o
+    __rmul__ = __mul__
+    def __floordiv__(self, o):
+        return Py2Int(int(self) // int(o)) if isinstance(o, int) else int(self) // o
+
+
 def install_shim():
     """(1) xrange, (2) text-mode gzip.open, (3) force the pure-Python editDistance."""
     builtins.xrange = range
@@ -65,10 +85,34 @@ def run_ref_main(argv):
         options.trim_front2 = 0
     else:
         options.barcode = False
+    # (6) the report: strandBiasPlotly (qualitycontrol.py:238-270) divides list lengths with `/` and feeds the result to
+    # xrange — python 2 integer division.  Inside qualitycontrol ONLY, len() hands out ints whose `/` floors like python 2's,
+    # so the reference's own code runs to the end and writes its HTML report (the one py2-vs-py3 delta of the report path).
+    import qualitycontrol
+    qualitycontrol.len = lambda x: Py2Int(builtins.len(x))
     try:
         after.processOptions(options)
-    except TypeError as e:  # qualitycontrol.py:241-254 under py3
+    except TypeError as e:  # (should not fire any more; kept so that FASTQ + JSON goldens survive a report problem)
         print("tolerated:", e)
+
+
+def js_to_json(text):
+    """the object literals the reference's *Plotly emitters write (bare keys, single quotes) -> JSON text"""
+    import re
+    text = text.replace("'", '"')
+    return re.sub(r'([{,]\s*)([A-Za-z_][A-Za-z0-9_]*)\s*:', r'\1"\2":', text)
+
+
+def parse_report(html):
+    """the reference's HTML report as data: menu titles, summary rows, and per Plotly div the traces + layout"""
+    import re
+    rep = {"menu": re.findall(r"<li class='menu-item'><a href='#([^']*)'>(\d+), (.*?)</a> </li>", html),
+           "summary": re.findall(r"<tr><td class='col1'>(.*?)</td><td class='col2'>(.*?)</td></tr>", html),
+           "sections": re.findall(r"<div class='figure-title'><a name='([^']*)'>(\d+), (.*?)</a></div>\n<div id='([^']*)' class='plotly-div'></div>", html),
+           "figures": {}}
+    for m in re.finditer(r"var data=(\[.*?\]);\s*var layout=(\{.*?\});\s*Plotly\.newPlot\('([A-Za-z0-9_]+)', data, layout\);", html, re.S):
+        rep["figures"][m.group(3)] = {"data": json.loads(js_to_json(m.group(1))), "layout": json.loads(js_to_json(m.group(2)))}
+    return rep
 
 
 def sha_lines(path):
@@ -100,6 +144,8 @@ def run_case(name, argv, setup, keep_outputs=False):
                         rec["stat"] = json.load(f)
                     rec["stat_file"] = sub + "/" + fn
                 elif fn.endswith(".html"):
+                    with open(path) as f:
+                        rec["report"] = parse_report(f.read())
                     continue
                 else:
                     rec["files"][sub + "/" + fn] = sha_lines(path)
@@ -432,6 +478,10 @@ def gen_text_vectors():
 # --------------------------------------------------------------------------------------------
 # end-to-end cases (G1, G3): the table lives in cases.py so the tests rebuild the same inputs
 # --------------------------------------------------------------------------------------------
+# cases whose HTML report (qcreporter.py + qualitycontrol.py:158-322 figures) is kept as a fixture
+REPORT_CASES = ("g1_testdata", "se_default", "pe_barcode", "pe_cfg5")
+
+
 def e2e_cases():
     import cases
     return [(name, argv, (lambda work, spec=spec: cases.materialize(spec, work)), keep)
@@ -462,18 +512,29 @@ def main():
         print("framing vectors:", {k: len(v["records"]) for k, v in vec.items()})
     if not only or "e2e" in only or any(o.startswith("case:") for o in only):
         path = os.path.join(HERE, "e2e_cases.json.gz")
-        recs = {}
+        rpath = os.path.join(HERE, "report_vectors.json.gz")
+        recs, reports = {}, {}
         if os.path.exists(path):
             with gzip.open(path, "rt") as f:
                 recs = json.load(f)
+        if os.path.exists(rpath):
+            with gzip.open(rpath, "rt") as f:
+                reports = json.load(f)
         for name, argv, setup, keep in e2e_cases():
             if any(o.startswith("case:") for o in only) and ("case:" + name) not in only:
                 continue
             recs[name] = run_case(name, argv, setup, keep)
+            rep = recs[name].pop("report", None)
+            if name in REPORT_CASES:
+                if rep is None or not rep["figures"]:
+                    raise RuntimeError("the reference wrote no report for " + name)
+                reports[name] = rep
             s = recs[name]["stat"]["afterqc_main_summary"]
-            print(name, {k: s[k] for k in ("total_reads", "good_reads", "bad_reads")})
+            print(name, {k: s[k] for k in ("total_reads", "good_reads", "bad_reads")}, "report figures:", len(rep["figures"]) if rep else 0)
         with gzip.open(path, "wt") as f:
             json.dump(recs, f, sort_keys=True)
+        with gzip.open(rpath, "wt") as f:
+            json.dump(reports, f, sort_keys=True)
 
 
 if __name__ == "__main__":

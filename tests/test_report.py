@@ -4,8 +4,11 @@ import json
 import os
 import re
 
+import gzip
+
 import pytest
 
+from conftest import GOLDEN
 from test_host_golden import run_case
 
 PE_DIVS = ["filter_stat", "error_matrix", "overlap_stat"] + ["r%d_%s_%s" % (m, w, k) for m in (1, 2) for w in ("pre", "post")
@@ -64,3 +67,57 @@ def test_report_matches_stats(name, divs, tmp_path, e2e):
         hist, _ = figs["overlap_stat"]
         assert len(hist[0]["y"]) == s["readlen"] + 1 and sum(hist[0]["y"]) <= s["total_reads"]
     assert ("2*%d pair end" % s["readlen"] if paired else "%d single end" % s["readlen"]) in html
+
+
+# ---- pinned to the reference: the report the REAL reference wrote for the same inputs ---------------------------------------
+# tests/golden/report_vectors.json.gz holds, per case, what tests/golden/make_golden.py parsed out of the reference's own
+# HTML (qcreporter.py:36-138 page, qualitycontrol.py:158-322 figures, preprocesser.py:785-830 figure list): menu entries,
+# summary table rows, section order and, per Plotly div, the traces and the layout.  The one python-2-vs-3 delta of that
+# code path — `/` on list lengths in strandBiasPlotly — is restored in the generator with ints whose `/` floors.
+def parse_own_report(html):
+    rep = {"menu": [list(t) for t in re.findall(r"<li class='menu-item'><a href='#([^']*)'>(\d+), (.*?)</a> </li>", html)],
+           "summary": [list(t) for t in re.findall(r"<tr><td class='col1'>(.*?)</td><td class='col2'>(.*?)</td></tr>", html)],
+           "sections": [list(t) for t in re.findall(r"<div class='figure-title'><a name='([^']*)'>(\d+), (.*?)</a></div>\n<div id='([^']*)' class='plotly-div'></div>", html)],
+           "figures": {d: {"data": data, "layout": layout} for d, (data, layout) in figures_of(html).items()}}
+    return rep
+
+
+REPORT_CASES = ["g1_testdata", "se_default", "pe_barcode", "pe_cfg5"]
+
+
+def check_report_against_reference(name, work, e2e):
+    with gzip.open(os.path.join(GOLDEN, "report_vectors.json.gz"), "rt") as f:
+        exp = json.load(f)[name]
+    rec = e2e[name]
+    with open(os.path.join(work, rec["stat_file"][:-5] + ".html")) as f:
+        got = parse_own_report(f.read())
+    assert got["menu"] == exp["menu"]
+    assert got["sections"] == exp["sections"]
+    # every row but the version string (the reference prints its own: 0.9.6)
+    assert [r for r in got["summary"] if r[0] != "AfterQC Version:"] == [r for r in exp["summary"] if r[0] != "AfterQC Version:"]
+    assert [r[0] for r in got["summary"]] == [r[0] for r in exp["summary"]]
+    assert set(got["figures"]) == set(exp["figures"])
+    for div, fig in exp["figures"].items():
+        mine = got["figures"][div]
+        assert mine["layout"] == fig["layout"], (name, div, mine["layout"], fig["layout"])
+        assert len(mine["data"]) == len(fig["data"]), (name, div)
+        for a, b in zip(mine["data"], fig["data"]):
+            assert a.keys() == b.keys(), (name, div, sorted(a), sorted(b))
+            for k in b:
+                assert a[k] == b[k], (name, div, k)
+
+
+@pytest.mark.parametrize("name", REPORT_CASES)
+def test_report_equals_the_reference_report(name, tmp_path, e2e):
+    from oracle import oracle
+    work, _ = run_case(name, tmp_path, oracle.OracleEngine(), "text")
+    check_report_against_reference(name, work, e2e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["text", "pipe"])
+@pytest.mark.parametrize("name", REPORT_CASES)
+def test_report_equals_the_reference_report_on_gpu(name, mode, tmp_path, e2e, gpu_engine):
+    """the same through the HIP engine: serial chunk loop and whole-input pipe"""
+    work, _ = run_case(name, tmp_path, gpu_engine, mode)
+    check_report_against_reference(name, work, e2e)
