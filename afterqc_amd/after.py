@@ -158,9 +158,10 @@ def processDir(folder, options, engine_factory=None, n_workers=None):
         print("no read files to run with, do you call the program correctly?")
         print("see -h for help")
         return []
+    # one worker per listed device (AQC_DEVICES may list a device more than once: that many workers share it)
+    devs = [0] if engine_factory else visible_devices()
     if n_workers is None:
-        from . import capi
-        n_workers = max(1, capi.load_library().aqc_device_count())
+        n_workers = len(devs)
     n_workers = max(1, min(n_workers, len(jobs)))
     todo = queue.Queue()
     for k, opt in enumerate(jobs):
@@ -179,7 +180,7 @@ def processDir(folder, options, engine_factory=None, n_workers=None):
             except BaseException as e:          # report after every worker has finished its files
                 errors.append((opt.read1_file, e))
 
-    threads = [threading.Thread(target=worker, args=(d,)) for d in range(n_workers)]
+    threads = [threading.Thread(target=worker, args=(devs[d % len(devs)],)) for d in range(n_workers)]
     for t in threads:
         t.start()
     for t in threads:

@@ -337,7 +337,12 @@ int Inflater<OutT>::decode_huffman() {
                 OutT* dst = o + op;
                 const OutT* src = dst - dd;
                 op += len;
-                if (dd >= COPY_W) {
+                if (dd >= 16 / sizeof(OutT)) {
+                    // 16 bytes per move (the headroom covers the up to 15 bytes a move may run past the match)
+                    constexpr size_t W16 = 16 / sizeof(OutT);
+                    OutT* const end = dst + len;
+                    do { memcpy(dst, src, 16); dst += W16; src += W16; } while (dst < end);
+                } else if (dd >= COPY_W) {
                     // 8 bytes at a time; the moves may run up to 7 bytes past the match (headroom), never into unread source
                     OutT* const end = dst + len;
                     do { store64(dst, load64((const uint8_t*)src)); dst += COPY_W; src += COPY_W; } while (dst < end);

@@ -252,8 +252,9 @@ def add_barcodes(d, seed, barcode_len=12, verify=b"CAGTA", tail_frac=0.0):
 
 
 def write_fastq(path, names, seq, qual, lens, plus="+"):
-    """Render records as 4-line FASTQ text; '.gz' suffix selects gzip (fastq.py:63-76)."""
-    opener = gzip.open if path.endswith(".gz") else open
+    """Render records as 4-line FASTQ text; a '.gz' / '.bz2' suffix selects gzip / bzip2 (fastq.py:23-28,63-76)."""
+    import bz2
+    opener = gzip.open if path.endswith(".gz") else bz2.open if path.endswith(".bz2") else open
     with opener(path, "wb") as f:
         buf = []
         for i in range(len(names)):

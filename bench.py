@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--pipe-runs", type=int, default=3, help="timed runs of the pinned->pinned pipe (0 = skip)")
     ap.add_argument("--device-steps", type=int, default=10, help="timed steps of the HBM-resident device pipeline (0 = skip)")
     ap.add_argument("--gz-runs", type=int, default=0, help="timed .gz -> .gz runs of the pipe (0 = skip)")
+    ap.add_argument("--device-only", action="store_true", help="profiling runs (rocprofv3): only the HBM-resident device step, no pipe "
+                    "runs; `value` is then the device step and says so")
     ap.add_argument("--contexts", type=int, default=1, help="contexts per device for the one-input pipe runs")
     ap.add_argument("--devices", default="", help="explicit device list for the one-input pipe runs, e.g. 0,0,0,0 (overrides --gpus / --contexts)")
     ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5"],
@@ -245,6 +247,9 @@ def main():
     pinned = f2f = f2f_gz = None
     step_times = []
     pipe_reads = reads_per_gpu * copies
+    if args.device_only:
+        args.pipe_runs = 0
+        args.warmup = args.steps = 0
     if rank == 0:
         engines = [eng]
         for g in dev_list[1:]:
@@ -280,10 +285,10 @@ def main():
     #      synchronisation on both sides; the previous run's output files are unlinked between runs (not timed: dropping
     #      3.4 GB of page cache belongs to no run).  Files live in the temp dir (page cache); AQC_BENCH_DIR picks another place.
     base = os.environ.get("AQC_BENCH_DIR") or None
-    work = tempfile.mkdtemp(prefix="aqc_bench_%d_" % rank, dir=base) if rank == 0 else None
+    work = tempfile.mkdtemp(prefix="aqc_bench_%d_" % rank, dir=base) if (rank == 0 and not args.device_only) else None
     try:
         paths, outs = [], []
-        if rank == 0:
+        if rank == 0 and not args.device_only:
             for k, t in enumerate(texts):
                 p = os.path.join(work, "R%d.fq" % (k + 1))
                 with open(p, "wb") as f:
@@ -312,7 +317,7 @@ def main():
                 assert not last.anomaly and int(last.records) == n_rec * copies, (last.anomaly, int(last.records))
             if it >= args.warmup:
                 step_times.append(dt)
-        if rank == 0:
+        if rank == 0 and step_times:
             f2f = {"seconds_mean": round(sum(step_times) / len(step_times), 4), "seconds_min": round(min(step_times), 4),
                    "seconds_max": round(max(step_times), 4), "where": base or tempfile.gettempdir(),
                    "input_gb": round(text_in * copies / 1e9, 3), "output_gb": round(sum(int(x) for x in last.bytes_out) / 1e9, 3),
@@ -350,9 +355,12 @@ def main():
     if pipe is not None:
         pipe.close()
 
-    elapsed = sum(step_times)
-    ms_per_step = 1000.0 * elapsed / max(1, len(step_times))
-    value = pipe_reads / (elapsed / max(1, len(step_times))) / 1e6
+    if step_times:
+        elapsed = sum(step_times)
+        ms_per_step = 1000.0 * elapsed / len(step_times)
+        value = pipe_reads / (elapsed / len(step_times)) / 1e6
+    else:                       # --device-only: a profiling run, not the metric
+        ms_per_step, value = dev_ms, dev_value
 
     wl = {"config3": "config3: ONE input of %d synthetic PE 2x150 bp pairs (%.1f M reads; %d x the per-GPU share of %d pairs) as two FASTQ files "
                      "(%.2f GB) -> four good / bad FASTQ files, seed 1003, overlap ~N(30,8), 3%% adapter read-through, defaults with -f 0 -t 0, "
@@ -362,7 +370,7 @@ def main():
                      "prefix as two FASTQ files -> good / bad files, barcode mode, qc_sample %d" % (n_rec * copies, args.qc_sample)}[args.workload]
     traffic, traffic_src = hbm_traffic(args, n_rec)
     out = {
-        "metric": "Mreads/s (paired 2x150 bp) end-to-end good/bad split",
+        "metric": "Mreads/s (paired 2x150 bp) end-to-end good/bad split" if step_times else "DEVICE STEP ONLY (--device-only profiling run, not the metric)",
         "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",

@@ -66,35 +66,38 @@ def n_number(seq):
     return n
 
 
+def _diagonal_ok(a, i0, b, j0, n):
+    """One diagonal of util.overlap_hm in closed form (checked there against the imported reference on
+    6,000 random pairs): with `tot` mismatches among a[i0 : i0 + n] vs b[j0 : j0 + n] and `c50` of them in the first 50
+    columns, the diagonal is accepted iff tot < 3, or c50 < 3 and n >= 52 (the third mismatch must not fall into columns
+    0..49, and the scan must get past column 50).  Returns (accepted, tot) — tot is only complete when accepted."""
+    tot = c50 = 0
+    for k in range(n):
+        if a[i0 + k] != b[j0 + k]:
+            tot += 1
+            if k < 50:
+                c50 += 1
+                if c50 >= 3:
+                    return False, tot        # no diagonal with three early mismatches is ever accepted
+    return tot < 3 or n >= 52, tot
+
+
 def overlap_hm(r1, r2):
-    """util.py:158-212: first offset whose Hamming test passes, forward offsets first"""
-    len1, len2 = len(r1), len(r2)
+    """util.overlap (util.py:88-89,158-212) restated from its closed form: the forward diagonals d = 0, 1, ... (read 1 from d
+    on against reverse_r2 from its start) in order, then the reverse ones (read 1 from its start against reverse_r2 from
+    |d| on), each while at least 31 columns remain; the first accepted one wins.  -> (offset, overlap_len, diff)"""
     rr2 = reverse_complement(r2)
-    limit_distance, overlap_require, complete_compare_require = 3, 30, 50
-    offset = 0
-    while offset < len1 - overlap_require:                     # forward: r1[offset + i] against rr2[i]
-        overlap_len = min(len1 - offset, len2)
-        diff, i = 0, 0
-        for i in range(overlap_len):
-            if r1[offset + i] != rr2[i]:
-                diff += 1
-                if diff >= limit_distance and i < complete_compare_require:
-                    break
-        if diff < limit_distance or (diff >= limit_distance and i > complete_compare_require):
-            return offset, overlap_len, diff
-        offset += 1
-    offset = 0
-    while offset > -(len2 - overlap_require):                  # reverse: r1[i] against rr2[-offset + i]
-        overlap_len = min(len1, len2 - abs(offset))
-        diff, i = 0, 0
-        for i in range(overlap_len):
-            if r1[i] != rr2[-offset + i]:
-                diff += 1
-                if diff >= limit_distance and i < complete_compare_require:
-                    break
-        if diff < limit_distance or (diff >= limit_distance and i > complete_compare_require):
-            return offset, overlap_len, diff
-        offset -= 1
+    n1, n2 = len(r1), len(r2)
+    for d in range(max(0, n1 - 30)):
+        n = min(n1 - d, n2)
+        ok, tot = _diagonal_ok(r1, d, rr2, 0, n)
+        if ok:
+            return d, n, tot
+    for d in range(max(0, n2 - 30)):
+        n = min(n1, n2 - d)
+        ok, tot = _diagonal_ok(r1, 0, rr2, d, n)
+        if ok:
+            return -d, n, tot
     return 0, 0, 0
 
 

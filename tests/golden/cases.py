@@ -55,6 +55,8 @@ CASES = [
     ("pe_index", PE + ["-7", "I1.fq", "-5", "I2.fq"] + F0, pe(1083, index=True), False),
     ("pe_gz", ["-1", "R1.fq.gz", "-2", "R2.fq.gz"] + F0, pe(1093, r1="R1.fq.gz", r2="R2.fq.gz"), False),
     ("pe_gz_out", PE + F0 + ["-z", "--compression", "4"], pe(1094), False),
+    # .bz2 inputs (fastq.py:25-26): read through bz2.BZ2File upstream; the outputs are plain (only ".gz" selects a codec)
+    ("pe_bz2", ["-1", "R1.fq.bz2", "-2", "R2.fq.bz2"] + F0, pe(1095, r1="R1.fq.bz2", r2="R2.fq.bz2"), False),
     ("pe_barcode", ["-1", "barcode_R1.fq", "-2", "barcode_R2.fq", "-t", "0"],
      pe(1103, L=120, r1="barcode_R1.fq", r2="barcode_R2.fq", barcode=True), False),
     ("se_barcode", ["-1", "barcode_R1.fq", "-t", "0"],

@@ -57,6 +57,11 @@ def install_shim():
             mode += "t"
         return _open(fn, mode, *a, **k)
     gzip.open = gzopen
+    # (2b) the same for bz2.BZ2File (fastq.py:25-26): python 2 hands out str lines, python 3 bytes
+    import bz2
+    import io
+    _bz = bz2.BZ2File
+    bz2.BZ2File = lambda fn, mode="r", *a, **k: io.TextIOWrapper(_bz(fn, mode, *a, **k)) if mode in ("r", "w") else _bz(fn, mode, *a, **k)
     sys.path.insert(0, REF)
     import util
     util.EDIT_DISTANCE_MODULE_EXISTS = False

@@ -149,3 +149,60 @@ def test_directory_mode_runs_pairs_concurrently(tmp_path):
                 if fn.startswith(sub_dir + "/"):
                     with open(os.path.join(work, fn), "rb") as f:
                         assert f.read() == data, fn
+
+
+@pytest.mark.gpu
+def test_directory_mode_two_workers_on_gpu0(tmp_path, monkeypatch):
+    """after.py -d DIR on the HIP engine (after.py:101-171): AQC_DEVICES=0,0 = two workers, each with its own context on GPU 0,
+    taking file pairs off one queue; outputs, statistics and reports equal to running each pair on its own"""
+    monkeypatch.setenv("AQC_DEVICES", "0,0")
+    work = str(tmp_path / "in")
+    os.makedirs(work)
+    pairs = []
+    for k in range(4):
+        sub = os.path.join(work, "s%d" % k)
+        os.makedirs(sub)
+        p1, p2 = write_pair(sub, 300 + 40 * k, 300 + 40 * k, seed=200 + k)
+        q1, q2 = os.path.join(work, "sample%d_R1.fq" % k), os.path.join(work, "sample%d_R2.fq" % k)
+        os.rename(p1, q1); os.rename(p2, q2)
+        pairs.append((q1, q2))
+    argv = ["-d", work, "-f", "0", "-t", "0", "-g", os.path.join(work, "good"), "-b", os.path.join(work, "bad"),
+            "-r", os.path.join(work, "QC")]
+    options, _ = after.parseCommand(argv)
+    after.finalize_options(options)
+    assert after.visible_devices() == [0, 0]
+    stats = after.processDir(work, options)
+    assert len(stats) == 4 and all(s is not None for s in stats)
+    for k, (q1, q2) in enumerate(pairs):
+        ref_stat, ref_files = run(str(tmp_path), q1, q2, "text", "solo%d" % k)       # (oracle engine, serial loop)
+        for fn, data in ref_files.items():
+            if fn.startswith(("good/", "bad/")):
+                with open(os.path.join(work, fn), "rb") as f:
+                    assert f.read() == data, fn
+        for key in ref_stat:
+            if key != "command":
+                assert json.dumps(stats[k][key], sort_keys=True) == json.dumps(ref_stat[key], sort_keys=True), (k, key)
+        assert os.path.exists(os.path.join(work, "QC", os.path.basename(q1) + ".html"))
+
+
+@pytest.mark.gpu
+def test_cli_one_input_over_two_contexts(tmp_path, monkeypatch, e2e):
+    """`after.py -1 R1 -2 R2` with AQC_DEVICES=0,0: the CLI deals ONE input over two contexts (here both on GPU 0) through
+    the whole-input pipe; outputs and statistics are the reference's (golden case pe_default)"""
+    import cases
+    from test_host_golden import CASE_TABLE, check_case
+    monkeypatch.setenv("AQC_DEVICES", "0,0")
+    name = "pe_default"
+    _, argv, spec, _ = CASE_TABLE[name]
+    work = str(tmp_path)
+    cases.materialize(spec, work)
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        after.main(list(argv))
+    finally:
+        os.chdir(cwd)
+    rec = e2e[name]
+    with open(os.path.join(work, rec["stat_file"])) as f:
+        stat = json.load(f)
+    check_case(name, work, stat, e2e)

@@ -1,13 +1,15 @@
 #!/bin/bash
-# full GPU validation: smoke, every -m gpu test, the bench line, rocprofv3 kernel trace + HBM / SQ counters of the step
+# full GPU validation: smoke, every -m gpu test, the bench line, rocprofv3 kernel trace + HBM / SQ counters of the device step
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/smoke.log
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu.log
-timeout 900 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?"; cat gpurun_out/bench.log
-OUT=$GRAFT_REPO_ROOT/gpurun_out; B="python $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --pipe-runs 0 --file-runs 0"
+timeout 900 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-600 gpurun_out/bench.log
+OUT=$GRAFT_REPO_ROOT/gpurun_out; W=${1:-config3}; P=5000000; [ $W = config5 ] && P=3000000
+B="python $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --device-only --device-steps 10 --workload $W --pairs $P"
+rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -o kt -- $B > /dev/null 2>&1)
 (cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -o f -- $B > /dev/null 2>&1)
 (cd /tmp && rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/prof_write -o w -- $B > /dev/null 2>&1)
 (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAVES VALUBusy GRBM_GUI_ACTIVE --output-format csv -d $OUT/prof_sq -o s -- $B > /dev/null 2>&1)
-python tools/pmc_summary.py $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq | grep -v -E "rocclr|kmer_compact" > gpurun_out/profile_summary.txt
-cat gpurun_out/profile_summary.txt | cut -c1-170
+python tools/pmc_summary.py $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq | grep -v -E "rocclr|kmer_compact" > gpurun_out/profile_summary_$W.txt
+cut -c1-170 gpurun_out/profile_summary_$W.txt
