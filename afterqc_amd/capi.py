@@ -334,6 +334,8 @@ def load_library():
     lib.aqc_format.argtypes = [P, C.c_int, C.c_uint64, C.c_int32, P]
     lib.aqc_format_plain.argtypes = [P, C.c_int, C.c_int, C.c_uint64, C.c_int32, P]
     lib.aqc_fetch_text.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.c_uint64]
+    lib.aqc_compress.argtypes = [P, C.c_int, C.c_int32, P]
+    lib.aqc_fetch_gz.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.c_uint64]
     lib.aqc_pipe_create.argtypes = [C.POINTER(P), C.c_int32, C.c_int32, C.c_int32, C.POINTER(P)]
     lib.aqc_pipe_create.restype = C.c_int
     lib.aqc_pipe_destroy.argtypes = [P]
@@ -387,7 +389,7 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_device_index", "
                     "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_last_deferred", "aqc_kernel_ms", "aqc_timing_reset",
                     "aqc_timing_mean", "aqc_get_counters",
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
-                    "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_host_alloc",
+                    "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_compress", "aqc_fetch_gz", "aqc_host_alloc",
                     "aqc_host_free",
                     "aqc_pipe_create", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
                     "aqc_host_count_newlines", "aqc_bgzf_compress", "aqc_pipe_split",
@@ -547,6 +549,15 @@ class Engine:
         sizes = np.zeros(6, dtype=np.uint64)
         self._check(self.lib.aqc_format_plain(self.h, slot, verdict_slot, int(n), 1 if store_overlap else 0, _ptr(sizes)))
         return [int(x) for x in sizes]
+
+    def compress(self, slot, level=2):
+        """the slot's formatted streams as gzip members, built on the device -> compressed bytes per stream"""
+        sizes = np.zeros(6, dtype=np.uint64)
+        self._check(self.lib.aqc_compress(self.h, slot, int(level), _ptr(sizes)))
+        return [int(x) for x in sizes]
+
+    def fetch_gz(self, slot, file, stream, dst, cap):
+        self._check(self.lib.aqc_fetch_gz(self.h, slot, file, stream, dst.ctypes.data if dst is not None else None, int(cap)))
 
     def fetch_text(self, slot, file, stream, dst, cap):
         """dst: numpy uint8 array with room for the stream (sizes from format())"""

@@ -18,6 +18,9 @@
 #include "aqc_kernels.hpp"
 #include "aqc_fast.hpp"
 #include "aqc_text.hpp"
+#include "aqc_gzdev.hpp"
+#include "aqc_gz.hpp"
+#include <zlib.h>
 
 using namespace aqc;
 
@@ -71,6 +74,10 @@ struct Slot {
     DevBuf t_scratch;              // FrameMeta[2] + scan totals
     DevBuf f_pos, f_tile, f_plan, f_over, f_out[6];
     uint64_t f_bytes[6] = {0, 0, 0, 0, 0, 0};
+    // gzip members built on the device (aqc_compress)
+    DevBuf g_stage, g_sizes, g_offsets, g_total, g_hist, g_code, g_packed[6];
+    uint64_t g_bytes[6] = {0, 0, 0, 0, 0, 0};
+    bool compressed = false;
     bool framed = false, formatted = false;
     aqc_text_chunk last_chunk{};   // what the slot's arenas hold (aqc_reframe)
     uint8_t last_byte[2] = {'\n', '\n'};
@@ -127,6 +134,7 @@ struct aqc_ctx {
     bool has_cfg = false;
     DevBuf circ[5];
     DevBuf kmer_partial;          // per-round u16 count slices of kmer_count_kernel
+    DevBuf gz_crc;                // GzCrcTables (aqc_compress)
     DevCircles circles{};
     unsigned long long *counters = nullptr, *ovl_hist = nullptr, *dist_hist = nullptr;
     QcDev qc[4];
@@ -229,7 +237,8 @@ void aqc_destroy(aqc_ctx* c) {
                           &s.t_line_end[0], &s.t_line_end[1], &s.t_tile[0], &s.t_tile[1], &s.t_name_off[0], &s.t_name_off[1],
                           &s.t_name_len[0], &s.t_name_len[1], &s.t_plus_off[0], &s.t_plus_off[1], &s.t_plus_len[0], &s.t_plus_len[1],
                           &s.t_qual_len[0], &s.t_qual_len[1], &s.t_scratch, &s.f_pos, &s.f_tile, &s.f_plan, &s.f_over, &s.f_out[0], &s.f_out[1], &s.f_out[2],
-                          &s.f_out[3], &s.f_out[4], &s.f_out[5]};
+                          &s.f_out[3], &s.f_out[4], &s.f_out[5], &s.g_stage, &s.g_sizes, &s.g_offsets, &s.g_total, &s.g_hist, &s.g_code,
+                          &s.g_packed[0], &s.g_packed[1], &s.g_packed[2], &s.g_packed[3], &s.g_packed[4], &s.g_packed[5]};
         for (DevBuf* b : bufs) b->release();
         for (int k = 0; k < AQC_N_KERNELS; k++)
             for (int j = 0; j < 2; j++) {
@@ -241,6 +250,7 @@ void aqc_destroy(aqc_ctx* c) {
     }
     for (auto& b : c->circ) b.release();
     c->kmer_partial.release();
+    c->gz_crc.release();
     (void)hipFree(c->counters); (void)hipFree(c->ovl_hist); (void)hipFree(c->dist_hist);
     for (int k = 0; k < 4; k++) {
         (void)hipFree(c->qc[k].acc);
@@ -856,7 +866,100 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
         HIP_TRY(hipGetLastError());
     }
     s->formatted = true;
+    s->compressed = false;
     return 0;
+}
+
+// ---- gzip output on the device (aqc_gzdev.hpp) --------------------------------------------------------------------------------
+static int ensure_gz_tables(aqc_ctx* c) {
+    if (c->gz_crc.p) return 0;
+    GzCrcTables t;
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t v = i;
+        for (int k = 0; k < 8; ++k) v = (v >> 1) ^ (0xEDB88320u & (0u - (v & 1u)));
+        t.byte_table[i] = v;
+    }
+    // "advance the CRC register by n zero bytes" is linear: column j is what zlib's crc32_combine makes of the unit vector
+    for (int k = 0; k < 8; ++k)
+        for (int j = 0; j < 32; ++j) t.shift[k][j] = (uint32_t)crc32_combine((uLong)(1u << j), 0UL, (z_off_t)(GZ_SEG << k));
+    if (c->gz_crc.reserve(sizeof(t))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemcpy(c->gz_crc.p, &t, sizeof(t), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int aqc_compress(aqc_ctx* c, int slot, int32_t level, uint64_t gz_bytes_out[6]) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!gz_bytes_out) return fail(AQC_ERR_ARG, "aqc_compress: null argument");
+    if (!s->formatted) return fail(AQC_ERR_STATE, "aqc_compress before aqc_format");
+    if (level < 1) return fail(AQC_ERR_UNSUPPORTED, "aqc_compress: level %d (stored output is the host writer's business)", level);
+    if ((rc = ensure_gz_tables(c))) return rc;
+    static_assert(sizeof(GzCodebookDev) == sizeof(aqcgz::GzCodebook), "host and device codebook layouts must agree");
+    GzJob J{};
+    uint32_t n_members = 0;
+    for (int q = 0; q < 6; ++q) {
+        J.text[q] = (const uint8_t*)s->f_out[q].p;
+        J.bytes[q] = s->f_bytes[q];
+        J.first_block[q] = n_members;
+        n_members += (uint32_t)((s->f_bytes[q] + GZ_TEXT - 1) / GZ_TEXT);
+        s->g_bytes[q] = 0;
+        gz_bytes_out[q] = 0;
+    }
+    J.first_block[6] = n_members;
+    s->compressed = true;
+    if (n_members == 0) return 0;
+    if (s->g_stage.reserve((size_t)n_members * GZ_SLOT) || s->g_sizes.reserve(4 * (size_t)n_members) || s->g_offsets.reserve(8 * (size_t)n_members) ||
+        s->g_total.reserve(64) || s->g_hist.reserve(6 * 320 * 4) || s->g_code.reserve(6 * sizeof(GzCodebookDev)))
+        return fail(AQC_ERR_HIP, "hipMalloc failed");
+    for (int q = 0; q < 6; ++q) {
+        const uint64_t nb = J.first_block[q + 1] - J.first_block[q];
+        if (s->g_packed[q].reserve(nb * (GZ_TEXT + 31) + 64)) return fail(AQC_ERR_HIP, "hipMalloc failed");
+        J.packed[q] = (uint8_t*)s->g_packed[q].p;
+    }
+    J.stage = (uint8_t*)s->g_stage.p; J.sizes = (uint32_t*)s->g_sizes.p; J.offsets = (uint64_t*)s->g_offsets.p; J.total = (uint64_t*)s->g_total.p;
+    J.hist = (uint32_t*)s->g_hist.p; J.code = (const GzCodebookDev*)s->g_code.p; J.crc = (const GzCrcTables*)c->gz_crc.p;
+    // 1. symbol counts of a sample of every stream's members
+    HIP_TRY(hipMemsetAsync(s->g_hist.p, 0, 6 * 320 * 4, s->stream));
+    hipLaunchKernelGGL(gz_hist_kernel, dim3(6 * GZ_SAMPLES), dim3(GZ_THREADS), 0, s->stream, J);
+    HIP_TRY(hipGetLastError());
+    uint32_t h[6][320];
+    HIP_TRY(hipMemcpyAsync(h, s->g_hist.p, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    // 2. one code per stream, built on the host with the routines of its own encoder
+    std::vector<aqcgz::GzCodebook> cb(6);
+    for (int q = 0; q < 6; ++q)
+        if (!aqcgz::build_codebook(h[q], h[q] + 286, &cb[q])) return fail(AQC_ERR_STATE, "aqc_compress: could not build a Huffman code");
+    HIP_TRY(hipMemcpyAsync(s->g_code.p, cb.data(), 6 * sizeof(aqcgz::GzCodebook), hipMemcpyHostToDevice, s->stream));
+    // 3. members, their places, the contiguous streams
+    hipLaunchKernelGGL(gz_encode_kernel, dim3(n_members), dim3(GZ_THREADS), 0, s->stream, J);
+    hipLaunchKernelGGL(gz_offsets_kernel, dim3(6), dim3(GZ_THREADS), 0, s->stream, J);
+    hipLaunchKernelGGL(gz_pack_kernel, dim3(n_members), dim3(GZ_THREADS), 0, s->stream, J);
+    HIP_TRY(hipGetLastError());
+    unsigned long long tot[6];
+    HIP_TRY(hipMemcpyAsync(tot, s->g_total.p, sizeof(tot), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));      // (cb and tot live on this stack frame)
+    for (int q = 0; q < 6; ++q) {
+        s->g_bytes[q] = tot[q];
+        gz_bytes_out[q] = tot[q];
+    }
+    return check_status(*s);
+}
+
+int aqc_fetch_gz(aqc_ctx* c, int slot, int file, int stream, uint8_t* dst, uint64_t cap) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!s->compressed) return fail(AQC_ERR_STATE, "aqc_fetch_gz before aqc_compress");
+    if (file < 0 || file > 1 || stream < 0 || stream > 2) return fail(AQC_ERR_ARG, "aqc_fetch_gz: bad file/stream");
+    const int q = file * 3 + stream;
+    if (s->g_bytes[q] > cap) return fail(AQC_ERR_ARG, "aqc_fetch_gz: %llu bytes do not fit %llu", (unsigned long long)s->g_bytes[q], (unsigned long long)cap);
+    if (s->g_bytes[q]) {
+        if (!dst) return fail(AQC_ERR_ARG, "aqc_fetch_gz: null destination");
+        HIP_TRY(hipMemcpyAsync(dst, s->g_packed[q].p, s->g_bytes[q], hipMemcpyDeviceToHost, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return check_status(*s);
 }
 
 int aqc_format(aqc_ctx* c, int slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]) {

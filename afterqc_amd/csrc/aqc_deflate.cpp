@@ -387,4 +387,75 @@ size_t deflate_block(const uint8_t* src, size_t n, int level, uint8_t* dst) {
     return (size_t)(o.finish() - dst);
 }
 
+// ---- a code for the DEVICE encoder (aqc_gzdev.hpp): one literal/length + distance code in which EVERY symbol has a code (it
+// is shared by all members of a stream, whatever bytes they hold), built from sampled symbol counts with the routines above,
+// plus the ready-made bits of the block header that announces it (BFINAL = 1, BTYPE = 2, HLIT, HDIST, HCLEN, code lengths).
+bool build_codebook(const uint32_t* lit_freq, const uint32_t* dist_freq, GzCodebook* cb) {
+    uint32_t freq[286], dfreq[30];
+    for (int s = 0; s < 286; ++s) freq[s] = lit_freq[s] + 1u;
+    for (int s = 0; s < 30; ++s) dfreq[s] = dist_freq[s] + 1u;
+    uint8_t ll[286], dl[30];
+    code_lengths(freq, 286, 15, ll);
+    code_lengths(dfreq, 30, 15, dl);
+    uint16_t lc[286], dc[30];
+    make_codes(ll, 286, lc);
+    make_codes(dl, 30, dc);
+    const int hlit = 286, hdist = 30;
+    uint8_t all[316];
+    memcpy(all, ll, 286);
+    memcpy(all + 286, dl, 30);
+    const int total = hlit + hdist;
+    uint8_t rsym[316], rext[316];
+    int nr = 0;
+    uint32_t clf[19] = {0};
+    for (int i = 0; i < total;) {
+        const uint8_t v = all[i];
+        int run = 1;
+        while (i + run < total && all[i + run] == v) ++run;
+        int left = run;
+        rsym[nr] = v; rext[nr++] = 0; clf[v]++; left--;            // (no zero lengths here: every symbol is coded)
+        while (left >= 3) { const int k = std::min(left, 6); rsym[nr] = 16; rext[nr++] = (uint8_t)(k - 3); clf[16]++; left -= k; }
+        while (left-- > 0) { rsym[nr] = v; rext[nr++] = 0; clf[v]++; }
+        i += run;
+    }
+    uint8_t cll[19];
+    uint16_t clc[19];
+    code_lengths(clf, 19, 7, cll);
+    {
+        int used = 0, first = -1;
+        for (int s = 0; s < 19; ++s) if (cll[s]) { used++; if (first < 0) first = s; }
+        if (used == 1) cll[first == 0 ? 1 : 0] = 1;
+    }
+    make_codes(cll, 19, clc);
+    auto complete = [](const uint8_t* l, int cnt, int maxb) {
+        uint32_t k = 0;
+        for (int s = 0; s < cnt; ++s) if (l[s]) k += (1u << maxb) >> l[s];
+        return k == (1u << maxb);
+    };
+    if (!complete(ll, 286, 15) || !complete(dl, 30, 15) || !complete(cll, 19, 7)) return false;
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    int hclen = 19;
+    while (hclen > 4 && cll[order[hclen - 1]] == 0) --hclen;
+    uint8_t buf[sizeof(cb->hdr) + 16];
+    memset(buf, 0, sizeof(buf));
+    BitOut o{buf};
+    uint64_t nbits = 0;
+    auto put = [&](uint64_t v, int n) { o.put(v, n); o.flush(); nbits += (uint64_t)n; };
+    put(1, 1); put(2, 2);
+    put((uint64_t)(hlit - 257), 5); put((uint64_t)(hdist - 1), 5); put((uint64_t)(hclen - 4), 4);
+    for (int k = 0; k < hclen; ++k) put(cll[order[k]], 3);
+    for (int k = 0; k < nr; ++k) {
+        put(clc[rsym[k]], cll[rsym[k]]);
+        if (rsym[k] == 16) put(rext[k], 2);
+    }
+    (void)o.finish();
+    if (nbits > 8 * sizeof(cb->hdr)) return false;
+    memset(cb, 0, sizeof(*cb));
+    memcpy(cb->hdr, buf, sizeof(cb->hdr));
+    cb->hdr_bits = (uint32_t)nbits;
+    for (int s = 0; s < 286; ++s) cb->lit[s] = (uint32_t)lc[s] | ((uint32_t)ll[s] << 16);
+    for (int s = 0; s < 30; ++s) cb->dist[s] = (uint32_t)dc[s] | ((uint32_t)dl[s] << 16);
+    return true;
+}
+
 }  // namespace aqcgz

@@ -128,4 +128,15 @@ private:
 size_t deflate_bound(size_t n);
 size_t deflate_block(const uint8_t* src, size_t n, int level, uint8_t* dst);
 
+// the shared code of the device encoder (aqc_gzdev.hpp: GzCodebookDev has this very layout): bit-reversed code | length << 16
+// for all 286 literal/length and 30 distance symbols, and the block header bits, from sampled symbol counts
+struct GzCodebook {
+    uint32_t lit[286];
+    uint32_t dist[30];
+    uint32_t hdr[192];
+    uint32_t hdr_bits;
+    uint32_t pad_[3];
+};
+bool build_codebook(const uint32_t* lit_freq /* [286] */, const uint32_t* dist_freq /* [30] */, GzCodebook* cb);
+
 }  // namespace aqcgz

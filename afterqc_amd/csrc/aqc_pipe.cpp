@@ -487,6 +487,8 @@ struct OutChunk {
     int set = -1;                // output buffer set (owned by a slot worker)
     int worker = -1;
     uint64_t sizes[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t gz_sizes[6] = {0, 0, 0, 0, 0, 0};      // the streams as gzip members made on the device (gz == true)
+    bool gz = false;
     uint64_t n = 0;
     bool last = false;
 };
@@ -562,6 +564,7 @@ struct Run {
     std::mutex set_mu;
     std::condition_variable set_cv;
     std::vector<char> set_free;        // [worker * 2 + set]
+    bool gz_on_device = false;
     // QC turn taking (post-filter sampling must be issued in chunk order, see aqc_qc_stat's time keys)
     std::mutex qc_mu;
     std::condition_variable qc_cv;
@@ -831,13 +834,18 @@ struct Run {
                 }
                 ns_wait_set += now_ns() - tt;
                 tt = now_ns();
+                // .gz output: the members are made on the device (aqc_gzdev.hpp) and come back compressed — no host CPU for
+                // deflate, a third of the bytes over PCIe.  --compression 0 (stored) and AQC_GZ_DEVICE=0 keep the host codec.
+                oc.gz = gz_on_device;
+                if (oc.gz && (rc = aqc_compress(c, slot, io->gzip_level, oc.gz_sizes))) { fail(rc, "aqc_compress: %s", aqc_last_error()); return; }
                 if (!gate_enter(dg, j.ticket, (uint64_t)P->slots)) return;
                 for (int q = 0; q < 6; ++q) {
                     if (!oc.sizes[q]) continue;
                     HostBuf& hb = P->wbufs[wid].out[set][q];
-                    hb.ensure(oc.sizes[q]);
-                    if (!hb.p) { fail(AQC_ERR_HIP, "page-locked allocation failed"); return; }
-                    if ((rc = aqc_fetch_text(c, slot, q / 3, q % 3, hb.p, hb.cap))) { gate_leave(dg); fail(rc, "aqc_fetch_text: %s", aqc_last_error()); return; }
+                    hb.ensure(oc.gz ? oc.gz_sizes[q] : oc.sizes[q]);
+                    if (!hb.p) { gate_leave(dg); fail(AQC_ERR_HIP, "page-locked allocation failed"); return; }
+                    rc = oc.gz ? aqc_fetch_gz(c, slot, q / 3, q % 3, hb.p, hb.cap) : aqc_fetch_text(c, slot, q / 3, q % 3, hb.p, hb.cap);
+                    if (rc) { gate_leave(dg); fail(rc, "fetching an output stream: %s", aqc_last_error()); return; }
                 }
                 gate_leave(dg);
                 ns_fetch += now_ns() - tt;
@@ -895,6 +903,7 @@ struct Run {
                 const uint8_t* p = P->wbufs[oc.worker].out[oc.set][q].p;
                 bool ok = true;
                 if (!io->gzip_out) ok = out[q].append(p, (size_t)oc.sizes[q]);
+                else if (oc.gz) ok = out[q].append(p, (size_t)oc.gz_sizes[q]);
                 else {
                     const size_t blk = 0xff00;                    // BGZF: at most 64 KiB per member, headers included (stored: text + 31 bytes)
                     const size_t nb = (oc.sizes[q] + blk - 1) / blk;
@@ -1050,6 +1059,10 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
         }
     }
     for (int q = 0; q < 6; ++q) R.fileq[q].reset(new BQueue<std::shared_ptr<Run::Commit>>(0));
+    {
+        const char* e = getenv("AQC_GZ_DEVICE");
+        R.gz_on_device = io->gzip_out && io->gzip_level >= 1 && !opt->no_output && !(e && e[0] == '0');
+    }
     const bool dbg = getenv("AQC_PIPE_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "pipe: outputs open at %.4f s\n", now_s() - t0);
     std::vector<std::thread> fw;

@@ -301,6 +301,14 @@ int aqc_format(aqc_ctx* ctx, int slot, uint64_t n, int32_t store_overlap, uint64
 int aqc_format_plain(aqc_ctx* ctx, int slot, int verdict_slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]);
 /* copy one formatted stream (file 0/1, stream 0 good / 1 bad / 2 overlap) to host memory and wait for it */
 int aqc_fetch_text(aqc_ctx* ctx, int slot, int file, int stream, uint8_t* dst, uint64_t cap);
+/* gzip output built on the device (fastq.Writer with a ".gz" name, fastq.py:65-68; --compression, after.py:91-92): the six
+ * formatted streams of the slot become BGZF-compatible gzip members in HBM (<= 0xff00 bytes of text each: one dynamic-Huffman
+ * block; matches = runs and "same column, four lines up"; one shared code per stream and call, built by the host from sampled
+ * symbol counts; CRC-32 on the device).  gz_bytes_out[file * 3 + stream] = compressed bytes; aqc_fetch_gz copies one
+ * compressed stream to host memory and waits for it.  Streams concatenate into valid .gz files; what they decompress to is
+ * byte for byte what aqc_fetch_text hands out.  level >= 1 (stored output, level 0, stays with the host writer). */
+int aqc_compress(aqc_ctx* ctx, int slot, int32_t level, uint64_t gz_bytes_out[6]);
+int aqc_fetch_gz(aqc_ctx* ctx, int slot, int file, int stream, uint8_t* dst, uint64_t cap);
 /* page-locked host memory for text chunks and fetched streams (hipHostMalloc): full-rate DMA */
 void* aqc_host_alloc(uint64_t bytes);
 void aqc_host_free(void* p);

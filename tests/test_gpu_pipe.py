@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from afterqc_amd import after, preprocesser, synth
+from afterqc_amd import after, capi, preprocesser, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -116,3 +116,40 @@ def test_pipe_reports_irregular_inputs(tmp_path):
     assert stat["afterqc_main_summary"]["total_reads"] == 2500
     files2, stat2, _ = run(work, r1, r2, ["-f", "0", "-t", "0"], tag="short_serial", use_pipe=False, devices=[0])
     assert files == files2 and stat == stat2
+
+
+def test_device_gzip_members(gpu_engine):
+    """aqc_compress / aqc_fetch_gz: the formatted streams as gzip members built on the device decompress (Python's gzip
+    module = zlib: header, dynamic-Huffman block, CRC-32, ISIZE all checked by it) to exactly what aqc_fetch_text hands out;
+    odd sizes: a stream of less than one member, of exactly one, with a short tail member; and the ratio is sane"""
+    import gzip
+    for n_pairs, L, seed in ((40, 100, 5), (94, 150, 6), (30000, 150, 7), (2500, 250, 8)):
+        d = synth.make_pairs(n_pairs, L, seed=seed, dirty=True)
+        t1, n1 = synth.render_fastq_fixed(d["seq1"], d["qual1"], 1)
+        t2, n2 = synth.render_fastq_fixed(d["seq2"], d["qual2"], 2)
+        cfg = capi.Config()
+        cfg.paired = 1
+        cfg.seq_len_req, cfg.poly_size_limit, cfg.allow_mismatch_in_poly = 35, 35, 2
+        cfg.qualified_quality_phred, cfg.unqualified_base_limit, cfg.n_base_limit = 15, 60, 5
+        cfg.barcode_length = 12
+        cfg.set_verify("CAGTA")
+        cfg.qc_kmer = 8
+        gpu_engine.set_config(cfg)
+        gpu_engine.reset_stats()
+        info = gpu_engine.frame(0, t1, n1, True, t2, n2, True)
+        gpu_engine.run(0)
+        sizes = gpu_engine.format(0, int(info.n), True)
+        gz = gpu_engine.compress(0, 2)
+        assert sum(sizes) > 0
+        for q, (nb, zb) in enumerate(zip(sizes, gz)):
+            assert (nb == 0) == (zb == 0)
+            if not nb:
+                continue
+            text = np.zeros(nb + 64, dtype=np.uint8)
+            gpu_engine.fetch_text(0, q // 3, q % 3, text, text.size)
+            comp = np.zeros(zb + 64, dtype=np.uint8)
+            gpu_engine.fetch_gz(0, q // 3, q % 3, comp, comp.size)
+            back = gzip.decompress(comp[:zb].tobytes())
+            assert back == text[:nb].tobytes(), (n_pairs, q, nb, zb, len(back))
+            if nb > 200000:
+                assert zb < nb / 2.2, (nb, zb)                  # FASTQ: well below half

@@ -173,7 +173,9 @@ def test_directory_mode_two_workers_on_gpu0(tmp_path, monkeypatch):
     assert after.visible_devices() == [0, 0]
     stats = after.processDir(work, options)
     assert len(stats) == 4 and all(s is not None for s in stats)
+    by_file = {os.path.basename(s["command"]["read1_file"]): s for s in stats}       # (the folder is listed in no particular order)
     for k, (q1, q2) in enumerate(pairs):
+        stat_k = by_file[os.path.basename(q1)]
         ref_stat, ref_files = run(str(tmp_path), q1, q2, "text", "solo%d" % k)       # (oracle engine, serial loop)
         for fn, data in ref_files.items():
             if fn.startswith(("good/", "bad/")):
@@ -181,7 +183,7 @@ def test_directory_mode_two_workers_on_gpu0(tmp_path, monkeypatch):
                     assert f.read() == data, fn
         for key in ref_stat:
             if key != "command":
-                assert json.dumps(stats[k][key], sort_keys=True) == json.dumps(ref_stat[key], sort_keys=True), (k, key)
+                assert json.dumps(stat_k[key], sort_keys=True) == json.dumps(ref_stat[key], sort_keys=True), (k, key)
         assert os.path.exists(os.path.join(work, "QC", os.path.basename(q1) + ".html"))
 
 
