@@ -79,6 +79,8 @@ struct Slot {
     uint64_t g_bytes[6] = {0, 0, 0, 0, 0, 0};
     bool compressed = false;
     bool framed = false, formatted = false;
+    hipEvent_t ev_main = nullptr, ev_qc = nullptr;     // ordering between the slot's stream and the context's QC stream
+    bool qc_pending = false;                           // QC kernels of this slot may still run on the QC stream
     aqc_text_chunk last_chunk{};   // what the slot's arenas hold (aqc_reframe)
     uint8_t last_byte[2] = {'\n', '\n'};
     uint32_t max_len = 0;
@@ -111,6 +113,17 @@ static hipEvent_t launch_event(Slot& s, int k, int which) {
     return s.ev[k][which];
 }
 
+// everything queued for the slot has finished: its own stream and, if statRead kernels of this slot were sent to the
+// context's QC stream, those too
+static hipError_t slot_sync(Slot& s) {
+    hipError_t e = hipStreamSynchronize(s.stream);
+    if (e == hipSuccess && s.qc_pending) {
+        e = hipEventSynchronize(s.ev_qc);
+        s.qc_pending = false;
+    }
+    return e;
+}
+
 constexpr uint64_t KMER_CAP = 1ull << 21;
 constexpr uint64_t DENSE_CAP = (uint64_t)N_XCD * DENSE_ENTRIES;   // 4^8 pure A/C/G/T k-mers, one copy per XCD
 
@@ -135,6 +148,7 @@ struct aqc_ctx {
     DevBuf circ[5];
     DevBuf kmer_partial;          // per-round u16 count slices of kmer_count_kernel
     DevBuf gz_crc;                // GzCrcTables (aqc_compress)
+    hipStream_t qc_stream = nullptr;   // statRead kernels (latency-bound, a few thousand waves) run beside the slots' bandwidth-bound kernels
     DevCircles circles{};
     unsigned long long *counters = nullptr, *ovl_hist = nullptr, *dist_hist = nullptr;
     QcDev qc[4];
@@ -208,10 +222,13 @@ int aqc_create(int device, int n_slots, aqc_ctx** out) {
     const char* fg = getenv("AQC_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
     HIP_TRY(hipFuncSetAttribute((const void*)kmer_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KMER_FUSED_LDS_BYTES));
+    HIP_TRY(hipStreamCreateWithFlags(&c->qc_stream, hipStreamNonBlocking));
     for (auto& s : c->slots) {
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         for (int k = 0; k < AQC_N_KERNELS; k++)
             for (int j = 0; j < 2; j++) HIP_TRY(hipEventCreate(&s.ev[k][j]));
+        HIP_TRY(hipEventCreateWithFlags(&s.ev_main, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.ev_qc, hipEventDisableTiming));
     }
     HIP_TRY(hipMalloc((void**)&c->counters, sizeof(unsigned long long) * (AQC_N_COUNTERS + 16)));   // +16: AQC_PROFILE builds
     HIP_TRY(hipMalloc((void**)&c->ovl_hist, sizeof(unsigned long long) * AQC_QC_COLS));
@@ -246,8 +263,11 @@ void aqc_destroy(aqc_ctx* c) {
                 for (hipEvent_t e : s.ring[k][j]) (void)hipEventDestroy(e);
             }
         if (s.status) (void)hipFree(s.status);
+        if (s.ev_main) (void)hipEventDestroy(s.ev_main);
+        if (s.ev_qc) (void)hipEventDestroy(s.ev_qc);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
+    if (c->qc_stream) (void)hipStreamDestroy(c->qc_stream);
     for (auto& b : c->circ) b.release();
     c->kmer_partial.release();
     c->gz_crc.release();
@@ -368,7 +388,7 @@ static int fill_slot(aqc_ctx* c, Slot& s, const aqc_batch* b, bool need_qual, bo
     const uint64_t lim = (1ull << 32) - 4096;      // 32-bit byte offsets on the device, chunk loads may run 288 bytes past a read's start
     if (b->bytes1 >= lim || b->qbytes1 >= lim || b->bytes2 >= lim || b->qbytes2 >= lim) return fail(AQC_ERR_ARG, "batch: an arena must be smaller than 4 GiB (split the batch)");
     // make sure earlier work on this slot has drained before its buffers are overwritten / regrown
-    HIP_TRY(hipStreamSynchronize(s.stream));
+    HIP_TRY(slot_sync(s));
     int rc;
     DevBatch v{};
     v.n = n;
@@ -472,6 +492,7 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
     aqc_config cfg = c->cfg;
     if (!cfg.paired) cfg.no_overlap = 1;
     DevStats st{c->counters, c->ovl_hist, c->dist_hist, s->status};
+    if (s->qc_pending) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_qc, 0));      // (statRead of the previous run still reads the results)
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_FILTER_OVERLAP, 0), s->stream));
     // lane-per-pair kernel whenever its preconditions hold; the general wave-per-record kernel otherwise
     const int thr = cfg.qualified_quality_phred + 33;
@@ -547,7 +568,13 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
     if (count == 0) return 0;
     QcDev& q = c->qc[which];
     if ((rc = ensure_kmer(c, q))) return rc;
-    HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 0), s->stream));
+    // the statRead kernels go to the context's QC stream, behind everything queued on the slot's stream so far (text, results):
+    // a few thousand latency-bound waves that overlap with the slot's bandwidth-bound kernels (the formatter) instead of
+    // holding them up.  The slot is "in sync" again only when they are done too (slot_sync).
+    hipStream_t qs = c->qc_stream;
+    HIP_TRY(hipEventRecord(s->ev_main, s->stream));
+    HIP_TRY(hipStreamWaitEvent(qs, s->ev_main, 0));
+    HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 0), qs));
     // LDS sized by the longest read of the slot: many resident workgroups for short reads
     const uint32_t mx = s->raw_max_len ? s->raw_max_len : AQC_MAX_READ_LEN;
     int cols = (int)((mx + 63) / 64 * 64);
@@ -572,7 +599,7 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
     const uint64_t rounds_per_block = (max_rounds + c->n_cu - 1) / c->n_cu;
     const bool fused = cols <= KMER_FUSED_MAX_COLS && rounds_per_block * rpr_max <= (uint64_t)QC_MAX_READS_PER_BLOCK;
     if (!fused)
-        hipLaunchKernelGGL(qc_stat_kernel, dim3((unsigned)blocks), dim3(QC_BLOCK), lds, s->stream, s->view, mate, first, count, post,
+        hipLaunchKernelGGL(qc_stat_kernel, dim3((unsigned)blocks), dim3(QC_BLOCK), lds, qs, s->view, mate, first, count, post,
                            (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, s->status, cols);
     // k-mer dictionary: LDS-resident u16 counters, rounds of <= 65535 k-mers per workgroup, slices reduced afterwards
     {
@@ -590,17 +617,19 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
             const uint32_t n_rounds = (uint32_t)((chunk + rpr - 1) / rpr);
             if (c->kmer_partial.reserve((size_t)n_rounds * DENSE_ENTRIES * sizeof(uint16_t))) return fail(AQC_ERR_HIP, "hipMalloc failed");
             unsigned kb = n_rounds < (unsigned)c->n_cu ? n_rounds : (unsigned)c->n_cu;
-            hipLaunchKernelGGL(kmer_count_kernel, dim3(kb), dim3(KMER_BLOCK), fused ? KMER_FUSED_LDS_BYTES : KMER_LDS_BYTES, s->stream, s->view,
+            hipLaunchKernelGGL(kmer_count_kernel, dim3(kb), dim3(KMER_BLOCK), fused ? KMER_FUSED_LDS_BYTES : KMER_LDS_BYTES, qs, s->view,
                                mate, first + done, chunk, post, (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.kt, order_base + done,
                                (uint16_t*)c->kmer_partial.p, rpr, n_rounds, s->status, fused ? q.acc : (unsigned long long*)nullptr,
                                fused ? cols : 0);
-            hipLaunchKernelGGL(kmer_reduce_kernel, dim3(DENSE_ENTRIES / KRED_ENTRIES), dim3(KRED_BLOCK), 0, s->stream,
+            hipLaunchKernelGGL(kmer_reduce_kernel, dim3(DENSE_ENTRIES / KRED_ENTRIES), dim3(KRED_BLOCK), 0, qs,
                                (const uint16_t*)c->kmer_partial.p, n_rounds, q.kt, c->cfg.qc_kmer);
             done += chunk;
         }
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 1), s->stream));
+    HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 1), qs));
+    HIP_TRY(hipEventRecord(s->ev_qc, qs));
+    s->qc_pending = true;
     s->timed[AQC_K_QC_STAT] = !s->collecting;
     return 0;
 }
@@ -618,7 +647,7 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
     const int final_[2] = {ch->final1, ch->final2};
     for (int k = 0; k < nf; k++)
         if (bytes[k] >= (1ull << 31) - IDX_TILE) return fail(AQC_ERR_ARG, "aqc_frame: chunks must be < 2 GiB");
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(slot_sync(*s));
     s->framed = s->formatted = false;
     s->ran = false;
     DevBuf* arena[2] = {&s->seq1, &s->seq2};
@@ -663,7 +692,7 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
                            (unsigned long long*)s->t_tile[0].p, (unsigned int*)((unsigned long long*)s->t_tile[0].p + all_tiles));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long) * nf, hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(slot_sync(*s));
         bool fits = true;
         for (int k = 0; k < nf; k++)
             if (h_tot[k] > cap[k]) {
@@ -685,7 +714,7 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
         if (virt) {
             const uint32_t end = (uint32_t)bytes[k] | LINE_WS;          // (may end in blanks: let the framing kernel look)
             HIP_TRY(hipMemcpyAsync((uint32_t*)s->t_line_end[k].p + lines[k], &end, sizeof(end), hipMemcpyHostToDevice, s->stream));
-            HIP_TRY(hipStreamSynchronize(s->stream));      // `end` lives on this stack frame
+            HIP_TRY(slot_sync(*s));      // `end` lives on this stack frame
             lines[k] += 1;
         }
         nrec[k] = lines[k] / 4;
@@ -704,7 +733,7 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_meta, d_meta, sizeof(h_meta), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(slot_sync(*s));
     // 3. lock-step record count (preprocesser.py:412-429)
     uint64_t avail[2] = {0, 0};
     for (int k = 0; k < nf; k++) avail[k] = h_meta[k].first_empty < nrec[k] ? h_meta[k].first_empty : nrec[k];
@@ -757,7 +786,7 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
             HIP_TRY(hipMemcpyAsync(&h_end[k], (const uint32_t*)s->t_line_end[k].p + (4 * n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     }
     if (avail[0] > n) HIP_TRY(hipMemcpyAsync(&h_next, (const uint32_t*)s->len1.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(slot_sync(*s));
     uint64_t consumed[2] = {0, 0};
     for (int k = 0; k < nf; k++)
         if (n) consumed[k] = (uint64_t)(h_end[k] & LINE_POS) + 1 < bytes[k] ? (uint64_t)(h_end[k] & LINE_POS) + 1 : bytes[k];
@@ -791,7 +820,7 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
     if (!s->framed) return fail(AQC_ERR_STATE, "aqc_format needs a slot filled by aqc_frame");
     if (!vs->ran) return fail(AQC_ERR_STATE, "aqc_format before aqc_run");
     if (n > s->n || n > vs->n) return fail(AQC_ERR_ARG, "aqc_format: n exceeds the slot's records");
-    if (plain) HIP_TRY(hipStreamSynchronize(vs->stream));      // the verdicts come from another slot's stream
+    if (plain) HIP_TRY(slot_sync(*vs));      // the verdicts come from another slot's stream
     FormatView v{};
     v.paired = s->paired ? 1 : 0;
     v.results = (const aqc_result*)vs->results.p;
@@ -1002,7 +1031,7 @@ int aqc_sync(aqc_ctx* c, int slot) {
     Slot* s;
     int rc = get_slot(c, slot, &s);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(slot_sync(*s));
     return check_status(*s);
 }
 
@@ -1013,7 +1042,7 @@ int aqc_fetch_results(aqc_ctx* c, int slot, aqc_result* out, uint64_t n) {
     if (!s->ran) return fail(AQC_ERR_STATE, "aqc_fetch_results before aqc_run");
     if (n > s->n) return fail(AQC_ERR_ARG, "aqc_fetch_results: n exceeds the slot's records");
     if (n) HIP_TRY(hipMemcpyAsync(out, s->results.p, sizeof(aqc_result) * n, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(slot_sync(*s));
     return check_status(*s);
 }
 
@@ -1023,7 +1052,7 @@ int aqc_last_deferred(aqc_ctx* c, int slot, uint32_t* idx, uint64_t cap, uint64_
     if (rc) return rc;
     if (!n) return fail(AQC_ERR_ARG, "aqc_last_deferred: null argument");
     if (!s->ran) return fail(AQC_ERR_STATE, "aqc_last_deferred before aqc_run");
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(slot_sync(*s));
     *n = 0;
     if (!s->used_fast || !s->n_deferred.p) return 0;
     unsigned int m = 0;
@@ -1038,7 +1067,7 @@ int aqc_kernel_ms(aqc_ctx* c, int slot, float* ms) {
     Slot* s;
     int rc = get_slot(c, slot, &s);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(slot_sync(*s));
     for (int k = 0; k < AQC_N_KERNELS; k++) {
         ms[k] = 0.f;
         if (s->timed[k]) HIP_TRY(hipEventElapsedTime(&ms[k], s->ev[k][0], s->ev[k][1]));
@@ -1050,7 +1079,7 @@ int aqc_timing_reset(aqc_ctx* c, int slot) {
     Slot* s;
     int rc = get_slot(c, slot, &s);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(slot_sync(*s));
     for (int k = 0; k < AQC_N_KERNELS; k++) { s->ring_used[k] = 0; s->timed[k] = false; }
     s->collecting = true;
     return 0;
@@ -1061,7 +1090,7 @@ int aqc_timing_mean(aqc_ctx* c, int slot, float* mean_ms, int32_t* launches) {
     int rc = get_slot(c, slot, &s);
     if (rc) return rc;
     if (!mean_ms || !launches) return fail(AQC_ERR_ARG, "null argument");
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(slot_sync(*s));
     for (int k = 0; k < AQC_N_KERNELS; k++) {
         double sum = 0;
         for (int i = 0; i < s->ring_used[k]; i++) {
@@ -1079,7 +1108,7 @@ int aqc_timing_mean(aqc_ctx* c, int slot, float* mean_ms, int32_t* launches) {
 static int sync_all(aqc_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     for (auto& s : c->slots) {
-        HIP_TRY(hipStreamSynchronize(s.stream));
+        HIP_TRY(slot_sync(s));
         int rc = check_status(s);
         if (rc) return rc;
     }
@@ -1224,7 +1253,7 @@ int aqc_overlap(aqc_ctx* c, const aqc_batch* b, int32_t* offset, int32_t* overla
                        (int32_t*)o[0].p, (int32_t*)o[1].p, (int32_t*)o[2].p);
     HIP_TRY(hipGetLastError());
     if ((rc = seam_out(s, o[0], offset, n)) || (rc = seam_out(s, o[1], overlap_len, n)) || (rc = seam_out(s, o[2], diff, n))) return rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(slot_sync(*s));
     for (auto& d : o) d.release();
     return 0;
 }
@@ -1242,7 +1271,7 @@ int aqc_read_stats(aqc_ctx* c, const aqc_batch* b, int32_t max_poly, int32_t mis
                        max_poly, mismatch, qual, (uint8_t*)o[0].p, (int32_t*)o[1].p, (int32_t*)o[2].p);
     HIP_TRY(hipGetLastError());
     if ((rc = seam_out(s, o[0], polyx, n)) || (rc = seam_out(s, o[1], low_qual, n)) || (rc = seam_out(s, o[2], n_count, n))) return rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(slot_sync(*s));
     for (auto& d : o) d.release();
     return 0;
 }
@@ -1259,7 +1288,7 @@ int aqc_edit_distance(aqc_ctx* c, const aqc_batch* b, int32_t* dist) {
                        (int32_t*)o.p, s->status);
     HIP_TRY(hipGetLastError());
     if ((rc = seam_out(s, o, dist, n))) return rc;
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(slot_sync(*s));
     o.release();
     return check_status(*s);
 }

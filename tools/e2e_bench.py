@@ -31,7 +31,11 @@ def main():
     ap.add_argument("--dir", default="/tmp/aqc_e2e")
     ap.add_argument("--single", action="store_true")
     ap.add_argument("--keep", action="store_true")
-    ap.add_argument("--gz", action="store_true", help="gzip input (and therefore, like upstream, gzip output)")
+    ap.add_argument("--gz", action="store_true", help="gzip input (and therefore, like upstream, gzip output): ONE gzip member per file, "
+                    "made with `gzip -<level>` — what real-world .fq.gz files are")
+    ap.add_argument("--gz-level", type=int, default=6, help="level of the single-member .gz inputs (gzip's default: 6)")
+    ap.add_argument("--bgzf", action="store_true", help="with --gz: inputs as BGZF-style independent 64 KiB members instead (the pipe's own "
+                    "writer's format; member-parallel inflate)")
     ap.add_argument("--config5", action="store_true", help="config-5 flavour: 2x250 bp + 17 bp barcode/verify prefix, file names with 'barcode', --debubble with a circles.csv")
     args = ap.parse_args()
     from afterqc_amd import after, preprocesser, synth
@@ -50,9 +54,21 @@ def main():
             f.write("x,y,radius,lane,tile\n")
             for k in range(8):
                 f.write("%r,%r,%r,1,101\n" % (250000.0 * (k + 1), 50000.0, 3000.0 + 100.0 * k))
-    synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
-    if not args.single:
-        synth.write_fastq_fixed(r2, d["seq2"], d["qual2"], 2)
+    if args.gz and not args.bgzf:
+        # single-member .gz: plain text first, then the gzip program (both mates at once)
+        import subprocess
+        jobs = []
+        for path, mate in ((r1, 1),) + (() if args.single else ((r2, 2),)):
+            plain = path[:-3]
+            synth.write_fastq_fixed(plain, d["seq%d" % mate], d["qual%d" % mate], mate)
+            jobs.append((subprocess.Popen(["gzip", "-%d" % args.gz_level, "-c", plain], stdout=open(path, "wb")), plain))
+        for pr, plain in jobs:
+            assert pr.wait() == 0
+            os.unlink(plain)
+    else:
+        synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
+        if not args.single:
+            synth.write_fastq_fixed(r2, d["seq2"], d["qual2"], 2)
     del d
     gen_s = time.perf_counter() - t
     argv = ["-1", r1] + ([] if args.single else ["-2", r2]) + ["-f", "0", "-t", "0", "-g", os.path.join(args.dir, "good"),
@@ -72,7 +88,7 @@ def main():
     reads = args.pairs * (1 if args.single else 2)
     in_bytes = os.path.getsize(r1) + (0 if args.single else os.path.getsize(r2))
     s = stat["afterqc_main_summary"]
-    out = {"mode": args.mode, "gz": args.gz, "pairs": args.pairs, "reads": reads, "input_bytes": in_bytes, "gen_s": round(gen_s, 1),
+    out = {"mode": args.mode, "gz": ("bgzf" if args.bgzf else "single member, gzip -%d" % args.gz_level) if args.gz else False, "pairs": args.pairs, "reads": reads, "input_bytes": in_bytes, "gen_s": round(gen_s, 1),
            "wall_s": round(wall, 3), "pass1_s": round(flt.timing["pass1_s"], 3), "pass2_s": round(flt.timing["pass2_s"], 3),
            "e2e_mreads_s": round(reads / wall / 1e6, 3), "pass2_mreads_s": round(reads / flt.timing["pass2_s"] / 1e6, 3),
            "pass2_input_gb_s": round(in_bytes / flt.timing["pass2_s"] / 1e9, 3),
