@@ -19,6 +19,7 @@
 #include "aqc_fast.hpp"
 #include "aqc_text.hpp"
 #include "aqc_gzdev.hpp"
+#include "aqc_gunzip_dev.hpp"
 #include "aqc_gz.hpp"
 #include <zlib.h>
 
@@ -989,6 +990,129 @@ int aqc_fetch_gz(aqc_ctx* c, int slot, int file, int stream, uint8_t* dst, uint6
     }
     HIP_TRY(hipStreamSynchronize(s->stream));
     return check_status(*s);
+}
+
+// ---- gzip input on the device (aqc_gunzip_dev.hpp) ------------------------------------------------------------------------------
+namespace {
+
+struct GzdDevice {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf comp, sec_start, sec_end, sec_flags, sec_nsym, sym, text, sec_off, result;
+    uint32_t section_bytes = 128u << 10, max_sections = 1024;
+    uint32_t sym_cap = 0;
+    // result of the last batch
+    uint64_t n_text = 0, end_bit = 0;
+    uint32_t accepted = 0, n_sections = 0;
+    bool final_block = false, corrupt = false;
+    float ms_find = 0, ms_decode = 0, ms_chain = 0, ms_resolve = 0;
+    hipEvent_t ev[5] = {};
+
+    int init(int dev) {
+        device = dev;
+        HIP_TRY(hipSetDevice(dev));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+        sym_cap = section_bytes * 10u;
+        return 0;
+    }
+    void release() {
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        DevBuf* b[] = {&comp, &sec_start, &sec_end, &sec_flags, &sec_nsym, &sym, &text, &sec_off, &result};
+        for (DevBuf* x : b) x->release();
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+    // one batch: the deflate data of data[0, size) from the block boundary at bit `start_bit` on, with the `wl` bytes of output
+    // before it in `window`.  The text of the sections that chained up stays in this->text (device) until the next call.
+    int decode(const uint8_t* data, uint64_t size, uint64_t start_bit, const uint8_t* window, size_t wl) {
+        HIP_TRY(hipSetDevice(device));
+        const uint64_t byte0 = (start_bit >> 3) & ~(uint64_t)3;
+        const uint64_t left = size - byte0;
+        uint64_t nsec = (left + section_bytes - 1) / section_bytes;
+        if (nsec > max_sections) nsec = max_sections;
+        const uint64_t span = std::min<uint64_t>(left, nsec * (uint64_t)section_bytes + (4u << 20));     // + room to finish the last block
+        n_sections = (uint32_t)nsec;
+        if (comp.reserve(span + 128) || sec_start.reserve(8 * nsec) || sec_end.reserve(8 * nsec) || sec_flags.reserve(4 * nsec) ||
+            sec_nsym.reserve(4 * nsec) || sec_off.reserve(8 * (nsec + 1)) || result.reserve(64) ||
+            sym.reserve((size_t)nsec * sym_cap * 2) || text.reserve(32768 + (size_t)nsec * sym_cap + 64))
+            return fail(AQC_ERR_HIP, "hipMalloc failed (device gunzip)");
+        HIP_TRY(hipMemcpyAsync(comp.p, data + byte0, span, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync((uint8_t*)comp.p + span, 0, 128, stream));
+        if (wl) HIP_TRY(hipMemcpyAsync((uint8_t*)text.p + 32768 - wl, window, wl, hipMemcpyHostToDevice, stream));
+        GzdJob J{};
+        J.comp = (const uint8_t*)comp.p; J.comp_bytes = span; J.start_bit = start_bit - byte0 * 8; J.n_sections = n_sections;
+        J.section_bytes = section_bytes;
+        J.sec_start = (uint64_t*)sec_start.p; J.sec_end = (uint64_t*)sec_end.p; J.sec_flags = (uint32_t*)sec_flags.p; J.sec_nsym = (uint32_t*)sec_nsym.p;
+        J.sym = (uint16_t*)sym.p; J.sym_cap = sym_cap; J.text = (uint8_t*)text.p + 32768; J.window_valid_from = (uint32_t)(32768 - wl);
+        J.sec_off = (uint64_t*)sec_off.p; J.result = (uint32_t*)result.p;
+        HIP_TRY(hipEventRecord(ev[0], stream));
+        hipLaunchKernelGGL(gzd_find_kernel, dim3(n_sections), dim3(WAVE), 0, stream, J);
+        HIP_TRY(hipEventRecord(ev[1], stream));
+        hipLaunchKernelGGL(gzd_decode_kernel, dim3(n_sections), dim3(WAVE), 0, stream, J);
+        HIP_TRY(hipEventRecord(ev[2], stream));
+        hipLaunchKernelGGL(gzd_chain_kernel, dim3(1), dim3(GZD_CHAIN_THREADS), 0, stream, J);
+        HIP_TRY(hipEventRecord(ev[3], stream));
+        hipLaunchKernelGGL(gzd_resolve_kernel, dim3(32, n_sections), dim3(256), 0, stream, J);
+        HIP_TRY(hipEventRecord(ev[4], stream));
+        HIP_TRY(hipGetLastError());
+        uint32_t r[8] = {0};
+        HIP_TRY(hipMemcpyAsync(r, result.p, sizeof(r), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        accepted = r[0];
+        corrupt = r[1] != 0;
+        final_block = r[2] != 0;
+        end_bit = byte0 * 8 + (((uint64_t)r[5] << 32) | r[4]);
+        n_text = ((uint64_t)r[7] << 32) | r[6];
+        (void)hipEventElapsedTime(&ms_find, ev[0], ev[1]);
+        (void)hipEventElapsedTime(&ms_decode, ev[1], ev[2]);
+        (void)hipEventElapsedTime(&ms_chain, ev[2], ev[3]);
+        (void)hipEventElapsedTime(&ms_resolve, ev[3], ev[4]);
+        return 0;
+    }
+    int fetch(uint64_t off, uint64_t n, uint8_t* dst) {
+        HIP_TRY(hipSetDevice(device));
+        if (n) HIP_TRY(hipMemcpyAsync(dst, (const uint8_t*)text.p + 32768 + off, n, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return 0;
+    }
+};
+
+}  // namespace
+
+// test / measurement entry: ONE gzip member decoded entirely by the device path (no host decoding: a section that does not
+// chain up ends the run with an error).  stats: batches, sections accepted, ms in find / decode / chain / resolve kernels (x1000)
+int aqc_gunzip_dev_selftest(int device, const uint8_t* gz, uint64_t size, uint8_t* out, uint64_t cap, uint64_t* n_out, uint64_t stats[8]) {
+    if (!gz || !out || !n_out || !stats) return fail(AQC_ERR_ARG, "null argument");
+    const size_t h = aqcgz::parse_gzip_header(gz, (size_t)size, 0);
+    if (!h) return fail(AQC_ERR_ARG, "not a gzip file");
+    GzdDevice D;
+    int rc = D.init(device);
+    if (rc) return rc;
+    memset(stats, 0, 8 * sizeof(uint64_t));
+    uint64_t bit = (uint64_t)h * 8, produced = 0;
+    std::vector<uint8_t> window;
+    for (;;) {
+        if ((rc = D.decode(gz, size, bit, window.data(), window.size()))) break;
+        stats[0] += 1; stats[1] += D.accepted;
+        stats[2] += (uint64_t)(D.ms_find * 1000); stats[3] += (uint64_t)(D.ms_decode * 1000); stats[4] += (uint64_t)(D.ms_chain * 1000); stats[5] += (uint64_t)(D.ms_resolve * 1000);
+        if (D.corrupt) { rc = fail(AQC_ERR_ARG, "corrupt stream (marker before the member start)"); break; }
+        if (D.accepted == 0 || D.n_text == 0) { rc = fail(AQC_ERR_STATE, "device gunzip: no section chained up at bit %llu (batch %llu)", (unsigned long long)bit, (unsigned long long)stats[0]); break; }
+        if (produced + D.n_text > cap) { rc = fail(AQC_ERR_ARG, "output does not fit"); break; }
+        if ((rc = D.fetch(0, D.n_text, out + produced))) break;
+        produced += D.n_text;
+        const size_t wl = (size_t)std::min<uint64_t>(32768, produced);
+        window.assign(out + produced - wl, out + produced);
+        bit = D.end_bit;
+        stats[6] = bit;
+        if (D.final_block) break;
+        if (D.accepted < D.n_sections && D.end_bit / 8 + 64 >= size) break;
+    }
+    *n_out = produced;
+    D.release();
+    return rc;
 }
 
 int aqc_format(aqc_ctx* c, int slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]) {

@@ -309,6 +309,10 @@ int aqc_fetch_text(aqc_ctx* ctx, int slot, int file, int stream, uint8_t* dst, u
  * byte for byte what aqc_fetch_text hands out.  level >= 1 (stored output, level 0, stays with the host writer). */
 int aqc_compress(aqc_ctx* ctx, int slot, int32_t level, uint64_t gz_bytes_out[6]);
 int aqc_fetch_gz(aqc_ctx* ctx, int slot, int file, int stream, uint8_t* dst, uint64_t cap);
+/* gzip INPUT decoded on the device (csrc/aqc_gunzip_dev.hpp), test / measurement entry: the one gzip member at gz[0, size) is
+ * decoded entirely by the device path into out (a section that does not chain up is an error here; in the pipe the host
+ * decoder takes over).  stats: batches, sections accepted, microseconds in the find / decode / chain / resolve kernels, end bit */
+int aqc_gunzip_dev_selftest(int device, const uint8_t* gz, uint64_t size, uint8_t* out, uint64_t cap, uint64_t* n_out, uint64_t stats[8]);
 /* page-locked host memory for text chunks and fetched streams (hipHostMalloc): full-rate DMA */
 void* aqc_host_alloc(uint64_t bytes);
 void aqc_host_free(void* p);

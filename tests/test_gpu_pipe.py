@@ -153,3 +153,33 @@ def test_device_gzip_members(gpu_engine):
             assert back == text[:nb].tobytes(), (n_pairs, q, nb, zb, len(back))
             if nb > 200000:
                 assert zb < nb / 2.2, (nb, zb)                  # FASTQ: well below half
+
+
+@pytest.mark.parametrize("level,strategy", [(1, "default"), (6, "default"), (9, "default"), (6, "huffman"), (6, "fixed")])
+def test_device_gunzip_sections_are_exact(level, strategy):
+    """csrc/aqc_gunzip_dev.hpp (groundwork, not yet in the pipe — DESIGN.md §8.1): ONE gzip member decoded by waves that start at
+    block boundaries they find themselves, in symbol form, committed only when they chain up bit for bit, markers resolved on
+    the device — the result is exactly zlib's, for dynamic, literal-only and fixed-Huffman streams"""
+    import zlib
+    d = synth.make_pairs(9000, 150, seed=40 + level, dirty=True)
+    buf, n = synth.render_fastq_fixed(d["seq1"], d["qual1"], 1)
+    text = bytes(memoryview(buf)[:n])
+    st = {"default": zlib.Z_DEFAULT_STRATEGY, "huffman": zlib.Z_HUFFMAN_ONLY, "fixed": zlib.Z_FIXED}[strategy]
+    c = zlib.compressobj(level, zlib.DEFLATED, 31, 8, st)
+    gz = c.compress(text) + c.flush()
+    lib = capi.load_library()
+    src = np.frombuffer(gz, dtype=np.uint8)
+    out = np.zeros(len(text) + 4096, dtype=np.uint8)
+    n_out = capi.C.c_uint64(0)
+    stats = np.zeros(8, dtype=np.uint64)
+    rc = lib.aqc_gunzip_dev_selftest(0, src.ctypes.data, len(gz), out.ctypes.data, out.size, capi.C.byref(n_out), stats.ctypes.data)
+    if strategy == "fixed":
+        # fixed-Huffman blocks carry no header the block search could recognise: only the first section (known start) decodes;
+        # the device path reports that nothing chained up behind it (the host decoder would take over) — or, for a stream of a
+        # single block, decodes it all
+        assert rc == 0 or b"no section chained up" in (lib.aqc_last_error() or b"")
+        if rc != 0:
+            return
+    assert rc == 0, (lib.aqc_last_error() or b"").decode()
+    assert n_out.value == len(text) and out[:len(text)].tobytes() == text
+    assert stats[1] >= 1
