@@ -1036,7 +1036,7 @@ struct GzdDevice {
         const uint64_t span = std::min<uint64_t>(left, nsec * (uint64_t)section_bytes + (4u << 20));     // + room to finish the last block
         n_sections = (uint32_t)nsec;
         if (comp.reserve(span + 128) || sec_start.reserve(8 * nsec) || sec_end.reserve(8 * nsec) || sec_flags.reserve(4 * nsec) ||
-            sec_nsym.reserve(4 * nsec) || sec_off.reserve(8 * (nsec + 1)) || result.reserve(64) ||
+            sec_nsym.reserve(4 * nsec) || sec_off.reserve(8 * (nsec + 1)) || result.reserve(256) ||
             sym.reserve((size_t)nsec * sym_cap * 2) || text.reserve(32768 + (size_t)nsec * sym_cap + 64))
             return fail(AQC_ERR_HIP, "hipMalloc failed (device gunzip)");
         HIP_TRY(hipMemcpyAsync(comp.p, data + byte0, span, hipMemcpyHostToDevice, stream));
@@ -1058,9 +1058,15 @@ struct GzdDevice {
         hipLaunchKernelGGL(gzd_resolve_kernel, dim3(32, n_sections), dim3(256), 0, stream, J);
         HIP_TRY(hipEventRecord(ev[4], stream));
         HIP_TRY(hipGetLastError());
-        uint32_t r[8] = {0};
+        uint32_t r[8 + 16] = {0};
         HIP_TRY(hipMemcpyAsync(r, result.p, sizeof(r), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
+#ifdef GZD_PROFILE
+        {
+            const unsigned long long* pr = reinterpret_cast<const unsigned long long*>(r + 8);
+            fprintf(stderr, "GZD section 1: decode+lookup %llu  walk %llu  scan %llu  output %llu  | rounds %llu tokens %llu matches %llu\n", pr[0], pr[1], pr[2], pr[3], pr[5], pr[6], pr[7]);
+        }
+#endif
         accepted = r[0];
         corrupt = r[1] != 0;
         final_block = r[2] != 0;

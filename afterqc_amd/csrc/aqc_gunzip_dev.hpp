@@ -33,7 +33,7 @@ namespace aqc {
 
 constexpr uint32_t GZD_MARKER = 0x8000u;
 constexpr int GZD_LROOT = 11, GZD_DROOT = 9;
-constexpr int GZD_RING = 8192;                     // symbols kept in LDS behind the write position
+constexpr int GZD_RING = 32768;                    // the whole window behind the write position stays in LDS (64 KiB per wave)
 constexpr uint64_t GZD_NONE = ~0ull;
 // section flags
 constexpr uint32_t GZD_FINAL = 1u, GZD_ERROR = 2u, GZD_OVERFLOW = 4u;
@@ -288,29 +288,38 @@ __global__ __launch_bounds__(WAVE) void gzd_decode_kernel(GzdJob J) {
         return;
     }
     const unsigned long long total_bits = J.comp_bytes * 8ull;
-    const unsigned long long stop = k + 1 < J.n_sections ? (unsigned long long)(k + 1) * J.section_bytes * 8ull : total_bits;
+    // (the last section of a batch stops like the others: at the first block boundary at or behind its nominal end — the
+    //  window holds some megabytes beyond it — or at the stream's final block)
+    const unsigned long long stop = (unsigned long long)(k + 1) * J.section_bytes * 8ull;
     const uint8_t* const comp = J.comp;
     uint16_t* const out = J.sym + (unsigned long long)k * J.sym_cap;
     const uint32_t cap = J.sym_cap;
     unsigned long long p = start;            // bit position (uniform)
     uint32_t op = 0;                         // symbols produced (uniform)
-    uint32_t pend = 0;                       // this lane's pending literal of the current 64-symbol group
+#ifdef GZD_PROFILE
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     uint32_t flags = 0;
-    // pending literals: symbol op goes to lane op & 63; the group [op & ~63, op) is written out when it fills up or a copy follows
-    auto flush_group = [&]() {
-        const uint32_t g0 = op & ~63u;
-        if ((uint32_t)lane < (op & 63u)) { out[g0 + lane] = (uint16_t)pend; W.ring[(g0 + lane) & (GZD_RING - 1)] = (uint16_t)pend; }
-    };
-    auto put_literal = [&](uint32_t sym) {
-        if ((uint32_t)lane == (op & 63u)) pend = sym;
-        ++op;
-        if ((op & 63u) == 0) { out[op - 64 + lane] = (uint16_t)pend; W.ring[(op - 64 + lane) & (GZD_RING - 1)] = (uint16_t)pend; }
-    };
-    // the symbol at section position i (i < op): before the section = a marker; recent = the ring; older = memory
+    // the symbol at section position i (i < op): before the section = a marker, else the ring (distances are <= 32768)
     auto fetch = [&](long long i) -> uint32_t {
         if (i < 0) return GZD_MARKER | (uint32_t)(32768 + i);
-        if ((long long)op - i <= (long long)(GZD_RING - 512)) return W.ring[(uint32_t)i & (GZD_RING - 1)];
-        return (uint32_t)__hip_atomic_load(&out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return W.ring[(uint32_t)i & (GZD_RING - 1)];
+    };
+    // `len` symbols from `dist` back to position op, the lanes side by side (positions that the copy itself produces repeat
+    // the pattern of the `dist` symbols before it)
+    auto copy_match = [&](uint32_t len, uint32_t dist) {
+        const long long src0 = (long long)op - (long long)dist;
+        for (uint32_t c0 = 0; c0 < len; c0 += WAVE) {
+            const uint32_t i = c0 + (uint32_t)lane;
+            uint32_t rel = i;
+            if (dist < WAVE && dist <= i) { if (dist == 1) rel = 0; else while (rel >= dist) rel -= dist; }
+            uint32_t val = 0;
+            if (i < len) val = fetch(src0 + (long long)rel);
+            __builtin_amdgcn_wave_barrier();
+            if (i < len) { out[op + i] = (uint16_t)val; W.ring[(op + i) & (GZD_RING - 1)] = (uint16_t)val; }
+            __builtin_amdgcn_wave_barrier();
+        }
+        op += len;
     };
     bool done = false;
     uint32_t guard_blocks = 0;
@@ -329,9 +338,6 @@ __global__ __launch_bounds__(WAVE) void gzd_decode_kernel(GzdJob J) {
             p += 32;
             if (len != (~nlen & 0xffffu) || p + 8ull * len > total_bits) { flags |= GZD_ERROR; break; }
             if (op + len + 64 > cap) { flags |= GZD_OVERFLOW; break; }
-            flush_group();
-            __builtin_amdgcn_wave_barrier();
-            // (the group in flight is complete in memory now; re-open it so that later literals keep filling its tail)
             const uint8_t* src = comp + (p >> 3);
             for (uint32_t i = (uint32_t)lane; i < len; i += WAVE) {
                 const uint16_t b = src[i];
@@ -340,11 +346,6 @@ __global__ __launch_bounds__(WAVE) void gzd_decode_kernel(GzdJob J) {
             }
             __builtin_amdgcn_wave_barrier();
             op += len;
-            // pending register: the lanes below op & 63 must hold the symbols of the open group again
-            {
-                const uint32_t g0 = op & ~63u;
-                pend = (uint32_t)lane < (op & 63u) ? W.ring[(g0 + lane) & (GZD_RING - 1)] : 0u;
-            }
             p += 8ull * len;
         } else {
             int hlit = 288, hdist = 30;
@@ -360,12 +361,14 @@ __global__ __launch_bounds__(WAVE) void gzd_decode_kernel(GzdJob J) {
             // (the distance lengths sit behind the literal/length ones)
             const int rd = gzd_build(W.T, W.T.lens + hlit, hdist, GZD_DROOT, W.T.dist, W.T.dsorted, W.T.dcount, lane, &dmax);
             if (rl == 1 || rd == 1 || (rl == 2 && lmax != 1) || (rd == 2 && dmax > 1)) { flags |= GZD_ERROR; break; }
-            // ---- symbols.  The bit buffer lives in scalar registers and is topped up 32 bits at a time from a 1 KiB window of
-            //      the stream in LDS (one coalesced load per KiB); the dword after the next is always on its way.
+            // ---- symbols, a ROUND at a time: lane i decodes the token that would start at bit p + i (literal, end of block, or
+            //      length + distance with their extra bits: <= 48 bits), a scalar walk from lane 0 follows the tokens' lengths
+            //      and marks the ones that are real (10 - 25 per round of 64 bit positions), a lane scan places their output.
+            //      Literals are stored by their lanes; matches are applied in order, the lanes sharing each copy.  A token whose
+            //      code is longer than the root index ends the round and is decoded on its own (canonical search).
             const uint32_t* const comp32 = reinterpret_cast<const uint32_t*>(comp);
             const uint32_t total_dwords = (uint32_t)((J.comp_bytes + 64) >> 2);
-            uint32_t wi = (uint32_t)(p >> 5);                 // next dword to enter the bit buffer
-            uint32_t cbase = wi;
+            uint32_t cbase = (uint32_t)(p >> 5);
             auto load_window = [&]() {
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -376,105 +379,176 @@ __global__ __launch_bounds__(WAVE) void gzd_decode_kernel(GzdJob J) {
                 __builtin_amdgcn_wave_barrier();
             };
             load_window();
-            auto next_dword = [&]() -> uint32_t {
-                if (wi - cbase >= (uint32_t)GZD_CWIN) { cbase = wi; load_window(); }
-                const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.cwin[wi - cbase]);
-                ++wi;
-                return d;
-            };
-            unsigned long long bb = (unsigned long long)next_dword() >> (p & 31u);
-            int bc = 32 - (int)(p & 31u);
-            uint32_t nd = next_dword();                        // (the dword that enters at the next top-up)
-#define GZD_TOPUP() do { if (bc < 32) { bb |= (unsigned long long)nd << bc; bc += 32; nd = next_dword(); } } while (0)
-#define GZD_DROP(n_) do { const int n__ = (int)(n_); bb >>= n__; bc -= n__; } while (0)
             bool eob = false;
             uint32_t guard = 0;
+#ifdef GZD_PROFILE
+#define GZD_T(k_) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[k_] += n_ - tlast; tlast = n_; } while (0)
+            unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#else
+#define GZD_T(k_)
+#endif
             while (!eob) {
-                if (wi > total_dwords + 4 || ++guard > (1u << 24)) { flags |= GZD_ERROR; break; }
-                if (op + 258 + 64 > cap) { flags |= GZD_OVERFLOW; break; }
-                GZD_TOPUP();
-                uint32_t e = W.T.lit[(uint32_t)bb & ((1u << GZD_LROOT) - 1u)];
-                e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
-                uint32_t l = e & 15u, sym = e >> 4;
-                if (l == 0) {
-                    // a code longer than the root index: canonical search, one length at a time
-                    uint32_t code = gzd_rev((uint32_t)bb & ((1u << GZD_LROOT) - 1u), GZD_LROOT), first = 0, index = 0;
-                    for (int q = 1; q <= GZD_LROOT; ++q) { const uint32_t c = W.T.lcount[q]; first = (first + c) << 1; index += c; }
-                    bool ok = false;
-                    for (int q = GZD_LROOT + 1; q <= 15; ++q) {
-                        code = (code << 1) | (uint32_t)((bb >> (q - 1)) & 1u);
-                        const uint32_t c = W.T.lcount[q];
-                        if (code - first < c) { sym = W.T.lsorted[index + (code - first)]; l = (uint32_t)q; ok = true; break; }
-                        index += c;
-                        first = (first + c) << 1;
-                    }
-                    if (!ok) { flags |= GZD_ERROR; break; }
-                    sym = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym);
-                }
-                GZD_DROP(l);
-                if (sym < 256) { put_literal(sym); continue; }
-                if (sym == 256) { eob = true; break; }
-                if (sym > 285) { flags |= GZD_ERROR; break; }
-                const uint32_t ls = sym - 257;
-                const uint32_t lx = GZD_LEN_EXTRA[ls];
-                const uint32_t len = GZD_LEN_BASE[ls] + ((uint32_t)bb & ((1u << lx) - 1u));
-                GZD_DROP(lx);
-                // distance
-                GZD_TOPUP();
-                uint32_t de = W.T.dist[(uint32_t)bb & ((1u << GZD_DROOT) - 1u)];
-                de = (uint32_t)__builtin_amdgcn_readfirstlane((int)de);
-                uint32_t dl = de & 15u, dsym = de >> 4;
-                if (dl == 0) {
-                    uint32_t code = gzd_rev((uint32_t)bb & ((1u << GZD_DROOT) - 1u), GZD_DROOT), first = 0, index = 0;
-                    for (int q = 1; q <= GZD_DROOT; ++q) { const uint32_t c = W.T.dcount[q]; first = (first + c) << 1; index += c; }
-                    bool ok = false;
-                    for (int q = GZD_DROOT + 1; q <= 15; ++q) {
-                        code = (code << 1) | (uint32_t)((bb >> (q - 1)) & 1u);
-                        const uint32_t c = W.T.dcount[q];
-                        if (code - first < c) { dsym = W.T.dsorted[index + (code - first)]; dl = (uint32_t)q; ok = true; break; }
-                        index += c;
-                        first = (first + c) << 1;
-                    }
-                    if (!ok) { flags |= GZD_ERROR; break; }
-                    dsym = (uint32_t)__builtin_amdgcn_readfirstlane((int)dsym);
-                }
-                if (dsym > 29) { flags |= GZD_ERROR; break; }
-                GZD_DROP(dl);
-                const uint32_t dx = GZD_DIST_EXTRA[dsym];
-                const uint32_t dist = GZD_DIST_BASE[dsym] + ((uint32_t)bb & ((1u << dx) - 1u));
-                GZD_DROP(dx);
-                if ((long long)op - (long long)dist < -32768) { flags |= GZD_ERROR; break; }
-                // ---- copy: pending literals out first, then `len` symbols from `dist` back, the lanes side by side
-                flush_group();
-                __builtin_amdgcn_wave_barrier();
-                const long long src0 = (long long)op - (long long)dist;
-                for (uint32_t c0 = 0; c0 < len; c0 += WAVE) {
-                    const uint32_t i = c0 + (uint32_t)lane;
-                    // (positions that this very copy produces repeat the pattern of the `dist` symbols before it)
-                    uint32_t rel = i;
-                    if (dist < WAVE && dist <= i) { if (dist == 1) rel = 0; else while (rel >= dist) rel -= dist; }
-                    uint32_t val = 0;
-                    if (i < len) val = fetch(src0 + (long long)rel);
-                    __builtin_amdgcn_wave_barrier();
-                    if (i < len) { out[op + i] = (uint16_t)val; W.ring[(op + i) & (GZD_RING - 1)] = (uint16_t)val; }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                op += len;
+                if ((p >> 5) > total_dwords || ++guard > (1u << 24)) { flags |= GZD_ERROR; break; }
+                if (op + 64u * 258u + 64u > cap) { flags |= GZD_OVERFLOW; break; }
+                // the window must hold the dwords of bits [p, p + 64 + 64)
+                if ((uint32_t)(p >> 5) - cbase + 6u > (uint32_t)GZD_CWIN) { cbase = (uint32_t)(p >> 5); load_window(); }
+                unsigned long long w;
                 {
-                    const uint32_t g0 = op & ~63u;
-                    pend = (uint32_t)lane < (op & 63u) ? W.ring[(g0 + lane) & (GZD_RING - 1)] : 0u;
+                    const unsigned long long q = p + (unsigned)lane;
+                    const uint32_t di = (uint32_t)(q >> 5) - cbase, sh = (uint32_t)q & 31u;
+                    const unsigned long long lo = ((unsigned long long)W.cwin[di + 1] << 32) | W.cwin[di];
+                    const uint32_t hi = W.cwin[di + 2];
+                    w = sh ? (lo >> sh) | ((unsigned long long)hi << (64u - sh)) : lo;
+                }
+                const uint32_t e = W.T.lit[(uint32_t)w & ((1u << GZD_LROOT) - 1u)];
+                const uint32_t l = e & 15u, sym = e >> 4;
+                uint32_t tb = l, kind = 0, tlen = 1, tdist = 0;          // bits of the token; 0 literal, 1 end of block, 2 match, 3 not decodable here
+                if (l == 0) kind = 3;
+                else if (sym == 256) kind = 1;
+                else if (sym > 256) {
+                    if (sym > 285) kind = 3;
+                    else {
+                        const uint32_t ls = sym - 257;
+                        const uint32_t lxe = ls < 8 || ls == 28 ? 0u : (ls - 4) >> 2;
+                        const uint32_t lbase = ls < 8 ? 3u + ls : ls == 28 ? 258u : 3u + ((4u + (ls & 3u)) << lxe);
+                        tlen = lbase + (uint32_t)((w >> l) & ((1u << lxe) - 1u));
+                        const uint32_t o = l + lxe;
+                        const uint32_t de = W.T.dist[(uint32_t)(w >> o) & ((1u << GZD_DROOT) - 1u)];
+                        const uint32_t dl = de & 15u, dsym = de >> 4;
+                        if (dl == 0 || dsym > 29) kind = 3;
+                        else {
+                            const uint32_t dxe = dsym < 4 ? 0u : (dsym >> 1) - 1u;
+                            const uint32_t dbase = dsym < 4 ? dsym + 1u : 1u + ((2u + (dsym & 1u)) << dxe);
+                            tdist = dbase + (uint32_t)((w >> (o + dl)) & ((1u << dxe) - 1u));
+                            tb = o + dl + dxe;
+                            kind = 2;
+                        }
+                    }
+                }
+                GZD_T(0);
+                // ---- the walk: which lanes start a real token
+                const uint32_t packed = tb | (kind << 8);
+                unsigned long long tok = 0;
+                uint32_t cur = 0;
+                bool slow = false;
+                while (cur < (uint32_t)WAVE) {
+                    const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)cur);
+                    const uint32_t k2 = pk >> 8;
+                    if (k2 == 3) { slow = true; break; }
+                    tok |= 1ull << cur;
+                    cur += pk & 0xffu;
+                    if (k2 == 1) { eob = true; break; }
+                }
+                GZD_T(1);
+                // ---- output positions: exclusive scan of the real tokens' output lengths
+                const bool mine = (tok >> lane) & 1ull;
+                const uint32_t olen = mine ? (kind == 0 ? 1u : kind == 2 ? tlen : 0u) : 0u;
+                uint32_t inc = olen;
+#pragma unroll
+                for (int d = 1; d < WAVE; d <<= 1) {
+                    const uint32_t o2 = (uint32_t)__shfl_up((int)inc, d, WAVE);
+                    if (lane >= d) inc += o2;
+                }
+                const uint32_t total_out = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
+                const uint32_t my_pos = op + inc - olen;
+                GZD_T(2);
+                // matches that reach before the window are errors
+                const unsigned long long mm_all = __ballot(mine && kind == 2);
+                if (__ballot(mine && kind == 2 && (long long)my_pos - (long long)tdist < -32768)) { flags |= GZD_ERROR; break; }
+                if (mm_all == 0) {
+                    // literals only: all at once
+                    if (mine && kind == 0) { out[my_pos] = (uint16_t)sym; W.ring[my_pos & (GZD_RING - 1)] = (uint16_t)sym; }
+                    op += total_out;
+                } else {
+                    if (mine && kind == 0) { out[my_pos] = (uint16_t)sym; W.ring[my_pos & (GZD_RING - 1)] = (uint16_t)sym; }
+                    __builtin_amdgcn_wave_barrier();
+                    unsigned long long mm = mm_all;
+                    const uint32_t op0 = op;
+                    while (mm) {
+                        const int ml = __ffsll((long long)mm) - 1;
+                        mm &= mm - 1;
+                        const uint32_t mlen = (uint32_t)__builtin_amdgcn_readlane((int)tlen, ml);
+                        const uint32_t mdist = (uint32_t)__builtin_amdgcn_readlane((int)tdist, ml);
+                        op = (uint32_t)__builtin_amdgcn_readlane((int)my_pos, ml);
+                        copy_match(mlen, mdist);
+                    }
+                    op = op0 + total_out;
+                }
+                p += cur;
+                GZD_T(3);
+#ifdef GZD_PROFILE
+                prof[5] += 1; prof[6] += (unsigned long long)__popcll(tok); prof[7] += (unsigned long long)__popcll(mm_all);
+#endif
+                if (slow) {
+                    // one token with a code longer than the root index, decoded on its own
+                    const unsigned long long v0 = gzd_peek(comp, p);
+                    unsigned long long v = v0;
+                    uint32_t e2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.T.lit[(uint32_t)v & ((1u << GZD_LROOT) - 1u)]);
+                    uint32_t l2 = e2 & 15u, sym2 = e2 >> 4;
+                    if (l2 == 0) {
+                        uint32_t code = gzd_rev((uint32_t)v & ((1u << GZD_LROOT) - 1u), GZD_LROOT), first = 0, index = 0;
+                        for (int q = 1; q <= GZD_LROOT; ++q) { const uint32_t c = W.T.lcount[q]; first = (first + c) << 1; index += c; }
+                        bool ok = false;
+                        for (int q = GZD_LROOT + 1; q <= 15; ++q) {
+                            code = (code << 1) | (uint32_t)((v >> (q - 1)) & 1u);
+                            const uint32_t c = W.T.lcount[q];
+                            if (code - first < c) { sym2 = W.T.lsorted[index + (code - first)]; l2 = (uint32_t)q; ok = true; break; }
+                            index += c;
+                            first = (first + c) << 1;
+                        }
+                        if (!ok) { flags |= GZD_ERROR; break; }
+                        sym2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym2);
+                    }
+                    p += l2;
+                    v >>= l2;
+                    if (sym2 < 256) {
+                        if (lane == 0) { out[op] = (uint16_t)sym2; W.ring[op & (GZD_RING - 1)] = (uint16_t)sym2; }
+                        ++op;
+                    } else if (sym2 == 256) eob = true;
+                    else if (sym2 > 285) { flags |= GZD_ERROR; break; }
+                    else {
+                        const uint32_t ls = sym2 - 257;
+                        const uint32_t lx = GZD_LEN_EXTRA[ls];
+                        const uint32_t len = GZD_LEN_BASE[ls] + (uint32_t)(v & ((1u << lx) - 1u));
+                        p += lx;
+                        v = gzd_peek(comp, p);
+                        uint32_t de = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.T.dist[(uint32_t)v & ((1u << GZD_DROOT) - 1u)]);
+                        uint32_t dl = de & 15u, dsym = de >> 4;
+                        if (dl == 0) {
+                            uint32_t code = gzd_rev((uint32_t)v & ((1u << GZD_DROOT) - 1u), GZD_DROOT), first = 0, index = 0;
+                            for (int q = 1; q <= GZD_DROOT; ++q) { const uint32_t c = W.T.dcount[q]; first = (first + c) << 1; index += c; }
+                            bool ok = false;
+                            for (int q = GZD_DROOT + 1; q <= 15; ++q) {
+                                code = (code << 1) | (uint32_t)((v >> (q - 1)) & 1u);
+                                const uint32_t c = W.T.dcount[q];
+                                if (code - first < c) { dsym = W.T.dsorted[index + (code - first)]; dl = (uint32_t)q; ok = true; break; }
+                                index += c;
+                                first = (first + c) << 1;
+                            }
+                            if (!ok) { flags |= GZD_ERROR; break; }
+                            dsym = (uint32_t)__builtin_amdgcn_readfirstlane((int)dsym);
+                        }
+                        if (dsym > 29) { flags |= GZD_ERROR; break; }
+                        p += dl;
+                        v >>= dl;
+                        const uint32_t dx = GZD_DIST_EXTRA[dsym];
+                        const uint32_t dist = GZD_DIST_BASE[dsym] + (uint32_t)(v & ((1u << dx) - 1u));
+                        p += dx;
+                        if ((long long)op - (long long)dist < -32768) { flags |= GZD_ERROR; break; }
+                        __builtin_amdgcn_wave_barrier();
+                        copy_match(len, dist);
+                    }
                 }
             }
-#undef GZD_TOPUP
-#undef GZD_DROP
-            // back to a plain bit position: everything in the buffer and in `nd` has not been consumed
-            p = (unsigned long long)wi * 32ull - 32ull - (unsigned long long)bc;
             if (flags) break;
         }
         if (bfinal) { flags |= GZD_FINAL; done = true; }
     }
-    flush_group();
     if (lane == 0) { J.sec_end[k] = p; J.sec_nsym[k] = op; J.sec_flags[k] = flags; }
+#ifdef GZD_PROFILE
+    if (lane == 0 && k == 1)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(J.result + 8)[i] = prof[i];
+#endif
 }
 
 // ---- commit in order + the last 32 KiB of every section -------------------------------------------------------------------------
