@@ -32,14 +32,18 @@ def isFastq(f):
     return False
 
 
-def open_binary(fname):
-    """the byte stream fastq.Reader reads (fastq.py:23-28): .gz / .bz2 decoded transparently"""
+def open_binary(fname, sample=False):
+    """the byte stream fastq.Reader reads (fastq.py:23-28): .gz / .bz2 decoded transparently.  sample=True: the caller reads
+    only the head of the file (the pre-filter sampling pass): a .gz is then decoded with a few small sections in flight instead
+    of speculating hundreds of megabytes ahead"""
     try:
         if fname.endswith(".bz2"):
             return bz2.BZ2File(fname)
         try:
-            # the native readers (parallel pread; BGZF members inflated in parallel, other gzip data as one zlib stream)
+            # the native readers (parallel pread; .gz: the pipe's own decoder, many threads per stream)
             from . import capi
+            if sample and fname.endswith(".gz"):
+                return capi.NativeSource(fname, True, io_threads=6, gz_section_bytes=1 << 20)
             return capi.NativeSource(fname, fname.endswith(".gz"))
         except (ImportError, RuntimeError, AttributeError):
             pass

@@ -156,7 +156,7 @@ class QualityControl:
         from . import fastq
         eng = self.engine
         cap = max(int(chunk_bytes), 4 << 20)          # the first chunk must hold the 999 skipped reads (fallback below)
-        f = fastq.open_binary(filename)
+        f = fastq.open_binary(filename, sample=self.sampleLimit > 0)
         buf = eng.host_buffer(cap)
         lo = READ_TO_SKIP - 1
         hi = lo + self.sampleLimit if self.sampleLimit > 0 else None    # stat 0-based [lo, hi)
