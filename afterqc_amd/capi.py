@@ -344,8 +344,6 @@ def load_library():
     lib.aqc_pipe_run.argtypes = [P, C.POINTER(PipeIO), C.POINTER(PipeOpts), C.POINTER(PipeResult)]
     lib.aqc_pipe_run.restype = C.c_int
     lib.aqc_pipe_last_error.restype = C.c_char_p
-    lib.aqc_pipe_prepare.argtypes = [P, C.c_uint64, C.c_double, C.c_int32]
-    lib.aqc_pipe_prepare.restype = C.c_int
     lib.aqc_source_open.argtypes = [C.c_char_p, C.c_int32, C.c_int32]
     lib.aqc_source_open.restype = P
     lib.aqc_source_read.argtypes = [P, P, C.c_uint64]
@@ -394,7 +392,7 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_device_index", "
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
                     "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_compress", "aqc_fetch_gz", "aqc_gunzip_dev_selftest", "aqc_host_alloc",
                     "aqc_host_free",
-                    "aqc_pipe_create", "aqc_pipe_prepare", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
+                    "aqc_pipe_create", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
                     "aqc_host_count_newlines", "aqc_bgzf_compress", "aqc_pipe_split",
                     "aqc_source_open", "aqc_source_open2", "aqc_source_read", "aqc_source_error", "aqc_source_gz_stats", "aqc_source_close",
                     "aqc_gz_deflate_block", "aqc_gz_inflate_raw", "aqc_gz_crc32",
@@ -601,10 +599,6 @@ class Pipe:
         if rc != 0:
             raise AqcError(rc, "aqc_pipe_create failed")
         self.h = h
-
-    def prepare(self, chunk_records, n_files, bytes_per_record=0.0):
-        """page-lock the rings from a side thread, now (aqc_pipe_prepare)"""
-        self.lib.aqc_pipe_prepare(self.h, int(chunk_records), float(bytes_per_record), int(n_files))
 
     def close(self):
         if getattr(self, "h", None):

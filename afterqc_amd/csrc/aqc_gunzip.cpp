@@ -1,6 +1,7 @@
 // aqc_gunzip.cpp — ParallelGunzip: one gzip stream decoded by many threads, exactly (see aqc_gz.hpp for the idea).
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -13,22 +14,41 @@
 
 namespace aqcgz {
 
+// -DAQC_GZ_PROFILE (tools/ubench/gz_rate.cpp): microseconds of thread time per phase, summed over all threads
+#ifdef AQC_GZ_PROFILE
+}  // namespace aqcgz
+#include <atomic>
+#include <chrono>
+namespace aqcgz {
+std::atomic<long> gz_prof[6];       // find, decode, translate, crc, consumer waits for the front section, accept
+struct ProfScope {
+    int k;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit ProfScope(int kk) : k(kk) {}
+    ~ProfScope() { gz_prof[k] += (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+#define GZ_PROF(k) ProfScope prof_scope_##k(k)
+#else
+#define GZ_PROF(k) do { } while (0)
+#endif
+
 namespace {
 
 // symbols -> bytes: literals pass, a marker j is byte j of the (right-aligned) 32 KiB window before the section; markers
 // below valid_from point before the start of the member: corrupt data.  Returns false on such a marker.
+// (no branch on "is it a marker": in FASTQ every read name is a copy of the one before it, so markers stay frequent through a
+// whole section and come in no predictable pattern)
 bool translate_generic(const uint16_t* s, size_t n, uint8_t* d, const uint8_t* win, size_t valid_from) {
-    bool ok = true;
+    uint32_t bad = 0;
     for (size_t i = 0; i < n; ++i) {
         const uint32_t v = s[i];
-        if (v < MARKER) d[i] = (uint8_t)v;
-        else {
-            const uint32_t j = v & 0x7fffu;
-            if (j < valid_from) ok = false;
-            d[i] = win[j];
-        }
+        const uint32_t j = v & 0x7fffu;
+        const uint32_t m = v >> 15;                       // 1: marker
+        const uint8_t w = win[j];                         // always readable: the window buffer holds all 32 Ki entries
+        d[i] = m ? w : (uint8_t)v;
+        bad |= m & (uint32_t)(j < valid_from);
     }
-    return ok;
+    return bad == 0;
 }
 
 #if defined(__x86_64__)
@@ -37,8 +57,12 @@ __attribute__((target("avx2"))) bool translate_avx2(const uint16_t* s, size_t n,
     size_t i = 0;
     for (; i + 32 <= n; i += 32) {
         const __m256i a = _mm256_loadu_si256((const __m256i*)(s + i)), b = _mm256_loadu_si256((const __m256i*)(s + i + 16));
-        if (_mm256_movemask_epi8(_mm256_or_si256(a, b)) & 0xAAAAAAAAu) {
-            ok &= translate_generic(s + i, 32, d + i, win, valid_from);
+        const uint32_t ma = (uint32_t)_mm256_movemask_epi8(a) & 0xAAAAAAAAu, mb = (uint32_t)_mm256_movemask_epi8(b) & 0xAAAAAAAAu;
+        if (ma | mb) {
+            if (ma) ok &= translate_generic(s + i, 16, d + i, win, valid_from);
+            else _mm_storeu_si128((__m128i*)(d + i), _mm_packus_epi16(_mm256_castsi256_si128(a), _mm256_extracti128_si256(a, 1)));
+            if (mb) ok &= translate_generic(s + i + 16, 16, d + i + 16, win, valid_from);
+            else _mm_storeu_si128((__m128i*)(d + i + 16), _mm_packus_epi16(_mm256_castsi256_si128(b), _mm256_extracti128_si256(b, 1)));
         } else {
             const __m256i p = _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8);
             _mm256_storeu_si256((__m256i*)(d + i), p);
@@ -67,12 +91,35 @@ constexpr size_t BRIDGE_CAP = 1u << 20;
 
 }  // namespace
 
+// a section's symbols: WINDOW marker entries, then the output.  Plain malloc'ed memory in 2 Mi-symbol size classes, recycled
+// through Shared::free_bufs — a std::vector would zero-fill (and page-fault) 30 MB per section, which costs as much as
+// decoding it.
+struct SymBuf {
+    uint16_t* p = nullptr;
+    size_t cap = 0;                             // symbols behind the WINDOW prefix (512 more are allocated as slack)
+    SymBuf() = default;
+    SymBuf(SymBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    SymBuf& operator=(SymBuf&& o) noexcept { if (this != &o) { free(p); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
+    SymBuf(const SymBuf&) = delete;
+    SymBuf& operator=(const SymBuf&) = delete;
+    ~SymBuf() { free(p); }
+    static size_t round_up(size_t n) { return (n + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1); }
+    bool grow(size_t want) {                    // keeps the contents
+        want = round_up(want);
+        if (want <= cap) return true;
+        uint16_t* q = (uint16_t*)realloc(p, (WINDOW + want + 512) * sizeof(uint16_t));
+        if (!q) return false;
+        p = q; cap = want;
+        return true;
+    }
+};
+
 struct ParallelGunzip::Shared {
     std::mutex mu;
     std::condition_variable cv;
     int pending = 0;                            // translation tasks in flight
     bool marker_error = false;
-    std::vector<std::vector<uint16_t>> free_bufs;
+    std::vector<SymBuf> free_bufs;
     std::deque<Event> events;                   // in commit order (filled by the consumer; piece CRCs by the tasks)
     size_t events_base = 0;                     // absolute index of events.front()
 };
@@ -83,7 +130,7 @@ struct ParallelGunzip::Section {
     uint64_t nominal_bit = 0, start_bit = 0, stop_bit = 0;
     bool done = false, found = false, error = false, hit_eof = false;
     uint64_t end_bit = 0;
-    std::vector<uint16_t> buf;
+    SymBuf buf;
     size_t n_out = 0;
     struct MemberEnd { size_t out_pos; uint32_t crc, isize; };
     std::vector<MemberEnd> ends;
@@ -91,7 +138,7 @@ struct ParallelGunzip::Section {
     std::condition_variable cv;
     std::shared_ptr<Shared> sh;
     ~Section() {
-        if (sh && !buf.empty()) {
+        if (sh && buf.p) {
             std::lock_guard<std::mutex> g(sh->mu);
             if (sh->free_bufs.size() < 256) sh->free_bufs.push_back(std::move(buf));
         }
@@ -128,32 +175,39 @@ namespace {
 void section_body(const uint8_t* data, size_t size, ParallelGunzip::Section& s) {
     uint64_t start = s.start_bit;
     if (!s.known_start) {
+        GZ_PROF(0);
         start = find_block_start(data, size, s.nominal_bit, s.stop_bit);
         if (start == UINT64_MAX) return;
     }
     s.start_bit = start;
     s.found = true;
+    GZ_PROF(1);
     std::unique_ptr<Inflater<uint16_t>> inf(new Inflater<uint16_t>());
-    if (s.sh) {
-        std::lock_guard<std::mutex> g(s.sh->mu);
-        if (!s.sh->free_bufs.empty()) { s.buf = std::move(s.sh->free_bufs.back()); s.sh->free_bufs.pop_back(); }
-    }
     const size_t span = (size_t)((std::min<uint64_t>(s.stop_bit, (uint64_t)size * 8) - std::min<uint64_t>(start, (uint64_t)size * 8)) >> 3);
-    size_t cap = span * 4 + (256u << 10);
-    if (s.buf.size() < WINDOW + cap + 512) {
-        const bool fresh = s.buf.size() < WINDOW;
-        s.buf.resize(WINDOW + cap + 512);
-        if (fresh) for (size_t j = 0; j < WINDOW; ++j) s.buf[j] = (uint16_t)(MARKER | j);
-    } else cap = s.buf.size() - WINDOW - 512;
+    const size_t need = SymBuf::round_up(span * 4 + (256u << 10));
+    if (s.sh) {
+        // a recycled buffer that is big enough (sections are all alike, so nearly any is), else the last one: it grows
+        std::lock_guard<std::mutex> g(s.sh->mu);
+        auto& fb = s.sh->free_bufs;
+        if (!fb.empty()) {
+            size_t pick = fb.size() - 1;
+            for (size_t i = 0; i < fb.size(); ++i) if (fb[i].cap >= need) { pick = i; break; }
+            s.buf = std::move(fb[pick]);
+            fb.erase(fb.begin() + (long)pick);
+        }
+    }
+    if (!s.buf.grow(need)) { s.error = true; return; }
+    size_t cap = s.buf.cap;
+    for (size_t j = 0; j < WINDOW; ++j) s.buf.p[j] = (uint16_t)(MARKER | j);
     inf->reset(data, size, start);
-    inf->out = s.buf.data() + WINDOW; inf->out_pos = 0; inf->out_cap = cap; inf->hist = WINDOW;
+    inf->out = s.buf.p + WINDOW; inf->out_pos = 0; inf->out_cap = cap; inf->hist = WINDOW;
     size_t base_off = 0;            // symbols of earlier members of this section (a new member has no history at all)
     for (;;) {
         const int rc = inf->run(s.stop_bit);
         if (rc == GZ_NEED_OUTPUT) {
-            cap = cap + cap / 2 + (1u << 20);
-            s.buf.resize(WINDOW + cap + 512);
-            inf->out = s.buf.data() + WINDOW + base_off; inf->out_cap = cap - base_off;
+            if (!s.buf.grow(cap + cap / 2 + (1u << 20))) { s.error = true; break; }
+            cap = s.buf.cap;
+            inf->out = s.buf.p + WINDOW + base_off; inf->out_cap = cap - base_off;
             continue;
         }
         if (rc == GZ_STOPPED) { s.end_bit = inf->bitpos; break; }
@@ -171,7 +225,7 @@ void section_body(const uint8_t* data, size_t size, ParallelGunzip::Section& s) 
             if (!h) { s.error = true; inf->out_pos = 0; break; }
             // the next member starts with no history: distances reaching before it are errors, no marker can appear in it
             inf->reset(data, size, (uint64_t)h * 8);
-            inf->out = s.buf.data() + WINDOW + base_off; inf->out_pos = 0; inf->out_cap = cap - base_off; inf->hist = 0;
+            inf->out = s.buf.p + WINDOW + base_off; inf->out_pos = 0; inf->out_cap = cap - base_off; inf->hist = 0;
             continue;
         }
         s.error = true;
@@ -274,7 +328,7 @@ void ParallelGunzip::drain_events(bool wait_all) {
 }
 
 void ParallelGunzip::accept(Section& s, uint8_t* dst, size_t& out, size_t want) {
-    const uint16_t* sym = s.buf.data() + WINDOW;
+    const uint16_t* sym = s.buf.p + WINDOW;
     const size_t n = s.n_out;
     const size_t to_dst = std::min(n, want - out);
     // (the spill buffer is empty here: read() serves it before anything else)
@@ -318,8 +372,10 @@ void ParallelGunzip::accept(Section& s, uint8_t* dst, size_t& out, size_t want) 
                 const uint16_t* src = sym + a;
                 const size_t len = b - a;
                 auto job = [sh, keep, win, src, len, d, valid_from, ev] {
-                    const bool ok = translate(src, len, d, win->data(), valid_from);
-                    const uint32_t c = crc32_fast(0u, d, len);
+                    bool ok;
+                    uint32_t c;
+                    { GZ_PROF(2); ok = translate(src, len, d, win->data(), valid_from); }
+                    { GZ_PROF(3); c = crc32_fast(0u, d, len); }
                     std::lock_guard<std::mutex> g(sh->mu);
                     if (!ok) sh->marker_error = true;
                     sh->events[ev - sh->events_base].crc = c;
@@ -416,11 +472,13 @@ size_t ParallelGunzip::read(uint8_t* dst, size_t want) {
         if (q_.empty()) { bridge(UINT64_MAX, dst, out, want); continue; }
         std::shared_ptr<Section> f = q_.front();
         {
+            GZ_PROF(4);
             std::unique_lock<std::mutex> lk(f->mu);
             f->cv.wait(lk, [&] { return f->done; });
         }
         const bool usable = f->found && !f->error;
         if (usable && f->start_bit == cur_bit_) {
+            GZ_PROF(5);
             accept(*f, dst, out, want);
             q_.erase(q_.begin());
         } else if (usable && f->start_bit > cur_bit_) {

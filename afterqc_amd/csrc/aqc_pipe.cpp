@@ -507,7 +507,6 @@ struct aqc_pipe {
     // per worker (ctx, slot): two sets of six output buffers
     struct WorkerBufs { HostBuf out[2][6]; };
     std::vector<WorkerBufs> wbufs;
-    std::thread prep;              // aqc_pipe_prepare: page-locks the rings while the caller does something else
 };
 
 namespace {
@@ -1007,32 +1006,8 @@ int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_
     return 0;
 }
 
-// Page-lock the input rings and the output buffer sets for chunks of `chunk_records` records of about `bytes_per_record` bytes
-// (0: 360) from a side thread: a fresh process spends 0.15 - 0.3 s on that (hipHostMalloc of ~1 GB) the first time the buffers
-// are touched; started before the caller's pre-filter sampling pass it is over by the time aqc_pipe_run needs them.
-// Buffers that turn out too small still grow on demand.
-int aqc_pipe_prepare(aqc_pipe* p, uint64_t chunk_records, double bytes_per_record, int32_t n_files) {
-    if (!p || n_files < 1 || n_files > 2) return AQC_ERR_ARG;
-    if (p->prep.joinable()) p->prep.join();
-    const uint64_t K = chunk_records ? chunk_records : (1u << 17);
-    const double est = bytes_per_record > 0 ? bytes_per_record : 360.0;
-    const size_t in_cap = (size_t)(est * 1.02 * (double)K) + (256 << 10);
-    p->prep = std::thread([p, in_cap, n_files] {
-        for (int f = 0; f < n_files; ++f)
-            for (auto& b : p->in_buf[f]) b.ensure(in_cap);
-        for (auto& w : p->wbufs)
-            for (int s = 0; s < 2; ++s)
-                for (int f = 0; f < n_files; ++f) {
-                    w.out[s][f * 3 + 0].ensure(in_cap);              // good: at most the input
-                    w.out[s][f * 3 + 1].ensure(in_cap / 16);         // bad: a few per cent
-                }
-    });
-    return 0;
-}
-
 void aqc_pipe_destroy(aqc_pipe* p) {
     if (!p) return;
-    if (p->prep.joinable()) p->prep.join();
     for (int f = 0; f < 2; ++f)
         for (auto& b : p->in_buf[f]) b.release();
     for (auto& w : p->wbufs)
@@ -1045,7 +1020,6 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
     if (!P || !io || !opt || !res) return AQC_ERR_ARG;
     memset(res, 0, sizeof(*res));
     if (!io->in_path[0] && !io->in_mem[0]) return AQC_ERR_ARG;
-    if (P->prep.joinable()) P->prep.join();
     const double t0 = now_s();
     Run R;
     R.P = P;

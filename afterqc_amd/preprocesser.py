@@ -364,14 +364,6 @@ class seqFilter:
             e.set_circles(self.bubbleCircles)
             e.reset_stats()
 
-        # the whole-input pipe page-locks ~1 GB of rings: started now, from a side thread, it is done when pass 2 needs them
-        self._pipe = None
-        files0 = [opt.read1_file, opt.read2_file, opt.index1_file, opt.index2_file]
-        if (self.use_text_path and self.use_pipe and not (has_i1 or has_i2) and not opt.qc_only and isinstance(eng, capi.Engine)
-                and len(self.devices) == 1 and not any(f is not None and f.endswith(".bz2") for f in files0)):
-            self._pipe = capi.Pipe([eng], slots=min(self.pipe_slots, eng.n_slots), io_threads=self.io_threads)
-            self._pipe.prepare(self.chunk_records, 2 if paired else 1)
-
         # ---- pass 1: pre-filter QC on a sample of each file (preprocesser.py:247-251)
         r1pre = QualityControl(opt.qc_sample, opt.qc_kmer, eng, capi.QC_R1_PRE)
         r2pre = QualityControl(opt.qc_sample, opt.qc_kmer, eng, capi.QC_R2_PRE)
@@ -492,9 +484,6 @@ class seqFilter:
                 self.timing["report_error"] = "%s: %s" % (type(e).__name__, e)
             self.timing["total_s"] = time.perf_counter() - t_run
         finally:
-            if getattr(self, "_pipe", None) is not None:
-                self._pipe.close()
-                self._pipe = None
             if self.own_engine:
                 for e in [self.engine] + self.extra_engines:
                     if e is not None:
@@ -518,10 +507,7 @@ class seqFilter:
             outputs.append((os.path.join(good_dir, main + ".good.fq" + ext), os.path.join(bad_dir, main + ".bad.fq" + ext),
                             os.path.join(overlap_dir, main + ".overlap.fq" + ext) if want_ovl else None))
         engines = self._engines(all_devices=True)
-        pipe = getattr(self, "_pipe", None)
-        self._pipe = None
-        if pipe is None:
-            pipe = capi.Pipe(engines, slots=min([self.pipe_slots] + [e.n_slots for e in engines]), io_threads=self.io_threads)
+        pipe = capi.Pipe(engines, slots=min([self.pipe_slots] + [e.n_slots for e in engines]), io_threads=self.io_threads)
         try:
             res = pipe.run(files[:nfiles], outputs, gzip_in=[f.endswith(".gz") for f in files[:nfiles]], gzip_out=gzip_out,
                            gzip_level=opt.compression, chunk_records=self.chunk_records, qc_sample=opt.qc_sample,

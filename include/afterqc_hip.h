@@ -375,10 +375,6 @@ typedef struct aqc_pipe_result {
 } aqc_pipe_result;
 
 int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_t io_threads, aqc_pipe** out);
-/* optional: page-lock the pipe's rings from a side thread now (chunks of chunk_records records of ~bytes_per_record bytes, 0 =
- * 360), so that a fresh process does not pay for it inside aqc_pipe_run; call it before other start-up work (the pre-filter
- * sampling pass of preprocesser.py:247-251) */
-int aqc_pipe_prepare(aqc_pipe* p, uint64_t chunk_records, double bytes_per_record, int32_t n_files);
 void aqc_pipe_destroy(aqc_pipe* p);
 int aqc_pipe_run(aqc_pipe* p, const aqc_pipe_io* io, const aqc_pipe_opts* opts, aqc_pipe_result* result);
 const char* aqc_pipe_last_error(void);

@@ -1,5 +1,5 @@
 // gz_rate.cpp — how the pipe's gzip codec scales with threads on this host (no GPU):
-//   g++ -O3 -std=c++17 -pthread tools/ubench/gz_rate.cpp afterqc_amd/csrc/aqc_{inflate,gunzip,deflate}.cpp -lz -o /tmp/gz_rate
+//   g++ -O3 -std=c++17 -pthread [-DAQC_GZ_PROFILE] tools/ubench/gz_rate.cpp afterqc_amd/csrc/aqc_{inflate,gunzip,deflate}.cpp -lz -o /tmp/gz_rate
 //   /tmp/gz_rate [MiB of FASTQ text, default 1024]
 // inflate: ONE single-member .gz (zlib level 2, what Python's gzip writes) through ParallelGunzip with T pool threads;
 // deflate: the same text as 0xff00-byte BGZF-style blocks over T threads.
@@ -16,6 +16,10 @@
 #include "../../afterqc_amd/csrc/aqc_gz.hpp"
 
 using namespace aqcgz;
+#ifdef AQC_GZ_PROFILE
+#include <atomic>
+namespace aqcgz { extern std::atomic<long> gz_prof[6]; }
+#endif
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char** argv) {
@@ -79,6 +83,10 @@ int main(int argc, char** argv) {
             const bool ok = !pg.failed() && got == text.size() && !memcmp(out.data(), text.data(), got);
             printf("inflate  T=%-3d %7.0f MB/s of text  (%s; sections %llu ok, %llu discarded, %.1f MB sequential; section %zu KiB, %d in flight)\n", T, text.size() / dt / 1e6,
                    ok ? "exact" : "MISMATCH", (unsigned long long)pg.sections_accepted, (unsigned long long)pg.sections_discarded, pg.bridged_bytes / 1e6, sec >> 10, inflight);
+#ifdef AQC_GZ_PROFILE
+            printf("         thread-ms: find %ld, decode %ld, translate %ld, crc %ld, consumer waiting %ld, accept %ld\n", gz_prof[0].exchange(0) / 1000, gz_prof[1].exchange(0) / 1000,
+                   gz_prof[2].exchange(0) / 1000, gz_prof[3].exchange(0) / 1000, gz_prof[4].exchange(0) / 1000, gz_prof[5].exchange(0) / 1000);
+#endif
         }
         // ---- deflate
         {
