@@ -22,6 +22,7 @@
 #include "aqc_gunzip_dev.hpp"
 #include "aqc_gz.hpp"
 #include <zlib.h>
+#include <sys/mman.h>
 
 using namespace aqc;
 
@@ -212,6 +213,13 @@ int aqc_create(int device, int n_slots, aqc_ctx** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(AQC_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= n) return fail(AQC_ERR_ARG, "device %d out of range (%d visible)", device, n);
     HIP_TRY(hipSetDevice(device));
+    {
+        // host threads waiting for a stream sleep instead of spinning: the pipe keeps half a dozen of them in
+        // hipStreamSynchronize, and under a CPU quota every spinning waiter is a core the gzip decoder does not get
+        // (AQC_SYNC=spin keeps the runtime's default)
+        const char* sy = getenv("AQC_SYNC");
+        if (!(sy && !strcmp(sy, "spin")) && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
+    }
     aqc_ctx* c = new aqc_ctx();
     c->device = device;
     c->n_slots = n_slots;
@@ -1146,15 +1154,50 @@ int aqc_fetch_text(aqc_ctx* c, int slot, int file, int stream, uint8_t* dst, uin
     return check_status(*s);
 }
 
+// Page-locked host memory.  Not hipHostMalloc: in a fresh process that costs 0.17 s per GiB (4 KiB pages faulted and pinned one by
+// one, and calls from several threads serialise), which is as long as the whole 10 M-read job takes.  Anonymous memory on
+// transparent huge pages, touched and then registered, is the same memory to the DMA engines (56.7 GB/s H2D either way) for
+// 0.04 s per GiB, and threads do it side by side (tools/ubench/pin_rate.cpp).  Portable: the rings are filled by reader threads
+// under whichever device is current and DMA-ed from by any context.
+namespace {
+struct HostRegion { void* user; void* base; size_t map_len; bool registered; };
+std::mutex g_host_mu;
+std::vector<HostRegion> g_host_regions;
+}  // namespace
+
 void* aqc_host_alloc(uint64_t bytes) {
+    const size_t HUGE = 2u << 20;
+    const size_t len = (((size_t)(bytes ? bytes : 1)) + HUGE - 1) & ~(HUGE - 1);
+    void* base = bytes >= (1u << 20) ? mmap(nullptr, len + HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0) : MAP_FAILED;
+    if (base != MAP_FAILED) {
+        uint8_t* p = (uint8_t*)(((uintptr_t)base + HUGE - 1) & ~(uintptr_t)(HUGE - 1));
+        (void)madvise(p, len, MADV_HUGEPAGE);
+        for (size_t o = 0; o < len; o += 4096) ((volatile uint8_t*)p)[o] = 0;
+        if (hipHostRegister(p, len, hipHostRegisterPortable) == hipSuccess) {
+            std::lock_guard<std::mutex> g(g_host_mu);
+            g_host_regions.push_back(HostRegion{p, base, len + HUGE, true});
+            return p;
+        }
+        (void)hipGetLastError();
+        munmap(base, len + HUGE);
+    }
     void* p = nullptr;
-    // portable: the rings are filled by reader threads under whichever device is current and DMA-ed from by any context
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
     return p;
 }
 
 void aqc_host_free(void* p) {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    HostRegion r{nullptr, nullptr, 0, false};
+    {
+        std::lock_guard<std::mutex> g(g_host_mu);
+        for (size_t i = 0; i < g_host_regions.size(); ++i)
+            if (g_host_regions[i].user == p) { r = g_host_regions[i]; g_host_regions.erase(g_host_regions.begin() + (long)i); break; }
+    }
+    if (r.registered) {
+        (void)hipHostUnregister(r.user);
+        munmap(r.base, r.map_len);
+    } else (void)hipHostFree(p);
 }
 
 int aqc_sync(aqc_ctx* c, int slot) {

@@ -6,6 +6,8 @@
 #include <deque>
 #include <mutex>
 
+#include <sys/mman.h>
+
 #include "aqc_gz.hpp"
 
 #if defined(__x86_64__)
@@ -91,27 +93,42 @@ constexpr size_t BRIDGE_CAP = 1u << 20;
 
 }  // namespace
 
-// a section's symbols: WINDOW marker entries, then the output.  Plain malloc'ed memory in 2 Mi-symbol size classes, recycled
-// through Shared::free_bufs — a std::vector would zero-fill (and page-fault) 30 MB per section, which costs as much as
-// decoding it.
+// a section's symbols: WINDOW marker entries, then the output.  Anonymous mappings on transparent huge pages in 2 Mi-symbol size
+// classes, recycled through Shared::free_bufs — a std::vector would zero-fill and page-fault 30 MB per section in 4 KiB steps,
+// which costs as much as decoding it.
 struct SymBuf {
     uint16_t* p = nullptr;
-    size_t cap = 0;                             // symbols behind the WINDOW prefix (512 more are allocated as slack)
+    size_t cap = 0;                             // symbols behind the WINDOW prefix (512 more are mapped as slack)
     SymBuf() = default;
-    SymBuf(SymBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
-    SymBuf& operator=(SymBuf&& o) noexcept { if (this != &o) { free(p); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
+    SymBuf(SymBuf&& o) noexcept : p(o.p), cap(o.cap), base_(o.base_), len_(o.len_) { o.forget(); }
+    SymBuf& operator=(SymBuf&& o) noexcept {
+        if (this != &o) { drop(); p = o.p; cap = o.cap; base_ = o.base_; len_ = o.len_; o.forget(); }
+        return *this;
+    }
     SymBuf(const SymBuf&) = delete;
     SymBuf& operator=(const SymBuf&) = delete;
-    ~SymBuf() { free(p); }
+    ~SymBuf() { drop(); }
     static size_t round_up(size_t n) { return (n + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1); }
     bool grow(size_t want) {                    // keeps the contents
         want = round_up(want);
         if (want <= cap) return true;
-        uint16_t* q = (uint16_t*)realloc(p, (WINDOW + want + 512) * sizeof(uint16_t));
-        if (!q) return false;
-        p = q; cap = want;
+        const size_t HUGE = 2u << 20;
+        const size_t bytes = ((WINDOW + want + 512) * sizeof(uint16_t) + HUGE - 1) & ~(HUGE - 1);
+        void* m = mmap(nullptr, bytes + HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) return false;
+        uint16_t* q = (uint16_t*)(((uintptr_t)m + HUGE - 1) & ~(uintptr_t)(HUGE - 1));
+        (void)madvise(q, bytes, MADV_HUGEPAGE);
+        if (p) memcpy(q, p, (WINDOW + cap + 512) * sizeof(uint16_t));
+        drop();
+        p = q; cap = want; base_ = m; len_ = bytes + HUGE;
         return true;
     }
+
+private:
+    void* base_ = nullptr;
+    size_t len_ = 0;
+    void forget() { p = nullptr; cap = 0; base_ = nullptr; len_ = 0; }
+    void drop() { if (base_) munmap(base_, len_); forget(); }
 };
 
 struct ParallelGunzip::Shared {

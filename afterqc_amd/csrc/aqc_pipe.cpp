@@ -278,12 +278,14 @@ struct GzSource : Source {
                 bgzf = is_bgzf_header(map, size);
                 if (!bgzf) {
                     const int threads = std::max(1, pool->size());
-                    const int inflight = std::max(4, std::min(threads + threads / 2, 96));
+                    // sections in flight: enough to keep the granted CPUs busy while the consumer commits (the pool holds 4 threads
+                    // per CPU); more only means more symbol buffers touched for the first time (tools/gpu_gzrate.sh, GZ_MATRIX)
+                    const int inflight = std::max(4, std::min(threads / 2, 32));
                     size_t sec = section_bytes;
                     if (!sec) {
                         if (const char* e = getenv("AQC_GZ_SECTION")) sec = (size_t)atoll(e);
                     }
-                    if (!sec) sec = std::min<size_t>(4u << 20, std::max<size_t>(256u << 10, size / (size_t)(4 * inflight)));
+                    if (!sec) sec = std::min<size_t>(2u << 20, std::max<size_t>(256u << 10, size / (size_t)(4 * inflight)));
                     pg.reset(new aqcgz::ParallelGunzip(map, size, pool, inflight, sec));
                 }
                 return;

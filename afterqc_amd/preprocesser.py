@@ -427,6 +427,7 @@ class seqFilter:
         # writer below as a cross-check.  An injected engine without the text calls takes the host path.
         self.text_path = self.use_text_path and hasattr(eng, "frame")
         t_p2 = time.perf_counter()
+        cpu_p2 = sum(os.times()[:2])
         outs = None
         extra_bases = None
         readers = []
@@ -457,6 +458,7 @@ class seqFilter:
         if outs is not None:
             outs.close()
         self.timing["pass2_s"] = time.perf_counter() - t_p2
+        self.timing["pass2_cpu_s"] = sum(os.times()[:2]) - cpu_p2          # user + system, all threads: how many cores pass 2 kept busy
 
         try:
             # statistics: per-GPU integers summed on the host (only the pipe spreads a run over several engines)

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--dir", default="/tmp/aqc_e2e")
     ap.add_argument("--single", action="store_true")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--reuse", action="store_true", help="use the input files a previous --keep run left in --dir (same --pairs / flavour) instead of making them again")
     ap.add_argument("--gz", action="store_true", help="gzip input (and therefore, like upstream, gzip output): ONE gzip member per file, "
                     "made with `gzip -<level>` — what real-world .fq.gz files are")
     ap.add_argument("--gz-level", type=int, default=6, help="level of the single-member .gz inputs (gzip's default: 6)")
@@ -44,9 +45,10 @@ def main():
     stem = "barcode_" if args.config5 else ""
     r1, r2 = os.path.join(args.dir, stem + "R1" + ext), os.path.join(args.dir, stem + "R2" + ext)
     t = time.perf_counter()
-    d = synth.make_pairs(args.pairs, 250 if args.config5 else 150, seed=1005 if args.config5 else 1003,
+    have = args.reuse and os.path.exists(r1) and (args.single or os.path.exists(r2))
+    d = None if have else synth.make_pairs(args.pairs, 250 if args.config5 else 150, seed=1005 if args.config5 else 1003,
                          workers=max(1, (os.cpu_count() or 8) // 2))
-    if args.config5:
+    if args.config5 and not have:
         d = synth.add_barcodes(d, 1005 + 7)
         os.makedirs(os.path.join(args.dir, "D"), exist_ok=True)
         with open(os.path.join(args.dir, "D", "circles.csv"), "w") as f:
@@ -54,7 +56,9 @@ def main():
             f.write("x,y,radius,lane,tile\n")
             for k in range(8):
                 f.write("%r,%r,%r,1,101\n" % (250000.0 * (k + 1), 50000.0, 3000.0 + 100.0 * k))
-    if args.gz and not args.bgzf:
+    if have:
+        pass
+    elif args.gz and not args.bgzf:
         # single-member .gz: plain text first, then the gzip program (both mates at once)
         import subprocess
         jobs = []
@@ -91,12 +95,15 @@ def main():
     out = {"mode": args.mode, "gz": ("bgzf" if args.bgzf else "single member, gzip -%d" % args.gz_level) if args.gz else False, "pairs": args.pairs, "reads": reads, "input_bytes": in_bytes, "gen_s": round(gen_s, 1),
            "wall_s": round(wall, 3), "pass1_s": round(flt.timing["pass1_s"], 3), "pass2_s": round(flt.timing["pass2_s"], 3),
            "e2e_mreads_s": round(reads / wall / 1e6, 3), "pass2_mreads_s": round(reads / flt.timing["pass2_s"] / 1e6, 3),
-           "pass2_input_gb_s": round(in_bytes / flt.timing["pass2_s"] / 1e9, 3),
+           "pass2_input_gb_s": round(in_bytes / flt.timing["pass2_s"] / 1e9, 3), "pass2_cores_busy": round(flt.timing["pass2_cpu_s"] / flt.timing["pass2_s"], 1),
            "good_reads": s["good_reads"], "bad_reads": s["bad_reads"], "text_path": flt.text_path, "used_pipe": flt.used_pipe,
            "config5": args.config5, "devices": args.devices, "pipe_threads": flt.timing.get("pipe_threads")}
     print(json.dumps(out))
     if not args.keep:
         shutil.rmtree(args.dir, ignore_errors=True)
+    else:
+        for sub in ("good", "bad", "QC"):          # the inputs stay (--reuse), the outputs go: the next run must not start on gigabytes of dirty pages
+            shutil.rmtree(os.path.join(args.dir, sub), ignore_errors=True)
 
 
 if __name__ == "__main__":

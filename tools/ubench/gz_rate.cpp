@@ -64,6 +64,32 @@ int main(int argc, char** argv) {
         printf("text %.2f GB -> .gz %.2f GB (zlib level 2, one stream: %.0f MB/s)\n", text.size() / 1e9, gz.size() / 1e9, text.size() / dt / 1e6);
     }
     std::vector<uint8_t> out(text.size() + 64);
+    if (const char* m = getenv("GZ_MATRIX")) {
+        // GZ_MATRIX="T:section KiB:in flight ..." — inflate only, one line per combination
+        for (const char* q = m; *q;) {
+            int T = 0, kib = 0, fl = 0, used = 0;
+            if (sscanf(q, "%d:%d:%d%n", &T, &kib, &fl, &used) != 3) break;
+            q += used;
+            while (*q == ' ') ++q;
+            aqc_host::Pool pool(T);
+            const double t0 = now();
+            ParallelGunzip pg(gz.data(), gz.size(), &pool, fl, (size_t)kib << 10);
+            size_t got = 0;
+            for (;;) {
+                const size_t k = pg.read(out.data() + got, std::min<size_t>(out.size() - got, 48u << 20));
+                got += k;
+                if (k == 0) break;
+            }
+            const double dt = now() - t0;
+            printf("inflate  T=%-3d section %5d KiB, %3d in flight: %7.0f MB/s of text (%s)\n", T, kib, fl, text.size() / dt / 1e6,
+                   !pg.failed() && got == text.size() && !memcmp(out.data(), text.data(), got) ? "exact" : "MISMATCH");
+#ifdef AQC_GZ_PROFILE
+            printf("         thread-ms: find %ld, decode %ld, translate %ld, crc %ld, consumer waiting %ld, accept %ld\n", gz_prof[0].exchange(0) / 1000, gz_prof[1].exchange(0) / 1000,
+                   gz_prof[2].exchange(0) / 1000, gz_prof[3].exchange(0) / 1000, gz_prof[4].exchange(0) / 1000, gz_prof[5].exchange(0) / 1000);
+#endif
+        }
+        return 0;
+    }
     for (int T : {1, 4, 8, 16, 32, 64, 96, 128}) {
         if (T > (int)std::thread::hardware_concurrency()) break;
         aqc_host::Pool pool(T);
