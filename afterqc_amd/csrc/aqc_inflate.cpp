@@ -502,11 +502,42 @@ uint64_t find_block_start(const uint8_t* data, size_t size, uint64_t from_bit, u
     // (per thread, kept: the scratch output of the trial decode and its marker prefix)
     static thread_local std::unique_ptr<Inflater<uint16_t>> inf;
     static thread_local std::vector<uint16_t> scratch;
-    for (uint64_t bit = from_bit; bit < end_bit; ++bit) {
-        const uint64_t w = load64(data + (bit >> 3)) >> (bit & 7);
-        // BFINAL = 0, BTYPE = 2 (bits: 0, then 0 1 LSB first -> value 0b100 = 4), HLIT <= 29, HDIST <= 29
-        if ((w & 7u) != 4u) continue;
-        if (((w >> 3) & 31u) > 29u || ((w >> 8) & 31u) > 29u) continue;
+    // which of the 8 bit offsets of a byte position can be a block start at all: BFINAL = 0, BTYPE = 2 (bits 0, then 0 1 LSB
+    // first -> value 0b100 = 4) and HLIT <= 29, from the 16 bits at that byte — one table lookup per BYTE of the section
+    // instead of a load and three tests per BIT (the search was 7 % of a .gz run's CPU time)
+    static const struct StartTab {
+        uint8_t t[65536];
+        StartTab() {
+            for (uint32_t x = 0; x < 65536; ++x) {
+                uint8_t m = 0;
+                for (int k = 0; k < 8; ++k)
+                    if (((x >> k) & 7u) == 4u && ((x >> (k + 3)) & 31u) <= 29u) m |= (uint8_t)(1u << k);
+                t[x] = m;
+            }
+        }
+    } ST;
+    uint32_t cand = 0;              // candidate offsets left in the current byte
+    uint64_t byte = from_bit >> 3;
+    bool first = true;
+    for (;;) {
+        if (!cand) {
+            if (!first) ++byte;
+            // skip bytes without candidates
+            for (;; ++byte) {
+                if (byte * 8 >= end_bit) return UINT64_MAX;
+                uint16_t x;
+                memcpy(&x, data + byte, 2);
+                cand = ST.t[x];
+                if (first) { cand &= 0xffu << (from_bit & 7); first = false; }
+                if (cand) break;
+            }
+        }
+        const int k = __builtin_ctz(cand);
+        cand &= cand - 1;
+        const uint64_t bit = byte * 8 + (uint64_t)k;
+        if (bit >= end_bit) return UINT64_MAX;
+        const uint64_t w = load64(data + byte) >> k;
+        if (((w >> 8) & 31u) > 29u) continue;          // HDIST
         // the code-length code must be complete: sum of 2^(7 - len) over its used lengths == 128
         const int hclen = (int)((w >> 13) & 15u) + 4;
         {

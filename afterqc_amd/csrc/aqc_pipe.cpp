@@ -51,12 +51,24 @@
 #include "aqc_gz.hpp"
 #include "aqc_pool.hpp"
 
+#ifdef AQC_GZ_PROFILE
+namespace aqcgz { extern std::atomic<long> gz_prof[6]; }
+#endif
+
 namespace {
 
 char g_pipe_err[512] = "";
 std::mutex g_pipe_err_mu;
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+double thread_cpu_s() {
+    timespec ts;
+    return clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0 ? (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec : 0.0;
+}
+double process_cpu_s() {
+    timespec ts;
+    return clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts) == 0 ? (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec : 0.0;
+}
 uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 using aqc_host::Pool;      // aqc_pool.hpp: parallel_for (front lane) + submit (background lane for speculative work)
@@ -278,9 +290,9 @@ struct GzSource : Source {
                 bgzf = is_bgzf_header(map, size);
                 if (!bgzf) {
                     const int threads = std::max(1, pool->size());
-                    // sections in flight: enough to keep the granted CPUs busy while the consumer commits (the pool holds 4 threads
-                    // per CPU); more only means more symbol buffers touched for the first time (tools/gpu_gzrate.sh, GZ_MATRIX)
-                    const int inflight = std::max(4, std::min(threads / 2, 32));
+                    // sections in flight: one per pool thread (a single-end run has only this stream to keep them busy); more only
+                    // means more symbol buffers touched for the first time (tools/gpu_gzrate.sh, GZ_MATRIX)
+                    const int inflight = std::max(4, std::min(threads, 32));
                     size_t sec = section_bytes;
                     if (!sec) {
                         if (const char* e = getenv("AQC_GZ_SECTION")) sec = (size_t)atoll(e);
@@ -995,10 +1007,14 @@ int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_
     unsigned share = 1;
     if (const char* lw = getenv("LOCAL_WORLD_SIZE")) share = (unsigned)std::max(1, atoi(lw));
     unsigned dflt = std::min(96u, std::max(4u, hc * 3 / 8 / share));
-    // ... but never far beyond what the container may actually use: under a cgroup CPU quota (the MI355X boxes: 256 hardware
-    // threads visible, cpu.max = 16 CPUs) more runnable threads only get the whole group throttled
+    // ... but not beyond what the container may actually use: under a cgroup CPU quota (the MI355X boxes: 256 hardware threads
+    // visible, cpu.max = 16 CPUs) more runnable threads get the whole group throttled in bursts and run with cold caches.
+    // Measured on such a box (tools/gpu_r3f.sh, 10 M reads, gzip -1 single-member input -> .gz): pool of 16 / 24 / 32 / 48 / 64 /
+    // 96 threads = 0.45 / 0.48 / 0.46 / 0.55 / 0.62 / 0.69 s; plain files 16 / 32 / 64 = 0.25 / 0.27 / 0.29 s.
     const double quota = cgroup_cpu_quota();
-    if (quota > 0) dflt = std::min(dflt, std::max(4u, (unsigned)(quota * 4.0 / share + 0.5)));      // (measured: 2 .. 4 threads per granted CPU do best, profiles/r03_gz_codec_scaling.txt)
+    if (quota > 0) dflt = std::min(dflt, std::max(4u, (unsigned)(quota * 1.25 / share + 0.5)));
+    if (io_threads <= 0)
+        if (const char* e = getenv("AQC_IO_THREADS")) io_threads = std::min(256, atoi(e));
     p->io_threads = io_threads > 0 ? io_threads : (int)dflt;
     p->pool.reset(new Pool(p->io_threads));
     const int ring = n_ctx * slots_per_ctx + 2;
@@ -1067,15 +1083,19 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
     }
     const bool dbg = getenv("AQC_PIPE_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "pipe: outputs open at %.4f s\n", now_s() - t0);
+    // (AQC_PIPE_DEBUG: CPU seconds per kind of thread, printed at the end — who uses the host's cores)
+    std::atomic<long> cpu_us[5] = {{0}, {0}, {0}, {0}, {0}};       // file writers, readers, dispatcher, slot workers, commit thread
+    const double cpu_proc0 = process_cpu_s(), cpu_pool0 = dbg ? P->pool->cpu_seconds() : 0.0;
+    auto timed = [&cpu_us](int kind, auto&& body) { body(); cpu_us[kind] += (long)(thread_cpu_s() * 1e6); };
     std::vector<std::thread> fw;
     for (int q = 0; q < 6; ++q)
-        if (R.out[q].fd >= 0) fw.emplace_back([&R, q] { R.file_writer(q); });
+        if (R.out[q].fd >= 0) fw.emplace_back([&R, q, &timed] { timed(0, [&] { R.file_writer(q); }); });
     std::vector<std::thread> th;
-    for (int f = 0; f < R.nf; ++f) th.emplace_back([&R, f] { R.reader(f); });
-    th.emplace_back([&R] { R.dispatcher(); });
+    for (int f = 0; f < R.nf; ++f) th.emplace_back([&R, f, &timed] { timed(1, [&] { R.reader(f); }); });
+    th.emplace_back([&R, &timed] { timed(2, [&] { R.dispatcher(); }); });
     for (int ci = 0; ci < P->n_ctx; ++ci)
-        for (int s = 0; s < P->slots; ++s) th.emplace_back([&R, ci, s] { R.worker(ci, s); });
-    std::thread wr([&R] { R.writer(); });
+        for (int s = 0; s < P->slots; ++s) th.emplace_back([&R, ci, s, &timed] { timed(3, [&] { R.worker(ci, s); }); });
+    std::thread wr([&R, &timed] { timed(4, [&] { R.writer(); }); });
     for (auto& t : th) t.join();
     if (dbg) fprintf(stderr, "pipe: readers / workers done at %.4f s\n", now_s() - t0);
     // all producers are done: if the last chunk never arrived (abort / anomaly) the writer must not wait for it
@@ -1094,7 +1114,18 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
             R.out[q].close_();
         }
     }
-    if (dbg) fprintf(stderr, "pipe: files closed at %.4f s\n", now_s() - t0);
+    if (dbg) {
+        fprintf(stderr, "pipe: files closed at %.4f s\n", now_s() - t0);
+        const double proc = process_cpu_s() - cpu_proc0, pool = P->pool->cpu_seconds() - cpu_pool0;
+        double named = 0;
+        for (auto& c : cpu_us) named += 1e-6 * (double)c.load();
+        fprintf(stderr, "pipe: CPU seconds — process %.3f = pool %.3f + readers %.3f + dispatcher %.3f + slot workers %.3f + commit %.3f + file writers %.3f + other threads (GPU runtime, caller) %.3f\n",
+                proc, pool, 1e-6 * cpu_us[1], 1e-6 * cpu_us[2], 1e-6 * cpu_us[3], 1e-6 * cpu_us[4], 1e-6 * cpu_us[0], proc - pool - named);
+#ifdef AQC_GZ_PROFILE
+        fprintf(stderr, "pipe: gunzip thread-CPU ms — find %ld, decode (find included) %ld, translate %ld, crc %ld, consumer waiting %ld, accept %ld\n", aqcgz::gz_prof[0].exchange(0) / 1000,
+                aqcgz::gz_prof[1].exchange(0) / 1000, aqcgz::gz_prof[2].exchange(0) / 1000, aqcgz::gz_prof[3].exchange(0) / 1000, aqcgz::gz_prof[4].exchange(0) / 1000, aqcgz::gz_prof[5].exchange(0) / 1000);
+#endif
+    }
     res->records = R.records.load();
     res->t_read = 1e-9 * (double)R.ns_read.load(); res->t_count = 1e-9 * (double)R.ns_count.load();
     res->t_frame = 1e-9 * (double)R.ns_frame.load(); res->t_kernels = 1e-9 * (double)R.ns_kernels.load();

@@ -11,6 +11,9 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <pthread.h>
+#include <time.h>
+
 #include <thread>
 #include <vector>
 
@@ -30,6 +33,16 @@ public:
         for (auto& t : th_) t.join();
     }
     int size() const { return (int)th_.size(); }
+    // CPU seconds the pool's threads have used so far (diagnostics: AQC_PIPE_DEBUG)
+    double cpu_seconds() {
+        double total = 0;
+        for (auto& t : th_) {
+            clockid_t cid;
+            timespec ts;
+            if (pthread_getcpuclockid(t.native_handle(), &cid) == 0 && clock_gettime(cid, &ts) == 0) total += (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+        }
+        return total;
+    }
 
     void submit(std::function<void()> job, bool background = false) {
         if (th_.empty()) { job(); return; }

@@ -4,6 +4,7 @@
 // buffered and O_DIRECT; two files at once.  read side: T threads pread()-ing a page-cached file.  Plus a memcpy ceiling.
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -33,8 +34,10 @@ int main(int argc, char** argv) {
     snprintf(path[1], 300, "%s/io_probe_b.bin", dir);
     auto report = [&](const char* what, int T, double dt, size_t bytes) { printf("%-46s T=%-3d %.3f s  %6.2f GB/s\n", what, T, dt, bytes / dt / 1e9); fflush(stdout); };
 
+    const bool only_mmap = argc > 3;          // io_probe <dir> <GiB> mmap: just the write() baseline and the shared-mapping variants
     // memcpy ceiling
     for (int T : {1, 4, 16, 32}) {
+        if (only_mmap) break;
         char* dst = aligned((size_t)T * (64 << 20));
         double t0 = now();
         std::vector<std::thread> th;
@@ -67,7 +70,7 @@ int main(int argc, char** argv) {
         unlink(path[1]);
     }
     // 3. T threads, disjoint contiguous ranges of one file: buffered (with / without fallocate), O_DIRECT
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 4 && !only_mmap; ++mode) {
         for (int T : {2, 4, 8, 16}) {
             unlink(path[0]);
             int flags = O_WRONLY | O_CREAT | O_TRUNC | (mode >= 2 ? O_DIRECT : 0);
@@ -97,6 +100,7 @@ int main(int argc, char** argv) {
     }
     // 3b. interleaved 8 MiB pieces (what a chunk-ordered writer would do) O_DIRECT
     for (int T : {4, 8}) {
+        if (only_mmap) break;
         unlink(path[0]);
         int fd = open(path[0], O_WRONLY | O_CREAT | O_TRUNC | O_DIRECT, 0644);
         if (fd < 0) break;
@@ -109,6 +113,33 @@ int main(int argc, char** argv) {
         report("pwrite interleaved 8 MiB, O_DIRECT+fallocate", T, now() - t0, N);
         close(fd);
     }
+    // 3c. shared mapping of the new file, T threads memcpy disjoint ranges into it (page faults instead of write(): no inode lock)
+    for (int mode = 0; mode < 3; ++mode) {
+        for (int T : {1, 2, 4, 8, 16}) {
+            unlink(path[0]);
+            int fd = open(path[0], O_RDWR | O_CREAT | O_TRUNC, 0644);
+            if (fd < 0) break;
+            double t0 = now();
+            if (mode == 1) { if (posix_fallocate(fd, 0, N)) printf("fallocate failed\n"); }
+            else if (ftruncate(fd, N)) printf("ftruncate failed\n");
+            char* m = (char*)mmap(nullptr, N, PROT_READ | PROT_WRITE, MAP_SHARED | (mode == 2 ? MAP_POPULATE : 0), fd, 0);
+            if (m == MAP_FAILED) { printf("mmap failed (%s)\n", strerror(errno)); close(fd); break; }
+            double tf = now() - t0;
+            std::vector<std::thread> th;
+            const size_t per = N / T;
+            for (int t = 0; t < T; ++t)
+                th.emplace_back([&, t] { for (size_t o = 0; o < per; o += 8 << 20) memcpy(m + t * per + o, src + ((t * per + o) % SRC), 8 << 20); });
+            for (auto& x : th) x.join();
+            double tc = now() - t0;
+            munmap(m, N);
+            close(fd);
+            double dt = now() - t0;
+            const char* nm[3] = {"mmap shared after ftruncate, memcpy ranges", "mmap shared after fallocate, memcpy ranges", "mmap shared + MAP_POPULATE, memcpy ranges"};
+            char w[160]; snprintf(w, 160, "%s (prep %.3f, copy done %.3f)", nm[mode], tf, tc);
+            report(w, T, dt, N);
+        }
+    }
+    if (argc > 3) { unlink(path[0]); return 0; }
     // 4. read side: the file is in the page cache now?  write it buffered first
     {
         unlink(path[0]);
