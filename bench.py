@@ -22,7 +22,8 @@ Other numbers on the same JSON line (never `value`):
                                `value`).  `roofline` is for its dominant kernel (fast_filter_overlap_kernel): HIP-event time
                                on the slot's stream, algorithmic bytes 4L+56 per pair.
   pinned_to_pinned_mreads_s    the pipe fed from / fetched into page-locked host memory (PCIe inclusive, no files)
-  file_to_file_gz              the pipe .gz -> .gz (own codec, host threads), on request (--gz-runs)
+  file_to_file_gz              the pipe .gz -> .gz: ONE-member `gzip -2` inputs decoded by the host pool (aqc_gunzip.cpp), .gz
+                               members built on the device (--gz-runs; by default two runs when the input is the 1-GPU one)
 `cpu_baseline` (N=1): the oracle (scalar C port of the reference loop) on one core over a bounded sample, checked against the
 GPU's verdicts; plus the same port on every host core and a pure-Python stand-in.
 """
@@ -67,7 +68,8 @@ def main():
     ap.add_argument("--chunk-records", type=int, default=1 << 17, help="records per chunk of the pipe")
     ap.add_argument("--pipe-runs", type=int, default=3, help="timed runs of the pinned->pinned pipe (0 = skip)")
     ap.add_argument("--device-steps", type=int, default=10, help="timed steps of the HBM-resident device pipeline (0 = skip)")
-    ap.add_argument("--gz-runs", type=int, default=0, help="timed .gz -> .gz runs of the pipe (0 = skip)")
+    ap.add_argument("--gz-runs", type=int, default=-1, help="timed .gz -> .gz runs of the pipe (0 = skip; default: 2 for the 1-GPU input, where making "
+                    "the inputs with gzip -2 takes ~20 s, else 0)")
     ap.add_argument("--device-only", action="store_true", help="profiling runs (rocprofv3): only the HBM-resident device step, no pipe "
                     "runs; `value` is then the device step and says so")
     ap.add_argument("--contexts", type=int, default=1, help="contexts per device for the one-input pipe runs")
@@ -322,18 +324,19 @@ def main():
                    "seconds_max": round(max(step_times), 4), "where": base or tempfile.gettempdir(),
                    "input_gb": round(text_in * copies / 1e9, 3), "output_gb": round(sum(int(x) for x in last.bytes_out) / 1e9, 3),
                    "contexts": n_ctx, "devices": dev_list, "thread_seconds_last_run": last.breakdown()}
-        # ---- optional: the same through gzip both ways (own codec on host threads; the box's CPU quota is the bound)
-        if args.gz_runs > 0 and rank == 0:
+        # ---- the same through gzip both ways: one-member inputs decoded by the host pool (the box's CPU quota is the bound),
+        # .gz members built on the device
+        gz_runs = args.gz_runs if args.gz_runs >= 0 else (2 if copies == 1 and shutil.which("gzip") else 0)
+        if gz_runs > 0 and rank == 0 and not args.device_only:
             import subprocess
-            gz_paths = []
-            for p in paths:
-                g = p + ".gz"
-                with open(g, "wb") as f:
-                    subprocess.check_call(["gzip", "-2", "-c", p], stdout=f)
-                gz_paths.append(g)
+            gz_paths = [p + ".gz" for p in paths]
+            jobs = [subprocess.Popen(["gzip", "-2", "-c", p], stdout=open(g, "wb")) for p, g in zip(paths, gz_paths)]
+            for j in jobs:
+                if j.wait() != 0:
+                    raise RuntimeError("gzip failed")
             gouts = [(o[0] + ".gz", o[1] + ".gz", None) for o in outs]
             ts = []
-            for it in range(args.gz_runs + 1):
+            for it in range(gz_runs + 1):
                 reset_all()
                 for trio in gouts:
                     for pth in trio:
