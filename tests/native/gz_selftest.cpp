@@ -172,6 +172,25 @@ int main(int argc, char** argv) {
             const size_t got = pg.read(out.data(), out.size());
             CHECK(!pg.failed() && got == all.size() && !memcmp(out.data(), all.data(), all.size()), "multi-member: %zu of %zu (%s)", got, all.size(), pg.error());
         }
+        // one record over and over (ratio in the hundreds): a section's output outgrows its symbol buffer many times over
+        {
+            const auto rec = fastq_like(1, 77);
+            std::vector<uint8_t> rep;
+            while (rep.size() < (bench ? 200u : 48u) * 1000 * 1000) rep.insert(rep.end(), rec.begin(), rec.end());
+            auto gz = zlib_deflate(rep, 6, 31);
+            ParallelGunzip pg(gz.data(), gz.size(), &pool, 6, 64 << 10);
+            std::vector<uint8_t> out(rep.size() + 10);
+            size_t got = 0;
+            for (;;) {
+                const size_t want = std::min<size_t>(out.size() - got, 5u << 20);
+                const size_t k = pg.read(out.data() + got, want);
+                got += k;
+                if (k < want) break;
+            }
+            CHECK(!pg.failed() && got == rep.size() && !memcmp(out.data(), rep.data(), rep.size()), "repeated record: %zu of %zu (%s)", got, rep.size(), pg.error());
+            printf("gunzip of a repeated record: %zu B -> %zu B, sections accepted %llu discarded %llu bridged %llu B\n", gz.size(), rep.size(), (unsigned long long)pg.sections_accepted,
+                   (unsigned long long)pg.sections_discarded, (unsigned long long)pg.bridged_bytes);
+        }
         // non-text payload: the block finder finds nothing, everything is bridged, still exact
         {
             auto gz = zlib_deflate(sets[1].second, 6, 31);
