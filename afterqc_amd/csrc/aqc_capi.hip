@@ -151,6 +151,7 @@ struct aqc_ctx {
     DevBuf kmer_partial;          // per-round u16 count slices of kmer_count_kernel
     DevBuf gz_crc;                // GzCrcTables (aqc_compress)
     hipStream_t qc_stream = nullptr;   // statRead kernels (latency-bound, a few thousand waves) run beside the slots' bandwidth-bound kernels
+    std::mutex qc_mu;             // aqc_qc_stat calls of different slots queue up here: they share kmer_partial and the QC stream
     DevCircles circles{};
     unsigned long long *counters = nullptr, *ovl_hist = nullptr, *dist_hist = nullptr;
     QcDev qc[4];
@@ -575,6 +576,8 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
     if (mate == 1 && !s->paired) return fail(AQC_ERR_ARG, "aqc_qc_stat: mate 1 of a single-end slot");
     if (post && !s->ran) return fail(AQC_ERR_STATE, "aqc_qc_stat(post) before aqc_run");
     if (count == 0) return 0;
+    // one call at a time per context: the count -> reduce pairs below go through ONE slice buffer (kmer_partial) in stream order
+    std::lock_guard<std::mutex> qc_lock(c->qc_mu);
     QcDev& q = c->qc[which];
     if ((rc = ensure_kmer(c, q))) return rc;
     // the statRead kernels go to the context's QC stream, behind everything queued on the slot's stream so far (text, results):

@@ -344,8 +344,11 @@ class seqFilter:
 
     # ---- the run -----------------------------------------------------------------------------------
     def run(self):
+        import time
         opt = self.options
+        t_init = time.perf_counter()
         eng = self._engine()
+        t_init = time.perf_counter() - t_init        # (a fresh process: HIP runtime start + the library's code object)
         paired = self.paired
         if opt.debubble:
             self.bubbleCircles = load_circles(opt.debubble_dir)
@@ -353,8 +356,7 @@ class seqFilter:
         if opt.barcode:
             opt.trim_front = 0
 
-        import time
-        self.timing = {}
+        self.timing = {"init_s": t_init}
         t_run = time.perf_counter()
         has_i1 = opt.index1_file is not None
         has_i2 = opt.index2_file is not None
@@ -371,8 +373,24 @@ class seqFilter:
         r2post = QualityControl(opt.qc_sample, opt.qc_kmer, eng, capi.QC_R2_POST)
         single = lambda rb: capi.Batch.from_raw(rb)
         if self.use_text_path and hasattr(eng, "frame"):
-            r1pre.statFileText(opt.read1_file, self.chunk_bytes)
-            if paired:
+            side, side_err = None, []
+            if paired and isinstance(eng, capi.Engine) and eng.n_slots >= 2:
+                # read 2 is sampled at the same time in slot 1 (a .gz spends most of this pass decoding)
+                def _sample_r2():
+                    try:
+                        r2pre.statFileText(opt.read2_file, self.chunk_bytes, slot=1)
+                    except BaseException as e:       # re-raised on the main thread
+                        side_err.append(e)
+                side = threading.Thread(target=_sample_r2, name="aqc-sample-r2")
+                side.start()
+            try:
+                r1pre.statFileText(opt.read1_file, self.chunk_bytes)
+            finally:
+                if side is not None:
+                    side.join()
+            if side_err:
+                raise side_err[0]
+            if paired and side is None:
                 r2pre.statFileText(opt.read2_file, self.chunk_bytes)
         else:
             r1pre.statFile(opt.read1_file, fastq.Reader, single, self.batch_records)
@@ -460,6 +478,7 @@ class seqFilter:
         self.timing["pass2_s"] = time.perf_counter() - t_p2
         self.timing["pass2_cpu_s"] = sum(os.times()[:2]) - cpu_p2          # user + system, all threads: how many cores pass 2 kept busy
 
+        t_stats = time.perf_counter()
         try:
             # statistics: per-GPU integers summed on the host (only the pipe spreads a run over several engines)
             stat_eng = capi.MergedEngines(self._engines()) if self.extra_engines else eng
@@ -472,6 +491,8 @@ class seqFilter:
             stat_path = os.path.join(qc_dir, os.path.basename(opt.read1_file) + ".json")
             with open(stat_path, "w") as f:
                 f.write(json.dumps(self.stat, sort_keys=True, indent=4, separators=(',', ': ')))
+            self.timing["stats_s"] = time.perf_counter() - t_stats
+            t_report = time.perf_counter()
             # the HTML report next to it (preprocesser.py:780-783, qcreporter.py).  The FASTQ outputs and the statistics are
             # complete at this point: a problem in the report is reported, it does not fail the run
             try:
@@ -484,14 +505,17 @@ class seqFilter:
                 print("afterqc_amd: the HTML report could not be written (%s: %s); outputs and %s are complete"
                       % (type(e).__name__, e, stat_path), file=sys.stderr)
                 self.timing["report_error"] = "%s: %s" % (type(e).__name__, e)
+            self.timing["report_s"] = time.perf_counter() - t_report
             self.timing["total_s"] = time.perf_counter() - t_run
         finally:
+            t_close = time.perf_counter()
             if self.own_engine:
                 for e in [self.engine] + self.extra_engines:
                     if e is not None:
                         e.close()
                 self.engine = None
                 self.extra_engines = []
+            self.timing["close_s"] = time.perf_counter() - t_close
         return self.stat
 
     # ---- pass 2 through the whole-input pipe (aqc_pipe_run) ---------------------------------------------------------------

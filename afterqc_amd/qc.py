@@ -75,6 +75,29 @@ class QualityControl:
         cnt = self._kmer_cnt.tolist()
         return {self._kmer_str(j): cnt[j] for j in range(len(cnt))}
 
+    def kmer_pairs(self, indices):
+        """(forward counts, reverse-complement counts) of the k-mers at positions `indices` of the count-sorted list — what
+        strandBiasPlotly looks up one by one in the kmerCount dict (qualitycontrol.py:238-270: complement through COMP with 'N'
+        for any other character, 0 for a reverse complement that was never seen); vectorised: the dict of all 4^k strings costs
+        more to build than the rest of the report"""
+        if self._kmer_sorted is None:
+            self._kmer_sorted = np.argsort(-self._kmer_cnt, kind="stable")
+        j = self._kmer_sorted[np.asarray(indices, dtype=np.int64)]
+        k = self.kmerLen
+        raw = np.frombuffer(self._kmer_raw, dtype=np.uint8).reshape(-1, 8)
+        comp = np.full(256, ord("N"), dtype=np.uint8)
+        for a, b in ("AT", "TA", "CG", "GC", "at", "ta", "cg", "gc", "NN"):
+            comp[ord(a)] = ord(b)
+        rc = np.zeros((len(j), 8), dtype=np.uint8)
+        rc[:, :k] = comp[raw[j, :k]][:, ::-1]
+        want = rc.view("<u8").ravel()
+        keys = np.frombuffer(self._kmer_raw, dtype="<u8")
+        order = np.argsort(keys, kind="stable")
+        pos = np.minimum(np.searchsorted(keys[order], want), max(len(keys) - 1, 0))
+        hit = keys[order][pos] == want if len(keys) else np.zeros(len(want), dtype=bool)
+        rev = np.where(hit, self._kmer_cnt[order][pos] if len(keys) else 0, 0)
+        return self._kmer_cnt[j].tolist(), [int(x) for x in rev]
+
     @property
     def topKmerCount(self):
         """sortKmer (qualitycontrol.py:155-156): stable, count-descending over dict order; a lazy sequence"""
@@ -150,9 +173,10 @@ class QualityControl:
         return [[k, c] for k, c in self.topKmerCount[:top]]
 
     # ---- sampling policy ----------------------------------------------------------------------------
-    def statFileText(self, filename, chunk_bytes):
+    def statFileText(self, filename, chunk_bytes, slot=0):
         """statFile (qualitycontrol.py:331-357) with the records framed on the device (aqc_frame): the host only reads
-        the file into a page-locked buffer.  Same policy as statFile below."""
+        the file into a page-locked buffer.  Same policy as statFile below.  `slot`: the engine slot to work in (the two
+        files of a pair are sampled side by side, each in its own slot)."""
         from . import fastq
         eng = self.engine
         cap = max(int(chunk_bytes), 4 << 20)          # the first chunk must hold the 999 skipped reads (fallback below)
@@ -165,16 +189,17 @@ class QualityControl:
         seen = 0
         left = 0
         file_eof = False
+        fill = cap                                  # bytes to have in the buffer before framing
         try:
             while stop is None or seen < stop:
                 end = left
-                while not file_eof and end < cap:
-                    got = f.readinto(buf.view[end:cap])
+                while not file_eof and end < fill:
+                    got = f.readinto(buf.view[end:fill])
                     if not got:
                         file_eof = True
                     else:
                         end += got
-                info = eng.frame(0, buf.array, end, file_eof, max_records=(2 ** 64 - 1) if stop is None else stop - seen,
+                info = eng.frame(slot, buf.array, end, file_eof, max_records=(2 ** 64 - 1) if stop is None else stop - seen,
                                  first_index=seen)
                 n = int(info.n)
                 if head is None:
@@ -182,8 +207,8 @@ class QualityControl:
                 a = max(lo, seen)
                 b = seen + n if hi is None else min(hi, seen + n)
                 if b > a:
-                    eng.qc_stat(0, self.which, 0, a - seen, b - a, 0)
-                    eng.sync(0)
+                    eng.qc_stat(slot, self.which, 0, a - seen, b - a, 0)
+                    eng.sync(slot)
                 seen += n
                 if info.eof1 or (file_eof and int(info.avail1) == n):
                     break
@@ -193,19 +218,24 @@ class QualityControl:
                     nb.array[:end] = buf.array[:end]
                     buf.free()
                     buf, cap, left = nb, cap * 2, end
+                    fill = cap
                     continue
                 left = end - int(info.consumed1)
                 if left:
                     buf.array[:left] = buf.array[int(info.consumed1):end].copy()
+                if stop is not None and n:
+                    # only the sample is wanted: read on for about as many bytes as the records still missing take (a .gz is
+                    # decoded for every byte asked for), not for another buffer-full
+                    fill = min(cap, left + int(int(info.consumed1) / n * (stop - seen) * 1.1) + (256 << 10))
             self.readCount = seen
             if max(0, seen - lo) < READ_TO_SKIP and head is not None and min(lo, seen) > 0:
                 if head_n < min(lo, seen):
                     raise RuntimeError("the first chunk must hold at least %d records" % lo)
                 pad = np.zeros(len(head) + 64, dtype=np.uint8)
                 pad[:len(head)] = head
-                eng.frame(0, pad, len(head), True, max_records=min(lo, seen), first_index=0)
-                eng.qc_stat(0, self.which, 0, 0, min(lo, seen), 0)
-                eng.sync(0)
+                eng.frame(slot, pad, len(head), True, max_records=min(lo, seen), first_index=0)
+                eng.qc_stat(slot, self.which, 0, 0, min(lo, seen), 0)
+                eng.sync(slot)
         finally:
             f.close()
             buf.free()

@@ -88,22 +88,16 @@ def strand_bias_figure(qc, div, title):
     most frequent skipped (qualitycontrol.py:238-270; its `/` is python-2 integer division)"""
     if qc.readLen == 0:
         return Figure(title, div, None, None)
-    top_list = qc.topKmerCount
-    total = len(top_list)
-    counts = qc.kmerCount
+    total = len(qc.topKmerCount)
     shift = min(50, total // 2)
     top = min(total - shift, 1000)
     step = max(1, (total - shift) // top) if top > 0 else 1
     fwd, rev, hi = [0] * max(top, 0), [0] * max(top, 0), 0
-    for i in range(top):
-        index = i * step + shift
-        if index >= total:
-            break
-        kmer = top_list[index][0]
-        rc = "".join(_COMP.get(c, "N") for c in reversed(kmer))
-        fwd[i] = counts[kmer]
-        rev[i] = counts.get(rc, 0)
-        hi = max(hi, fwd[i], rev[i])
+    picked = [i * step + shift for i in range(max(top, 0)) if i * step + shift < total]      # (the reference breaks at the first index >= total)
+    if picked:
+        f, r = qc.kmer_pairs(picked)
+        fwd[:len(f)], rev[:len(r)] = f, r
+        hi = max(0, max(f), max(r))
     return Figure(title, div, [{"x": fwd, "y": rev, "mode": "markers", "type": "scatter", "marker": {"size": 2, "color": "rgba(0,0,50,128)"}}],
                   {"title": title, "xaxis": {"title": "relative forward strand KMER count", "range": [-10, hi]},
                    "yaxis": {"title": "relative reverse strand KMER count", "range": [-10, hi]}})

@@ -223,7 +223,9 @@ int aqc_run(aqc_ctx* ctx, int slot, uint64_t accum_limit);
 /* QualityControl.statRead (qualitycontrol.py:73-122) over records [first, first+count) of the slot
  * into accumulator `which`, reading mate 0 (seq1/qual1) or mate 1 (seq2/qual2) of each record.
  * post != 0: stat the FINAL reads (trim + edits from the slot's results applied) and only records
- * whose verdict is AQC_GOOD (preprocesser.py:624-627). */
+ * whose verdict is AQC_GOOD (preprocesser.py:624-627).  Calls for different slots of one context may come from different
+ * threads (they queue up inside); the k-mer dictionary's insertion order follows the records' global indices, so calls
+ * into ONE accumulator must still be issued in record order. */
 int aqc_qc_stat(aqc_ctx* ctx, int slot, int which, int mate, uint64_t first, uint64_t count, int post);
 /* diagnostics: the records of the slot's last aqc_run that the lane-per-read kernel did NOT decide itself but handed to the
  * general wave-per-record kernel (bytes outside A C G T N, reads under 16 bases, the second-scan corner of the adapter

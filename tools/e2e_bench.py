@@ -96,6 +96,8 @@ def main():
            "wall_s": round(wall, 3), "pass1_s": round(flt.timing["pass1_s"], 3), "pass2_s": round(flt.timing["pass2_s"], 3),
            "e2e_mreads_s": round(reads / wall / 1e6, 3), "pass2_mreads_s": round(reads / flt.timing["pass2_s"] / 1e6, 3),
            "pass2_input_gb_s": round(in_bytes / flt.timing["pass2_s"] / 1e9, 3), "pass2_cores_busy": round(flt.timing["pass2_cpu_s"] / flt.timing["pass2_s"], 1),
+           "init_s": round(flt.timing.get("init_s", 0), 3), "stats_s": round(flt.timing.get("stats_s", 0), 3), "report_s": round(flt.timing.get("report_s", 0), 3),
+           "close_s": round(flt.timing.get("close_s", 0), 3),
            "good_reads": s["good_reads"], "bad_reads": s["bad_reads"], "text_path": flt.text_path, "used_pipe": flt.used_pipe,
            "config5": args.config5, "devices": args.devices, "pipe_threads": flt.timing.get("pipe_threads")}
     print(json.dumps(out))
