@@ -42,11 +42,44 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 L = 150
 
 
-def hbm_traffic(args, n_rec):
-    """HBM bytes per launch of the dominant kernel as measured with the PMC counters (FETCH_SIZE / WRITE_SIZE, separate
-    rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md prescribes) for exactly this workload — profiles/hbm_traffic.json,
-    written from the rocprofv3 summaries under profiles/ — or None when that measurement is of another workload.  Counters
-    cannot be read from inside the process that is being measured; `traffic_source` in the JSON line says where it is from."""
+def hbm_traffic(args, n_rec, live):
+    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc
+    passes, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE is in KB and tallies the 128-byte requests of a streaming
+    read at 64 bytes on gfx950, so it is doubled; WRITE_SIZE in KB as reported).  Counters cannot be read from inside the process
+    that is being measured: with `live` two short child runs of this script (`--device-only`, the same workload) are made under
+    rocprofv3 on this box; otherwise, or when that fails, the committed measurement of the same workload is quoted
+    (profiles/hbm_traffic.json).  `traffic_source` in the JSON line says which."""
+    import glob
+    import subprocess
+    rp = shutil.which("rocprofv3")
+    if live and rp and not os.environ.get("AQC_BENCH_CHILD"):
+        tmp = tempfile.mkdtemp(prefix="aqc_pmc_")
+        try:
+            kb = {}
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, counter)
+                cmd = [rp, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--device-only",
+                       "--device-steps", "3", "--cpu-sample", "0", "--workload", args.workload, "--pairs", str(int(n_rec))]
+                subprocess.run(cmd, cwd=tmp, env=dict(os.environ, AQC_BENCH_CHILD="1", TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=300, check=True)
+                tot, cnt = 0.0, 0
+                import csv
+                for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    with open(fn) as fh:
+                        for row in csv.DictReader(fh):
+                            if row["Counter_Name"] == counter and "fast_filter_overlap_kernel" in row["Kernel_Name"]:
+                                tot += float(row["Counter_Value"])
+                                cnt += 1
+                if not cnt:
+                    raise RuntimeError("no dispatch of the kernel in the counter file")
+                kb[counter] = tot / cnt
+            return (int(kb["FETCH_SIZE"] * 1024 * 2 + kb["WRITE_SIZE"] * 1024),
+                    "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over two child runs of this script on this box (--device-only --device-steps 3): "
+                    "FETCH_SIZE %.0f KB x 2 + WRITE_SIZE %.0f KB per launch" % (kb["FETCH_SIZE"], kb["WRITE_SIZE"]))
+        except Exception as e:          # noqa: BLE001 — profiler missing / refused: quote the committed measurement instead
+            sys.stderr.write("bench: live PMC pass failed (%s: %s); quoting profiles/hbm_traffic.json\n" % (type(e).__name__, e))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             t = json.load(f)
@@ -70,6 +103,7 @@ def main():
     ap.add_argument("--device-steps", type=int, default=10, help="timed steps of the HBM-resident device pipeline (0 = skip)")
     ap.add_argument("--gz-runs", type=int, default=-1, help="timed .gz -> .gz runs of the pipe (0 = skip; default: 2 for the 1-GPU input, where making "
                     "the inputs with gzip -2 takes ~20 s, else 0)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with two rocprofv3 --pmc child runs (quote profiles/hbm_traffic.json)")
     ap.add_argument("--device-only", action="store_true", help="profiling runs (rocprofv3): only the HBM-resident device step, no pipe "
                     "runs; `value` is then the device step and says so")
     ap.add_argument("--contexts", type=int, default=1, help="contexts per device for the one-input pipe runs")
@@ -371,7 +405,7 @@ def main():
           "config2": "config2: ONE input of %d synthetic SE 1x150 bp reads as one FASTQ file -> good / bad files, -f 5 -t 5, qc_sample %d" % (n_rec * copies, args.qc_sample),
           "config5": "config5 (plain text; gzip: tools/e2e_bench.py / --gz-runs): ONE input of %d synthetic PE 2x250 bp pairs + 17-base barcode/verify "
                      "prefix as two FASTQ files -> good / bad files, barcode mode, qc_sample %d" % (n_rec * copies, args.qc_sample)}[args.workload]
-    traffic, traffic_src = hbm_traffic(args, n_rec)
+    traffic, traffic_src = hbm_traffic(args, n_rec, live=(rank == 0 and world == 1 and not args.device_only and not args.no_pmc))
     out = {
         "metric": "Mreads/s (paired 2x150 bp) end-to-end good/bad split" if step_times else "DEVICE STEP ONLY (--device-only profiling run, not the metric)",
         "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
