@@ -347,3 +347,54 @@ def test_empty_inputs(gpu_engine):
     gpu_engine.run(0)
     assert gpu_engine.format(0, 0, True) == [0] * 6
     assert not gpu_engine.counters().any()
+
+
+def test_qc_stat_from_two_threads(gpu_engine):
+    """aqc_qc_stat for two slots of one context from two threads at once (the CLI samples both mates of a pair side by side):
+    the calls share one slice buffer and one stream inside, so they must queue up — accumulators and k-mer dictionaries equal a
+    serial run's, call by call interleaved as it comes"""
+    import threading
+    eng = gpu_engine
+    eng.set_config(default_cfg(False))
+    d1 = synth.make_pairs(6000, 150, seed=901, dirty=True)
+    d2 = synth.make_pairs(6000, 150, seed=902, dirty=True)
+    b = [capi.Batch.from_matrices(d1["seq1"], d1["qual1"], d1["len1"]), capi.Batch.from_matrices(d2["seq1"], d2["qual1"], d2["len1"])]
+    which = [capi.QC_R1_PRE, capi.QC_R2_PRE]
+    pieces = [(k * 250, 250) for k in range(24)]
+
+    def serial():
+        eng.reset_stats()
+        for s in (0, 1):
+            eng.upload(s, b[s])
+            for first, count in pieces:
+                eng.qc_stat(s, which[s], 0, first, count, 0)
+            eng.sync(s)
+        return [(eng.qc(w).copy(), [a.copy() for a in eng.kmers(w)]) for w in which]
+
+    def threaded():
+        eng.reset_stats()
+        errs = []
+
+        def work(s):
+            try:
+                eng.upload(s, b[s])
+                for first, count in pieces:
+                    eng.qc_stat(s, which[s], 0, first, count, 0)
+                eng.sync(s)
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(s,)) for s in (0, 1)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        return [(eng.qc(w).copy(), [a.copy() for a in eng.kmers(w)]) for w in which]
+
+    ref = serial()
+    for _ in range(3):
+        got = threaded()
+        for (acc_r, km_r), (acc_g, km_g) in zip(ref, got):
+            assert np.array_equal(acc_r, acc_g)
+            for a, c in zip(km_r, km_g):
+                assert np.array_equal(a, c)
