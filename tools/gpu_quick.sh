@@ -1,7 +1,7 @@
 #!/bin/bash
-# chunk size sweep of the file -> file metric (and .gz -> .gz)
+# stream waits sleeping (default) vs spinning: the HBM-resident device step
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
-for K in 131072 32768 65536 262144 131072; do
-  timeout 300 python bench.py --pipe-runs 0 --device-steps 3 --gz-runs 2 --no-pmc --cpu-sample 0 --steps 6 --warmup 2 --chunk-records $K 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print($K, d['value'], d['file_to_file']['seconds_min'], d['file_to_file']['seconds_mean'], 'gz', d['file_to_file_gz']['mreads_s'])"
+for mode in block spin block spin; do
+  AQC_SYNC=$mode timeout 300 python bench.py --device-only --device-steps 20 --cpu-sample 0 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$mode', d['device_step_mreads_s'], d['device_step']['ms_per_step'], d['roofline']['kernel_ms'])"
 done
