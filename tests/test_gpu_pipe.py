@@ -183,3 +183,50 @@ def test_device_gunzip_sections_are_exact(level, strategy):
     assert rc == 0, (lib.aqc_last_error() or b"").decode()
     assert n_out.value == len(text) and out[:len(text)].tobytes() == text
     assert stats[1] >= 1
+
+
+def test_one_gigabyte_member_is_inflated_exactly(tmp_path):
+    """ONE gzip member of more than 1 GB of FASTQ text (zlib level 1, a single deflate stream) read back through the pipe's
+    parallel decoder (aqc_gunzip.cpp: sections started at block boundaries found mid-stream, committed only when they chain
+    up bit for bit): byte-identical, and the sections really were used.  No kernel is involved — the test runs with the
+    GPU-box suite because of its size (zlib needs ~10 s there to make the member)."""
+    import zlib
+    d = synth.make_pairs(200_000, 150, seed=4242, workers=4)
+    plain = str(tmp_path / "piece.fq")
+    synth.write_fastq_fixed(plain, d["seq1"], d["qual1"], 1)
+    piece = np.fromfile(plain, dtype=np.uint8)
+    os.unlink(plain)
+    reps = (1 << 30) // len(piece) + 1
+    gz = str(tmp_path / "big.fq.gz")
+    want = hashlib.sha256()
+    total = 0
+    comp = zlib.compressobj(1, zlib.DEFLATED, 31)
+    with open(gz, "wb") as f:
+        for r in range(reps):
+            # every repetition gets its own tile number in the read names, so that no two stretches of the file are equal
+            blk = piece.copy()
+            tile = ("%04d" % (1101 + r)).encode()
+            pos = np.flatnonzero(blk == ord("@"))
+            pos = pos[(pos == 0) | (blk[np.maximum(pos, 1) - 1] == 10)]          # '@' at a line start: the name lines (and a few quality lines: harmless)
+            for k, c in enumerate(tile):
+                blk[pos + 13 + k] = np.where(blk[pos + 12] == ord(":"), c, blk[pos + 13 + k])
+            b = blk.tobytes()
+            want.update(b)
+            total += len(b)
+            f.write(comp.compress(b))
+        f.write(comp.flush())
+    assert total > (1 << 30)
+    src = capi.NativeSource(gz, True)
+    got = hashlib.sha256()
+    n = 0
+    buf = np.empty(64 << 20, dtype=np.uint8)
+    while True:
+        k = src.readinto(memoryview(buf))
+        if not k:
+            break
+        got.update(memoryview(buf)[:k])
+        n += k
+    accepted, discarded, sequential, out = src.gz_stats()
+    src.close()
+    assert n == total and got.digest() == want.digest()
+    assert out == total and accepted > 50 and sequential < total // 20, (accepted, discarded, sequential)
