@@ -1009,7 +1009,7 @@ int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_
     unsigned dflt = std::min(96u, std::max(4u, hc * 3 / 8 / share));
     // ... but not beyond what the container may actually use: under a cgroup CPU quota (the MI355X boxes: 256 hardware threads
     // visible, cpu.max = 16 CPUs) more runnable threads get the whole group throttled in bursts and run with cold caches.
-    // Measured on such a box (tools/gpu_r3f.sh, 10 M reads, gzip -1 single-member input -> .gz): pool of 16 / 24 / 32 / 48 / 64 /
+    // Measured on such a box (tools/gpu_pool_sweep.sh, 10 M reads, gzip -1 single-member input -> .gz): pool of 16 / 24 / 32 / 48 / 64 /
     // 96 threads = 0.45 / 0.48 / 0.46 / 0.55 / 0.62 / 0.69 s; plain files 16 / 32 / 64 = 0.25 / 0.27 / 0.29 s.
     const double quota = cgroup_cpu_quota();
     if (quota > 0) dflt = std::min(dflt, std::max(4u, (unsigned)(quota * 1.25 / share + 0.5)));
