@@ -61,7 +61,7 @@ def hbm_traffic(args, n_rec, live):
                 cmd = [rp, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--device-only",
                        "--device-steps", "3", "--cpu-sample", "0", "--workload", args.workload, "--pairs", str(int(n_rec))]
                 subprocess.run(cmd, cwd=tmp, env=dict(os.environ, AQC_BENCH_CHILD="1", TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                               timeout=300, check=True)
+                               timeout=150, check=True)
                 tot, cnt = 0.0, 0
                 import csv
                 for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
