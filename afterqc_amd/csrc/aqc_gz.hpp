@@ -20,7 +20,7 @@
 
 namespace aqcgz {
 
-enum { GZ_OK = 0, GZ_ERR_DATA = -1, GZ_NEED_OUTPUT = 1, GZ_STOPPED = 2, GZ_FINAL = 3 };
+enum { GZ_OK = 0, GZ_ERR_DATA = -1, GZ_NEED_OUTPUT = 1, GZ_STOPPED = 2, GZ_FINAL = 3, GZ_CONTINUE = 4, GZ_SLOW = 5 };
 
 constexpr int LIT_ROOT = 11, DIST_ROOT = 8;
 constexpr int LIT_TABLE = (1 << LIT_ROOT) + 2048, DIST_TABLE = (1 << DIST_ROOT) + 1024;
@@ -52,11 +52,24 @@ struct Inflater {
     // decode until: the final block has ended (GZ_FINAL); a block boundary at or behind stop_bit is reached (GZ_STOPPED);
     // the output is (nearly) full (GZ_NEED_OUTPUT); the data is invalid or ends early (GZ_ERR_DATA)
     int run(uint64_t stop_bit);
+    // one transition of run(): a block header read, or a whole block decoded -> GZ_CONTINUE; else what run() would return
+    int run_step(uint64_t stop_bit);
+    // the rest of the current Huffman block (in_block == 2) -> GZ_OK at its end-of-block code, GZ_NEED_OUTPUT, GZ_ERR_DATA
+    int decode_huffman();
+    // bookkeeping behind a block's end-of-block code (run_step does it itself; for the callers of decode_pair)
+    void end_block() { in_block = 0; blocks++; if (bfinal) final_done = true; }
 
 private:
     int read_header();
-    int decode_huffman();
 };
+
+// Two streams, both inside a Huffman block (in_block == 2), decoded ALTERNATELY symbol group by symbol group until one of them
+// leaves its fast loop: returns 0 / 1 = which one, *rc = GZ_OK (its end-of-block code is consumed: call end_block()),
+// GZ_ERR_DATA, or GZ_SLOW (input or output headroom used up: decode_huffman() takes it from there).  The other stream stops
+// between two symbols, consistent.  One decoder is a single dependency chain that leaves most of a core idle; two independent
+// ones in the same instruction window run at 1.4 - 1.6 x the rate of one after the other (tools/ubench/gz_rate.cpp).
+template <typename OutT>
+int decode_pair(Inflater<OutT>& a, Inflater<OutT>& b, int* rc);
 
 // gzip member header at data[pos]: returns the offset of the deflate data, 0 on a malformed / truncated header
 size_t parse_gzip_header(const uint8_t* data, size_t size, size_t pos);
@@ -68,6 +81,8 @@ uint64_t find_block_start(const uint8_t* data, size_t size, uint64_t from_bit, u
 
 // whole raw-deflate stream with no history into exactly `cap` bytes (BGZF members): returns bytes written or -1
 int64_t inflate_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+// two such streams decoded alternately on one thread (decode_pair): got[k] = bytes written or -1
+void inflate_raw2(const uint8_t* const src[2], const size_t n[2], uint8_t* const dst[2], const size_t cap[2], int64_t got[2]);
 
 uint32_t crc32_fast(uint32_t crc, const uint8_t* p, size_t n);
 uint32_t crc32_combine_fast(uint32_t crc1, uint32_t crc2, uint64_t len2);
@@ -108,6 +123,7 @@ private:
     size_t section_bytes_;
     std::shared_ptr<Shared> sh_;
     std::vector<std::shared_ptr<Section>> q_;       // in flight, by nominal start
+    std::shared_ptr<Section> unlaunched_;          // the last of them, while it waits for a partner (sections are decoded in pairs)
     size_t next_section_ = 0;                      // next section index to launch (nominal start = index * section_bytes)
     uint64_t cur_bit_ = 0;                         // everything before this bit is decoded and committed
     bool started_ = false, done_ = false, bad_ = false;

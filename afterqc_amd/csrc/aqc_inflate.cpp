@@ -2,6 +2,7 @@
 #include <zlib.h>      // crc32 / crc32_combine only
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 
@@ -270,94 +271,151 @@ int Inflater<OutT>::read_header() {
     return GZ_OK;
 }
 
+// ---- the fast loop's state and body --------------------------------------------------------------------------------------
+// One stream position held in locals: 64-bit bit buffer (bb, bc valid bits, ip next byte to load), output cursor, the block's
+// tables.  fast_step() decodes one "group" — up to three table lookups of literals (each up to two bytes), or one match — with
+// no per-bit checks: the caller guarantees >= 32 input bytes and >= 320 output elements of headroom (ip <= ip_end, op < op_end).
+// It is a function of its own (always inlined) because TWO streams can be stepped alternately in one loop: a DEFLATE decoder
+// is one long dependency chain (bit buffer -> table load -> shift -> table load ...) that leaves most of a core's issue slots
+// empty, and FASTQ streams are nearly all matches (94 % of the bytes at gzip -6: two dependent lookups per 8 bytes), so a
+// second, independent chain in the same instruction window comes almost for free (decode_pair below).
+constexpr int FAST_CONT = -100, FAST_BOUNDS = -101;
+template <typename OutT>
+struct FastStream {
+    // hot: five registers per stream (two streams fit the sixteen of x86-64 with room for the temporaries)
+    uint64_t bb;
+    int bc;
+    const uint8_t* ip;
+    OutT* op;                   // output cursor
+    const uint32_t* tab;        // the block's tables: litlen at tab[0 ..], distance at tab[LIT_TABLE ..] (Inflater::lit, ::dist)
+    // cold: only compared against
+    const uint8_t* ip_end;
+    OutT* op_end;
+    OutT* lo;                   // lowest readable output element (out - hist)
+};
+
+// FAST_CONT: go on; FAST_BOUNDS: headroom used up (nothing consumed); GZ_OK: end-of-block code consumed; GZ_ERR_DATA
+template <typename OutT>
+__attribute__((always_inline)) inline int fast_step(FastStream<OutT>& s) {
+    constexpr size_t COPY_W = 8 / sizeof(OutT);            // elements per 8-byte move
+    constexpr uint64_t LMASK = (1u << LIT_ROOT) - 1u, DMASK = (1u << DIST_ROOT) - 1u;
+    if (s.ip > s.ip_end || s.op >= s.op_end) return FAST_BOUNDS;
+    const uint32_t* const L = s.tab;
+    const uint32_t* const D = s.tab + LIT_TABLE;
+#define AQC_REFILL() do { s.bb |= load64(s.ip) << s.bc; s.ip += (63 - s.bc) >> 3; s.bc |= 56; } while (0)
+#define AQC_DROP(k) do { const int k_ = (int)(k); s.bb >>= k_; s.bc -= k_; } while (0)
+    // (both bytes are always stored: without E_PAIR the second one is overwritten by the next symbol)
+#define AQC_LITS() do { s.op[0] = (OutT)((e >> 16) & 0xffu); s.op[1] = (OutT)((e >> 8) & 0xffu); s.op += 1 + ((e >> 27) & 1u); AQC_DROP(e & 0xffu); } while (0)
+    AQC_REFILL();
+    uint32_t e = L[s.bb & LMASK];
+    if (e & E_LIT) {
+        AQC_LITS();
+        e = L[s.bb & LMASK];
+        if (e & E_LIT) {
+            AQC_LITS();
+            e = L[s.bb & LMASK];
+            if (e & E_LIT) {
+                AQC_LITS();
+                return FAST_CONT;
+            }
+        }
+        AQC_REFILL();
+    }
+    if (e & E_SUB) {
+        AQC_DROP(LIT_ROOT);
+        e = L[((e >> 8) & 0xfffffu) + (uint32_t)(s.bb & ((1u << (e & 0xffu)) - 1u))];
+        if (e & E_LIT) { AQC_LITS(); return FAST_CONT; }
+    }
+    if ((e & 0xffu) == 0 || (e & E_BAD)) return GZ_ERR_DATA;
+    if (e & E_EOB) { AQC_DROP(e & 0xffu); return GZ_OK; }
+    AQC_DROP(e & 0xffu);
+    const uint32_t xb = (e >> 8) & 0x1fu;
+    const size_t len = (size_t)(e >> 16) + (size_t)(s.bb & ((1u << xb) - 1u));
+    AQC_DROP(xb);
+    uint32_t d = D[s.bb & DMASK];
+    if (d & D_SUB) {
+        AQC_DROP(DIST_ROOT);
+        d = D[((d >> 8) & 0xffffu) + (uint32_t)(s.bb & ((1u << (d & 0xfu)) - 1u))];
+    }
+    if ((d & 0xfu) == 0 || (d & D_BAD)) return GZ_ERR_DATA;
+    AQC_DROP(d & 0xfu);
+    const uint32_t db = (d >> 4) & 0xfu;
+    const size_t dd = (size_t)((d >> 8) & 0xffffu) + (size_t)(s.bb & ((1u << db) - 1u));
+    AQC_DROP(db);
+    if (dd > (size_t)(s.op - s.lo)) return GZ_ERR_DATA;
+    OutT* dst = s.op;
+    const OutT* src = dst - dd;
+    s.op += len;
+    if (dd >= 16 / sizeof(OutT)) {
+        // 16 bytes per move.  The first two moves are unconditional (a loop that runs once or twice by the data's whim is a
+        // mispredicted branch per match, and FASTQ is nearly all matches of 4 - 20 bytes); the headroom covers the up to 31
+        // bytes they may run past the match.  The second move may read what the first one wrote (dd < 32 bytes): it is behind it.
+        constexpr size_t W16 = 16 / sizeof(OutT);
+        memcpy(dst, src, 16);
+        memcpy(dst + W16, src + W16, 16);
+        if (len > 2 * W16) {
+            OutT* const end = dst + len;
+            dst += 2 * W16; src += 2 * W16;
+            do { memcpy(dst, src, 16); dst += W16; src += W16; } while (dst < end);
+        }
+    } else if (dd >= COPY_W) {
+        // 8 bytes at a time; the moves may run up to 7 bytes past the match (headroom), never into unread source
+        OutT* const end = dst + len;
+        do { store64(dst, load64((const uint8_t*)src)); dst += COPY_W; src += COPY_W; } while (dst < end);
+    } else if (dd == 1) {
+        fill_run<OutT>(dst, src[0], len);
+    } else {
+        for (size_t i = 0; i < len; ++i) dst[i] = src[i];
+    }
+    return FAST_CONT;
+#undef AQC_REFILL
+#undef AQC_DROP
+#undef AQC_LITS
+}
+
+// the stream's position as a FastStream (false: too little input or output left for the fast loop)
+template <typename OutT>
+inline bool fast_open(const Inflater<OutT>& f, FastStream<OutT>& s) {
+    static_assert(offsetof(Inflater<OutT>, dist) == offsetof(Inflater<OutT>, lit) + sizeof(uint32_t) * LIT_TABLE, "dist must follow lit");
+    if (f.in_size < 40 || f.out_cap < 320) return false;
+    s.ip = f.in + (f.bitpos >> 3);
+    s.ip_end = f.in + f.in_size - 32;
+    s.op = f.out + f.out_pos;
+    s.op_end = f.out + (f.out_cap - 320);
+    s.lo = f.out - f.hist;
+    s.tab = f.lit;
+    if (s.ip > s.ip_end || s.op >= s.op_end) return false;
+    s.bb = load64(s.ip);
+    s.ip += 7;
+    s.bc = 56;
+    const int k = (int)(f.bitpos & 7);
+    s.bb >>= k;
+    s.bc -= k;
+    return true;
+}
+template <typename OutT>
+inline void fast_close(Inflater<OutT>& f, const FastStream<OutT>& s) {
+    f.bitpos = (uint64_t)(s.ip - f.in) * 8 - (uint64_t)s.bc;
+    f.out_pos = (size_t)(s.op - f.out);
+}
+
 // symbols of the current Huffman block until its end-of-block code (GZ_OK), the output runs short (GZ_NEED_OUTPUT) or an error
 template <typename OutT>
 int Inflater<OutT>::decode_huffman() {
-    constexpr size_t COPY_W = 8 / sizeof(OutT);            // elements per 8-byte move
-    const uint8_t* const base = in;
     OutT* const o = out;
     size_t op = out_pos;
     const uint32_t* const L = lit;
     const uint32_t* const D = dist;
     constexpr uint64_t LMASK = (1u << LIT_ROOT) - 1u, DMASK = (1u << DIST_ROOT) - 1u;
     // ---- fast loop: >= 32 input bytes and >= 320 output elements of headroom, no per-bit checks
-    if (in_size >= 40 && out_cap >= 320) {
-        const uint8_t* ip = base + (bitpos >> 3);
-        const uint8_t* const ip_end = base + in_size - 32;
-        const size_t op_end = out_cap - 320;
-        if (ip <= ip_end && op < op_end) {
-            uint64_t bb = load64(ip);
-            ip += 7;
-            int bc = 56;
-            { const int k = (int)(bitpos & 7); bb >>= k; bc -= k; }
-#define AQC_REFILL() do { bb |= load64(ip) << bc; ip += (63 - bc) >> 3; bc |= 56; } while (0)
-#define AQC_DROP(k) do { const int k_ = (int)(k); bb >>= k_; bc -= k_; } while (0)
-            int rc = -100;
-            for (;;) {
-                if (ip > ip_end || op >= op_end) break;
-                AQC_REFILL();
-                uint32_t e = L[bb & LMASK];
-                if (e & E_LIT) {
-                    // (both bytes are always stored: without E_PAIR the second one is overwritten by the next symbol)
-#define AQC_LITS() do { o[op] = (OutT)((e >> 16) & 0xffu); o[op + 1] = (OutT)((e >> 8) & 0xffu); op += 1 + ((e >> 27) & 1u); AQC_DROP(e & 0xffu); } while (0)
-                    AQC_LITS();
-                    e = L[bb & LMASK];
-                    if (e & E_LIT) {
-                        AQC_LITS();
-                        e = L[bb & LMASK];
-                        if (e & E_LIT) {
-                            AQC_LITS();
-                            continue;
-                        }
-                    }
-                    AQC_REFILL();
-                }
-                if (e & E_SUB) {
-                    AQC_DROP(LIT_ROOT);
-                    e = L[((e >> 8) & 0xfffffu) + (uint32_t)(bb & ((1u << (e & 0xffu)) - 1u))];
-                    if (e & E_LIT) { AQC_LITS(); continue; }
-                }
-                if ((e & 0xffu) == 0 || (e & E_BAD)) { rc = GZ_ERR_DATA; break; }
-                if (e & E_EOB) { AQC_DROP(e & 0xffu); rc = GZ_OK; break; }
-                AQC_DROP(e & 0xffu);
-                const uint32_t xb = (e >> 8) & 0x1fu;
-                const size_t len = (size_t)(e >> 16) + (size_t)(bb & ((1u << xb) - 1u));
-                AQC_DROP(xb);
-                uint32_t d = D[bb & DMASK];
-                if (d & D_SUB) {
-                    AQC_DROP(DIST_ROOT);
-                    d = D[((d >> 8) & 0xffffu) + (uint32_t)(bb & ((1u << (d & 0xfu)) - 1u))];
-                }
-                if ((d & 0xfu) == 0 || (d & D_BAD)) { rc = GZ_ERR_DATA; break; }
-                AQC_DROP(d & 0xfu);
-                const uint32_t db = (d >> 4) & 0xfu;
-                const size_t dd = (size_t)((d >> 8) & 0xffffu) + (size_t)(bb & ((1u << db) - 1u));
-                AQC_DROP(db);
-                if (dd > op + hist) { rc = GZ_ERR_DATA; break; }
-                OutT* dst = o + op;
-                const OutT* src = dst - dd;
-                op += len;
-                if (dd >= 16 / sizeof(OutT)) {
-                    // 16 bytes per move (the headroom covers the up to 15 bytes a move may run past the match)
-                    constexpr size_t W16 = 16 / sizeof(OutT);
-                    OutT* const end = dst + len;
-                    do { memcpy(dst, src, 16); dst += W16; src += W16; } while (dst < end);
-                } else if (dd >= COPY_W) {
-                    // 8 bytes at a time; the moves may run up to 7 bytes past the match (headroom), never into unread source
-                    OutT* const end = dst + len;
-                    do { store64(dst, load64((const uint8_t*)src)); dst += COPY_W; src += COPY_W; } while (dst < end);
-                } else if (dd == 1) {
-                    fill_run<OutT>(dst, src[0], len);
-                } else {
-                    for (size_t i = 0; i < len; ++i) dst[i] = src[i];
-                }
-            }
-#undef AQC_REFILL
-#undef AQC_DROP
-#undef AQC_LITS
-            bitpos = (uint64_t)(ip - base) * 8 - (uint64_t)bc;
-            out_pos = op;
-            if (rc != -100) return rc;
+    {
+        FastStream<OutT> st;
+        if (fast_open(*this, st)) {
+            int rc;
+            while ((rc = fast_step(st)) == FAST_CONT) {}
+            fast_close(*this, st);
+            op = out_pos;
+            if (rc != FAST_BOUNDS) return rc;
         }
     }
     // ---- careful loop: every symbol checked against the end of the input and of the output
@@ -410,37 +468,63 @@ int Inflater<OutT>::decode_huffman() {
 }
 
 template <typename OutT>
+int Inflater<OutT>::run_step(uint64_t stop_bit) {
+    if (in_block == 0) {
+        if (final_done) return GZ_FINAL;
+        if (bitpos >= stop_bit) return GZ_STOPPED;
+        if (bitpos + 3 > (uint64_t)in_size * 8) return GZ_ERR_DATA;
+        const int rc = read_header();
+        return rc != GZ_OK ? rc : GZ_CONTINUE;
+    }
+    if (in_block == 1) {
+        const size_t byte = (size_t)(bitpos >> 3);
+        if (byte + stored_left > in_size) return GZ_ERR_DATA;
+        const size_t room = out_cap - out_pos;
+        const size_t k = std::min<size_t>(stored_left, room);
+        for (size_t i = 0; i < k; ++i) out[out_pos + i] = (OutT)in[byte + i];
+        out_pos += k;
+        stored_left -= (uint32_t)k;
+        bitpos += (uint64_t)k * 8;
+        if (stored_left) return GZ_NEED_OUTPUT;
+    } else {
+        const int rc = decode_huffman();
+        if (rc != GZ_OK) return rc;
+    }
+    end_block();
+    return GZ_CONTINUE;
+}
+
+template <typename OutT>
 int Inflater<OutT>::run(uint64_t stop_bit) {
     for (;;) {
-        if (in_block == 0) {
-            if (final_done) return GZ_FINAL;
-            if (bitpos >= stop_bit) return GZ_STOPPED;
-            if (bitpos + 3 > (uint64_t)in_size * 8) return GZ_ERR_DATA;
-            const int rc = read_header();
-            if (rc != GZ_OK) return rc;
-        }
-        if (in_block == 1) {
-            const size_t byte = (size_t)(bitpos >> 3);
-            if (byte + stored_left > in_size) return GZ_ERR_DATA;
-            const size_t room = out_cap - out_pos;
-            const size_t k = std::min<size_t>(stored_left, room);
-            for (size_t i = 0; i < k; ++i) out[out_pos + i] = (OutT)in[byte + i];
-            out_pos += k;
-            stored_left -= (uint32_t)k;
-            bitpos += (uint64_t)k * 8;
-            if (stored_left) return GZ_NEED_OUTPUT;
-        } else {
-            const int rc = decode_huffman();
-            if (rc != GZ_OK) return rc;
-        }
-        in_block = 0;
-        blocks++;
-        if (bfinal) final_done = true;
+        const int rc = run_step(stop_bit);
+        if (rc != GZ_CONTINUE) return rc;
     }
+}
+
+template <typename OutT>
+int decode_pair(Inflater<OutT>& A, Inflater<OutT>& B, int* rc) {
+    FastStream<OutT> a, b;
+    if (!fast_open(A, a)) { *rc = GZ_SLOW; return 0; }
+    if (!fast_open(B, b)) { *rc = GZ_SLOW; return 1; }
+    int ra, rb = FAST_CONT;
+    for (;;) {
+        ra = fast_step(a);
+        if (ra != FAST_CONT) break;
+        rb = fast_step(b);
+        if (rb != FAST_CONT) break;
+    }
+    fast_close(A, a);
+    fast_close(B, b);
+    if (ra != FAST_CONT) { *rc = ra == FAST_BOUNDS ? GZ_SLOW : ra; return 0; }
+    *rc = rb == FAST_BOUNDS ? GZ_SLOW : rb;
+    return 1;
 }
 
 template struct Inflater<uint8_t>;
 template struct Inflater<uint16_t>;
+template int decode_pair<uint8_t>(Inflater<uint8_t>&, Inflater<uint8_t>&, int*);
+template int decode_pair<uint16_t>(Inflater<uint16_t>&, Inflater<uint16_t>&, int*);
 
 size_t parse_gzip_header(const uint8_t* d, size_t n, size_t pos) {
     if (pos + 10 > n || d[pos] != 0x1f || d[pos + 1] != 0x8b || d[pos + 2] != 8) return 0;
@@ -472,6 +556,38 @@ int64_t inflate_raw(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
     const int rc = inf->run(UINT64_MAX);
     if (rc != GZ_FINAL) return -1;
     return (int64_t)inf->out_pos;
+}
+
+// two independent raw-deflate streams (two BGZF members) decoded alternately, see decode_pair; got[k] = bytes written or -1
+void inflate_raw2(const uint8_t* const src[2], const size_t n[2], uint8_t* const dst[2], const size_t cap[2], int64_t got[2]) {
+    std::unique_ptr<Inflater<uint8_t>> inf[2];
+    bool done[2] = {false, false};
+    for (int k = 0; k < 2; ++k) {
+        inf[k].reset(new Inflater<uint8_t>());
+        inf[k]->reset(src[k], n[k], 0);
+        inf[k]->out = dst[k]; inf[k]->out_pos = 0; inf[k]->out_cap = cap[k]; inf[k]->hist = 0;
+        got[k] = -1;
+    }
+    auto settle = [&](int k, int rc) {           // a return code other than "go on" ends the stream: complete or broken
+        done[k] = true;
+        if (rc == GZ_FINAL) got[k] = (int64_t)inf[k]->out_pos;
+    };
+    while (!done[0] || !done[1]) {
+        if (!done[0] && !done[1] && inf[0]->in_block == 2 && inf[1]->in_block == 2) {
+            int rc;
+            const int k = decode_pair(*inf[0], *inf[1], &rc);
+            if (rc == GZ_OK) inf[k]->end_block();
+            else if (rc == GZ_SLOW) {
+                const int r2 = inf[k]->decode_huffman();
+                if (r2 == GZ_OK) inf[k]->end_block();
+                else settle(k, r2);
+            } else settle(k, rc);
+            continue;
+        }
+        const int k = (!done[0] && (done[1] || inf[0]->in_block != 2)) ? 0 : 1;
+        const int rc = inf[k]->run_step(UINT64_MAX);
+        if (rc != GZ_CONTINUE) settle(k, rc);
+    }
 }
 
 // ---- block boundaries in the middle of a stream ----------------------------------------------------------------------------

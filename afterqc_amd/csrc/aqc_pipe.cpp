@@ -290,9 +290,10 @@ struct GzSource : Source {
                 bgzf = is_bgzf_header(map, size);
                 if (!bgzf) {
                     const int threads = std::max(1, pool->size());
-                    // sections in flight: one per pool thread (a single-end run has only this stream to keep them busy); more only
-                    // means more symbol buffers touched for the first time (tools/gpu_gzrate.sh, GZ_MATRIX)
-                    const int inflight = std::max(4, std::min(threads, 32));
+                    // sections in flight: two per pool thread (a thread decodes two sections alternately, aqc_gunzip.cpp; a single-end
+                    // run has only this stream to keep the pool busy); more only means more symbol buffers touched for the first
+                    // time (tools/gpu_gzrate.sh, GZ_MATRIX)
+                    const int inflight = std::max(4, std::min(2 * threads, 64));
                     size_t sec = section_bytes;
                     if (!sec) {
                         if (const char* e = getenv("AQC_GZ_SECTION")) sec = (size_t)atoll(e);
@@ -375,11 +376,24 @@ struct GzSource : Source {
             spill_lo = 0;
             std::atomic<bool> e{false};
             uint8_t* const d0 = dst + out;
-            pool->parallel_for(blks.size(), [&](size_t i) {
-                const Blk& b = blks[i];
-                uint8_t* o = b.ooff + b.isize <= room ? d0 + b.ooff : spill.data() + (b.ooff - fit_total);
-                const int64_t got = aqcgz::inflate_raw(map + b.coff, b.clen, o, b.isize);
-                if (got != (int64_t)b.isize || aqcgz::crc32_fast(0u, o, b.isize) != b.crc) e = true;
+            // two members per task, decoded alternately (aqcgz::decode_pair: two dependency chains share one core's issue slots)
+            pool->parallel_for((blks.size() + 1) / 2, [&](size_t t) {
+                const size_t i0 = 2 * t, i1 = std::min(2 * t + 1, blks.size() - 1);
+                uint8_t* o[2];
+                const uint8_t* src[2];
+                size_t n[2], cap[2];
+                int64_t got[2];
+                for (int k = 0; k < 2; ++k) {
+                    const Blk& b = blks[k ? i1 : i0];
+                    o[k] = b.ooff + b.isize <= room ? d0 + b.ooff : spill.data() + (b.ooff - fit_total);
+                    src[k] = map + b.coff; n[k] = b.clen; cap[k] = b.isize;
+                }
+                if (i1 != i0) aqcgz::inflate_raw2(src, n, o, cap, got);
+                else got[0] = got[1] = aqcgz::inflate_raw(src[0], n[0], o[0], cap[0]);
+                for (int k = 0; k < 2; ++k) {
+                    const Blk& b = blks[k ? i1 : i0];
+                    if (got[k] != (int64_t)b.isize || aqcgz::crc32_fast(0u, o[k], b.isize) != b.crc) e = true;
+                }
             });
             if (e) { fail("corrupt BGZF member (inflate / CRC-32 / length)"); break; }
             pos = p;

@@ -115,6 +115,35 @@ int main(int argc, char** argv) {
             }
         }
     }
+    // ---- A2. two streams decoded alternately (inflate_raw2 / decode_pair): every pairing of the data sets, mixed levels and
+    //          strategies (stored, fixed and dynamic blocks meet each other), and a broken partner must not disturb the good one
+    {
+        std::vector<std::vector<uint8_t>> comp;
+        std::vector<const std::vector<uint8_t>*> plain;
+        int v = 0;
+        for (auto& ds : sets)
+            for (int level : {0, 1, 6, 9}) {
+                const int strat = (v++ % 3 == 2) ? Z_FIXED : Z_DEFAULT_STRATEGY;
+                comp.push_back(zlib_deflate(ds.second, level, -15, strat));
+                plain.push_back(&ds.second);
+            }
+        for (size_t i = 0; i < comp.size(); ++i)
+            for (size_t j = 0; j < comp.size(); j += (i % 3) + 1) {
+                std::vector<uint8_t> o0(plain[i]->size() + 1), o1(plain[j]->size() + 1);
+                const uint8_t* src[2] = {comp[i].data(), comp[j].data()};
+                const size_t n[2] = {comp[i].size(), comp[j].size()}, cap[2] = {plain[i]->size(), plain[j]->size()};
+                uint8_t* dst[2] = {o0.data(), o1.data()};
+                int64_t got[2];
+                inflate_raw2(src, n, dst, cap, got);
+                CHECK(got[0] == (int64_t)cap[0] && !memcmp(o0.data(), plain[i]->data(), cap[0]) && got[1] == (int64_t)cap[1] && !memcmp(o1.data(), plain[j]->data(), cap[1]),
+                      "inflate_raw2 of streams %zu and %zu: %lld of %zu, %lld of %zu", i, j, (long long)got[0], cap[0], (long long)got[1], cap[1]);
+                if (comp[j].size() > 8 && (i + j) % 5 == 0) {
+                    const size_t n2[2] = {comp[i].size(), comp[j].size() / 2};
+                    inflate_raw2(src, n2, dst, cap, got);
+                    CHECK(got[0] == (int64_t)cap[0] && !memcmp(o0.data(), plain[i]->data(), cap[0]) && got[1] < 0, "inflate_raw2 with a truncated partner (%zu, %zu)", i, j);
+                }
+            }
+    }
     // ---- B. deflate_block -> zlib inflate
     for (auto& ds : sets) {
         for (size_t n : {(size_t)0, (size_t)1, (size_t)15, (size_t)16, (size_t)17, (size_t)100, (size_t)4096, (size_t)0xff00, (size_t)65535, (size_t)200000}) {
