@@ -51,15 +51,16 @@ inline uint32_t dist_value(int sym) {
 }
 
 // Canonical Huffman code (lens[0, n), 0 = unused) -> root table of 2^R entries + subtables for the longer codes.
-// *complete: the code uses the whole code space.  false: over-subscribed, or the table does not fit.
+// *complete: the code uses the whole code space.  false: over-subscribed, or the table does not fit.  Entries no code leads to
+// hold `empty` (the decoders' BAD flag, so that the hot loops need no separate test for them).
 template <class Value>
-bool build_table(const uint8_t* lens, int n, int R, uint32_t* table, int cap, uint32_t sub_flag, Value value, bool* complete, int* max_len) {
+bool build_table(const uint8_t* lens, int n, int R, uint32_t* table, int cap, uint32_t sub_flag, uint32_t empty, Value value, bool* complete, int* max_len) {
     int count[16] = {0};
     for (int s = 0; s < n; ++s) count[lens[s]]++;
     int mx = 15;
     while (mx > 0 && count[mx] == 0) --mx;
     *max_len = mx;
-    for (int i = 0; i < (1 << R); ++i) table[i] = 0;
+    for (int i = 0; i < (1 << R); ++i) table[i] = empty;
     if (mx == 0) { *complete = false; return true; }
     int left = 1;
     for (int l = 1; l <= 15; ++l) {
@@ -103,7 +104,7 @@ bool build_table(const uint8_t* lens, int n, int R, uint32_t* table, int cap, ui
         if (!(table[p] & sub_flag)) {
             if (free_at + (1 << sb) > cap) return false;
             table[p] = sub_flag | ((uint32_t)free_at << 8) | (uint32_t)sb;
-            for (int i = 0; i < (1 << sb); ++i) table[free_at + i] = 0;
+            for (int i = 0; i < (1 << sb); ++i) table[free_at + i] = empty;
             free_at += 1 << sb;
         }
         const uint32_t start = (table[p] >> 8) & 0xfffffu;
@@ -140,10 +141,10 @@ struct FixedTables {
         uint8_t l[288];
         for (int i = 0; i < 288; ++i) l[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
         bool c; int m;
-        build_table(l, 288, LIT_ROOT, lit, LIT_TABLE, E_SUB, lit_value, &c, &m);
+        build_table(l, 288, LIT_ROOT, lit, LIT_TABLE, E_SUB, E_BAD, lit_value, &c, &m);
         uint8_t d[32];
         for (int i = 0; i < 32; ++i) d[i] = 5;
-        build_table(d, 32, DIST_ROOT, dist, DIST_TABLE, D_SUB, dist_value, &c, &m);
+        build_table(d, 32, DIST_ROOT, dist, DIST_TABLE, D_SUB, D_BAD, dist_value, &c, &m);
     }
 };
 const FixedTables& fixed_tables() {
@@ -161,7 +162,7 @@ int read_code_lengths(BitIn& b, uint8_t* lens, int& hlit, int& hdist) {
     for (int i = 0; i < hclen; ++i) cl[order[i]] = (uint8_t)b.get(3);
     uint32_t clt[128];
     bool complete; int mx;
-    if (!build_table(cl, 19, 7, clt, 128, 0u, [](int s) { return (uint32_t)s << 8; }, &complete, &mx)) return GZ_ERR_DATA;
+    if (!build_table(cl, 19, 7, clt, 128, 0u, 0u, [](int s) { return (uint32_t)s << 8; }, &complete, &mx)) return GZ_ERR_DATA;
     if (mx > 0 && !complete) return GZ_ERR_DATA;          // (zlib: an incomplete code-length code is an error)
     int i = 0;
     const int total = hlit + hdist;
@@ -219,9 +220,9 @@ void add_literal_pairs(uint32_t* lit) {
 
 int build_block_tables(const uint8_t* lens, int hlit, int hdist, uint32_t* lit, uint32_t* dist) {
     bool complete; int mx;
-    if (!build_table(lens, hlit, LIT_ROOT, lit, LIT_TABLE, E_SUB, lit_value, &complete, &mx)) return GZ_ERR_DATA;
+    if (!build_table(lens, hlit, LIT_ROOT, lit, LIT_TABLE, E_SUB, E_BAD, lit_value, &complete, &mx)) return GZ_ERR_DATA;
     if (!complete && mx != 1) return GZ_ERR_DATA;
-    if (!build_table(lens + hlit, hdist, DIST_ROOT, dist, DIST_TABLE, D_SUB, dist_value, &complete, &mx)) return GZ_ERR_DATA;
+    if (!build_table(lens + hlit, hdist, DIST_ROOT, dist, DIST_TABLE, D_SUB, D_BAD, dist_value, &complete, &mx)) return GZ_ERR_DATA;
     if (!complete && mx > 1) return GZ_ERR_DATA;
     add_literal_pairs(lit);
     return GZ_OK;
@@ -294,12 +295,22 @@ struct FastStream {
     OutT* lo;                   // lowest readable output element (out - hist)
 };
 
-// FAST_CONT: go on; FAST_BOUNDS: headroom used up (nothing consumed); GZ_OK: end-of-block code consumed; GZ_ERR_DATA
+// headroom the loops keep in front of a GROUP of steps (checked once per group): a step takes at most two refills (<= 16 input
+// bytes are touched beyond ip, <= 8 consumed each) and emits at most 6 literals or a 258-element match whose copies may run 31
+// bytes past it.  What lies behind the headroom is left to the careful loop: sections (symbols, megabytes long) take groups of
+// four; byte streams are often BGZF members of 64 KiB decoded straight into their slot of the output, where a kilobyte of
+// careful decoding per member would cost more than the saved tests.
+template <typename OutT> struct FastCfg;
+template <> struct FastCfg<uint16_t> { static constexpr int GROUP = 4; };
+template <> struct FastCfg<uint8_t> { static constexpr int GROUP = 1; };
+template <typename OutT> constexpr size_t fast_in_room() { return 32 + 16 * (size_t)FastCfg<OutT>::GROUP; }
+template <typename OutT> constexpr size_t fast_out_room() { return 320 * (size_t)FastCfg<OutT>::GROUP; }
+
+// FAST_CONT: go on; GZ_OK: end-of-block code consumed; GZ_ERR_DATA.  No bounds are looked at in here (see fast_room).
 template <typename OutT>
 __attribute__((always_inline)) inline int fast_step(FastStream<OutT>& s) {
     constexpr size_t COPY_W = 8 / sizeof(OutT);            // elements per 8-byte move
     constexpr uint64_t LMASK = (1u << LIT_ROOT) - 1u, DMASK = (1u << DIST_ROOT) - 1u;
-    if (s.ip > s.ip_end || s.op >= s.op_end) return FAST_BOUNDS;
     const uint32_t* const L = s.tab;
     const uint32_t* const D = s.tab + LIT_TABLE;
 #define AQC_REFILL() do { s.bb |= load64(s.ip) << s.bc; s.ip += (63 - s.bc) >> 3; s.bc |= 56; } while (0)
@@ -321,23 +332,27 @@ __attribute__((always_inline)) inline int fast_step(FastStream<OutT>& s) {
         }
         AQC_REFILL();
     }
-    if (e & E_SUB) {
-        AQC_DROP(LIT_ROOT);
-        e = L[((e >> 8) & 0xfffffu) + (uint32_t)(s.bb & ((1u << (e & 0xffu)) - 1u))];
-        if (e & E_LIT) { AQC_LITS(); return FAST_CONT; }
+    if (e & (E_SUB | E_BAD | E_EOB)) {           // everything that is not a plain length code: one test in the common case
+        if (e & E_SUB) {
+            AQC_DROP(LIT_ROOT);
+            e = L[((e >> 8) & 0xfffffu) + (uint32_t)(s.bb & ((1u << (e & 0xffu)) - 1u))];
+            if (e & E_LIT) { AQC_LITS(); return FAST_CONT; }
+        }
+        if (e & E_BAD) return GZ_ERR_DATA;       // (entries no code leads to carry E_BAD as well)
+        if (e & E_EOB) { AQC_DROP(e & 0xffu); return GZ_OK; }
     }
-    if ((e & 0xffu) == 0 || (e & E_BAD)) return GZ_ERR_DATA;
-    if (e & E_EOB) { AQC_DROP(e & 0xffu); return GZ_OK; }
     AQC_DROP(e & 0xffu);
     const uint32_t xb = (e >> 8) & 0x1fu;
     const size_t len = (size_t)(e >> 16) + (size_t)(s.bb & ((1u << xb) - 1u));
     AQC_DROP(xb);
     uint32_t d = D[s.bb & DMASK];
-    if (d & D_SUB) {
-        AQC_DROP(DIST_ROOT);
-        d = D[((d >> 8) & 0xffffu) + (uint32_t)(s.bb & ((1u << (d & 0xfu)) - 1u))];
+    if (d & (D_SUB | D_BAD)) {
+        if (d & D_SUB) {
+            AQC_DROP(DIST_ROOT);
+            d = D[((d >> 8) & 0xffffu) + (uint32_t)(s.bb & ((1u << (d & 0xfu)) - 1u))];
+        }
+        if (d & D_BAD) return GZ_ERR_DATA;
     }
-    if ((d & 0xfu) == 0 || (d & D_BAD)) return GZ_ERR_DATA;
     AQC_DROP(d & 0xfu);
     const uint32_t db = (d >> 4) & 0xfu;
     const size_t dd = (size_t)((d >> 8) & 0xffffu) + (size_t)(s.bb & ((1u << db) - 1u));
@@ -377,11 +392,11 @@ __attribute__((always_inline)) inline int fast_step(FastStream<OutT>& s) {
 template <typename OutT>
 inline bool fast_open(const Inflater<OutT>& f, FastStream<OutT>& s) {
     static_assert(offsetof(Inflater<OutT>, dist) == offsetof(Inflater<OutT>, lit) + sizeof(uint32_t) * LIT_TABLE, "dist must follow lit");
-    if (f.in_size < 40 || f.out_cap < 320) return false;
+    if (f.in_size < fast_in_room<OutT>() + 8 || f.out_cap < fast_out_room<OutT>()) return false;
     s.ip = f.in + (f.bitpos >> 3);
-    s.ip_end = f.in + f.in_size - 32;
+    s.ip_end = f.in + f.in_size - fast_in_room<OutT>();
     s.op = f.out + f.out_pos;
-    s.op_end = f.out + (f.out_cap - 320);
+    s.op_end = f.out + (f.out_cap - fast_out_room<OutT>());
     s.lo = f.out - f.hist;
     s.tab = f.lit;
     if (s.ip > s.ip_end || s.op >= s.op_end) return false;
@@ -399,6 +414,9 @@ inline void fast_close(Inflater<OutT>& f, const FastStream<OutT>& s) {
     f.out_pos = (size_t)(s.op - f.out);
 }
 
+template <typename OutT>
+__attribute__((always_inline)) inline bool fast_room(const FastStream<OutT>& s) { return s.ip <= s.ip_end && s.op < s.op_end; }
+
 // The loops themselves exist twice: for BMI2 (shrx / shlx / bzhi: the variable shifts and masks the body is made of, one
 // micro-operation each and any register for the count — 5 - 7 % faster) and for plain x86-64; the dynamic linker picks one.
 #if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
@@ -411,25 +429,42 @@ inline void fast_close(Inflater<OutT>& f, const FastStream<OutT>& s) {
 #define AQC_FAST_RUN(NAME, T) \
     AQC_CLONES int NAME(FastStream<T>& ref) { \
         FastStream<T> st = ref; \
-        int rc; \
-        while ((rc = fast_step(st)) == FAST_CONT) {} \
+        int rc = FAST_BOUNDS; \
+        while (fast_room(st)) { \
+            if ((rc = fast_step(st)) != FAST_CONT) break; \
+            if (FastCfg<T>::GROUP == 4) { \
+                if ((rc = fast_step(st)) != FAST_CONT) break; \
+                if ((rc = fast_step(st)) != FAST_CONT) break; \
+                if ((rc = fast_step(st)) != FAST_CONT) break; \
+            } \
+            rc = FAST_BOUNDS; \
+        } \
         ref = st; \
         return rc; \
     }
 #define AQC_FAST_RUN2(NAME, T) \
     AQC_CLONES int NAME(FastStream<T>& ra, FastStream<T>& rb, int* rc) { \
         FastStream<T> a = ra, b = rb; \
-        int which, r; \
+        int which = 0, r = FAST_BOUNDS; \
         for (;;) { \
-            r = fast_step(a); \
-            if (r != FAST_CONT) { which = 0; break; } \
-            r = fast_step(b); \
-            if (r != FAST_CONT) { which = 1; break; } \
+            if (!fast_room(a)) { which = 0; r = FAST_BOUNDS; break; } \
+            if (!fast_room(b)) { which = 1; r = FAST_BOUNDS; break; } \
+            if ((r = fast_step(a)) != FAST_CONT) { which = 0; break; } \
+            if ((r = fast_step(b)) != FAST_CONT) { which = 1; break; } \
+            if (FastCfg<T>::GROUP == 4) { \
+                if ((r = fast_step(a)) != FAST_CONT) { which = 0; break; } \
+                if ((r = fast_step(b)) != FAST_CONT) { which = 1; break; } \
+                if ((r = fast_step(a)) != FAST_CONT) { which = 0; break; } \
+                if ((r = fast_step(b)) != FAST_CONT) { which = 1; break; } \
+                if ((r = fast_step(a)) != FAST_CONT) { which = 0; break; } \
+                if ((r = fast_step(b)) != FAST_CONT) { which = 1; break; } \
+            } \
         } \
         ra = a; rb = b; \
         *rc = r; \
         return which; \
     }
+static_assert(FastCfg<uint16_t>::GROUP == 4 && FastCfg<uint8_t>::GROUP == 1, "the loops below are written out for groups of one and of four steps");
 AQC_FAST_RUN(fast_run_u8, uint8_t)
 AQC_FAST_RUN(fast_run_u16, uint16_t)
 inline int fast_run(FastStream<uint8_t>& st) { return fast_run_u8(st); }
