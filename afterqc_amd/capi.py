@@ -334,7 +334,7 @@ def load_library():
     lib.aqc_format.argtypes = [P, C.c_int, C.c_uint64, C.c_int32, P]
     lib.aqc_format_plain.argtypes = [P, C.c_int, C.c_int, C.c_uint64, C.c_int32, P]
     lib.aqc_fetch_text.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.c_uint64]
-    lib.aqc_gunzip_dev_selftest.argtypes = [C.c_int, P, C.c_uint64, P, C.c_uint64, C.POINTER(C.c_uint64), P]
+    lib.aqc_gunzip_dev.argtypes = [C.c_int, P, C.c_uint64, P, C.c_uint64, C.POINTER(C.c_uint64), P, C.c_int, C.c_uint64, C.c_uint64]
     lib.aqc_compress.argtypes = [P, C.c_int, C.c_int32, P]
     lib.aqc_fetch_gz.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.c_uint64]
     lib.aqc_pipe_create.argtypes = [C.POINTER(P), C.c_int32, C.c_int32, C.c_int32, C.POINTER(P)]
@@ -356,6 +356,8 @@ def load_library():
     lib.aqc_source_error.restype = C.c_char_p
     lib.aqc_source_gz_stats.argtypes = [P, C.POINTER(C.c_uint64 * 4)]
     lib.aqc_source_gz_stats.restype = C.c_int
+    lib.aqc_gz_input_stats.argtypes = [C.POINTER(C.c_uint64 * 4)]
+    lib.aqc_gz_input_stats.restype = C.c_int
     lib.aqc_gz_deflate_block.argtypes = [P, C.c_uint64, C.c_int32, P, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.aqc_gz_deflate_block.restype = C.c_int
     lib.aqc_gz_inflate_raw.argtypes = [P, C.c_uint64, P, C.c_uint64]
@@ -390,11 +392,11 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_device_index", "
                     "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_last_deferred", "aqc_kernel_ms", "aqc_timing_reset",
                     "aqc_timing_mean", "aqc_get_counters",
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
-                    "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_compress", "aqc_fetch_gz", "aqc_gunzip_dev_selftest", "aqc_host_alloc",
+                    "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_compress", "aqc_fetch_gz", "aqc_gunzip_dev", "aqc_host_alloc",
                     "aqc_host_free",
                     "aqc_pipe_create", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
                     "aqc_host_count_newlines", "aqc_bgzf_compress", "aqc_pipe_split",
-                    "aqc_source_open", "aqc_source_open2", "aqc_source_read", "aqc_source_error", "aqc_source_gz_stats", "aqc_source_close",
+                    "aqc_source_open", "aqc_source_open2", "aqc_source_read", "aqc_source_error", "aqc_source_gz_stats", "aqc_gz_input_stats", "aqc_source_close",
                     "aqc_gz_deflate_block", "aqc_gz_inflate_raw", "aqc_gz_crc32",
                     # the reference's own native seam (editdistance/_editdistance.h:16,23), same names and signatures
                     "edit_distance", "seek_overlap"]

@@ -12,7 +12,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "aqc_kernels.hpp"
@@ -1004,131 +1009,325 @@ int aqc_fetch_gz(aqc_ctx* c, int slot, int file, int stream, uint8_t* dst, uint6
 }
 
 // ---- gzip input on the device (aqc_gunzip_dev.hpp) ------------------------------------------------------------------------------
+// DeviceInflate: the SectionOffload of aqc_gz.hpp.  A group of consecutive sections = one window of the compressed file = one
+// pass of scan -> compact -> decode -> chain -> gather on one of two LANES (own thread, own stream, own device buffers: a group
+// is uploaded while the other decodes).  The symbols come back into page-locked arenas that the sections keep until the host
+// has translated them.
 namespace {
 
-struct GzdDevice {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    DevBuf comp, sec_start, sec_end, sec_flags, sec_nsym, sym, text, sec_off, result;
-    uint32_t section_bytes = 128u << 10, max_sections = 1024;
-    uint32_t sym_cap = 0;
-    // result of the last batch
-    uint64_t n_text = 0, end_bit = 0;
-    uint32_t accepted = 0, n_sections = 0;
-    bool final_block = false, corrupt = false;
-    float ms_find = 0, ms_decode = 0, ms_chain = 0, ms_resolve = 0;
-    hipEvent_t ev[5] = {};
+std::atomic<uint64_t> g_gzb_stats[8];
 
-    int init(int dev) {
-        device = dev;
-        HIP_TRY(hipSetDevice(dev));
-        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
-        sym_cap = section_bytes * 10u;
-        return 0;
-    }
-    void release() {
-        (void)hipSetDevice(device);
-        if (stream) (void)hipStreamSynchronize(stream);
-        DevBuf* b[] = {&comp, &sec_start, &sec_end, &sec_flags, &sec_nsym, &sym, &text, &sec_off, &result};
-        for (DevBuf* x : b) x->release();
-        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-        if (stream) (void)hipStreamDestroy(stream);
-        stream = nullptr;
-    }
-    // one batch: the deflate data of data[0, size) from the block boundary at bit `start_bit` on, with the `wl` bytes of output
-    // before it in `window`.  The text of the sections that chained up stays in this->text (device) until the next call.
-    int decode(const uint8_t* data, uint64_t size, uint64_t start_bit, const uint8_t* window, size_t wl) {
-        HIP_TRY(hipSetDevice(device));
-        const uint64_t byte0 = (start_bit >> 3) & ~(uint64_t)3;
-        const uint64_t left = size - byte0;
-        uint64_t nsec = (left + section_bytes - 1) / section_bytes;
-        if (nsec > max_sections) nsec = max_sections;
-        const uint64_t span = std::min<uint64_t>(left, nsec * (uint64_t)section_bytes + (4u << 20));     // + room to finish the last block
-        n_sections = (uint32_t)nsec;
-        if (comp.reserve(span + 128) || sec_start.reserve(8 * nsec) || sec_end.reserve(8 * nsec) || sec_flags.reserve(4 * nsec) ||
-            sec_nsym.reserve(4 * nsec) || sec_off.reserve(8 * (nsec + 1)) || result.reserve(256) ||
-            sym.reserve((size_t)nsec * sym_cap * 2) || text.reserve(32768 + (size_t)nsec * sym_cap + 64))
-            return fail(AQC_ERR_HIP, "hipMalloc failed (device gunzip)");
-        HIP_TRY(hipMemcpyAsync(comp.p, data + byte0, span, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemsetAsync((uint8_t*)comp.p + span, 0, 128, stream));
-        if (wl) HIP_TRY(hipMemcpyAsync((uint8_t*)text.p + 32768 - wl, window, wl, hipMemcpyHostToDevice, stream));
-        GzdJob J{};
-        J.comp = (const uint8_t*)comp.p; J.comp_bytes = span; J.start_bit = start_bit - byte0 * 8; J.n_sections = n_sections;
-        J.section_bytes = section_bytes;
-        J.sec_start = (uint64_t*)sec_start.p; J.sec_end = (uint64_t*)sec_end.p; J.sec_flags = (uint32_t*)sec_flags.p; J.sec_nsym = (uint32_t*)sec_nsym.p;
-        J.sym = (uint16_t*)sym.p; J.sym_cap = sym_cap; J.text = (uint8_t*)text.p + 32768; J.window_valid_from = (uint32_t)(32768 - wl);
-        J.sec_off = (uint64_t*)sec_off.p; J.result = (uint32_t*)result.p;
-        HIP_TRY(hipEventRecord(ev[0], stream));
-        hipLaunchKernelGGL(gzd_find_kernel, dim3(n_sections), dim3(WAVE), 0, stream, J);
-        HIP_TRY(hipEventRecord(ev[1], stream));
-        hipLaunchKernelGGL(gzd_decode_kernel, dim3(n_sections), dim3(WAVE), 0, stream, J);
-        HIP_TRY(hipEventRecord(ev[2], stream));
-        hipLaunchKernelGGL(gzd_chain_kernel, dim3(1), dim3(GZD_CHAIN_THREADS), 0, stream, J);
-        HIP_TRY(hipEventRecord(ev[3], stream));
-        hipLaunchKernelGGL(gzd_resolve_kernel, dim3(32, n_sections), dim3(256), 0, stream, J);
-        HIP_TRY(hipEventRecord(ev[4], stream));
-        HIP_TRY(hipGetLastError());
-        uint32_t r[8 + 16] = {0};
-        HIP_TRY(hipMemcpyAsync(r, result.p, sizeof(r), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-#ifdef GZD_PROFILE
+constexpr size_t GZB_SLACK = 4u << 20;              // compressed bytes uploaded behind the last section's stop bit (its last block ends there)
+constexpr uint32_t GZB_RATIO_CAP = 20;
+
+class DeviceInflate : public aqcgz::SectionOffload {
+public:
+    DeviceInflate(int device, size_t group_bytes) : device_(device), group_bytes_(std::min<size_t>(std::max<size_t>(group_bytes, 1u << 20), 192u << 20)) {}
+    ~DeviceInflate() override {
         {
-            const unsigned long long* pr = reinterpret_cast<const unsigned long long*>(r + 8);
-            fprintf(stderr, "GZD section 1: decode+lookup %llu  walk %llu  scan %llu  output %llu  | rounds %llu tokens %llu matches %llu\n", pr[0], pr[1], pr[2], pr[3], pr[5], pr[6], pr[7]);
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
         }
-#endif
-        accepted = r[0];
-        corrupt = r[1] != 0;
-        final_block = r[2] != 0;
-        end_bit = byte0 * 8 + (((uint64_t)r[5] << 32) | r[4]);
-        n_text = ((uint64_t)r[7] << 32) | r[6];
-        (void)hipEventElapsedTime(&ms_find, ev[0], ev[1]);
-        (void)hipEventElapsedTime(&ms_decode, ev[1], ev[2]);
-        (void)hipEventElapsedTime(&ms_chain, ev[2], ev[3]);
-        (void)hipEventElapsedTime(&ms_resolve, ev[3], ev[4]);
-        return 0;
+        cv_.notify_all();
+        for (auto& l : lanes_) if (l.th.joinable()) l.th.join();
+        (void)hipSetDevice(device_);
+        for (auto& l : lanes_) l.release();
+        for (auto& a : arenas_) if (a.p) aqc_host_free(a.p);
     }
-    int fetch(uint64_t off, uint64_t n, uint8_t* dst) {
-        HIP_TRY(hipSetDevice(device));
-        if (n) HIP_TRY(hipMemcpyAsync(dst, (const uint8_t*)text.p + 32768 + off, n, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        return 0;
+    bool start() {
+        if (hipSetDevice(device_) != hipSuccess) { (void)hipGetLastError(); return false; }
+        for (auto& l : lanes_) {
+            if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) return false;
+            for (auto& e : l.ev) if (hipEventCreate(&e) != hipSuccess) return false;
+        }
+        for (int i = 0; i < N_LANES; ++i) lanes_[i].th = std::thread([this, i] { loop(i); });
+        return true;
     }
+    size_t group_bytes() const override { return group_bytes_; }
+    bool ready() override {
+        std::lock_guard<std::mutex> g(mu_);
+        if (broken_ || stop_) return false;
+        for (auto& l : lanes_) if (!l.job) return true;
+        return false;
+    }
+    bool submit(const uint8_t* data, size_t size, int n, const uint64_t* nominal, const uint64_t* stop, const uint8_t* exact,
+                std::function<void(int, const aqcgz::OffloadResult&)> done) override {
+        if (n <= 0) return false;
+        std::unique_ptr<Group> gr(new Group());
+        gr->data = data; gr->size = size; gr->n = n;
+        gr->nominal.assign(nominal, nominal + n); gr->stop.assign(stop, stop + n); gr->exact.assign(exact, exact + n);
+        gr->done = std::move(done);
+        // one window: from the first section's nominal start to the last one's stop bit (+ slack); bit positions are 32-bit inside it
+        const uint64_t byte0 = (nominal[0] >> 3) & ~(uint64_t)15;
+        const uint64_t last = (stop[n - 1] >> 3) + 1;
+        if (stop[n - 1] == UINT64_MAX || last <= byte0 || last - byte0 + GZB_SLACK >= (500u << 20)) return false;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (broken_ || stop_) return false;
+            Lane* pick = nullptr;
+            for (auto& l : lanes_) if (!l.job) { pick = &l; break; }
+            if (!pick) return false;
+            pick->job = std::move(gr);
+        }
+        cv_.notify_all();
+        return true;
+    }
+    void release(void* token) override {
+        Token* t = (Token*)token;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            arenas_[t->arena].refs--;
+        }
+        cv_.notify_all();
+        delete t;
+    }
+
+private:
+    static constexpr int N_LANES = 2, N_ARENAS = 5;
+    struct Group {
+        const uint8_t* data; size_t size; int n;
+        std::vector<uint64_t> nominal, stop;
+        std::vector<uint8_t> exact;
+        std::function<void(int, const aqcgz::OffloadResult&)> done;
+    };
+    struct Token { int arena; };
+    struct Arena { uint8_t* p = nullptr; size_t cap = 0; int refs = 0; bool filling = false; };
+    struct Lane {
+        std::thread th;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev[6] = {};
+        std::unique_ptr<Group> job;
+        DevBuf comp, tile_cnt, tile_cand, n_cand, c_start, c_end, c_nsym, c_flags, c_symoff, c_symcap, blk_sym, tables;
+        DevBuf s_in, s_out, s_blocks, s_sym;
+        void release() {
+            if (stream) (void)hipStreamSynchronize(stream);
+            DevBuf* b[] = {&comp, &tile_cnt, &tile_cand, &n_cand, &c_start, &c_end, &c_nsym, &c_flags, &c_symoff, &c_symcap, &blk_sym, &tables, &s_in, &s_out, &s_blocks, &s_sym};
+            for (DevBuf* x : b) x->release();
+            for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+            if (stream) (void)hipStreamDestroy(stream);
+            stream = nullptr;
+        }
+    };
+
+    void loop(int li) {
+        Lane& L = lanes_[li];
+        (void)hipSetDevice(device_);
+        for (;;) {
+            Group* gr = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || L.job; });
+                if (stop_ && !L.job) return;
+                gr = L.job.get();
+            }
+            if (!run_group(L, *gr)) {
+                // the device path failed for this group: the sections come back empty, the host decodes that stretch itself
+                (void)hipGetLastError();
+                aqcgz::OffloadResult none;
+                for (int k = 0; k < gr->n; ++k) gr->done(k, none);
+                std::lock_guard<std::mutex> g(mu_);
+                broken_ = true;
+            }
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                L.job.reset();
+            }
+        }
+    }
+
+    // a free arena of at least `need` bytes (waits for one; grows the smallest free one when none is big enough)
+    int take_arena(size_t need) {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            int best = -1, empty = -1, small = -1;
+            for (int i = 0; i < N_ARENAS; ++i) {
+                Arena& a = arenas_[i];
+                if (a.refs || a.filling) continue;
+                if (!a.p) { if (empty < 0) empty = i; continue; }
+                if (a.cap >= need) { if (best < 0 || a.cap < arenas_[best].cap) best = i; }
+                else if (small < 0) small = i;
+            }
+            int pick = best >= 0 ? best : (empty >= 0 ? empty : small);
+            if (pick >= 0) {
+                Arena& a = arenas_[pick];
+                a.filling = true;
+                if (a.cap < need) {
+                    lk.unlock();
+                    if (a.p) aqc_host_free(a.p);
+                    const size_t want = need + need / 4 + (8u << 20);
+                    a.p = (uint8_t*)aqc_host_alloc(want);
+                    a.cap = a.p ? want : 0;
+                    lk.lock();
+                    if (!a.p) { a.filling = false; return -1; }
+                }
+                return pick;
+            }
+            if (stop_) return -1;
+            cv_.wait(lk);
+        }
+    }
+
+#define GZB_TRY(expr) do { if ((expr) != hipSuccess) return false; } while (0)
+    bool run_group(Lane& L, Group& G) {
+        const int n = G.n;
+        const uint64_t byte0 = (G.nominal[0] >> 3) & ~(uint64_t)15;
+        const uint64_t end_byte = std::min<uint64_t>(G.size, (G.stop[n - 1] >> 3) + 1 + GZB_SLACK);
+        const size_t span = (size_t)(end_byte - byte0);
+        const uint32_t first_bit = (uint32_t)(G.nominal[0] - byte0 * 8), last_bit = (uint32_t)std::min<uint64_t>(G.stop[n - 1] - byte0 * 8, (uint64_t)span * 8);
+        const uint32_t n_tiles = (uint32_t)(((size_t)(last_bit >> 3) + 1 + GZB_SCAN_TILE - 1) / GZB_SCAN_TILE);
+        const uint32_t cand_cap = (uint32_t)(span / 4096 + 256);
+        uint64_t sec_max = 0;
+        for (int k = 0; k < n; ++k) sec_max = std::max<uint64_t>(sec_max, (G.stop[k] - G.nominal[k]) >> 3);
+        const uint32_t s_symcap = (uint32_t)((sec_max * 12 + (2u << 20) + 7) & ~(uint64_t)7);
+        const uint64_t blk_sym_cap = (uint64_t)span * GZB_RATIO_CAP + (uint64_t)cand_cap * 4104;
+        if (L.comp.reserve(span + 256) || L.tile_cnt.reserve(4ull * n_tiles) || L.tile_cand.reserve(4ull * n_tiles * GZB_TILE_CAND) || L.n_cand.reserve(64) ||
+            L.c_start.reserve(4ull * cand_cap) || L.c_end.reserve(4ull * cand_cap) || L.c_nsym.reserve(4ull * cand_cap) || L.c_flags.reserve(4ull * cand_cap) ||
+            L.c_symoff.reserve(8ull * cand_cap) || L.c_symcap.reserve(4ull * cand_cap) || L.blk_sym.reserve(2ull * blk_sym_cap + 64) ||
+            L.tables.reserve(4ull * cand_cap * GZB_TAB_WORDS) || L.s_in.reserve(12ull * n) || L.s_out.reserve(16ull * n) ||
+            L.s_blocks.reserve(12ull * n * GZB_SEC_BLOCKS) || L.s_sym.reserve(2ull * n * s_symcap + 64))
+            return false;
+        // section table: nominal, stop, exact (bits relative to the window)
+        std::vector<uint32_t> sin(3 * (size_t)n);
+        for (int k = 0; k < n; ++k) {
+            sin[k] = (uint32_t)(G.nominal[k] - byte0 * 8);
+            sin[n + k] = (uint32_t)std::min<uint64_t>(G.stop[k] - byte0 * 8, (uint64_t)span * 8);
+            sin[2 * n + k] = G.exact[k];
+        }
+        GZB_TRY(hipEventRecord(L.ev[0], L.stream));
+        GZB_TRY(hipMemcpyAsync(L.comp.p, G.data + byte0, span, hipMemcpyHostToDevice, L.stream));
+        GZB_TRY(hipMemsetAsync((uint8_t*)L.comp.p + span, 0, 256, L.stream));
+        GZB_TRY(hipMemcpyAsync(L.s_in.p, sin.data(), 12ull * n, hipMemcpyHostToDevice, L.stream));
+        GzbJob J{};
+        J.comp = (const uint8_t*)L.comp.p; J.comp_bytes = (uint32_t)span; J.scan_byte0 = 0; J.first_bit = first_bit; J.last_bit = last_bit;
+        J.n_tiles = n_tiles; J.tile_cnt = (uint32_t*)L.tile_cnt.p; J.tile_cand = (uint32_t*)L.tile_cand.p;
+        J.cand_cap = cand_cap; J.n_cand = (uint32_t*)L.n_cand.p;
+        J.c_start = (uint32_t*)L.c_start.p; J.c_end = (uint32_t*)L.c_end.p; J.c_nsym = (uint32_t*)L.c_nsym.p; J.c_flags = (uint32_t*)L.c_flags.p;
+        J.c_symoff = (uint64_t*)L.c_symoff.p; J.c_symcap = (uint32_t*)L.c_symcap.p; J.blk_sym = (uint16_t*)L.blk_sym.p; J.blk_sym_cap = blk_sym_cap;
+        J.ratio_cap = GZB_RATIO_CAP; J.tables = (uint32_t*)L.tables.p;
+        J.n_sec = (uint32_t)n; J.s_nominal = (const uint32_t*)L.s_in.p; J.s_stop = J.s_nominal + n; J.s_exact = J.s_nominal + 2 * n;
+        J.s_start = (uint32_t*)L.s_out.p; J.s_end = J.s_start + n; J.s_nsym = J.s_start + 2 * n; J.s_nblk = J.s_start + 3 * n;
+        J.s_blocks = (uint32_t*)L.s_blocks.p; J.s_sym = (uint16_t*)L.s_sym.p; J.s_symcap = s_symcap;
+        GZB_TRY(hipEventRecord(L.ev[1], L.stream));
+        hipLaunchKernelGGL(gzb_scan_kernel, dim3(n_tiles), dim3(GZB_SCAN_THREADS), 0, L.stream, J);
+        hipLaunchKernelGGL(gzb_compact_kernel, dim3(1), dim3(1024), 0, L.stream, J);
+        GZB_TRY(hipEventRecord(L.ev[2], L.stream));
+        hipLaunchKernelGGL(gzb_decode_kernel, dim3((cand_cap + GZB_DEC_THREADS - 1) / GZB_DEC_THREADS), dim3(GZB_DEC_THREADS), 0, L.stream, J);
+        GZB_TRY(hipEventRecord(L.ev[3], L.stream));
+        hipLaunchKernelGGL(gzb_chain_kernel, dim3((n + 63) / 64), dim3(64), 0, L.stream, J);
+        hipLaunchKernelGGL(gzb_gather_kernel, dim3(n), dim3(GZB_GATHER_THREADS), 0, L.stream, J);
+        GZB_TRY(hipEventRecord(L.ev[4], L.stream));
+        GZB_TRY(hipGetLastError());
+        std::vector<uint32_t> sout(4 * (size_t)n);
+        GZB_TRY(hipMemcpyAsync(sout.data(), L.s_out.p, 16ull * n, hipMemcpyDeviceToHost, L.stream));
+        GZB_TRY(hipStreamSynchronize(L.stream));
+        // the symbols of the sections that found a start, packed into one arena
+        std::vector<size_t> aoff((size_t)n, 0);
+        size_t need = 0;
+        for (int k = 0; k < n; ++k) {
+            if (sout[k] == GZB_NONE || sout[2 * n + k] == 0) continue;
+            aoff[k] = need;
+            need += ((size_t)sout[2 * n + k] * 2 + 63) & ~(size_t)63;
+        }
+        int ai = -1;
+        if (need) {
+            ai = take_arena(need);
+            if (ai < 0) return false;
+            for (int k = 0; k < n; ++k) {
+                if (sout[k] == GZB_NONE || sout[2 * n + k] == 0) continue;
+                if (hipMemcpyAsync(arenas_[ai].p + aoff[k], (const uint16_t*)L.s_sym.p + (size_t)k * s_symcap, (size_t)sout[2 * n + k] * 2, hipMemcpyDeviceToHost, L.stream) != hipSuccess) {
+                    std::lock_guard<std::mutex> g(mu_);
+                    arenas_[ai].filling = false;
+                    return false;
+                }
+            }
+        }
+        const bool ok = hipEventRecord(L.ev[5], L.stream) == hipSuccess && hipStreamSynchronize(L.stream) == hipSuccess;
+        int live = 0;
+        for (int k = 0; k < n; ++k) if (sout[k] != GZB_NONE && sout[2 * n + k] != 0) ++live;
+        if (ai >= 0) {
+            std::lock_guard<std::mutex> g(mu_);
+            arenas_[ai].filling = false;
+            arenas_[ai].refs = ok ? live : 0;
+        }
+        if (ai >= 0 && !ok) cv_.notify_all();
+        if (!ok) return false;
+        float ms[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], L.ev[i], L.ev[i + 1]);
+        g_gzb_stats[0] += (uint64_t)(ms[1] * 1000); g_gzb_stats[1] += (uint64_t)(ms[2] * 1000); g_gzb_stats[2] += (uint64_t)(ms[3] * 1000);
+        g_gzb_stats[3] += (uint64_t)(ms[0] * 1000); g_gzb_stats[4] += (uint64_t)(ms[4] * 1000); g_gzb_stats[5] += 1; g_gzb_stats[6] += (uint64_t)n; g_gzb_stats[7] += (uint64_t)live;
+        for (int k = 0; k < n; ++k) {
+            aqcgz::OffloadResult r;
+            if (sout[k] != GZB_NONE && sout[2 * n + k] != 0) {
+                r.found = true;
+                r.start_bit = byte0 * 8 + sout[k];
+                r.end_bit = byte0 * 8 + sout[n + k];
+                r.sym = (const uint16_t*)(arenas_[ai].p + aoff[k]);
+                r.n_sym = sout[2 * n + k];
+                r.token = new Token{ai};
+            }
+            G.done(k, r);
+        }
+        return true;
+    }
+#undef GZB_TRY
+
+    int device_;
+    size_t group_bytes_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false, broken_ = false;
+    Lane lanes_[N_LANES];
+    Arena arenas_[N_ARENAS];
 };
 
 }  // namespace
 
-// test / measurement entry: ONE gzip member decoded entirely by the device path (no host decoding: a section that does not
-// chain up ends the run with an error).  stats: batches, sections accepted, ms in find / decode / chain / resolve kernels (x1000)
-int aqc_gunzip_dev_selftest(int device, const uint8_t* gz, uint64_t size, uint8_t* out, uint64_t cap, uint64_t* n_out, uint64_t stats[8]) {
+}  // extern "C"
+namespace aqcgz {
+SectionOffload* make_device_offload(int device, size_t group_bytes) {
+    std::unique_ptr<DeviceInflate> d(new DeviceInflate(device, group_bytes));
+    if (!d->start()) { (void)hipGetLastError(); return nullptr; }
+    return d.release();
+}
+void device_offload_stats(uint64_t out[8]) {
+    for (int i = 0; i < 8; ++i) out[i] = g_gzb_stats[i].load();
+}
+}  // namespace aqcgz
+extern "C" {
+
+// One gzip file decoded with the device taking every section it can (what the pipe does for a `.gz` input, minus the pool's share
+// of the sections): `threads` host threads translate symbols and check CRC-32 / ISIZE, the stream's last section and whatever the
+// device does not chain up is decoded on the host.  stats: sections committed from the device / from the host, bytes decoded
+// sequentially on the host (bridges), then aqcgz::device_offload_stats()[0..5) of this call (microseconds in the scan + compact,
+// decode, chain + gather kernels, H2D, D2H).
+int aqc_gunzip_dev(int device, const uint8_t* gz, uint64_t size, uint8_t* out, uint64_t cap, uint64_t* n_out, uint64_t stats[8], int threads,
+                   uint64_t section_bytes, uint64_t group_bytes) {
     if (!gz || !out || !n_out || !stats) return fail(AQC_ERR_ARG, "null argument");
-    const size_t h = aqcgz::parse_gzip_header(gz, (size_t)size, 0);
-    if (!h) return fail(AQC_ERR_ARG, "not a gzip file");
-    GzdDevice D;
-    int rc = D.init(device);
-    if (rc) return rc;
+    std::unique_ptr<aqcgz::SectionOffload> off(aqcgz::make_device_offload(device, group_bytes ? (size_t)group_bytes : (64u << 20)));
+    if (!off) return fail(AQC_ERR_HIP, "device gunzip: cannot set up device %d", device);
+    uint64_t before[8], after[8];
+    aqcgz::device_offload_stats(before);
+    aqc_host::Pool pool(threads > 0 ? threads : 0);
     memset(stats, 0, 8 * sizeof(uint64_t));
-    uint64_t bit = (uint64_t)h * 8, produced = 0;
-    std::vector<uint8_t> window;
-    for (;;) {
-        if ((rc = D.decode(gz, size, bit, window.data(), window.size()))) break;
-        stats[0] += 1; stats[1] += D.accepted;
-        stats[2] += (uint64_t)(D.ms_find * 1000); stats[3] += (uint64_t)(D.ms_decode * 1000); stats[4] += (uint64_t)(D.ms_chain * 1000); stats[5] += (uint64_t)(D.ms_resolve * 1000);
-        if (D.corrupt) { rc = fail(AQC_ERR_ARG, "corrupt stream (marker before the member start)"); break; }
-        if (D.accepted == 0 || D.n_text == 0) { rc = fail(AQC_ERR_STATE, "device gunzip: no section chained up at bit %llu (batch %llu)", (unsigned long long)bit, (unsigned long long)stats[0]); break; }
-        if (produced + D.n_text > cap) { rc = fail(AQC_ERR_ARG, "output does not fit"); break; }
-        if ((rc = D.fetch(0, D.n_text, out + produced))) break;
-        produced += D.n_text;
-        const size_t wl = (size_t)std::min<uint64_t>(32768, produced);
-        window.assign(out + produced - wl, out + produced);
-        bit = D.end_bit;
-        stats[6] = bit;
-        if (D.final_block) break;
-        if (D.accepted < D.n_sections && D.end_bit / 8 + 64 >= size) break;
+    uint64_t produced = 0;
+    int rc = 0;
+    {
+        aqcgz::ParallelGunzip pg(gz, (size_t)size, threads > 0 ? &pool : nullptr, std::max(4, 2 * threads), section_bytes ? (size_t)section_bytes : (1u << 20), off.get(), true);
+        while (produced < cap) {
+            const size_t got = pg.read(out + produced, (size_t)std::min<uint64_t>(cap - produced, 256u << 20));
+            if (pg.failed()) { rc = fail(AQC_ERR_ARG, "device gunzip: %s", pg.error()); break; }
+            if (!got) break;
+            produced += got;
+        }
+        if (!rc && produced == cap) {
+            uint8_t probe;
+            if (pg.read(&probe, 1) != 0) rc = fail(AQC_ERR_ARG, "output does not fit");
+        }
+        stats[0] = pg.offloaded_accepted; stats[1] = pg.sections_accepted - pg.offloaded_accepted; stats[2] = pg.bridged_bytes;
     }
+    aqcgz::device_offload_stats(after);
+    for (int i = 0; i < 5; ++i) stats[3 + i] = after[i] - before[i];
     *n_out = produced;
-    D.release();
     return rc;
 }
 

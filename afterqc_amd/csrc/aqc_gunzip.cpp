@@ -158,12 +158,18 @@ struct ParallelGunzip::Section {
     uint64_t end_bit = 0;
     SymBuf buf;
     size_t n_out = 0;
+    // decoded by a SectionOffload (the device): the symbols live in its buffer until the section is dropped
+    bool offloaded = false;
+    const uint16_t* ext_sym = nullptr;
+    void* ext_token = nullptr;
+    SectionOffload* ext_owner = nullptr;
     struct MemberEnd { size_t out_pos; uint32_t crc, isize; };
     std::vector<MemberEnd> ends;
     std::mutex mu;
     std::condition_variable cv;
     std::shared_ptr<Shared> sh;
     ~Section() {
+        if (ext_owner && ext_token) ext_owner->release(ext_token);
         if (sh && buf.p) {
             std::lock_guard<std::mutex> g(sh->mu);
             if (sh->free_bufs.size() < 256) sh->free_bufs.push_back(std::move(buf));
@@ -177,9 +183,10 @@ void run_sections(const uint8_t* data, size_t size, const std::shared_ptr<Parall
 
 }  // namespace
 
-ParallelGunzip::ParallelGunzip(const uint8_t* data, size_t size, aqc_host::Pool* pool, int inflight, size_t section_bytes)
+ParallelGunzip::ParallelGunzip(const uint8_t* data, size_t size, aqc_host::Pool* pool, int inflight, size_t section_bytes, SectionOffload* offload,
+                               bool offload_only)
     : data_(data), size_(size), pool_(pool), inflight_(inflight < 1 ? 1 : inflight), section_bytes_(section_bytes < (64u << 10) ? (64u << 10) : section_bytes),
-      sh_(new Shared()) {}
+      offload_(offload), offload_only_(offload_only && offload), sh_(new Shared()) {}
 
 ParallelGunzip::~ParallelGunzip() {
     // speculative sections still running hold their own references; wait for them (they read data_)
@@ -206,7 +213,9 @@ struct SectionRun {
     const uint8_t* data;
     size_t size;
     std::unique_ptr<Inflater<uint16_t>> inf;
-    size_t cap = 0;
+    size_t cap = 0, cap_limit = 0;  // symbols the buffer holds / may ever hold (64 x the compressed span: a speculative section that
+                                    // wants more — a gzip bomb, a false start in constant data — is given up, the consumer then
+                                    // decodes that stretch sequentially through its 1 MiB bridge buffer)
     size_t base_off = 0;            // symbols of earlier members of this section (a new member has no history at all)
     bool done = false;
 
@@ -225,6 +234,7 @@ struct SectionRun {
         inf.reset(new Inflater<uint16_t>());
         const size_t span = (size_t)((std::min<uint64_t>(s.stop_bit, (uint64_t)size * 8) - std::min<uint64_t>(start, (uint64_t)size * 8)) >> 3);
         const size_t need = SymBuf::round_up(span * 4 + (256u << 10));
+        cap_limit = SymBuf::round_up(span * 64 + (8u << 20));
         if (s.sh) {
             // a recycled buffer that is big enough (sections are all alike, so nearly any is), else the last one: it grows
             std::lock_guard<std::mutex> g(s.sh->mu);
@@ -247,7 +257,7 @@ struct SectionRun {
     // what a return code of the decoder (other than GZ_CONTINUE) means here
     void on_rc(int rc) {
         if (rc == GZ_NEED_OUTPUT) {
-            if (!s.buf.grow(cap + cap / 2 + (1u << 20))) { s.error = true; done = true; return; }
+            if (cap >= cap_limit || !s.buf.grow(std::min(cap_limit, cap + cap / 2 + (1u << 20)))) { s.error = true; done = true; return; }
             cap = s.buf.cap;
             inf->out = s.buf.p + WINDOW + base_off; inf->out_cap = cap - base_off;
             return;
@@ -325,16 +335,10 @@ void run_sections(const uint8_t* data, size_t size, const std::shared_ptr<Parall
 
 }  // namespace
 
-void ParallelGunzip::top_up() {
-    auto launch = [this](const std::shared_ptr<Section>& s0, const std::shared_ptr<Section>& s1) {
-        const uint8_t* data = data_;
-        const size_t size = size_;
-        if (pool_) pool_->submit([data, size, s0, s1] { run_sections(data, size, s0, s1); }, true);
-        else run_sections(data, size, s0, s1);
-    };
-    bool no_more = false;
-    while ((int)q_.size() < inflight_) {
-        std::shared_ptr<Section> s;
+// the next section in stream order; nullptr when the stream has no further section to launch (no_more) 
+std::shared_ptr<ParallelGunzip::Section> ParallelGunzip::new_section(bool& no_more) {
+    std::shared_ptr<Section> s;
+    for (;;) {
         if (!started_) {
             started_ = true;
             s.reset(new Section());
@@ -345,7 +349,7 @@ void ParallelGunzip::top_up() {
             next_section_ = (size_t)((cur_bit_ >> 3) / section_bytes_) + 1;
         } else {
             const uint64_t nominal = (uint64_t)next_section_ * section_bytes_;
-            if (nominal + 64 >= size_) { no_more = true; break; }
+            if (nominal + 64 >= size_) { no_more = true; return nullptr; }
             if (nominal * 8 <= cur_bit_) { ++next_section_; continue; }
             s.reset(new Section());
             s->index = next_section_++;
@@ -354,13 +358,82 @@ void ParallelGunzip::top_up() {
         const uint64_t next_nominal = (uint64_t)next_section_ * section_bytes_;
         s->stop_bit = next_nominal + 64 >= size_ ? UINT64_MAX : next_nominal * 8;
         s->sh = sh_;
+        return s;
+    }
+}
+
+void ParallelGunzip::top_up() {
+    auto launch = [this](const std::shared_ptr<Section>& s0, const std::shared_ptr<Section>& s1) {
+        const uint8_t* data = data_;
+        const size_t size = size_;
+        if (pool_) pool_->submit([data, size, s0, s1] { run_sections(data, size, s0, s1); }, true);
+        else run_sections(data, size, s0, s1);
+    };
+    // sections go to the pool two at a time (run_sections decodes a pair alternately); an odd one waits for its partner
+    auto to_pool = [&](const std::shared_ptr<Section>& s) {
         q_.push_back(s);
-        // sections go to the pool two at a time (run_sections decodes a pair alternately); an odd one waits for its partner
         if (unlaunched_) { launch(unlaunched_, s); unlaunched_.reset(); }
         else unlaunched_ = s;
+    };
+    bool no_more = false;
+    for (;;) {
+        size_t on_pool = 0, on_device = 0;
+        for (auto& s : q_) (s->offloaded ? on_device : on_pool)++;
+        // The pool's share first (the sections the consumer will want next), then — whenever the device is free — a GROUP of
+        // sections behind them.  Who gets how much settles by itself: the device takes a group each time it is ready, the pool
+        // a section each time one of its `inflight_` is committed.
+        if (!offload_only_ && on_pool < (size_t)inflight_ * (offload_ ? 2u : 1u)) {
+            std::shared_ptr<Section> s = new_section(no_more);
+            if (!s) break;
+            to_pool(s);
+            continue;
+        }
+        if (!offload_ || no_more) break;
+        const size_t per_group = std::max<size_t>(1, offload_->group_bytes() / section_bytes_);
+        if (on_device >= 3 * per_group || !offload_->ready()) break;
+        std::vector<std::shared_ptr<Section>> group;
+        std::shared_ptr<Section> last;                       // the stream's last section runs to the end of the file: the pool's
+        while (group.size() < per_group) {
+            std::shared_ptr<Section> s = new_section(no_more);
+            if (!s) break;
+            if (s->stop_bit == UINT64_MAX) { last = s; break; }
+            group.push_back(s);
+        }
+        if (!group.empty()) {
+            std::vector<uint64_t> nominal(group.size()), stop(group.size());
+            std::vector<uint8_t> exact(group.size());
+            for (size_t k = 0; k < group.size(); ++k) {
+                group[k]->offloaded = true;
+                nominal[k] = group[k]->nominal_bit; stop[k] = group[k]->stop_bit; exact[k] = group[k]->known_start ? 1 : 0;
+            }
+            SectionOffload* const off = offload_;
+            auto done = [group, off](int k, const OffloadResult& r) {
+                Section& s = *group[(size_t)k];
+                s.found = r.found;
+                s.start_bit = r.start_bit;
+                s.end_bit = r.end_bit;
+                s.ext_sym = r.sym;
+                s.n_out = r.n_sym;
+                s.ext_token = r.token;
+                s.ext_owner = off;
+                {
+                    std::lock_guard<std::mutex> g(s.mu);
+                    s.done = true;
+                }
+                s.cv.notify_all();
+            };
+            if (offload_->submit(data_, size_, (int)group.size(), nominal.data(), stop.data(), exact.data(), done)) {
+                for (auto& s : group) q_.push_back(s);
+                sections_offloaded += group.size();
+            } else {
+                for (auto& s : group) { s->offloaded = false; to_pool(s); }
+            }
+        }
+        if (last) to_pool(last);
+        if (group.empty() && !last) break;
     }
     // ... but not when nothing will follow it, and never when it is the section the consumer is going to wait for
-    if (unlaunched_ && (no_more || q_.front() == unlaunched_ || !pool_)) { launch(unlaunched_, nullptr); unlaunched_.reset(); }
+    if (unlaunched_ && (no_more || q_.front() == unlaunched_ || !pool_ || offload_only_)) { launch(unlaunched_, nullptr); unlaunched_.reset(); }
 }
 
 void ParallelGunzip::push_window(const uint8_t* p, size_t n) {
@@ -416,7 +489,7 @@ void ParallelGunzip::drain_events(bool wait_all) {
 }
 
 void ParallelGunzip::accept(Section& s, uint8_t* dst, size_t& out, size_t want) {
-    const uint16_t* sym = s.buf.p + WINDOW;
+    const uint16_t* sym = s.ext_sym ? s.ext_sym : s.buf.p + WINDOW;
     const size_t n = s.n_out;
     const size_t to_dst = std::min(n, want - out);
     // (the spill buffer is empty here: read() serves it before anything else)
@@ -486,6 +559,7 @@ void ParallelGunzip::accept(Section& s, uint8_t* dst, size_t& out, size_t want) 
     cur_bit_ = s.end_bit;
     if (s.hit_eof) done_ = true;
     sections_accepted++;
+    if (s.offloaded) { offloaded_accepted++; offloaded_bytes += n; }
 }
 
 // sequential decoding from cur_bit_ with the window known, one buffer-full per call, until a block boundary at or behind

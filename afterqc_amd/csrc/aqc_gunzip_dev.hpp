@@ -1,642 +1,697 @@
-// aqc_gunzip_dev.hpp — gzip INPUT decoded on the device (round 3): the sections of aqc_gunzip.cpp's ParallelGunzip, one WAVE
-// per section instead of one host thread (fastq.py:23-24 upstream: gzip.open + readline on the one CPU thread).
+// aqc_gunzip_dev.hpp — gzip INPUT decoded on the device (round 4): one LANE per DEFLATE BLOCK (fastq.py:23-24 upstream: gzip.open +
+// readline on the one CPU thread).
 //
-// Why: the MI355X boxes grant a container 16 CPUs; the host decoder makes ~4 GB/s of text out of that, which is what bounds
-// a `.gz -> .gz` run once the writer's deflate is on the device (aqc_gzdev.hpp).  The structure of the host decoder carries over:
+// Why a lane per block.  Huffman decoding is one dependency chain per stream — bit position -> table entry -> next bit
+// position — and nothing inside a block breaks it.  Round 3's decoder gave a whole WAVE to one stream (64 lanes guessing token
+// starts, a scalar walk picking the real ones): 5 tokens per ~4,800-cycle round, 4 MB/s per wave, 2.75 GB/s per GPU.  But one
+// gzip stream is tens of thousands of blocks (zlib closes a block every 16 K tokens: ~110 KB of FASTQ text at level 6), every
+// dynamic-Huffman block carries its own code, and where a block begins can be RECOGNISED without decoding anything before it
+// (the header must describe three complete prefix codes: about one false hit per gigabyte).  So:
 //
-//   gzd_find_kernel      a wave per section tests 64 bit positions at a time for "a non-final dynamic-Huffman block starts here"
-//                        (header fields, Kraft sum of the code-length code; survivors: the code lengths must parse and give
-//                        complete literal/length and distance codes).  No trial decoding: the commit rule below catches a
-//                        false start.
-//   gzd_decode_kernel    a wave per section decodes sequentially from its start to the first block boundary at or behind the
-//                        next section's nominal start, in 16-bit SYMBOLS (>= 0x8000: "byte j of the 32 KiB before my start").
-//                        Control flow is wave-uniform — bit buffer, table indices, lengths and distances live in scalar
-//                        registers; the Huffman root tables (2048 + 512 entries) and a ring of the last 8192 symbols are in
-//                        LDS; literals collect in one register across the lanes and leave as 128-byte stores; match copies are
-//                        shared by the lanes (from the ring; from memory only beyond it, where every store has long landed).
-//   gzd_chain_kernel     ONE workgroup walks the sections in order: section k counts only if it starts at the very bit section
-//                        k - 1 ended on (decoding is deterministic from a block boundary: exact, not heuristic); it places the
-//                        sections in the output and resolves the markers of each section's LAST 32 KiB (they point into the
-//                        32 KiB before the section, resolved one step earlier).
-//   gzd_resolve_kernel   everything else, in parallel: a marker's byte is in a region the chain pass has finished.
+//   gzb_scan_kernel     EVERY bit position of the batch is tested for "a non-final dynamic-Huffman block begins here": the
+//                       three header bits and HLIT / HDIST <= 29 for 32 positions at a time with bitwise logic on 64-bit words
+//                       (~1 instruction per position), the Kraft sum of the code-length code for the ~11 % that remain (seven
+//                       LDS look-ups of three 3-bit fields each), and for the ~0.2 % that remain the code lengths themselves: they
+//                       must parse and form a complete literal/length code with an end-of-block symbol and a usable distance code.
+//   gzb_compact_kernel  the per-tile hits become one sorted candidate list; a candidate's output space is sized from the
+//                       compressed bytes up to the next candidate.
+//   gzb_decode_kernel   a LANE per candidate: builds its own root tables (10-bit literal/length, 8-bit distance, entries
+//                       carry base + extra-bit count; longer codes: canonical search) in its own 6 KiB of global memory and
+//                       decodes its block the way a CPU thread would — one 8-byte peek per token, 8-byte match copies — into
+//                       16-bit SYMBOLS (>= 0x8000: "byte j of the 32 KiB before this BLOCK").  A lane runs at a few MB/s (every
+//                       step is a dependent trip to L2); tens of thousands of them run at once.  No LDS, no cross-lane traffic.
+//   gzb_chain_kernel    a lane per SECTION (the host's unit of work, aqc_gunzip.cpp): from the first candidate at or behind the
+//                       section's nominal start it follows  end of block == start of a candidate  until the section's stop bit;
+//                       stored blocks (pigz's sync markers) are stepped over in place.  A false candidate never chains up.
+//   gzb_gather_kernel   a workgroup per section copies the chained blocks into one symbol stream and re-bases their markers
+//                       from "before my block" to "before my section" (or resolves them: the byte is in an earlier block).
 //
-// The host (aqc_capi.hip: DeviceGunzip) feeds compressed windows, takes the text of the sections that chained up and hands
-// anything else — a block the search did not find, a final block, an error, an overflow — back to the host decoder, which
-// also checks the members' CRC-32 / ISIZE over the bytes it receives.
+// What comes back is exactly what a host pool thread would have produced for the section — start bit, end bit, symbols — so
+// the consumer's commit rule (a section counts only if it starts at the very bit its predecessor ended on) is unchanged and
+// the result stays exact.  Final blocks, fixed-Huffman blocks and anything the scan does not recognise end a chain; the host
+// decodes on from there (ParallelGunzip::bridge).
+//
+// Everything a LANE does is a plain __host__ __device__ function (GZB_HD): tests/native/gzb_selftest.cpp compiles this header
+// with the host compiler and runs the same scan tests, table builder, block decoder, chain walk and marker re-basing over
+// zlib streams on the CPU (`-m "not gpu"`); the kernels below only deal the work to lanes.
 #pragma once
-#include <hip/hip_runtime.h>
 #include <stdint.h>
-
-#include "aqc_kernels.hpp"
+#include <string.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GZB_HD __host__ __device__
+#else
+#define GZB_HD
+#endif
 
 namespace aqc {
 
-constexpr uint32_t GZD_MARKER = 0x8000u;
-constexpr int GZD_LROOT = 11, GZD_DROOT = 9;
-constexpr int GZD_RING = 32768;                    // the whole window behind the write position stays in LDS (64 KiB per wave)
-constexpr uint64_t GZD_NONE = ~0ull;
-// section flags
-constexpr uint32_t GZD_FINAL = 1u, GZD_ERROR = 2u, GZD_OVERFLOW = 4u;
+GZB_HD inline uint32_t gzb_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
+GZB_HD inline uint32_t gzb_max(uint32_t a, uint32_t b) { return a > b ? a : b; }
+// the low `len` bits of c, reversed
+GZB_HD inline uint32_t gzb_rev(uint32_t c, uint32_t len) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(c) >> (32u - len);
+#else
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < len; ++i) r |= ((c >> i) & 1u) << (len - 1u - i);
+    return r;
+#endif
+}
 
-struct GzdJob {
-    const uint8_t* comp;        // compressed window; comp[0] is byte `base` of the file (not used by the kernels), 4-byte aligned
-    uint64_t comp_bytes;        // readable bytes (the buffer is padded with 64 zero bytes behind)
-    uint64_t start_bit;         // section 0 starts here (a known block boundary), relative to comp[0]
-    uint32_t n_sections;
-    uint32_t section_bytes;     // section k >= 1 is searched from bit k * section_bytes * 8 on
-    uint64_t* sec_start;        // [n] found start bit (GZD_NONE: none)
-    uint64_t* sec_end;          // [n] block boundary the section stopped at
-    uint32_t* sec_flags;        // [n]
-    uint32_t* sec_nsym;         // [n] symbols produced
-    uint16_t* sym;              // [n][sym_cap]
-    uint32_t sym_cap;
-    // chain / resolve
-    uint8_t* text;              // output bytes; text[-32768 .. 0) holds the window before the batch (right-aligned)
-    uint32_t window_valid_from; // markers below this index of the first section's window point before the member's start
-    uint64_t* sec_off;          // [n + 1] offset of each section's bytes in text
-    uint32_t* result;           // [0] sections accepted, [1] a marker reached before the member start (corrupt), [2] the last
-                                // accepted section ended a member (BFINAL), [4..5] bit position reached, [6..7] bytes of text
+constexpr uint32_t GZB_MARKER = 0x8000u;
+constexpr int GZB_LROOT = 10, GZB_DROOT = 8;
+// a candidate's private table space (32-bit words): literal/length root, distance root, then 16-bit arrays: symbols sorted by
+// code (288 + 32), codes per length (16 + 16), and the 320 code lengths as bytes
+constexpr int GZB_T_DIST = 1 << GZB_LROOT, GZB_T_LSORT = GZB_T_DIST + (1 << GZB_DROOT), GZB_T_DSORT = GZB_T_LSORT + 144, GZB_T_LCOUNT = GZB_T_DSORT + 16,
+              GZB_T_DCOUNT = GZB_T_LCOUNT + 8, GZB_T_LENS = GZB_T_DCOUNT + 8, GZB_TAB_WORDS = GZB_T_LENS + 80;
+constexpr int GZB_SCAN_THREADS = 256, GZB_SCAN_TILE = GZB_SCAN_THREADS * 16, GZB_TILE_CAND = 16;
+constexpr int GZB_DEC_THREADS = 64;
+constexpr int GZB_SEC_BLOCKS = 4096;                // chain entries per section (3 words each)
+constexpr int GZB_GATHER_THREADS = 1024;
+constexpr uint32_t GZB_F_ERROR = 1u, GZB_F_OVERFLOW = 2u, GZB_F_SKIP = 4u;
+constexpr uint32_t GZB_NONE = 0xffffffffu;
+constexpr uint32_t GZB_STORED = 0x80000000u;
+
+// One batch: a window of the compressed file on the device.  Bit positions are 32-bit, relative to comp[0]: a window is < 512 MiB.
+struct GzbJob {
+    const uint8_t* comp;         // 16-byte aligned, zero-padded for 64 bytes behind comp_bytes
+    uint32_t comp_bytes;
+    uint32_t scan_byte0;         // first byte whose bit positions are scanned (multiple of 16)
+    uint32_t first_bit, last_bit;// candidates are kept in [first_bit, last_bit)
+    uint32_t n_tiles;
+    uint32_t* tile_cnt;          // [n_tiles]
+    uint32_t* tile_cand;         // [n_tiles][GZB_TILE_CAND]
+    uint32_t cand_cap;
+    uint32_t* n_cand;            // [0] candidates, [1] 1 when the symbol space ran out
+    uint32_t* c_start;           // [cand_cap] header bit
+    uint32_t* c_end;             // [cand_cap] bit behind the end-of-block code
+    uint32_t* c_nsym;
+    uint32_t* c_flags;
+    uint64_t* c_symoff;          // [cand_cap] first symbol of the candidate in blk_sym
+    uint32_t* c_symcap;
+    uint16_t* blk_sym;
+    uint64_t blk_sym_cap;        // symbols
+    uint32_t ratio_cap;          // a block may expand to ratio_cap x its compressed size (+ 4096 symbols)
+    uint32_t* tables;            // [cand_cap][GZB_TAB_WORDS]
+    // sections
+    uint32_t n_sec;
+    const uint32_t* s_nominal;   // [n_sec] search from this bit
+    const uint32_t* s_stop;      // [n_sec] stop at the first block boundary at or behind this bit
+    const uint32_t* s_exact;     // [n_sec] 1: the section must start AT s_nominal (a known boundary)
+    uint32_t* s_start;           // [n_sec] GZB_NONE: nothing found
+    uint32_t* s_end;
+    uint32_t* s_nsym;
+    uint32_t* s_nblk;
+    uint32_t* s_blocks;          // [n_sec][GZB_SEC_BLOCKS][3]: candidate (or GZB_STORED | length), source byte (stored), offset
+    uint16_t* s_sym;             // [n_sec][s_symcap]
+    uint32_t s_symcap;
 };
 
-__device__ __constant__ uint16_t GZD_LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ __constant__ uint8_t GZD_LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ __constant__ uint16_t GZD_DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__device__ __constant__ uint8_t GZD_DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-__device__ __constant__ uint8_t GZD_CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+GZB_HD inline uint32_t gzb_len_base(uint32_t i) {
+    static const uint16_t T[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    return T[i];
+}
+GZB_HD inline uint32_t gzb_len_extra(uint32_t i) {
+    static const uint8_t T[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    return T[i];
+}
+GZB_HD inline uint32_t gzb_dist_base(uint32_t i) {
+    static const uint16_t T[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    return T[i];
+}
+GZB_HD inline uint32_t gzb_dist_extra(uint32_t i) {
+    static const uint8_t T[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    return T[i];
+}
+GZB_HD inline uint32_t gzb_cl_order(uint32_t i) {
+    static const uint8_t T[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    return T[i];
+}
 
 // >= 57 bits of the stream from bit position p on (any alignment; the buffer is padded)
-__device__ __forceinline__ unsigned long long gzd_peek(const uint8_t* comp, unsigned long long p) {
+GZB_HD inline unsigned long long gzb_peek(const uint8_t* comp, uint32_t p) {
     unsigned long long v;
-    __builtin_memcpy(&v, comp + (p >> 3), 8);
-    return v >> (p & 7);
+    memcpy(&v, comp + (p >> 3), 8);
+    return v >> (p & 7u);
 }
 
-__device__ __forceinline__ uint32_t gzd_rev(uint32_t c, int len) { return __builtin_bitreverse32(c) >> (32 - len); }
-
-// One wave's decoding tables (LDS).  Root entries: low 4 bits = code length (0: not a root code: use the canonical search),
-// bits 4.. = symbol.  The canonical search (codes longer than the root) uses first[] / offs[] / sorted[].
-struct GzdTables {
-    uint32_t lit[1 << GZD_LROOT];
-    uint32_t dist[1 << GZD_DROOT];
-    uint16_t lsorted[288], dsorted[32];
-    uint16_t lcount[16], dcount[16];
-    uint8_t lens[320];
-    uint8_t cll[32];          // the 19 lengths of the code-length code
-    uint32_t cl[128];
-    uint32_t cnt[16], next[16], offs[16];      // scratch of the table builder (LDS: indexed by code length at run time)
-};
-
-// Canonical Huffman code from lens[0, n) -> root table + sorted symbols / counts.  Uniform (every lane runs it; the table fill
-// is shared by the lanes).  Returns 0 ok, 1 over-subscribed, 2 incomplete (the caller applies zlib's single-code rule).
-__device__ __forceinline__ uint32_t gzd_wave_sum(uint32_t v) {
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) v += (uint32_t)__shfl_xor((int)v, sft, WAVE);
-    return v;
+// Root table entries.  bits 3:0 code length (0: not a root code), 7:4 extra bits, 8 literal, 9 end of block, 10 invalid symbol,
+// 31:16 literal byte / base length / base distance.
+GZB_HD inline uint32_t gzb_lit_entry(uint32_t s, uint32_t l) {
+    if (s < 256u) return l | 0x100u | (s << 16);
+    if (s == 256u) return l | 0x200u;
+    if (s > 285u) return l | 0x400u;
+    return l | (gzb_len_extra(s - 257u) << 4) | (gzb_len_base(s - 257u) << 16);
 }
-__device__ __forceinline__ uint32_t gzd_wave_max(uint32_t v) {
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, sft, WAVE));
-    return v;
+GZB_HD inline uint32_t gzb_dist_entry(uint32_t s, uint32_t l) {
+    if (s > 29u) return l | 0x400u;
+    return l | (gzb_dist_extra(s) << 4) | (gzb_dist_base(s) << 16);
 }
 
-__device__ inline int gzd_build(GzdTables& T, const uint8_t* lens, int n, int R, uint32_t* root, uint16_t* sorted, uint16_t* count, int lane, int* max_len) {
-    uint32_t* const cnt = T.cnt; uint32_t* const next = T.next; uint32_t* const offs = T.offs;
-    if (lane < 16) cnt[lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    for (int s = lane; s < n; s += WAVE) { const int l = lens[s]; if (l) atomicAdd(&cnt[l], 1u); }
-    __builtin_amdgcn_wave_barrier();
-    int left = 1, mx = 0;
-    for (int l = 1; l <= 15; ++l) {
-        const int c = (int)cnt[l];
-        left = (left << 1) - c;
-        if (left < 0) return 1;
-        if (c) mx = l;
+// The header of a dynamic-Huffman block whose three header bits sit at bit p: HLIT, HDIST, HCLEN, the code-length code, the
+// HLIT + HDIST code lengths.  Returns false unless the code-length code is complete, the lengths parse, the literal/length
+// code is complete and has an end-of-block symbol, and the distance code is complete, a single 1-bit code, or empty (what
+// zlib's inflate accepts, minus the incomplete single-code literal case no compressor writes).  cl: this lane's 128-entry
+// table of the code-length code, entry i at cl[i * stride]; lens (may be null): the lengths as bytes, 320 of them.
+GZB_HD inline bool gzb_header(const uint8_t* comp, uint32_t limit_bit, uint32_t p, uint8_t* cl, int stride, uint8_t* lens,
+                                  uint32_t& data_bit, uint32_t& hlit_out, uint32_t& hdist_out) {
+    if (p + 17u + 64u > limit_bit) return false;
+    const unsigned long long w = gzb_peek(comp, p);
+    const uint32_t hlit = (uint32_t)((w >> 3) & 31u) + 257u, hdist = (uint32_t)((w >> 8) & 31u) + 1u, hclen = (uint32_t)((w >> 13) & 15u) + 4u;
+    if (hlit > 286u || hdist > 30u) return false;
+    uint32_t q = p + 17u;
+    unsigned long long v = gzb_peek(comp, q);
+    q += 3u * hclen;
+    // the 19 code-length-code lengths, 3 bits each, by symbol; codes per length, 8 bits each
+    unsigned long long cl3 = 0, cnt = 0;
+    for (uint32_t i = 0; i < hclen; ++i) {
+        const unsigned long long l = v & 7u;
+        v >>= 3;
+        cl3 |= l << (3u * gzb_cl_order(i));
+        cnt += 1ull << (8u * (uint32_t)l);
     }
-    *max_len = mx;
-    for (int i = lane; i < (1 << R); i += WAVE) root[i] = 0;
+    unsigned long long next = 0;
     {
-        uint32_t code = 0, o = 0, prev = 0;
+        uint32_t code = 0, left = 1, prevc = 0;
+        for (uint32_t l = 1; l <= 7; ++l) {
+            const uint32_t c = (uint32_t)(cnt >> (8u * l)) & 255u;
+            code = (code + prevc) << 1;
+            prevc = c;
+            next |= (unsigned long long)(code & 255u) << (8u * l);
+            left <<= 1;
+            if (c > left) return false;
+            left -= c;
+        }
+        if (left != 0) return false;
+    }
+    for (uint32_t s = 0; s < 19; ++s) {
+        const uint32_t l = (uint32_t)(cl3 >> (3u * s)) & 7u;
+        if (!l) continue;
+        const uint32_t c = (uint32_t)(next >> (8u * l)) & 255u;
+        next += 1ull << (8u * l);
+        const uint32_t r = gzb_rev(c, l);
+        const uint8_t e = (uint8_t)((s << 3) | l);
+        for (uint32_t i = r; i < 128u; i += 1u << l) cl[i * stride] = e;
+    }
+    const uint32_t total = hlit + hdist;
+    uint32_t i = 0, prev = 0, klit = 0, kdist = 0, maxd = 0;
+    bool has_eob = false;
+    while (i < total) {
+        if (q + 64u > limit_bit) return false;
+        const unsigned long long x = gzb_peek(comp, q);
+        const uint32_t e = cl[((uint32_t)x & 127u) * stride];
+        const uint32_t l = e & 7u, sym = e >> 3;
+        q += l;
+        uint32_t rep = 1, val = sym;
+        if (sym >= 16u) {
+            const uint32_t y = (uint32_t)(x >> l);
+            if (sym == 16u) { if (i == 0) return false; val = prev; rep = 3u + (y & 3u); q += 2; }
+            else if (sym == 17u) { val = 0; rep = 3u + (y & 7u); q += 3; }
+            else { val = 0; rep = 11u + (y & 127u); q += 7; }
+            if (i + rep > total) return false;
+        }
+        prev = val;
+        if (val) {
+            const uint32_t k = 32768u >> val;
+            const uint32_t nl = i < hlit ? gzb_min(rep, hlit - i) : 0u;
+            klit += nl * k;
+            kdist += (rep - nl) * k;
+            if (rep > nl) maxd = gzb_max(maxd, val);
+            if (i <= 256u && i + rep > 256u) has_eob = true;
+        }
+        if (lens)
+            for (uint32_t k = 0; k < rep; ++k) lens[i + k] = (uint8_t)val;
+        i += rep;
+    }
+    if (!has_eob || klit != 32768u) return false;
+    if (!(kdist == 32768u || (kdist <= 16384u && maxd <= 1u))) return false;
+    data_bit = q; hlit_out = hlit; hdist_out = hdist;
+    return true;
+}
+
+// ---- what a lane does, as plain functions ------------------------------------------------------------------------------------------
+// 32 positions at a time (v = 64 bits of the stream from the first position on): BFINAL = 0 and BTYPE = 2 (bits 0 0 1),
+// HLIT <= 29 and HDIST <= 29 (not: the upper four bits of the five all set)
+GZB_HD inline uint32_t gzb_quick32(unsigned long long v) {
+    const unsigned long long z = ~v & ~(v >> 1) & (v >> 2);
+    const unsigned long long hl = (v >> 4) & (v >> 5) & (v >> 6) & (v >> 7);
+    const unsigned long long hd = (v >> 9) & (v >> 10) & (v >> 11) & (v >> 12);
+    return (uint32_t)(z & ~hl & ~hd);
+}
+// kraft9[i] = sum over the three 3-bit lengths packed in i of 128 >> l (0 for l == 0)
+GZB_HD inline uint32_t gzb_kraft9(uint32_t i) {
+    uint32_t k = 0;
+    for (int f = 0; f < 3; ++f) { const uint32_t l = (i >> (3 * f)) & 7u; k += l ? 128u >> l : 0u; }
+    return k;
+}
+// the code-length code of the header at bit p must be complete: Kraft sum of its `hclen` 3-bit lengths
+GZB_HD inline bool gzb_kraft_ok(const uint8_t* comp, uint32_t p, uint32_t hclen, const uint8_t* kraft9) {
+    unsigned long long v = gzb_peek(comp, p + 17u);
+    v &= (1ull << (3u * hclen)) - 1ull;
+    const uint32_t kraft = (uint32_t)kraft9[v & 511u] + kraft9[(v >> 9) & 511u] + kraft9[(v >> 18) & 511u] + kraft9[(v >> 27) & 511u] +
+                           kraft9[(v >> 36) & 511u] + kraft9[(v >> 45) & 511u] + kraft9[(v >> 54) & 511u];
+    return kraft == 128u;
+}
+
+// canonical Huffman code from lens[0, n): root table + symbols sorted by code + codes per length.  cnt / nxt / off: three arrays
+// of 16 counters, element l at [l * S] (the lanes' columns of LDS arrays).
+template <bool LIT>
+GZB_HD inline void gzb_build(const uint8_t* lens, uint32_t n, uint32_t R, uint32_t* root, uint16_t* sorted, uint16_t* count,
+                             uint32_t* cnt, uint32_t* nxt, uint32_t* off, int S) {
+    for (int l = 0; l < 16; ++l) cnt[l * S] = 0;
+    for (uint32_t s = 0; s < n; ++s) cnt[(uint32_t)lens[s] * S] += 1u;
+    {
+        uint32_t code = 0, prev = 0, o = 0;
+        count[0] = 0;
         for (int l = 1; l <= 15; ++l) {
             code = (code + prev) << 1;
-            prev = cnt[l];
-            if (lane == 0) { next[l] = code; offs[l] = o; count[l] = (uint16_t)prev; }
+            prev = cnt[l * S];
+            nxt[l * S] = code;
+            off[l * S] = o;
+            count[l] = (uint16_t)prev;
             o += prev;
         }
-        if (lane == 0) count[0] = 0;
     }
-    __builtin_amdgcn_wave_barrier();
-    for (int s = 0; s < n; ++s) {
-        const int l = lens[s];
-        if (l == 0) continue;
-        const uint32_t c = next[l], o = offs[l];
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) { sorted[o] = (uint16_t)s; next[l] = c + 1; offs[l] = o + 1; }
+    for (uint32_t i = 0; i < (1u << R); ++i) root[i] = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+        const uint32_t l = lens[s];
+        if (!l) continue;
+        const uint32_t c = nxt[l * S];
+        nxt[l * S] = c + 1;
+        const uint32_t o = off[l * S];
+        off[l * S] = o + 1;
+        sorted[o] = (uint16_t)s;
         if (l <= R) {
-            const uint32_t e = ((uint32_t)s << 4) | (uint32_t)l;
-            const uint32_t r = gzd_rev(c, l);
-            for (uint32_t i = r + ((uint32_t)lane << l); i < (1u << R); i += (uint32_t)WAVE << l) root[i] = e;
+            const uint32_t e = LIT ? gzb_lit_entry(s, l) : gzb_dist_entry(s, l);
+            for (uint32_t i = gzb_rev(c, l); i < (1u << R); i += 1u << l) root[i] = e;
         }
-        __builtin_amdgcn_wave_barrier();
     }
-    return left == 0 ? 0 : 2;
 }
 
-// the code lengths of a dynamic block header at bit p (behind the 3 header bits) into T.lens; returns 0 and sets hlit / hdist /
-// the bit position behind the header, or 1 when the header is not valid
-__device__ inline int gzd_code_lengths(const uint8_t* comp, unsigned long long limit_bit, unsigned long long& p, GzdTables& T, int lane, int& hlit, int& hdist) {
-    const unsigned long long w = gzd_peek(comp, p);
-    hlit = (int)(w & 31u) + 257; hdist = (int)((w >> 5) & 31u) + 1;
-    const int hclen = (int)((w >> 10) & 15u) + 4;
-    p += 14;
-    if (hlit > 286 || hdist > 30) return 1;
-    uint8_t* cl_lens = T.cll;
-    if (lane < 19) cl_lens[lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    if (lane < hclen) cl_lens[GZD_CL_ORDER[lane]] = (uint8_t)(gzd_peek(comp, p + 3ull * (unsigned)lane) & 7u);
-    p += 3ull * (unsigned)hclen;
-    __builtin_amdgcn_wave_barrier();
-    // the code-length code: complete, at most 7 bits -> a flat 128-entry table
-    {
-        uint32_t* const cnt = T.cnt; uint32_t* const next = T.next;
-        if (lane < 16) cnt[lane] = 0;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 19 && cl_lens[lane]) atomicAdd(&cnt[cl_lens[lane]], 1u);
-        __builtin_amdgcn_wave_barrier();
-        int left = 1, used = 0;
-        for (int l = 1; l <= 7; ++l) { const int c = (int)cnt[l]; left = (left << 1) - c; if (left < 0) return 1; used += c; }
-        if (used == 0 || left != 0) return 1;
-        {
-            uint32_t code = 0, prev = 0;
-            for (int l = 1; l <= 7; ++l) { code = (code + prev) << 1; prev = cnt[l]; if (lane == 0) next[l] = code; }
+// a code longer than the root index: canonical search, one bit at a time (w: the stream from the code's first bit on)
+template <bool LIT>
+GZB_HD inline uint32_t gzb_slow(unsigned long long w, const uint16_t* count, const uint16_t* sorted) {
+    uint32_t code = 0, first = 0, index = 0;
+    for (uint32_t len = 1; len <= 15; ++len) {
+        code |= (uint32_t)(w & 1u);
+        w >>= 1;
+        const uint32_t c = count[len];
+        if (code - first < c) {
+            const uint32_t s = sorted[index + (code - first)];
+            return LIT ? gzb_lit_entry(s, len) : gzb_dist_entry(s, len);
         }
-        for (int i = lane; i < 128; i += WAVE) T.cl[i] = 0;
-        __builtin_amdgcn_wave_barrier();
-        for (int s = 0; s < 19; ++s) {
-            const int l = cl_lens[s];
-            if (!l) continue;
-            const uint32_t c = next[l];
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) next[l] = c + 1;
-            const uint32_t r = gzd_rev(c, l);
-            const uint32_t e = ((uint32_t)s << 4) | (uint32_t)l;
-            for (uint32_t i = r + ((uint32_t)lane << l); i < 128u; i += (uint32_t)WAVE << l) T.cl[i] = e;
-            __builtin_amdgcn_wave_barrier();
-        }
+        index += c;
+        first = (first + c) << 1;
+        code <<= 1;
     }
-    const int total = hlit + hdist;
-    int i = 0;
-    uint32_t prev = 0;
-    while (i < total) {
-        if (p > limit_bit) return 1;
-        const unsigned long long v = gzd_peek(comp, p);
-        const uint32_t e = T.cl[v & 127u];
-        const uint32_t l = e & 15u;
-        if (l == 0) return 1;
-        const uint32_t sym = e >> 4;
-        p += l;
-        if (sym < 16) {
-            if (lane == 0) T.lens[i] = (uint8_t)sym;
-            prev = sym;
-            ++i;
-        } else {
-            uint32_t rep, val = 0;
-            const uint32_t x = (uint32_t)(v >> l);
-            if (sym == 16) { if (i == 0) return 1; val = prev; rep = 3 + (x & 3u); p += 2; }
-            else if (sym == 17) { rep = 3 + (x & 7u); p += 3; prev = 0; }
-            else { rep = 11 + (x & 127u); p += 7; prev = 0; }
-            if (i + (int)rep > total) return 1;
-            for (uint32_t k = (uint32_t)lane; k < rep; k += WAVE) T.lens[i + (int)k] = (uint8_t)val;
-            i += (int)rep;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (T.lens[256] == 0) return 1;
     return 0;
 }
 
-// zlib's acceptance rule for a literal/length or distance code: not over-subscribed; incomplete only as a single 1-bit code.
-// (Kraft sum in units of 2^-15 over the lanes.)
-__device__ inline bool gzd_code_ok(const uint8_t* lens, int n, int lane) {
-    uint32_t kraft = 0, mx = 0;
-    for (int s = lane; s < n; s += WAVE) {
-        const uint32_t l = lens[s];
-        if (l) { kraft += 32768u >> l; mx = max(mx, l); }
-    }
-    kraft = gzd_wave_sum(kraft);
-    mx = gzd_wave_max(mx);
-    return kraft == 32768u || (kraft < 32768u && mx <= 1u);
-}
-
-// ---- block starts in the middle of the stream -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void gzd_find_kernel(GzdJob J) {
-    __shared__ GzdTables T;
-    const uint32_t k = blockIdx.x;
-    const int lane = lane_id();
-    if (k == 0) { if (lane == 0) J.sec_start[0] = J.start_bit; return; }
-    const unsigned long long from = (unsigned long long)k * J.section_bytes * 8ull;
-    const unsigned long long total_bits = J.comp_bytes * 8ull;
-    unsigned long long to = from + (unsigned long long)J.section_bytes * 8ull;
-    if (to + 600 > total_bits) to = total_bits > 600 ? total_bits - 600 : 0;
-    unsigned long long found = GZD_NONE;
-    for (unsigned long long base = from; base < to && found == GZD_NONE; base += WAVE) {
-        const unsigned long long p = base + (unsigned)lane;
-        bool cand = false;
-        if (p < to) {
-            const unsigned long long w = gzd_peek(J.comp, p);
-            // BFINAL = 0, BTYPE = 2; HLIT <= 29, HDIST <= 29
-            if ((w & 7u) == 4u && ((w >> 3) & 31u) <= 29u && ((w >> 8) & 31u) <= 29u) {
-                const int hclen = (int)((w >> 13) & 15u) + 4;
-                const unsigned long long v = gzd_peek(J.comp, p + 17);
-                uint32_t kraft = 0;
-                for (int i = 0; i < 19; ++i) {
-                    const uint32_t l = i < hclen ? (uint32_t)((v >> (3 * i)) & 7u) : 0u;
-                    kraft += l ? 128u >> l : 0u;
-                }
-                cand = kraft == 128u;
-            }
-        }
-        unsigned long long m = __ballot(cand);
-        while (m && found == GZD_NONE) {
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            unsigned long long q = base + (unsigned)l + 3;
-            int hlit, hdist;
-            if (gzd_code_lengths(J.comp, total_bits, q, T, lane, hlit, hdist) == 0 && gzd_code_ok(T.lens, hlit, lane) && gzd_code_ok(T.lens + hlit, hdist, lane))
-                found = base + (unsigned)l;
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    if (lane == 0) J.sec_start[k] = found;
-}
-
-// ---- one section -----------------------------------------------------------------------------------------------------------------
-constexpr int GZD_CWIN = 256;              // dwords of the compressed stream staged in LDS at a time (1 KiB)
-
-struct GzdWave {
-    GzdTables T;
-    uint16_t ring[GZD_RING];
-    uint32_t cwin[GZD_CWIN];
+// the pieces of a candidate's table space
+struct GzbTables {
+    uint32_t *lit, *dist;
+    uint16_t *lsorted, *dsorted, *lcount, *dcount;
+    uint8_t* lens;
+    GZB_HD explicit GzbTables(uint32_t* tab)
+        : lit(tab), dist(tab + GZB_T_DIST), lsorted(reinterpret_cast<uint16_t*>(tab + GZB_T_LSORT)), dsorted(reinterpret_cast<uint16_t*>(tab + GZB_T_DSORT)),
+          lcount(reinterpret_cast<uint16_t*>(tab + GZB_T_LCOUNT)), dcount(reinterpret_cast<uint16_t*>(tab + GZB_T_DCOUNT)), lens(reinterpret_cast<uint8_t*>(tab + GZB_T_LENS)) {}
 };
 
-__global__ __launch_bounds__(WAVE) void gzd_decode_kernel(GzdJob J) {
-    __shared__ GzdWave W;
-    const uint32_t k = blockIdx.x;
-    const int lane = lane_id();
-    const unsigned long long start = J.sec_start[k];
-    if (start == GZD_NONE) {
-        if (lane == 0) { J.sec_end[k] = GZD_NONE; J.sec_nsym[k] = 0; J.sec_flags[k] = 0; }
-        return;
-    }
-    const unsigned long long total_bits = J.comp_bytes * 8ull;
-    // (the last section of a batch stops like the others: at the first block boundary at or behind its nominal end — the
-    //  window holds some megabytes beyond it — or at the stream's final block)
-    const unsigned long long stop = (unsigned long long)(k + 1) * J.section_bytes * 8ull;
-    const uint8_t* const comp = J.comp;
-    uint16_t* const out = J.sym + (unsigned long long)k * J.sym_cap;
-    const uint32_t cap = J.sym_cap;
-    unsigned long long p = start;            // bit position (uniform)
-    uint32_t op = 0;                         // symbols produced (uniform)
-#ifdef GZD_PROFILE
-    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    uint32_t flags = 0;
-    // the symbol at section position i (i < op): before the section = a marker, else the ring (distances are <= 32768)
-    auto fetch = [&](long long i) -> uint32_t {
-        if (i < 0) return GZD_MARKER | (uint32_t)(32768 + i);
-        return W.ring[(uint32_t)i & (GZD_RING - 1)];
-    };
-    // `len` symbols from `dist` back to position op, the lanes side by side (positions that the copy itself produces repeat
-    // the pattern of the `dist` symbols before it)
-    auto copy_match = [&](uint32_t len, uint32_t dist) {
-        const long long src0 = (long long)op - (long long)dist;
-        for (uint32_t c0 = 0; c0 < len; c0 += WAVE) {
-            const uint32_t i = c0 + (uint32_t)lane;
-            uint32_t rel = i;
-            if (dist < WAVE && dist <= i) { if (dist == 1) rel = 0; else while (rel >= dist) rel -= dist; }
-            uint32_t val = 0;
-            if (i < len) val = fetch(src0 + (long long)rel);
-            __builtin_amdgcn_wave_barrier();
-            if (i < len) { out[op + i] = (uint16_t)val; W.ring[(op + i) & (GZD_RING - 1)] = (uint16_t)val; }
-            __builtin_amdgcn_wave_barrier();
+// One block's symbols from its first data bit p on, into out[0, cap): returns the flags (0: the end-of-block code was reached),
+// p = the bit behind it, op = symbols written.  A symbol >= 0x8000 is "byte j of the 32 KiB before this block".
+GZB_HD inline uint32_t gzb_decode_block(const uint8_t* comp, uint32_t limit_bit, const GzbTables& T, uint16_t* out, uint32_t cap, uint32_t& p, uint32_t& op) {
+    uint32_t fl = 0;
+    op = 0;
+    for (;;) {
+        if (p + 64u > limit_bit) { fl = GZB_F_ERROR; break; }
+        if (op + 272u > cap) { fl = GZB_F_OVERFLOW; break; }
+        unsigned long long w = gzb_peek(comp, p);
+        uint32_t e = T.lit[(uint32_t)w & ((1u << GZB_LROOT) - 1u)];
+        if ((e & 15u) == 0u) {
+            e = gzb_slow<true>(w, T.lcount, T.lsorted);
+            if (!e) { fl = GZB_F_ERROR; break; }
+        }
+        const uint32_t l = e & 15u;
+        w >>= l;
+        p += l;
+        if (e & 0x100u) { out[op++] = (uint16_t)(e >> 16); continue; }
+        if (e & 0x600u) { if (e & 0x400u) fl = GZB_F_ERROR; break; }           // end of block
+        const uint32_t xb = (e >> 4) & 15u;
+        const uint32_t len = (e >> 16) + ((uint32_t)w & ((1u << xb) - 1u));
+        w >>= xb;
+        uint32_t de = T.dist[(uint32_t)w & ((1u << GZB_DROOT) - 1u)];
+        if ((de & 15u) == 0u) {
+            de = gzb_slow<false>(w, T.dcount, T.dsorted);
+            if (!de) { fl = GZB_F_ERROR; break; }
+        }
+        if (de & 0x400u) { fl = GZB_F_ERROR; break; }
+        const uint32_t dl = de & 15u, dxb = (de >> 4) & 15u;
+        w >>= dl;
+        const uint32_t dd = (de >> 16) + ((uint32_t)w & ((1u << dxb) - 1u));
+        p += xb + dl + dxb;
+        const int src = (int)op - (int)dd;
+        if (src < -32768) { fl = GZB_F_ERROR; break; }
+        uint16_t* const dst = out + op;
+        if (src >= 0 && dd >= 4u) {
+            // four symbols per step (the steps may run up to three symbols over: the next token overwrites them)
+            const uint16_t* const s = out + src;
+            for (uint32_t i = 0; i < len; i += 4) {
+                unsigned long long v;
+                memcpy(&v, s + i, 8);
+                memcpy(dst + i, &v, 8);
+            }
+        } else if (dd <= 3u) {
+            // distance 1 .. 3 (runs: the quality strings): the period-dd pattern, twelve symbols of it, four per step
+            uint32_t a[3];
+            for (int k = 0; k < 3; ++k) {
+                const int q = src + (int)((uint32_t)k % dd);
+                a[k] = q >= 0 ? (uint32_t)out[q] : (GZB_MARKER | (uint32_t)(32768 + q));
+            }
+            // pattern position j holds symbol j % dd of the source = a[j % dd] (dd = 1: a[0] = a[1] = a[2])
+            unsigned long long q3[3];
+            for (int g = 0; g < 3; ++g) {
+                unsigned long long v = 0;
+                for (int j = 0; j < 4; ++j) {
+                    const int pos = 4 * g + j;
+                    v |= (unsigned long long)(dd == 2u ? a[pos & 1] : a[pos % 3]) << (16 * j);
+                }
+                q3[g] = v;
+            }
+            uint32_t ph = 0;
+            for (uint32_t i = 0; i < len; i += 4) {
+                const unsigned long long v = ph == 0u ? q3[0] : ph == 1u ? q3[1] : q3[2];
+                memcpy(dst + i, &v, 8);
+                ph = ph == 2u ? 0u : ph + 1u;
+            }
+        } else {
+            // the source begins before the block: markers for that part
+            for (uint32_t i = 0; i < len; ++i) {
+                const int q = src + (int)i;
+                dst[i] = q >= 0 ? out[q] : (uint16_t)(GZB_MARKER | (uint32_t)(32768 + q));
+            }
         }
         op += len;
-    };
-    bool done = false;
-    uint32_t guard_blocks = 0;
-    while (!done) {
-        if (p >= stop) break;                                   // a block boundary at or behind the next section's start
-        if (p + 3 > total_bits || ++guard_blocks > (1u << 20)) { flags |= GZD_ERROR; break; }
-        const unsigned long long hw = gzd_peek(comp, p);
-        const uint32_t bfinal = (uint32_t)(hw & 1u), btype = (uint32_t)((hw >> 1) & 3u);
-        p += 3;
-        if (btype == 3) { flags |= GZD_ERROR; break; }
-        if (btype == 0) {
-            // stored: to the byte boundary, LEN, ~LEN, bytes
-            p = (p + 7) & ~7ull;
-            const unsigned long long v = gzd_peek(comp, p);
-            const uint32_t len = (uint32_t)(v & 0xffffu), nlen = (uint32_t)((v >> 16) & 0xffffu);
-            p += 32;
-            if (len != (~nlen & 0xffffu) || p + 8ull * len > total_bits) { flags |= GZD_ERROR; break; }
-            if (op + len + 64 > cap) { flags |= GZD_OVERFLOW; break; }
-            const uint8_t* src = comp + (p >> 3);
-            for (uint32_t i = (uint32_t)lane; i < len; i += WAVE) {
-                const uint16_t b = src[i];
-                out[op + i] = b;
-                W.ring[(op + i) & (GZD_RING - 1)] = b;
-            }
-            __builtin_amdgcn_wave_barrier();
-            op += len;
-            p += 8ull * len;
-        } else {
-            int hlit = 288, hdist = 30;
-            if (btype == 1) {
-                for (int i = lane; i < 288; i += WAVE) W.T.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
-                for (int i = lane; i < 30; i += WAVE) W.T.lens[288 + i] = 5;
-                if (lane < 2) W.T.lens[288 + 30 + lane] = 5;
-                hdist = 32;
-                __builtin_amdgcn_wave_barrier();
-            } else if (gzd_code_lengths(comp, total_bits, p, W.T, lane, hlit, hdist) != 0) { flags |= GZD_ERROR; break; }
-            int lmax, dmax;
-            const int rl = gzd_build(W.T, W.T.lens, hlit, GZD_LROOT, W.T.lit, W.T.lsorted, W.T.lcount, lane, &lmax);
-            // (the distance lengths sit behind the literal/length ones)
-            const int rd = gzd_build(W.T, W.T.lens + hlit, hdist, GZD_DROOT, W.T.dist, W.T.dsorted, W.T.dcount, lane, &dmax);
-            if (rl == 1 || rd == 1 || (rl == 2 && lmax != 1) || (rd == 2 && dmax > 1)) { flags |= GZD_ERROR; break; }
-            // ---- symbols, a ROUND at a time: lane i decodes the token that would start at bit p + i (literal, end of block, or
-            //      length + distance with their extra bits: <= 48 bits), a scalar walk from lane 0 follows the tokens' lengths
-            //      and marks the ones that are real (10 - 25 per round of 64 bit positions), a lane scan places their output.
-            //      Literals are stored by their lanes; matches are applied in order, the lanes sharing each copy.  A token whose
-            //      code is longer than the root index ends the round and is decoded on its own (canonical search).
-            const uint32_t* const comp32 = reinterpret_cast<const uint32_t*>(comp);
-            const uint32_t total_dwords = (uint32_t)((J.comp_bytes + 64) >> 2);
-            uint32_t cbase = (uint32_t)(p >> 5);
-            auto load_window = [&]() {
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < GZD_CWIN / WAVE; ++r) {
-                    const uint32_t i = cbase + (uint32_t)(r * WAVE + lane);
-                    W.cwin[r * WAVE + lane] = i < total_dwords ? comp32[i] : 0u;
-                }
-                __builtin_amdgcn_wave_barrier();
-            };
-            load_window();
-            bool eob = false;
-            uint32_t guard = 0;
-#ifdef GZD_PROFILE
-#define GZD_T(k_) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[k_] += n_ - tlast; tlast = n_; } while (0)
-            unsigned long long tlast = __builtin_amdgcn_s_memtime();
-#else
-#define GZD_T(k_)
-#endif
-            while (!eob) {
-                if ((p >> 5) > total_dwords || ++guard > (1u << 24)) { flags |= GZD_ERROR; break; }
-                if (op + 64u * 258u + 64u > cap) { flags |= GZD_OVERFLOW; break; }
-                // the window must hold the dwords of bits [p, p + 64 + 64)
-                if ((uint32_t)(p >> 5) - cbase + 6u > (uint32_t)GZD_CWIN) { cbase = (uint32_t)(p >> 5); load_window(); }
-                unsigned long long w;
-                {
-                    const unsigned long long q = p + (unsigned)lane;
-                    const uint32_t di = (uint32_t)(q >> 5) - cbase, sh = (uint32_t)q & 31u;
-                    const unsigned long long lo = ((unsigned long long)W.cwin[di + 1] << 32) | W.cwin[di];
-                    const uint32_t hi = W.cwin[di + 2];
-                    w = sh ? (lo >> sh) | ((unsigned long long)hi << (64u - sh)) : lo;
-                }
-                const uint32_t e = W.T.lit[(uint32_t)w & ((1u << GZD_LROOT) - 1u)];
-                const uint32_t l = e & 15u, sym = e >> 4;
-                uint32_t tb = l, kind = 0, tlen = 1, tdist = 0;          // bits of the token; 0 literal, 1 end of block, 2 match, 3 not decodable here
-                if (l == 0) kind = 3;
-                else if (sym == 256) kind = 1;
-                else if (sym > 256) {
-                    if (sym > 285) kind = 3;
-                    else {
-                        const uint32_t ls = sym - 257;
-                        const uint32_t lxe = ls < 8 || ls == 28 ? 0u : (ls - 4) >> 2;
-                        const uint32_t lbase = ls < 8 ? 3u + ls : ls == 28 ? 258u : 3u + ((4u + (ls & 3u)) << lxe);
-                        tlen = lbase + (uint32_t)((w >> l) & ((1u << lxe) - 1u));
-                        const uint32_t o = l + lxe;
-                        const uint32_t de = W.T.dist[(uint32_t)(w >> o) & ((1u << GZD_DROOT) - 1u)];
-                        const uint32_t dl = de & 15u, dsym = de >> 4;
-                        if (dl == 0 || dsym > 29) kind = 3;
-                        else {
-                            const uint32_t dxe = dsym < 4 ? 0u : (dsym >> 1) - 1u;
-                            const uint32_t dbase = dsym < 4 ? dsym + 1u : 1u + ((2u + (dsym & 1u)) << dxe);
-                            tdist = dbase + (uint32_t)((w >> (o + dl)) & ((1u << dxe) - 1u));
-                            tb = o + dl + dxe;
-                            kind = 2;
-                        }
-                    }
-                }
-                GZD_T(0);
-                // ---- the walk: which lanes start a real token
-                const uint32_t packed = tb | (kind << 8);
-                unsigned long long tok = 0;
-                uint32_t cur = 0;
-                bool slow = false;
-                while (cur < (uint32_t)WAVE) {
-                    const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)cur);
-                    const uint32_t k2 = pk >> 8;
-                    if (k2 == 3) { slow = true; break; }
-                    tok |= 1ull << cur;
-                    cur += pk & 0xffu;
-                    if (k2 == 1) { eob = true; break; }
-                }
-                GZD_T(1);
-                // ---- output positions: exclusive scan of the real tokens' output lengths
-                const bool mine = (tok >> lane) & 1ull;
-                const uint32_t olen = mine ? (kind == 0 ? 1u : kind == 2 ? tlen : 0u) : 0u;
-                uint32_t inc = olen;
-#pragma unroll
-                for (int d = 1; d < WAVE; d <<= 1) {
-                    const uint32_t o2 = (uint32_t)__shfl_up((int)inc, d, WAVE);
-                    if (lane >= d) inc += o2;
-                }
-                const uint32_t total_out = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
-                const uint32_t my_pos = op + inc - olen;
-                GZD_T(2);
-                // matches that reach before the window are errors
-                const unsigned long long mm_all = __ballot(mine && kind == 2);
-                if (__ballot(mine && kind == 2 && (long long)my_pos - (long long)tdist < -32768)) { flags |= GZD_ERROR; break; }
-                if (mm_all == 0) {
-                    // literals only: all at once
-                    if (mine && kind == 0) { out[my_pos] = (uint16_t)sym; W.ring[my_pos & (GZD_RING - 1)] = (uint16_t)sym; }
-                    op += total_out;
-                } else {
-                    if (mine && kind == 0) { out[my_pos] = (uint16_t)sym; W.ring[my_pos & (GZD_RING - 1)] = (uint16_t)sym; }
-                    __builtin_amdgcn_wave_barrier();
-                    unsigned long long mm = mm_all;
-                    const uint32_t op0 = op;
-                    while (mm) {
-                        const int ml = __ffsll((long long)mm) - 1;
-                        mm &= mm - 1;
-                        const uint32_t mlen = (uint32_t)__builtin_amdgcn_readlane((int)tlen, ml);
-                        const uint32_t mdist = (uint32_t)__builtin_amdgcn_readlane((int)tdist, ml);
-                        op = (uint32_t)__builtin_amdgcn_readlane((int)my_pos, ml);
-                        copy_match(mlen, mdist);
-                    }
-                    op = op0 + total_out;
-                }
-                p += cur;
-                GZD_T(3);
-#ifdef GZD_PROFILE
-                prof[5] += 1; prof[6] += (unsigned long long)__popcll(tok); prof[7] += (unsigned long long)__popcll(mm_all);
-#endif
-                if (slow) {
-                    // one token with a code longer than the root index, decoded on its own
-                    const unsigned long long v0 = gzd_peek(comp, p);
-                    unsigned long long v = v0;
-                    uint32_t e2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.T.lit[(uint32_t)v & ((1u << GZD_LROOT) - 1u)]);
-                    uint32_t l2 = e2 & 15u, sym2 = e2 >> 4;
-                    if (l2 == 0) {
-                        uint32_t code = gzd_rev((uint32_t)v & ((1u << GZD_LROOT) - 1u), GZD_LROOT), first = 0, index = 0;
-                        for (int q = 1; q <= GZD_LROOT; ++q) { const uint32_t c = W.T.lcount[q]; first = (first + c) << 1; index += c; }
-                        bool ok = false;
-                        for (int q = GZD_LROOT + 1; q <= 15; ++q) {
-                            code = (code << 1) | (uint32_t)((v >> (q - 1)) & 1u);
-                            const uint32_t c = W.T.lcount[q];
-                            if (code - first < c) { sym2 = W.T.lsorted[index + (code - first)]; l2 = (uint32_t)q; ok = true; break; }
-                            index += c;
-                            first = (first + c) << 1;
-                        }
-                        if (!ok) { flags |= GZD_ERROR; break; }
-                        sym2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym2);
-                    }
-                    p += l2;
-                    v >>= l2;
-                    if (sym2 < 256) {
-                        if (lane == 0) { out[op] = (uint16_t)sym2; W.ring[op & (GZD_RING - 1)] = (uint16_t)sym2; }
-                        ++op;
-                    } else if (sym2 == 256) eob = true;
-                    else if (sym2 > 285) { flags |= GZD_ERROR; break; }
-                    else {
-                        const uint32_t ls = sym2 - 257;
-                        const uint32_t lx = GZD_LEN_EXTRA[ls];
-                        const uint32_t len = GZD_LEN_BASE[ls] + (uint32_t)(v & ((1u << lx) - 1u));
-                        p += lx;
-                        v = gzd_peek(comp, p);
-                        uint32_t de = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.T.dist[(uint32_t)v & ((1u << GZD_DROOT) - 1u)]);
-                        uint32_t dl = de & 15u, dsym = de >> 4;
-                        if (dl == 0) {
-                            uint32_t code = gzd_rev((uint32_t)v & ((1u << GZD_DROOT) - 1u), GZD_DROOT), first = 0, index = 0;
-                            for (int q = 1; q <= GZD_DROOT; ++q) { const uint32_t c = W.T.dcount[q]; first = (first + c) << 1; index += c; }
-                            bool ok = false;
-                            for (int q = GZD_DROOT + 1; q <= 15; ++q) {
-                                code = (code << 1) | (uint32_t)((v >> (q - 1)) & 1u);
-                                const uint32_t c = W.T.dcount[q];
-                                if (code - first < c) { dsym = W.T.dsorted[index + (code - first)]; dl = (uint32_t)q; ok = true; break; }
-                                index += c;
-                                first = (first + c) << 1;
-                            }
-                            if (!ok) { flags |= GZD_ERROR; break; }
-                            dsym = (uint32_t)__builtin_amdgcn_readfirstlane((int)dsym);
-                        }
-                        if (dsym > 29) { flags |= GZD_ERROR; break; }
-                        p += dl;
-                        v >>= dl;
-                        const uint32_t dx = GZD_DIST_EXTRA[dsym];
-                        const uint32_t dist = GZD_DIST_BASE[dsym] + (uint32_t)(v & ((1u << dx) - 1u));
-                        p += dx;
-                        if ((long long)op - (long long)dist < -32768) { flags |= GZD_ERROR; break; }
-                        __builtin_amdgcn_wave_barrier();
-                        copy_match(len, dist);
-                    }
-                }
-            }
-            if (flags) break;
-        }
-        if (bfinal) { flags |= GZD_FINAL; done = true; }
     }
-    if (lane == 0) { J.sec_end[k] = p; J.sec_nsym[k] = op; J.sec_flags[k] = flags; }
-#ifdef GZD_PROFILE
-    if (lane == 0 && k == 1)
-        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(J.result + 8)[i] = prof[i];
-#endif
+    return fl;
 }
 
-// ---- commit in order + the last 32 KiB of every section -------------------------------------------------------------------------
-constexpr int GZD_CHAIN_THREADS = 1024;
+// symbol space of candidate c of n: ratio_cap x the compressed bytes up to the next candidate (the last one: to the window's end)
+GZB_HD inline uint32_t gzb_symcap_of(const GzbJob& J, uint32_t c, uint32_t n) {
+    const uint32_t nxt = c + 1 < n ? J.c_start[c + 1] : J.comp_bytes * 8u;
+    const uint32_t span = gzb_min((nxt - J.c_start[c] + 7u) >> 3, 2u << 20);        // (a block of more than 2 MiB: overflow, host)
+    return ((span * J.ratio_cap + 4096u) + 7u) & ~7u;
+}
 
-__global__ __launch_bounds__(GZD_CHAIN_THREADS) void gzd_chain_kernel(GzdJob J) {
-    __shared__ uint32_t bad;
-    if (threadIdx.x == 0) bad = 0;
+GZB_HD inline uint32_t gzb_lower_bound(const uint32_t* a, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// the usable candidate that starts exactly at bit x (GZB_NONE: none)
+GZB_HD inline uint32_t gzb_cand_at(const GzbJob& J, uint32_t n, uint32_t x) {
+    const uint32_t i = gzb_lower_bound(J.c_start, n, x);
+    return (i < n && J.c_start[i] == x && J.c_flags[i] == 0u) ? i : GZB_NONE;
+}
+// a non-final stored block at bit e: returns true and its data byte / length / the bit behind it
+GZB_HD inline bool gzb_stored_at(const GzbJob& J, uint32_t e, uint32_t& byte, uint32_t& len, uint32_t& next) {
+    const uint32_t limit = J.comp_bytes * 8u;
+    if (e + 3u + 7u + 32u + 64u > limit) return false;
+    const uint32_t h = (uint32_t)(gzb_peek(J.comp, e) & 7u);
+    if (h != 0u) return false;                              // BFINAL = 0, BTYPE = 0
+    const uint32_t q = (e + 3u + 7u) & ~7u;
+    const uint32_t v = (uint32_t)gzb_peek(J.comp, q);
+    len = v & 0xffffu;
+    if (len != (~(v >> 16) & 0xffffu)) return false;
+    byte = (q >> 3) + 4u;
+    if ((unsigned long long)byte + len > J.comp_bytes) return false;
+    next = q + 32u + 8u * len;
+    return true;
+}
+
+// section k: which blocks, in which order
+GZB_HD inline void gzb_chain_section(const GzbJob& J, uint32_t k) {
+    const uint32_t n = J.n_cand[0];
+    const uint32_t nom = J.s_nominal[k], stop = J.s_stop[k];
+    const bool exact = J.s_exact[k] != 0u;
+    // the first usable candidate at or behind the nominal start; one whose end is itself a block start (or reaches the stop
+    // bit) is preferred over one that merely parses: that is what a false hit practically never does
+    uint32_t pick = GZB_NONE, fallback = GZB_NONE;
+    {
+        uint32_t i = gzb_lower_bound(J.c_start, n, nom);
+        for (uint32_t tries = 0; i < n && tries < 64u; ++i, ++tries) {
+            const uint32_t st = J.c_start[i];
+            if (exact && st != nom) break;
+            if (st >= stop) break;
+            if (J.c_flags[i] == 0u) {
+                const uint32_t e = J.c_end[i];
+                uint32_t b, l, nx;
+                if (e >= stop || gzb_cand_at(J, n, e) != GZB_NONE || gzb_stored_at(J, e, b, l, nx)) { pick = i; break; }
+                if (fallback == GZB_NONE) fallback = i;
+            }
+            if (exact) break;
+        }
+        if (pick == GZB_NONE) pick = fallback;
+    }
+    uint32_t nb = 0, off = 0, end = 0, start = GZB_NONE;
+    if (pick != GZB_NONE) {
+        start = J.c_start[pick];
+        uint32_t* const blocks = J.s_blocks + (size_t)k * GZB_SEC_BLOCKS * 3u;
+        uint32_t cur = pick;
+        end = start;
+        for (;;) {
+            if (cur != GZB_NONE) {
+                const uint32_t ns = J.c_nsym[cur];
+                if (nb >= (uint32_t)GZB_SEC_BLOCKS || off + ns > J.s_symcap) break;
+                blocks[3u * nb] = cur; blocks[3u * nb + 1] = 0; blocks[3u * nb + 2] = off;
+                ++nb;
+                off += ns;
+                end = J.c_end[cur];
+            }
+            if (end >= stop) break;
+            cur = gzb_cand_at(J, n, end);
+            if (cur == GZB_NONE) {
+                uint32_t b, l, nx;
+                if (!gzb_stored_at(J, end, b, l, nx)) break;
+                if (nb >= (uint32_t)GZB_SEC_BLOCKS || off + l > J.s_symcap) break;
+                blocks[3u * nb] = GZB_STORED | l; blocks[3u * nb + 1] = b; blocks[3u * nb + 2] = off;
+                ++nb;
+                off += l;
+                end = nx;
+            }
+        }
+        if (nb == 0) start = GZB_NONE;
+    }
+    J.s_start[k] = start;
+    J.s_end[k] = end;
+    J.s_nsym[k] = off;
+    J.s_nblk[k] = nb;
+}
+
+// symbol x of a block that begins `off` symbols into its section, for the section's stream dst: a marker j stands for section
+// position off - 32768 + j — in an earlier block (already in dst), or still before the section
+GZB_HD inline uint16_t gzb_rebase(uint32_t x, uint32_t off, const uint16_t* dst) {
+    if (x & GZB_MARKER) {
+        const int q = (int)off - 32768 + (int)(x & 0x7fffu);
+        x = q >= 0 ? (uint32_t)dst[q] : (GZB_MARKER | (uint32_t)(q + 32768));
+    }
+    return (uint16_t)x;
+}
+
+#if defined(__HIPCC__)
+// ---- every block start of the batch -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GZB_SCAN_THREADS) void gzb_scan_kernel(GzbJob J) {
+    __shared__ uint8_t s_kraft[512];
+    __shared__ uint8_t s_cl[128 * GZB_SCAN_THREADS];
+    __shared__ uint32_t s_found[GZB_TILE_CAND];
+    __shared__ uint32_t s_n;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 512; i += GZB_SCAN_THREADS) s_kraft[i] = (uint8_t)gzb_kraft9((uint32_t)i);
+    if (tid == 0) s_n = 0;
     __syncthreads();
-    unsigned long long off = 0, expect = J.start_bit;
-    uint32_t accepted = 0, final_seen = 0;
-    for (uint32_t k = 0; k < J.n_sections; ++k) {
-        const unsigned long long st = J.sec_start[k];
-        const uint32_t fl = J.sec_flags[k];
-        // a section without a start inside a long block is simply skipped: its predecessor ran through it
-        if (st == GZD_NONE && k > 0) {
-            if (expect >= (unsigned long long)(k + 1) * J.section_bytes * 8ull) { if (threadIdx.x == 0) J.sec_off[k] = off; ++accepted; continue; }
-            break;
-        }
-        if (st != expect || (fl & (GZD_ERROR | GZD_OVERFLOW))) break;
-        const uint32_t n = J.sec_nsym[k];
-        if (threadIdx.x == 0) J.sec_off[k] = off;
-        const uint32_t tail = n < 32768u ? n : 32768u;
-        const uint16_t* s = J.sym + (unsigned long long)k * J.sym_cap + (n - tail);
-        uint8_t* d = J.text + off + (n - tail);
-        const uint8_t* win = J.text + off - 32768;             // the 32 KiB before this section
-        const uint32_t valid_from = k == 0 ? J.window_valid_from : 0u;   // (later sections: the member started before them)
-        // (32 symbols per thread: all loads first, so that one memory latency covers them, then the few marker look-ups)
-        uint32_t v[32];
+    const uint32_t byte0 = J.scan_byte0 + blockIdx.x * (uint32_t)GZB_SCAN_TILE + (uint32_t)tid * 16u;
+    const uint32_t limit_bit = J.comp_bytes * 8u;
+    uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (byte0 < J.comp_bytes) {                             // (the buffer is padded: 32 bytes are readable from any byte of the data)
+        const uint4 a = *reinterpret_cast<const uint4*>(J.comp + byte0), b = *reinterpret_cast<const uint4*>(J.comp + byte0 + 16);
+        d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+    }
+    uint32_t m[4], k2[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const uint32_t i = threadIdx.x + (uint32_t)r * GZD_CHAIN_THREADS;
-            v[r] = i < tail ? (uint32_t)s[i] : 0u;
+    for (int i = 0; i < 4; ++i) {
+        uint32_t mm = gzb_quick32(((unsigned long long)d[i + 1] << 32) | d[i]);
+        // keep [first_bit, last_bit)
+        const uint32_t b0 = (byte0 + 4u * (uint32_t)i) * 8u;
+        if (b0 + 32u <= J.first_bit || b0 >= J.last_bit || byte0 >= J.comp_bytes) mm = 0;
+        else {
+            if (b0 < J.first_bit) mm &= ~0u << (J.first_bit - b0);
+            if (b0 + 32u > J.last_bit) mm &= (1u << (J.last_bit - b0)) - 1u;
         }
+        m[i] = mm;
+    }
+    // (a lane pops its own survivors: every iteration of these loops does useful work on most lanes)
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const uint32_t i = threadIdx.x + (uint32_t)r * GZD_CHAIN_THREADS;
-            if (i < tail) {
-                uint8_t b;
-                if (v[r] < GZD_MARKER) b = (uint8_t)v[r];
-                else {
-                    const uint32_t j = v[r] & 0x7fffu;
-                    if (j < valid_from) bad = 1;
-                    b = win[j];
-                }
-                d[i] = b;
+    for (int i = 0; i < 4; ++i) {
+        const unsigned long long v64 = ((unsigned long long)d[i + 1] << 32) | d[i];
+        uint32_t mm = m[i];
+        while (mm) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(mm);
+            mm &= mm - 1;
+            const uint32_t p = (byte0 + 4u * (uint32_t)i) * 8u + bit;
+            const uint32_t hclen = ((uint32_t)(v64 >> (bit + 13u)) & 15u) + 4u;
+            if (gzb_kraft_ok(J.comp, p, hclen, s_kraft)) k2[i] |= 1u << bit;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t mm = k2[i];
+        while (mm) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(mm);
+            mm &= mm - 1;
+            const uint32_t p = (byte0 + 4u * (uint32_t)i) * 8u + bit;
+            uint32_t data_bit, hlit, hdist;
+            if (gzb_header(J.comp, limit_bit, p, s_cl + tid, GZB_SCAN_THREADS, nullptr, data_bit, hlit, hdist)) {
+                const uint32_t at = atomicAdd(&s_n, 1u);
+                if (at < (uint32_t)GZB_TILE_CAND) s_found[at] = p;
             }
         }
-        __threadfence();
-        __syncthreads();
-        off += n;
-        expect = J.sec_end[k];
-        ++accepted;
-        if (fl & GZD_FINAL) { final_seen = 1; break; }
     }
-    if (threadIdx.x == 0) {
-        J.sec_off[J.n_sections] = off;
-        J.result[0] = accepted;
-        J.result[1] = bad;
-        J.result[2] = final_seen;
-        J.result[4] = (uint32_t)expect; J.result[5] = (uint32_t)(expect >> 32);
-        J.result[6] = (uint32_t)off; J.result[7] = (uint32_t)(off >> 32);
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t n = gzb_min(s_n, (uint32_t)GZB_TILE_CAND);
+        for (uint32_t a = 1; a < n; ++a) {                  // (a handful at most: insertion sort)
+            const uint32_t x = s_found[a];
+            uint32_t b = a;
+            while (b > 0 && s_found[b - 1] > x) { s_found[b] = s_found[b - 1]; --b; }
+            s_found[b] = x;
+        }
+        J.tile_cnt[blockIdx.x] = n;
+        for (uint32_t a = 0; a < n; ++a) J.tile_cand[blockIdx.x * (uint32_t)GZB_TILE_CAND + a] = s_found[a];
     }
 }
 
-// the rest of every accepted section (all but its last 32 KiB), in parallel
-__global__ __launch_bounds__(256) void gzd_resolve_kernel(GzdJob J) {
-    const uint32_t k = blockIdx.y;
-    if (k >= J.result[0]) return;
-    if (J.sec_start[k] == GZD_NONE) return;
-    const uint32_t n = J.sec_nsym[k];
-    const uint32_t body = n > 32768u ? n - 32768u : 0u;
-    const unsigned long long off = J.sec_off[k];
-    const uint16_t* s = J.sym + (unsigned long long)k * J.sym_cap;
-    uint8_t* d = J.text + off;
-    const uint8_t* win = J.text + off - 32768;
-    const uint32_t valid_from = k == 0 ? J.window_valid_from : 0u;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < body; i += gridDim.x * 256u) {
-        const uint32_t v = s[i];
-        uint8_t b;
-        if (v < GZD_MARKER) b = (uint8_t)v;
-        else {
-            const uint32_t j = v & 0x7fffu;
-            if (j < valid_from) J.result[1] = 1;
-            b = win[j];
+// ---- one sorted candidate list + each candidate's symbol space -------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void gzb_compact_kernel(GzbJob J) {
+    __shared__ uint32_t s_part[1024];
+    __shared__ unsigned long long s_part64[1024];
+    __shared__ uint32_t s_total;
+    const uint32_t tid = threadIdx.x;
+    // (1) tile counts -> offsets (a thread owns a contiguous run of tiles)
+    const uint32_t per = (J.n_tiles + 1023u) / 1024u;
+    const uint32_t t0 = gzb_min(J.n_tiles, tid * per), t1 = gzb_min(J.n_tiles, t0 + per);
+    uint32_t mine = 0;
+    for (uint32_t t = t0; t < t1; ++t) mine += J.tile_cnt[t];
+    s_part[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 1024; ++i) { const uint32_t c = s_part[i]; s_part[i] = run; run += c; }
+        s_total = gzb_min(run, J.cand_cap);
+        J.n_cand[0] = s_total;
+        J.n_cand[1] = 0;
+    }
+    __syncthreads();
+    {
+        uint32_t o = s_part[tid];
+        for (uint32_t t = t0; t < t1; ++t) {
+            const uint32_t c = J.tile_cnt[t];
+            for (uint32_t a = 0; a < c; ++a, ++o)
+                if (o < J.cand_cap) J.c_start[o] = J.tile_cand[t * (uint32_t)GZB_TILE_CAND + a];
         }
-        d[i] = b;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // (2) symbol space
+    const uint32_t n = s_total;
+    const uint32_t per2 = (n + 1023u) / 1024u;
+    const uint32_t c0 = gzb_min(n, tid * per2), c1 = gzb_min(n, c0 + per2);
+    unsigned long long sum = 0;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t cap = gzb_symcap_of(J, c, n);
+        J.c_symcap[c] = cap;
+        sum += cap;
+    }
+    s_part64[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; ++i) { const unsigned long long c = s_part64[i]; s_part64[i] = run; run += c; }
+        if (run > J.blk_sym_cap) J.n_cand[1] = 1;
+    }
+    __syncthreads();
+    unsigned long long o = s_part64[tid];
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint32_t cap = J.c_symcap[c];
+        J.c_symoff[c] = o;
+        // candidates that do not fit the symbol buffer are not decoded (their sections fall back to the host)
+        if (o + cap > J.blk_sym_cap) J.c_symcap[c] = 0;
+        o += cap;
     }
 }
+
+// ---- a lane per block --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
+    __shared__ uint8_t s_cl[128 * GZB_DEC_THREADS];
+    __shared__ uint32_t s_cnt[16 * GZB_DEC_THREADS], s_nxt[16 * GZB_DEC_THREADS], s_off[16 * GZB_DEC_THREADS];
+    const int tid = threadIdx.x;
+    const uint32_t c = blockIdx.x * (uint32_t)GZB_DEC_THREADS + (uint32_t)tid;
+    if (c >= J.n_cand[0]) return;
+    const uint32_t limit_bit = J.comp_bytes * 8u;
+    const uint32_t cap = J.c_symcap[c];
+    const GzbTables T(J.tables + (size_t)c * GZB_TAB_WORDS);
+    uint32_t p = 0, hlit = 0, hdist = 0, op = 0, fl = 0;
+    if (cap == 0) fl = GZB_F_SKIP;
+    else if (!gzb_header(J.comp, limit_bit, J.c_start[c], s_cl + tid, GZB_DEC_THREADS, T.lens, p, hlit, hdist)) fl = GZB_F_ERROR;
+    if (!fl) {
+        gzb_build<true>(T.lens, hlit, GZB_LROOT, T.lit, T.lsorted, T.lcount, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
+        gzb_build<false>(T.lens + hlit, hdist, GZB_DROOT, T.dist, T.dsorted, T.dcount, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
+        fl = gzb_decode_block(J.comp, limit_bit, T, J.blk_sym + J.c_symoff[c], cap, p, op);
+    }
+    J.c_end[c] = p;
+    J.c_nsym[c] = op;
+    J.c_flags[c] = fl;
+}
+
+// ---- a lane per section --------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gzb_chain_kernel(GzbJob J) {
+    const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+    if (k < J.n_sec) gzb_chain_section(J, k);
+}
+
+// ---- a workgroup per section: the blocks' symbols as one stream, markers relative to the section ---------------------------------
+__global__ __launch_bounds__(GZB_GATHER_THREADS) void gzb_gather_kernel(GzbJob J) {
+    const uint32_t k = blockIdx.x;
+    const uint32_t nb = J.s_nblk[k];
+    uint16_t* const dst = J.s_sym + (size_t)k * J.s_symcap;
+    const uint32_t* const blocks = J.s_blocks + (size_t)k * GZB_SEC_BLOCKS * 3u;
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint32_t w0 = blocks[3u * b], w1 = blocks[3u * b + 1], off = blocks[3u * b + 2];
+        if (w0 & GZB_STORED) {
+            const uint32_t len = w0 & 0xffffu;
+            const uint8_t* const s = J.comp + w1;
+            for (uint32_t i = threadIdx.x; i < len; i += GZB_GATHER_THREADS) dst[off + i] = s[i];
+        } else {
+            const uint32_t n = J.c_nsym[w0];
+            const uint16_t* const s = J.blk_sym + J.c_symoff[w0];
+            for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 4u * GZB_GATHER_THREADS) {
+                uint32_t v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const uint32_t i = i0 + (uint32_t)r * GZB_GATHER_THREADS; v[r] = i < n ? (uint32_t)s[i] : 0u; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t i = i0 + (uint32_t)r * GZB_GATHER_THREADS;
+                    if (i < n) dst[off + i] = gzb_rebase(v[r], off, dst);
+                }
+            }
+        }
+        // (the next block's markers may point into this one)
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+#endif  // __HIPCC__
 
 }  // namespace aqc

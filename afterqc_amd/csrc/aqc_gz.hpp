@@ -13,6 +13,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -87,16 +88,47 @@ void inflate_raw2(const uint8_t* const src[2], const size_t n[2], uint8_t* const
 uint32_t crc32_fast(uint32_t crc, const uint8_t* p, size_t n);
 uint32_t crc32_combine_fast(uint32_t crc1, uint32_t crc2, uint64_t len2);
 
+// Sections decoded somewhere else than on the pool: the GPU (aqc_capi.hip: DeviceInflate, kernels in aqc_gunzip_dev.hpp).  A
+// GROUP of consecutive sections is handed over at once; each comes back as what a pool thread would have produced — the block
+// boundary it starts at, the one it ends at, its symbols — or as "nothing found".  The consumer's commit rule does not care who
+// decoded a section, so exactness does not depend on the device being right, only speed does.
+struct OffloadResult {
+    bool found = false;
+    uint64_t start_bit = 0, end_bit = 0;
+    const uint16_t* sym = nullptr;      // n_sym symbols, markers relative to the section's start; valid until release(token)
+    size_t n_sym = 0;
+    void* token = nullptr;
+};
+class SectionOffload {
+public:
+    virtual ~SectionOffload() {}
+    virtual size_t group_bytes() const = 0;          // compressed bytes it likes to take per group
+    virtual bool ready() = 0;                        // would submit() be accepted right now?  (never blocks)
+    // n consecutive sections of data[0, size): search from nominal[k] (exact[k]: the section must start AT it), stop at the first
+    // block boundary at or behind stop[k].  done(k, result) is called exactly once per section, from another thread.
+    virtual bool submit(const uint8_t* data, size_t size, int n, const uint64_t* nominal, const uint64_t* stop, const uint8_t* exact,
+                        std::function<void(int, const OffloadResult&)> done) = 0;
+    virtual void release(void* token) = 0;           // the symbols of one result are no longer needed
+};
+// the device decoder of GPU `device` (aqc_capi.hip); nullptr when it cannot be set up
+SectionOffload* make_device_offload(int device, size_t group_bytes);
+// kernel / copy microseconds of every device decoder of the process so far: scan, decode, chain + gather, H2D, D2H, groups, sections given, sections found
+void device_offload_stats(uint64_t out[8]);
+
 class ParallelGunzip {
 public:
-    // data: the whole compressed file (mapped); sections of `section_bytes` compressed bytes, at most `inflight` at a time
-    ParallelGunzip(const uint8_t* data, size_t size, aqc_host::Pool* pool, int inflight, size_t section_bytes);
+    // data: the whole compressed file (mapped); sections of `section_bytes` compressed bytes, at most `inflight` of them on the
+    // pool at a time.  offload: groups of sections go there whenever it is ready (offload_only: the pool only takes what cannot
+    // be grouped: the stream's last section).
+    ParallelGunzip(const uint8_t* data, size_t size, aqc_host::Pool* pool, int inflight, size_t section_bytes, SectionOffload* offload = nullptr,
+                   bool offload_only = false);
     ~ParallelGunzip();
     size_t read(uint8_t* dst, size_t want);
     bool failed() const { return bad_; }
     const char* error() const { return err_; }
     // statistics
     uint64_t sections_accepted = 0, sections_discarded = 0, bridged_bytes = 0, total_out = 0;
+    uint64_t sections_offloaded = 0, offloaded_accepted = 0, offloaded_bytes = 0;      // handed to the device / committed from it / their text
 
     struct Section;
     struct Shared;
@@ -121,6 +153,9 @@ private:
     aqc_host::Pool* pool_;
     int inflight_;
     size_t section_bytes_;
+    SectionOffload* offload_ = nullptr;
+    bool offload_only_ = false;
+    std::shared_ptr<Section> new_section(bool& no_more);     // the next section in stream order (nullptr: nothing to launch now)
     std::shared_ptr<Shared> sh_;
     std::vector<std::shared_ptr<Section>> q_;       // in flight, by nominal start
     std::shared_ptr<Section> unlaunched_;          // the last of them, while it waits for a partner (sections are decoded in pairs)

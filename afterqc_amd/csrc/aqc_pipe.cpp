@@ -256,6 +256,8 @@ struct FileSource : Source {
 //   * anything else — one big member as gzip / pigz / Python write it, or members without sizes — goes through
 //     aqcgz::ParallelGunzip: speculative sections from block boundaries found in the middle of the stream, committed in order.
 // Every member's CRC-32 and length are checked; a file that ends inside a member is an error (gzip.open raises EOFError).
+std::atomic<uint64_t> g_gz_in_stats[4];      // sections committed / of them from the device / text bytes / of them from the device (process-wide)
+
 struct GzSource : Source {
     int fd = -1;
     Pool* pool;
@@ -275,7 +277,7 @@ struct GzSource : Source {
     z_stream zs{};
     bool zs_init = false;
 
-    GzSource(const char* path, Pool* p, size_t section_bytes = 0) : pool(p) {
+    GzSource(const char* path, Pool* p, size_t section_bytes = 0, aqcgz::SectionOffload* offload = nullptr) : pool(p) {
         fd = open(path, O_RDONLY);
         if (fd < 0) return;
         struct stat st;
@@ -298,8 +300,9 @@ struct GzSource : Source {
                     if (!sec) {
                         if (const char* e = getenv("AQC_GZ_SECTION")) sec = (size_t)atoll(e);
                     }
-                    if (!sec) sec = std::min<size_t>(2u << 20, std::max<size_t>(256u << 10, size / (size_t)(4 * inflight)));
-                    pg.reset(new aqcgz::ParallelGunzip(map, size, pool, inflight, sec));
+                    if (!sec) sec = std::min<size_t>(offload ? (1u << 20) : (2u << 20), std::max<size_t>(256u << 10, size / (size_t)(4 * inflight)));
+                    // (with a device decoder the pool keeps twice its sections in flight, see ParallelGunzip::top_up)
+                    pg.reset(new aqcgz::ParallelGunzip(map, size, pool, offload ? std::max(4, inflight / 2) : inflight, sec, offload));
                 }
                 return;
             }
@@ -307,6 +310,14 @@ struct GzSource : Source {
         in.resize(8 << 20);
     }
     ~GzSource() override {
+        if (pg) {
+            g_gz_in_stats[0] += pg->sections_accepted; g_gz_in_stats[1] += pg->offloaded_accepted;
+            g_gz_in_stats[2] += pg->total_out; g_gz_in_stats[3] += pg->offloaded_bytes;
+            if (getenv("AQC_PIPE_DEBUG"))
+                fprintf(stderr, "pipe: gunzip — %llu sections committed (%llu from the device of %llu handed to it), %llu discarded, %.1f MB of %.1f MB decoded sequentially\n",
+                        (unsigned long long)pg->sections_accepted, (unsigned long long)pg->offloaded_accepted, (unsigned long long)pg->sections_offloaded,
+                        (unsigned long long)pg->sections_discarded, 1e-6 * (double)pg->bridged_bytes, 1e-6 * (double)pg->total_out);
+        }
         pg.reset();
         if (map) munmap((void*)map, size);
         if (zs_init) inflateEnd(&zs);
@@ -535,6 +546,10 @@ struct aqc_pipe {
     // per worker (ctx, slot): two sets of six output buffers
     struct WorkerBufs { HostBuf out[2][6]; };
     std::vector<WorkerBufs> wbufs;
+    // per input file: the device decoder of its gzip stream (created with the first .gz input, kept: its device buffers and
+    // page-locked arenas are as expensive to set up as a whole run)
+    std::unique_ptr<aqcgz::SectionOffload> gz_offload[2];
+    bool gz_offload_tried[2] = {false, false};
 };
 
 namespace {
@@ -656,7 +671,17 @@ struct Run {
         const bool mem = io->in_mem[f] != nullptr;
         std::unique_ptr<Source> src;
         if (!mem) {
-            if (io->gzip_in[f]) src.reset(new GzSource(io->in_path[f], P->pool.get()));
+            if (io->gzip_in[f]) {
+                // gzip input: the GPUs take groups of sections off the pool's hands (file f -> the device of context f % n)
+                const char* e = getenv("AQC_GZ_DEVICE_IN");
+                if (!(e && e[0] == '0') && !P->gz_offload_tried[f] && !P->ctx.empty()) {
+                    P->gz_offload_tried[f] = true;
+                    size_t group = 64u << 20;
+                    if (const char* g = getenv("AQC_GZ_GROUP")) group = (size_t)std::max(1ll, atoll(g));
+                    P->gz_offload[f].reset(aqcgz::make_device_offload(aqc_device_index(P->ctx[(size_t)f % P->ctx.size()]), group));
+                }
+                src.reset(new GzSource(io->in_path[f], P->pool.get(), 0, (e && e[0] == '0') ? nullptr : P->gz_offload[f].get()));
+            }
             else src.reset(new FileSource(io->in_path[f], P->pool.get()));
             if (src->failed()) { fail(AQC_ERR_ARG, "cannot open %s", io->in_path[f]); return; }
         }
@@ -1182,6 +1207,12 @@ int aqc_source_gz_stats(aqc_source* s, uint64_t out[4]) {
     out[0] = out[1] = out[2] = out[3] = 0;
     if (GzSource* g = dynamic_cast<GzSource*>(s->src.get()))
         if (g->pg) { out[0] = g->pg->sections_accepted; out[1] = g->pg->sections_discarded; out[2] = g->pg->bridged_bytes; out[3] = g->pg->total_out; }
+    return 0;
+}
+
+int aqc_gz_input_stats(uint64_t out[4]) {
+    if (!out) return AQC_ERR_ARG;
+    for (int i = 0; i < 4; ++i) out[i] = g_gz_in_stats[i].load();
     return 0;
 }
 

@@ -311,10 +311,16 @@ int aqc_fetch_text(aqc_ctx* ctx, int slot, int file, int stream, uint8_t* dst, u
  * byte for byte what aqc_fetch_text hands out.  level >= 1 (stored output, level 0, stays with the host writer). */
 int aqc_compress(aqc_ctx* ctx, int slot, int32_t level, uint64_t gz_bytes_out[6]);
 int aqc_fetch_gz(aqc_ctx* ctx, int slot, int file, int stream, uint8_t* dst, uint64_t cap);
-/* gzip INPUT decoded on the device (csrc/aqc_gunzip_dev.hpp), test / measurement entry: the one gzip member at gz[0, size) is
- * decoded entirely by the device path into out (a section that does not chain up is an error here; in the pipe the host
- * decoder takes over).  stats: batches, sections accepted, microseconds in the find / decode / chain / resolve kernels, end bit */
-int aqc_gunzip_dev_selftest(int device, const uint8_t* gz, uint64_t size, uint8_t* out, uint64_t cap, uint64_t* n_out, uint64_t stats[8]);
+/* gzip INPUT decoded with the device's help (fastq.py:23-24: gzip.open(name, "r"); csrc/aqc_gunzip_dev.hpp): the gzip file at
+ * gz[0, size) into out.  Every section the stream can be cut into goes to the GPU `device` in groups of `group_bytes` compressed
+ * bytes (0: 64 MiB; sections of `section_bytes`, 0: 1 MiB) — a LANE per deflate block, the blocks found by scanning every bit
+ * position — while `threads` host threads resolve the markers and check each member's CRC-32 / ISIZE; what the device does
+ * not chain up (final / fixed-Huffman blocks, the stream's last section) is decoded on the host, so ANY valid gzip file
+ * comes out exactly.  It is what a `.gz` input of aqc_pipe_run goes through, minus the host pool's share of the sections.
+ * stats: sections committed from the device / from the host, bytes decoded sequentially on the host, microseconds in the
+ * scan + compact / decode / chain + gather kernels and in the H2D / D2H copies. */
+int aqc_gunzip_dev(int device, const uint8_t* gz, uint64_t size, uint8_t* out, uint64_t cap, uint64_t* n_out, uint64_t stats[8], int threads,
+                   uint64_t section_bytes, uint64_t group_bytes);
 /* page-locked host memory for text chunks and fetched streams (hipHostMalloc): full-rate DMA */
 void* aqc_host_alloc(uint64_t bytes);
 void aqc_host_free(void* p);
@@ -394,6 +400,9 @@ int64_t aqc_source_read(aqc_source* s, uint8_t* dst, uint64_t want);
 const char* aqc_source_error(aqc_source* s);
 /* diagnostics of the parallel gunzip: sections accepted, sections discarded, bytes decoded sequentially instead, bytes out */
 int aqc_source_gz_stats(aqc_source* s, uint64_t out[4]);
+/* gzip inputs of every aqc_pipe_run of the process so far: sections committed, of them decoded on a GPU (aqc_gunzip_dev.hpp),
+ * bytes of text, of them from sections decoded on a GPU.  AQC_GZ_DEVICE_IN=0 keeps gzip input on the host pool. */
+int aqc_gz_input_stats(uint64_t out[4]);
 void aqc_source_close(aqc_source* s);
 /* the codec's pieces on their own (host only; the CPU tests pin them against zlib): one raw DEFLATE stream for src[0, n)
  * (dst must hold n + n / 1000 + 400 bytes; level <= 0 stores), its inverse into exactly `cap` bytes (-1: invalid data or a

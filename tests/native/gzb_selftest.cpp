@@ -1,0 +1,316 @@
+// gzb_selftest.cpp — the device gunzip's per-lane logic (afterqc_amd/csrc/aqc_gunzip_dev.hpp), run on the CPU.
+//
+// The header's GZB_HD functions are what the kernels' lanes execute: the block-start tests, the table builder, the block
+// decoder, the chain walk, the marker re-basing.  CpuOffload below deals them out with plain loops in the kernels' order
+// (scan -> compact -> decode -> chain -> gather, same buffers, same GzbJob) and plugs into the real ParallelGunzip through
+// the SectionOffload interface the GPU uses (aqc_capi.hip: DeviceInflate).  So this checks, without a GPU:
+//   * every zlib stream below comes out byte-identical (ParallelGunzip also verifies CRC-32 / ISIZE itself);
+//   * the offloaded sections really are committed (the chain rule accepts them) for dynamic-Huffman streams;
+//   * stored blocks inside a chain, concatenated members, fixed-Huffman and stored-only streams, false section starts,
+//     tiny symbol space (overflow -> host) and tiny candidate space all degrade to host decoding, never to wrong bytes.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../afterqc_amd/csrc/aqc_gunzip_dev.hpp"
+#include "../../afterqc_amd/csrc/aqc_gz.hpp"
+
+using namespace aqc;
+
+namespace {
+
+struct CpuOffload : aqcgz::SectionOffload {
+    size_t group;
+    uint32_t ratio_cap = 20;
+    uint32_t cand_div = 4096;            // candidate capacity = span / cand_div + 256
+    uint64_t groups = 0, sections = 0, found = 0, candidates = 0, false_ends = 0;
+    std::vector<std::vector<uint16_t>*> live;
+    explicit CpuOffload(size_t g) : group(g) {}
+    size_t group_bytes() const override { return group; }
+    bool ready() override { return true; }
+    void release(void* token) override { delete (std::vector<uint16_t>*)token; }
+
+    bool submit(const uint8_t* data, size_t size, int n, const uint64_t* nominal, const uint64_t* stop, const uint8_t* exact,
+                std::function<void(int, const aqcgz::OffloadResult&)> done) override {
+        const uint64_t SLACK = 256u << 10;
+        const uint64_t byte0 = (nominal[0] >> 3) & ~(uint64_t)15;
+        const uint64_t end_byte = std::min<uint64_t>(size, (stop[n - 1] >> 3) + 1 + SLACK);
+        const size_t span = (size_t)(end_byte - byte0);
+        std::vector<uint8_t> comp(span + 256, 0);
+        memcpy(comp.data(), data + byte0, span);
+        GzbJob J{};
+        J.comp = comp.data(); J.comp_bytes = (uint32_t)span; J.scan_byte0 = 0;
+        J.first_bit = (uint32_t)(nominal[0] - byte0 * 8);
+        J.last_bit = (uint32_t)std::min<uint64_t>(stop[n - 1] - byte0 * 8, (uint64_t)span * 8);
+        J.n_tiles = (uint32_t)(((size_t)(J.last_bit >> 3) + 1 + GZB_SCAN_TILE - 1) / GZB_SCAN_TILE);
+        J.cand_cap = (uint32_t)(span / cand_div + 256);
+        J.ratio_cap = ratio_cap;
+        std::vector<uint32_t> tile_cnt(J.n_tiles), tile_cand((size_t)J.n_tiles * GZB_TILE_CAND), n_cand(2), c_start(J.cand_cap), c_end(J.cand_cap), c_nsym(J.cand_cap),
+            c_flags(J.cand_cap), c_symcap(J.cand_cap);
+        std::vector<uint64_t> c_symoff(J.cand_cap);
+        J.tile_cnt = tile_cnt.data(); J.tile_cand = tile_cand.data(); J.n_cand = n_cand.data(); J.c_start = c_start.data(); J.c_end = c_end.data();
+        J.c_nsym = c_nsym.data(); J.c_flags = c_flags.data(); J.c_symcap = c_symcap.data(); J.c_symoff = c_symoff.data();
+        J.blk_sym_cap = (uint64_t)span * ratio_cap + (uint64_t)J.cand_cap * 4104;
+        std::vector<uint16_t> blk_sym(J.blk_sym_cap + 64);
+        J.blk_sym = blk_sym.data();
+        std::vector<uint32_t> tables((size_t)J.cand_cap * GZB_TAB_WORDS);
+        J.tables = tables.data();
+        // ---- scan: every lane of every tile
+        uint8_t kraft[512];
+        for (int i = 0; i < 512; ++i) kraft[i] = (uint8_t)gzb_kraft9((uint32_t)i);
+        std::vector<uint8_t> cl(128);
+        const uint32_t limit_bit = J.comp_bytes * 8u;
+        for (uint32_t tile = 0; tile < J.n_tiles; ++tile) {
+            std::vector<uint32_t> hits;
+            for (uint32_t tid = 0; tid < (uint32_t)GZB_SCAN_THREADS; ++tid) {
+                const uint32_t b0 = tile * (uint32_t)GZB_SCAN_TILE + tid * 16u;
+                if (b0 >= J.comp_bytes) continue;
+                uint32_t d[8];
+                memcpy(d, comp.data() + b0, 32);
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned long long v64 = ((unsigned long long)d[i + 1] << 32) | d[i];
+                    uint32_t mm = gzb_quick32(v64);
+                    const uint32_t bb = (b0 + 4u * (uint32_t)i) * 8u;
+                    if (bb + 32u <= J.first_bit || bb >= J.last_bit) mm = 0;
+                    else {
+                        if (bb < J.first_bit) mm &= ~0u << (J.first_bit - bb);
+                        if (bb + 32u > J.last_bit) mm &= (1u << (J.last_bit - bb)) - 1u;
+                    }
+                    while (mm) {
+                        const uint32_t bit = (uint32_t)__builtin_ctz(mm);
+                        mm &= mm - 1;
+                        const uint32_t p = bb + bit;
+                        const uint32_t hclen = ((uint32_t)(v64 >> (bit + 13u)) & 15u) + 4u;
+                        if (!gzb_kraft_ok(comp.data(), p, hclen, kraft)) continue;
+                        uint32_t db, hl, hd;
+                        if (gzb_header(comp.data(), limit_bit, p, cl.data(), 1, nullptr, db, hl, hd)) hits.push_back(p);
+                    }
+                }
+            }
+            std::sort(hits.begin(), hits.end());
+            const uint32_t c = (uint32_t)std::min<size_t>(hits.size(), (size_t)GZB_TILE_CAND);
+            tile_cnt[tile] = c;
+            for (uint32_t a = 0; a < c; ++a) tile_cand[(size_t)tile * GZB_TILE_CAND + a] = hits[a];
+        }
+        // ---- compact
+        uint32_t nc = 0;
+        for (uint32_t t = 0; t < J.n_tiles; ++t)
+            for (uint32_t a = 0; a < tile_cnt[t]; ++a)
+                if (nc < J.cand_cap) c_start[nc++] = tile_cand[(size_t)t * GZB_TILE_CAND + a];
+        n_cand[0] = nc; n_cand[1] = 0;
+        candidates += nc;
+        {
+            unsigned long long o = 0;
+            for (uint32_t c = 0; c < nc; ++c) {
+                const uint32_t cap = gzb_symcap_of(J, c, nc);
+                c_symoff[c] = o;
+                c_symcap[c] = o + cap > J.blk_sym_cap ? 0u : cap;
+                o += cap;
+            }
+        }
+        // ---- decode: a lane per candidate
+        std::vector<uint32_t> cnt(16), nxt(16), off(16);
+        for (uint32_t c = 0; c < nc; ++c) {
+            const GzbTables T(J.tables + (size_t)c * GZB_TAB_WORDS);
+            uint32_t p = 0, hlit = 0, hdist = 0, op = 0, fl = 0;
+            if (c_symcap[c] == 0) fl = GZB_F_SKIP;
+            else if (!gzb_header(J.comp, limit_bit, c_start[c], cl.data(), 1, T.lens, p, hlit, hdist)) fl = GZB_F_ERROR;
+            if (!fl) {
+                gzb_build<true>(T.lens, hlit, GZB_LROOT, T.lit, T.lsorted, T.lcount, cnt.data(), nxt.data(), off.data(), 1);
+                gzb_build<false>(T.lens + hlit, hdist, GZB_DROOT, T.dist, T.dsorted, T.dcount, cnt.data(), nxt.data(), off.data(), 1);
+                fl = gzb_decode_block(J.comp, limit_bit, T, J.blk_sym + c_symoff[c], c_symcap[c], p, op);
+            }
+            c_end[c] = p; c_nsym[c] = op; c_flags[c] = fl;
+        }
+        // ---- chain + gather
+        uint64_t sec_max = 0;
+        for (int k = 0; k < n; ++k) sec_max = std::max<uint64_t>(sec_max, (stop[k] - nominal[k]) >> 3);
+        J.s_symcap = (uint32_t)((sec_max * 12 + (2u << 20) + 7) & ~(uint64_t)7);
+        J.n_sec = (uint32_t)n;
+        std::vector<uint32_t> s_nom(n), s_stop(n), s_exact(n), s_start(n), s_end(n), s_nsym(n), s_nblk(n), s_blocks((size_t)n * GZB_SEC_BLOCKS * 3);
+        for (int k = 0; k < n; ++k) {
+            s_nom[k] = (uint32_t)(nominal[k] - byte0 * 8);
+            s_stop[k] = (uint32_t)std::min<uint64_t>(stop[k] - byte0 * 8, (uint64_t)span * 8);
+            s_exact[k] = exact[k];
+        }
+        J.s_nominal = s_nom.data(); J.s_stop = s_stop.data(); J.s_exact = s_exact.data(); J.s_start = s_start.data(); J.s_end = s_end.data();
+        J.s_nsym = s_nsym.data(); J.s_nblk = s_nblk.data(); J.s_blocks = s_blocks.data();
+        std::vector<uint16_t> s_sym((size_t)J.s_symcap + 64);         // (one section at a time here)
+        J.s_sym = s_sym.data();
+        ++groups;
+        sections += (uint64_t)n;
+        for (int k = 0; k < n; ++k) {
+            gzb_chain_section(J, (uint32_t)k);
+            aqcgz::OffloadResult r;
+            if (s_start[k] != GZB_NONE && s_nsym[k] != 0) {
+                uint16_t* const dst = s_sym.data();
+                const uint32_t* const blocks = s_blocks.data() + (size_t)k * GZB_SEC_BLOCKS * 3u;
+                for (uint32_t b = 0; b < s_nblk[k]; ++b) {
+                    const uint32_t w0 = blocks[3u * b], w1 = blocks[3u * b + 1], o = blocks[3u * b + 2];
+                    if (w0 & GZB_STORED) { for (uint32_t i = 0; i < (w0 & 0xffffu); ++i) dst[o + i] = comp[w1 + i]; }
+                    else {
+                        const uint16_t* const s = J.blk_sym + c_symoff[w0];
+                        for (uint32_t i = 0; i < c_nsym[w0]; ++i) dst[o + i] = gzb_rebase(s[i], o, dst);
+                    }
+                }
+                auto* keep = new std::vector<uint16_t>(s_sym.begin(), s_sym.begin() + s_nsym[k]);
+                r.found = true;
+                r.start_bit = byte0 * 8 + s_start[k];
+                r.end_bit = byte0 * 8 + s_end[k];
+                r.sym = keep->data();
+                r.n_sym = s_nsym[k];
+                r.token = keep;
+                ++found;
+            }
+            done(k, r);
+        }
+        return true;
+    }
+};
+
+std::vector<uint8_t> fastq_like(size_t n_reads, unsigned seed) {
+    std::mt19937 rng(seed);
+    std::vector<uint8_t> t;
+    const char B[] = "ACGT", Q[] = "#/6<AEEEEEEEEE";
+    for (size_t r = 0; r < n_reads; ++r) {
+        char name[96];
+        const int nl = snprintf(name, sizeof(name), "@SIM:1:FC1:%u:%u:%u:%u 1:N:0:ACGT\n", (unsigned)(1 + rng() % 4), (unsigned)(1101 + rng() % 1200), (unsigned)(1000 + rng() % 24000), (unsigned)(1000 + rng() % 19000));
+        t.insert(t.end(), name, name + nl);
+        for (int i = 0; i < 150; ++i) t.push_back((uint8_t)(rng() % 500 == 0 ? 'N' : B[rng() & 3]));
+        t.push_back('\n'); t.push_back('+'); t.push_back('\n');
+        uint8_t q = 'E';
+        for (int i = 0; i < 150; ++i) { if (rng() % 7 == 0) q = (uint8_t)Q[rng() % 14]; t.push_back(q); }
+        t.push_back('\n');
+    }
+    return t;
+}
+
+std::vector<uint8_t> gz_of(const std::vector<uint8_t>& text, int level, int strategy, size_t flush_every = 0, int flush = Z_FULL_FLUSH) {
+    z_stream zs{};
+    deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, strategy);
+    std::vector<uint8_t> out(deflateBound(&zs, (uLong)text.size()) + (flush_every ? text.size() / flush_every * 16 + 64 : 0) + 64);
+    zs.next_out = out.data(); zs.avail_out = (uInt)out.size();
+    size_t pos = 0;
+    while (pos < text.size()) {
+        const size_t k = flush_every ? std::min(flush_every, text.size() - pos) : text.size() - pos;
+        zs.next_in = (Bytef*)text.data() + pos; zs.avail_in = (uInt)k;
+        deflate(&zs, pos + k == text.size() ? Z_FINISH : flush);
+        pos += k;
+    }
+    if (text.empty()) deflate(&zs, Z_FINISH);
+    out.resize(zs.total_out);
+    deflateEnd(&zs);
+    return out;
+}
+
+int failures = 0;
+
+// decode gz through ParallelGunzip with the CPU emulation of the device as its offloader; returns the offloader's counters
+bool run_case(const char* what, const std::vector<uint8_t>& gz, const std::vector<uint8_t>& text, size_t section, size_t group, int threads, bool want_device,
+              uint32_t ratio_cap = 20, uint32_t cand_div = 4096, bool expect_fail = false) {
+    CpuOffload off(group);
+    off.ratio_cap = ratio_cap; off.cand_div = cand_div;
+    aqc_host::Pool pool(threads);
+    std::vector<uint8_t> out(text.size() + 65536);
+    size_t produced = 0;
+    bool failed = false;
+    uint64_t dev_acc = 0, host_acc = 0, bridged = 0;
+    {
+        aqcgz::ParallelGunzip pg(gz.data(), gz.size(), threads ? &pool : nullptr, 4, section, &off, true);
+        for (;;) {
+            const size_t got = pg.read(out.data() + produced, std::min<size_t>(out.size() - produced, 777777));
+            if (pg.failed()) { failed = true; break; }
+            if (!got) break;
+            produced += got;
+        }
+        dev_acc = pg.offloaded_accepted; host_acc = pg.sections_accepted - pg.offloaded_accepted; bridged = pg.bridged_bytes;
+    }
+    bool ok;
+    if (expect_fail) ok = failed;
+    else {
+        ok = !failed && produced == text.size() && (text.empty() || memcmp(out.data(), text.data(), text.size()) == 0);
+        if (ok && want_device && dev_acc == 0) ok = false;
+    }
+    printf("%-46s %s  gz %8zu -> %9zu B  sec %7zu  device sections %3llu  host %3llu  bridged %9llu B  candidates %llu  groups %llu\n", what, ok ? "ok  " : "FAIL", gz.size(),
+           text.size(), section, (unsigned long long)dev_acc, (unsigned long long)host_acc, (unsigned long long)bridged, (unsigned long long)off.candidates, (unsigned long long)off.groups);
+    if (!ok) ++failures;
+    return ok;
+}
+
+}  // namespace
+
+int main() {
+    const std::vector<uint8_t> fq = fastq_like(14000, 3);        // ~4.9 MB
+    // dynamic-Huffman streams of every level: the device must supply sections
+    for (int level : {1, 2, 4, 6, 9}) {
+        const std::vector<uint8_t> gz = gz_of(fq, level, Z_DEFAULT_STRATEGY);
+        char what[80];
+        snprintf(what, sizeof(what), "fastq level %d, 64 KiB sections", level);
+        run_case(what, gz, fq, 64 << 10, 512 << 10, 3, true);
+    }
+    {
+        const std::vector<uint8_t> gz = gz_of(fq, 6, Z_DEFAULT_STRATEGY);
+        run_case("fastq level 6, 256 KiB sections, one group", gz, fq, 256 << 10, 64 << 20, 2, true);
+        run_case("fastq level 6, no host threads", gz, fq, 128 << 10, 1 << 20, 0, true);
+        run_case("fastq level 6, symbol space 2x (overflow)", gz, fq, 64 << 10, 512 << 10, 2, false, 2);
+        run_case("fastq level 6, 8 candidates per MiB", gz, fq, 64 << 10, 512 << 10, 2, false, 20, 1u << 30);
+        std::vector<uint8_t> bad = gz;
+        bad[bad.size() / 2] ^= 0x21;
+        run_case("fastq level 6, one byte damaged", bad, fq, 64 << 10, 512 << 10, 2, false, 20, 4096, true);
+        std::vector<uint8_t> cut(gz.begin(), gz.begin() + (long)(gz.size() * 2 / 3));
+        run_case("fastq level 6, truncated", cut, fq, 64 << 10, 512 << 10, 2, false, 20, 4096, true);
+    }
+    run_case("fastq huffman-only", gz_of(fq, 6, Z_HUFFMAN_ONLY), fq, 64 << 10, 512 << 10, 2, true);
+    run_case("fastq run-length", gz_of(fq, 6, Z_RLE), fq, 64 << 10, 512 << 10, 2, true);
+    run_case("fastq fixed codes (host only)", gz_of(fq, 6, Z_FIXED), fq, 64 << 10, 512 << 10, 2, false);
+    run_case("fastq stored (host only)", gz_of(fq, 0, Z_DEFAULT_STRATEGY), fq, 64 << 10, 512 << 10, 2, false);
+    // pigz-style: an empty stored block between the deflate blocks every 128 KiB of text; and sync flushes
+    run_case("fastq level 6, full flush every 128 KiB", gz_of(fq, 6, Z_DEFAULT_STRATEGY, 128 << 10, Z_FULL_FLUSH), fq, 64 << 10, 512 << 10, 2, true);
+    run_case("fastq level 1, sync flush every 40 KB", gz_of(fq, 1, Z_DEFAULT_STRATEGY, 40000, Z_SYNC_FLUSH), fq, 64 << 10, 512 << 10, 2, true);
+    {
+        // concatenated members of different levels + zero padding behind the last one
+        std::vector<uint8_t> cat, text;
+        int lv = 1;
+        for (size_t a = 0; a < fq.size(); a += fq.size() / 3 + 1) {
+            std::vector<uint8_t> part(fq.begin() + (long)a, fq.begin() + (long)std::min(fq.size(), a + fq.size() / 3 + 1));
+            const std::vector<uint8_t> g = gz_of(part, lv, Z_DEFAULT_STRATEGY);
+            cat.insert(cat.end(), g.begin(), g.end());
+            text.insert(text.end(), part.begin(), part.end());
+            lv += 4;
+        }
+        cat.insert(cat.end(), 100, 0);
+        run_case("three members (levels 1, 5, 9) + zero padding", cat, text, 64 << 10, 512 << 10, 2, true);
+    }
+    {
+        // data in which block headers are easy to mistake: random bytes (stored by zlib), long runs, a tiny alphabet
+        std::mt19937 rng(9);
+        std::vector<uint8_t> r(1500000);
+        for (auto& b : r) b = (uint8_t)rng();
+        run_case("random bytes level 6", gz_of(r, 6, Z_DEFAULT_STRATEGY), r, 64 << 10, 512 << 10, 2, false);
+        std::vector<uint8_t> runs;
+        while (runs.size() < 3000000) { const int k = 1 + (int)(rng() % 900); runs.insert(runs.end(), (size_t)k, (uint8_t)('a' + rng() % 3)); }
+        run_case("long runs level 6 (ratio > 20: overflow)", gz_of(runs, 6, Z_DEFAULT_STRATEGY), runs, 64 << 10, 512 << 10, 2, false);
+        run_case("long runs level 6, symbol space 400x", gz_of(runs, 6, Z_DEFAULT_STRATEGY), runs, 64 << 10, 512 << 10, 2, false, 400);
+        std::vector<uint8_t> two(2000000);
+        for (auto& b : two) b = (uint8_t)("AC"[rng() & 1]);
+        run_case("two-symbol text level 9", gz_of(two, 9, Z_DEFAULT_STRATEGY), two, 64 << 10, 512 << 10, 2, true);
+        std::vector<uint8_t> one(1, 'x'), none;
+        run_case("one byte", gz_of(one, 6, Z_DEFAULT_STRATEGY), one, 64 << 10, 512 << 10, 2, false);
+        run_case("empty", gz_of(none, 6, Z_DEFAULT_STRATEGY), none, 64 << 10, 512 << 10, 2, false);
+    }
+    {
+        const std::vector<uint8_t> big = fastq_like(60000, 11);   // ~21 MB: several groups of 2 MiB, distances near 32 KiB do occur at level 9
+        run_case("fastq 21 MB level 9, 256 KiB sections", gz_of(big, 9, Z_DEFAULT_STRATEGY), big, 256 << 10, 2 << 20, 4, true);
+        run_case("fastq 21 MB level 1, 1 MiB sections", gz_of(big, 1, Z_DEFAULT_STRATEGY), big, 1 << 20, 4 << 20, 4, true);
+    }
+    if (failures) { printf("%d FAILED\n", failures); return 1; }
+    printf("all device-gunzip logic checks passed\n");
+    return 0;
+}

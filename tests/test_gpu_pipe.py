@@ -155,16 +155,18 @@ def test_device_gzip_members(gpu_engine):
                 assert zb < nb / 2.2, (nb, zb)                  # FASTQ: well below half
 
 
-@pytest.mark.parametrize("level,strategy", [(1, "default"), (6, "default"), (9, "default"), (6, "huffman"), (6, "fixed")])
-def test_device_gunzip_sections_are_exact(level, strategy):
-    """csrc/aqc_gunzip_dev.hpp (groundwork, not yet in the pipe — DESIGN.md §8.1): ONE gzip member decoded by waves that start at
-    block boundaries they find themselves, in symbol form, committed only when they chain up bit for bit, markers resolved on
-    the device — the result is exactly zlib's, for dynamic, literal-only and fixed-Huffman streams"""
+@pytest.mark.parametrize("level,strategy,sec_kb", [(1, "default", 64), (6, "default", 64), (9, "default", 256), (6, "huffman", 64), (6, "fixed", 64), (6, "rle", 64),
+                                                   (0, "default", 64)])
+def test_device_gunzip_sections_are_exact(level, strategy, sec_kb):
+    """csrc/aqc_gunzip_dev.hpp through aqc_gunzip_dev: ONE gzip member, every section handed to the device (a lane per deflate
+    block; the blocks are found by scanning every bit position), committed only when they chain up bit for bit, markers
+    resolved and CRC-32 checked on the host — the result is exactly zlib's for dynamic, literal-only, run-length, fixed-Huffman
+    and stored streams; and for the dynamic ones the device really supplied the sections"""
     import zlib
     d = synth.make_pairs(9000, 150, seed=40 + level, dirty=True)
     buf, n = synth.render_fastq_fixed(d["seq1"], d["qual1"], 1)
     text = bytes(memoryview(buf)[:n])
-    st = {"default": zlib.Z_DEFAULT_STRATEGY, "huffman": zlib.Z_HUFFMAN_ONLY, "fixed": zlib.Z_FIXED}[strategy]
+    st = {"default": zlib.Z_DEFAULT_STRATEGY, "huffman": zlib.Z_HUFFMAN_ONLY, "fixed": zlib.Z_FIXED, "rle": zlib.Z_RLE}[strategy]
     c = zlib.compressobj(level, zlib.DEFLATED, 31, 8, st)
     gz = c.compress(text) + c.flush()
     lib = capi.load_library()
@@ -172,17 +174,96 @@ def test_device_gunzip_sections_are_exact(level, strategy):
     out = np.zeros(len(text) + 4096, dtype=np.uint8)
     n_out = capi.C.c_uint64(0)
     stats = np.zeros(8, dtype=np.uint64)
-    rc = lib.aqc_gunzip_dev_selftest(0, src.ctypes.data, len(gz), out.ctypes.data, out.size, capi.C.byref(n_out), stats.ctypes.data)
-    if strategy == "fixed":
-        # fixed-Huffman blocks carry no header the block search could recognise: only the first section (known start) decodes;
-        # the device path reports that nothing chained up behind it (the host decoder would take over) — or, for a stream of a
-        # single block, decodes it all
-        assert rc == 0 or b"no section chained up" in (lib.aqc_last_error() or b"")
-        if rc != 0:
-            return
+    rc = lib.aqc_gunzip_dev(0, src.ctypes.data, len(gz), out.ctypes.data, out.size, capi.C.byref(n_out), stats.ctypes.data, 4, sec_kb << 10, 1 << 20)
     assert rc == 0, (lib.aqc_last_error() or b"").decode()
     assert n_out.value == len(text) and out[:len(text)].tobytes() == text
-    assert stats[1] >= 1
+    if strategy not in ("fixed",) and level > 0:
+        # (fixed-Huffman and stored streams carry no block header the scan looks for: the host decodes them)
+        assert stats[0] >= 1 and stats[0] >= stats[1], stats
+        assert stats[2] < len(text) // 2, stats
+
+
+def test_device_gunzip_takes_concatenated_members_and_pigz_style_sync_blocks():
+    """members glued together (cat a.gz b.gz) and empty stored blocks between the deflate blocks (Z_FULL_FLUSH, what pigz writes
+    between its chunks): the chain steps over stored blocks on the device, member ends go through the host — exact either way"""
+    import zlib
+    d = synth.make_pairs(12000, 150, seed=77, dirty=True)
+    buf, n = synth.render_fastq_fixed(d["seq1"], d["qual1"], 1)
+    text = bytes(memoryview(buf)[:n])
+    third = len(text) // 3
+    c = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gz = b""
+    for k in range(0, third, 200_000):
+        gz += c.compress(text[k:min(third, k + 200_000)]) + c.flush(zlib.Z_FULL_FLUSH)
+    gz += c.flush()
+    c2 = zlib.compressobj(1, zlib.DEFLATED, 31)
+    gz += c2.compress(text[third:2 * third]) + c2.flush()
+    c3 = zlib.compressobj(9, zlib.DEFLATED, 31)
+    gz += c3.compress(text[2 * third:]) + c3.flush()
+    lib = capi.load_library()
+    src = np.frombuffer(gz, dtype=np.uint8)
+    out = np.zeros(len(text) + 4096, dtype=np.uint8)
+    n_out = capi.C.c_uint64(0)
+    stats = np.zeros(8, dtype=np.uint64)
+    rc = lib.aqc_gunzip_dev(0, src.ctypes.data, len(gz), out.ctypes.data, out.size, capi.C.byref(n_out), stats.ctypes.data, 4, 64 << 10, 512 << 10)
+    assert rc == 0, (lib.aqc_last_error() or b"").decode()
+    assert n_out.value == len(text) and out[:len(text)].tobytes() == text
+    assert stats[0] >= 3, stats
+    # a damaged stream is an error, not silence
+    bad = bytearray(gz)
+    bad[len(bad) // 2] ^= 0x5a
+    srcb = np.frombuffer(bytes(bad), dtype=np.uint8)
+    rc = lib.aqc_gunzip_dev(0, srcb.ctypes.data, len(bad), out.ctypes.data, out.size, capi.C.byref(n_out), stats.ctypes.data, 4, 64 << 10, 512 << 10)
+    assert rc != 0
+
+
+def test_pipe_single_member_gzip_input_is_shared_with_the_device(tmp_path):
+    """one-member `gzip -6` inputs big enough to be cut into many sections, through aqc_pipe_run: the GPU takes groups of sections
+    off the host pool (ParallelGunzip + DeviceInflate), the outputs equal the plain-input run byte for byte, and the device
+    supplied more than 30 % of the committed sections; with AQC_GZ_DEVICE_IN=0 the host does it all, same bytes"""
+    import gzip
+    work = str(tmp_path)
+    d = synth.make_pairs(400_000, 150, seed=8811, workers=4)
+    r1, r2 = os.path.join(work, "R1.fq"), os.path.join(work, "R2.fq")
+    synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
+    synth.write_fastq_fixed(r2, d["seq2"], d["qual2"], 2)
+    ref_files, ref_stat, _ = run(work, r1, r2, ["-f", "0", "-t", "0"], tag="plain", use_pipe=True, devices=[0])
+    for p in (r1, r2):
+        with open(p, "rb") as f, gzip.open(p + ".gz", "wb", compresslevel=6) as g:
+            g.write(f.read())
+    lib = capi.load_library()
+
+    def gz_run(tag):
+        before = (capi.C.c_uint64 * 4)()
+        lib.aqc_gz_input_stats(capi.C.byref(before))
+        out = os.path.join(work, tag)
+        argv = ["-1", r1 + ".gz", "-2", r2 + ".gz", "-f", "0", "-t", "0", "--compression", "0", "-g", os.path.join(out, "good"), "-b", os.path.join(out, "bad"),
+                "-r", os.path.join(out, "QC")]
+        options, _ = after.parseCommand(argv)
+        after.finalize_options(options)
+        options.barcode = False
+        flt = preprocesser.seqFilter(options, use_pipe=True, devices=[0])
+        flt.run()
+        assert flt.used_pipe
+        after_ = (capi.C.c_uint64 * 4)()
+        lib.aqc_gz_input_stats(capi.C.byref(after_))
+        for name in ("good/R1.good.fq", "good/R2.good.fq", "bad/R1.bad.fq", "bad/R2.bad.fq"):
+            with gzip.open(os.path.join(out, name + ".gz"), "rb") as f:
+                assert hashlib.sha256(f.read()).hexdigest() == ref_files[name], (tag, name)
+        return [int(a) - int(b) for a, b in zip(after_, before)]
+
+    os.environ["AQC_GZ_GROUP"] = str(8 << 20)
+    try:
+        sections, from_device, text_bytes, device_bytes = gz_run("gzdev")
+    finally:
+        del os.environ["AQC_GZ_GROUP"]
+    assert sections > 20 and from_device > 0.3 * sections and device_bytes > 0.3 * text_bytes, (sections, from_device, text_bytes, device_bytes)
+    os.environ["AQC_GZ_DEVICE_IN"] = "0"
+    try:
+        sections, from_device, _, _ = gz_run("gzhost")
+    finally:
+        del os.environ["AQC_GZ_DEVICE_IN"]
+    assert sections > 20 and from_device == 0
 
 
 def test_one_gigabyte_member_is_inflated_exactly(tmp_path):
@@ -230,3 +311,14 @@ def test_one_gigabyte_member_is_inflated_exactly(tmp_path):
     src.close()
     assert n == total and got.digest() == want.digest()
     assert out == total and accepted > 50 and sequential < total // 20, (accepted, discarded, sequential)
+    # the same member with the DEVICE decoding its sections (aqc_gunzip_dev: a lane per deflate block, chain-validated): exact
+    # again, and the device supplied nearly all of it
+    lib = capi.load_library()
+    comp_bytes = np.fromfile(gz, dtype=np.uint8)
+    text = np.empty(total + 4096, dtype=np.uint8)
+    n_out = capi.C.c_uint64(0)
+    stats = np.zeros(8, dtype=np.uint64)
+    rc = lib.aqc_gunzip_dev(0, comp_bytes.ctypes.data, comp_bytes.size, text.ctypes.data, text.size, capi.C.byref(n_out), stats.ctypes.data, 8, 1 << 20, 64 << 20)
+    assert rc == 0, (lib.aqc_last_error() or b"").decode()
+    assert n_out.value == total and hashlib.sha256(memoryview(text)[:total]).digest() == want.digest()
+    assert stats[0] > 50 and stats[0] > 3 * stats[1] and stats[2] < total // 10, stats

@@ -32,6 +32,19 @@ def test_native_selftest(tmp_path):
     assert "all gz codec checks passed" in out.stdout
 
 
+def test_device_gunzip_logic_on_the_cpu(tmp_path):
+    """csrc/aqc_gunzip_dev.hpp's per-lane functions (block-start scan, table builder, block decoder, chain walk, marker
+    re-basing) dealt out by plain loops and plugged into the real ParallelGunzip through the SectionOffload interface the GPU
+    uses (tests/native/gzb_selftest.cpp): zlib streams of every level and strategy, flush-separated blocks, concatenated
+    members, damaged and truncated files — byte-identical or a loud error, and the offloaded sections really are committed"""
+    exe = str(tmp_path / "gzb_selftest")
+    src = [os.path.join(ROOT, "tests", "native", "gzb_selftest.cpp")] + [os.path.join(ROOT, "afterqc_amd", "csrc", f) for f in ("aqc_inflate.cpp", "aqc_gunzip.cpp")]
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wno-stringop-overflow"] + src + ["-lz", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "all device-gunzip logic checks passed" in out.stdout
+
+
 def _read_all(path, section=0, threads=4, piece=1 << 20):
     s = capi.NativeSource(path, True, io_threads=threads, gz_section_bytes=section)
     out = bytearray()

@@ -21,13 +21,16 @@ src = np.frombuffer(gz, dtype=np.uint8)
 out = np.zeros(len(text) + 4096, dtype=np.uint8)
 n_out = capi.C.c_uint64(0)
 stats = np.zeros(8, dtype=np.uint64)
-for rep in range(2):
+threads = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+sec = int(sys.argv[5]) if len(sys.argv) > 5 else 1 << 20
+group = int(sys.argv[6]) if len(sys.argv) > 6 else 64 << 20
+for rep in range(3):
     t0 = time.perf_counter()
-    rc = lib.aqc_gunzip_dev_selftest(0, src.ctypes.data, len(gz), out.ctypes.data, out.size, capi.C.byref(n_out), stats.ctypes.data)
+    rc = lib.aqc_gunzip_dev(0, src.ctypes.data, len(gz), out.ctypes.data, out.size, capi.C.byref(n_out), stats.ctypes.data, threads, sec, group)
     dt = time.perf_counter() - t0
     ok = rc == 0 and n_out.value == len(text) and out[:len(text)].tobytes() == text
-    print("rc %d  %s  %d of %d bytes  %.3f s = %.2f GB/s of text; batches %d sections %d; kernels ms: find %.1f decode %.1f chain %.1f resolve %.1f; err: %s" % (
-        rc, "EXACT" if ok else "MISMATCH", n_out.value, len(text), dt, len(text) / dt / 1e9, stats[0], stats[1], stats[2] / 1e3, stats[3] / 1e3, stats[4] / 1e3, stats[5] / 1e3,
+    print("rc %d  %s  %d of %d bytes  %.3f s = %.2f GB/s of text; sections device %d host %d, bridged %d B; kernels ms: scan %.1f decode %.1f chain+gather %.1f h2d %.1f d2h %.1f; err: %s" % (
+        rc, "EXACT" if ok else "MISMATCH", n_out.value, len(text), dt, len(text) / dt / 1e9, stats[0], stats[1], stats[2], stats[3] / 1e3, stats[4] / 1e3, stats[5] / 1e3, stats[6] / 1e3, stats[7] / 1e3,
         (lib.aqc_last_error() or b"").decode() if rc else ""), flush=True)
     if not ok and rc == 0:
         a = np.frombuffer(text, dtype=np.uint8); b = out[:len(text)]
