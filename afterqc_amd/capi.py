@@ -334,6 +334,7 @@ def load_library():
     lib.aqc_format.argtypes = [P, C.c_int, C.c_uint64, C.c_int32, P]
     lib.aqc_format_plain.argtypes = [P, C.c_int, C.c_int, C.c_uint64, C.c_int32, P]
     lib.aqc_fetch_text.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.c_uint64]
+    lib.aqc_fetch_streams.argtypes = [P, C.c_int, C.c_int32, C.POINTER(C.c_void_p * 6), C.POINTER(C.c_uint64 * 6)]
     lib.aqc_gunzip_dev.argtypes = [C.c_int, P, C.c_uint64, P, C.c_uint64, C.POINTER(C.c_uint64), P, C.c_int, C.c_uint64, C.c_uint64]
     lib.aqc_compress.argtypes = [P, C.c_int, C.c_int32, P]
     lib.aqc_fetch_gz.argtypes = [P, C.c_int, C.c_int, C.c_int, P, C.c_uint64]
@@ -392,7 +393,7 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_device_index", "
                     "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_last_deferred", "aqc_kernel_ms", "aqc_timing_reset",
                     "aqc_timing_mean", "aqc_get_counters",
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
-                    "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_compress", "aqc_fetch_gz", "aqc_gunzip_dev", "aqc_host_alloc",
+                    "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_fetch_streams", "aqc_compress", "aqc_fetch_gz", "aqc_gunzip_dev", "aqc_host_alloc",
                     "aqc_host_free",
                     "aqc_pipe_create", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
                     "aqc_host_count_newlines", "aqc_bgzf_compress", "aqc_pipe_split",

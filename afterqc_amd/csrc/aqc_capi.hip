@@ -87,7 +87,17 @@ struct Slot {
     bool compressed = false;
     bool framed = false, formatted = false;
     hipEvent_t ev_main = nullptr, ev_qc = nullptr;     // ordering between the slot's stream and the context's QC stream
-    bool qc_pending = false;                           // QC kernels of this slot may still run on the QC stream
+    // QC kernels of this slot may still run on the QC stream: `gen` counts the aqc_qc_stat calls (bumped AFTER ev_qc is recorded),
+    // `synced` how many of them somebody has waited for.  Two threads may look at one slot at a time — the thread that drives
+    // it and another thread's aqc_get_qc / aqc_get_kmers, which synchronise every slot (the round-3 advisory: a plain flag that
+    // either of them cleared could swallow the other's newer launch).  A waiter only ever marks what it has seen.
+    struct QcGen {
+        std::atomic<uint64_t> gen{0}, synced{0};
+        QcGen() = default;
+        QcGen(const QcGen&) {}
+        QcGen& operator=(const QcGen&) { return *this; }
+        bool pending() const { return synced.load(std::memory_order_acquire) < gen.load(std::memory_order_acquire); }
+    } qc;
     aqc_text_chunk last_chunk{};   // what the slot's arenas hold (aqc_reframe)
     uint8_t last_byte[2] = {'\n', '\n'};
     uint32_t max_len = 0;
@@ -124,9 +134,13 @@ static hipEvent_t launch_event(Slot& s, int k, int which) {
 // context's QC stream, those too
 static hipError_t slot_sync(Slot& s) {
     hipError_t e = hipStreamSynchronize(s.stream);
-    if (e == hipSuccess && s.qc_pending) {
-        e = hipEventSynchronize(s.ev_qc);
-        s.qc_pending = false;
+    const uint64_t g = s.qc.gen.load(std::memory_order_acquire);
+    if (e == hipSuccess && s.qc.synced.load(std::memory_order_acquire) < g) {
+        e = hipEventSynchronize(s.ev_qc);          // (waits for the event's LATEST record: generation g or a newer one)
+        if (e == hipSuccess) {
+            uint64_t seen = s.qc.synced.load(std::memory_order_relaxed);
+            while (seen < g && !s.qc.synced.compare_exchange_weak(seen, g, std::memory_order_release)) { }
+        }
     }
     return e;
 }
@@ -507,7 +521,7 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
     aqc_config cfg = c->cfg;
     if (!cfg.paired) cfg.no_overlap = 1;
     DevStats st{c->counters, c->ovl_hist, c->dist_hist, s->status};
-    if (s->qc_pending) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_qc, 0));      // (statRead of the previous run still reads the results)
+    if (s->qc.pending()) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_qc, 0));      // (statRead of the previous run still reads the results)
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_FILTER_OVERLAP, 0), s->stream));
     // lane-per-pair kernel whenever its preconditions hold; the general wave-per-record kernel otherwise
     const int thr = cfg.qualified_quality_phred + 33;
@@ -646,7 +660,7 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 1), qs));
     HIP_TRY(hipEventRecord(s->ev_qc, qs));
-    s->qc_pending = true;
+    s->qc.gen.fetch_add(1, std::memory_order_release);
     s->timed[AQC_K_QC_STAT] = !s->collecting;
     return 0;
 }
@@ -696,7 +710,17 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
     }
     const uint64_t all_tiles = tiles[0] + (paired ? tiles[1] : 0);
     if (s->t_tile[0].reserve(sizeof(unsigned long long) * (all_tiles + 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
-    unsigned long long h_tot[2] = {0, 0};
+    // 2. ... the four lines of every complete group, the lock-step record count, the bytes consumed: all queued behind the index
+    //    pass without asking the host for anything — the kernels read the line totals where the index pass left them, their grids
+    //    are sized for the most lines the chunk could hold.  ONE copy back (FrameOut), ONE wait per chunk.
+    const FrameMeta init{0xffffffffu, 0u, 0xffffffffu, 0u};
+    FrameMeta h_meta[2] = {init, init};
+    FrameOut fo{};
+    FrameOut* d_out = (FrameOut*)((uint8_t*)s->t_scratch.p + 128);
+    uint32_t virt[2] = {0, 0};
+    for (int k = 0; k < nf; k++)      // an unterminated last line of the file is a line (readline() returns it); it may end in blanks
+        if (final_[k] && bytes[k] > 0 && s->last_byte[k] != '\n') virt[k] = (uint32_t)bytes[k] | LINE_WS;
+    const bool bubble = c->has_cfg && c->cfg.debubble;
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIP_TRY(hipMemsetAsync(s->t_tile[0].p, 0, sizeof(unsigned long long) * (all_tiles + 1), s->stream));
         IndexFile f[2] = {};
@@ -708,66 +732,61 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
         hipLaunchKernelGGL(text_index_kernel, dim3((unsigned)all_tiles), dim3(TXT_BLOCK), 0, s->stream, f[0], f[1],
                            (unsigned long long*)s->t_tile[0].p, (unsigned int*)((unsigned long long*)s->t_tile[0].p + all_tiles));
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long) * nf, hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(slot_sync(*s));
-        bool fits = true;
-        for (int k = 0; k < nf; k++)
-            if (h_tot[k] > cap[k]) {
-                fits = false;
-                cap[k] = h_tot[k];
-                if (s->t_line_end[k].reserve(sizeof(uint32_t) * (cap[k] + 2))) return fail(AQC_ERR_HIP, "hipMalloc failed");
-            }
-        if (fits) break;
-    }
-    // 2. the four lines of every complete group
-    uint64_t lines[2] = {0, 0}, nrec[2] = {0, 0};
-    const FrameMeta init{0xffffffffu, 0u, 0xffffffffu, 0u};
-    FrameMeta h_meta[2] = {init, init};
-    HIP_TRY(hipMemcpyAsync(d_meta, h_meta, sizeof(h_meta), hipMemcpyHostToDevice, s->stream));
-    for (int k = 0; k < nf; k++) {
-        lines[k] = h_tot[k];
-        // an unterminated last line of the file is a line (readline() returns it)
-        const bool virt = final_[k] && bytes[k] > 0 && s->last_byte[k] != '\n';
-        if (virt) {
-            const uint32_t end = (uint32_t)bytes[k] | LINE_WS;          // (may end in blanks: let the framing kernel look)
-            HIP_TRY(hipMemcpyAsync((uint32_t*)s->t_line_end[k].p + lines[k], &end, sizeof(end), hipMemcpyHostToDevice, s->stream));
-            HIP_TRY(slot_sync(*s));      // `end` lives on this stack frame
-            lines[k] += 1;
-        }
-        nrec[k] = lines[k] / 4;
-        const uint64_t m = nrec[k] ? nrec[k] : 1;
-        if (seq_off[k]->reserve(4 * m) || qual_off[k]->reserve(4 * m) || seq_len[k]->reserve(4 * m) || s->t_name_off[k].reserve(4 * m) ||
-            s->t_name_len[k].reserve(4 * m) || s->t_plus_off[k].reserve(4 * m) || s->t_plus_len[k].reserve(4 * m) ||
-            s->t_qual_len[k].reserve(4 * m))
-            return fail(AQC_ERR_HIP, "hipMalloc failed");
-        if (nrec[k]) {
+        HIP_TRY(hipMemcpyAsync(d_meta, h_meta, sizeof(h_meta), hipMemcpyHostToDevice, s->stream));
+        uint64_t rec_cap = 0;
+        for (int k = 0; k < nf; k++) {
+            const uint64_t m = (cap[k] + 1) / 4 + 1;            // records the line table could describe
+            rec_cap = std::max(rec_cap, m);
+            if (seq_off[k]->reserve(4 * m) || qual_off[k]->reserve(4 * m) || seq_len[k]->reserve(4 * m) || s->t_name_off[k].reserve(4 * m) ||
+                s->t_name_len[k].reserve(4 * m) || s->t_plus_off[k].reserve(4 * m) || s->t_plus_len[k].reserve(4 * m) ||
+                s->t_qual_len[k].reserve(4 * m))
+                return fail(AQC_ERR_HIP, "hipMalloc failed");
             FramedFile ff{(uint32_t*)seq_off[k]->p, (uint32_t*)qual_off[k]->p, (uint32_t*)seq_len[k]->p, (uint32_t*)s->t_name_off[k].p,
                           (uint32_t*)s->t_name_len[k].p, (uint32_t*)s->t_plus_off[k].p, (uint32_t*)s->t_plus_len[k].p,
                           (uint32_t*)s->t_qual_len[k].p};
-            hipLaunchKernelGGL(frame_records_kernel, dim3((unsigned)((nrec[k] + TXT_BLOCK - 1) / TXT_BLOCK)), dim3(TXT_BLOCK), 0, s->stream,
-                               (const uint8_t*)tbase[k], (const uint32_t*)s->t_line_end[k].p, nrec[k], ff, d_meta + k);
+            hipLaunchKernelGGL(frame_records_kernel, dim3((unsigned)((m + TXT_BLOCK - 1) / TXT_BLOCK)), dim3(TXT_BLOCK), 0, s->stream,
+                               (const uint8_t*)tbase[k], (const uint32_t*)s->t_line_end[k].p, (const unsigned long long*)(d_tot + k), virt[k], ff, d_meta + k);
         }
+        hipLaunchKernelGGL(frame_finish_kernel, dim3(1), dim3(1), 0, s->stream, (const unsigned long long*)d_tot, (const FrameMeta*)d_meta,
+                           (const uint32_t*)s->t_line_end[0].p, (const uint32_t*)(paired ? s->t_line_end[1].p : s->t_line_end[0].p), (const uint32_t*)s->len1.p,
+                           virt[0], virt[1], (unsigned long long)bytes[0], (unsigned long long)bytes[1], nf, (unsigned long long)ch->max_records, d_out);
+        if (bubble) {
+            // lane / tile / x / y out of the R1 names (preprocesser.py:180-192) for the bubble filter
+            for (int k = 0; k < 5; k++)
+                if (s->aux[k].reserve((k < 4 ? sizeof(int32_t) : 1) * rec_cap)) return fail(AQC_ERR_HIP, "hipMalloc failed");
+            hipLaunchKernelGGL(parse_names_kernel, dim3((unsigned)((rec_cap + TXT_BLOCK - 1) / TXT_BLOCK)), dim3(TXT_BLOCK), 0, s->stream,
+                               (const uint8_t*)tbase[0], (const uint32_t*)s->t_name_off[0].p, (const uint32_t*)s->t_name_len[0].p, (const unsigned long long*)&d_out->n,
+                               (int32_t*)s->aux[0].p, (int32_t*)s->aux[1].p, (int32_t*)s->aux[2].p, (int32_t*)s->aux[3].p,
+                               (uint8_t*)s->aux[4].p);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&fo, d_out, sizeof(fo), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(slot_sync(*s));
+        // FASTQ lines average ~90 bytes; a chunk with more lines than the table was sized for (counted, not written) is done again
+        bool fits = true;
+        for (int k = 0; k < nf; k++) {
+            const uint64_t real = fo.lines[k] - (virt[k] ? 1 : 0);
+            if (real > cap[k]) {
+                fits = false;
+                cap[k] = real;
+                if (s->t_line_end[k].reserve(sizeof(uint32_t) * (cap[k] + 2))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+            }
+        }
+        if (fits) break;
     }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_meta, d_meta, sizeof(h_meta), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(slot_sync(*s));
     // 3. lock-step record count (preprocesser.py:412-429)
-    uint64_t avail[2] = {0, 0};
-    for (int k = 0; k < nf; k++) avail[k] = h_meta[k].first_empty < nrec[k] ? h_meta[k].first_empty : nrec[k];
-    uint64_t n = avail[0];
-    if (paired && avail[1] < n) n = avail[1];
-    if (ch->max_records < n) n = ch->max_records;
+    const uint64_t n = fo.n;
     for (int k = 0; k < nf; k++)
-        if (h_meta[k].first_mismatch < n)
+        if (fo.first_mismatch[k] < n)
             return fail(AQC_ERR_ARG, "malformed FASTQ: sequence and quality lines differ in length (read %d, record %u of the chunk)", k + 1,
-                        h_meta[k].first_mismatch);
+                        fo.first_mismatch[k]);
     memset(info, 0, sizeof(*info));
     info->n = n;
-    info->avail1 = avail[0];
-    info->avail2 = avail[1];
-    info->eof1 = h_meta[0].first_empty < nrec[0];
-    info->eof2 = paired && h_meta[1].first_empty < nrec[1];
-    info->max_len = h_meta[0].max_len > h_meta[1].max_len ? h_meta[0].max_len : h_meta[1].max_len;
+    info->avail1 = fo.avail[0];
+    info->avail2 = fo.avail[1];
+    info->eof1 = (int32_t)fo.eof[0];
+    info->eof2 = paired ? (int32_t)fo.eof[1] : 0;
+    info->max_len = fo.max_len;
     // 4. slot view: the text IS the arena, every kernel reads the records in place
     DevBatch v{};
     v.n = n;
@@ -779,15 +798,7 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
         v.off2 = (const uint32_t*)s->off2.p; v.qoff2 = (const uint32_t*)s->qoff2.p; v.len2 = (const uint32_t*)s->len2.p;
     }
     if (s->results.reserve(sizeof(aqc_result) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
-    if (c->has_cfg && c->cfg.debubble) {
-        // lane / tile / x / y out of the R1 names (preprocesser.py:180-192) for the bubble filter
-        for (int k = 0; k < 5; k++)
-            if (s->aux[k].reserve((k < 4 ? sizeof(int32_t) : 1) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
-        if (n)
-            hipLaunchKernelGGL(parse_names_kernel, dim3((unsigned)((n + TXT_BLOCK - 1) / TXT_BLOCK)), dim3(TXT_BLOCK), 0, s->stream,
-                               (const uint8_t*)tbase[0], (const uint32_t*)s->t_name_off[0].p, (const uint32_t*)s->t_name_len[0].p, n,
-                               (int32_t*)s->aux[0].p, (int32_t*)s->aux[1].p, (int32_t*)s->aux[2].p, (int32_t*)s->aux[3].p,
-                               (uint8_t*)s->aux[4].p);
+    if (bubble) {
         v.aux_lane = (const int32_t*)s->aux[0].p; v.aux_tile = (const int32_t*)s->aux[1].p;
         v.aux_x = (const int32_t*)s->aux[2].p; v.aux_y = (const int32_t*)s->aux[3].p; v.aux_ok = (const uint8_t*)s->aux[4].p;
     }
@@ -797,16 +808,8 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
     s->raw_max_len = info->max_len;
     s->max_len = info->max_len;
     // 5. bytes consumed by the n records (+ R1's next sequence length for the TOTAL_BASES quirk)
-    uint32_t h_end[2] = {0, 0}, h_next = 0;
-    if (n) {
-        for (int k = 0; k < nf; k++)
-            HIP_TRY(hipMemcpyAsync(&h_end[k], (const uint32_t*)s->t_line_end[k].p + (4 * n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    }
-    if (avail[0] > n) HIP_TRY(hipMemcpyAsync(&h_next, (const uint32_t*)s->len1.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(slot_sync(*s));
-    uint64_t consumed[2] = {0, 0};
-    for (int k = 0; k < nf; k++)
-        if (n) consumed[k] = (uint64_t)(h_end[k] & LINE_POS) + 1 < bytes[k] ? (uint64_t)(h_end[k] & LINE_POS) + 1 : bytes[k];
+    const uint64_t consumed[2] = {fo.consumed[0], fo.consumed[1]};
+    const uint32_t h_next = fo.next_len1;
     info->consumed1 = consumed[0];
     info->consumed2 = consumed[1];
     info->next_len1 = h_next;
@@ -953,8 +956,8 @@ int aqc_compress(aqc_ctx* c, int slot, int32_t level, uint64_t gz_bytes_out[6]) 
         gz_bytes_out[q] = 0;
     }
     J.first_block[6] = n_members;
-    s->compressed = true;
-    if (n_members == 0) return 0;
+    // (`compressed` is set once the streams exist: an error on the way must not let aqc_fetch_gz hand out empty streams)
+    if (n_members == 0) { s->compressed = true; return 0; }
     if (s->g_stage.reserve((size_t)n_members * GZ_SLOT) || s->g_sizes.reserve(4 * (size_t)n_members) || s->g_offsets.reserve(8 * (size_t)n_members) ||
         s->g_total.reserve(64) || s->g_hist.reserve(6 * 320 * 4) || s->g_code.reserve(6 * sizeof(GzCodebookDev)))
         return fail(AQC_ERR_HIP, "hipMalloc failed");
@@ -989,7 +992,9 @@ int aqc_compress(aqc_ctx* c, int slot, int32_t level, uint64_t gz_bytes_out[6]) 
         s->g_bytes[q] = tot[q];
         gz_bytes_out[q] = tot[q];
     }
-    return check_status(*s);
+    rc = check_status(*s);
+    s->compressed = rc == 0;
+    return rc;
 }
 
 int aqc_fetch_gz(aqc_ctx* c, int slot, int file, int stream, uint8_t* dst, uint64_t cap) {
@@ -1022,7 +1027,7 @@ constexpr uint32_t GZB_RATIO_CAP = 20;
 
 class DeviceInflate : public aqcgz::SectionOffload {
 public:
-    DeviceInflate(int device, size_t group_bytes) : device_(device), group_bytes_(std::min<size_t>(std::max<size_t>(group_bytes, 1u << 20), 192u << 20)) {}
+    DeviceInflate(int device, size_t group_bytes) : device_(device), group_bytes_(std::min<size_t>(std::max<size_t>(group_bytes, 1u << 20), 448u << 20)) {}
     ~DeviceInflate() override {
         {
             std::lock_guard<std::mutex> g(mu_);
@@ -1031,7 +1036,7 @@ public:
         cv_.notify_all();
         for (auto& l : lanes_) if (l.th.joinable()) l.th.join();
         (void)hipSetDevice(device_);
-        for (auto& l : lanes_) l.release();
+        for (auto& l : lanes_) { l.release(); if (l.stage) aqc_host_free(l.stage); }
         for (auto& a : arenas_) if (a.p) aqc_host_free(a.p);
     }
     bool start() {
@@ -1098,10 +1103,12 @@ private:
         hipEvent_t ev[6] = {};
         std::unique_ptr<Group> job;
         DevBuf comp, tile_cnt, tile_cand, n_cand, c_start, c_end, c_nsym, c_flags, c_symoff, c_symcap, blk_sym, tables;
-        DevBuf s_in, s_out, s_blocks, s_sym;
+        DevBuf s_in, s_out, s_blocks, s_sym, s_off;
+        uint8_t* stage = nullptr;          // page-locked copy of the group's compressed bytes (the file itself is a pageable mapping)
+        size_t stage_cap = 0;
         void release() {
             if (stream) (void)hipStreamSynchronize(stream);
-            DevBuf* b[] = {&comp, &tile_cnt, &tile_cand, &n_cand, &c_start, &c_end, &c_nsym, &c_flags, &c_symoff, &c_symcap, &blk_sym, &tables, &s_in, &s_out, &s_blocks, &s_sym};
+            DevBuf* b[] = {&comp, &tile_cnt, &tile_cand, &n_cand, &c_start, &c_end, &c_nsym, &c_flags, &c_symoff, &c_symcap, &blk_sym, &tables, &s_in, &s_out, &s_blocks, &s_sym, &s_off};
             for (DevBuf* x : b) x->release();
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
@@ -1178,14 +1185,32 @@ private:
         const uint32_t cand_cap = (uint32_t)(span / 4096 + 256);
         uint64_t sec_max = 0;
         for (int k = 0; k < n; ++k) sec_max = std::max<uint64_t>(sec_max, (G.stop[k] - G.nominal[k]) >> 3);
-        const uint32_t s_symcap = (uint32_t)((sec_max * 12 + (2u << 20) + 7) & ~(uint64_t)7);
+        const uint32_t s_symcap = (uint32_t)std::min<uint64_t>((sec_max * 24 + (2u << 20) + 7) & ~(uint64_t)7, 0xfffffff0u);
+        const uint64_t s_sym_total = (uint64_t)span * 12 + (uint64_t)n * 64 + (1u << 20);
         const uint64_t blk_sym_cap = (uint64_t)span * GZB_RATIO_CAP + (uint64_t)cand_cap * 4104;
         if (L.comp.reserve(span + 256) || L.tile_cnt.reserve(4ull * n_tiles) || L.tile_cand.reserve(4ull * n_tiles * GZB_TILE_CAND) || L.n_cand.reserve(64) ||
             L.c_start.reserve(4ull * cand_cap) || L.c_end.reserve(4ull * cand_cap) || L.c_nsym.reserve(4ull * cand_cap) || L.c_flags.reserve(4ull * cand_cap) ||
             L.c_symoff.reserve(8ull * cand_cap) || L.c_symcap.reserve(4ull * cand_cap) || L.blk_sym.reserve(2ull * blk_sym_cap + 64) ||
-            L.tables.reserve(4ull * cand_cap * GZB_TAB_WORDS) || L.s_in.reserve(12ull * n) || L.s_out.reserve(16ull * n) ||
-            L.s_blocks.reserve(12ull * n * GZB_SEC_BLOCKS) || L.s_sym.reserve(2ull * n * s_symcap + 64))
+            L.tables.reserve(4ull * cand_cap * GZB_TAB_WORDS) || L.s_in.reserve(12ull * n) || L.s_out.reserve(16ull * n) || L.s_off.reserve(8ull * (n + 1)) ||
+            L.s_blocks.reserve(12ull * n * GZB_SEC_BLOCKS) || L.s_sym.reserve(2ull * s_sym_total + 64))
             return false;
+        // the compressed bytes: out of the (pageable, possibly not yet faulted-in) file mapping into page-locked memory with a few
+        // threads side by side, then one DMA — a copy straight from the mapping runs at the page-fault rate of one thread
+        if (L.stage_cap < span) {
+            if (L.stage) aqc_host_free(L.stage);
+            L.stage_cap = span + span / 8 + (1u << 20);
+            L.stage = (uint8_t*)aqc_host_alloc(L.stage_cap);
+            if (!L.stage) { L.stage_cap = 0; return false; }
+        }
+        {
+            const int T = span > (8u << 20) ? 4 : 1;
+            std::vector<std::thread> th;
+            const size_t per = (span + T - 1) / T;
+            for (int t = 1; t < T; ++t)
+                th.emplace_back([&, t] { const size_t a = std::min(span, t * per), b = std::min(span, a + per); memcpy(L.stage + a, G.data + byte0 + a, b - a); });
+            memcpy(L.stage, G.data + byte0, std::min(span, per));
+            for (auto& x : th) x.join();
+        }
         // section table: nominal, stop, exact (bits relative to the window)
         std::vector<uint32_t> sin(3 * (size_t)n);
         for (int k = 0; k < n; ++k) {
@@ -1194,7 +1219,7 @@ private:
             sin[2 * n + k] = G.exact[k];
         }
         GZB_TRY(hipEventRecord(L.ev[0], L.stream));
-        GZB_TRY(hipMemcpyAsync(L.comp.p, G.data + byte0, span, hipMemcpyHostToDevice, L.stream));
+        GZB_TRY(hipMemcpyAsync(L.comp.p, L.stage, span, hipMemcpyHostToDevice, L.stream));
         GZB_TRY(hipMemsetAsync((uint8_t*)L.comp.p + span, 0, 256, L.stream));
         GZB_TRY(hipMemcpyAsync(L.s_in.p, sin.data(), 12ull * n, hipMemcpyHostToDevice, L.stream));
         GzbJob J{};
@@ -1206,7 +1231,7 @@ private:
         J.ratio_cap = GZB_RATIO_CAP; J.tables = (uint32_t*)L.tables.p;
         J.n_sec = (uint32_t)n; J.s_nominal = (const uint32_t*)L.s_in.p; J.s_stop = J.s_nominal + n; J.s_exact = J.s_nominal + 2 * n;
         J.s_start = (uint32_t*)L.s_out.p; J.s_end = J.s_start + n; J.s_nsym = J.s_start + 2 * n; J.s_nblk = J.s_start + 3 * n;
-        J.s_blocks = (uint32_t*)L.s_blocks.p; J.s_sym = (uint16_t*)L.s_sym.p; J.s_symcap = s_symcap;
+        J.s_blocks = (uint32_t*)L.s_blocks.p; J.s_off = (uint64_t*)L.s_off.p; J.s_sym = (uint16_t*)L.s_sym.p; J.s_sym_total = s_sym_total; J.s_symcap = s_symcap;
         GZB_TRY(hipEventRecord(L.ev[1], L.stream));
         hipLaunchKernelGGL(gzb_scan_kernel, dim3(n_tiles), dim3(GZB_SCAN_THREADS), 0, L.stream, J);
         hipLaunchKernelGGL(gzb_compact_kernel, dim3(1), dim3(1024), 0, L.stream, J);
@@ -1214,42 +1239,35 @@ private:
         hipLaunchKernelGGL(gzb_decode_kernel, dim3((cand_cap + GZB_DEC_THREADS - 1) / GZB_DEC_THREADS), dim3(GZB_DEC_THREADS), 0, L.stream, J);
         GZB_TRY(hipEventRecord(L.ev[3], L.stream));
         hipLaunchKernelGGL(gzb_chain_kernel, dim3((n + 63) / 64), dim3(64), 0, L.stream, J);
+        hipLaunchKernelGGL(gzb_place_kernel, dim3(1), dim3(1), 0, L.stream, J);
         hipLaunchKernelGGL(gzb_gather_kernel, dim3(n), dim3(GZB_GATHER_THREADS), 0, L.stream, J);
         GZB_TRY(hipEventRecord(L.ev[4], L.stream));
         GZB_TRY(hipGetLastError());
+        // what each section became (start, end, symbols) and where its symbols are; then ALL symbols with one copy
         std::vector<uint32_t> sout(4 * (size_t)n);
+        std::vector<uint64_t> soff((size_t)n + 1);
         GZB_TRY(hipMemcpyAsync(sout.data(), L.s_out.p, 16ull * n, hipMemcpyDeviceToHost, L.stream));
+        GZB_TRY(hipMemcpyAsync(soff.data(), L.s_off.p, 8ull * (n + 1), hipMemcpyDeviceToHost, L.stream));
         GZB_TRY(hipStreamSynchronize(L.stream));
-        // the symbols of the sections that found a start, packed into one arena
-        std::vector<size_t> aoff((size_t)n, 0);
-        size_t need = 0;
-        for (int k = 0; k < n; ++k) {
-            if (sout[k] == GZB_NONE || sout[2 * n + k] == 0) continue;
-            aoff[k] = need;
-            need += ((size_t)sout[2 * n + k] * 2 + 63) & ~(size_t)63;
-        }
-        int ai = -1;
-        if (need) {
-            ai = take_arena(need);
-            if (ai < 0) return false;
-            for (int k = 0; k < n; ++k) {
-                if (sout[k] == GZB_NONE || sout[2 * n + k] == 0) continue;
-                if (hipMemcpyAsync(arenas_[ai].p + aoff[k], (const uint16_t*)L.s_sym.p + (size_t)k * s_symcap, (size_t)sout[2 * n + k] * 2, hipMemcpyDeviceToHost, L.stream) != hipSuccess) {
-                    std::lock_guard<std::mutex> g(mu_);
-                    arenas_[ai].filling = false;
-                    return false;
-                }
-            }
-        }
-        const bool ok = hipEventRecord(L.ev[5], L.stream) == hipSuccess && hipStreamSynchronize(L.stream) == hipSuccess;
+        const size_t need = (size_t)soff[n] * 2;
         int live = 0;
         for (int k = 0; k < n; ++k) if (sout[k] != GZB_NONE && sout[2 * n + k] != 0) ++live;
-        if (ai >= 0) {
-            std::lock_guard<std::mutex> g(mu_);
-            arenas_[ai].filling = false;
-            arenas_[ai].refs = ok ? live : 0;
+        int ai = -1;
+        bool ok = true;
+        if (need && live) {
+            ai = take_arena(need);
+            if (ai < 0) return false;
+            ok = hipMemcpyAsync(arenas_[ai].p, L.s_sym.p, need, hipMemcpyDeviceToHost, L.stream) == hipSuccess;
         }
-        if (ai >= 0 && !ok) cv_.notify_all();
+        ok = ok && hipEventRecord(L.ev[5], L.stream) == hipSuccess && hipStreamSynchronize(L.stream) == hipSuccess;
+        if (ai >= 0) {
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                arenas_[ai].filling = false;
+                arenas_[ai].refs = ok ? live : 0;
+            }
+            if (!ok) cv_.notify_all();
+        }
         if (!ok) return false;
         float ms[5] = {0, 0, 0, 0, 0};
         for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], L.ev[i], L.ev[i + 1]);
@@ -1261,7 +1279,7 @@ private:
                 r.found = true;
                 r.start_bit = byte0 * 8 + sout[k];
                 r.end_bit = byte0 * 8 + sout[n + k];
-                r.sym = (const uint16_t*)(arenas_[ai].p + aoff[k]);
+                r.sym = (const uint16_t*)arenas_[ai].p + soff[k];
                 r.n_sym = sout[2 * n + k];
                 r.token = new Token{ai};
             }
@@ -1303,7 +1321,7 @@ extern "C" {
 int aqc_gunzip_dev(int device, const uint8_t* gz, uint64_t size, uint8_t* out, uint64_t cap, uint64_t* n_out, uint64_t stats[8], int threads,
                    uint64_t section_bytes, uint64_t group_bytes) {
     if (!gz || !out || !n_out || !stats) return fail(AQC_ERR_ARG, "null argument");
-    std::unique_ptr<aqcgz::SectionOffload> off(aqcgz::make_device_offload(device, group_bytes ? (size_t)group_bytes : (64u << 20)));
+    std::unique_ptr<aqcgz::SectionOffload> off(aqcgz::make_device_offload(device, group_bytes ? (size_t)group_bytes : (256u << 20)));
     if (!off) return fail(AQC_ERR_HIP, "device gunzip: cannot set up device %d", device);
     uint64_t before[8], after[8];
     aqcgz::device_offload_stats(before);
@@ -1338,6 +1356,23 @@ int aqc_format(aqc_ctx* c, int slot, uint64_t n, int32_t store_overlap, uint64_t
 int aqc_format_plain(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]) {
     if (slot == verdict_slot) return fail(AQC_ERR_ARG, "aqc_format_plain: the verdicts must come from another slot");
     return format_impl(c, slot, verdict_slot, n, store_overlap, bytes_out);
+}
+
+int aqc_fetch_streams(aqc_ctx* c, int slot, int32_t gz, uint8_t* const dst[6], const uint64_t cap[6]) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!dst || !cap) return fail(AQC_ERR_ARG, "aqc_fetch_streams: null argument");
+    if (!s->formatted) return fail(AQC_ERR_STATE, "aqc_fetch_streams before aqc_format");
+    if (gz && !s->compressed) return fail(AQC_ERR_STATE, "aqc_fetch_streams(gz) before aqc_compress");
+    for (int q = 0; q < 6; ++q) {
+        const uint64_t nb = gz ? s->g_bytes[q] : s->f_bytes[q];
+        if (!nb) continue;
+        if (!dst[q] || nb > cap[q]) return fail(AQC_ERR_ARG, "aqc_fetch_streams: stream %d (%llu bytes) does not fit", q, (unsigned long long)nb);
+        HIP_TRY(hipMemcpyAsync(dst[q], gz ? s->g_packed[q].p : s->f_out[q].p, nb, hipMemcpyDeviceToHost, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return check_status(*s);
 }
 
 int aqc_fetch_text(aqc_ctx* c, int slot, int file, int stream, uint8_t* dst, uint64_t cap) {

@@ -88,6 +88,29 @@ __device__ __forceinline__ int wave_sum_u(int v) {
     return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 
+// Inclusive prefix sum / running maximum over the 64 lanes, in uniform control flow: four DPP row_shr steps scan the rows of 16
+// lanes (lanes shifted in from outside a row read 0), the three row totals come through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ int dpp_shr0(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ int wave_incl_sum(int v, int lane) {
+    v += dpp_shr0<0x111>(v);
+    v += dpp_shr0<0x112>(v);
+    v += dpp_shr0<0x114>(v);
+    v += dpp_shr0<0x118>(v);
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    return v + (row >= 1 ? t0 : 0) + (row >= 2 ? t1 : 0) + (row >= 3 ? t2 : 0);
+}
+__device__ __forceinline__ int wave_incl_max(int v, int lane) {      // (values >= 0)
+    v = max(v, dpp_shr0<0x111>(v));
+    v = max(v, dpp_shr0<0x112>(v));
+    v = max(v, dpp_shr0<0x114>(v));
+    v = max(v, dpp_shr0<0x118>(v));
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    return max(max(v, row >= 1 ? t0 : 0), max(row >= 2 ? t1 : 0, row >= 3 ? t2 : 0));
+}
+
 // 16 sequence bytes -> lo plane (2 bits/base: (c >> 1) & 3), e plane ('N' flag, bit 3 of the byte, on the odd bit)
 __device__ __forceinline__ void pack_dword(uint32_t d, uint32_t& lo8, uint32_t& e8) {
     lo8 = udot4((d >> 1) & 0x03030303u, 0x40100401u, 0u);
@@ -207,8 +230,13 @@ __device__ __forceinline__ uint32_t mm_word(uint32_t mlo0, uint32_t mlo1, uint32
 #ifndef AQC_PRIO1
 #define AQC_PRIO1 0
 #endif
+#ifndef AQC_COOP_VERIFY
+#define AQC_COOP_VERIFY 1      // 1: the survivors' diagonals are verified by the whole wave, a lane per (survivor, 16-base word); 0: every lane its own
+#endif
 #ifndef AQC_ABL
-#define AQC_ABL 0      // ablation builds only (tools/gpu_ablate.sh): 1 = no alphabet validation, 2 = no length masks
+#define AQC_ABL 0      // ablation builds only (tools/gpu_ablate.sh; results are WRONG, only instruction counts / times mean anything):
+                       // 1 no alphabet validation, 2 no length masks, 4 no polyX screen, 8 no diagonal scan, 16 no correction walk,
+                       // 32 no N count, 64 no phase 1 packing (loads only)
 #endif
 
 // what the barcode stage needs of aqc_config, decoded once per kernel (uniform): verify as 2-bit codes
@@ -745,7 +773,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         // ---- length (preprocesser.py:476-479)
         if (flag < 0 && len1 < Rb->cfg.seq_len_req) flag = AQC_BADLEN;
         // ---- polyX (preprocesser.py:482-490): run-length screen per read, exact check by the wave for the few hits
-        if (Rb->cfg.poly_size_limit > 0) {
+        if (Rb->cfg.poly_size_limit > 0 && !(AQC_ABL & 4)) {
             bool sus = false;
             if (o_run_req < 2) sus = len_own >= Rb->cfg.poly_size_limit;
             else {
@@ -774,6 +802,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 for (int j = 0; j < NW; ++j) any |= r[j];
                 sus = any != 0 && len_own >= Rb->cfg.poly_size_limit;
             }
+            if (AQC_ABL & 4) sus = false;
             bool poly = false;
             unsigned long long todo = __ballot(valid && !defer && flag < 0 && sus);
             while (todo) {
@@ -798,7 +827,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         // ---- low quality: read 1 only (preprocesser.py:498)
         if (flag < 0 && Rb->cfg.unqualified_base_limit > 0 && lq_cnt > Rb->cfg.unqualified_base_limit) flag = AQC_BADLQC;
         // ---- N (preprocesser.py:504-512)
-        if (Rb->cfg.n_base_limit > 0) {
+        if (Rb->cfg.n_base_limit > 0 && !(AQC_ABL & 32)) {
             int n_own = 0;
 #pragma unroll
             for (int j = 0; j < NW; ++j) n_own += __popc(own[NW + j]);
@@ -815,7 +844,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         if (PAIRED && !Rb->cfg.no_overlap) {
             // own candidates: offsets c = 0 .. len_own - 31, the own stream moving over the partner's prefix
             const int n_own = len_own > 30 ? len_own - 30 : 0;
-            bool scan = valid && !defer && flag < 0;
+            bool scan = valid && !defer && flag < 0 && !(AQC_ABL & 8);
             {
                 // the 16-base prefix test needs 16 columns on every diagonal
                 const bool short16 = scan && n_own > 0 && len_par < 16;
@@ -827,6 +856,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
             int from = 0;               // first own candidate still to be examined
             bool found = false;
             int f_off = 0, f_len = 0, f_tot = 0, f_p0 = 0, f_p1 = 0, f_p2 = 0;   // accepted candidate + its first mismatch columns
+            uint32_t f_wm = 0;          // (cooperative verification: which 16-base words of the accepted diagonal hold a mismatch)
             const uint32_t F = par[0];                          // partner's first 16 bases
             // mismatches of one diagonal — the own stream from base c on against the partner's first QL bases: their number,
             // how many lie in columns 0..49, and the columns of the first three (the correction walk needs them)
@@ -890,6 +920,73 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 }
                 PROF(4);
                 // exact verification of up to three survivors per lane, in order (util.py:177-184 / 200-207)
+#if AQC_COOP_VERIFY
+                // By the WHOLE wave: a diagonal is QL / 16 words long — two for the ~30-base overlaps of a long insert, ten for an
+                // adapter read-through — and a lane that walks its own diagonal keeps the other 63 waiting for the longest one
+                // (measured: scan + verification 36 of the kernel's 78 vector instructions per pair, the scan itself 16).  So the
+                // (survivor, word) pairs of a round become tasks dealt to consecutive lanes: the owners' word counts are scanned,
+                // each owner marks its first task lane in the wave's staging bytes, a running maximum tells every lane whose word
+                // it has, the owner's candidate comes over the LDS crossbar (ds_bpermute), and the word's mismatch count goes to
+                // the owner with one LDS atomic (into the row's low-quality words, which nobody needs any more at this point).
+                // The mismatch COLUMNS the correction walk needs are looked up later, by the lanes that walk, in the words this
+                // pass has flagged.
+#pragma nounroll
+                for (int v = 0; v < 3; ++v) {
+                    const int c = v == 0 ? s0 : v == 1 ? s1 : s2;
+                    const bool check = live && !found && c != NONE_CAND;
+                    if (!__ballot(check)) break;
+                    const int QL = min(len_own - c, len_par);
+                    const int nwv = check ? (QL + 15) >> 4 : 0;
+                    const int desc = c | (QL << 10);
+                    uint32_t* const acc = pr + WL::LQ0 + 2 * role;
+                    bool pend = check;
+                    while (__ballot(pend)) {
+                        // owners whose words fit the 64 lanes of this sub-round (a prefix of the pending ones)
+                        const int incl = wave_incl_sum(pend ? nwv : 0, lane);
+                        const bool now = pend && incl <= WAVE;
+                        const unsigned long long nowm = __ballot(now);
+                        const int n_task = __builtin_amdgcn_readlane(incl, 63 - __builtin_clzll(nowm));
+                        L.stage[lane] = 0;
+                        __builtin_amdgcn_wave_barrier();
+                        if (now) {
+                            L.stage[incl - nwv] = (uint8_t)(lane + 1);
+                            acc[0] = 0; acc[1] = 0;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        const int mark = (int)L.stage[lane];
+                        const int key = wave_incl_max(mark ? ((lane << 8) | mark) : 0, lane);
+                        const bool task = lane < n_task;
+                        const int owner = task ? (key & 0xff) - 1 : 0;
+                        const int j = task ? lane - (key >> 8) : 0;
+                        const int od = __builtin_amdgcn_ds_bpermute(owner << 2, desc);
+                        const int oc = od & 0x3ff, oq = od >> 10;
+                        uint32_t* const orow = L.planes[owner >> 1];
+                        const uint32_t* const oown = orow + ((owner & 1) ? 2 * NW : 0);
+                        const uint32_t* const opar = orow + ((owner & 1) ? 0 : 2 * NW);
+                        const int k = (oc >> 4) + j;
+                        const uint32_t sh = (uint32_t)(oc & 15) * 2;
+                        const bool in1 = k + 1 < NW;
+                        const uint32_t lo0 = oown[min(k, NW - 1)], lo1 = in1 ? oown[min(k + 1, NW - 1)] : 0u;
+                        const uint32_t e0 = oown[NW + min(k, NW - 1)], e1 = in1 ? oown[NW + min(k + 1, NW - 1)] : 0u;
+                        const uint32_t mm = task ? mm_word(lo0, lo1, e0, e1, sh, opar[min(j, NW - 1)], opar[NW + min(j, NW - 1)], min(max(oq - 16 * j, 0), 16)) : 0u;
+                        const uint32_t cnt_all = (uint32_t)__popc(mm);
+                        const uint32_t cnt50 = j < 3 ? cnt_all : j == 3 ? (uint32_t)__popc(mm & 0xFu) : 0u;      // columns 0..49
+                        if (mm) {
+                            uint32_t* const oacc = orow + WL::LQ0 + 2 * (owner & 1);
+                            atomicAdd(&oacc[0], cnt_all | (cnt50 << 16));
+                            atomicOr(&oacc[1], 1u << j);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        if (now) {
+                            const uint32_t a0 = acc[0];
+                            const int tot = (int)(a0 & 0xffffu), c50 = (int)(a0 >> 16);
+                            if (tot < 3 || (c50 < 3 && QL >= 52)) { found = true; f_off = c; f_len = QL; f_tot = tot; f_wm = acc[1]; }
+                            pend = false;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+#else
 #pragma unroll
                 for (int v = 0; v < 3; ++v) {
                     const int c = v == 0 ? s0 : v == 1 ? s1 : s2;
@@ -905,6 +1002,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                         }
                     }
                 }
+#endif
                 PROF(5);
                 // a lane whose three survivors all failed and that may have more continues after the third one
                 const bool more = live && !found && s2 != NONE_CAND;
@@ -967,7 +1065,36 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 }
             }
             const int w_n = min(dist, w_tot);                 // mismatches the walk handles
-            walker = walk_pair && i_found_it;
+            walker = walk_pair && i_found_it && !(AQC_ABL & 16);
+#if AQC_COOP_VERIFY
+            {
+                // the columns of the walker's first w_n mismatches: only the words the verification flagged are looked at (a pair
+                // walked along a diagonal of its own got its columns from diag_mismatches above)
+                const bool lookup = walker && !(walk_pair && !c_adapter_read && ovl != len1 - offset);
+                uint32_t wm = lookup ? f_wm : 0u;
+                int have = 0;
+                while (__ballot(wm != 0 && have < w_n)) {
+                    const bool act = wm != 0 && have < w_n;
+                    const int j = act ? __builtin_ctz(wm) : 0;
+                    wm &= wm - 1;
+                    const int k = (f_off >> 4) + j;
+                    const uint32_t sh = (uint32_t)(f_off & 15) * 2;
+                    const bool in1 = k + 1 < NW;
+                    const uint32_t lo0 = own[min(k, NW - 1)], lo1 = in1 ? own[min(k + 1, NW - 1)] : 0u;
+                    const uint32_t e0 = own[NW + min(k, NW - 1)], e1 = in1 ? own[NW + min(k + 1, NW - 1)] : 0u;
+                    uint32_t mm = act ? mm_word(lo0, lo1, e0, e1, sh, par[min(j, NW - 1)], par[NW + min(j, NW - 1)], min(max(f_len - 16 * j, 0), 16)) : 0u;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        if (mm != 0 && have < 3) {
+                            const int col = 16 * j + ((__ffs((int)mm) - 1) >> 1);
+                            if (have == 0) f_p0 = col; else if (have == 1) f_p1 = col; else f_p2 = col;
+                            ++have;
+                            mm &= mm - 1;
+                        }
+                    }
+                }
+            }
+#endif
             if (__ballot(walker)) {
                 // Straight-line and in the streams' 2-bit codes (A 0, C 1, T 2, G 3; complement = code ^ 2): lanes that do not
                 // walk run along with column 0 and switch their results off.

@@ -389,7 +389,9 @@ void ParallelGunzip::top_up() {
             continue;
         }
         if (!offload_ || no_more) break;
-        const size_t per_group = std::max<size_t>(1, offload_->group_bytes() / section_bytes_);
+        // a group costs the device a fixed ~50 ms (one block is decoded by one lane, start to end) plus its transfers, whatever its
+        // size: big groups are what makes it fast, but a file should still be several groups (two are in flight at a time)
+        const size_t per_group = std::max<size_t>(1, (offload_only_ ? offload_->group_bytes() : std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ / 4))) / section_bytes_);
         if (on_device >= 3 * per_group || !offload_->ready()) break;
         std::vector<std::shared_ptr<Section>> group;
         std::shared_ptr<Section> last;                       // the stream's last section runs to the end of the file: the pool's

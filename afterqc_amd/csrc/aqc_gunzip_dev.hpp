@@ -104,8 +104,10 @@ struct GzbJob {
     uint32_t* s_nsym;
     uint32_t* s_nblk;
     uint32_t* s_blocks;          // [n_sec][GZB_SEC_BLOCKS][3]: candidate (or GZB_STORED | length), source byte (stored), offset
-    uint16_t* s_sym;             // [n_sec][s_symcap]
-    uint32_t s_symcap;
+    uint64_t* s_off;             // [n_sec + 1] first symbol of each section in s_sym (gzb_place), [n_sec] = symbols in all
+    uint16_t* s_sym;             // the sections' symbols, packed (64-byte aligned starts): ONE copy takes them to the host
+    uint64_t s_sym_total;        // symbols s_sym holds
+    uint32_t s_symcap;           // most symbols one section may have
 };
 
 GZB_HD inline uint32_t gzb_len_base(uint32_t i) {
@@ -491,6 +493,19 @@ GZB_HD inline void gzb_chain_section(const GzbJob& J, uint32_t k) {
     J.s_nblk[k] = nb;
 }
 
+// where each section's symbols go in the packed buffer; a section that does not fit any more is dropped (the host decodes it)
+GZB_HD inline void gzb_place(const GzbJob& J) {
+    unsigned long long o = 0;
+    for (uint32_t k = 0; k < J.n_sec; ++k) {
+        J.s_off[k] = o;
+        if (J.s_start[k] == GZB_NONE) continue;
+        const unsigned long long n = ((unsigned long long)J.s_nsym[k] + 31ull) & ~31ull;
+        if (o + n > J.s_sym_total) { J.s_start[k] = GZB_NONE; J.s_nsym[k] = 0; J.s_nblk[k] = 0; continue; }
+        o += n;
+    }
+    J.s_off[J.n_sec] = o;
+}
+
 // symbol x of a block that begins `off` symbols into its section, for the section's stream dst: a marker j stands for section
 // position off - 32768 + j — in an earlier block (already in dst), or still before the section
 GZB_HD inline uint16_t gzb_rebase(uint32_t x, uint32_t off, const uint16_t* dst) {
@@ -661,11 +676,13 @@ __global__ __launch_bounds__(64) void gzb_chain_kernel(GzbJob J) {
     if (k < J.n_sec) gzb_chain_section(J, k);
 }
 
+__global__ void gzb_place_kernel(GzbJob J) { gzb_place(J); }
+
 // ---- a workgroup per section: the blocks' symbols as one stream, markers relative to the section ---------------------------------
 __global__ __launch_bounds__(GZB_GATHER_THREADS) void gzb_gather_kernel(GzbJob J) {
     const uint32_t k = blockIdx.x;
     const uint32_t nb = J.s_nblk[k];
-    uint16_t* const dst = J.s_sym + (size_t)k * J.s_symcap;
+    uint16_t* const dst = J.s_sym + J.s_off[k];
     const uint32_t* const blocks = J.s_blocks + (size_t)k * GZB_SEC_BLOCKS * 3u;
     for (uint32_t b = 0; b < nb; ++b) {
         const uint32_t w0 = blocks[3u * b], w1 = blocks[3u * b + 1], off = blocks[3u * b + 2];

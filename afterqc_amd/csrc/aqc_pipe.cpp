@@ -356,13 +356,17 @@ struct GzSource : Source {
             size_t p = pos, total = 0;
             bool foreign = false;
             while (p < size && total < (want - out) + (1u << 20)) {
-                if (map[p] == 0) { size_t q = p; while (q < size && map[q] == 0) ++q; if (q == size) { p = size; break; } }
+                // zero bytes between / behind members are padding (Python's gzip module, which upstream reads through, skips them)
+                while (p < size && map[p] == 0) ++p;
+                if (p == size) break;
                 if (!is_bgzf_header(map + p, size - p)) { foreign = true; break; }
                 const size_t bsize = (size_t)(map[p + 16] | (map[p + 17] << 8)) + 1;
                 if (bsize < 26 || p + bsize > size) { fail("truncated BGZF member"); break; }
                 const uint8_t* t = map + p + bsize - 8;
                 uint32_t crc, isz;
                 memcpy(&crc, t, 4); memcpy(&isz, t + 4, 4);
+                // (a BGZF member holds at most 64 KiB of data: a larger ISIZE is a damaged trailer, not a reason to allocate gigabytes)
+                if (isz > 65536u) { fail("corrupt BGZF member (ISIZE beyond 64 KiB)"); break; }
                 blks.push_back(Blk{p + 18, bsize - 18 - 8, (size_t)isz, total, crc});
                 total += isz;
                 p += bsize;
@@ -676,7 +680,7 @@ struct Run {
                 const char* e = getenv("AQC_GZ_DEVICE_IN");
                 if (!(e && e[0] == '0') && !P->gz_offload_tried[f] && !P->ctx.empty()) {
                     P->gz_offload_tried[f] = true;
-                    size_t group = 64u << 20;
+                    size_t group = 256u << 20;
                     if (const char* g = getenv("AQC_GZ_GROUP")) group = (size_t)std::max(1ll, atoll(g));
                     P->gz_offload[f].reset(aqcgz::make_device_offload(aqc_device_index(P->ctx[(size_t)f % P->ctx.size()]), group));
                 }
@@ -892,15 +896,19 @@ struct Run {
                 oc.gz = gz_on_device;
                 if (oc.gz && (rc = aqc_compress(c, slot, io->gzip_level, oc.gz_sizes))) { fail(rc, "aqc_compress: %s", aqc_last_error()); return; }
                 if (!gate_enter(dg, j.ticket, (uint64_t)P->slots)) return;
+                // the six streams with one wait (aqc_fetch_streams)
+                uint8_t* dstq[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                uint64_t capq[6] = {0, 0, 0, 0, 0, 0};
                 for (int q = 0; q < 6; ++q) {
                     if (!oc.sizes[q]) continue;
                     HostBuf& hb = P->wbufs[wid].out[set][q];
                     hb.ensure(oc.gz ? oc.gz_sizes[q] : oc.sizes[q]);
                     if (!hb.p) { gate_leave(dg); fail(AQC_ERR_HIP, "page-locked allocation failed"); return; }
-                    rc = oc.gz ? aqc_fetch_gz(c, slot, q / 3, q % 3, hb.p, hb.cap) : aqc_fetch_text(c, slot, q / 3, q % 3, hb.p, hb.cap);
-                    if (rc) { gate_leave(dg); fail(rc, "fetching an output stream: %s", aqc_last_error()); return; }
+                    dstq[q] = hb.p; capq[q] = hb.cap;
                 }
+                rc = aqc_fetch_streams(c, slot, oc.gz ? 1 : 0, dstq, capq);
                 gate_leave(dg);
+                if (rc) { fail(rc, "fetching the output streams: %s", aqc_last_error()); return; }
                 ns_fetch += now_ns() - tt;
                 oc.set = set;
                 set ^= 1;

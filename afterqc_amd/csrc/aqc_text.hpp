@@ -334,15 +334,23 @@ struct FramedFile {
     uint32_t* qual_len;      // bit 31: the byte behind the (stripped) quality line is its '\n'
 };
 
+// (the number of lines comes from the index pass's device-side total: nothing of it goes through the host first.  virt_end != 0:
+//  the file's unterminated last line ends at this virtual line end — readline() returns it — which is line number *d_total)
 __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t* __restrict__ text,
-                                                                  const uint32_t* __restrict__ line_end, uint64_t n_rec,
-                                                                  FramedFile out, FrameMeta* __restrict__ meta) {
+                                                                  const uint32_t* __restrict__ line_end, const unsigned long long* __restrict__ d_total,
+                                                                  uint32_t virt_end, FramedFile out, FrameMeta* __restrict__ meta) {
+    const uint64_t real = *d_total;
+    const uint64_t n_rec = (real + (virt_end ? 1u : 0u)) / 4;
+    if ((uint64_t)blockIdx.x * TXT_BLOCK >= n_rec) return;          // (the grid is sized for the most lines the chunk could hold)
     const uint64_t r = (uint64_t)blockIdx.x * TXT_BLOCK + threadIdx.x;
     const bool in = r < n_rec;
     const int lane = lane_id();
     // the record's four line ends in one 16-byte load; the end of the line before it is the neighbour lane's fourth
     uint4 le4 = make_uint4(0, 0, 0, 0);
-    if (in) le4 = reinterpret_cast<const uint4*>(line_end)[r];
+    if (in) {
+        le4 = reinterpret_cast<const uint4*>(line_end)[r];
+        if (virt_end && 4 * r + 3 == real) le4.w = virt_end;         // (a virtual line can only be the last line of the last record)
+    }
     uint32_t before = (uint32_t)__shfl_up((int)le4.w, 1, WAVE);
     if (lane == 0) before = (in && r > 0) ? line_end[4 * r - 1] : 0u;
     const uint32_t le[4] = {le4.x, le4.y, le4.z, le4.w};
@@ -393,6 +401,45 @@ __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t*
     }
 }
 
+// What aqc_frame reports, worked out on the device behind the framing kernels (one thread): the lock-step record count of
+// preprocesser.py:412-429, the bytes the n records take, R1's next sequence length.  The host reads it with ONE copy and ONE wait
+// per chunk (rounds 1 - 3: three round trips — line totals, frame meta, tail values).
+struct FrameOut {
+    unsigned long long n, avail[2], lines[2], consumed[2];
+    unsigned int eof[2], first_mismatch[2], max_len, next_len1;
+};
+
+__global__ void frame_finish_kernel(const unsigned long long* __restrict__ d_total, const FrameMeta* __restrict__ meta, const uint32_t* __restrict__ line_end0,
+                                    const uint32_t* __restrict__ line_end1, const uint32_t* __restrict__ seq_len0, uint32_t virt0, uint32_t virt1,
+                                    unsigned long long bytes0, unsigned long long bytes1, int nf, unsigned long long max_records, FrameOut* __restrict__ out) {
+    const uint32_t* const le[2] = {line_end0, line_end1};
+    const uint32_t virt[2] = {virt0, virt1};
+    const unsigned long long bytes[2] = {bytes0, bytes1};
+    FrameOut o{};
+    unsigned long long nrec[2] = {0, 0};
+    for (int k = 0; k < nf; ++k) {
+        o.lines[k] = d_total[k] + (virt[k] ? 1u : 0u);
+        nrec[k] = o.lines[k] / 4;
+        o.avail[k] = meta[k].first_empty < nrec[k] ? meta[k].first_empty : nrec[k];
+        o.eof[k] = meta[k].first_empty < nrec[k] ? 1u : 0u;
+        o.first_mismatch[k] = meta[k].first_mismatch;
+        o.max_len = meta[k].max_len > o.max_len ? meta[k].max_len : o.max_len;
+    }
+    unsigned long long n = o.avail[0];
+    if (nf == 2 && o.avail[1] < n) n = o.avail[1];
+    if (max_records < n) n = max_records;
+    o.n = n;
+    for (int k = 0; k < nf; ++k) {
+        if (!n) continue;
+        const unsigned long long i = 4 * n - 1;
+        const uint32_t e = (virt[k] && i == d_total[k]) ? virt[k] : le[k][i];
+        const unsigned long long end = (unsigned long long)(e & LINE_POS) + 1;
+        o.consumed[k] = end < bytes[k] ? end : bytes[k];
+    }
+    o.next_len1 = o.avail[0] > n ? seq_len0[n] : 0u;
+    *out = o;
+}
+
 // ---- Illumina read names for the bubble filter (preprocesser.py:155,176-192) ---------------------------------------
 // re.search(r'\S+\:\d+\:\S+\:\d+\:\d+\:\d+\:\d+', name), then items = match.split(':'), lane = int(items[3]),
 // tile = int(items[4][1:]), x = int(items[5]), y = int(items[6]).  The search is reproduced with the regex engine's
@@ -417,12 +464,12 @@ __device__ __forceinline__ bool parse_uint(const uint8_t* name, int a, int b, in
 }
 
 __global__ __launch_bounds__(TXT_BLOCK) void parse_names_kernel(const uint8_t* __restrict__ text, const uint32_t* __restrict__ name_off,
-                                                                const uint32_t* __restrict__ name_len, uint64_t n,
+                                                                const uint32_t* __restrict__ name_len, const unsigned long long* __restrict__ n_dev,
                                                                 int32_t* __restrict__ lane_out, int32_t* __restrict__ tile_out,
                                                                 int32_t* __restrict__ x_out, int32_t* __restrict__ y_out,
                                                                 uint8_t* __restrict__ ok_out) {
     const uint64_t r = (uint64_t)blockIdx.x * TXT_BLOCK + threadIdx.x;
-    if (r >= n) return;
+    if (r >= *n_dev) return;                              // (FrameOut::n: the grid is sized for the most records the chunk could hold)
     const uint8_t* name = text + name_off[r];
     const int len = (int)name_len[r];
     int m_s = -1, m_e = -1;

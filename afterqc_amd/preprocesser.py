@@ -502,6 +502,8 @@ class seqFilter:
                 with open(os.path.join(qc_dir, os.path.basename(opt.read1_file) + ".html"), "w") as f:
                     f.write(qcreporter.render(self.stat, figures, getattr(opt, "version", "")))
             except Exception as e:      # noqa: BLE001 — whatever it is, the run's results stand
+                if os.environ.get("AQC_REPORT_STRICT"):      # the test suites: a broken report must not pass unseen
+                    raise
                 print("afterqc_amd: the HTML report could not be written (%s: %s); outputs and %s are complete"
                       % (type(e).__name__, e, stat_path), file=sys.stderr)
                 self.timing["report_error"] = "%s: %s" % (type(e).__name__, e)

@@ -22,8 +22,11 @@ Other numbers on the same JSON line (never `value`):
                                `value`).  `roofline` is for its dominant kernel (fast_filter_overlap_kernel): HIP-event time
                                on the slot's stream, algorithmic bytes 4L+56 per pair.
   pinned_to_pinned_mreads_s    the pipe fed from / fetched into page-locked host memory (PCIe inclusive, no files)
-  file_to_file_gz              the pipe .gz -> .gz: ONE-member `gzip -2` inputs decoded by the host pool (aqc_gunzip.cpp), .gz
-                               members built on the device (--gz-runs; by default two runs when the input is the 1-GPU one)
+  file_to_file_gz              the pipe .gz -> .gz: ONE-member `gzip -2` inputs decoded by the host pool AND the GPU (groups of sections,
+                               a lane per deflate block: aqc_gunzip_dev.hpp; `gunzip_text_share_from_device`), .gz members built on the device (--gz-runs; by default two runs when the input is the 1-GPU one)
+  file_to_gz                   plain FASTQ in, .gz out (the outputs a third of the size: the file writers are not the bound)
+  multi_input_file_to_file     K (--inputs, default 2) independent inputs through K pipes at once on the same GPU: the reference's own
+                               parallelism is one seqFilter per input file (after.py:168-171), and K inputs write 4 K files
 `cpu_baseline` (N=1): the oracle (scalar C port of the reference loop) on one core over a bounded sample, checked against the
 GPU's verdicts; plus the same port on every host core and a pure-Python stand-in.
 """
@@ -106,6 +109,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with two rocprofv3 --pmc child runs (quote profiles/hbm_traffic.json)")
     ap.add_argument("--device-only", action="store_true", help="profiling runs (rocprofv3): only the HBM-resident device step, no pipe "
                     "runs; `value` is then the device step and says so")
+    ap.add_argument("--slots", type=int, default=3, help="slots (chunks in flight) per context of the pipe")
+    ap.add_argument("--inputs", type=int, default=2, help="K > 1: also run K independent file pairs through K pipes at once on the same GPU(s) — the "
+                    "reference's own fan-out, one seqFilter per input (after.py:168-171) — reported as multi_input_file_to_file (never `value`); 0 / 1 = skip")
     ap.add_argument("--contexts", type=int, default=1, help="contexts per device for the one-input pipe runs")
     ap.add_argument("--devices", default="", help="explicit device list for the one-input pipe runs, e.g. 0,0,0,0 (overrides --gpus / --contexts)")
     ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config5"],
@@ -161,7 +167,7 @@ def main():
     if args.workload == "config5":
         cfg.barcode = 1
 
-    eng = capi.Engine(device_index, 3)
+    eng = capi.Engine(device_index, max(3, args.slots))
     eng.set_config(cfg)
     eng.reset_stats()
 
@@ -280,20 +286,36 @@ def main():
         dev_list = [g for g in range(world) for _ in range(max(1, args.contexts))]
     n_ctx = len(dev_list)
     copies = max(1, world)                      # the one input holds `world` x the per-GPU share (weak scaling, one input)
-    pinned = f2f = f2f_gz = None
+    pinned = f2f = f2f_gz = f2gz = multi = None
     step_times = []
     pipe_reads = reads_per_gpu * copies
     if args.device_only:
         args.pipe_runs = 0
         args.warmup = args.steps = 0
-    if rank == 0:
+    # One input over N GPUs needs rank 0 to SEE the N devices.  When the launcher narrows every rank's visibility to its own GPU
+    # (HIP_VISIBLE_DEVICES per rank) that is impossible: then every rank runs its OWN pipe on its own GPU over its own share of
+    # the input (independent batches, as north_star's shards; files R<k>.rank<r>.*), and `value` = all ranks' reads / the slowest
+    # rank's time.  config.parallelism says which of the two it was.
+    per_rank = False
+    if world > 1 and not args.devices:
+        n_visible = capi.load_library().aqc_device_count()
+        seen = torch.tensor([n_visible], dtype=torch.int64, device="cpu" if share_gpu else "cuda")
+        dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+        per_rank = (not share_gpu and int(seen.item()) < world) or os.environ.get("AQC_BENCH_PER_RANK") == "1"
+    if per_rank:
+        dev_list = [device_index] * max(1, args.contexts)
+        n_ctx = len(dev_list)
+        copies = 1
+        pipe_reads = reads_per_gpu * world
+    driver = rank == 0 or per_rank               # this rank drives a pipe
+    if driver:
         engines = [eng]
         for g in dev_list[1:]:
-            e2 = capi.Engine(g, 3)
+            e2 = capi.Engine(g, max(3, args.slots))
             e2.set_config(cfg)
             e2.reset_stats()
             engines.append(e2)
-        pipe = capi.Pipe(engines, slots=3)
+        pipe = capi.Pipe(engines, slots=args.slots)
     else:
         engines, pipe = [], None
 
@@ -324,17 +346,20 @@ def main():
     work = tempfile.mkdtemp(prefix="aqc_bench_%d_" % rank, dir=base) if (rank == 0 and not args.device_only) else None
     try:
         paths, outs = [], []
-        if rank == 0 and not args.device_only:
+        tag = (".rank%d" % rank) if per_rank else ""
+        if per_rank and not args.device_only:
+            work = tempfile.mkdtemp(prefix="aqc_bench_%d_" % rank, dir=base)
+        if driver and not args.device_only:
             for k, t in enumerate(texts):
-                p = os.path.join(work, "R%d.fq" % (k + 1))
+                p = os.path.join(work, "R%d%s.fq" % (k + 1, tag))
                 with open(p, "wb") as f:
                     for _ in range(copies):
                         f.write(memoryview(t[0].array)[:t[1]])
                 paths.append(p)
-            outs = [(os.path.join(work, "R%d.good.fq" % (k + 1)), os.path.join(work, "R%d.bad.fq" % (k + 1)), None) for k in range(len(texts))]
+            outs = [(os.path.join(work, "R%d%s.good.fq" % (k + 1, tag)), os.path.join(work, "R%d%s.bad.fq" % (k + 1, tag)), None) for k in range(len(texts))]
         last = None
         for it in range(args.warmup + args.steps):
-            if rank == 0:
+            if driver:
                 reset_all()
                 for trio in outs:
                     for pth in trio:
@@ -342,14 +367,14 @@ def main():
                             os.unlink(pth)
             barrier()
             t1 = time.perf_counter()
-            if rank == 0:
+            if driver:
                 last = pipe.run(paths, outs, chunk_records=K, qc_sample=args.qc_sample)
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
             dt = max_over_ranks(time.perf_counter() - t1)
-            if rank == 0:
+            if driver:
                 assert not last.anomaly and int(last.records) == n_rec * copies, (last.anomaly, int(last.records))
             if it >= args.warmup:
                 step_times.append(dt)
@@ -357,7 +382,62 @@ def main():
             f2f = {"seconds_mean": round(sum(step_times) / len(step_times), 4), "seconds_min": round(min(step_times), 4),
                    "seconds_max": round(max(step_times), 4), "where": base or tempfile.gettempdir(),
                    "input_gb": round(text_in * copies / 1e9, 3), "output_gb": round(sum(int(x) for x in last.bytes_out) / 1e9, 3),
-                   "contexts": n_ctx, "devices": dev_list, "thread_seconds_last_run": last.breakdown()}
+                   "contexts": n_ctx, "devices": dev_list, "slots": args.slots, "thread_seconds_last_run": last.breakdown()}
+        # ---- K inputs at once (rank 0, N = 1 runs): K file pairs, K contexts on the device(s), K pipes, 4 K output files.  One input
+        #      cannot be written faster than its two big output files take (~10 GB/s per file on these hosts); the
+        #      reference's own parallelism is per input file, and that shape is not bound by one file's write rate.
+        if args.inputs > 1 and rank == 0 and world == 1 and not args.device_only and step_times:
+            import threading
+            KI = args.inputs
+            mi_eng, mi_pipe, mi_paths, mi_outs = [eng], [pipe], [paths], [outs]
+            for k in range(1, KI):
+                e2 = capi.Engine(dev_list[k % len(dev_list)], max(3, args.slots))
+                e2.set_config(cfg)
+                e2.reset_stats()
+                mi_eng.append(e2)
+                mi_pipe.append(capi.Pipe([e2], slots=args.slots))
+                pk = []
+                for j, src in enumerate(paths):
+                    dst = os.path.join(work, "in%d_R%d.fq" % (k, j + 1))
+                    shutil.copyfile(src, dst)
+                    pk.append(dst)
+                mi_paths.append(pk)
+                mi_outs.append([(os.path.join(work, "in%d_R%d.good.fq" % (k, j + 1)), os.path.join(work, "in%d_R%d.bad.fq" % (k, j + 1)), None) for j in range(len(paths))])
+            mi_times = []
+            for it in range(3):
+                for e in mi_eng:
+                    e.reset_stats()
+                for oo in mi_outs:
+                    for trio in oo:
+                        for pth in trio:
+                            if pth and os.path.exists(pth):
+                                os.unlink(pth)
+                res_k = [None] * KI
+
+                def one(k):
+                    res_k[k] = mi_pipe[k].run(mi_paths[k], mi_outs[k], chunk_records=K, qc_sample=args.qc_sample)
+                th = [threading.Thread(target=one, args=(k,)) for k in range(KI)]
+                t1 = time.perf_counter()
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                dt = time.perf_counter() - t1
+                assert all(r is not None and not r.anomaly and int(r.records) == n_rec for r in res_k)
+                if it:
+                    mi_times.append(dt)
+            multi = {"inputs": KI, "mreads_s": round(KI * reads_per_gpu / min(mi_times) / 1e6, 2), "seconds": round(min(mi_times), 4), "runs": len(mi_times),
+                     "output_files": 2 * KI * len(paths), "what": "%d independent inputs of %.1f M reads each, one pipe + one context per input, all on device(s) %s, at once"
+                     % (KI, reads_per_gpu / 1e6, sorted(set(dev_list)))}
+            for k in range(1, KI):
+                mi_pipe[k].close()
+                mi_eng[k].close()
+                for pth in mi_paths[k]:
+                    os.unlink(pth)
+                for trio in mi_outs[k]:
+                    for pth in trio:
+                        if pth and os.path.exists(pth):
+                            os.unlink(pth)
         # ---- the same through gzip both ways: one-member inputs decoded by the host pool (the box's CPU quota is the bound),
         # .gz members built on the device
         gz_runs = args.gz_runs if args.gz_runs >= 0 else (2 if copies == 1 and shutil.which("gzip") else 0)
@@ -369,6 +449,8 @@ def main():
                 if j.wait() != 0:
                     raise RuntimeError("gzip failed")
             gouts = [(o[0] + ".gz", o[1] + ".gz", None) for o in outs]
+            gz_before = (capi.C.c_uint64 * 4)()
+            capi.load_library().aqc_gz_input_stats(capi.C.byref(gz_before))
             ts = []
             for it in range(gz_runs + 1):
                 reset_all()
@@ -382,7 +464,26 @@ def main():
                 assert not pr.anomaly and int(pr.records) == n_rec * copies
                 if it:
                     ts.append(dt)
+            gzs = (capi.C.c_uint64 * 4)()
+            capi.load_library().aqc_gz_input_stats(capi.C.byref(gzs))
+            sec_all, sec_dev, by_all, by_dev = [int(a) - int(b) for a, b in zip(gzs, gz_before)]
+            # plain text in -> .gz out (the output a third of the size: the two writers are no longer the bound)
+            tz = []
+            for it in range(gz_runs + 1):
+                reset_all()
+                for trio in gouts:
+                    for pth in trio:
+                        if pth and os.path.exists(pth):
+                            os.unlink(pth)
+                t1 = time.perf_counter()
+                pz = pipe.run(paths, gouts, gzip_out=True, gzip_level=2, chunk_records=K, qc_sample=args.qc_sample)
+                dtz = time.perf_counter() - t1
+                assert not pz.anomaly and int(pz.records) == n_rec * copies
+                if it:
+                    tz.append(dtz)
+            f2gz = {"mreads_s": round(pipe_reads / min(tz) / 1e6, 2), "seconds": round(min(tz), 4), "runs": len(tz), "thread_seconds_last_run": pz.breakdown()}
             f2f_gz = {"mreads_s": round(pipe_reads / min(ts) / 1e6, 2), "seconds": round(min(ts), 4), "runs": len(ts),
+                      "gunzip_sections": sec_all, "gunzip_sections_from_device": sec_dev, "gunzip_text_share_from_device": round(by_dev / max(1, by_all), 3),
                       "input_gz_gb": round(sum(os.path.getsize(g) for g in gz_paths) / 1e9, 3),
                       "output_gz_gb": round(sum(os.path.getsize(x) for trio in gouts for x in trio if x and os.path.exists(x)) / 1e9, 3),
                       "thread_seconds_last_run": pr.breakdown(), "cpu_quota": _cpu_quota()}
@@ -407,14 +508,18 @@ def main():
                      "prefix as two FASTQ files -> good / bad files, barcode mode, qc_sample %d" % (n_rec * copies, args.qc_sample)}[args.workload]
     traffic, traffic_src = hbm_traffic(args, n_rec, live=(rank == 0 and world == 1 and not args.device_only and not args.no_pmc))
     out = {
-        "metric": "Mreads/s (paired 2x150 bp) end-to-end good/bad split" if step_times else "DEVICE STEP ONLY (--device-only profiling run, not the metric)",
+        "metric": ({"config3": "Mreads/s (paired 2x150 bp) end-to-end good/bad split", "config2": "Mreads/s (single-end 1x150 bp, BASELINE config 2) end-to-end good/bad split",
+                    "config5": "Mreads/s (paired 2x250 bp + barcodes, BASELINE config 5 shape) end-to-end good/bad split"}[args.workload]
+                   if step_times else "DEVICE STEP ONLY (--device-only profiling run, not the metric)"),
         "value": round(value, 3), "unit": "Mreads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": wl + "; step = file -> file: aqc_pipe_run (pread -> page-locked rings -> H2D -> framing -> filter / overlap / "
                                     "correction verdicts -> QC sampling -> good / bad text -> D2H -> one writer per output file)",
                    "pairs_per_gpu": args.pairs, "read_len": RL,
-                   "parallelism": "one input, chunks of %d records dealt round robin over %d context(s) on device(s) %s by one process, no collective" % (K, n_ctx, dev_list),
+                   "parallelism": ("%d ranks, each its own pipe on its own GPU over its own %d-pair share of the input (the launcher shows a rank one device: one "
+                                   "process cannot drive them all), no collective" % (world, n_rec)) if per_rank else
+                                  ("one input, chunks of %d records dealt round robin over %d context(s) on device(s) %s by one process, no collective" % (K, n_ctx, dev_list)),
                    "text_in_gb": round(text_in * copies / 1e9, 3), "timing": "%d runs, each bracketed by barrier + device sync; outputs of the previous run unlinked in between (untimed)" % len(step_times)},
         "roofline": {"bound": "hbm", "kernel": "fast_filter_overlap_kernel (+ its deferral list kernel)", "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -428,7 +533,8 @@ def main():
                         "text_out_gb_per_gpu": round(text_out / 1e9, 3), "step_text_gb_s": round((text_in + text_out) / (dev_ms * 1e-3) / 1e9, 1),
                         "what": "text resident in HBM -> aqc_reframe -> aqc_run -> aqc_qc_stat -> aqc_format (no PCIe, no files), every rank on its own GPU"},
         "pinned_to_pinned_mreads_s": pinned["mreads_s"] if pinned else None,
-        "pinned_to_pinned": pinned, "file_to_file": f2f, "file_to_file_gz": f2f_gz,
+        "pinned_to_pinned": pinned, "file_to_file": f2f, "file_to_file_gz": f2f_gz, "file_to_gz": f2gz,
+        "multi_input_file_to_file_mreads_s": multi["mreads_s"] if multi else None, "multi_input_file_to_file": multi,
         "good_reads_frac": round(good_frac, 5),
         "gen_s": round(t_gen, 1), "text_render_s": round(t_txt, 1), "first_upload_s": round(t_up, 3),
         "host": {"cpus": os.cpu_count(), "cpu_quota": _cpu_quota()},

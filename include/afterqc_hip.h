@@ -303,6 +303,10 @@ int aqc_format(aqc_ctx* ctx, int slot, uint64_t n, int32_t store_overlap, uint64
 int aqc_format_plain(aqc_ctx* ctx, int slot, int verdict_slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]);
 /* copy one formatted stream (file 0/1, stream 0 good / 1 bad / 2 overlap) to host memory and wait for it */
 int aqc_fetch_text(aqc_ctx* ctx, int slot, int file, int stream, uint8_t* dst, uint64_t cap);
+/* all six streams of the slot with ONE wait (what the pipe's slot workers call): the text of aqc_format (gz == 0) or the
+ * compressed streams of aqc_compress (gz != 0) into dst[file * 3 + stream] (cap[...] bytes each; an empty stream may have a
+ * NULL destination). */
+int aqc_fetch_streams(aqc_ctx* ctx, int slot, int32_t gz, uint8_t* const dst[6], const uint64_t cap[6]);
 /* gzip output built on the device (fastq.Writer with a ".gz" name, fastq.py:65-68; --compression, after.py:91-92): the six
  * formatted streams of the slot become BGZF-compatible gzip members in HBM (<= 0xff00 bytes of text each: one dynamic-Huffman
  * block; matches = runs and "same column, four lines up"; one shared code per stream and call, built by the host from sampled
@@ -313,7 +317,7 @@ int aqc_compress(aqc_ctx* ctx, int slot, int32_t level, uint64_t gz_bytes_out[6]
 int aqc_fetch_gz(aqc_ctx* ctx, int slot, int file, int stream, uint8_t* dst, uint64_t cap);
 /* gzip INPUT decoded with the device's help (fastq.py:23-24: gzip.open(name, "r"); csrc/aqc_gunzip_dev.hpp): the gzip file at
  * gz[0, size) into out.  Every section the stream can be cut into goes to the GPU `device` in groups of `group_bytes` compressed
- * bytes (0: 64 MiB; sections of `section_bytes`, 0: 1 MiB) — a LANE per deflate block, the blocks found by scanning every bit
+ * bytes (0: 256 MiB, and never more than a quarter of the file; sections of `section_bytes`, 0: 1 MiB) — a LANE per deflate block, the blocks found by scanning every bit
  * position — while `threads` host threads resolve the markers and check each member's CRC-32 / ISIZE; what the device does
  * not chain up (final / fixed-Huffman blocks, the stream's last section) is decoded on the host, so ANY valid gzip file
  * comes out exactly.  It is what a `.gz` input of aqc_pipe_run goes through, minus the host pool's share of the sections.

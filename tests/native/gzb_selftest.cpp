@@ -142,15 +142,19 @@ struct CpuOffload : aqcgz::SectionOffload {
         }
         J.s_nominal = s_nom.data(); J.s_stop = s_stop.data(); J.s_exact = s_exact.data(); J.s_start = s_start.data(); J.s_end = s_end.data();
         J.s_nsym = s_nsym.data(); J.s_nblk = s_nblk.data(); J.s_blocks = s_blocks.data();
-        std::vector<uint16_t> s_sym((size_t)J.s_symcap + 64);         // (one section at a time here)
+        std::vector<uint64_t> s_off((size_t)n + 1);
+        J.s_off = s_off.data();
+        J.s_sym_total = (uint64_t)span * 12 + (uint64_t)n * 64 + (1u << 20);
+        std::vector<uint16_t> s_sym(J.s_sym_total + 64);
         J.s_sym = s_sym.data();
         ++groups;
         sections += (uint64_t)n;
+        for (int k = 0; k < n; ++k) gzb_chain_section(J, (uint32_t)k);
+        gzb_place(J);
         for (int k = 0; k < n; ++k) {
-            gzb_chain_section(J, (uint32_t)k);
             aqcgz::OffloadResult r;
             if (s_start[k] != GZB_NONE && s_nsym[k] != 0) {
-                uint16_t* const dst = s_sym.data();
+                uint16_t* const dst = s_sym.data() + s_off[k];
                 const uint32_t* const blocks = s_blocks.data() + (size_t)k * GZB_SEC_BLOCKS * 3u;
                 for (uint32_t b = 0; b < s_nblk[k]; ++b) {
                     const uint32_t w0 = blocks[3u * b], w1 = blocks[3u * b + 1], o = blocks[3u * b + 2];
@@ -160,7 +164,7 @@ struct CpuOffload : aqcgz::SectionOffload {
                         for (uint32_t i = 0; i < c_nsym[w0]; ++i) dst[o + i] = gzb_rebase(s[i], o, dst);
                     }
                 }
-                auto* keep = new std::vector<uint16_t>(s_sym.begin(), s_sym.begin() + s_nsym[k]);
+                auto* keep = new std::vector<uint16_t>(dst, dst + s_nsym[k]);
                 r.found = true;
                 r.start_bit = byte0 * 8 + s_start[k];
                 r.end_bit = byte0 * 8 + s_end[k];

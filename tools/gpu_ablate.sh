@@ -2,7 +2,7 @@
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 for f in afterqc_amd/csrc/libafterqc_hip.so build/ablate/*.so; do
-  AQC_LIB=$PWD/$f python bench.py --steps 5 --warmup 2 --cpu-sample 0 --pipe-runs 0 --file-runs 0 "$@" > gpurun_out/b.log 2>gpurun_out/b.err
+  AQC_LIB=$PWD/$f python bench.py --device-only --device-steps 10 --cpu-sample 0 --no-pmc "$@" > gpurun_out/b.log 2>gpurun_out/b.err
   grep PROF gpurun_out/b.err
   python - "$f" <<'PY'
 import json, sys

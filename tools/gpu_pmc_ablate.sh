@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 for f in afterqc_amd/csrc/libafterqc_hip.so build/ablate/*.so; do
   tag=$(basename $f .so)
-  (cd /tmp && AQC_LIB=$GRAFT_REPO_ROOT/$f rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pa_$tag -o x -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --pipe-runs 0 --file-runs 0 $AQC_BENCH_ARGS > /dev/null 2>&1)
+  (cd /tmp && AQC_LIB=$GRAFT_REPO_ROOT/$f rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pa_$tag -o x -- python $GRAFT_REPO_ROOT/bench.py --device-only --device-steps 3 --cpu-sample 0 --no-pmc $AQC_BENCH_ARGS > /dev/null 2>&1)
   python - "$tag" <<'PY'
 import csv, sys, glob, collections
 tag = sys.argv[1]
