@@ -388,7 +388,7 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_device_index", "aqc_last_error", "aqc_create", "aqc_destroy",
+EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_device_index", "aqc_device_numa_node", "aqc_device_numa_node_of", "aqc_bind_thread_to_node", "aqc_last_error", "aqc_create", "aqc_destroy",
                     "aqc_device_name", "aqc_set_config", "aqc_set_circles", "aqc_reset_stats", "aqc_upload", "aqc_run",
                     "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_last_deferred", "aqc_kernel_ms", "aqc_timing_reset",
                     "aqc_timing_mean", "aqc_get_counters",

@@ -28,6 +28,9 @@
 #include "aqc_gz.hpp"
 #include <zlib.h>
 #include <sys/mman.h>
+#include <sched.h>
+#include <pthread.h>
+#include <cctype>
 
 using namespace aqc;
 
@@ -312,6 +315,56 @@ void aqc_destroy(aqc_ctx* c) {
 }
 
 int aqc_device_index(aqc_ctx* c) { return c ? c->device : -1; }
+
+// The NUMA node the GPU hangs off (its PCI function's numa_node in sysfs); -1: unknown / the host has a single node.
+int aqc_device_numa_node_of(int device) {
+    char bus[64] = "";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char* p = bus; *p; ++p) *p = (char)tolower((unsigned char)*p);
+    char path[160];
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    int node = -1;
+    if (FILE* f = fopen(path, "r")) {
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    return node;
+}
+int aqc_device_numa_node(aqc_ctx* c) { return c ? aqc_device_numa_node_of(c->device) : -1; }
+
+// Bind the calling thread to the CPUs of `node` that it may run on (its current affinity mask intersected with the node's
+// cpulist); memory the thread touches first then comes from that node.  Returns the number of CPUs it is bound to, 0 when
+// nothing was changed (unknown node, a single-node host, an empty intersection, AQC_PIPE_NUMA=0).
+int aqc_bind_thread_to_node(int node) {
+    if (node < 0) return 0;
+    if (const char* e = getenv("AQC_PIPE_NUMA")) if (e[0] == '0') return 0;
+    char path[96];
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return 0;
+    char list[4096] = "";
+    const bool got = fgets(list, sizeof(list), f) != nullptr;
+    fclose(f);
+    if (!got) return 0;
+    cpu_set_t have, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(have), &have) != 0) return 0;
+    int n = 0;
+    for (char* p = list; *p;) {
+        char* q;
+        const long a = strtol(p, &q, 10);
+        if (q == p) break;
+        long b = a;
+        if (*q == '-') { p = q + 1; b = strtol(p, &q, 10); }
+        for (long cpu = a; cpu <= b && cpu < CPU_SETSIZE; ++cpu)
+            if (CPU_ISSET((int)cpu, &have)) { CPU_SET((int)cpu, &want); ++n; }
+        p = *q == ',' ? q + 1 : q;
+        if (*q != ',') break;
+    }
+    if (n == 0 || n == CPU_COUNT(&have)) return 0;           // nothing to choose from
+    if (pthread_setaffinity_np(pthread_self(), sizeof(want), &want) != 0) return 0;
+    return n;
+}
 
 int aqc_device_name(aqc_ctx* c, char* buf, int buflen) {
     if (!c || !buf || buflen <= 0) return fail(AQC_ERR_ARG, "aqc_device_name: bad arguments");
@@ -1100,7 +1153,7 @@ private:
     struct Lane {
         std::thread th;
         hipStream_t stream = nullptr;
-        hipEvent_t ev[6] = {};
+        hipEvent_t ev[7] = {};
         std::unique_ptr<Group> job;
         DevBuf comp, tile_cnt, tile_cand, n_cand, c_start, c_end, c_nsym, c_flags, c_symoff, c_symcap, blk_sym, tables;
         DevBuf s_in, s_out, s_blocks, s_sym, s_off;
@@ -1119,6 +1172,7 @@ private:
     void loop(int li) {
         Lane& L = lanes_[li];
         (void)hipSetDevice(device_);
+        (void)aqc_bind_thread_to_node(aqc_device_numa_node_of(device_));       // (the staging copies and the arenas' first touch happen here)
         for (;;) {
             Group* gr = nullptr;
             {
@@ -1257,8 +1311,9 @@ private:
         if (need && live) {
             ai = take_arena(need);
             if (ai < 0) return false;
-            ok = hipMemcpyAsync(arenas_[ai].p, L.s_sym.p, need, hipMemcpyDeviceToHost, L.stream) == hipSuccess;
-        }
+            ok = hipEventRecord(L.ev[6], L.stream) == hipSuccess &&
+                 hipMemcpyAsync(arenas_[ai].p, L.s_sym.p, need, hipMemcpyDeviceToHost, L.stream) == hipSuccess;
+        } else ok = hipEventRecord(L.ev[6], L.stream) == hipSuccess;
         ok = ok && hipEventRecord(L.ev[5], L.stream) == hipSuccess && hipStreamSynchronize(L.stream) == hipSuccess;
         if (ai >= 0) {
             {
@@ -1270,7 +1325,8 @@ private:
         }
         if (!ok) return false;
         float ms[5] = {0, 0, 0, 0, 0};
-        for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], L.ev[i], L.ev[i + 1]);
+        for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], L.ev[i], L.ev[i + 1]);
+        (void)hipEventElapsedTime(&ms[4], L.ev[6], L.ev[5]);       // (the symbols' copy alone: getting an arena is host time)
         g_gzb_stats[0] += (uint64_t)(ms[1] * 1000); g_gzb_stats[1] += (uint64_t)(ms[2] * 1000); g_gzb_stats[2] += (uint64_t)(ms[3] * 1000);
         g_gzb_stats[3] += (uint64_t)(ms[0] * 1000); g_gzb_stats[4] += (uint64_t)(ms[4] * 1000); g_gzb_stats[5] += 1; g_gzb_stats[6] += (uint64_t)n; g_gzb_stats[7] += (uint64_t)live;
         for (int k = 0; k < n; ++k) {

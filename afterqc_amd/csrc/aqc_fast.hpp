@@ -905,12 +905,23 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                         for (int q = 0; q < 8; ++q) cnt[q] = (int32_t)__popc(alignbit(w1, w0, 2 * (r0 + q)) ^ F) - 5;
                         const int32_t any = ((cnt[0] | cnt[1] | cnt[2]) | (cnt[3] | cnt[4] | cnt[5])) | (cnt[6] | cnt[7]);
                         if (__ballot(any < 0)) {
-                            // rare: re-derive the eight counts in a rolled loop, keeping this path out of the hot code
-#pragma nounroll
-                            for (int q = 0; q < 8; ++q) {
-                                const int c = 16 * k + r0 + q;
-                                const uint32_t cq = __popc(alignbit(w1, w0, 2 * (r0 + q)) ^ F);
-                                if (cq < 5 && live && c < n_own && c >= from) {
+                            // Not rare at all: half the pairs of a 2 x 150 run with ~30-base overlaps have their true offset
+                            // in the scan's last two words, so four of the sixteen half-steps come through here in nearly every
+                            // batch (measured, round 4: a rolled loop over the eight diagonals with a branch each cost ~100 vector
+                            // and ~120 scalar instructions per visit, a fifth of the kernel).  The eight sign bits become a mask
+                            // with one v_alignbit each, the candidates this lane still wants ([from, n_own)) a v_bfm, and the
+                            // survivors — one per lane as a rule — are taken off the mask lowest first.
+                            uint32_t m8 = 0;
+#pragma unroll
+                            for (int q = 7; q >= 0; --q) m8 = alignbit(m8, (uint32_t)cnt[q], 31);
+                            const int base8 = 16 * k + r0;
+                            const int lo_q = min(max(from - base8, 0), 8), hi_q = min(max(n_own - base8, 0), 8);
+                            const uint32_t want = live && hi_q > lo_q ? ((1u << hi_q) - 1u) & ~((1u << lo_q) - 1u) : 0u;
+                            m8 &= want;
+                            while (__ballot(m8 != 0)) {
+                                if (m8 != 0) {
+                                    const int c = base8 + __builtin_ctz(m8);
+                                    m8 &= m8 - 1;
                                     if (s0 == NONE_CAND) s0 = c; else if (s1 == NONE_CAND) s1 = c; else if (s2 == NONE_CAND) s2 = c;
                                 }
                             }

@@ -382,7 +382,10 @@ void ParallelGunzip::top_up() {
         // The pool's share first (the sections the consumer will want next), then — whenever the device is free — a GROUP of
         // sections behind them.  Who gets how much settles by itself: the device takes a group each time it is ready, the pool
         // a section each time one of its `inflight_` is committed.
-        if (!offload_only_ && on_pool < (size_t)inflight_ * (offload_ ? 2u : 1u)) {
+        // (with a device decoder the pool works four times as far ahead: the consumer reaches a device group only after the pool
+        //  sections in front of it, and while it waits there for the group's ~70 ms the pool must have sections BEHIND the group
+        //  to decode — round 4's first wiring kept 2 x inflight and the pool sat idle behind every group: 0.60 s instead of 0.35)
+        if (!offload_only_ && on_pool < (size_t)inflight_ * (offload_ ? 4u : 1u)) {
             std::shared_ptr<Section> s = new_section(no_more);
             if (!s) break;
             to_pool(s);
@@ -390,8 +393,9 @@ void ParallelGunzip::top_up() {
         }
         if (!offload_ || no_more) break;
         // a group costs the device a fixed ~50 ms (one block is decoded by one lane, start to end) plus its transfers, whatever its
-        // size: big groups are what makes it fast, but a file should still be several groups (two are in flight at a time)
-        const size_t per_group = std::max<size_t>(1, (offload_only_ ? offload_->group_bytes() : std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ / 4))) / section_bytes_);
+        // size: big groups are what makes it fast, but a file should still be many groups (two are in flight at a time, and the
+        // pool must have its share between them)
+        const size_t per_group = std::max<size_t>(1, (offload_only_ ? offload_->group_bytes() : std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ / 8))) / section_bytes_);
         if (on_device >= 3 * per_group || !offload_->ready()) break;
         std::vector<std::shared_ptr<Section>> group;
         std::shared_ptr<Section> last;                       // the stream's last section runs to the end of the file: the pool's

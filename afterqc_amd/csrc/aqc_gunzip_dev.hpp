@@ -15,11 +15,11 @@
 //                       must parse and form a complete literal/length code with an end-of-block symbol and a usable distance code.
 //   gzb_compact_kernel  the per-tile hits become one sorted candidate list; a candidate's output space is sized from the
 //                       compressed bytes up to the next candidate.
-//   gzb_decode_kernel   a LANE per candidate: builds its own root tables (10-bit literal/length, 8-bit distance, entries
-//                       carry base + extra-bit count; longer codes: canonical search) in its own 6 KiB of global memory and
-//                       decodes its block the way a CPU thread would — one 8-byte peek per token, 8-byte match copies — into
-//                       16-bit SYMBOLS (>= 0x8000: "byte j of the 32 KiB before this BLOCK").  A lane runs at a few MB/s (every
-//                       step is a dependent trip to L2); tens of thousands of them run at once.  No LDS, no cross-lane traffic.
+//   gzb_decode_kernel   a LANE per candidate: builds its own tables (9-bit literal/length and 7-bit distance roots, 16-bit
+//                       entries; longer codes: canonical search) in its own 2 KiB column of LDS and decodes its block the way
+//                       a CPU thread would — a 64-bit bit buffer whose next word is always on its way, LDS table look-ups, 8-byte
+//                       match copies — into 16-bit SYMBOLS (>= 0x8000: "byte j of the 32 KiB before this BLOCK").  A lane runs
+//                       at a few MB/s; tens of thousands of them run at once.  No cross-lane traffic.
 //   gzb_chain_kernel    a lane per SECTION (the host's unit of work, aqc_gunzip.cpp): from the first candidate at or behind the
 //                       section's nominal start it follows  end of block == start of a candidate  until the section's stop bit;
 //                       stored blocks (pigz's sync markers) are stepped over in place.  A false candidate never chains up.
@@ -60,11 +60,15 @@ GZB_HD inline uint32_t gzb_rev(uint32_t c, uint32_t len) {
 }
 
 constexpr uint32_t GZB_MARKER = 0x8000u;
-constexpr int GZB_LROOT = 10, GZB_DROOT = 8;
-// a candidate's private table space (32-bit words): literal/length root, distance root, then 16-bit arrays: symbols sorted by
-// code (288 + 32), codes per length (16 + 16), and the 320 code lengths as bytes
-constexpr int GZB_T_DIST = 1 << GZB_LROOT, GZB_T_LSORT = GZB_T_DIST + (1 << GZB_DROOT), GZB_T_DSORT = GZB_T_LSORT + 144, GZB_T_LCOUNT = GZB_T_DSORT + 16,
-              GZB_T_DCOUNT = GZB_T_LCOUNT + 8, GZB_T_LENS = GZB_T_DCOUNT + 8, GZB_TAB_WORDS = GZB_T_LENS + 80;
+constexpr int GZB_LROOT = 9, GZB_DROOT = 7;
+// A lane's decoding tables, 16-bit entries: literal/length root (2^9), distance root (2^7), symbols sorted by code (288 + 32),
+// codes per length (16 + 16) = 992 entries.  On the device they live in LDS, entry e of lane l at [e * 64 + l] (the 64 lanes of a
+// wave hit 32 consecutive words: no bank conflicts) — 124 KiB per wave, one wave per CU; every table look-up of the decoder is
+// an LDS access (~50 cycles) instead of a trip to L2 or HBM (200 - 900; round 4's first version: 7,000 cycles per token).
+constexpr int GZB_E_DIST = 1 << GZB_LROOT, GZB_E_LSORT = GZB_E_DIST + (1 << GZB_DROOT), GZB_E_DSORT = GZB_E_LSORT + 288, GZB_E_LCOUNT = GZB_E_DSORT + 32,
+              GZB_E_DCOUNT = GZB_E_LCOUNT + 16, GZB_TAB_ENTRIES = GZB_E_DCOUNT + 16;
+// a candidate's scratch in global memory: its 320 code lengths as bytes
+constexpr int GZB_TAB_WORDS = 80;
 constexpr int GZB_SCAN_THREADS = 256, GZB_SCAN_TILE = GZB_SCAN_THREADS * 16, GZB_TILE_CAND = 16;
 constexpr int GZB_DEC_THREADS = 64;
 constexpr int GZB_SEC_BLOCKS = 4096;                // chain entries per section (3 words each)
@@ -93,7 +97,7 @@ struct GzbJob {
     uint16_t* blk_sym;
     uint64_t blk_sym_cap;        // symbols
     uint32_t ratio_cap;          // a block may expand to ratio_cap x its compressed size (+ 4096 symbols)
-    uint32_t* tables;            // [cand_cap][GZB_TAB_WORDS]
+    uint32_t* tables;            // [cand_cap][GZB_TAB_WORDS]: a candidate's code lengths
     // sections
     uint32_t n_sec;
     const uint32_t* s_nominal;   // [n_sec] search from this bit
@@ -138,17 +142,17 @@ GZB_HD inline unsigned long long gzb_peek(const uint8_t* comp, uint32_t p) {
     return v >> (p & 7u);
 }
 
-// Root table entries.  bits 3:0 code length (0: not a root code), 7:4 extra bits, 8 literal, 9 end of block, 10 invalid symbol,
-// 31:16 literal byte / base length / base distance.
+// Table entries (16 bits).  Literal/length: bits 3:0 code length (0: not a root code), 4 literal, 5 end of block, 6 invalid symbol,
+// 15:8 the literal byte or the length symbol - 257.  Distance: bits 3:0 code length, 8:4 distance symbol, 15 invalid.
 GZB_HD inline uint32_t gzb_lit_entry(uint32_t s, uint32_t l) {
-    if (s < 256u) return l | 0x100u | (s << 16);
-    if (s == 256u) return l | 0x200u;
-    if (s > 285u) return l | 0x400u;
-    return l | (gzb_len_extra(s - 257u) << 4) | (gzb_len_base(s - 257u) << 16);
+    if (s < 256u) return l | 0x10u | (s << 8);
+    if (s == 256u) return l | 0x20u;
+    if (s > 285u) return l | 0x40u;
+    return l | ((s - 257u) << 8);
 }
 GZB_HD inline uint32_t gzb_dist_entry(uint32_t s, uint32_t l) {
-    if (s > 29u) return l | 0x400u;
-    return l | (gzb_dist_extra(s) << 4) | (gzb_dist_base(s) << 16);
+    if (s > 29u) return l | 0x8000u;
+    return l | (s << 4);
 }
 
 // The header of a dynamic-Huffman block whose three header bits sit at bit p: HLIT, HDIST, HCLEN, the code-length code, the
@@ -256,51 +260,60 @@ GZB_HD inline bool gzb_kraft_ok(const uint8_t* comp, uint32_t p, uint32_t hclen,
     return kraft == 128u;
 }
 
+// One lane's tables: entry e at base[e * S] (S = 64 on the device: see GZB_E_*; 1 on the host).
+template <int S>
+struct GzbLaneTab {
+    uint16_t* base;
+    GZB_HD uint16_t& at(int e) const { return base[e * S]; }
+};
+
 // canonical Huffman code from lens[0, n): root table + symbols sorted by code + codes per length.  cnt / nxt / off: three arrays
-// of 16 counters, element l at [l * S] (the lanes' columns of LDS arrays).
-template <bool LIT>
-GZB_HD inline void gzb_build(const uint8_t* lens, uint32_t n, uint32_t R, uint32_t* root, uint16_t* sorted, uint16_t* count,
-                             uint32_t* cnt, uint32_t* nxt, uint32_t* off, int S) {
-    for (int l = 0; l < 16; ++l) cnt[l * S] = 0;
-    for (uint32_t s = 0; s < n; ++s) cnt[(uint32_t)lens[s] * S] += 1u;
+// of 16 counters, element l at [l * CS] (the lanes' columns of LDS arrays).
+template <bool LIT, int S>
+GZB_HD inline void gzb_build(const uint8_t* lens, uint32_t n, const GzbLaneTab<S>& T, uint32_t* cnt, uint32_t* nxt, uint32_t* off, int CS) {
+    const uint32_t R = LIT ? GZB_LROOT : GZB_DROOT;
+    const int root = LIT ? 0 : GZB_E_DIST, sorted = LIT ? GZB_E_LSORT : GZB_E_DSORT, count = LIT ? GZB_E_LCOUNT : GZB_E_DCOUNT;
+    for (int l = 0; l < 16; ++l) cnt[l * CS] = 0;
+    for (uint32_t s = 0; s < n; ++s) cnt[(uint32_t)lens[s] * CS] += 1u;
     {
         uint32_t code = 0, prev = 0, o = 0;
-        count[0] = 0;
+        T.at(count) = 0;
         for (int l = 1; l <= 15; ++l) {
             code = (code + prev) << 1;
-            prev = cnt[l * S];
-            nxt[l * S] = code;
-            off[l * S] = o;
-            count[l] = (uint16_t)prev;
+            prev = cnt[l * CS];
+            nxt[l * CS] = code;
+            off[l * CS] = o;
+            T.at(count + l) = (uint16_t)prev;
             o += prev;
         }
     }
-    for (uint32_t i = 0; i < (1u << R); ++i) root[i] = 0;
+    for (uint32_t i = 0; i < (1u << R); ++i) T.at(root + (int)i) = 0;
     for (uint32_t s = 0; s < n; ++s) {
         const uint32_t l = lens[s];
         if (!l) continue;
-        const uint32_t c = nxt[l * S];
-        nxt[l * S] = c + 1;
-        const uint32_t o = off[l * S];
-        off[l * S] = o + 1;
-        sorted[o] = (uint16_t)s;
+        const uint32_t c = nxt[l * CS];
+        nxt[l * CS] = c + 1;
+        const uint32_t o = off[l * CS];
+        off[l * CS] = o + 1;
+        T.at(sorted + (int)o) = (uint16_t)s;
         if (l <= R) {
-            const uint32_t e = LIT ? gzb_lit_entry(s, l) : gzb_dist_entry(s, l);
-            for (uint32_t i = gzb_rev(c, l); i < (1u << R); i += 1u << l) root[i] = e;
+            const uint16_t e = (uint16_t)(LIT ? gzb_lit_entry(s, l) : gzb_dist_entry(s, l));
+            for (uint32_t i = gzb_rev(c, l); i < (1u << R); i += 1u << l) T.at(root + (int)i) = e;
         }
     }
 }
 
 // a code longer than the root index: canonical search, one bit at a time (w: the stream from the code's first bit on)
-template <bool LIT>
-GZB_HD inline uint32_t gzb_slow(unsigned long long w, const uint16_t* count, const uint16_t* sorted) {
+template <bool LIT, int S>
+GZB_HD inline uint32_t gzb_slow(unsigned long long w, const GzbLaneTab<S>& T) {
+    const int sorted = LIT ? GZB_E_LSORT : GZB_E_DSORT, count = LIT ? GZB_E_LCOUNT : GZB_E_DCOUNT;
     uint32_t code = 0, first = 0, index = 0;
     for (uint32_t len = 1; len <= 15; ++len) {
         code |= (uint32_t)(w & 1u);
         w >>= 1;
-        const uint32_t c = count[len];
+        const uint32_t c = T.at(count + (int)len);
         if (code - first < c) {
-            const uint32_t s = sorted[index + (code - first)];
+            const uint32_t s = T.at(sorted + (int)(index + (code - first)));
             return LIT ? gzb_lit_entry(s, len) : gzb_dist_entry(s, len);
         }
         index += c;
@@ -310,48 +323,66 @@ GZB_HD inline uint32_t gzb_slow(unsigned long long w, const uint16_t* count, con
     return 0;
 }
 
-// the pieces of a candidate's table space
-struct GzbTables {
-    uint32_t *lit, *dist;
-    uint16_t *lsorted, *dsorted, *lcount, *dcount;
-    uint8_t* lens;
-    GZB_HD explicit GzbTables(uint32_t* tab)
-        : lit(tab), dist(tab + GZB_T_DIST), lsorted(reinterpret_cast<uint16_t*>(tab + GZB_T_LSORT)), dsorted(reinterpret_cast<uint16_t*>(tab + GZB_T_DSORT)),
-          lcount(reinterpret_cast<uint16_t*>(tab + GZB_T_LCOUNT)), dcount(reinterpret_cast<uint16_t*>(tab + GZB_T_DCOUNT)), lens(reinterpret_cast<uint8_t*>(tab + GZB_T_LENS)) {}
-};
+GZB_HD inline unsigned long long gzb_load64(const uint8_t* p) {
+    unsigned long long v;
+    memcpy(&v, p, 8);
+    return v;
+}
 
 // One block's symbols from its first data bit p on, into out[0, cap): returns the flags (0: the end-of-block code was reached),
 // p = the bit behind it, op = symbols written.  A symbol >= 0x8000 is "byte j of the 32 KiB before this block".
-GZB_HD inline uint32_t gzb_decode_block(const uint8_t* comp, uint32_t limit_bit, const GzbTables& T, uint16_t* out, uint32_t cap, uint32_t& p, uint32_t& op) {
+// The stream is read through a 64-bit bit buffer; the word the NEXT refill needs is loaded when the buffer has just been
+// refilled, two or three tokens before it is used, so the loop does not wait for the compressed bytes.
+template <int S>
+GZB_HD inline uint32_t gzb_decode_block(const uint8_t* comp, uint32_t limit_bit, const GzbLaneTab<S>& T, uint16_t* out, uint32_t cap, uint32_t& p, uint32_t& op) {
     uint32_t fl = 0;
     op = 0;
+    const uint8_t* const end = comp + (limit_bit >> 3);      // (limit_bit is a multiple of 8; the buffer is padded for 64 bytes behind)
+    const uint8_t* ip = comp + (p >> 3);
+    unsigned long long bb = gzb_load64(ip) >> (p & 7u);
+    uint32_t bn = 64u - (p & 7u);                             // valid bits in bb
+    ip += 8;
+    unsigned long long nx = gzb_load64(ip);                   // the eight bytes at ip, on their way
+#define GZB_REFILL()                                                                       \
+    do {                                                                                   \
+        bb |= nx << bn;                                                                    \
+        const uint32_t adv_ = (63u - bn) >> 3;                                             \
+        ip += adv_;                                                                        \
+        bn += adv_ << 3;                                                                   \
+        nx = gzb_load64(ip);                                                               \
+    } while (0)
     for (;;) {
-        if (p + 64u > limit_bit) { fl = GZB_F_ERROR; break; }
+        if (ip > end) { fl = GZB_F_ERROR; break; }
         if (op + 272u > cap) { fl = GZB_F_OVERFLOW; break; }
-        unsigned long long w = gzb_peek(comp, p);
-        uint32_t e = T.lit[(uint32_t)w & ((1u << GZB_LROOT) - 1u)];
+        if (bn < 32u) GZB_REFILL();                           // >= 56 bits now; a literal/length code + its extra bits take <= 20
+        uint32_t e = T.at((int)((uint32_t)bb & ((1u << GZB_LROOT) - 1u)));
         if ((e & 15u) == 0u) {
-            e = gzb_slow<true>(w, T.lcount, T.lsorted);
+            e = gzb_slow<true, S>(bb, T);
             if (!e) { fl = GZB_F_ERROR; break; }
         }
         const uint32_t l = e & 15u;
-        w >>= l;
-        p += l;
-        if (e & 0x100u) { out[op++] = (uint16_t)(e >> 16); continue; }
-        if (e & 0x600u) { if (e & 0x400u) fl = GZB_F_ERROR; break; }           // end of block
-        const uint32_t xb = (e >> 4) & 15u;
-        const uint32_t len = (e >> 16) + ((uint32_t)w & ((1u << xb) - 1u));
-        w >>= xb;
-        uint32_t de = T.dist[(uint32_t)w & ((1u << GZB_DROOT) - 1u)];
+        bb >>= l;
+        bn -= l;
+        if (e & 0x10u) { out[op++] = (uint16_t)(e >> 8); continue; }
+        if (e & 0x60u) { if (e & 0x40u) fl = GZB_F_ERROR; break; }            // end of block
+        const uint32_t ls = e >> 8;
+        const uint32_t xb = gzb_len_extra(ls);
+        const uint32_t len = gzb_len_base(ls) + ((uint32_t)bb & ((1u << xb) - 1u));
+        bb >>= xb;
+        bn -= xb;
+        if (bn < 32u) GZB_REFILL();                           // a distance code + its extra bits take <= 28
+        uint32_t de = T.at(GZB_E_DIST + (int)((uint32_t)bb & ((1u << GZB_DROOT) - 1u)));
         if ((de & 15u) == 0u) {
-            de = gzb_slow<false>(w, T.dcount, T.dsorted);
+            de = gzb_slow<false, S>(bb, T);
             if (!de) { fl = GZB_F_ERROR; break; }
         }
-        if (de & 0x400u) { fl = GZB_F_ERROR; break; }
-        const uint32_t dl = de & 15u, dxb = (de >> 4) & 15u;
-        w >>= dl;
-        const uint32_t dd = (de >> 16) + ((uint32_t)w & ((1u << dxb) - 1u));
-        p += xb + dl + dxb;
+        if (de & 0x8000u) { fl = GZB_F_ERROR; break; }
+        const uint32_t dl = de & 15u, ds = (de >> 4) & 31u;
+        bb >>= dl;
+        const uint32_t dxb = gzb_dist_extra(ds);
+        const uint32_t dd = gzb_dist_base(ds) + ((uint32_t)bb & ((1u << dxb) - 1u));
+        bb >>= dxb;
+        bn -= dl + dxb;
         const int src = (int)op - (int)dd;
         if (src < -32768) { fl = GZB_F_ERROR; break; }
         uint16_t* const dst = out + op;
@@ -395,6 +426,9 @@ GZB_HD inline uint32_t gzb_decode_block(const uint8_t* comp, uint32_t limit_bit,
         }
         op += len;
     }
+#undef GZB_REFILL
+    // the bit behind the last consumed one: ip points 8 bytes behind the word whose unconsumed bits are the top of bb
+    p = (uint32_t)((ip - comp) << 3) - bn;
     return fl;
 }
 
@@ -649,6 +683,7 @@ __global__ __launch_bounds__(1024) void gzb_compact_kernel(GzbJob J) {
 
 // ---- a lane per block --------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
+    __shared__ uint16_t s_tab[GZB_TAB_ENTRIES * GZB_DEC_THREADS];
     __shared__ uint8_t s_cl[128 * GZB_DEC_THREADS];
     __shared__ uint32_t s_cnt[16 * GZB_DEC_THREADS], s_nxt[16 * GZB_DEC_THREADS], s_off[16 * GZB_DEC_THREADS];
     const int tid = threadIdx.x;
@@ -656,13 +691,14 @@ __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
     if (c >= J.n_cand[0]) return;
     const uint32_t limit_bit = J.comp_bytes * 8u;
     const uint32_t cap = J.c_symcap[c];
-    const GzbTables T(J.tables + (size_t)c * GZB_TAB_WORDS);
+    uint8_t* const lens = reinterpret_cast<uint8_t*>(J.tables + (size_t)c * GZB_TAB_WORDS);
+    const GzbLaneTab<GZB_DEC_THREADS> T{s_tab + tid};
     uint32_t p = 0, hlit = 0, hdist = 0, op = 0, fl = 0;
     if (cap == 0) fl = GZB_F_SKIP;
-    else if (!gzb_header(J.comp, limit_bit, J.c_start[c], s_cl + tid, GZB_DEC_THREADS, T.lens, p, hlit, hdist)) fl = GZB_F_ERROR;
+    else if (!gzb_header(J.comp, limit_bit, J.c_start[c], s_cl + tid, GZB_DEC_THREADS, lens, p, hlit, hdist)) fl = GZB_F_ERROR;
     if (!fl) {
-        gzb_build<true>(T.lens, hlit, GZB_LROOT, T.lit, T.lsorted, T.lcount, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
-        gzb_build<false>(T.lens + hlit, hdist, GZB_DROOT, T.dist, T.dsorted, T.dcount, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
+        gzb_build<true>(lens, hlit, T, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
+        gzb_build<false>(lens + hlit, hdist, T, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
         fl = gzb_decode_block(J.comp, limit_bit, T, J.blk_sym + J.c_symoff[c], cap, p, op);
     }
     J.c_end[c] = p;

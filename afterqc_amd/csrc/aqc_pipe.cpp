@@ -301,8 +301,7 @@ struct GzSource : Source {
                         if (const char* e = getenv("AQC_GZ_SECTION")) sec = (size_t)atoll(e);
                     }
                     if (!sec) sec = std::min<size_t>(offload ? (1u << 20) : (2u << 20), std::max<size_t>(256u << 10, size / (size_t)(4 * inflight)));
-                    // (with a device decoder the pool keeps twice its sections in flight, see ParallelGunzip::top_up)
-                    pg.reset(new aqcgz::ParallelGunzip(map, size, pool, offload ? std::max(4, inflight / 2) : inflight, sec, offload));
+                    pg.reset(new aqcgz::ParallelGunzip(map, size, pool, inflight, sec, offload));
                 }
                 return;
             }
@@ -680,7 +679,7 @@ struct Run {
                 const char* e = getenv("AQC_GZ_DEVICE_IN");
                 if (!(e && e[0] == '0') && !P->gz_offload_tried[f] && !P->ctx.empty()) {
                     P->gz_offload_tried[f] = true;
-                    size_t group = 256u << 20;
+                    size_t group = 64u << 20;
                     if (const char* g = getenv("AQC_GZ_GROUP")) group = (size_t)std::max(1ll, atoll(g));
                     P->gz_offload[f].reset(aqcgz::make_device_offload(aqc_device_index(P->ctx[(size_t)f % P->ctx.size()]), group));
                 }
@@ -823,6 +822,14 @@ struct Run {
     void worker(int ci, int slot) {
         aqc_ctx* c = P->ctx[ci];
         const int wid = ci * P->slots + slot;
+        // this thread drives one GPU: it runs on the CPUs next to that GPU, and the page-locked output sets it touches first
+        // (P->wbufs[wid]) come from that node's memory.  Readers and file writers serve every context: they float.
+        {
+            const int node = aqc_device_numa_node(c), bound = aqc_bind_thread_to_node(node);
+            if (slot == 0 && getenv("AQC_PIPE_DEBUG"))
+                fprintf(stderr, "pipe: context %d (device %d) — NUMA node %d, its %d slot workers %s; reader / writer / pool threads are not bound (they serve all contexts)\n",
+                        ci, aqc_device_index(c), node, P->slots, bound ? "bound to that node's CPUs" : "not bound (single node, unknown, or AQC_PIPE_NUMA=0)");
+        }
         Job j;
         int set = 0;
         while (!abort && jobq[ci]->pop(j)) {
@@ -1168,6 +1175,12 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
         for (auto& c : cpu_us) named += 1e-6 * (double)c.load();
         fprintf(stderr, "pipe: CPU seconds — process %.3f = pool %.3f + readers %.3f + dispatcher %.3f + slot workers %.3f + commit %.3f + file writers %.3f + other threads (GPU runtime, caller) %.3f\n",
                 proc, pool, 1e-6 * cpu_us[1], 1e-6 * cpu_us[2], 1e-6 * cpu_us[3], 1e-6 * cpu_us[4], 1e-6 * cpu_us[0], proc - pool - named);
+        {
+            uint64_t ds[8];
+            aqcgz::device_offload_stats(ds);
+            if (ds[5]) fprintf(stderr, "pipe: device gunzip so far (process-wide) — %llu groups, %llu sections given / %llu found; ms in scan %.1f, decode %.1f, chain + gather %.1f, H2D %.1f, D2H %.1f\n",
+                               (unsigned long long)ds[5], (unsigned long long)ds[6], (unsigned long long)ds[7], ds[0] / 1e3, ds[1] / 1e3, ds[2] / 1e3, ds[3] / 1e3, ds[4] / 1e3);
+        }
 #ifdef AQC_GZ_PROFILE
         fprintf(stderr, "pipe: gunzip thread-CPU ms — find %ld, decode (find included) %ld, translate %ld, crc %ld, consumer waiting %ld, accept %ld\n", aqcgz::gz_prof[0].exchange(0) / 1000,
                 aqcgz::gz_prof[1].exchange(0) / 1000, aqcgz::gz_prof[2].exchange(0) / 1000, aqcgz::gz_prof[3].exchange(0) / 1000, aqcgz::gz_prof[4].exchange(0) / 1000, aqcgz::gz_prof[5].exchange(0) / 1000);

@@ -204,6 +204,13 @@ int aqc_create(int device, int n_slots, aqc_ctx** out);
 void aqc_destroy(aqc_ctx* ctx);
 int aqc_device_name(aqc_ctx* ctx, char* buf, int buflen);
 int aqc_device_index(aqc_ctx* ctx); /* the HIP device the context lives on */
+/* The NUMA node the context's GPU hangs off (/sys/bus/pci/devices/<bus id>/numa_node; -1: unknown or a single-node host), and a
+ * helper that binds the CALLING thread to that node's CPUs (intersected with the CPUs it may use; returns how many, 0 = left
+ * alone; AQC_PIPE_NUMA=0 switches it off).  aqc_pipe_run binds every slot worker to the node of its context's GPU: the
+ * page-locked output buffers it touches first and the copies it drives then stay on the GPU's side of the socket link. */
+int aqc_device_numa_node(aqc_ctx* ctx);
+int aqc_device_numa_node_of(int device);
+int aqc_bind_thread_to_node(int node);
 
 /* ---- configuration ---------------------------------------------------------------------------- */
 int aqc_set_config(aqc_ctx* ctx, const aqc_config* cfg);

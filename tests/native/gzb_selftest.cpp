@@ -117,14 +117,16 @@ struct CpuOffload : aqcgz::SectionOffload {
         }
         // ---- decode: a lane per candidate
         std::vector<uint32_t> cnt(16), nxt(16), off(16);
+        std::vector<uint16_t> tab(GZB_TAB_ENTRIES);
         for (uint32_t c = 0; c < nc; ++c) {
-            const GzbTables T(J.tables + (size_t)c * GZB_TAB_WORDS);
+            uint8_t* const lens = reinterpret_cast<uint8_t*>(J.tables + (size_t)c * GZB_TAB_WORDS);
+            const GzbLaneTab<1> T{tab.data()};
             uint32_t p = 0, hlit = 0, hdist = 0, op = 0, fl = 0;
             if (c_symcap[c] == 0) fl = GZB_F_SKIP;
-            else if (!gzb_header(J.comp, limit_bit, c_start[c], cl.data(), 1, T.lens, p, hlit, hdist)) fl = GZB_F_ERROR;
+            else if (!gzb_header(J.comp, limit_bit, c_start[c], cl.data(), 1, lens, p, hlit, hdist)) fl = GZB_F_ERROR;
             if (!fl) {
-                gzb_build<true>(T.lens, hlit, GZB_LROOT, T.lit, T.lsorted, T.lcount, cnt.data(), nxt.data(), off.data(), 1);
-                gzb_build<false>(T.lens + hlit, hdist, GZB_DROOT, T.dist, T.dsorted, T.dcount, cnt.data(), nxt.data(), off.data(), 1);
+                gzb_build<true>(lens, hlit, T, cnt.data(), nxt.data(), off.data(), 1);
+                gzb_build<false>(lens + hlit, hdist, T, cnt.data(), nxt.data(), off.data(), 1);
                 fl = gzb_decode_block(J.comp, limit_bit, T, J.blk_sym + c_symoff[c], c_symcap[c], p, op);
             }
             c_end[c] = p; c_nsym[c] = op; c_flags[c] = fl;
