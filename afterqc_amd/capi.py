@@ -744,9 +744,54 @@ def pipe_split(source, chunk_records, gzip_in=False, io_threads=4, cap=1 << 16):
     return nbytes[:k].tolist(), lines[:k].tolist(), int(crc.value)
 
 
+def merge_kmer_parts(parts):
+    """k-mer dictionaries of several engines / ranks as one: counts add up, the first-seen key (the GLOBAL index of the read that
+    inserted the k-mer, stamped by the device) takes the minimum — so that ties order exactly like a sequential run
+    (qualitycontrol.py:113-122,155-156).  parts: (keys, counts, order) triples; returns one."""
+    parts = list(parts)
+    if len(parts) == 1:
+        return parts[0]
+    keys = np.concatenate([p[0] for p in parts])
+    counts = np.concatenate([p[1] for p in parts])
+    order = np.concatenate([p[2] for p in parts])
+    uk, inv = np.unique(keys, return_inverse=True)
+    c = np.zeros(len(uk), dtype=np.int64)
+    np.add.at(c, inv, counts)
+    o = np.full(len(uk), np.iinfo(np.uint64).max, dtype=np.uint64)
+    np.minimum.at(o, inv, order)
+    return uk, c, o
+
+
+def collect_stats(engine, paired=True):
+    """Every statistic of one engine as plain numpy (picklable: what a rank of a multi-process run sends to rank 0)."""
+    whichs = (0, 1, 2, 3) if paired else (QC_R1_PRE, QC_R1_POST)
+    ovl, dist = engine.histograms()
+    return {"counters": engine.counters(), "ovl": ovl, "dist": dist, "qc": {w: engine.qc(w) for w in whichs},
+            "kmers": {w: tuple(np.asarray(a) for a in engine.kmers(w)) for w in whichs}}
+
+
+def merge_stats(parts):
+    """SURVEY.md §8e, the ONE merge rule of this package (MergedEngines uses the same pieces): counters, histograms and QC rows
+    are summed, k-mer dictionaries go through merge_kmer_parts.  No collective: integers on the host."""
+    parts = list(parts)
+    out = {"counters": sum(p["counters"] for p in parts), "ovl": sum(p["ovl"] for p in parts), "dist": sum(p["dist"] for p in parts),
+           "qc": {}, "kmers": {}}
+    for w in parts[0]["qc"]:
+        out["qc"][w] = sum(p["qc"][w] for p in parts)
+        out["kmers"][w] = merge_kmer_parts([p["kmers"][w] for p in parts])
+    return out
+
+
+def top_kmers(kmers, kmer_len, top=10):
+    """sortKmer (qualitycontrol.py:155-156) on a (keys, counts, order) triple: count descending, insertion order for ties"""
+    keys, counts, order = kmers
+    idx = sorted(range(len(keys)), key=lambda i: (-int(counts[i]), int(order[i])))[:top]
+    return [[int(keys[i]).to_bytes(8, "little")[:kmer_len].decode("latin-1"), int(counts[i])] for i in idx]
+
+
 class MergedEngines:
     """Statistics of several engines seen as one (per-GPU integers are summed on the host; k-mer dictionaries
-    merge by count sum and smallest first-seen key).  Read-only: counters / histograms / qc / kmers."""
+    merge by count sum and smallest first-seen key — merge_kmer_parts).  Read-only: counters / histograms / qc / kmers."""
 
     def __init__(self, engines):
         self.engines = list(engines)
@@ -762,15 +807,4 @@ class MergedEngines:
         return sum(e.qc(which) for e in self.engines)
 
     def kmers(self, which, cap=1 << 22):
-        parts = [e.kmers(which, cap) for e in self.engines]
-        if len(parts) == 1:
-            return parts[0]
-        keys = np.concatenate([p[0] for p in parts])
-        counts = np.concatenate([p[1] for p in parts])
-        order = np.concatenate([p[2] for p in parts])
-        uk, inv = np.unique(keys, return_inverse=True)
-        c = np.zeros(len(uk), dtype=np.int64)
-        np.add.at(c, inv, counts)
-        o = np.full(len(uk), np.iinfo(np.uint64).max, dtype=np.uint64)
-        np.minimum.at(o, inv, order)
-        return uk, c, o
+        return merge_kmer_parts([e.kmers(which, cap) for e in self.engines])

@@ -311,6 +311,8 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
     // (the division runs on the vector unit: bring the result back to a scalar register once)
     const int run_req = __builtin_amdgcn_readfirstlane(cfg.allow_mismatch_in_poly >= 0 ? (need + cfg.allow_mismatch_in_poly) / (cfg.allow_mismatch_in_poly + 1) : 0);
     const int r2b = __builtin_amdgcn_readfirstlane((PAIRED && cfg.count_r2_bases) ? 1 : 0);
+    // (the one-word polyX screen needs the firing span to hold a whole aligned word and the word test to mean something)
+    const int poly_word = __builtin_amdgcn_readfirstlane((cfg.allow_mismatch_in_poly >= 0 && cfg.poly_size_limit - cfg.allow_mismatch_in_poly >= 31 && cfg.allow_mismatch_in_poly <= 5) ? 1 : 0);
     BarcodeCodes bc{0, 0, 0, 0};
     if (BARCODE) {
         for (int j = 0; j < cfg.barcode_verify_len && j < 32; ++j) {
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         // spills them to VGPR lanes — v_writelane / v_readlane + hazard nops were ~6 % of the vector instructions issued.
         FastArgsRare Rb = R;
         asm volatile("" : "+s"(Rb));
-        const int o_do_trim = do_trim, o_run_req = run_req, o_r2b = r2b, o_thr4 = thr4;
+        const int o_do_trim = do_trim, o_run_req = run_req, o_r2b = r2b, o_thr4 = thr4, o_poly_word = poly_word;
         __builtin_amdgcn_s_setprio(AQC_PRIO1);
         const uint32_t base = cur * PPW;
         // exactly ONE batch of lookahead (its descriptors travel while this batch is processed): a slow wave never sits
@@ -776,7 +778,21 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
         if (Rb->cfg.poly_size_limit > 0 && !(AQC_ABL & 4)) {
             bool sus = false;
             if (o_run_req < 2) sus = len_own >= Rb->cfg.poly_size_limit;
-            else {
+            else if (o_poly_word) {
+                // hasPolyX fires on a span of >= maxPoly - mismatch >= 31 bases that holds at most `mismatch` foreign ones
+                // (preprocesser.py:37-50).  Such a span contains a whole aligned 16-base word of the stream, and in that word at
+                // most 2 * mismatch of the 15 neighbour pairs differ: one word test — XOR with the stream moved on by a base, count
+                // the non-zero fields — instead of the run-length doubling over every word (6 of the kernel's 78 vector
+                // instructions per pair).  The exact check below decides, as before.
+                int fewest = 15;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) {
+                    const uint32_t w = own[j];
+                    const uint32_t x = w ^ (w >> 2);
+                    fewest = min(fewest, (int)__popc((x | (x >> 1)) & 0x15555555u));
+                }
+                sus = fewest <= 2 * Rb->cfg.allow_mismatch_in_poly && len_own >= Rb->cfg.poly_size_limit;
+            } else {
                 uint32_t r[NW + 1];
                 uint32_t lo0 = own[0], e0 = own[NW];
 #pragma unroll
@@ -1117,10 +1133,15 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 // byte offsets of column 0's qualities (32-bit, from the arenas' bases: one add per load, no 64-bit address math)
                 const uint32_t qa0 = walker ? pr[WL::D_Q1] + (uint32_t)(a1 + (len1 - ovl)) : 0u;
                 const uint32_t qb0 = walker ? pr[WL::D_Q2] + (uint32_t)(a2 + (len2 - 1)) : 0u;
-                int wcol[3];
-                uint32_t wq1[3], wq2[3];
+                // (a second / third mismatch is walked only when some pair of the batch has one: with ~0.3 mismatches per
+                //  overlapping pair most batches stop after the first — the three steps used to run unconditionally, 8 of the
+                //  kernel's 78 vector instructions per pair)
+                const bool any_q[3] = {true, __ballot(walker && w_n > 1) != 0, __ballot(walker && w_n > 2) != 0};
+                int wcol[3] = {0, 0, 0};
+                uint32_t wq1[3] = {0, 0, 0}, wq2[3] = {0, 0, 0};
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
+                    if (!any_q[q]) continue;
                     wcol[q] = walker && q < w_n ? (q == 0 ? f_p0 : q == 1 ? f_p1 : f_p2) : 0;
                     wq1[q] = fb.qual1[qa0 + (uint32_t)wcol[q]];
                     wq2[q] = fb.qual2[qb0 - (uint32_t)wcol[q]];
@@ -1128,6 +1149,7 @@ __global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overla
                 uint32_t El0 = 0, El1 = 0, El2 = 0, Eh0 = 0, Eh1 = 0, Eh2 = 0;      // edits: column | kind << 16 | base << 24, quality
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
+                    if (!any_q[q]) continue;
                     const bool on = walker && q < w_n;
                     const int oo = wcol[q];
                     const int x1 = on ? shift1 + oo : 0, x2 = on ? shift2 + oo : 0;

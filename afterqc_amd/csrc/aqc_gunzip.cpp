@@ -3,8 +3,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <deque>
 #include <mutex>
+#include <thread>
 
 #include <sys/mman.h>
 
@@ -190,7 +192,8 @@ ParallelGunzip::ParallelGunzip(const uint8_t* data, size_t size, aqc_host::Pool*
 
 ParallelGunzip::~ParallelGunzip() {
     // speculative sections still running hold their own references; wait for them (they read data_)
-    for (auto& s : q_) {
+    for (auto& kv : q_) {
+        const std::shared_ptr<Section>& s = kv.second;
         if (s == unlaunched_) continue;             // (never went to the pool)
         std::unique_lock<std::mutex> lk(s->mu);
         s->cv.wait(lk, [&] { return s->done; });
@@ -335,111 +338,129 @@ void run_sections(const uint8_t* data, size_t size, const std::shared_ptr<Parall
 
 }  // namespace
 
-// the next section in stream order; nullptr when the stream has no further section to launch (no_more) 
-std::shared_ptr<ParallelGunzip::Section> ParallelGunzip::new_section(bool& no_more) {
-    std::shared_ptr<Section> s;
-    for (;;) {
-        if (!started_) {
-            started_ = true;
-            s.reset(new Section());
-            s->index = 0;
-            s->known_start = true;
-            s->start_bit = cur_bit_;
-            s->nominal_bit = cur_bit_;
-            next_section_ = (size_t)((cur_bit_ >> 3) / section_bytes_) + 1;
-        } else {
-            const uint64_t nominal = (uint64_t)next_section_ * section_bytes_;
-            if (nominal + 64 >= size_) { no_more = true; return nullptr; }
-            if (nominal * 8 <= cur_bit_) { ++next_section_; continue; }
-            s.reset(new Section());
-            s->index = next_section_++;
-            s->nominal_bit = nominal * 8;
-        }
-        const uint64_t next_nominal = (uint64_t)next_section_ * section_bytes_;
-        s->stop_bit = next_nominal + 64 >= size_ ? UINT64_MAX : next_nominal * 8;
-        s->sh = sh_;
-        return s;
-    }
+std::shared_ptr<ParallelGunzip::Section> ParallelGunzip::make_section(size_t idx) {
+    std::shared_ptr<Section> s(new Section());
+    s->index = idx;
+    if (idx == start_idx_) {
+        s->known_start = true;
+        s->start_bit = start_bit0_;
+        s->nominal_bit = start_bit0_;
+    } else s->nominal_bit = (uint64_t)idx * section_bytes_ * 8;
+    s->stop_bit = idx < last_idx_ ? (uint64_t)(idx + 1) * section_bytes_ * 8 : UINT64_MAX;
+    s->sh = sh_;
+    return s;
 }
 
-void ParallelGunzip::top_up() {
+// sections go to the pool two at a time (run_sections decodes a pair alternately); an odd one waits for its partner
+void ParallelGunzip::to_pool(const std::shared_ptr<Section>& s) {
+    q_[s->index] = s;
     auto launch = [this](const std::shared_ptr<Section>& s0, const std::shared_ptr<Section>& s1) {
         const uint8_t* data = data_;
         const size_t size = size_;
         if (pool_) pool_->submit([data, size, s0, s1] { run_sections(data, size, s0, s1); }, true);
         else run_sections(data, size, s0, s1);
     };
-    // sections go to the pool two at a time (run_sections decodes a pair alternately); an odd one waits for its partner
-    auto to_pool = [&](const std::shared_ptr<Section>& s) {
-        q_.push_back(s);
-        if (unlaunched_) { launch(unlaunched_, s); unlaunched_.reset(); }
-        else unlaunched_ = s;
-    };
-    bool no_more = false;
+    if (unlaunched_) { launch(unlaunched_, s); unlaunched_.reset(); }
+    else unlaunched_ = s;
+}
+
+// the next window of section indices: [win_lo_, win_hi_); the file's last section runs to the end of the file (its stop bit is
+// "none"), which the device cannot take: it goes to the pool at once
+void ParallelGunzip::next_window() {
+    const size_t per_group = std::max<size_t>(1, (offload_ ? std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ / 8)) : section_bytes_) / section_bytes_);
+    win_hi_ = std::min(last_idx_ + 1, win_lo_ + 8 * per_group);
+    pool_next_ = win_lo_;
+    dev_hi_ = win_hi_;
+    if (win_hi_ == last_idx_ + 1) {
+        dev_hi_ = last_idx_;
+        to_pool(make_section(last_idx_));
+    }
+}
+
+// need_front: the consumer has nothing it may commit next — the lowest section not yet created is made now, whatever the quotas say
+void ParallelGunzip::top_up(bool need_front) {
+    if (!started_) {
+        started_ = true;
+        start_bit0_ = cur_bit_;
+        start_idx_ = (size_t)((cur_bit_ >> 3) / section_bytes_);
+        last_idx_ = start_idx_;
+        // index i > start_idx_ exists while byte i * section_bytes + 64 lies inside the file
+        if (size_ > 64 && (size_ - 65) / section_bytes_ > start_idx_) last_idx_ = (size_ - 65) / section_bytes_;
+        win_lo_ = start_idx_;
+        next_window();
+    }
     for (;;) {
-        size_t on_pool = 0, on_device = 0;
-        for (auto& s : q_) (s->offloaded ? on_device : on_pool)++;
-        // The pool's share first (the sections the consumer will want next), then — whenever the device is free — a GROUP of
-        // sections behind them.  Who gets how much settles by itself: the device takes a group each time it is ready, the pool
-        // a section each time one of its `inflight_` is committed.
-        // (with a device decoder the pool works four times as far ahead: the consumer reaches a device group only after the pool
-        //  sections in front of it, and while it waits there for the group's ~70 ms the pool must have sections BEHIND the group
-        //  to decode — round 4's first wiring kept 2 x inflight and the pool sat idle behind every group: 0.60 s instead of 0.35)
-        if (!offload_only_ && on_pool < (size_t)inflight_ * (offload_ ? 4u : 1u)) {
-            std::shared_ptr<Section> s = new_section(no_more);
-            if (!s) break;
-            to_pool(s);
+        if (pool_next_ >= dev_hi_) {                          // this window is handed out
+            if (win_hi_ > last_idx_) break;
+            win_lo_ = win_hi_;
+            next_window();
             continue;
         }
-        if (!offload_ || no_more) break;
-        // a group costs the device a fixed ~50 ms (one block is decoded by one lane, start to end) plus its transfers, whatever its
-        // size: big groups are what makes it fast, but a file should still be many groups (two are in flight at a time, and the
-        // pool must have its share between them)
-        const size_t per_group = std::max<size_t>(1, (offload_only_ ? offload_->group_bytes() : std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ / 8))) / section_bytes_);
-        if (on_device >= 3 * per_group || !offload_->ready()) break;
+        size_t on_pool = 0, on_device = 0;
+        for (auto& kv : q_) (kv.second->offloaded ? on_device : on_pool)++;
+        const bool front_missing = need_front && (q_.empty() || q_.begin()->first >= lowest_uncreated());
+        const size_t per_group = std::max<size_t>(1, (offload_ ? (offload_only_ ? offload_->group_bytes() : std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ / 8)))
+                                                               : section_bytes_) / section_bytes_);
+        // The pool's share, from the bottom of the window up: the sections the consumer wants next.  (With a device decoder it
+        // may work twice as far ahead: it is the only one feeding the consumer while a device group is under way.)
+        if (!offload_only_ && (on_pool < (size_t)inflight_ * (offload_ ? 2u : 1u) || front_missing)) {
+            const size_t idx = pool_next_++;
+            if (idx != start_idx_ && (uint64_t)idx * section_bytes_ * 8 <= cur_bit_) continue;     // (its predecessor ran through it)
+            to_pool(make_section(idx));
+            need_front = false;
+            continue;
+        }
+        // The device's share: a GROUP of sections whenever it is free — from the TOP of the window down, so that the consumer,
+        // who commits in index order, gets there last (offload_only: from the bottom up, nobody else feeds the consumer)
+        if (!offload_ || on_device >= 4 * per_group || !offload_->ready()) break;
+        size_t lo, hi;
+        if (offload_only_) { lo = pool_next_; hi = std::min(dev_hi_, lo + per_group); }
+        else { hi = dev_hi_; lo = hi > pool_next_ + per_group ? hi - per_group : pool_next_; }
         std::vector<std::shared_ptr<Section>> group;
-        std::shared_ptr<Section> last;                       // the stream's last section runs to the end of the file: the pool's
-        while (group.size() < per_group) {
-            std::shared_ptr<Section> s = new_section(no_more);
-            if (!s) break;
-            if (s->stop_bit == UINT64_MAX) { last = s; break; }
-            group.push_back(s);
+        for (size_t idx = lo; idx < hi; ++idx) {
+            if (idx != start_idx_ && (uint64_t)idx * section_bytes_ * 8 <= cur_bit_) continue;
+            group.push_back(make_section(idx));
         }
-        if (!group.empty()) {
-            std::vector<uint64_t> nominal(group.size()), stop(group.size());
-            std::vector<uint8_t> exact(group.size());
-            for (size_t k = 0; k < group.size(); ++k) {
-                group[k]->offloaded = true;
-                nominal[k] = group[k]->nominal_bit; stop[k] = group[k]->stop_bit; exact[k] = group[k]->known_start ? 1 : 0;
-            }
-            SectionOffload* const off = offload_;
-            auto done = [group, off](int k, const OffloadResult& r) {
-                Section& s = *group[(size_t)k];
-                s.found = r.found;
-                s.start_bit = r.start_bit;
-                s.end_bit = r.end_bit;
-                s.ext_sym = r.sym;
-                s.n_out = r.n_sym;
-                s.ext_token = r.token;
-                s.ext_owner = off;
-                {
-                    std::lock_guard<std::mutex> g(s.mu);
-                    s.done = true;
-                }
-                s.cv.notify_all();
-            };
-            if (offload_->submit(data_, size_, (int)group.size(), nominal.data(), stop.data(), exact.data(), done)) {
-                for (auto& s : group) q_.push_back(s);
-                sections_offloaded += group.size();
-            } else {
-                for (auto& s : group) { s->offloaded = false; to_pool(s); }
-            }
+        if (offload_only_) pool_next_ = hi; else dev_hi_ = lo;
+        if (group.empty()) continue;
+        std::vector<uint64_t> nominal(group.size()), stop(group.size());
+        std::vector<uint8_t> exact(group.size());
+        for (size_t k = 0; k < group.size(); ++k) {
+            group[k]->offloaded = true;
+            nominal[k] = group[k]->nominal_bit; stop[k] = group[k]->stop_bit; exact[k] = group[k]->known_start ? 1 : 0;
         }
-        if (last) to_pool(last);
-        if (group.empty() && !last) break;
+        SectionOffload* const off = offload_;
+        auto done = [group, off](int k, const OffloadResult& r) {
+            Section& s = *group[(size_t)k];
+            s.found = r.found;
+            s.start_bit = r.start_bit;
+            s.end_bit = r.end_bit;
+            s.ext_sym = r.sym;
+            s.n_out = r.n_sym;
+            s.ext_token = r.token;
+            s.ext_owner = off;
+            {
+                std::lock_guard<std::mutex> g(s.mu);
+                s.done = true;
+            }
+            s.cv.notify_all();
+        };
+        if (offload_->submit(data_, size_, (int)group.size(), nominal.data(), stop.data(), exact.data(), done)) {
+            for (auto& g : group) q_[g->index] = g;
+            sections_offloaded += group.size();
+        } else {
+            for (auto& g : group) { g->offloaded = false; to_pool(g); }
+        }
     }
-    // ... but not when nothing will follow it, and never when it is the section the consumer is going to wait for
-    if (unlaunched_ && (no_more || q_.front() == unlaunched_ || !pool_ || offload_only_)) { launch(unlaunched_, nullptr); unlaunched_.reset(); }
+    // an odd pool section is launched alone when nothing will follow it, and always when it is the one the consumer waits for
+    if (unlaunched_ && (pool_next_ >= dev_hi_ || q_.begin()->second == unlaunched_ || !pool_ || offload_only_)) {
+        const std::shared_ptr<Section> s0 = unlaunched_;
+        unlaunched_.reset();
+        const uint8_t* data = data_;
+        const size_t size = size_;
+        if (pool_) pool_->submit([data, size, s0] { run_sections(data, size, s0, nullptr); }, true);
+        else run_sections(data, size, s0, nullptr);
+    }
 }
 
 void ParallelGunzip::push_window(const uint8_t* p, size_t n) {
@@ -504,7 +525,7 @@ void ParallelGunzip::accept(Section& s, uint8_t* dst, size_t& out, size_t want) 
     uint8_t* const d0 = dst + out;
     size_t pos = 0;
     std::shared_ptr<Section> keep;
-    for (auto& q : q_) if (q.get() == &s) keep = q;
+    for (auto& kv : q_) if (kv.second.get() == &s) keep = kv.second;
     for (size_t me = 0; me <= s.ends.size(); ++me) {
         const size_t seg_end = me < s.ends.size() ? s.ends[me].out_pos : n;
         if (seg_end > pos) {
@@ -636,9 +657,16 @@ size_t ParallelGunzip::read(uint8_t* dst, size_t want) {
     }
     while (out < want && !bad_ && !done_) {
         if (bridge_state_ && bridge_state_->active) { bridge(0, dst, out, want); continue; }
-        top_up();
+        // the lowest section in the queue may be committed next only if every section below it has been created (the device's
+        // groups come from the top of the window: there may be a gap below them that nobody has been given yet)
+        for (bool need = false;; need = true) {
+            top_up(need);
+            if (!q_.empty() && q_.begin()->first < lowest_uncreated()) break;
+            if (lowest_uncreated() > last_idx_) break;            // nothing left to create
+            if (need) std::this_thread::sleep_for(std::chrono::microseconds(50));      // (offload_only: a device lane is about to be free)
+        }
         if (q_.empty()) { bridge(UINT64_MAX, dst, out, want); continue; }
-        std::shared_ptr<Section> f = q_.front();
+        std::shared_ptr<Section> f = q_.begin()->second;
         {
             GZ_PROF(4);
             std::unique_lock<std::mutex> lk(f->mu);

@@ -386,8 +386,22 @@ GZB_HD inline uint32_t gzb_decode_block(const uint8_t* comp, uint32_t limit_bit,
         const int src = (int)op - (int)dd;
         if (src < -32768) { fl = GZB_F_ERROR; break; }
         uint16_t* const dst = out + op;
-        if (src >= 0 && dd >= 4u) {
-            // four symbols per step (the steps may run up to three symbols over: the next token overwrites them)
+        if (src >= 0 && dd >= len) {
+            // The usual match of a FASTQ stream — the same column of the record before — does not overlap itself: up to eight
+            // 8-byte loads are issued before the first store, ONE trip to memory for 32 symbols.  (A load behind a store the
+            // compiler cannot prove disjoint waits for it: the step-by-step loop below pays a memory round trip per four symbols,
+            // which was most of the 4 microseconds a token took.)  The last word may run up to three symbols over: the next token
+            // overwrites them.
+            const uint16_t* const s = out + src;
+            for (uint32_t b = 0; b < len; b += 32) {
+                unsigned long long v[8];
+                for (int k = 0; k < 8; ++k)
+                    if (b + 4u * (uint32_t)k < len) memcpy(&v[k], s + b + 4 * k, 8);
+                for (int k = 0; k < 8; ++k)
+                    if (b + 4u * (uint32_t)k < len) memcpy(dst + b + 4 * k, &v[k], 8);
+            }
+        } else if (src >= 0 && dd >= 4u) {
+            // overlapping, period >= 4: four symbols per step
             const uint16_t* const s = out + src;
             for (uint32_t i = 0; i < len; i += 4) {
                 unsigned long long v;

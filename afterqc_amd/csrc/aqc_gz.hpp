@@ -14,6 +14,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <functional>
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -139,7 +140,7 @@ private:
         bool active = false;
         uint64_t until = 0;
     };
-    void top_up();
+    void top_up(bool need_front = false);
     void accept(Section& s, uint8_t* dst, size_t& out, size_t want);
     void bridge(uint64_t until_bit, uint8_t* dst, size_t& out, size_t want);
     void emit(const uint8_t* p, size_t n, uint8_t* dst, size_t& out, size_t want);
@@ -155,11 +156,20 @@ private:
     size_t section_bytes_;
     SectionOffload* offload_ = nullptr;
     bool offload_only_ = false;
-    std::shared_ptr<Section> new_section(bool& no_more);     // the next section in stream order (nullptr: nothing to launch now)
+    std::shared_ptr<Section> make_section(size_t idx);
+    void to_pool(const std::shared_ptr<Section>& s);
+    void next_window();
+    size_t lowest_uncreated() const { return pool_next_ < dev_hi_ ? pool_next_ : win_hi_; }
     std::shared_ptr<Shared> sh_;
-    std::vector<std::shared_ptr<Section>> q_;       // in flight, by nominal start
-    std::shared_ptr<Section> unlaunched_;          // the last of them, while it waits for a partner (sections are decoded in pairs)
-    size_t next_section_ = 0;                      // next section index to launch (nominal start = index * section_bytes)
+    std::map<size_t, std::shared_ptr<Section>> q_;  // created and not yet committed, by section index
+    std::shared_ptr<Section> unlaunched_;          // the last pool section, while it waits for a partner (sections are decoded in pairs)
+    // Section indices: start_idx_ is the section that begins at the stream's known first block, index i > start_idx_ is searched
+    // from byte i * section_bytes on, last_idx_ runs to the end of the file.  They are handed out window by window
+    // ([win_lo_, win_hi_)): the POOL takes them from the bottom up (pool_next_), the DEVICE in groups from the top down
+    // (dev_hi_) — the consumer commits in index order, so it reaches a device group only after everything the pool did in
+    // front of it, which is as long as the device can possibly be given; the two meet wherever their speeds put them.
+    size_t start_idx_ = 0, last_idx_ = 0, win_lo_ = 0, win_hi_ = 0, pool_next_ = 0, dev_hi_ = 0;
+    uint64_t start_bit0_ = 0;
     uint64_t cur_bit_ = 0;                         // everything before this bit is decoded and committed
     bool started_ = false, done_ = false, bad_ = false;
     char err_[160] = "";

@@ -677,13 +677,18 @@ struct Run {
             if (io->gzip_in[f]) {
                 // gzip input: the GPUs take groups of sections off the pool's hands (file f -> the device of context f % n)
                 const char* e = getenv("AQC_GZ_DEVICE_IN");
-                if (!(e && e[0] == '0') && !P->gz_offload_tried[f] && !P->ctx.empty()) {
+                if (!(e && e[0] == '0') && !P->gz_offload_tried[f] && !P->ctx.empty()) {      // (set up with the first .gz input of this file slot)
                     P->gz_offload_tried[f] = true;
                     size_t group = 64u << 20;
                     if (const char* g = getenv("AQC_GZ_GROUP")) group = (size_t)std::max(1ll, atoll(g));
                     P->gz_offload[f].reset(aqcgz::make_device_offload(aqc_device_index(P->ctx[(size_t)f % P->ctx.size()]), group));
                 }
-                src.reset(new GzSource(io->in_path[f], P->pool.get(), 0, (e && e[0] == '0') ? nullptr : P->gz_offload[f].get()));
+                // (a device group costs ~50 ms whatever its size: files the pool finishes sooner than that are left to the pool)
+                size_t dev_min = 48u << 20;
+                if (const char* m = getenv("AQC_GZ_DEVICE_MIN")) dev_min = (size_t)std::max(0ll, atoll(m));
+                struct stat gst;
+                const bool big = stat(io->in_path[f], &gst) == 0 && (size_t)gst.st_size >= dev_min;
+                src.reset(new GzSource(io->in_path[f], P->pool.get(), 0, (big && !(e && e[0] == '0')) ? P->gz_offload[f].get() : nullptr));
             }
             else src.reset(new FileSource(io->in_path[f], P->pool.get()));
             if (src->failed()) { fail(AQC_ERR_ARG, "cannot open %s", io->in_path[f]); return; }

@@ -220,7 +220,7 @@ int failures = 0;
 
 // decode gz through ParallelGunzip with the CPU emulation of the device as its offloader; returns the offloader's counters
 bool run_case(const char* what, const std::vector<uint8_t>& gz, const std::vector<uint8_t>& text, size_t section, size_t group, int threads, bool want_device,
-              uint32_t ratio_cap = 20, uint32_t cand_div = 4096, bool expect_fail = false) {
+              uint32_t ratio_cap = 20, uint32_t cand_div = 4096, bool expect_fail = false, bool hybrid = false) {
     CpuOffload off(group);
     off.ratio_cap = ratio_cap; off.cand_div = cand_div;
     aqc_host::Pool pool(threads);
@@ -229,7 +229,7 @@ bool run_case(const char* what, const std::vector<uint8_t>& gz, const std::vecto
     bool failed = false;
     uint64_t dev_acc = 0, host_acc = 0, bridged = 0;
     {
-        aqcgz::ParallelGunzip pg(gz.data(), gz.size(), threads ? &pool : nullptr, 4, section, &off, true);
+        aqcgz::ParallelGunzip pg(gz.data(), gz.size(), threads ? &pool : nullptr, 4, section, &off, !hybrid);
         for (;;) {
             const size_t got = pg.read(out.data() + produced, std::min<size_t>(out.size() - produced, 777777));
             if (pg.failed()) { failed = true; break; }
@@ -243,6 +243,7 @@ bool run_case(const char* what, const std::vector<uint8_t>& gz, const std::vecto
     else {
         ok = !failed && produced == text.size() && (text.empty() || memcmp(out.data(), text.data(), text.size()) == 0);
         if (ok && want_device && dev_acc == 0) ok = false;
+        if (ok && hybrid && want_device && host_acc == 0) ok = false;      // the pool and the device both supplied sections
     }
     printf("%-46s %s  gz %8zu -> %9zu B  sec %7zu  device sections %3llu  host %3llu  bridged %9llu B  candidates %llu  groups %llu\n", what, ok ? "ok  " : "FAIL", gz.size(),
            text.size(), section, (unsigned long long)dev_acc, (unsigned long long)host_acc, (unsigned long long)bridged, (unsigned long long)off.candidates, (unsigned long long)off.groups);
@@ -315,6 +316,20 @@ int main() {
         const std::vector<uint8_t> big = fastq_like(60000, 11);   // ~21 MB: several groups of 2 MiB, distances near 32 KiB do occur at level 9
         run_case("fastq 21 MB level 9, 256 KiB sections", gz_of(big, 9, Z_DEFAULT_STRATEGY), big, 256 << 10, 2 << 20, 4, true);
         run_case("fastq 21 MB level 1, 1 MiB sections", gz_of(big, 1, Z_DEFAULT_STRATEGY), big, 1 << 20, 4 << 20, 4, true);
+    }
+    {
+        // HYBRID: the pool takes the window's sections from the bottom up, the device groups from the top down (what the pipe runs)
+        const std::vector<uint8_t> big = fastq_like(60000, 12);
+        const std::vector<uint8_t> g6 = gz_of(big, 6, Z_DEFAULT_STRATEGY), g1 = gz_of(big, 1, Z_DEFAULT_STRATEGY);
+        run_case("hybrid: 21 MB level 6, 64 KiB sections, groups of 4", g6, big, 64 << 10, 256 << 10, 3, true, 20, 4096, false, true);
+        run_case("hybrid: 21 MB level 1, 128 KiB sections, groups of 8", g1, big, 128 << 10, 1 << 20, 2, true, 20, 4096, false, true);
+        run_case("hybrid: 21 MB level 6, no pool threads", g6, big, 64 << 10, 512 << 10, 0, true, 20, 4096, false, true);
+        run_case("hybrid: full flush every 128 KiB", gz_of(big, 6, Z_DEFAULT_STRATEGY, 128 << 10, Z_FULL_FLUSH), big, 64 << 10, 256 << 10, 3, true, 20, 4096, false, true);
+        std::vector<uint8_t> bad = g6;
+        bad[bad.size() / 3] ^= 0x44;
+        run_case("hybrid: one byte damaged", bad, big, 64 << 10, 256 << 10, 3, false, 20, 4096, true, true);
+        const std::vector<uint8_t> small = fastq_like(300, 13);
+        run_case("hybrid: 100 KB file", gz_of(small, 6, Z_DEFAULT_STRATEGY), small, 64 << 10, 256 << 10, 2, false, 20, 4096, false, true);
     }
     if (failures) { printf("%d FAILED\n", failures); return 1; }
     printf("all device-gunzip logic checks passed\n");

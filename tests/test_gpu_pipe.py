@@ -253,10 +253,12 @@ def test_pipe_single_member_gzip_input_is_shared_with_the_device(tmp_path):
         return [int(a) - int(b) for a, b in zip(after_, before)]
 
     os.environ["AQC_GZ_GROUP"] = str(8 << 20)
+    os.environ["AQC_GZ_DEVICE_MIN"] = "0"        # (files this small are normally left to the pool)
     try:
         sections, from_device, text_bytes, device_bytes = gz_run("gzdev")
     finally:
         del os.environ["AQC_GZ_GROUP"]
+        del os.environ["AQC_GZ_DEVICE_MIN"]
     assert sections > 20 and from_device > 0.3 * sections and device_bytes > 0.3 * text_bytes, (sections, from_device, text_bytes, device_bytes)
     os.environ["AQC_GZ_DEVICE_IN"] = "0"
     try:

@@ -9,7 +9,7 @@ import numpy as np
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from afterqc_amd import capi, sharding, synth
+from afterqc_amd import capi, synth
 
 
 def _cfg():
@@ -33,15 +33,48 @@ def _batches(n=3000, per=500):
     return out
 
 
+def owner(batch_index, world):
+    """rank that processes batch `batch_index`: fixed-size batches dealt round robin, each carrying its first_index"""
+    return batch_index % world
+
+
+def run_rank(engine, cfg, batches, rank, world, qc_sample, paired=True):
+    """Process the batches owned by `rank` (list of (batch_index, Batch) for ALL batches, in file order).
+    Returns ({batch_index: result records}, statistics in capi.collect_stats form)."""
+    engine.set_config(cfg)
+    engine.reset_stats()
+    results = {}
+    for bi, batch in batches:
+        if owner(bi, world) != rank:
+            continue
+        engine.upload(0, batch)
+        engine.run(0)
+        # post-filter QC while TOTAL_READS < qc_sample (preprocesser.py:624): global 0-based index < qc_sample - 1
+        n_qc = batch.n if qc_sample <= 0 else max(0, min(batch.n, qc_sample - 1 - batch.first_index))
+        if n_qc > 0:
+            engine.qc_stat(0, capi.QC_R1_POST, 0, 0, n_qc, 1)
+            if paired:
+                engine.qc_stat(0, capi.QC_R2_POST, 1, 0, n_qc, 1)
+        results[bi] = engine.fetch_results(0)
+    return results, capi.collect_stats(engine, paired)
+
+
+def gather_to_root(obj, rank, world):
+    """host-side merge transport: no tensor collective, just pickled objects to rank 0"""
+    bucket = [None] * world if rank == 0 else None
+    dist.gather_object(obj, bucket, dst=0)
+    return bucket
+
+
 def _worker(rank, world, port, qc_sample, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle
-    res, stats = sharding.run_rank(oracle.OracleEngine(), _cfg(), _batches(), rank, world, qc_sample)
-    parts = sharding.gather_to_root((res, stats), dist, rank, world)
+    res, stats = run_rank(oracle.OracleEngine(), _cfg(), _batches(), rank, world, qc_sample)
+    parts = gather_to_root((res, stats), rank, world)
     if rank == 0:
-        merged = sharding.merge([p[1] for p in parts])
+        merged = capi.merge_stats([p[1] for p in parts])
         allres = {}
         for p in parts:
             allres.update(p[0])
@@ -54,7 +87,7 @@ def _worker(rank, world, port, qc_sample, ret):
 def test_two_ranks_equal_one():
     qc_sample = 1800
     from oracle import oracle
-    single_res, single = sharding.run_rank(oracle.OracleEngine(), _cfg(), _batches(), 0, 1, qc_sample)
+    single_res, single = run_rank(oracle.OracleEngine(), _cfg(), _batches(), 0, 1, qc_sample)
     single_results = np.concatenate([single_res[k] for k in sorted(single_res)])
 
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -68,14 +101,16 @@ def test_two_ranks_equal_one():
     assert merged["ovl"].tolist() == single["ovl"].tolist() and merged["dist"].tolist() == single["dist"].tolist()
     for w in (0, 1, 2, 3):
         assert np.array_equal(merged["qc"][w], single["qc"][w])
-        assert merged["kmers"][w].keys() == single["kmers"][w].keys()
-        # counts add up exactly; ties are ordered by the merged (global) time keys exactly like the sequential run
-        assert sharding.top_kmers(merged["kmers"][w], 8, 200) == sharding.top_kmers(single["kmers"][w], 8, 200)
-        full_m = sorted(merged["kmers"][w].items(), key=lambda kv: kv[1][1])
-        full_s = sorted(single["kmers"][w].items(), key=lambda kv: kv[1][1])
-        assert [k for k, _ in full_m] == [k for k, _ in full_s]
+        km, ks = merged["kmers"][w], single["kmers"][w]
+
+        def by_key(t):
+            return {int(k): (int(c), int(o)) for k, c, o in zip(*[a.tolist() for a in t])}
+        # the same dictionary: counts add up exactly, every k-mer keeps the earliest (global) first-seen key
+        assert by_key(km) == by_key(ks)
+        # ... so ties are ordered exactly like the sequential run
+        assert capi.top_kmers(km, 8, 200) == capi.top_kmers(ks, 8, 200)
     assert int(merged["counters"][capi.C_TOTAL_READS]) == 3000
 
 
 def test_owner_round_robin():
-    assert [sharding.owner(i, 4) for i in range(8)] == [0, 1, 2, 3, 0, 1, 2, 3]
+    assert [owner(i, 4) for i in range(8)] == [0, 1, 2, 3, 0, 1, 2, 3]
