@@ -1283,6 +1283,10 @@ private:
         J.c_start = (uint32_t*)L.c_start.p; J.c_end = (uint32_t*)L.c_end.p; J.c_nsym = (uint32_t*)L.c_nsym.p; J.c_flags = (uint32_t*)L.c_flags.p;
         J.c_symoff = (uint64_t*)L.c_symoff.p; J.c_symcap = (uint32_t*)L.c_symcap.p; J.blk_sym = (uint16_t*)L.blk_sym.p; J.blk_sym_cap = blk_sym_cap;
         J.ratio_cap = GZB_RATIO_CAP; J.tables = (uint32_t*)L.tables.p;
+        {
+            static const uint32_t slice = [] { const char* e = getenv("AQC_GZ_SLICE"); return e ? (uint32_t)std::max(16, atoi(e)) : 512u; }();
+            J.slice_tokens = slice;
+        }
         J.n_sec = (uint32_t)n; J.s_nominal = (const uint32_t*)L.s_in.p; J.s_stop = J.s_nominal + n; J.s_exact = J.s_nominal + 2 * n;
         J.s_start = (uint32_t*)L.s_out.p; J.s_end = J.s_start + n; J.s_nsym = J.s_start + 2 * n; J.s_nblk = J.s_start + 3 * n;
         J.s_blocks = (uint32_t*)L.s_blocks.p; J.s_off = (uint64_t*)L.s_off.p; J.s_sym = (uint16_t*)L.s_sym.p; J.s_sym_total = s_sym_total; J.s_symcap = s_symcap;
@@ -1290,7 +1294,14 @@ private:
         hipLaunchKernelGGL(gzb_scan_kernel, dim3(n_tiles), dim3(GZB_SCAN_THREADS), 0, L.stream, J);
         hipLaunchKernelGGL(gzb_compact_kernel, dim3(1), dim3(1024), 0, L.stream, J);
         GZB_TRY(hipEventRecord(L.ev[2], L.stream));
-        hipLaunchKernelGGL(gzb_decode_kernel, dim3((cand_cap + GZB_DEC_THREADS - 1) / GZB_DEC_THREADS), dim3(GZB_DEC_THREADS), 0, L.stream, J);
+        // the decoder in slices (aqc_gunzip_dev.hpp): 48 x 512 tokens cover any block zlib writes (<= 16 K tokens) with room to
+        // spare; a block that needs more stays unfinished, its section ends before it and the host goes on from there
+        {
+            static const int n_slices = [] { const char* e = getenv("AQC_GZ_SLICES"); return e ? std::max(1, atoi(e)) : 48; }();
+            const dim3 grid((cand_cap + GZB_DEC_THREADS - 1) / GZB_DEC_THREADS);
+            hipLaunchKernelGGL(gzb_decode_kernel<true>, grid, dim3(GZB_DEC_THREADS), 0, L.stream, J);
+            for (int sl = 1; sl < n_slices; ++sl) hipLaunchKernelGGL(gzb_decode_kernel<false>, grid, dim3(GZB_DEC_THREADS), 0, L.stream, J);
+        }
         GZB_TRY(hipEventRecord(L.ev[3], L.stream));
         hipLaunchKernelGGL(gzb_chain_kernel, dim3((n + 63) / 64), dim3(64), 0, L.stream, J);
         hipLaunchKernelGGL(gzb_place_kernel, dim3(1), dim3(1), 0, L.stream, J);

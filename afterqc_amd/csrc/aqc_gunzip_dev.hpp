@@ -62,18 +62,17 @@ GZB_HD inline uint32_t gzb_rev(uint32_t c, uint32_t len) {
 constexpr uint32_t GZB_MARKER = 0x8000u;
 constexpr int GZB_LROOT = 9, GZB_DROOT = 7;
 // A lane's decoding tables, 16-bit entries: literal/length root (2^9), distance root (2^7), symbols sorted by code (288 + 32),
-// codes per length (16 + 16) = 992 entries.  On the device they live in LDS, entry e of lane l at [e * 64 + l] (the 64 lanes of a
-// wave hit 32 consecutive words: no bank conflicts) — 124 KiB per wave, one wave per CU; every table look-up of the decoder is
-// an LDS access (~50 cycles) instead of a trip to L2 or HBM (200 - 900; round 4's first version: 7,000 cycles per token).
+// codes per length (16 + 16) = 992 entries, in the candidate's own 2.3 KiB of global memory (with its 320 code lengths behind
+// them).  They were in LDS for a while (round 4, second version: 124 KiB per wave): no faster — the look-ups are not what a
+// token waits for — and a decoder that fills a CU's LDS for 50 ms keeps the filter's kernels off that CU for as long.
 constexpr int GZB_E_DIST = 1 << GZB_LROOT, GZB_E_LSORT = GZB_E_DIST + (1 << GZB_DROOT), GZB_E_DSORT = GZB_E_LSORT + 288, GZB_E_LCOUNT = GZB_E_DSORT + 32,
               GZB_E_DCOUNT = GZB_E_LCOUNT + 16, GZB_TAB_ENTRIES = GZB_E_DCOUNT + 16;
-// a candidate's scratch in global memory: its 320 code lengths as bytes
-constexpr int GZB_TAB_WORDS = 80;
+constexpr int GZB_TAB_WORDS = GZB_TAB_ENTRIES / 2 + 80;          // 32-bit words per candidate: the tables, then the code lengths
 constexpr int GZB_SCAN_THREADS = 256, GZB_SCAN_TILE = GZB_SCAN_THREADS * 16, GZB_TILE_CAND = 16;
 constexpr int GZB_DEC_THREADS = 64;
 constexpr int GZB_SEC_BLOCKS = 4096;                // chain entries per section (3 words each)
 constexpr int GZB_GATHER_THREADS = 1024;
-constexpr uint32_t GZB_F_ERROR = 1u, GZB_F_OVERFLOW = 2u, GZB_F_SKIP = 4u;
+constexpr uint32_t GZB_F_ERROR = 1u, GZB_F_OVERFLOW = 2u, GZB_F_SKIP = 4u, GZB_F_MORE = 8u;     // MORE: the slice ended inside the block
 constexpr uint32_t GZB_NONE = 0xffffffffu;
 constexpr uint32_t GZB_STORED = 0x80000000u;
 
@@ -97,7 +96,8 @@ struct GzbJob {
     uint16_t* blk_sym;
     uint64_t blk_sym_cap;        // symbols
     uint32_t ratio_cap;          // a block may expand to ratio_cap x its compressed size (+ 4096 symbols)
-    uint32_t* tables;            // [cand_cap][GZB_TAB_WORDS]: a candidate's code lengths
+    uint32_t* tables;            // [cand_cap][GZB_TAB_WORDS]: a candidate's tables and code lengths
+    uint32_t slice_tokens;       // tokens a lane decodes per launch (the decoder runs in slices: see gzb_decode_kernel)
     // sections
     uint32_t n_sec;
     const uint32_t* s_nominal;   // [n_sec] search from this bit
@@ -333,10 +333,11 @@ GZB_HD inline unsigned long long gzb_load64(const uint8_t* p) {
 // p = the bit behind it, op = symbols written.  A symbol >= 0x8000 is "byte j of the 32 KiB before this block".
 // The stream is read through a 64-bit bit buffer; the word the NEXT refill needs is loaded when the buffer has just been
 // refilled, two or three tokens before it is used, so the loop does not wait for the compressed bytes.
+// At most max_tokens tokens per call: GZB_F_MORE = not at the end of the block yet, call again with the same p / op.
 template <int S>
-GZB_HD inline uint32_t gzb_decode_block(const uint8_t* comp, uint32_t limit_bit, const GzbLaneTab<S>& T, uint16_t* out, uint32_t cap, uint32_t& p, uint32_t& op) {
-    uint32_t fl = 0;
-    op = 0;
+GZB_HD inline uint32_t gzb_decode_block(const uint8_t* comp, uint32_t limit_bit, const GzbLaneTab<S>& T, uint16_t* out, uint32_t cap, uint32_t& p, uint32_t& op,
+                                        uint32_t max_tokens) {
+    uint32_t fl = 0, tokens = 0;
     const uint8_t* const end = comp + (limit_bit >> 3);      // (limit_bit is a multiple of 8; the buffer is padded for 64 bytes behind)
     const uint8_t* ip = comp + (p >> 3);
     unsigned long long bb = gzb_load64(ip) >> (p & 7u);
@@ -354,6 +355,7 @@ GZB_HD inline uint32_t gzb_decode_block(const uint8_t* comp, uint32_t limit_bit,
     for (;;) {
         if (ip > end) { fl = GZB_F_ERROR; break; }
         if (op + 272u > cap) { fl = GZB_F_OVERFLOW; break; }
+        if (tokens++ >= max_tokens) { fl = GZB_F_MORE; break; }
         if (bn < 32u) GZB_REFILL();                           // >= 56 bits now; a literal/length code + its extra bits take <= 20
         uint32_t e = T.at((int)((uint32_t)bb & ((1u << GZB_LROOT) - 1u)));
         if ((e & 15u) == 0u) {
@@ -696,25 +698,36 @@ __global__ __launch_bounds__(1024) void gzb_compact_kernel(GzbJob J) {
 }
 
 // ---- a lane per block --------------------------------------------------------------------------------------------------------------
+// The decoder runs in SLICES of J.slice_tokens tokens per lane and launch (~1.5 ms): a block takes a lane ~50 ms from start to
+// end whatever else the chip does, and a kernel that sits on its CUs for that long keeps the filter's kernels — which want every
+// CU, with all its registers — waiting behind it (measured: the first wiring made `.gz -> .gz` slower than the host alone).
+// Between two slices they get their turn.  FIRST: header, tables, first slice; else: lanes whose block is not finished go on.
+template <bool FIRST>
 __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
-    __shared__ uint16_t s_tab[GZB_TAB_ENTRIES * GZB_DEC_THREADS];
-    __shared__ uint8_t s_cl[128 * GZB_DEC_THREADS];
-    __shared__ uint32_t s_cnt[16 * GZB_DEC_THREADS], s_nxt[16 * GZB_DEC_THREADS], s_off[16 * GZB_DEC_THREADS];
+    __shared__ uint8_t s_cl[FIRST ? 128 * GZB_DEC_THREADS : 1];
+    __shared__ uint32_t s_cnt[FIRST ? 16 * GZB_DEC_THREADS : 1], s_nxt[FIRST ? 16 * GZB_DEC_THREADS : 1], s_off[FIRST ? 16 * GZB_DEC_THREADS : 1];
     const int tid = threadIdx.x;
     const uint32_t c = blockIdx.x * (uint32_t)GZB_DEC_THREADS + (uint32_t)tid;
     if (c >= J.n_cand[0]) return;
     const uint32_t limit_bit = J.comp_bytes * 8u;
     const uint32_t cap = J.c_symcap[c];
-    uint8_t* const lens = reinterpret_cast<uint8_t*>(J.tables + (size_t)c * GZB_TAB_WORDS);
-    const GzbLaneTab<GZB_DEC_THREADS> T{s_tab + tid};
+    uint32_t* const tw = J.tables + (size_t)c * GZB_TAB_WORDS;
+    const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(tw)};
+    uint8_t* const lens = reinterpret_cast<uint8_t*>(tw + GZB_TAB_ENTRIES / 2);
     uint32_t p = 0, hlit = 0, hdist = 0, op = 0, fl = 0;
-    if (cap == 0) fl = GZB_F_SKIP;
-    else if (!gzb_header(J.comp, limit_bit, J.c_start[c], s_cl + tid, GZB_DEC_THREADS, lens, p, hlit, hdist)) fl = GZB_F_ERROR;
-    if (!fl) {
-        gzb_build<true>(lens, hlit, T, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
-        gzb_build<false>(lens + hlit, hdist, T, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
-        fl = gzb_decode_block(J.comp, limit_bit, T, J.blk_sym + J.c_symoff[c], cap, p, op);
+    if (FIRST) {
+        if (cap == 0) fl = GZB_F_SKIP;
+        else if (!gzb_header(J.comp, limit_bit, J.c_start[c], s_cl + tid, GZB_DEC_THREADS, lens, p, hlit, hdist)) fl = GZB_F_ERROR;
+        if (!fl) {
+            gzb_build<true>(lens, hlit, T, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
+            gzb_build<false>(lens + hlit, hdist, T, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
+        }
+    } else {
+        if (J.c_flags[c] != GZB_F_MORE) return;
+        p = J.c_end[c];
+        op = J.c_nsym[c];
     }
+    if (!fl) fl = gzb_decode_block(J.comp, limit_bit, T, J.blk_sym + J.c_symoff[c], cap, p, op, J.slice_tokens);
     J.c_end[c] = p;
     J.c_nsym[c] = op;
     J.c_flags[c] = fl;

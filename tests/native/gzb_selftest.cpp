@@ -30,6 +30,7 @@ struct CpuOffload : aqcgz::SectionOffload {
     size_t group;
     uint32_t ratio_cap = 20;
     uint32_t cand_div = 4096;            // candidate capacity = span / cand_div + 256
+    uint32_t slice_tokens = 300, max_slices = 1u << 20;
     uint64_t groups = 0, sections = 0, found = 0, candidates = 0, false_ends = 0;
     std::vector<std::vector<uint16_t>*> live;
     explicit CpuOffload(size_t g) : group(g) {}
@@ -117,17 +118,20 @@ struct CpuOffload : aqcgz::SectionOffload {
         }
         // ---- decode: a lane per candidate
         std::vector<uint32_t> cnt(16), nxt(16), off(16);
-        std::vector<uint16_t> tab(GZB_TAB_ENTRIES);
         for (uint32_t c = 0; c < nc; ++c) {
-            uint8_t* const lens = reinterpret_cast<uint8_t*>(J.tables + (size_t)c * GZB_TAB_WORDS);
-            const GzbLaneTab<1> T{tab.data()};
+            uint32_t* const tw = J.tables + (size_t)c * GZB_TAB_WORDS;
+            const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(tw)};
+            uint8_t* const lens = reinterpret_cast<uint8_t*>(tw + GZB_TAB_ENTRIES / 2);
             uint32_t p = 0, hlit = 0, hdist = 0, op = 0, fl = 0;
             if (c_symcap[c] == 0) fl = GZB_F_SKIP;
             else if (!gzb_header(J.comp, limit_bit, c_start[c], cl.data(), 1, lens, p, hlit, hdist)) fl = GZB_F_ERROR;
             if (!fl) {
                 gzb_build<true>(lens, hlit, T, cnt.data(), nxt.data(), off.data(), 1);
                 gzb_build<false>(lens + hlit, hdist, T, cnt.data(), nxt.data(), off.data(), 1);
-                fl = gzb_decode_block(J.comp, limit_bit, T, J.blk_sym + c_symoff[c], c_symcap[c], p, op);
+                // in slices, like the kernels: a slice ends after slice_tokens tokens, the next one resumes at the saved bit / symbol
+                uint32_t slices = 0;
+                do fl = gzb_decode_block(J.comp, limit_bit, T, J.blk_sym + c_symoff[c], c_symcap[c], p, op, slice_tokens);
+                while (fl == GZB_F_MORE && ++slices < max_slices);
             }
             c_end[c] = p; c_nsym[c] = op; c_flags[c] = fl;
         }
@@ -217,12 +221,13 @@ std::vector<uint8_t> gz_of(const std::vector<uint8_t>& text, int level, int stra
 }
 
 int failures = 0;
+uint32_t g_max_slices = 1u << 20;      // (a case may cut the decoder off: unfinished blocks then go to the host)
 
 // decode gz through ParallelGunzip with the CPU emulation of the device as its offloader; returns the offloader's counters
 bool run_case(const char* what, const std::vector<uint8_t>& gz, const std::vector<uint8_t>& text, size_t section, size_t group, int threads, bool want_device,
               uint32_t ratio_cap = 20, uint32_t cand_div = 4096, bool expect_fail = false, bool hybrid = false) {
     CpuOffload off(group);
-    off.ratio_cap = ratio_cap; off.cand_div = cand_div;
+    off.ratio_cap = ratio_cap; off.cand_div = cand_div; off.max_slices = g_max_slices;
     aqc_host::Pool pool(threads);
     std::vector<uint8_t> out(text.size() + 65536);
     size_t produced = 0;
@@ -268,6 +273,9 @@ int main() {
         run_case("fastq level 6, no host threads", gz, fq, 128 << 10, 1 << 20, 0, true);
         run_case("fastq level 6, symbol space 2x (overflow)", gz, fq, 64 << 10, 512 << 10, 2, false, 2);
         run_case("fastq level 6, 8 candidates per MiB", gz, fq, 64 << 10, 512 << 10, 2, false, 20, 1u << 30);
+        g_max_slices = 3;
+        run_case("fastq level 6, decoder cut off after 3 slices", gz, fq, 64 << 10, 512 << 10, 2, false);
+        g_max_slices = 1u << 20;
         std::vector<uint8_t> bad = gz;
         bad[bad.size() / 2] ^= 0x21;
         run_case("fastq level 6, one byte damaged", bad, fq, 64 << 10, 512 << 10, 2, false, 20, 4096, true);

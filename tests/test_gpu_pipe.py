@@ -52,6 +52,25 @@ def test_one_input_over_two_contexts(tmp_path, paired):
     assert a_stat["afterqc_main_summary"]["total_reads"] == n
 
 
+def test_one_million_pairs_over_four_contexts_on_one_device(tmp_path):
+    """the N-GPU code path at a size where every context sees hundreds of chunks: ONE 1 M-pair input dealt over FOUR contexts on
+    GPU 0 (what AQC_DEVICES=0,0,0,0 sets up: per-device DMA gates, NUMA binding of the slot workers, host-side merge of four
+    contexts' statistics) — outputs byte-identical to the one-context run, statistics JSON identical"""
+    work = str(tmp_path)
+    n = 1_000_000
+    d = synth.make_pairs(n, 150, seed=8844, workers=4)
+    r1, r2 = os.path.join(work, "R1.fq"), os.path.join(work, "R2.fq")
+    synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
+    synth.write_fastq_fixed(r2, d["seq2"], d["qual2"], 2)
+    extra = ["-f", "0", "-t", "0"]
+    a_files, a_stat, a = run(work, r1, r2, extra, tag="one", use_pipe=True, devices=[0], chunk_records=1 << 14)
+    b_files, b_stat, b = run(work, r1, r2, extra, tag="four", use_pipe=True, devices=[0, 0, 0, 0], chunk_records=3000, pipe_slots=3)
+    assert a.used_pipe and b.used_pipe
+    assert a_files == b_files
+    assert a_stat == b_stat
+    assert a_stat["afterqc_main_summary"]["total_reads"] == n
+
+
 def test_pipe_gzip_in_and_out(tmp_path):
     """.gz in (our own BGZF-style multi-member files: inflated member-parallel; and a single-member stream) -> .gz out"""
     import gzip
@@ -259,7 +278,7 @@ def test_pipe_single_member_gzip_input_is_shared_with_the_device(tmp_path):
     finally:
         del os.environ["AQC_GZ_GROUP"]
         del os.environ["AQC_GZ_DEVICE_MIN"]
-    assert sections > 20 and from_device > 0.3 * sections and device_bytes > 0.3 * text_bytes, (sections, from_device, text_bytes, device_bytes)
+    assert sections > 20 and from_device > 0.3 * sections and device_bytes > 0.2 * text_bytes, (sections, from_device, text_bytes, device_bytes)
     os.environ["AQC_GZ_DEVICE_IN"] = "0"
     try:
         sections, from_device, _, _ = gz_run("gzhost")
