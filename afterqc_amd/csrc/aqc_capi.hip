@@ -1284,7 +1284,7 @@ private:
         J.c_symoff = (uint64_t*)L.c_symoff.p; J.c_symcap = (uint32_t*)L.c_symcap.p; J.blk_sym = (uint16_t*)L.blk_sym.p; J.blk_sym_cap = blk_sym_cap;
         J.ratio_cap = GZB_RATIO_CAP; J.tables = (uint32_t*)L.tables.p;
         {
-            static const uint32_t slice = [] { const char* e = getenv("AQC_GZ_SLICE"); return e ? (uint32_t)std::max(16, atoi(e)) : 512u; }();
+            static const uint32_t slice = [] { const char* e = getenv("AQC_GZ_SLICE"); return e ? (uint32_t)std::max(16, atoi(e)) : 640u; }();
             J.slice_tokens = slice;
         }
         J.n_sec = (uint32_t)n; J.s_nominal = (const uint32_t*)L.s_in.p; J.s_stop = J.s_nominal + n; J.s_exact = J.s_nominal + 2 * n;
@@ -1294,10 +1294,10 @@ private:
         hipLaunchKernelGGL(gzb_scan_kernel, dim3(n_tiles), dim3(GZB_SCAN_THREADS), 0, L.stream, J);
         hipLaunchKernelGGL(gzb_compact_kernel, dim3(1), dim3(1024), 0, L.stream, J);
         GZB_TRY(hipEventRecord(L.ev[2], L.stream));
-        // the decoder in slices (aqc_gunzip_dev.hpp): 48 x 512 tokens cover any block zlib writes (<= 16 K tokens) with room to
-        // spare; a block that needs more stays unfinished, its section ends before it and the host goes on from there
+        // the decoder in slices (aqc_gunzip_dev.hpp): 64 x 640 tokens cover the blocks of zlib (<= 16 K tokens) and of GNU gzip
+        // (<= 32 K); a block that needs more stays unfinished, its section ends before it and the host goes on from there
         {
-            static const int n_slices = [] { const char* e = getenv("AQC_GZ_SLICES"); return e ? std::max(1, atoi(e)) : 48; }();
+            static const int n_slices = [] { const char* e = getenv("AQC_GZ_SLICES"); return e ? std::max(1, atoi(e)) : 64; }();
             const dim3 grid((cand_cap + GZB_DEC_THREADS - 1) / GZB_DEC_THREADS);
             hipLaunchKernelGGL(gzb_decode_kernel<true>, grid, dim3(GZB_DEC_THREADS), 0, L.stream, J);
             for (int sl = 1; sl < n_slices; ++sl) hipLaunchKernelGGL(gzb_decode_kernel<false>, grid, dim3(GZB_DEC_THREADS), 0, L.stream, J);

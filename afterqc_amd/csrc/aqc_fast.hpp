@@ -262,8 +262,10 @@ struct FastArgs {
 };
 typedef const FastArgs __attribute__((address_space(4))) * FastArgsRare;
 
+// (one workgroup of WPBT waves per CU — its LDS rows allow no second one — is WPBT / 4 waves per SIMD: that is the occupancy the
+//  register budget is sized for: 128 VGPRs for the 16-wave 2 x 150 variant, 168 for the 12-wave ones)
 template <int NW, bool PAIRED, int WPBT, bool BARCODE>
-__global__ __launch_bounds__(WPBT * WAVE, AQC_MIN_WAVES) void fast_filter_overlap_kernel(FastArgs K) {
+__global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT + 3) / 4 : AQC_MIN_WAVES) void fast_filter_overlap_kernel(FastArgs K) {
     const DevBatch& fb = K.fb;
     const aqc_config& cfg = K.cfg;
     aqc_result* __restrict__ const results = K.results;

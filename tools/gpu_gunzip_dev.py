@@ -2,7 +2,8 @@
 """device gunzip self-test / timing: python tools/gpu_gunzip_dev.py [MB of text] [gzip level]"""
 import gzip, subprocess, sys, time, zlib
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from afterqc_amd import capi, synth
 
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 64
