@@ -1094,8 +1094,11 @@ public:
     }
     bool start() {
         if (hipSetDevice(device_) != hipSuccess) { (void)hipGetLastError(); return false; }
+        // (the lowest stream priority: where a decoder slice and a kernel of the filter compete for the chip, the filter goes first)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         for (auto& l : lanes_) {
-            if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) return false;
+            if (hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return false;
             for (auto& e : l.ev) if (hipEventCreate(&e) != hipSuccess) return false;
         }
         for (int i = 0; i < N_LANES; ++i) lanes_[i].th = std::thread([this, i] { loop(i); });

@@ -367,7 +367,7 @@ void ParallelGunzip::to_pool(const std::shared_ptr<Section>& s) {
 // the next window of section indices: [win_lo_, win_hi_); the file's last section runs to the end of the file (its stop bit is
 // "none"), which the device cannot take: it goes to the pool at once
 void ParallelGunzip::next_window() {
-    const size_t per_group = std::max<size_t>(1, (offload_ ? std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ / 8)) : section_bytes_) / section_bytes_);
+    const size_t per_group = std::max<size_t>(1, (offload_ ? std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ * 2 / 9)) : section_bytes_) / section_bytes_);
     win_hi_ = std::min(last_idx_ + 1, win_lo_ + 8 * per_group);
     pool_next_ = win_lo_;
     dev_hi_ = win_hi_;
@@ -399,7 +399,7 @@ void ParallelGunzip::top_up(bool need_front) {
         size_t on_pool = 0, on_device = 0;
         for (auto& kv : q_) (kv.second->offloaded ? on_device : on_pool)++;
         const bool front_missing = need_front && (q_.empty() || q_.begin()->first >= lowest_uncreated());
-        const size_t per_group = std::max<size_t>(1, (offload_ ? (offload_only_ ? offload_->group_bytes() : std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ / 8)))
+        const size_t per_group = std::max<size_t>(1, (offload_ ? (offload_only_ ? offload_->group_bytes() : std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ * 2 / 9)))
                                                                : section_bytes_) / section_bytes_);
         // The pool's share, from the bottom of the window up: the sections the consumer wants next.  (With a device decoder it
         // may work twice as far ahead: it is the only one feeding the consumer while a device group is under way.)
@@ -413,6 +413,10 @@ void ParallelGunzip::top_up(bool need_front) {
         // The device's share: a GROUP of sections whenever it is free — from the TOP of the window down, so that the consumer,
         // who commits in index order, gets there last (offload_only: from the bottom up, nobody else feeds the consumer)
         if (!offload_ || on_device >= 4 * per_group || !offload_->ready()) break;
+        // ... but only while the pool still has more than two groups' worth of sections in front of it: a group takes the device
+        // a fixed 100 - 200 ms (a block is decoded by one lane from start to end), and one that is started when the pool is about
+        // to arrive makes the consumer wait for it
+        if (!offload_only_ && dev_hi_ - pool_next_ < per_group * 12 / 5) break;
         size_t lo, hi;
         if (offload_only_) { lo = pool_next_; hi = std::min(dev_hi_, lo + per_group); }
         else { hi = dev_hi_; lo = hi > pool_next_ + per_group ? hi - per_group : pool_next_; }

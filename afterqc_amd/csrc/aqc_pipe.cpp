@@ -679,7 +679,7 @@ struct Run {
                 const char* e = getenv("AQC_GZ_DEVICE_IN");
                 if (!(e && e[0] == '0') && !P->gz_offload_tried[f] && !P->ctx.empty()) {      // (set up with the first .gz input of this file slot)
                     P->gz_offload_tried[f] = true;
-                    size_t group = 64u << 20;
+                    size_t group = 192u << 20;
                     if (const char* g = getenv("AQC_GZ_GROUP")) group = (size_t)std::max(1ll, atoll(g));
                     P->gz_offload[f].reset(aqcgz::make_device_offload(aqc_device_index(P->ctx[(size_t)f % P->ctx.size()]), group));
                 }
