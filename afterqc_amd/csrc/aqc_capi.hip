@@ -1076,7 +1076,7 @@ namespace {
 std::atomic<uint64_t> g_gzb_stats[8];
 
 constexpr size_t GZB_SLACK = 4u << 20;              // compressed bytes uploaded behind the last section's stop bit (its last block ends there)
-constexpr uint32_t GZB_RATIO_CAP = 20;
+constexpr uint32_t GZB_RATIO_CAP = 12;
 
 class DeviceInflate : public aqcgz::SectionOffload {
 public:
@@ -1158,13 +1158,13 @@ private:
         hipStream_t stream = nullptr;
         hipEvent_t ev[7] = {};
         std::unique_ptr<Group> job;
-        DevBuf comp, tile_cnt, tile_cand, n_cand, c_start, c_end, c_nsym, c_flags, c_symoff, c_symcap, blk_sym, tables;
+        DevBuf comp, tile_cnt, tile_cand, n_cand, c_start, c_end, c_nsym, c_flags, c_symoff, c_symcap, blk_sym, tables, blk_tok, c_ntok;
         DevBuf s_in, s_out, s_blocks, s_sym, s_off;
         uint8_t* stage = nullptr;          // page-locked copy of the group's compressed bytes (the file itself is a pageable mapping)
         size_t stage_cap = 0;
         void release() {
             if (stream) (void)hipStreamSynchronize(stream);
-            DevBuf* b[] = {&comp, &tile_cnt, &tile_cand, &n_cand, &c_start, &c_end, &c_nsym, &c_flags, &c_symoff, &c_symcap, &blk_sym, &tables, &s_in, &s_out, &s_blocks, &s_sym, &s_off};
+            DevBuf* b[] = {&comp, &tile_cnt, &tile_cand, &n_cand, &c_start, &c_end, &c_nsym, &c_flags, &c_symoff, &c_symcap, &blk_sym, &tables, &blk_tok, &c_ntok, &s_in, &s_out, &s_blocks, &s_sym, &s_off};
             for (DevBuf* x : b) x->release();
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
@@ -1248,6 +1248,7 @@ private:
         if (L.comp.reserve(span + 256) || L.tile_cnt.reserve(4ull * n_tiles) || L.tile_cand.reserve(4ull * n_tiles * GZB_TILE_CAND) || L.n_cand.reserve(64) ||
             L.c_start.reserve(4ull * cand_cap) || L.c_end.reserve(4ull * cand_cap) || L.c_nsym.reserve(4ull * cand_cap) || L.c_flags.reserve(4ull * cand_cap) ||
             L.c_symoff.reserve(8ull * cand_cap) || L.c_symcap.reserve(4ull * cand_cap) || L.blk_sym.reserve(2ull * blk_sym_cap + 64) ||
+            L.blk_tok.reserve(2ull * blk_sym_cap + 256) || L.c_ntok.reserve(4ull * cand_cap) ||
             L.tables.reserve(4ull * cand_cap * GZB_TAB_WORDS) || L.s_in.reserve(12ull * n) || L.s_out.reserve(16ull * n) || L.s_off.reserve(8ull * (n + 1)) ||
             L.s_blocks.reserve(12ull * n * GZB_SEC_BLOCKS) || L.s_sym.reserve(2ull * s_sym_total + 64))
             return false;
@@ -1285,7 +1286,7 @@ private:
         J.cand_cap = cand_cap; J.n_cand = (uint32_t*)L.n_cand.p;
         J.c_start = (uint32_t*)L.c_start.p; J.c_end = (uint32_t*)L.c_end.p; J.c_nsym = (uint32_t*)L.c_nsym.p; J.c_flags = (uint32_t*)L.c_flags.p;
         J.c_symoff = (uint64_t*)L.c_symoff.p; J.c_symcap = (uint32_t*)L.c_symcap.p; J.blk_sym = (uint16_t*)L.blk_sym.p; J.blk_sym_cap = blk_sym_cap;
-        J.ratio_cap = GZB_RATIO_CAP; J.tables = (uint32_t*)L.tables.p;
+        J.ratio_cap = GZB_RATIO_CAP; J.tables = (uint32_t*)L.tables.p; J.blk_tok = (uint32_t*)L.blk_tok.p; J.c_ntok = (uint32_t*)L.c_ntok.p;
         {
             static const uint32_t slice = [] { const char* e = getenv("AQC_GZ_SLICE"); return e ? (uint32_t)std::max(16, atoi(e)) : 640u; }();
             J.slice_tokens = slice;
@@ -1304,6 +1305,8 @@ private:
             const dim3 grid((cand_cap + GZB_DEC_THREADS - 1) / GZB_DEC_THREADS);
             hipLaunchKernelGGL(gzb_decode_kernel<true>, grid, dim3(GZB_DEC_THREADS), 0, L.stream, J);
             for (int sl = 1; sl < n_slices; ++sl) hipLaunchKernelGGL(gzb_decode_kernel<false>, grid, dim3(GZB_DEC_THREADS), 0, L.stream, J);
+            // phase 2: a wave per block applies its tokens
+            hipLaunchKernelGGL(gzb_expand_kernel, dim3((cand_cap + GZB_EXP_WAVES - 1) / GZB_EXP_WAVES), dim3(64 * GZB_EXP_WAVES), 0, L.stream, J);
         }
         GZB_TRY(hipEventRecord(L.ev[3], L.stream));
         hipLaunchKernelGGL(gzb_chain_kernel, dim3((n + 63) / 64), dim3(64), 0, L.stream, J);

@@ -15,11 +15,12 @@
 //                       must parse and form a complete literal/length code with an end-of-block symbol and a usable distance code.
 //   gzb_compact_kernel  the per-tile hits become one sorted candidate list; a candidate's output space is sized from the
 //                       compressed bytes up to the next candidate.
-//   gzb_decode_kernel   a LANE per candidate: builds its own tables (9-bit literal/length and 7-bit distance roots, 16-bit
-//                       entries; longer codes: canonical search) in its own 2 KiB column of LDS and decodes its block the way
-//                       a CPU thread would — a 64-bit bit buffer whose next word is always on its way, LDS table look-ups, 8-byte
-//                       match copies — into 16-bit SYMBOLS (>= 0x8000: "byte j of the 32 KiB before this BLOCK").  A lane runs
-//                       at a few MB/s; tens of thousands of them run at once.  No cross-lane traffic.
+//   gzb_decode_kernel   a LANE per candidate: builds its own tables (12-bit literal/length and 10-bit distance roots, 16-bit
+//                       entries; longer codes: canonical search) and turns its block into TOKENS (literal | length, distance) the
+//                       way a CPU thread reads a Huffman stream — a 64-bit bit buffer whose next word is always on its way, one
+//                       table look-up per code — in slices of a few hundred tokens per launch.  Thousands of lanes at once.
+//   gzb_expand_kernel   a WAVE per block applies the tokens: literals of 64 tokens stored at once, every match copied by the
+//                       64 lanes together, into 16-bit SYMBOLS (>= 0x8000: "byte j of the 32 KiB before this BLOCK").
 //   gzb_chain_kernel    a lane per SECTION (the host's unit of work, aqc_gunzip.cpp): from the first candidate at or behind the
 //                       section's nominal start it follows  end of block == start of a candidate  until the section's stop bit;
 //                       stored blocks (pigz's sync markers) are stepped over in place.  A false candidate never chains up.
@@ -60,11 +61,12 @@ GZB_HD inline uint32_t gzb_rev(uint32_t c, uint32_t len) {
 }
 
 constexpr uint32_t GZB_MARKER = 0x8000u;
-constexpr int GZB_LROOT = 9, GZB_DROOT = 7;
-// A lane's decoding tables, 16-bit entries: literal/length root (2^9), distance root (2^7), symbols sorted by code (288 + 32),
-// codes per length (16 + 16) = 992 entries, in the candidate's own 2.3 KiB of global memory (with its 320 code lengths behind
-// them).  They were in LDS for a while (round 4, second version: 124 KiB per wave): no faster — the look-ups are not what a
-// token waits for — and a decoder that fills a CU's LDS for 50 ms keeps the filter's kernels off that CU for as long.
+constexpr int GZB_LROOT = 12, GZB_DROOT = 10;
+// A lane's decoding tables, 16-bit entries: literal/length root (2^12), distance root (2^10), symbols sorted by code (288 + 32),
+// codes per length (16 + 16), in the candidate's own 11 KiB of global memory (with its 320 code lengths behind them).  Roots this
+// wide make a code longer than the root — the canonical search, a dozen dependent loads — a rarity: with 9 bits SOME lane of a
+// wave needed it in most iterations, and the whole wave waits for it.  (The tables were in LDS for a while, round 4's second
+// version, 124 KiB per wave: no faster, and a decoder that fills a CU's LDS keeps the filter's kernels off that CU.)
 constexpr int GZB_E_DIST = 1 << GZB_LROOT, GZB_E_LSORT = GZB_E_DIST + (1 << GZB_DROOT), GZB_E_DSORT = GZB_E_LSORT + 288, GZB_E_LCOUNT = GZB_E_DSORT + 32,
               GZB_E_DCOUNT = GZB_E_LCOUNT + 16, GZB_TAB_ENTRIES = GZB_E_DCOUNT + 16;
 constexpr int GZB_TAB_WORDS = GZB_TAB_ENTRIES / 2 + 80;          // 32-bit words per candidate: the tables, then the code lengths
@@ -95,6 +97,8 @@ struct GzbJob {
     uint32_t* c_symcap;
     uint16_t* blk_sym;
     uint64_t blk_sym_cap;        // symbols
+    uint32_t* blk_tok;           // tokens of candidate c at [c_symoff[c] / 2, + c_symcap[c] / 2): bit 31 literal | byte, else length << 16 | distance - 1
+    uint32_t* c_ntok;            // [cand_cap] tokens written
     uint32_t ratio_cap;          // a block may expand to ratio_cap x its compressed size (+ 4096 symbols)
     uint32_t* tables;            // [cand_cap][GZB_TAB_WORDS]: a candidate's tables and code lengths
     uint32_t slice_tokens;       // tokens a lane decodes per launch (the decoder runs in slices: see gzb_decode_kernel)
@@ -329,14 +333,15 @@ GZB_HD inline unsigned long long gzb_load64(const uint8_t* p) {
     return v;
 }
 
-// One block's symbols from its first data bit p on, into out[0, cap): returns the flags (0: the end-of-block code was reached),
-// p = the bit behind it, op = symbols written.  A symbol >= 0x8000 is "byte j of the 32 KiB before this block".
-// The stream is read through a 64-bit bit buffer; the word the NEXT refill needs is loaded when the buffer has just been
-// refilled, two or three tokens before it is used, so the loop does not wait for the compressed bytes.
-// At most max_tokens tokens per call: GZB_F_MORE = not at the end of the block yet, call again with the same p / op.
+// PHASE 1 — one block's TOKENS from its first data bit p on: a literal is 0x80000000 | byte, a match length << 16 | distance - 1.
+// Nothing is copied here: what a lane waits for per token is one table look-up (two for a match) and, every few tokens, the
+// next word of the stream, which was asked for when the bit buffer was last refilled.  (The first version copied the matches
+// as it went: 41 scattered memory instructions per wave step, 4 microseconds per token.)  Returns the flags (0: the
+// end-of-block code was reached, GZB_F_MORE: max_tokens done, call again with the same p / nt / op); p = the bit reached,
+// nt = tokens written so far, op = symbols they stand for.
 template <int S>
-GZB_HD inline uint32_t gzb_decode_block(const uint8_t* comp, uint32_t limit_bit, const GzbLaneTab<S>& T, uint16_t* out, uint32_t cap, uint32_t& p, uint32_t& op,
-                                        uint32_t max_tokens) {
+GZB_HD inline uint32_t gzb_tokenize_block(const uint8_t* comp, uint32_t limit_bit, const GzbLaneTab<S>& T, uint32_t* tok, uint32_t tok_cap, uint32_t sym_cap,
+                                          uint32_t& p, uint32_t& nt, uint32_t& op, uint32_t max_tokens) {
     uint32_t fl = 0, tokens = 0;
     const uint8_t* const end = comp + (limit_bit >> 3);      // (limit_bit is a multiple of 8; the buffer is padded for 64 bytes behind)
     const uint8_t* ip = comp + (p >> 3);
@@ -354,7 +359,7 @@ GZB_HD inline uint32_t gzb_decode_block(const uint8_t* comp, uint32_t limit_bit,
     } while (0)
     for (;;) {
         if (ip > end) { fl = GZB_F_ERROR; break; }
-        if (op + 272u > cap) { fl = GZB_F_OVERFLOW; break; }
+        if (nt >= tok_cap || op + 258u > sym_cap) { fl = GZB_F_OVERFLOW; break; }
         if (tokens++ >= max_tokens) { fl = GZB_F_MORE; break; }
         if (bn < 32u) GZB_REFILL();                           // >= 56 bits now; a literal/length code + its extra bits take <= 20
         uint32_t e = T.at((int)((uint32_t)bb & ((1u << GZB_LROOT) - 1u)));
@@ -365,7 +370,7 @@ GZB_HD inline uint32_t gzb_decode_block(const uint8_t* comp, uint32_t limit_bit,
         const uint32_t l = e & 15u;
         bb >>= l;
         bn -= l;
-        if (e & 0x10u) { out[op++] = (uint16_t)(e >> 8); continue; }
+        if (e & 0x10u) { tok[nt++] = 0x80000000u | (e >> 8); op += 1u; continue; }
         if (e & 0x60u) { if (e & 0x40u) fl = GZB_F_ERROR; break; }            // end of block
         const uint32_t ls = e >> 8;
         const uint32_t xb = gzb_len_extra(ls);
@@ -385,67 +390,30 @@ GZB_HD inline uint32_t gzb_decode_block(const uint8_t* comp, uint32_t limit_bit,
         const uint32_t dd = gzb_dist_base(ds) + ((uint32_t)bb & ((1u << dxb) - 1u));
         bb >>= dxb;
         bn -= dl + dxb;
-        const int src = (int)op - (int)dd;
-        if (src < -32768) { fl = GZB_F_ERROR; break; }
-        uint16_t* const dst = out + op;
-        if (src >= 0 && dd >= len) {
-            // The usual match of a FASTQ stream — the same column of the record before — does not overlap itself: up to eight
-            // 8-byte loads are issued before the first store, ONE trip to memory for 32 symbols.  (A load behind a store the
-            // compiler cannot prove disjoint waits for it: the step-by-step loop below pays a memory round trip per four symbols,
-            // which was most of the 4 microseconds a token took.)  The last word may run up to three symbols over: the next token
-            // overwrites them.
-            const uint16_t* const s = out + src;
-            for (uint32_t b = 0; b < len; b += 32) {
-                unsigned long long v[8];
-                for (int k = 0; k < 8; ++k)
-                    if (b + 4u * (uint32_t)k < len) memcpy(&v[k], s + b + 4 * k, 8);
-                for (int k = 0; k < 8; ++k)
-                    if (b + 4u * (uint32_t)k < len) memcpy(dst + b + 4 * k, &v[k], 8);
-            }
-        } else if (src >= 0 && dd >= 4u) {
-            // overlapping, period >= 4: four symbols per step
-            const uint16_t* const s = out + src;
-            for (uint32_t i = 0; i < len; i += 4) {
-                unsigned long long v;
-                memcpy(&v, s + i, 8);
-                memcpy(dst + i, &v, 8);
-            }
-        } else if (dd <= 3u) {
-            // distance 1 .. 3 (runs: the quality strings): the period-dd pattern, twelve symbols of it, four per step
-            uint32_t a[3];
-            for (int k = 0; k < 3; ++k) {
-                const int q = src + (int)((uint32_t)k % dd);
-                a[k] = q >= 0 ? (uint32_t)out[q] : (GZB_MARKER | (uint32_t)(32768 + q));
-            }
-            // pattern position j holds symbol j % dd of the source = a[j % dd] (dd = 1: a[0] = a[1] = a[2])
-            unsigned long long q3[3];
-            for (int g = 0; g < 3; ++g) {
-                unsigned long long v = 0;
-                for (int j = 0; j < 4; ++j) {
-                    const int pos = 4 * g + j;
-                    v |= (unsigned long long)(dd == 2u ? a[pos & 1] : a[pos % 3]) << (16 * j);
-                }
-                q3[g] = v;
-            }
-            uint32_t ph = 0;
-            for (uint32_t i = 0; i < len; i += 4) {
-                const unsigned long long v = ph == 0u ? q3[0] : ph == 1u ? q3[1] : q3[2];
-                memcpy(dst + i, &v, 8);
-                ph = ph == 2u ? 0u : ph + 1u;
-            }
-        } else {
-            // the source begins before the block: markers for that part
-            for (uint32_t i = 0; i < len; ++i) {
-                const int q = src + (int)i;
-                dst[i] = q >= 0 ? out[q] : (uint16_t)(GZB_MARKER | (uint32_t)(32768 + q));
-            }
-        }
+        if ((int)op - (int)dd < -32768) { fl = GZB_F_ERROR; break; }         // reaches before the window
+        tok[nt++] = (len << 16) | (dd - 1u);
         op += len;
     }
 #undef GZB_REFILL
     // the bit behind the last consumed one: ip points 8 bytes behind the word whose unconsumed bits are the top of bb
     p = (uint32_t)((ip - comp) << 3) - bn;
     return fl;
+}
+
+// PHASE 2 as the host tests run it (the kernel does the same a wave per block, the lanes sharing every copy): the tokens'
+// symbols; a symbol >= 0x8000 is "byte j of the 32 KiB before this block"
+GZB_HD inline void gzb_expand_block(const uint32_t* tok, uint32_t nt, uint16_t* out) {
+    uint32_t op = 0;
+    for (uint32_t i = 0; i < nt; ++i) {
+        const uint32_t t = tok[i];
+        if (t >> 31) { out[op++] = (uint16_t)(t & 0xffu); continue; }
+        const uint32_t len = (t >> 16) & 0x1ffu, dd = (t & 0x7fffu) + 1u;
+        for (uint32_t k = 0; k < len; ++k) {
+            const int q = (int)op - (int)dd;
+            out[op] = q >= 0 ? out[q] : (uint16_t)(GZB_MARKER | (uint32_t)(32768 + q));
+            ++op;
+        }
+    }
 }
 
 // symbol space of candidate c of n: ratio_cap x the compressed bytes up to the next candidate (the last one: to the window's end)
@@ -698,10 +666,10 @@ __global__ __launch_bounds__(1024) void gzb_compact_kernel(GzbJob J) {
 }
 
 // ---- a lane per block --------------------------------------------------------------------------------------------------------------
-// The decoder runs in SLICES of J.slice_tokens tokens per lane and launch (~1.5 ms): a block takes a lane ~50 ms from start to
-// end whatever else the chip does, and a kernel that sits on its CUs for that long keeps the filter's kernels — which want every
-// CU, with all its registers — waiting behind it (measured: the first wiring made `.gz -> .gz` slower than the host alone).
-// Between two slices they get their turn.  FIRST: header, tables, first slice; else: lanes whose block is not finished go on.
+// PHASE 1 runs in SLICES of J.slice_tokens tokens per lane and launch: a kernel that sits on its CUs for tens of milliseconds
+// keeps the filter's kernels — which want every CU, with all its registers — waiting behind it (measured: the first wiring made
+// `.gz -> .gz` slower than the host alone).  Between two slices they get their turn.  FIRST: header, tables, first slice; else:
+// lanes whose block is not finished go on.
 template <bool FIRST>
 __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
     __shared__ uint8_t s_cl[FIRST ? 128 * GZB_DEC_THREADS : 1];
@@ -714,7 +682,7 @@ __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
     uint32_t* const tw = J.tables + (size_t)c * GZB_TAB_WORDS;
     const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(tw)};
     uint8_t* const lens = reinterpret_cast<uint8_t*>(tw + GZB_TAB_ENTRIES / 2);
-    uint32_t p = 0, hlit = 0, hdist = 0, op = 0, fl = 0;
+    uint32_t p = 0, hlit = 0, hdist = 0, op = 0, nt = 0, fl = 0;
     if (FIRST) {
         if (cap == 0) fl = GZB_F_SKIP;
         else if (!gzb_header(J.comp, limit_bit, J.c_start[c], s_cl + tid, GZB_DEC_THREADS, lens, p, hlit, hdist)) fl = GZB_F_ERROR;
@@ -726,11 +694,60 @@ __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
         if (J.c_flags[c] != GZB_F_MORE) return;
         p = J.c_end[c];
         op = J.c_nsym[c];
+        nt = J.c_ntok[c];
     }
-    if (!fl) fl = gzb_decode_block(J.comp, limit_bit, T, J.blk_sym + J.c_symoff[c], cap, p, op, J.slice_tokens);
+    if (!fl) fl = gzb_tokenize_block(J.comp, limit_bit, T, J.blk_tok + J.c_symoff[c] / 2, cap / 2, cap, p, nt, op, J.slice_tokens);
     J.c_end[c] = p;
     J.c_nsym[c] = op;
+    J.c_ntok[c] = nt;
     J.c_flags[c] = fl;
+}
+
+// PHASE 2 — a WAVE per block turns its tokens into symbols: 64 tokens at a time, their output positions from a lane scan; the
+// literals of the chunk are stored at once, the matches applied in order, the 64 lanes sharing each copy (a copy that overlaps
+// itself repeats its period).  A wave's loads and stores to global memory are performed in issue order, so a copy sees what
+// the one before it wrote.
+constexpr int GZB_EXP_WAVES = 4;
+__global__ __launch_bounds__(64 * GZB_EXP_WAVES) void gzb_expand_kernel(GzbJob J) {
+    const uint32_t c = blockIdx.x * (uint32_t)GZB_EXP_WAVES + (threadIdx.x >> 6);
+    const int lane = (int)(threadIdx.x & 63u);
+    if (c >= J.n_cand[0] || J.c_flags[c] != 0u) return;
+    const uint32_t* const tok = J.blk_tok + J.c_symoff[c] / 2;
+    uint16_t* const out = J.blk_sym + J.c_symoff[c];
+    const uint32_t nt = J.c_ntok[c];
+    uint32_t op = 0;
+    for (uint32_t base = 0; base < nt; base += 64u) {
+        const bool have = base + (uint32_t)lane < nt;
+        const uint32_t t = have ? tok[base + (uint32_t)lane] : 0x80000000u;
+        const bool lit = (t >> 31) != 0u;
+        const uint32_t len = have ? (lit ? 1u : (t >> 16) & 0x1ffu) : 0u;
+        uint32_t inc = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        const uint32_t pos = op + inc - len;
+        if (have && lit) out[pos] = (uint16_t)(t & 0xffu);
+        unsigned long long mm = __ballot(have && !lit);
+        while (mm) {
+            const int l = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const uint32_t m_len = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
+            const uint32_t m_dd = ((uint32_t)__builtin_amdgcn_readlane((int)t, l) & 0x7fffu) + 1u;
+            const uint32_t m_pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, l);
+            const int src = (int)m_pos - (int)m_dd;
+            for (uint32_t j0 = 0; j0 < m_len; j0 += 64u) {
+                const uint32_t j = j0 + (uint32_t)lane;
+                if (j < m_len) {
+                    const uint32_t rel = m_dd < m_len ? j % m_dd : j;
+                    const int q = src + (int)rel;
+                    out[m_pos + j] = q >= 0 ? out[q] : (uint16_t)(GZB_MARKER | (uint32_t)(32768 + q));
+                }
+            }
+        }
+        op += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
 }
 
 // ---- a lane per section --------------------------------------------------------------------------------------------------------

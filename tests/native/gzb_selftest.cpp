@@ -61,6 +61,8 @@ struct CpuOffload : aqcgz::SectionOffload {
         J.blk_sym_cap = (uint64_t)span * ratio_cap + (uint64_t)J.cand_cap * 4104;
         std::vector<uint16_t> blk_sym(J.blk_sym_cap + 64);
         J.blk_sym = blk_sym.data();
+        std::vector<uint32_t> blk_tok(J.blk_sym_cap / 2 + 64), c_ntok(J.cand_cap);
+        J.blk_tok = blk_tok.data(); J.c_ntok = c_ntok.data();
         std::vector<uint32_t> tables((size_t)J.cand_cap * GZB_TAB_WORDS);
         J.tables = tables.data();
         // ---- scan: every lane of every tile
@@ -129,9 +131,12 @@ struct CpuOffload : aqcgz::SectionOffload {
                 gzb_build<true>(lens, hlit, T, cnt.data(), nxt.data(), off.data(), 1);
                 gzb_build<false>(lens + hlit, hdist, T, cnt.data(), nxt.data(), off.data(), 1);
                 // in slices, like the kernels: a slice ends after slice_tokens tokens, the next one resumes at the saved bit / symbol
-                uint32_t slices = 0;
-                do fl = gzb_decode_block(J.comp, limit_bit, T, J.blk_sym + c_symoff[c], c_symcap[c], p, op, slice_tokens);
+                uint32_t slices = 0, nt = 0;
+                do fl = gzb_tokenize_block(J.comp, limit_bit, T, J.blk_tok + c_symoff[c] / 2, c_symcap[c] / 2, c_symcap[c], p, nt, op, slice_tokens);
                 while (fl == GZB_F_MORE && ++slices < max_slices);
+                c_ntok[c] = nt;
+                // phase 2: the tokens' symbols
+                if (!fl) gzb_expand_block(J.blk_tok + c_symoff[c] / 2, nt, J.blk_sym + c_symoff[c]);
             }
             c_end[c] = p; c_nsym[c] = op; c_flags[c] = fl;
         }
