@@ -1394,7 +1394,20 @@ extern "C" {
 int aqc_gunzip_dev(int device, const uint8_t* gz, uint64_t size, uint8_t* out, uint64_t cap, uint64_t* n_out, uint64_t stats[8], int threads,
                    uint64_t section_bytes, uint64_t group_bytes) {
     if (!gz || !out || !n_out || !stats) return fail(AQC_ERR_ARG, "null argument");
-    std::unique_ptr<aqcgz::SectionOffload> off(aqcgz::make_device_offload(device, group_bytes ? (size_t)group_bytes : (256u << 20)));
+    // (one decoder per device and group size for the life of the process: its device buffers and page-locked arenas cost more to
+    //  set up than a gigabyte takes to decode)
+    static std::mutex cache_mu;
+    static std::vector<std::pair<std::pair<int, size_t>, std::unique_ptr<aqcgz::SectionOffload>>> cache;
+    const size_t gb = group_bytes ? (size_t)group_bytes : (256u << 20);
+    aqcgz::SectionOffload* off = nullptr;
+    {
+        std::lock_guard<std::mutex> g(cache_mu);
+        for (auto& e : cache) if (e.first.first == device && e.first.second == gb) off = e.second.get();
+        if (!off) {
+            std::unique_ptr<aqcgz::SectionOffload> made(aqcgz::make_device_offload(device, gb));
+            if (made) { off = made.get(); cache.emplace_back(std::make_pair(device, gb), std::move(made)); }
+        }
+    }
     if (!off) return fail(AQC_ERR_HIP, "device gunzip: cannot set up device %d", device);
     uint64_t before[8], after[8];
     aqcgz::device_offload_stats(before);
@@ -1403,7 +1416,7 @@ int aqc_gunzip_dev(int device, const uint8_t* gz, uint64_t size, uint8_t* out, u
     uint64_t produced = 0;
     int rc = 0;
     {
-        aqcgz::ParallelGunzip pg(gz, (size_t)size, threads > 0 ? &pool : nullptr, std::max(4, 2 * threads), section_bytes ? (size_t)section_bytes : (1u << 20), off.get(), true);
+        aqcgz::ParallelGunzip pg(gz, (size_t)size, threads > 0 ? &pool : nullptr, std::max(4, 2 * threads), section_bytes ? (size_t)section_bytes : (1u << 20), off, true);
         while (produced < cap) {
             const size_t got = pg.read(out + produced, (size_t)std::min<uint64_t>(cap - produced, 256u << 20));
             if (pg.failed()) { rc = fail(AQC_ERR_ARG, "device gunzip: %s", pg.error()); break; }

@@ -271,7 +271,7 @@ def test_pipe_single_member_gzip_input_is_shared_with_the_device(tmp_path):
                 assert hashlib.sha256(f.read()).hexdigest() == ref_files[name], (tag, name)
         return [int(a) - int(b) for a, b in zip(after_, before)]
 
-    os.environ["AQC_GZ_GROUP"] = str(8 << 20)
+    os.environ["AQC_GZ_GROUP"] = str(16 << 20)       # (a 40 MB file: one group of 64 sections per mate, a third of the file)
     os.environ["AQC_GZ_DEVICE_MIN"] = "0"        # (files this small are normally left to the pool)
     try:
         sections, from_device, text_bytes, device_bytes = gz_run("gzdev")
