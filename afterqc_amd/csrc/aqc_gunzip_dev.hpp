@@ -72,6 +72,9 @@ constexpr int GZB_E_DIST = 1 << GZB_LROOT, GZB_E_LSORT = GZB_E_DIST + (1 << GZB_
 constexpr int GZB_TAB_WORDS = GZB_TAB_ENTRIES / 2 + 80;          // 32-bit words per candidate: the tables, then the code lengths
 constexpr int GZB_SCAN_THREADS = 256, GZB_SCAN_TILE = GZB_SCAN_THREADS * 16, GZB_TILE_CAND = 16;
 constexpr int GZB_DEC_THREADS = 64;
+constexpr int GZB_K = 8;                           // lanes per block (entry points guessed inside it, see gzb_decode_kernel)
+constexpr uint32_t GZB_OVERLAP_BITS = 8192;        // how far a lane reads into its successor's share to meet its token list
+constexpr uint32_t GZB_T_EOB = 0x40000000u, GZB_T_JUNK = 0x20000000u;
 constexpr int GZB_SEC_BLOCKS = 4096;                // chain entries per section (3 words each)
 constexpr int GZB_GATHER_THREADS = 1024;
 constexpr uint32_t GZB_F_ERROR = 1u, GZB_F_OVERFLOW = 2u, GZB_F_SKIP = 4u, GZB_F_MORE = 8u;     // MORE: the slice ended inside the block
@@ -97,8 +100,15 @@ struct GzbJob {
     uint32_t* c_symcap;
     uint16_t* blk_sym;
     uint64_t blk_sym_cap;        // symbols
-    uint32_t* blk_tok;           // tokens of candidate c at [c_symoff[c] / 2, + c_symcap[c] / 2): bit 31 literal | byte, else length << 16 | distance - 1
-    uint32_t* c_ntok;            // [cand_cap] tokens written
+    uint32_t* blk_tok;           // tokens of candidate c at [c_symoff[c] / 2, + c_symcap[c] / 2), GZB_K equal shares for its GZB_K lanes:
+                                 // bit 31 literal | byte, GZB_T_EOB, GZB_T_JUNK, else length << 16 | distance - 1
+    uint32_t* blk_tpos;          // the bit each token starts at (same layout)
+    uint32_t* c_lanes;           // [cand_cap] lanes that read this block: GZB_K from guessed entry points, or 1 (plain)
+    uint32_t* l_p;               // [cand_cap * GZB_K] per lane: bit position reached ...
+    uint32_t* l_stop;            //   ... where it stops (a lane reads on behind its share until it has met its successor's list)
+    uint32_t* l_start;           //   ... where it started
+    uint32_t* l_ntok;            //   ... tokens written
+    uint32_t* l_flags;           //   ... GZB_F_MORE while it has work left, 0 done, GZB_F_OVERFLOW
     uint32_t ratio_cap;          // a block may expand to ratio_cap x its compressed size (+ 4096 symbols)
     uint32_t* tables;            // [cand_cap][GZB_TAB_WORDS]: a candidate's tables and code lengths
     uint32_t slice_tokens;       // tokens a lane decodes per launch (the decoder runs in slices: see gzb_decode_kernel)
@@ -327,21 +337,37 @@ GZB_HD inline uint32_t gzb_slow(unsigned long long w, const GzbLaneTab<S>& T) {
     return 0;
 }
 
+GZB_HD inline uint32_t gzb_lower_bound(const uint32_t* a, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 GZB_HD inline unsigned long long gzb_load64(const uint8_t* p) {
     unsigned long long v;
     memcpy(&v, p, 8);
     return v;
 }
 
-// PHASE 1 — one block's TOKENS from its first data bit p on: a literal is 0x80000000 | byte, a match length << 16 | distance - 1.
-// Nothing is copied here: what a lane waits for per token is one table look-up (two for a match) and, every few tokens, the
-// next word of the stream, which was asked for when the bit buffer was last refilled.  (The first version copied the matches
-// as it went: 41 scattered memory instructions per wave step, 4 microseconds per token.)  Returns the flags (0: the
-// end-of-block code was reached, GZB_F_MORE: max_tokens done, call again with the same p / nt / op); p = the bit reached,
-// nt = tokens written so far, op = symbols they stand for.
+// PHASE 1 — TOKENS of a stretch of a block, from bit p on: a literal is 0x80000000 | byte, a match length << 16 | distance - 1,
+// the end-of-block code GZB_T_EOB; tpos gets the bit every token starts at.  Nothing is copied here: what a lane waits for per
+// token is one table look-up (two for a match) and, every few tokens, the next word of the stream, which was asked for when the
+// bit buffer was last refilled.  (The first version copied the matches as it went: 41 scattered memory instructions per wave
+// step, 4 microseconds per token.)
+//
+// A block is read by SEVERAL lanes: lane k starts at a guessed bit inside the block.  Until its reading frame happens to fall
+// on a real token boundary it produces nonsense (including "end of block" and codes no symbol has: GZB_T_JUNK, one bit
+// consumed); from then on — Huffman streams re-synchronise within tens of tokens — it produces the true tokens, because what
+// follows a bit position depends on nothing but the tables.  So a lane never stops at an end-of-block code (spec) and reads on
+// to stop_bit, some way into its successor's share; gzb_stitch picks, per lane, the tokens from the first bit position it SHARES
+// with its predecessor's list — a check, not a guess.  A plain lane (spec == false) stops behind the end-of-block code.
+// Returns 0 done, GZB_F_MORE (max_tokens written: call again with the same p / nt), GZB_F_OVERFLOW, GZB_F_ERROR (plain only).
 template <int S>
-GZB_HD inline uint32_t gzb_tokenize_block(const uint8_t* comp, uint32_t limit_bit, const GzbLaneTab<S>& T, uint32_t* tok, uint32_t tok_cap, uint32_t sym_cap,
-                                          uint32_t& p, uint32_t& nt, uint32_t& op, uint32_t max_tokens) {
+GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, const GzbLaneTab<S>& T, uint32_t* tok, uint32_t* tpos, uint32_t tok_cap,
+                                    uint32_t& p, uint32_t& nt, uint32_t stop_bit, uint32_t max_tokens, bool spec) {
     uint32_t fl = 0, tokens = 0;
     const uint8_t* const end = comp + (limit_bit >> 3);      // (limit_bit is a multiple of 8; the buffer is padded for 64 bytes behind)
     const uint8_t* ip = comp + (p >> 3);
@@ -358,20 +384,29 @@ GZB_HD inline uint32_t gzb_tokenize_block(const uint8_t* comp, uint32_t limit_bi
         nx = gzb_load64(ip);                                                               \
     } while (0)
     for (;;) {
-        if (ip > end) { fl = GZB_F_ERROR; break; }
-        if (nt >= tok_cap || op + 258u > sym_cap) { fl = GZB_F_OVERFLOW; break; }
+        if (ip > end) { fl = spec ? 0u : GZB_F_ERROR; break; }
+        const uint32_t at = (uint32_t)((ip - comp) << 3) - bn;       // the bit this token starts at
+        if (at >= stop_bit) break;
+        if (nt >= tok_cap) { fl = GZB_F_OVERFLOW; break; }
         if (tokens++ >= max_tokens) { fl = GZB_F_MORE; break; }
         if (bn < 32u) GZB_REFILL();                           // >= 56 bits now; a literal/length code + its extra bits take <= 20
         uint32_t e = T.at((int)((uint32_t)bb & ((1u << GZB_LROOT) - 1u)));
-        if ((e & 15u) == 0u) {
-            e = gzb_slow<true, S>(bb, T);
-            if (!e) { fl = GZB_F_ERROR; break; }
+        if ((e & 15u) == 0u) e = gzb_slow<true, S>(bb, T);
+        if (!e || (e & 0x40u)) {                              // no such code / a symbol that does not exist
+            if (!spec) { fl = GZB_F_ERROR; break; }
+            bb >>= 1; bn -= 1;
+            tpos[nt] = at; tok[nt++] = GZB_T_JUNK;
+            continue;
         }
         const uint32_t l = e & 15u;
         bb >>= l;
         bn -= l;
-        if (e & 0x10u) { tok[nt++] = 0x80000000u | (e >> 8); op += 1u; continue; }
-        if (e & 0x60u) { if (e & 0x40u) fl = GZB_F_ERROR; break; }            // end of block
+        if (e & 0x10u) { tpos[nt] = at; tok[nt++] = 0x80000000u | (e >> 8); continue; }
+        if (e & 0x20u) {                                      // end of block
+            tpos[nt] = at; tok[nt++] = GZB_T_EOB;
+            if (spec) continue;
+            break;
+        }
         const uint32_t ls = e >> 8;
         const uint32_t xb = gzb_len_extra(ls);
         const uint32_t len = gzb_len_base(ls) + ((uint32_t)bb & ((1u << xb) - 1u));
@@ -379,20 +414,19 @@ GZB_HD inline uint32_t gzb_tokenize_block(const uint8_t* comp, uint32_t limit_bi
         bn -= xb;
         if (bn < 32u) GZB_REFILL();                           // a distance code + its extra bits take <= 28
         uint32_t de = T.at(GZB_E_DIST + (int)((uint32_t)bb & ((1u << GZB_DROOT) - 1u)));
-        if ((de & 15u) == 0u) {
-            de = gzb_slow<false, S>(bb, T);
-            if (!de) { fl = GZB_F_ERROR; break; }
+        if ((de & 15u) == 0u) de = gzb_slow<false, S>(bb, T);
+        if (!de || (de & 0x8000u)) {
+            if (!spec) { fl = GZB_F_ERROR; break; }
+            tpos[nt] = at; tok[nt++] = GZB_T_JUNK;            // (the length code's bits are gone: any rule will do before the frames meet)
+            continue;
         }
-        if (de & 0x8000u) { fl = GZB_F_ERROR; break; }
         const uint32_t dl = de & 15u, ds = (de >> 4) & 31u;
         bb >>= dl;
         const uint32_t dxb = gzb_dist_extra(ds);
         const uint32_t dd = gzb_dist_base(ds) + ((uint32_t)bb & ((1u << dxb) - 1u));
         bb >>= dxb;
         bn -= dl + dxb;
-        if ((int)op - (int)dd < -32768) { fl = GZB_F_ERROR; break; }         // reaches before the window
-        tok[nt++] = (len << 16) | (dd - 1u);
-        op += len;
+        tpos[nt] = at; tok[nt++] = (len << 16) | (dd - 1u);
     }
 #undef GZB_REFILL
     // the bit behind the last consumed one: ip points 8 bytes behind the word whose unconsumed bits are the top of bb
@@ -400,20 +434,73 @@ GZB_HD inline uint32_t gzb_tokenize_block(const uint8_t* comp, uint32_t limit_bi
     return fl;
 }
 
-// PHASE 2 as the host tests run it (the kernel does the same a wave per block, the lanes sharing every copy): the tokens'
-// symbols; a symbol >= 0x8000 is "byte j of the 32 KiB before this block"
-GZB_HD inline void gzb_expand_block(const uint32_t* tok, uint32_t nt, uint16_t* out) {
-    uint32_t op = 0;
-    for (uint32_t i = 0; i < nt; ++i) {
-        const uint32_t t = tok[i];
-        if (t >> 31) { out[op++] = (uint16_t)(t & 0xffu); continue; }
-        const uint32_t len = (t >> 16) & 0x1ffu, dd = (t & 0x7fffu) + 1u;
-        for (uint32_t k = 0; k < len; ++k) {
-            const int q = (int)op - (int)dd;
-            out[op] = q >= 0 ? out[q] : (uint16_t)(GZB_MARKER | (uint32_t)(32768 + q));
-            ++op;
+// Where the lanes of candidate c (of n) start and stop.  data_bit: the block's first data bit (behind its header); the block is
+// taken to end where the next candidate starts (the window's end for the last one).  If it ends earlier — stored and fixed-code
+// blocks are no candidates — the lanes behind its end read nonsense nobody looks at; if it ends LATER (the next candidate was
+// a false hit inside it) its last list runs out and the block counts as failed: the host inflates that section.  A small block
+// is read by one plain lane.
+GZB_HD inline void gzb_plan_lanes(const GzbJob& J, uint32_t c, uint32_t n, uint32_t data_bit) {
+    const uint32_t limit = J.comp_bytes * 8u;
+    const uint32_t est_end = c + 1 < n ? J.c_start[c + 1] : limit;
+    const bool plain = est_end <= data_bit || est_end - data_bit < (uint32_t)GZB_K * 4096u;
+    J.c_lanes[c] = plain ? 1u : (uint32_t)GZB_K;
+    for (uint32_t k = 0; k < (uint32_t)GZB_K; ++k) {
+        const uint32_t i = c * (uint32_t)GZB_K + k;
+        uint32_t st = data_bit, sp = 0xffffffffu;
+        if (!plain) {
+            const uint32_t share = (est_end - data_bit) / (uint32_t)GZB_K;
+            st = data_bit + k * share;
+            sp = k + 1 < (uint32_t)GZB_K ? data_bit + (k + 1) * share + GZB_OVERLAP_BITS : gzb_min(est_end + 64u, limit);
         }
+        J.l_start[i] = st; J.l_p[i] = st; J.l_stop[i] = sp; J.l_ntok[i] = 0;
+        J.l_flags[i] = (plain && k > 0) ? 0u : GZB_F_MORE;
     }
+}
+
+// PHASE 2 as the host tests run it (the kernel does the same a wave per block, the lanes sharing every copy and every search):
+// the block's symbols from its lanes' token lists.  Lane k's list counts from the first bit position it shares with lane
+// k - 1's; the block ends at the first end-of-block token met on the way.  A symbol >= 0x8000 is "byte j of the 32 KiB before
+// this block".  Returns the block's flags; n_sym / end_bit as gzb_chain_section wants them.
+GZB_HD inline uint32_t gzb_stitch_expand(const GzbJob& J, uint32_t c, uint32_t& n_sym, uint32_t& end_bit) {
+    const uint32_t lanes = J.c_lanes[c], cap = J.c_symcap[c];
+    const uint32_t share = (cap / 2u) / (uint32_t)GZB_K;
+    const uint32_t* const tok0 = J.blk_tok + J.c_symoff[c] / 2;
+    const uint32_t* const pos0 = J.blk_tpos + J.c_symoff[c] / 2;
+    uint16_t* const out = J.blk_sym + J.c_symoff[c];
+    for (uint32_t k = 0; k < lanes; ++k)
+        if (J.l_flags[c * GZB_K + k] != 0u) return J.l_flags[c * GZB_K + k] == GZB_F_MORE ? GZB_F_OVERFLOW : J.l_flags[c * GZB_K + k];
+    uint32_t k = 0, i = 0, op = 0;
+    for (;;) {
+        const uint32_t* const tok = tok0 + k * share;
+        const uint32_t* const pos = pos0 + k * share;
+        const uint32_t n = J.l_ntok[c * GZB_K + k];
+        if (i >= n) return GZB_F_ERROR;                       // the list ran out before it met the next one / an end of block
+        const uint32_t t = tok[i], at = pos[i];
+        if (k + 1 < lanes && at >= J.l_start[c * GZB_K + k + 1]) {
+            const uint32_t* const npos = pos0 + (k + 1) * share;
+            const uint32_t nn = J.l_ntok[c * GZB_K + k + 1];
+            const uint32_t j = gzb_lower_bound(npos, nn, at);
+            if (j < nn && npos[j] == at) { ++k; i = j; continue; }        // the two reading frames have met: go on in the next list
+        }
+        if (t == GZB_T_EOB) { end_bit = i + 1 < n ? pos[i + 1] : J.l_p[c * GZB_K + k]; break; }
+        if (t & GZB_T_JUNK) return GZB_F_ERROR;
+        if (t >> 31) {
+            if (op + 1u > cap) return GZB_F_OVERFLOW;
+            out[op++] = (uint16_t)(t & 0xffu);
+        } else {
+            const uint32_t len = (t >> 16) & 0x1ffu, dd = (t & 0x7fffu) + 1u;
+            if (op + len > cap) return GZB_F_OVERFLOW;
+            if ((int)op - (int)dd < -32768) return GZB_F_ERROR;
+            for (uint32_t q = 0; q < len; ++q) {
+                const int src = (int)op - (int)dd;
+                out[op] = src >= 0 ? out[src] : (uint16_t)(GZB_MARKER | (uint32_t)(32768 + src));
+                ++op;
+            }
+        }
+        ++i;
+    }
+    n_sym = op;
+    return 0;
 }
 
 // symbol space of candidate c of n: ratio_cap x the compressed bytes up to the next candidate (the last one: to the window's end)
@@ -423,14 +510,6 @@ GZB_HD inline uint32_t gzb_symcap_of(const GzbJob& J, uint32_t c, uint32_t n) {
     return ((span * J.ratio_cap + 4096u) + 7u) & ~7u;
 }
 
-GZB_HD inline uint32_t gzb_lower_bound(const uint32_t* a, uint32_t n, uint32_t x) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (a[mid] < x) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
 // the usable candidate that starts exactly at bit x (GZB_NONE: none)
 GZB_HD inline uint32_t gzb_cand_at(const GzbJob& J, uint32_t n, uint32_t x) {
     const uint32_t i = gzb_lower_bound(J.c_start, n, x);
@@ -668,74 +747,121 @@ __global__ __launch_bounds__(1024) void gzb_compact_kernel(GzbJob J) {
 // ---- a lane per block --------------------------------------------------------------------------------------------------------------
 // PHASE 1 runs in SLICES of J.slice_tokens tokens per lane and launch: a kernel that sits on its CUs for tens of milliseconds
 // keeps the filter's kernels — which want every CU, with all its registers — waiting behind it (measured: the first wiring made
-// `.gz -> .gz` slower than the host alone).  Between two slices they get their turn.  FIRST: header, tables, first slice; else:
-// lanes whose block is not finished go on.
-template <bool FIRST>
-__global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
-    __shared__ uint8_t s_cl[FIRST ? 128 * GZB_DEC_THREADS : 1];
-    __shared__ uint32_t s_cnt[FIRST ? 16 * GZB_DEC_THREADS : 1], s_nxt[FIRST ? 16 * GZB_DEC_THREADS : 1], s_off[FIRST ? 16 * GZB_DEC_THREADS : 1];
+// `.gz -> .gz` slower than the host alone).  Between two slices they get their turn.
+// gzb_tables_kernel: a lane per candidate — header, tables, where its GZB_K lanes start and stop.
+__global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_tables_kernel(GzbJob J) {
+    __shared__ uint8_t s_cl[128 * GZB_DEC_THREADS];
+    __shared__ uint32_t s_cnt[16 * GZB_DEC_THREADS], s_nxt[16 * GZB_DEC_THREADS], s_off[16 * GZB_DEC_THREADS];
     const int tid = threadIdx.x;
     const uint32_t c = blockIdx.x * (uint32_t)GZB_DEC_THREADS + (uint32_t)tid;
-    if (c >= J.n_cand[0]) return;
+    const uint32_t n = J.n_cand[0];
+    if (c >= n) return;
     const uint32_t limit_bit = J.comp_bytes * 8u;
-    const uint32_t cap = J.c_symcap[c];
     uint32_t* const tw = J.tables + (size_t)c * GZB_TAB_WORDS;
     const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(tw)};
     uint8_t* const lens = reinterpret_cast<uint8_t*>(tw + GZB_TAB_ENTRIES / 2);
-    uint32_t p = 0, hlit = 0, hdist = 0, op = 0, nt = 0, fl = 0;
-    if (FIRST) {
-        if (cap == 0) fl = GZB_F_SKIP;
-        else if (!gzb_header(J.comp, limit_bit, J.c_start[c], s_cl + tid, GZB_DEC_THREADS, lens, p, hlit, hdist)) fl = GZB_F_ERROR;
-        if (!fl) {
-            gzb_build<true>(lens, hlit, T, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
-            gzb_build<false>(lens + hlit, hdist, T, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
-        }
+    uint32_t p = 0, hlit = 0, hdist = 0, fl = 0;
+    if (J.c_symcap[c] == 0) fl = GZB_F_SKIP;
+    else if (!gzb_header(J.comp, limit_bit, J.c_start[c], s_cl + tid, GZB_DEC_THREADS, lens, p, hlit, hdist)) fl = GZB_F_ERROR;
+    if (!fl) {
+        gzb_build<true>(lens, hlit, T, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
+        gzb_build<false>(lens + hlit, hdist, T, s_cnt + tid, s_nxt + tid, s_off + tid, GZB_DEC_THREADS);
+        gzb_plan_lanes(J, c, n, p);
     } else {
-        if (J.c_flags[c] != GZB_F_MORE) return;
-        p = J.c_end[c];
-        op = J.c_nsym[c];
-        nt = J.c_ntok[c];
+        J.c_lanes[c] = 0;
+        for (uint32_t k = 0; k < (uint32_t)GZB_K; ++k) J.l_flags[c * GZB_K + k] = 0;
     }
-    if (!fl) fl = gzb_tokenize_block(J.comp, limit_bit, T, J.blk_tok + J.c_symoff[c] / 2, cap / 2, cap, p, nt, op, J.slice_tokens);
-    J.c_end[c] = p;
-    J.c_nsym[c] = op;
-    J.c_ntok[c] = nt;
     J.c_flags[c] = fl;
+    J.c_nsym[c] = 0;
+    J.c_end[c] = 0;
 }
 
-// PHASE 2 — a WAVE per block turns its tokens into symbols: 64 tokens at a time, their output positions from a lane scan; the
-// literals of the chunk are stored at once, the matches applied in order, the 64 lanes sharing each copy (a copy that overlaps
-// itself repeats its period).  A wave's loads and stores to global memory are performed in issue order, so a copy sees what
-// the one before it wrote.
+// gzb_decode_kernel: a lane per (candidate, entry point) reads one slice of tokens
+__global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
+    const uint32_t i = blockIdx.x * (uint32_t)GZB_DEC_THREADS + threadIdx.x;
+    const uint32_t c = i / (uint32_t)GZB_K, k = i % (uint32_t)GZB_K;
+    if (c >= J.n_cand[0] || J.l_flags[i] != GZB_F_MORE) return;
+    const uint32_t lanes = J.c_lanes[c];
+    const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(J.tables + (size_t)c * GZB_TAB_WORDS)};
+    const uint32_t share = (J.c_symcap[c] / 2u) / (uint32_t)GZB_K;
+    const size_t at = J.c_symoff[c] / 2 + (size_t)k * share;
+    uint32_t p = J.l_p[i], nt = J.l_ntok[i];
+    const uint32_t fl = gzb_tokenize(J.comp, J.comp_bytes * 8u, T, J.blk_tok + at, J.blk_tpos + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i],
+                                     J.slice_tokens, lanes != 1u);
+    J.l_p[i] = p;
+    J.l_ntok[i] = nt;
+    J.l_flags[i] = fl;
+}
+
+// PHASE 2 — a WAVE per block turns its lanes' token lists into symbols (gzb_stitch_expand is the same thing on the host): 64
+// tokens at a time.  Where the chunk reaches into the next lane's share every lane looks its token's bit position up in that
+// lane's list (a binary search); the first lane that finds it is where the two reading frames have met: the tokens before it
+// are applied and the walk goes on in the next list.  Output positions come from a lane scan, the chunk's literals are stored
+// at once, its matches applied in order with the 64 lanes sharing each copy (a copy that overlaps itself repeats its period).
+// A wave's loads and stores to global memory are performed in issue order, so a copy sees what the one before it wrote.
 constexpr int GZB_EXP_WAVES = 4;
 __global__ __launch_bounds__(64 * GZB_EXP_WAVES) void gzb_expand_kernel(GzbJob J) {
     const uint32_t c = blockIdx.x * (uint32_t)GZB_EXP_WAVES + (threadIdx.x >> 6);
     const int lane = (int)(threadIdx.x & 63u);
     if (c >= J.n_cand[0] || J.c_flags[c] != 0u) return;
-    const uint32_t* const tok = J.blk_tok + J.c_symoff[c] / 2;
+    const uint32_t lanes = J.c_lanes[c], cap = J.c_symcap[c];
+    const uint32_t share = (cap / 2u) / (uint32_t)GZB_K;
+    const uint32_t* const tok0 = J.blk_tok + J.c_symoff[c] / 2;
+    const uint32_t* const pos0 = J.blk_tpos + J.c_symoff[c] / 2;
     uint16_t* const out = J.blk_sym + J.c_symoff[c];
-    const uint32_t nt = J.c_ntok[c];
-    uint32_t op = 0;
-    for (uint32_t base = 0; base < nt; base += 64u) {
-        const bool have = base + (uint32_t)lane < nt;
-        const uint32_t t = have ? tok[base + (uint32_t)lane] : 0x80000000u;
+    uint32_t fl = 0;
+    for (uint32_t q = 0; q < lanes; ++q) {
+        const uint32_t f = J.l_flags[c * GZB_K + q];
+        if (f != 0u) fl = f == GZB_F_MORE ? GZB_F_OVERFLOW : f;
+    }
+    uint32_t k = 0, i = 0, op = 0, end_bit = 0;
+    bool done = false;
+    while (!fl && !done) {
+        const uint32_t* const tok = tok0 + k * share;
+        const uint32_t* const pos = pos0 + k * share;
+        const uint32_t n = J.l_ntok[c * GZB_K + k];
+        if (i >= n) { fl = GZB_F_ERROR; break; }              // the list ran out before it met the next one / an end of block
+        const bool have = i + (uint32_t)lane < n;
+        const uint32_t t = have ? tok[i + (uint32_t)lane] : GZB_T_JUNK;
+        const uint32_t at = have ? pos[i + (uint32_t)lane] : 0u;
+        // does the next lane's list have a token at this very bit?
+        uint32_t jn = GZB_NONE;
+        if (k + 1 < lanes) {
+            const uint32_t nstart = J.l_start[c * GZB_K + k + 1];
+            if (__ballot(have && at >= nstart)) {
+                const uint32_t* const npos = pos0 + (k + 1) * share;
+                const uint32_t nn = J.l_ntok[c * GZB_K + k + 1];
+                if (have && at >= nstart) {
+                    const uint32_t j = gzb_lower_bound(npos, nn, at);
+                    if (j < nn && npos[j] == at) jn = j;
+                }
+            }
+        }
+        const unsigned long long m_meet = __ballot(jn != GZB_NONE), m_eob = __ballot(have && t == GZB_T_EOB),
+                                 m_junk = __ballot((t & GZB_T_JUNK) != 0u);        // (lanes behind the list's end hold JUNK too)
+        const unsigned long long m_cut = m_meet | m_eob | m_junk;
+        const int cut = m_cut ? __ffsll((long long)m_cut) - 1 : 64;       // tokens of lanes < cut are applied
+        const bool use = lane < cut;
         const bool lit = (t >> 31) != 0u;
-        const uint32_t len = have ? (lit ? 1u : (t >> 16) & 0x1ffu) : 0u;
+        const uint32_t len = use ? (lit ? 1u : (t >> 16) & 0x1ffu) : 0u;
         uint32_t inc = len;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
             if (lane >= d) inc += o;
         }
-        const uint32_t pos = op + inc - len;
-        if (have && lit) out[pos] = (uint16_t)(t & 0xffu);
-        unsigned long long mm = __ballot(have && !lit);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        if (op + total > cap) { fl = GZB_F_OVERFLOW; break; }
+        const uint32_t opos = op + inc - len;
+        if (use && lit) out[opos] = (uint16_t)(t & 0xffu);
+        unsigned long long mm = __ballot(use && !lit);
+        if (__ballot(use && !lit && (int)opos - (int)((t & 0x7fffu) + 1u) < -32768)) { fl = GZB_F_ERROR; break; }
         while (mm) {
             const int l = __ffsll((long long)mm) - 1;
             mm &= mm - 1;
             const uint32_t m_len = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
             const uint32_t m_dd = ((uint32_t)__builtin_amdgcn_readlane((int)t, l) & 0x7fffu) + 1u;
-            const uint32_t m_pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, l);
+            const uint32_t m_pos = (uint32_t)__builtin_amdgcn_readlane((int)opos, l);
             const int src = (int)m_pos - (int)m_dd;
             for (uint32_t j0 = 0; j0 < m_len; j0 += 64u) {
                 const uint32_t j = j0 + (uint32_t)lane;
@@ -746,7 +872,22 @@ __global__ __launch_bounds__(64 * GZB_EXP_WAVES) void gzb_expand_kernel(GzbJob J
                 }
             }
         }
-        op += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        op += total;
+        if (cut == 64) { i += 64u; continue; }
+        // what stopped the chunk at lane `cut`: the frames met (first: the next list takes over AT this token), the block's end, or nonsense
+        if ((m_meet >> cut) & 1ull) {
+            i = (uint32_t)__builtin_amdgcn_readlane((int)jn, cut);
+            ++k;
+        } else if ((m_eob >> cut) & 1ull) {
+            const uint32_t ci = i + (uint32_t)cut;
+            end_bit = ci + 1u < n ? pos[ci + 1u] : J.l_p[c * GZB_K + k];
+            done = true;
+        } else fl = GZB_F_ERROR;
+    }
+    if (lane == 0) {
+        J.c_flags[c] = fl;
+        J.c_nsym[c] = fl ? 0u : op;
+        J.c_end[c] = end_bit;
     }
 }
 

@@ -31,7 +31,7 @@ struct CpuOffload : aqcgz::SectionOffload {
     uint32_t ratio_cap = 20;
     uint32_t cand_div = 4096;            // candidate capacity = span / cand_div + 256
     uint32_t slice_tokens = 300, max_slices = 1u << 20;
-    uint64_t groups = 0, sections = 0, found = 0, candidates = 0, false_ends = 0;
+    uint64_t groups = 0, sections = 0, found = 0, candidates = 0, false_ends = 0, spec_lanes = 0, failed_blocks = 0, stitched_blocks = 0;
     std::vector<std::vector<uint16_t>*> live;
     explicit CpuOffload(size_t g) : group(g) {}
     size_t group_bytes() const override { return group; }
@@ -61,8 +61,10 @@ struct CpuOffload : aqcgz::SectionOffload {
         J.blk_sym_cap = (uint64_t)span * ratio_cap + (uint64_t)J.cand_cap * 4104;
         std::vector<uint16_t> blk_sym(J.blk_sym_cap + 64);
         J.blk_sym = blk_sym.data();
-        std::vector<uint32_t> blk_tok(J.blk_sym_cap / 2 + 64), c_ntok(J.cand_cap);
-        J.blk_tok = blk_tok.data(); J.c_ntok = c_ntok.data();
+        std::vector<uint32_t> blk_tok(J.blk_sym_cap / 2 + 64), blk_tpos(J.blk_sym_cap / 2 + 64), c_lanes(J.cand_cap), l_u32((size_t)5 * J.cand_cap * GZB_K);
+        J.blk_tok = blk_tok.data(); J.blk_tpos = blk_tpos.data(); J.c_lanes = c_lanes.data();
+        J.l_p = l_u32.data(); J.l_stop = J.l_p + (size_t)J.cand_cap * GZB_K; J.l_start = J.l_stop + (size_t)J.cand_cap * GZB_K;
+        J.l_ntok = J.l_start + (size_t)J.cand_cap * GZB_K; J.l_flags = J.l_ntok + (size_t)J.cand_cap * GZB_K;
         std::vector<uint32_t> tables((size_t)J.cand_cap * GZB_TAB_WORDS);
         J.tables = tables.data();
         // ---- scan: every lane of every tile
@@ -118,27 +120,47 @@ struct CpuOffload : aqcgz::SectionOffload {
                 o += cap;
             }
         }
-        // ---- decode: a lane per candidate
+        // ---- decode: tables per candidate, then GZB_K lanes per candidate in slices, then the stitch
         std::vector<uint32_t> cnt(16), nxt(16), off(16);
         for (uint32_t c = 0; c < nc; ++c) {
             uint32_t* const tw = J.tables + (size_t)c * GZB_TAB_WORDS;
             const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(tw)};
             uint8_t* const lens = reinterpret_cast<uint8_t*>(tw + GZB_TAB_ENTRIES / 2);
-            uint32_t p = 0, hlit = 0, hdist = 0, op = 0, fl = 0;
+            uint32_t p = 0, hlit = 0, hdist = 0, fl = 0;
             if (c_symcap[c] == 0) fl = GZB_F_SKIP;
             else if (!gzb_header(J.comp, limit_bit, c_start[c], cl.data(), 1, lens, p, hlit, hdist)) fl = GZB_F_ERROR;
             if (!fl) {
                 gzb_build<true>(lens, hlit, T, cnt.data(), nxt.data(), off.data(), 1);
                 gzb_build<false>(lens + hlit, hdist, T, cnt.data(), nxt.data(), off.data(), 1);
-                // in slices, like the kernels: a slice ends after slice_tokens tokens, the next one resumes at the saved bit / symbol
-                uint32_t slices = 0, nt = 0;
-                do fl = gzb_tokenize_block(J.comp, limit_bit, T, J.blk_tok + c_symoff[c] / 2, c_symcap[c] / 2, c_symcap[c], p, nt, op, slice_tokens);
-                while (fl == GZB_F_MORE && ++slices < max_slices);
-                c_ntok[c] = nt;
-                // phase 2: the tokens' symbols
-                if (!fl) gzb_expand_block(J.blk_tok + c_symoff[c] / 2, nt, J.blk_sym + c_symoff[c]);
+                gzb_plan_lanes(J, c, nc, p);
+            } else {
+                c_lanes[c] = 0;
+                for (uint32_t k = 0; k < (uint32_t)GZB_K; ++k) J.l_flags[c * GZB_K + k] = 0;
             }
-            c_end[c] = p; c_nsym[c] = op; c_flags[c] = fl;
+            c_flags[c] = fl; c_nsym[c] = 0; c_end[c] = 0;
+        }
+        // in slices, like the kernels: a slice ends after slice_tokens tokens, the next one resumes at the saved bit / token count
+        for (uint32_t sl = 0; sl < max_slices; ++sl)
+            for (uint32_t i = 0; i < nc * (uint32_t)GZB_K; ++i) {
+                const uint32_t c = i / (uint32_t)GZB_K, k = i % (uint32_t)GZB_K;
+                if (J.l_flags[i] != GZB_F_MORE) continue;
+                const uint32_t lanes = c_lanes[c];
+                if (lanes > 1) ++spec_lanes;
+                const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(J.tables + (size_t)c * GZB_TAB_WORDS)};
+                const uint32_t share = (c_symcap[c] / 2u) / (uint32_t)GZB_K;
+                const size_t at = c_symoff[c] / 2 + (size_t)k * share;
+                uint32_t p = J.l_p[i], nt = J.l_ntok[i];
+                J.l_flags[i] = gzb_tokenize(J.comp, limit_bit, T, J.blk_tok + at, J.blk_tpos + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i],
+                                            slice_tokens, lanes != 1u);
+                J.l_p[i] = p; J.l_ntok[i] = nt;
+            }
+        for (uint32_t c = 0; c < nc; ++c) {
+            if (c_flags[c]) continue;
+            uint32_t ns = 0, eb = 0;
+            const uint32_t fl = gzb_stitch_expand(J, c, ns, eb);
+            c_flags[c] = fl; c_nsym[c] = fl ? 0u : ns; c_end[c] = eb;
+            if (fl) ++failed_blocks;
+            if (!fl && c_lanes[c] > 1) ++stitched_blocks;
         }
         // ---- chain + gather
         uint64_t sec_max = 0;
@@ -255,8 +277,9 @@ bool run_case(const char* what, const std::vector<uint8_t>& gz, const std::vecto
         if (ok && want_device && dev_acc == 0) ok = false;
         if (ok && hybrid && want_device && host_acc == 0) ok = false;      // the pool and the device both supplied sections
     }
-    printf("%-46s %s  gz %8zu -> %9zu B  sec %7zu  device sections %3llu  host %3llu  bridged %9llu B  candidates %llu  groups %llu\n", what, ok ? "ok  " : "FAIL", gz.size(),
-           text.size(), section, (unsigned long long)dev_acc, (unsigned long long)host_acc, (unsigned long long)bridged, (unsigned long long)off.candidates, (unsigned long long)off.groups);
+    printf("%-46s %s  gz %8zu -> %9zu B  sec %7zu  device sections %3llu  host %3llu  bridged %9llu B  candidates %llu  groups %llu  stitched %llu  failed %llu\n", what, ok ? "ok  " : "FAIL", gz.size(),
+           text.size(), section, (unsigned long long)dev_acc, (unsigned long long)host_acc, (unsigned long long)bridged, (unsigned long long)off.candidates, (unsigned long long)off.groups, (unsigned long long)off.stitched_blocks,
+           (unsigned long long)off.failed_blocks);
     if (!ok) ++failures;
     return ok;
 }
