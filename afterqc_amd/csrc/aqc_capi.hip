@@ -1158,13 +1158,13 @@ private:
         hipStream_t stream = nullptr;
         hipEvent_t ev[7] = {};
         std::unique_ptr<Group> job;
-        DevBuf comp, tile_cnt, tile_cand, n_cand, c_start, c_end, c_nsym, c_flags, c_symoff, c_symcap, blk_sym, tables, blk_tok, blk_tpos, c_lanes, l_u32;
+        DevBuf comp, tile_cnt, tile_cand, n_cand, c_start, c_end, c_nsym, c_flags, c_symoff, c_symcap, blk_sym, tables, blk_tp, c_lanes, l_u32;
         DevBuf s_in, s_out, s_blocks, s_sym, s_off;
         uint8_t* stage = nullptr;          // page-locked copy of the group's compressed bytes (the file itself is a pageable mapping)
         size_t stage_cap = 0;
         void release() {
             if (stream) (void)hipStreamSynchronize(stream);
-            DevBuf* b[] = {&comp, &tile_cnt, &tile_cand, &n_cand, &c_start, &c_end, &c_nsym, &c_flags, &c_symoff, &c_symcap, &blk_sym, &tables, &blk_tok, &blk_tpos, &c_lanes, &l_u32, &s_in, &s_out, &s_blocks, &s_sym, &s_off};
+            DevBuf* b[] = {&comp, &tile_cnt, &tile_cand, &n_cand, &c_start, &c_end, &c_nsym, &c_flags, &c_symoff, &c_symcap, &blk_sym, &tables, &blk_tp, &c_lanes, &l_u32, &s_in, &s_out, &s_blocks, &s_sym, &s_off};
             for (DevBuf* x : b) x->release();
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
@@ -1248,7 +1248,7 @@ private:
         if (L.comp.reserve(span + 256) || L.tile_cnt.reserve(4ull * n_tiles) || L.tile_cand.reserve(4ull * n_tiles * GZB_TILE_CAND) || L.n_cand.reserve(64) ||
             L.c_start.reserve(4ull * cand_cap) || L.c_end.reserve(4ull * cand_cap) || L.c_nsym.reserve(4ull * cand_cap) || L.c_flags.reserve(4ull * cand_cap) ||
             L.c_symoff.reserve(8ull * cand_cap) || L.c_symcap.reserve(4ull * cand_cap) || L.blk_sym.reserve(2ull * blk_sym_cap + 64) ||
-            L.blk_tok.reserve(2ull * blk_sym_cap + 256) || L.blk_tpos.reserve(2ull * blk_sym_cap + 256) || L.c_lanes.reserve(4ull * cand_cap) ||
+            L.blk_tp.reserve(4ull * blk_sym_cap + 512) || L.c_lanes.reserve(4ull * cand_cap) ||
             L.l_u32.reserve(5ull * 4ull * cand_cap * GZB_K) ||
             L.tables.reserve(4ull * cand_cap * GZB_TAB_WORDS) || L.s_in.reserve(12ull * n) || L.s_out.reserve(16ull * n) || L.s_off.reserve(8ull * (n + 1)) ||
             L.s_blocks.reserve(12ull * n * GZB_SEC_BLOCKS) || L.s_sym.reserve(2ull * s_sym_total + 64))
@@ -1287,7 +1287,7 @@ private:
         J.cand_cap = cand_cap; J.n_cand = (uint32_t*)L.n_cand.p;
         J.c_start = (uint32_t*)L.c_start.p; J.c_end = (uint32_t*)L.c_end.p; J.c_nsym = (uint32_t*)L.c_nsym.p; J.c_flags = (uint32_t*)L.c_flags.p;
         J.c_symoff = (uint64_t*)L.c_symoff.p; J.c_symcap = (uint32_t*)L.c_symcap.p; J.blk_sym = (uint16_t*)L.blk_sym.p; J.blk_sym_cap = blk_sym_cap;
-        J.ratio_cap = GZB_RATIO_CAP; J.tables = (uint32_t*)L.tables.p; J.blk_tok = (uint32_t*)L.blk_tok.p; J.blk_tpos = (uint32_t*)L.blk_tpos.p;
+        J.ratio_cap = GZB_RATIO_CAP; J.tables = (uint32_t*)L.tables.p; J.blk_tp = (unsigned long long*)L.blk_tp.p;
         J.c_lanes = (uint32_t*)L.c_lanes.p;
         J.l_p = (uint32_t*)L.l_u32.p; J.l_stop = J.l_p + (size_t)cand_cap * GZB_K; J.l_start = J.l_stop + (size_t)cand_cap * GZB_K;
         J.l_ntok = J.l_start + (size_t)cand_cap * GZB_K; J.l_flags = J.l_ntok + (size_t)cand_cap * GZB_K;
@@ -1302,7 +1302,7 @@ private:
         hipLaunchKernelGGL(gzb_scan_kernel, dim3(n_tiles), dim3(GZB_SCAN_THREADS), 0, L.stream, J);
         hipLaunchKernelGGL(gzb_compact_kernel, dim3(1), dim3(1024), 0, L.stream, J);
         GZB_TRY(hipEventRecord(L.ev[2], L.stream));
-        // the decoder in slices (aqc_gunzip_dev.hpp): GZB_K lanes per block, each with an eighth of it and the overlap: 16 x 640
+        // the decoder in slices (aqc_gunzip_dev.hpp): GZB_K lanes per block, each with its share of it and the overlap: 16 x 640
         // tokens cover the blocks of zlib (<= 16 K tokens) and of GNU gzip (<= 32 K) with room to spare; a lane that needs more
         // stays unfinished, its block counts as failed, the section ends before it and the host goes on from there
         {

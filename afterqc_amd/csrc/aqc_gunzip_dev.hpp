@@ -72,7 +72,7 @@ constexpr int GZB_E_DIST = 1 << GZB_LROOT, GZB_E_LSORT = GZB_E_DIST + (1 << GZB_
 constexpr int GZB_TAB_WORDS = GZB_TAB_ENTRIES / 2 + 80;          // 32-bit words per candidate: the tables, then the code lengths
 constexpr int GZB_SCAN_THREADS = 256, GZB_SCAN_TILE = GZB_SCAN_THREADS * 16, GZB_TILE_CAND = 16;
 constexpr int GZB_DEC_THREADS = 64;
-constexpr int GZB_K = 8;                           // lanes per block (entry points guessed inside it, see gzb_decode_kernel)
+constexpr int GZB_K = 16;                          // lanes per block (entry points guessed inside it, see gzb_decode_kernel)
 constexpr uint32_t GZB_OVERLAP_BITS = 8192;        // how far a lane reads into its successor's share to meet its token list
 constexpr uint32_t GZB_T_EOB = 0x40000000u, GZB_T_JUNK = 0x20000000u;
 constexpr int GZB_SEC_BLOCKS = 4096;                // chain entries per section (3 words each)
@@ -100,9 +100,8 @@ struct GzbJob {
     uint32_t* c_symcap;
     uint16_t* blk_sym;
     uint64_t blk_sym_cap;        // symbols
-    uint32_t* blk_tok;           // tokens of candidate c at [c_symoff[c] / 2, + c_symcap[c] / 2), GZB_K equal shares for its GZB_K lanes:
-                                 // bit 31 literal | byte, GZB_T_EOB, GZB_T_JUNK, else length << 16 | distance - 1
-    uint32_t* blk_tpos;          // the bit each token starts at (same layout)
+    unsigned long long* blk_tp;  // tokens of candidate c at [c_symoff[c] / 2, + c_symcap[c] / 2), GZB_K equal shares for its GZB_K lanes: the token in the
+                                 // low word, the bit it starts at in the high one (one store per token)
     uint32_t* c_lanes;           // [cand_cap] lanes that read this block: GZB_K from guessed entry points, or 1 (plain)
     uint32_t* l_p;               // [cand_cap * GZB_K] per lane: bit position reached ...
     uint32_t* l_stop;            //   ... where it stops (a lane reads on behind its share until it has met its successor's list)
@@ -346,6 +345,16 @@ GZB_HD inline uint32_t gzb_lower_bound(const uint32_t* a, uint32_t n, uint32_t x
     return lo;
 }
 
+// the same over the bit positions of a token list (high words)
+GZB_HD inline uint32_t gzb_lower_bound_pos(const unsigned long long* a, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint32_t)(a[mid] >> 32) < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 GZB_HD inline unsigned long long gzb_load64(const uint8_t* p) {
     unsigned long long v;
     memcpy(&v, p, 8);
@@ -353,7 +362,7 @@ GZB_HD inline unsigned long long gzb_load64(const uint8_t* p) {
 }
 
 // PHASE 1 — TOKENS of a stretch of a block, from bit p on: a literal is 0x80000000 | byte, a match length << 16 | distance - 1,
-// the end-of-block code GZB_T_EOB; tpos gets the bit every token starts at.  Nothing is copied here: what a lane waits for per
+// the end-of-block code GZB_T_EOB; the bit every token starts at goes into the entry's high word.  Nothing is copied here: what a lane waits for per
 // token is one table look-up (two for a match) and, every few tokens, the next word of the stream, which was asked for when the
 // bit buffer was last refilled.  (The first version copied the matches as it went: 41 scattered memory instructions per wave
 // step, 4 microseconds per token.)
@@ -366,7 +375,7 @@ GZB_HD inline unsigned long long gzb_load64(const uint8_t* p) {
 // with its predecessor's list — a check, not a guess.  A plain lane (spec == false) stops behind the end-of-block code.
 // Returns 0 done, GZB_F_MORE (max_tokens written: call again with the same p / nt), GZB_F_OVERFLOW, GZB_F_ERROR (plain only).
 template <int S>
-GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, const GzbLaneTab<S>& T, uint32_t* tok, uint32_t* tpos, uint32_t tok_cap,
+GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, const GzbLaneTab<S>& T, unsigned long long* tp, uint32_t tok_cap,
                                     uint32_t& p, uint32_t& nt, uint32_t stop_bit, uint32_t max_tokens, bool spec) {
     uint32_t fl = 0, tokens = 0;
     const uint8_t* const end = comp + (limit_bit >> 3);      // (limit_bit is a multiple of 8; the buffer is padded for 64 bytes behind)
@@ -375,6 +384,7 @@ GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, con
     uint32_t bn = 64u - (p & 7u);                             // valid bits in bb
     ip += 8;
     unsigned long long nx = gzb_load64(ip);                   // the eight bytes at ip, on their way
+#define GZB_TP(at_, t_) (((unsigned long long)(at_) << 32) | (unsigned long long)(t_))
 #define GZB_REFILL()                                                                       \
     do {                                                                                   \
         bb |= nx << bn;                                                                    \
@@ -395,15 +405,15 @@ GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, con
         if (!e || (e & 0x40u)) {                              // no such code / a symbol that does not exist
             if (!spec) { fl = GZB_F_ERROR; break; }
             bb >>= 1; bn -= 1;
-            tpos[nt] = at; tok[nt++] = GZB_T_JUNK;
+            tp[nt++] = GZB_TP(at, GZB_T_JUNK);
             continue;
         }
         const uint32_t l = e & 15u;
         bb >>= l;
         bn -= l;
-        if (e & 0x10u) { tpos[nt] = at; tok[nt++] = 0x80000000u | (e >> 8); continue; }
+        if (e & 0x10u) { tp[nt++] = GZB_TP(at, 0x80000000u | (e >> 8)); continue; }
         if (e & 0x20u) {                                      // end of block
-            tpos[nt] = at; tok[nt++] = GZB_T_EOB;
+            tp[nt++] = GZB_TP(at, GZB_T_EOB);
             if (spec) continue;
             break;
         }
@@ -417,7 +427,7 @@ GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, con
         if ((de & 15u) == 0u) de = gzb_slow<false, S>(bb, T);
         if (!de || (de & 0x8000u)) {
             if (!spec) { fl = GZB_F_ERROR; break; }
-            tpos[nt] = at; tok[nt++] = GZB_T_JUNK;            // (the length code's bits are gone: any rule will do before the frames meet)
+            tp[nt++] = GZB_TP(at, GZB_T_JUNK);            // (the length code's bits are gone: any rule will do before the frames meet)
             continue;
         }
         const uint32_t dl = de & 15u, ds = (de >> 4) & 31u;
@@ -426,9 +436,10 @@ GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, con
         const uint32_t dd = gzb_dist_base(ds) + ((uint32_t)bb & ((1u << dxb) - 1u));
         bb >>= dxb;
         bn -= dl + dxb;
-        tpos[nt] = at; tok[nt++] = (len << 16) | (dd - 1u);
+        tp[nt++] = GZB_TP(at, (len << 16) | (dd - 1u));
     }
 #undef GZB_REFILL
+#undef GZB_TP
     // the bit behind the last consumed one: ip points 8 bytes behind the word whose unconsumed bits are the top of bb
     p = (uint32_t)((ip - comp) << 3) - bn;
     return fl;
@@ -464,25 +475,23 @@ GZB_HD inline void gzb_plan_lanes(const GzbJob& J, uint32_t c, uint32_t n, uint3
 GZB_HD inline uint32_t gzb_stitch_expand(const GzbJob& J, uint32_t c, uint32_t& n_sym, uint32_t& end_bit) {
     const uint32_t lanes = J.c_lanes[c], cap = J.c_symcap[c];
     const uint32_t share = (cap / 2u) / (uint32_t)GZB_K;
-    const uint32_t* const tok0 = J.blk_tok + J.c_symoff[c] / 2;
-    const uint32_t* const pos0 = J.blk_tpos + J.c_symoff[c] / 2;
+    const unsigned long long* const tp0 = J.blk_tp + J.c_symoff[c] / 2;
     uint16_t* const out = J.blk_sym + J.c_symoff[c];
     for (uint32_t k = 0; k < lanes; ++k)
         if (J.l_flags[c * GZB_K + k] != 0u) return J.l_flags[c * GZB_K + k] == GZB_F_MORE ? GZB_F_OVERFLOW : J.l_flags[c * GZB_K + k];
     uint32_t k = 0, i = 0, op = 0;
     for (;;) {
-        const uint32_t* const tok = tok0 + k * share;
-        const uint32_t* const pos = pos0 + k * share;
+        const unsigned long long* const tp = tp0 + (size_t)k * share;
         const uint32_t n = J.l_ntok[c * GZB_K + k];
         if (i >= n) return GZB_F_ERROR;                       // the list ran out before it met the next one / an end of block
-        const uint32_t t = tok[i], at = pos[i];
+        const uint32_t t = (uint32_t)tp[i], at = (uint32_t)(tp[i] >> 32);
         if (k + 1 < lanes && at >= J.l_start[c * GZB_K + k + 1]) {
-            const uint32_t* const npos = pos0 + (k + 1) * share;
+            const unsigned long long* const ntp = tp0 + (size_t)(k + 1) * share;
             const uint32_t nn = J.l_ntok[c * GZB_K + k + 1];
-            const uint32_t j = gzb_lower_bound(npos, nn, at);
-            if (j < nn && npos[j] == at) { ++k; i = j; continue; }        // the two reading frames have met: go on in the next list
+            const uint32_t j = gzb_lower_bound_pos(ntp, nn, at);
+            if (j < nn && (uint32_t)(ntp[j] >> 32) == at) { ++k; i = j; continue; }        // the two reading frames have met: go on in the next list
         }
-        if (t == GZB_T_EOB) { end_bit = i + 1 < n ? pos[i + 1] : J.l_p[c * GZB_K + k]; break; }
+        if (t == GZB_T_EOB) { end_bit = i + 1 < n ? (uint32_t)(tp[i + 1] >> 32) : J.l_p[c * GZB_K + k]; break; }
         if (t & GZB_T_JUNK) return GZB_F_ERROR;
         if (t >> 31) {
             if (op + 1u > cap) return GZB_F_OVERFLOW;
@@ -776,18 +785,35 @@ __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_tables_kernel(GzbJob J) {
     J.c_end[c] = 0;
 }
 
-// gzb_decode_kernel: a lane per (candidate, entry point) reads one slice of tokens
+// gzb_decode_kernel: a lane per (candidate, entry point) reads one slice of tokens.  The 64 lanes of a workgroup belong to
+// 64 / GZB_K blocks, whose tables (11 KB each) are copied into LDS first: what a lane waits for per token is then an LDS
+// look-up, not a trip to L2 (1.4 us per token measured with the tables in global memory, the lanes spending their time waiting).
+constexpr int GZB_DEC_BLOCKS = GZB_DEC_THREADS / GZB_K;
 __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
+    __shared__ uint32_t s_tab[GZB_DEC_BLOCKS][GZB_TAB_ENTRIES / 2];
     const uint32_t i = blockIdx.x * (uint32_t)GZB_DEC_THREADS + threadIdx.x;
     const uint32_t c = i / (uint32_t)GZB_K, k = i % (uint32_t)GZB_K;
-    if (c >= J.n_cand[0] || J.l_flags[i] != GZB_F_MORE) return;
+    const bool live = c < J.n_cand[0] && J.l_flags[i] == GZB_F_MORE;
+    if (!__syncthreads_or(live ? 1 : 0)) return;
+    {
+        // GZB_K lanes copy their block's tables, four words at a time (a block none of whose lanes has work left is skipped)
+        const uint32_t b = threadIdx.x / (uint32_t)GZB_K;
+        const bool any = __ballot(live) & (((1ull << GZB_K) - 1ull) << (b * GZB_K));
+        if (any) {
+            const uint4* const src = reinterpret_cast<const uint4*>(J.tables + (size_t)c * GZB_TAB_WORDS);
+            uint4* const dst = reinterpret_cast<uint4*>(s_tab[b]);
+            for (uint32_t w = k; w < (uint32_t)(GZB_TAB_ENTRIES / 8); w += (uint32_t)GZB_K) dst[w] = src[w];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
     const uint32_t lanes = J.c_lanes[c];
-    const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(J.tables + (size_t)c * GZB_TAB_WORDS)};
+    const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(s_tab[threadIdx.x / (uint32_t)GZB_K])};
     const uint32_t share = (J.c_symcap[c] / 2u) / (uint32_t)GZB_K;
     const size_t at = J.c_symoff[c] / 2 + (size_t)k * share;
     uint32_t p = J.l_p[i], nt = J.l_ntok[i];
-    const uint32_t fl = gzb_tokenize(J.comp, J.comp_bytes * 8u, T, J.blk_tok + at, J.blk_tpos + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i],
-                                     J.slice_tokens, lanes != 1u);
+    const uint32_t fl = gzb_tokenize(J.comp, J.comp_bytes * 8u, T, J.blk_tp + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i], J.slice_tokens,
+                                     lanes != 1u);
     J.l_p[i] = p;
     J.l_ntok[i] = nt;
     J.l_flags[i] = fl;
@@ -806,8 +832,7 @@ __global__ __launch_bounds__(64 * GZB_EXP_WAVES) void gzb_expand_kernel(GzbJob J
     if (c >= J.n_cand[0] || J.c_flags[c] != 0u) return;
     const uint32_t lanes = J.c_lanes[c], cap = J.c_symcap[c];
     const uint32_t share = (cap / 2u) / (uint32_t)GZB_K;
-    const uint32_t* const tok0 = J.blk_tok + J.c_symoff[c] / 2;
-    const uint32_t* const pos0 = J.blk_tpos + J.c_symoff[c] / 2;
+    const unsigned long long* const tp0 = J.blk_tp + J.c_symoff[c] / 2;
     uint16_t* const out = J.blk_sym + J.c_symoff[c];
     uint32_t fl = 0;
     for (uint32_t q = 0; q < lanes; ++q) {
@@ -817,23 +842,22 @@ __global__ __launch_bounds__(64 * GZB_EXP_WAVES) void gzb_expand_kernel(GzbJob J
     uint32_t k = 0, i = 0, op = 0, end_bit = 0;
     bool done = false;
     while (!fl && !done) {
-        const uint32_t* const tok = tok0 + k * share;
-        const uint32_t* const pos = pos0 + k * share;
+        const unsigned long long* const tp = tp0 + (size_t)k * share;
         const uint32_t n = J.l_ntok[c * GZB_K + k];
         if (i >= n) { fl = GZB_F_ERROR; break; }              // the list ran out before it met the next one / an end of block
         const bool have = i + (uint32_t)lane < n;
-        const uint32_t t = have ? tok[i + (uint32_t)lane] : GZB_T_JUNK;
-        const uint32_t at = have ? pos[i + (uint32_t)lane] : 0u;
+        const unsigned long long e = have ? tp[i + (uint32_t)lane] : (unsigned long long)GZB_T_JUNK;
+        const uint32_t t = (uint32_t)e, at = (uint32_t)(e >> 32);
         // does the next lane's list have a token at this very bit?
         uint32_t jn = GZB_NONE;
         if (k + 1 < lanes) {
             const uint32_t nstart = J.l_start[c * GZB_K + k + 1];
             if (__ballot(have && at >= nstart)) {
-                const uint32_t* const npos = pos0 + (k + 1) * share;
+                const unsigned long long* const ntp = tp0 + (size_t)(k + 1) * share;
                 const uint32_t nn = J.l_ntok[c * GZB_K + k + 1];
                 if (have && at >= nstart) {
-                    const uint32_t j = gzb_lower_bound(npos, nn, at);
-                    if (j < nn && npos[j] == at) jn = j;
+                    const uint32_t j = gzb_lower_bound_pos(ntp, nn, at);
+                    if (j < nn && (uint32_t)(ntp[j] >> 32) == at) jn = j;
                 }
             }
         }
@@ -880,7 +904,7 @@ __global__ __launch_bounds__(64 * GZB_EXP_WAVES) void gzb_expand_kernel(GzbJob J
             ++k;
         } else if ((m_eob >> cut) & 1ull) {
             const uint32_t ci = i + (uint32_t)cut;
-            end_bit = ci + 1u < n ? pos[ci + 1u] : J.l_p[c * GZB_K + k];
+            end_bit = ci + 1u < n ? (uint32_t)(tp[ci + 1u] >> 32) : J.l_p[c * GZB_K + k];
             done = true;
         } else fl = GZB_F_ERROR;
     }

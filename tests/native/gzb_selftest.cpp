@@ -61,8 +61,9 @@ struct CpuOffload : aqcgz::SectionOffload {
         J.blk_sym_cap = (uint64_t)span * ratio_cap + (uint64_t)J.cand_cap * 4104;
         std::vector<uint16_t> blk_sym(J.blk_sym_cap + 64);
         J.blk_sym = blk_sym.data();
-        std::vector<uint32_t> blk_tok(J.blk_sym_cap / 2 + 64), blk_tpos(J.blk_sym_cap / 2 + 64), c_lanes(J.cand_cap), l_u32((size_t)5 * J.cand_cap * GZB_K);
-        J.blk_tok = blk_tok.data(); J.blk_tpos = blk_tpos.data(); J.c_lanes = c_lanes.data();
+        std::vector<unsigned long long> blk_tp(J.blk_sym_cap / 2 + 64);
+        std::vector<uint32_t> c_lanes(J.cand_cap), l_u32((size_t)5 * J.cand_cap * GZB_K);
+        J.blk_tp = blk_tp.data(); J.c_lanes = c_lanes.data();
         J.l_p = l_u32.data(); J.l_stop = J.l_p + (size_t)J.cand_cap * GZB_K; J.l_start = J.l_stop + (size_t)J.cand_cap * GZB_K;
         J.l_ntok = J.l_start + (size_t)J.cand_cap * GZB_K; J.l_flags = J.l_ntok + (size_t)J.cand_cap * GZB_K;
         std::vector<uint32_t> tables((size_t)J.cand_cap * GZB_TAB_WORDS);
@@ -150,7 +151,7 @@ struct CpuOffload : aqcgz::SectionOffload {
                 const uint32_t share = (c_symcap[c] / 2u) / (uint32_t)GZB_K;
                 const size_t at = c_symoff[c] / 2 + (size_t)k * share;
                 uint32_t p = J.l_p[i], nt = J.l_ntok[i];
-                J.l_flags[i] = gzb_tokenize(J.comp, limit_bit, T, J.blk_tok + at, J.blk_tpos + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i],
+                J.l_flags[i] = gzb_tokenize(J.comp, limit_bit, T, J.blk_tp + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i],
                                             slice_tokens, lanes != 1u);
                 J.l_p[i] = p; J.l_ntok[i] = nt;
             }
