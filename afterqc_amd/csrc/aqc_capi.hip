@@ -1244,7 +1244,7 @@ private:
         for (int k = 0; k < n; ++k) sec_max = std::max<uint64_t>(sec_max, (G.stop[k] - G.nominal[k]) >> 3);
         const uint32_t s_symcap = (uint32_t)std::min<uint64_t>((sec_max * 24 + (2u << 20) + 7) & ~(uint64_t)7, 0xfffffff0u);
         const uint64_t s_sym_total = (uint64_t)span * 12 + (uint64_t)n * 64 + (1u << 20);
-        const uint64_t blk_sym_cap = (uint64_t)span * GZB_RATIO_CAP + (uint64_t)cand_cap * 4104;
+        const uint64_t blk_sym_cap = gzb_sym_budget(span, GZB_RATIO_CAP);
         if (L.comp.reserve(span + 256) || L.tile_cnt.reserve(4ull * n_tiles) || L.tile_cand.reserve(4ull * n_tiles * GZB_TILE_CAND) || L.n_cand.reserve(64) ||
             L.c_start.reserve(4ull * cand_cap) || L.c_end.reserve(4ull * cand_cap) || L.c_nsym.reserve(4ull * cand_cap) || L.c_flags.reserve(4ull * cand_cap) ||
             L.c_symoff.reserve(8ull * cand_cap) || L.c_symcap.reserve(4ull * cand_cap) || L.blk_sym.reserve(2ull * blk_sym_cap + 64) ||
@@ -1292,7 +1292,7 @@ private:
         J.l_p = (uint32_t*)L.l_u32.p; J.l_stop = J.l_p + (size_t)cand_cap * GZB_K; J.l_start = J.l_stop + (size_t)cand_cap * GZB_K;
         J.l_ntok = J.l_start + (size_t)cand_cap * GZB_K; J.l_flags = J.l_ntok + (size_t)cand_cap * GZB_K;
         {
-            static const uint32_t slice = [] { const char* e = getenv("AQC_GZ_SLICE"); return e ? (uint32_t)std::max(16, atoi(e)) : 640u; }();
+            static const uint32_t slice = [] { const char* e = getenv("AQC_GZ_SLICE"); return e ? (uint32_t)std::max(16, atoi(e)) : 1024u; }();
             J.slice_tokens = slice;
         }
         J.n_sec = (uint32_t)n; J.s_nominal = (const uint32_t*)L.s_in.p; J.s_stop = J.s_nominal + n; J.s_exact = J.s_nominal + 2 * n;
@@ -1302,7 +1302,7 @@ private:
         hipLaunchKernelGGL(gzb_scan_kernel, dim3(n_tiles), dim3(GZB_SCAN_THREADS), 0, L.stream, J);
         hipLaunchKernelGGL(gzb_compact_kernel, dim3(1), dim3(1024), 0, L.stream, J);
         GZB_TRY(hipEventRecord(L.ev[2], L.stream));
-        // the decoder in slices (aqc_gunzip_dev.hpp): GZB_K lanes per block, each with its share of it and the overlap: 16 x 640
+        // the decoder in slices (aqc_gunzip_dev.hpp): GZB_K lanes per block, each with its share of it and the overlap: 16 x 1024
         // tokens cover the blocks of zlib (<= 16 K tokens) and of GNU gzip (<= 32 K) with room to spare; a lane that needs more
         // stays unfinished, its block counts as failed, the section ends before it and the host goes on from there
         {

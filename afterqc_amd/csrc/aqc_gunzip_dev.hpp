@@ -74,6 +74,9 @@ constexpr int GZB_SCAN_THREADS = 256, GZB_SCAN_TILE = GZB_SCAN_THREADS * 16, GZB
 constexpr int GZB_DEC_THREADS = 64;
 constexpr int GZB_K = 16;                          // lanes per block (entry points guessed inside it, see gzb_decode_kernel)
 constexpr uint32_t GZB_OVERLAP_BITS = 8192;        // how far a lane reads into its successor's share to meet its token list
+constexpr int GZB_STAGE = 8;
+constexpr uint32_t GZB_PLAIN_BITS = 8192;           // a block shorter than this is read by one lane
+constexpr uint32_t GZB_CAND_EXTRA = 4104u + (uint32_t)GZB_K * GZB_OVERLAP_BITS;       // symbol space per candidate beyond ratio_cap x its bytes
 constexpr uint32_t GZB_T_EOB = 0x40000000u, GZB_T_JUNK = 0x20000000u;
 constexpr int GZB_SEC_BLOCKS = 4096;                // chain entries per section (3 words each)
 constexpr int GZB_GATHER_THREADS = 1024;
@@ -374,17 +377,29 @@ GZB_HD inline unsigned long long gzb_load64(const uint8_t* p) {
 // to stop_bit, some way into its successor's share; gzb_stitch picks, per lane, the tokens from the first bit position it SHARES
 // with its predecessor's list — a check, not a guess.  A plain lane (spec == false) stops behind the end-of-block code.
 // Returns 0 done, GZB_F_MORE (max_tokens written: call again with the same p / nt), GZB_F_OVERFLOW, GZB_F_ERROR (plain only).
+//
+// The tokens go through `stage` (GZB_STAGE entries of this lane, element j at [j * SS]: a column of an LDS array on the device)
+// and are written out GZB_STAGE at a time.  gfx9 counts loads and stores with ONE counter: a lane that stores a token per step
+// waits, at its next look at the stream, for the store's acknowledgement — 0.8 us per token measured, with the tables already
+// in LDS.  Every step emits exactly one token, so the lanes of a wave fill their columns in step and flush together.
 template <int S>
-GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, const GzbLaneTab<S>& T, unsigned long long* tp, uint32_t tok_cap,
-                                    uint32_t& p, uint32_t& nt, uint32_t stop_bit, uint32_t max_tokens, bool spec) {
-    uint32_t fl = 0, tokens = 0;
+GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, const GzbLaneTab<S>& T, unsigned long long* tp, uint32_t tok_cap, uint32_t& p, uint32_t& nt,
+                                    uint32_t stop_bit, uint32_t max_tokens, bool spec, unsigned long long* stage, int SS) {
+    uint32_t fl = 0, tokens = 0, ns = 0;       // ns: tokens emitted by this call (nt + ns % GZB_STAGE exist; the last ns % GZB_STAGE are staged)
     const uint8_t* const end = comp + (limit_bit >> 3);      // (limit_bit is a multiple of 8; the buffer is padded for 64 bytes behind)
     const uint8_t* ip = comp + (p >> 3);
     unsigned long long bb = gzb_load64(ip) >> (p & 7u);
     uint32_t bn = 64u - (p & 7u);                             // valid bits in bb
     ip += 8;
     unsigned long long nx = gzb_load64(ip);                   // the eight bytes at ip, on their way
-#define GZB_TP(at_, t_) (((unsigned long long)(at_) << 32) | (unsigned long long)(t_))
+#define GZB_EMIT(at_, t_)                                                                          \
+    do {                                                                                           \
+        stage[(int)(ns & (uint32_t)(GZB_STAGE - 1)) * SS] = ((unsigned long long)(at_) << 32) | (unsigned long long)(t_); \
+        if ((++ns & (uint32_t)(GZB_STAGE - 1)) == 0u) {                                            \
+            for (int j_ = 0; j_ < GZB_STAGE; ++j_) tp[nt + (uint32_t)j_] = stage[j_ * SS];         \
+            nt += (uint32_t)GZB_STAGE;                                                             \
+        }                                                                                          \
+    } while (0)
 #define GZB_REFILL()                                                                       \
     do {                                                                                   \
         bb |= nx << bn;                                                                    \
@@ -397,7 +412,7 @@ GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, con
         if (ip > end) { fl = spec ? 0u : GZB_F_ERROR; break; }
         const uint32_t at = (uint32_t)((ip - comp) << 3) - bn;       // the bit this token starts at
         if (at >= stop_bit) break;
-        if (nt >= tok_cap) { fl = GZB_F_OVERFLOW; break; }
+        if (nt + (uint32_t)GZB_STAGE > tok_cap) { fl = GZB_F_OVERFLOW; break; }
         if (tokens++ >= max_tokens) { fl = GZB_F_MORE; break; }
         if (bn < 32u) GZB_REFILL();                           // >= 56 bits now; a literal/length code + its extra bits take <= 20
         uint32_t e = T.at((int)((uint32_t)bb & ((1u << GZB_LROOT) - 1u)));
@@ -405,15 +420,15 @@ GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, con
         if (!e || (e & 0x40u)) {                              // no such code / a symbol that does not exist
             if (!spec) { fl = GZB_F_ERROR; break; }
             bb >>= 1; bn -= 1;
-            tp[nt++] = GZB_TP(at, GZB_T_JUNK);
+            GZB_EMIT(at, GZB_T_JUNK);
             continue;
         }
         const uint32_t l = e & 15u;
         bb >>= l;
         bn -= l;
-        if (e & 0x10u) { tp[nt++] = GZB_TP(at, 0x80000000u | (e >> 8)); continue; }
+        if (e & 0x10u) { GZB_EMIT(at, 0x80000000u | (e >> 8)); continue; }
         if (e & 0x20u) {                                      // end of block
-            tp[nt++] = GZB_TP(at, GZB_T_EOB);
+            GZB_EMIT(at, GZB_T_EOB);
             if (spec) continue;
             break;
         }
@@ -427,7 +442,7 @@ GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, con
         if ((de & 15u) == 0u) de = gzb_slow<false, S>(bb, T);
         if (!de || (de & 0x8000u)) {
             if (!spec) { fl = GZB_F_ERROR; break; }
-            tp[nt++] = GZB_TP(at, GZB_T_JUNK);            // (the length code's bits are gone: any rule will do before the frames meet)
+            GZB_EMIT(at, GZB_T_JUNK);            // (the length code's bits are gone: any rule will do before the frames meet)
             continue;
         }
         const uint32_t dl = de & 15u, ds = (de >> 4) & 31u;
@@ -436,10 +451,12 @@ GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, con
         const uint32_t dd = gzb_dist_base(ds) + ((uint32_t)bb & ((1u << dxb) - 1u));
         bb >>= dxb;
         bn -= dl + dxb;
-        tp[nt++] = GZB_TP(at, (len << 16) | (dd - 1u));
+        GZB_EMIT(at, (len << 16) | (dd - 1u));
     }
 #undef GZB_REFILL
-#undef GZB_TP
+#undef GZB_EMIT
+    for (uint32_t j = 0; j < (ns & (uint32_t)(GZB_STAGE - 1)); ++j) tp[nt + j] = stage[(int)j * SS];        // (room for these was checked)
+    nt += ns & (uint32_t)(GZB_STAGE - 1);
     // the bit behind the last consumed one: ip points 8 bytes behind the word whose unconsumed bits are the top of bb
     p = (uint32_t)((ip - comp) << 3) - bn;
     return fl;
@@ -453,7 +470,7 @@ GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, con
 GZB_HD inline void gzb_plan_lanes(const GzbJob& J, uint32_t c, uint32_t n, uint32_t data_bit) {
     const uint32_t limit = J.comp_bytes * 8u;
     const uint32_t est_end = c + 1 < n ? J.c_start[c + 1] : limit;
-    const bool plain = est_end <= data_bit || est_end - data_bit < (uint32_t)GZB_K * 4096u;
+    const bool plain = est_end <= data_bit || est_end - data_bit < GZB_PLAIN_BITS;
     J.c_lanes[c] = plain ? 1u : (uint32_t)GZB_K;
     for (uint32_t k = 0; k < (uint32_t)GZB_K; ++k) {
         const uint32_t i = c * (uint32_t)GZB_K + k;
@@ -512,11 +529,14 @@ GZB_HD inline uint32_t gzb_stitch_expand(const GzbJob& J, uint32_t c, uint32_t& 
     return 0;
 }
 
-// symbol space of candidate c of n: ratio_cap x the compressed bytes up to the next candidate (the last one: to the window's end)
+// symbol space of candidate c of n: ratio_cap x the compressed bytes up to the next candidate (the last one: to the window's end),
+// and what its lanes' overlaps need: the tokens live in half as many 64-bit entries, a lane's share of them must hold the
+// tokens of its share of the block AND of GZB_OVERLAP_BITS more (two bits a token are assumed; less: overflow, the host's)
+GZB_HD inline uint64_t gzb_sym_budget(uint64_t span, uint32_t ratio_cap) { return span * ratio_cap + (span / 16384u + 32u) * (uint64_t)GZB_CAND_EXTRA; }
 GZB_HD inline uint32_t gzb_symcap_of(const GzbJob& J, uint32_t c, uint32_t n) {
     const uint32_t nxt = c + 1 < n ? J.c_start[c + 1] : J.comp_bytes * 8u;
     const uint32_t span = gzb_min((nxt - J.c_start[c] + 7u) >> 3, 2u << 20);        // (a block of more than 2 MiB: overflow, host)
-    return ((span * J.ratio_cap + 4096u) + 7u) & ~7u;
+    return ((span * J.ratio_cap + GZB_CAND_EXTRA - 8u) + 7u) & ~7u;
 }
 
 // the usable candidate that starts exactly at bit x (GZB_NONE: none)
@@ -791,6 +811,7 @@ __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_tables_kernel(GzbJob J) {
 constexpr int GZB_DEC_BLOCKS = GZB_DEC_THREADS / GZB_K;
 __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
     __shared__ uint32_t s_tab[GZB_DEC_BLOCKS][GZB_TAB_ENTRIES / 2];
+    __shared__ unsigned long long s_stage[GZB_STAGE * GZB_DEC_THREADS];
     const uint32_t i = blockIdx.x * (uint32_t)GZB_DEC_THREADS + threadIdx.x;
     const uint32_t c = i / (uint32_t)GZB_K, k = i % (uint32_t)GZB_K;
     const bool live = c < J.n_cand[0] && J.l_flags[i] == GZB_F_MORE;
@@ -813,7 +834,7 @@ __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
     const size_t at = J.c_symoff[c] / 2 + (size_t)k * share;
     uint32_t p = J.l_p[i], nt = J.l_ntok[i];
     const uint32_t fl = gzb_tokenize(J.comp, J.comp_bytes * 8u, T, J.blk_tp + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i], J.slice_tokens,
-                                     lanes != 1u);
+                                     lanes != 1u, s_stage + threadIdx.x, GZB_DEC_THREADS);
     J.l_p[i] = p;
     J.l_ntok[i] = nt;
     J.l_flags[i] = fl;

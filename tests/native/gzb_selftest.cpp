@@ -17,6 +17,7 @@
 #include <random>
 #include <string>
 #include <thread>
+#include <memory>
 #include <vector>
 
 #include "../../afterqc_amd/csrc/aqc_gunzip_dev.hpp"
@@ -58,12 +59,12 @@ struct CpuOffload : aqcgz::SectionOffload {
         std::vector<uint64_t> c_symoff(J.cand_cap);
         J.tile_cnt = tile_cnt.data(); J.tile_cand = tile_cand.data(); J.n_cand = n_cand.data(); J.c_start = c_start.data(); J.c_end = c_end.data();
         J.c_nsym = c_nsym.data(); J.c_flags = c_flags.data(); J.c_symcap = c_symcap.data(); J.c_symoff = c_symoff.data();
-        J.blk_sym_cap = (uint64_t)span * ratio_cap + (uint64_t)J.cand_cap * 4104;
-        std::vector<uint16_t> blk_sym(J.blk_sym_cap + 64);
-        J.blk_sym = blk_sym.data();
-        std::vector<unsigned long long> blk_tp(J.blk_sym_cap / 2 + 64);
+        J.blk_sym_cap = gzb_sym_budget(span, ratio_cap);
+        std::unique_ptr<uint16_t[]> blk_sym(new uint16_t[J.blk_sym_cap + 64]);
+        J.blk_sym = blk_sym.get();
+        std::unique_ptr<unsigned long long[]> blk_tp(new unsigned long long[J.blk_sym_cap / 2 + 64]);
         std::vector<uint32_t> c_lanes(J.cand_cap), l_u32((size_t)5 * J.cand_cap * GZB_K);
-        J.blk_tp = blk_tp.data(); J.c_lanes = c_lanes.data();
+        J.blk_tp = blk_tp.get(); J.c_lanes = c_lanes.data();
         J.l_p = l_u32.data(); J.l_stop = J.l_p + (size_t)J.cand_cap * GZB_K; J.l_start = J.l_stop + (size_t)J.cand_cap * GZB_K;
         J.l_ntok = J.l_start + (size_t)J.cand_cap * GZB_K; J.l_flags = J.l_ntok + (size_t)J.cand_cap * GZB_K;
         std::vector<uint32_t> tables((size_t)J.cand_cap * GZB_TAB_WORDS);
@@ -123,6 +124,7 @@ struct CpuOffload : aqcgz::SectionOffload {
         }
         // ---- decode: tables per candidate, then GZB_K lanes per candidate in slices, then the stitch
         std::vector<uint32_t> cnt(16), nxt(16), off(16);
+        unsigned long long stage[GZB_STAGE];
         for (uint32_t c = 0; c < nc; ++c) {
             uint32_t* const tw = J.tables + (size_t)c * GZB_TAB_WORDS;
             const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(tw)};
@@ -152,7 +154,7 @@ struct CpuOffload : aqcgz::SectionOffload {
                 const size_t at = c_symoff[c] / 2 + (size_t)k * share;
                 uint32_t p = J.l_p[i], nt = J.l_ntok[i];
                 J.l_flags[i] = gzb_tokenize(J.comp, limit_bit, T, J.blk_tp + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i],
-                                            slice_tokens, lanes != 1u);
+                                            slice_tokens, lanes != 1u, stage, 1);
                 J.l_p[i] = p; J.l_ntok[i] = nt;
             }
         for (uint32_t c = 0; c < nc; ++c) {
@@ -249,13 +251,13 @@ std::vector<uint8_t> gz_of(const std::vector<uint8_t>& text, int level, int stra
 }
 
 int failures = 0;
-uint32_t g_max_slices = 1u << 20;      // (a case may cut the decoder off: unfinished blocks then go to the host)
+uint32_t g_max_slices = 1u << 20, g_slice_tokens = 300;      // (a case may cut the decoder off: unfinished blocks then go to the host)
 
 // decode gz through ParallelGunzip with the CPU emulation of the device as its offloader; returns the offloader's counters
 bool run_case(const char* what, const std::vector<uint8_t>& gz, const std::vector<uint8_t>& text, size_t section, size_t group, int threads, bool want_device,
               uint32_t ratio_cap = 20, uint32_t cand_div = 4096, bool expect_fail = false, bool hybrid = false) {
     CpuOffload off(group);
-    off.ratio_cap = ratio_cap; off.cand_div = cand_div; off.max_slices = g_max_slices;
+    off.ratio_cap = ratio_cap; off.cand_div = cand_div; off.max_slices = g_max_slices; off.slice_tokens = g_slice_tokens;
     aqc_host::Pool pool(threads);
     std::vector<uint8_t> out(text.size() + 65536);
     size_t produced = 0;
@@ -287,7 +289,25 @@ bool run_case(const char* what, const std::vector<uint8_t>& gz, const std::vecto
 
 }  // namespace
 
-int main() {
+// gzb_selftest FILE.gz TEXT [section [group [ratio_cap]]]: one single-member file through the emulation with the kernels' own slice budget
+static std::vector<uint8_t> slurp(const char* path) {
+    std::vector<uint8_t> v;
+    FILE* f = fopen(path, "rb");
+    if (!f) return v;
+    uint8_t buf[65536];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof(buf), f)) > 0) v.insert(v.end(), buf, buf + k);
+    fclose(f);
+    return v;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 2) {
+        const std::vector<uint8_t> gz = slurp(argv[1]), text = slurp(argv[2]);
+        g_max_slices = 16; g_slice_tokens = 1024;
+        const bool ok = run_case(argv[1], gz, text, argc > 3 ? (size_t)atol(argv[3]) : 65536, argc > 4 ? (size_t)atol(argv[4]) : 1 << 20, 4, true, argc > 5 ? (uint32_t)atoi(argv[5]) : 12);
+        return ok ? 0 : 1;
+    }
     const std::vector<uint8_t> fq = fastq_like(14000, 3);        // ~4.9 MB
     // dynamic-Huffman streams of every level: the device must supply sections
     for (int level : {1, 2, 4, 6, 9}) {
