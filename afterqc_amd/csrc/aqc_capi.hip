@@ -1245,7 +1245,7 @@ private:
         const uint32_t s_symcap = (uint32_t)std::min<uint64_t>((sec_max * 24 + (2u << 20) + 7) & ~(uint64_t)7, 0xfffffff0u);
         const uint64_t s_sym_total = (uint64_t)span * 12 + (uint64_t)n * 64 + (1u << 20);
         const uint64_t blk_sym_cap = gzb_sym_budget(span, GZB_RATIO_CAP);
-        if (L.comp.reserve(span + 256) || L.tile_cnt.reserve(4ull * n_tiles) || L.tile_cand.reserve(4ull * n_tiles * GZB_TILE_CAND) || L.n_cand.reserve(64) ||
+        if (L.comp.reserve(span + 512) || L.tile_cnt.reserve(4ull * n_tiles) || L.tile_cand.reserve(4ull * n_tiles * GZB_TILE_CAND) || L.n_cand.reserve(64) ||
             L.c_start.reserve(4ull * cand_cap) || L.c_end.reserve(4ull * cand_cap) || L.c_nsym.reserve(4ull * cand_cap) || L.c_flags.reserve(4ull * cand_cap) ||
             L.c_symoff.reserve(8ull * cand_cap) || L.c_symcap.reserve(4ull * cand_cap) || L.blk_sym.reserve(2ull * blk_sym_cap + 64) ||
             L.blk_tp.reserve(4ull * blk_sym_cap + 512) || L.c_lanes.reserve(4ull * cand_cap) ||
@@ -1279,7 +1279,7 @@ private:
         }
         GZB_TRY(hipEventRecord(L.ev[0], L.stream));
         GZB_TRY(hipMemcpyAsync(L.comp.p, L.stage, span, hipMemcpyHostToDevice, L.stream));
-        GZB_TRY(hipMemsetAsync((uint8_t*)L.comp.p + span, 0, 256, L.stream));
+        GZB_TRY(hipMemsetAsync((uint8_t*)L.comp.p + span, 0, 512, L.stream));       // (the lanes' stream windows read up to 200 bytes ahead)
         GZB_TRY(hipMemcpyAsync(L.s_in.p, sin.data(), 12ull * n, hipMemcpyHostToDevice, L.stream));
         GzbJob J{};
         J.comp = (const uint8_t*)L.comp.p; J.comp_bytes = (uint32_t)span; J.scan_byte0 = 0; J.first_bit = first_bit; J.last_bit = last_bit;

@@ -61,7 +61,7 @@ GZB_HD inline uint32_t gzb_rev(uint32_t c, uint32_t len) {
 }
 
 constexpr uint32_t GZB_MARKER = 0x8000u;
-constexpr int GZB_LROOT = 12, GZB_DROOT = 10;
+constexpr int GZB_LROOT = 11, GZB_DROOT = 10;
 // A lane's decoding tables, 16-bit entries: literal/length root (2^12), distance root (2^10), symbols sorted by code (288 + 32),
 // codes per length (16 + 16), in the candidate's own 11 KiB of global memory (with its 320 code lengths behind them).  Roots this
 // wide make a code longer than the root — the canonical search, a dozen dependent loads — a rarity: with 9 bits SOME lane of a
@@ -74,7 +74,6 @@ constexpr int GZB_SCAN_THREADS = 256, GZB_SCAN_TILE = GZB_SCAN_THREADS * 16, GZB
 constexpr int GZB_DEC_THREADS = 64;
 constexpr int GZB_K = 16;                          // lanes per block (entry points guessed inside it, see gzb_decode_kernel)
 constexpr uint32_t GZB_OVERLAP_BITS = 8192;        // how far a lane reads into its successor's share to meet its token list
-constexpr int GZB_STAGE = 8;
 constexpr uint32_t GZB_PLAIN_BITS = 8192;           // a block shorter than this is read by one lane
 constexpr uint32_t GZB_CAND_EXTRA = 4104u + (uint32_t)GZB_K * GZB_OVERLAP_BITS;       // symbol space per candidate beyond ratio_cap x its bytes
 constexpr uint32_t GZB_T_EOB = 0x40000000u, GZB_T_JUNK = 0x20000000u;
@@ -378,43 +377,46 @@ GZB_HD inline unsigned long long gzb_load64(const uint8_t* p) {
 // with its predecessor's list — a check, not a guess.  A plain lane (spec == false) stops behind the end-of-block code.
 // Returns 0 done, GZB_F_MORE (max_tokens written: call again with the same p / nt), GZB_F_OVERFLOW, GZB_F_ERROR (plain only).
 //
-// The tokens go through `stage` (GZB_STAGE entries of this lane, element j at [j * SS]: a column of an LDS array on the device)
-// and are written out GZB_STAGE at a time.  gfx9 counts loads and stores with ONE counter: a lane that stores a token per step
-// waits, at its next look at the stream, for the store's acknowledgement — 0.8 us per token measured, with the tables already
-// in LDS.  Every step emits exactly one token, so the lanes of a wave fill their columns in step and flush together.
-template <int S>
-GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, const GzbLaneTab<S>& T, unsigned long long* tp, uint32_t tok_cap, uint32_t& p, uint32_t& nt,
-                                    uint32_t stop_bit, uint32_t max_tokens, bool spec, unsigned long long* stage, int SS) {
-    uint32_t fl = 0, tokens = 0, ns = 0;       // ns: tokens emitted by this call (nt + ns % GZB_STAGE exist; the last ns % GZB_STAGE are staged)
-    const uint8_t* const end = comp + (limit_bit >> 3);      // (limit_bit is a multiple of 8; the buffer is padded for 64 bytes behind)
-    const uint8_t* ip = comp + (p >> 3);
-    unsigned long long bb = gzb_load64(ip) >> (p & 7u);
-    uint32_t bn = 64u - (p & 7u);                             // valid bits in bb
-    ip += 8;
-    unsigned long long nx = gzb_load64(ip);                   // the eight bytes at ip, on their way
-#define GZB_EMIT(at_, t_)                                                                          \
-    do {                                                                                           \
-        stage[(int)(ns & (uint32_t)(GZB_STAGE - 1)) * SS] = ((unsigned long long)(at_) << 32) | (unsigned long long)(t_); \
-        if ((++ns & (uint32_t)(GZB_STAGE - 1)) == 0u) {                                            \
-            for (int j_ = 0; j_ < GZB_STAGE; ++j_) tp[nt + (uint32_t)j_] = stage[j_ * SS];         \
-            nt += (uint32_t)GZB_STAGE;                                                             \
-        }                                                                                          \
-    } while (0)
-#define GZB_REFILL()                                                                       \
-    do {                                                                                   \
-        bb |= nx << bn;                                                                    \
-        const uint32_t adv_ = (63u - bn) >> 3;                                             \
-        ip += adv_;                                                                        \
-        bn += adv_ << 3;                                                                   \
-        nx = gzb_load64(ip);                                                               \
+// The stream is read 32 bits at a time through `in`: the host reads memory; a device lane reads an LDS window of 128 bytes of
+// its stretch that it fills 64 bytes at a time, the next 64 already on their way in registers (GzbInLds).  The first device
+// version read the stream eight bytes at a time from global memory with one read in flight: of a wave's 64 lanes, each on
+// its own cache lines, a few are always about to touch a new line, so nearly every refill waited for HBM — 0.8 us per token.
+struct GzbInMem {
+    const uint8_t* comp;
+    uint32_t wi;                 // the next word to hand out
+    GZB_HD void start(uint32_t word) { wi = word; }
+    GZB_HD uint32_t next() {
+        uint32_t v;
+        memcpy(&v, comp + 4ull * wi, 4);
+        ++wi;
+        return v;
+    }
+};
+
+template <int S, class In>
+GZB_HD inline uint32_t gzb_tokenize(In& in, uint32_t limit_bit, const GzbLaneTab<S>& T, unsigned long long* tp, uint32_t tok_cap, uint32_t& p, uint32_t& nt,
+                                    uint32_t stop_bit, uint32_t max_tokens, bool spec) {
+    uint32_t fl = 0, tokens = 0;
+    in.start(p >> 5);
+    unsigned long long bb = in.next();
+    bb |= (unsigned long long)in.next() << 32;
+    bb >>= p & 31u;
+    uint32_t bn = 64u - (p & 31u);                            // valid bits in bb; the next unread bit of the stream is in.wi * 32
+#define GZB_EMIT(at_, t_) (tp[nt++] = ((unsigned long long)(at_) << 32) | (unsigned long long)(t_))
+#define GZB_REFILL()                                                 \
+    do {                                                             \
+        if (bn <= 32u) {                                             \
+            bb |= (unsigned long long)in.next() << bn;               \
+            bn += 32u;                                               \
+        }                                                            \
     } while (0)
     for (;;) {
-        if (ip > end) { fl = spec ? 0u : GZB_F_ERROR; break; }
-        const uint32_t at = (uint32_t)((ip - comp) << 3) - bn;       // the bit this token starts at
+        const uint32_t at = in.wi * 32u - bn;                 // the bit this token starts at
+        if (at + 64u > limit_bit) { fl = spec ? 0u : GZB_F_ERROR; break; }      // (the buffer is padded: reading on is harmless, but nothing ends there)
         if (at >= stop_bit) break;
-        if (nt + (uint32_t)GZB_STAGE > tok_cap) { fl = GZB_F_OVERFLOW; break; }
+        if (nt >= tok_cap) { fl = GZB_F_OVERFLOW; break; }
         if (tokens++ >= max_tokens) { fl = GZB_F_MORE; break; }
-        if (bn < 32u) GZB_REFILL();                           // >= 56 bits now; a literal/length code + its extra bits take <= 20
+        GZB_REFILL();                                         // > 32 bits now; a literal/length code + its extra bits take <= 20
         uint32_t e = T.at((int)((uint32_t)bb & ((1u << GZB_LROOT) - 1u)));
         if ((e & 15u) == 0u) e = gzb_slow<true, S>(bb, T);
         if (!e || (e & 0x40u)) {                              // no such code / a symbol that does not exist
@@ -437,7 +439,7 @@ GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, con
         const uint32_t len = gzb_len_base(ls) + ((uint32_t)bb & ((1u << xb) - 1u));
         bb >>= xb;
         bn -= xb;
-        if (bn < 32u) GZB_REFILL();                           // a distance code + its extra bits take <= 28
+        GZB_REFILL();                                         // a distance code + its extra bits take <= 28
         uint32_t de = T.at(GZB_E_DIST + (int)((uint32_t)bb & ((1u << GZB_DROOT) - 1u)));
         if ((de & 15u) == 0u) de = gzb_slow<false, S>(bb, T);
         if (!de || (de & 0x8000u)) {
@@ -455,10 +457,7 @@ GZB_HD inline uint32_t gzb_tokenize(const uint8_t* comp, uint32_t limit_bit, con
     }
 #undef GZB_REFILL
 #undef GZB_EMIT
-    for (uint32_t j = 0; j < (ns & (uint32_t)(GZB_STAGE - 1)); ++j) tp[nt + j] = stage[(int)j * SS];        // (room for these was checked)
-    nt += ns & (uint32_t)(GZB_STAGE - 1);
-    // the bit behind the last consumed one: ip points 8 bytes behind the word whose unconsumed bits are the top of bb
-    p = (uint32_t)((ip - comp) << 3) - bn;
+    p = in.wi * 32u - bn;                                     // the first bit not consumed
     return fl;
 }
 
@@ -809,9 +808,50 @@ __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_tables_kernel(GzbJob J) {
 // 64 / GZB_K blocks, whose tables (11 KB each) are copied into LDS first: what a lane waits for per token is then an LDS
 // look-up, not a trip to L2 (1.4 us per token measured with the tables in global memory, the lanes spending their time waiting).
 constexpr int GZB_DEC_BLOCKS = GZB_DEC_THREADS / GZB_K;
+// A lane's window of the stream: 32 words in a column of an LDS array (word j at [(j % 32) * GZB_DEC_THREADS]), two halves of 64
+// bytes; when the lane steps from one half into the other the half it left is filled from `pend` — 64 bytes asked for when
+// the lane entered that half, two to three microseconds ago — and the 64 bytes behind those are asked for.
+struct GzbInLds {
+    const uint4* comp16;
+    uint32_t* ring;
+    uint4 pend[4];
+    uint32_t wi;
+    __device__ void start(uint32_t word) {
+        wi = word;
+        const uint32_t base = word & ~15u;
+        uint4 a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = comp16[(base >> 2) + (uint32_t)j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pend[j] = comp16[(base >> 2) + 8u + (uint32_t)j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t w = (base + 4u * (uint32_t)j) & 31u;
+            ring[(w + 0u) * GZB_DEC_THREADS] = a[j].x; ring[(w + 1u) * GZB_DEC_THREADS] = a[j].y;
+            ring[(w + 2u) * GZB_DEC_THREADS] = a[j].z; ring[(w + 3u) * GZB_DEC_THREADS] = a[j].w;
+        }
+    }
+    __device__ uint32_t next() {
+        const uint32_t v = ring[(wi & 31u) * GZB_DEC_THREADS];
+        ++wi;
+        if ((wi & 15u) == 0u) {
+            const uint32_t h = (wi + 16u) & 16u;          // the half just left = the half of words [wi + 16, wi + 32)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t w = h + 4u * (uint32_t)j;
+                ring[(w + 0u) * GZB_DEC_THREADS] = pend[j].x; ring[(w + 1u) * GZB_DEC_THREADS] = pend[j].y;
+                ring[(w + 2u) * GZB_DEC_THREADS] = pend[j].z; ring[(w + 3u) * GZB_DEC_THREADS] = pend[j].w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pend[j] = comp16[((wi + 32u) >> 2) + (uint32_t)j];
+        }
+        return v;
+    }
+};
+
 __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
     __shared__ uint32_t s_tab[GZB_DEC_BLOCKS][GZB_TAB_ENTRIES / 2];
-    __shared__ unsigned long long s_stage[GZB_STAGE * GZB_DEC_THREADS];
+    __shared__ uint32_t s_ring[32 * GZB_DEC_THREADS];
     const uint32_t i = blockIdx.x * (uint32_t)GZB_DEC_THREADS + threadIdx.x;
     const uint32_t c = i / (uint32_t)GZB_K, k = i % (uint32_t)GZB_K;
     const bool live = c < J.n_cand[0] && J.l_flags[i] == GZB_F_MORE;
@@ -833,8 +873,10 @@ __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
     const uint32_t share = (J.c_symcap[c] / 2u) / (uint32_t)GZB_K;
     const size_t at = J.c_symoff[c] / 2 + (size_t)k * share;
     uint32_t p = J.l_p[i], nt = J.l_ntok[i];
-    const uint32_t fl = gzb_tokenize(J.comp, J.comp_bytes * 8u, T, J.blk_tp + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i], J.slice_tokens,
-                                     lanes != 1u, s_stage + threadIdx.x, GZB_DEC_THREADS);
+    GzbInLds in;
+    in.comp16 = reinterpret_cast<const uint4*>(J.comp);
+    in.ring = s_ring + threadIdx.x;
+    const uint32_t fl = gzb_tokenize(in, J.comp_bytes * 8u, T, J.blk_tp + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i], J.slice_tokens, lanes != 1u);
     J.l_p[i] = p;
     J.l_ntok[i] = nt;
     J.l_flags[i] = fl;

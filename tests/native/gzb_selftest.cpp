@@ -124,7 +124,6 @@ struct CpuOffload : aqcgz::SectionOffload {
         }
         // ---- decode: tables per candidate, then GZB_K lanes per candidate in slices, then the stitch
         std::vector<uint32_t> cnt(16), nxt(16), off(16);
-        unsigned long long stage[GZB_STAGE];
         for (uint32_t c = 0; c < nc; ++c) {
             uint32_t* const tw = J.tables + (size_t)c * GZB_TAB_WORDS;
             const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(tw)};
@@ -153,8 +152,8 @@ struct CpuOffload : aqcgz::SectionOffload {
                 const uint32_t share = (c_symcap[c] / 2u) / (uint32_t)GZB_K;
                 const size_t at = c_symoff[c] / 2 + (size_t)k * share;
                 uint32_t p = J.l_p[i], nt = J.l_ntok[i];
-                J.l_flags[i] = gzb_tokenize(J.comp, limit_bit, T, J.blk_tp + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i],
-                                            slice_tokens, lanes != 1u, stage, 1);
+                GzbInMem in{J.comp, 0};
+                J.l_flags[i] = gzb_tokenize(in, limit_bit, T, J.blk_tp + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i], slice_tokens, lanes != 1u);
                 J.l_p[i] = p; J.l_ntok[i] = nt;
             }
         for (uint32_t c = 0; c < nc; ++c) {
