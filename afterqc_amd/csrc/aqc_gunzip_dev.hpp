@@ -129,25 +129,15 @@ struct GzbJob {
     uint32_t s_symcap;           // most symbols one section may have
 };
 
-GZB_HD inline uint32_t gzb_len_base(uint32_t i) {
-    static const uint16_t T[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    return T[i];
-}
-GZB_HD inline uint32_t gzb_len_extra(uint32_t i) {
-    static const uint8_t T[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    return T[i];
-}
-GZB_HD inline uint32_t gzb_dist_base(uint32_t i) {
-    static const uint16_t T[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-    return T[i];
-}
-GZB_HD inline uint32_t gzb_dist_extra(uint32_t i) {
-    static const uint8_t T[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-    return T[i];
-}
+// base value and number of extra bits of length symbol 257 + i and of distance symbol i (RFC 1951 3.2.5), COMPUTED: a table in
+// memory is a trip to the cache per token for every lane (two trips in a row for a match: that alone was 0.8 us per token)
+GZB_HD inline uint32_t gzb_len_extra(uint32_t i) { return (i < 8u || i == 28u) ? 0u : (i - 4u) >> 2; }
+GZB_HD inline uint32_t gzb_len_base(uint32_t i) { return i == 28u ? 258u : i < 8u ? 3u + i : 3u + ((4u + (i & 3u)) << ((i - 4u) >> 2)); }
+GZB_HD inline uint32_t gzb_dist_extra(uint32_t i) { return i < 4u ? 0u : (i - 2u) >> 1; }
+GZB_HD inline uint32_t gzb_dist_base(uint32_t i) { return i < 4u ? 1u + i : 1u + ((2u + (i & 1u)) << ((i - 2u) >> 1)); }
+// the order the code-length code's lengths come in (16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15), five bits each in two constants
 GZB_HD inline uint32_t gzb_cl_order(uint32_t i) {
-    static const uint8_t T[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    return T[i];
+    return i < 12u ? (uint32_t)(0x22caa324e804a30ull >> (5u * i)) & 31u : (uint32_t)(0x3c2e1346cull >> (5u * (i - 12u))) & 31u;
 }
 
 // >= 57 bits of the stream from bit position p on (any alignment; the buffer is padded)

@@ -301,6 +301,17 @@ static std::vector<uint8_t> slurp(const char* path) {
 }
 
 int main(int argc, char** argv) {
+    {
+        // the computed length / distance bases against RFC 1951's tables
+        static const uint16_t LB[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+        static const uint8_t LX[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+        static const uint16_t DB[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+        static const uint8_t DX[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+        for (uint32_t i = 0; i < 29; ++i)
+            if (gzb_len_base(i) != LB[i] || gzb_len_extra(i) != LX[i]) { printf("length symbol %u: base / extra wrong\n", i); return 1; }
+        for (uint32_t i = 0; i < 30; ++i)
+            if (gzb_dist_base(i) != DB[i] || gzb_dist_extra(i) != DX[i]) { printf("distance symbol %u: base / extra wrong\n", i); return 1; }
+    }
     if (argc > 2) {
         const std::vector<uint8_t> gz = slurp(argv[1]), text = slurp(argv[2]);
         g_max_slices = 16; g_slice_tokens = 1024;
