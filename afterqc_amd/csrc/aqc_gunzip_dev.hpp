@@ -368,13 +368,16 @@ GZB_HD inline unsigned long long gzb_load64(const uint8_t* p) {
 // Returns 0 done, GZB_F_MORE (max_tokens written: call again with the same p / nt), GZB_F_OVERFLOW, GZB_F_ERROR (plain only).
 //
 // The stream is read 32 bits at a time through `in`: the host reads memory; a device lane reads an LDS window of 128 bytes of
-// its stretch that it fills 64 bytes at a time, the next 64 already on their way in registers (GzbInLds).  The first device
-// version read the stream eight bytes at a time from global memory with one read in flight: of a wave's 64 lanes, each on
-// its own cache lines, a few are always about to touch a new line, so nearly every refill waited for HBM — 0.8 us per token.
+// its stretch (GzbInLds) that is topped up at in.sync(), which every lane of the wave reaches at the same step.  That is the
+// point: the hardware counts a WAVE's outstanding loads, not a lane's.  Whenever lanes ask for the next piece of their streams
+// at steps of their own — eight bytes per refill in the first version, 64 bytes whenever a lane left a half of its window in
+// the second — nearly every step has some lane asking and some lane needing what it asked for long ago, and the wave waits
+// for the newest request to come back from memory: 0.8 us per token, whatever the tables and the stores were doing.
 struct GzbInMem {
     const uint8_t* comp;
     uint32_t wi;                 // the next word to hand out
     GZB_HD void start(uint32_t word) { wi = word; }
+    GZB_HD void sync() {}
     GZB_HD uint32_t next() {
         uint32_t v;
         memcpy(&v, comp + 4ull * wi, 4);
@@ -382,6 +385,7 @@ struct GzbInMem {
         return v;
     }
 };
+constexpr uint32_t GZB_SYNC_STEPS = 8;             // the tokenizer calls in.sync() every so many tokens (a token takes <= 48 bits)
 
 template <int S, class In>
 GZB_HD inline uint32_t gzb_tokenize(In& in, uint32_t limit_bit, const GzbLaneTab<S>& T, unsigned long long* tp, uint32_t tok_cap, uint32_t& p, uint32_t& nt,
@@ -406,6 +410,7 @@ GZB_HD inline uint32_t gzb_tokenize(In& in, uint32_t limit_bit, const GzbLaneTab
         if (at >= stop_bit) break;
         if (nt >= tok_cap) { fl = GZB_F_OVERFLOW; break; }
         if (tokens++ >= max_tokens) { fl = GZB_F_MORE; break; }
+        if ((tokens & (GZB_SYNC_STEPS - 1u)) == 0u) in.sync();
         GZB_REFILL();                                         // > 32 bits now; a literal/length code + its extra bits take <= 20
         uint32_t e = T.at((int)((uint32_t)bb & ((1u << GZB_LROOT) - 1u)));
         if ((e & 15u) == 0u) e = gzb_slow<true, S>(bb, T);
@@ -458,7 +463,14 @@ GZB_HD inline uint32_t gzb_tokenize(In& in, uint32_t limit_bit, const GzbLaneTab
 // is read by one plain lane.
 GZB_HD inline void gzb_plan_lanes(const GzbJob& J, uint32_t c, uint32_t n, uint32_t data_bit) {
     const uint32_t limit = J.comp_bytes * 8u;
-    const uint32_t est_end = c + 1 < n ? J.c_start[c + 1] : limit;
+    // (the window's last candidate: blocks of one stream are of similar size — half as much again as its predecessor, not the
+    // megabytes of slack up to the window's end, which sixteen lanes would read to the last bit)
+    uint32_t est_end = limit;
+    if (c + 1 < n) est_end = J.c_start[c + 1];
+    else if (c > 0) {
+        const uint32_t gap = J.c_start[c] - J.c_start[c - 1];
+        est_end = gzb_min(limit, J.c_start[c] + gap + gap / 2u + 4096u);
+    }
     const bool plain = est_end <= data_bit || est_end - data_bit < GZB_PLAIN_BITS;
     J.c_lanes[c] = plain ? 1u : (uint32_t)GZB_K;
     for (uint32_t k = 0; k < (uint32_t)GZB_K; ++k) {
@@ -798,43 +810,46 @@ __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_tables_kernel(GzbJob J) {
 // 64 / GZB_K blocks, whose tables (11 KB each) are copied into LDS first: what a lane waits for per token is then an LDS
 // look-up, not a trip to L2 (1.4 us per token measured with the tables in global memory, the lanes spending their time waiting).
 constexpr int GZB_DEC_BLOCKS = GZB_DEC_THREADS / GZB_K;
-// A lane's window of the stream: 32 words in a column of an LDS array (word j at [(j % 32) * GZB_DEC_THREADS]), two halves of 64
-// bytes; when the lane steps from one half into the other the half it left is filled from `pend` — 64 bytes asked for when
-// the lane entered that half, two to three microseconds ago — and the 64 bytes behind those are asked for.
+// A lane's window of the stream: 32 words in a column of an LDS array (word j at [(j % 32) * GZB_DEC_THREADS]).  At sync(), every
+// GZB_SYNC_STEPS tokens and for all lanes at once, the pieces asked for at the previous sync() (32 bytes each, <= 2) are put
+// into the window and new ones are asked for, as many as there is room for.  A token takes <= 48 bits, GZB_SYNC_STEPS of them
+// <= 12 words: a lane leaves sync() with more than 12 words at hand or on their way, so it never runs dry, and what arrives
+// only overwrites words it had consumed when it asked.
 struct GzbInLds {
     const uint4* comp16;
     uint32_t* ring;
     uint4 pend[4];
-    uint32_t wi;
+    uint32_t wi, wf, kp;         // next word to hand out; words [.., wf) are in the window or on their way; pieces on their way
+    __device__ void put(uint32_t word, const uint4& v) {
+        const uint32_t w = word & 31u;
+        ring[(w + 0u) * GZB_DEC_THREADS] = v.x; ring[(w + 1u) * GZB_DEC_THREADS] = v.y;
+        ring[(w + 2u) * GZB_DEC_THREADS] = v.z; ring[(w + 3u) * GZB_DEC_THREADS] = v.w;
+    }
     __device__ void start(uint32_t word) {
         wi = word;
-        const uint32_t base = word & ~15u;
+        const uint32_t base = word & ~3u;           // (>= 29 words at hand: the bit buffer takes two, eight tokens <= 12, > 12 are left at the first sync())
         uint4 a[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = comp16[(base >> 2) + (uint32_t)j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pend[j] = comp16[(base >> 2) + 8u + (uint32_t)j];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t w = (base + 4u * (uint32_t)j) & 31u;
-            ring[(w + 0u) * GZB_DEC_THREADS] = a[j].x; ring[(w + 1u) * GZB_DEC_THREADS] = a[j].y;
-            ring[(w + 2u) * GZB_DEC_THREADS] = a[j].z; ring[(w + 3u) * GZB_DEC_THREADS] = a[j].w;
-        }
+        for (int j = 0; j < 8; ++j) put(base + 4u * (uint32_t)j, a[j]);
+        wf = base + 32u;
+        kp = 0;
+    }
+    __device__ void sync() {
+        // what was asked for last time has had GZB_SYNC_STEPS tokens' time to arrive
+        if (kp > 0u) { put(wf - 8u * kp, pend[0]); put(wf - 8u * kp + 4u, pend[1]); }
+        if (kp > 1u) { put(wf - 8u, pend[2]); put(wf - 4u, pend[3]); }
+        const uint32_t room = 32u - (wf - wi);           // (wf - wi <= 32 always)
+        kp = room >> 3;
+        if (kp > 2u) kp = 2u;
+        if (kp > 0u) { pend[0] = comp16[wf >> 2]; pend[1] = comp16[(wf >> 2) + 1u]; }
+        if (kp > 1u) { pend[2] = comp16[(wf >> 2) + 2u]; pend[3] = comp16[(wf >> 2) + 3u]; }
+        wf += 8u * kp;
     }
     __device__ uint32_t next() {
         const uint32_t v = ring[(wi & 31u) * GZB_DEC_THREADS];
         ++wi;
-        if ((wi & 15u) == 0u) {
-            const uint32_t h = (wi + 16u) & 16u;          // the half just left = the half of words [wi + 16, wi + 32)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t w = h + 4u * (uint32_t)j;
-                ring[(w + 0u) * GZB_DEC_THREADS] = pend[j].x; ring[(w + 1u) * GZB_DEC_THREADS] = pend[j].y;
-                ring[(w + 2u) * GZB_DEC_THREADS] = pend[j].z; ring[(w + 3u) * GZB_DEC_THREADS] = pend[j].w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pend[j] = comp16[((wi + 32u) >> 2) + (uint32_t)j];
-        }
         return v;
     }
 };
