@@ -1097,6 +1097,7 @@ public:
         // (the lowest stream priority: where a decoder slice and a kernel of the filter compete for the chip, the filter goes first)
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (const char* e = getenv("AQC_GZ_PRIO")) { if (e[0] == '0') prio_lo = 0; else if (e[0] == '2') prio_lo = prio_hi; }      // (experiments: 0 normal, 2 highest)
         for (auto& l : lanes_) {
             if (hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return false;
             for (auto& e : l.ev) if (hipEventCreate(&e) != hipSuccess) return false;
@@ -1292,7 +1293,7 @@ private:
         J.l_p = (uint32_t*)L.l_u32.p; J.l_stop = J.l_p + (size_t)cand_cap * GZB_K; J.l_start = J.l_stop + (size_t)cand_cap * GZB_K;
         J.l_ntok = J.l_start + (size_t)cand_cap * GZB_K; J.l_flags = J.l_ntok + (size_t)cand_cap * GZB_K;
         {
-            static const uint32_t slice = [] { const char* e = getenv("AQC_GZ_SLICE"); return e ? (uint32_t)std::max(16, atoi(e)) : 1024u; }();
+            static const uint32_t slice = [] { const char* e = getenv("AQC_GZ_SLICE"); return e ? (uint32_t)std::max(16, atoi(e)) : 2048u; }();
             J.slice_tokens = slice;
         }
         J.n_sec = (uint32_t)n; J.s_nominal = (const uint32_t*)L.s_in.p; J.s_stop = J.s_nominal + n; J.s_exact = J.s_nominal + 2 * n;
@@ -1302,11 +1303,11 @@ private:
         hipLaunchKernelGGL(gzb_scan_kernel, dim3(n_tiles), dim3(GZB_SCAN_THREADS), 0, L.stream, J);
         hipLaunchKernelGGL(gzb_compact_kernel, dim3(1), dim3(1024), 0, L.stream, J);
         GZB_TRY(hipEventRecord(L.ev[2], L.stream));
-        // the decoder in slices (aqc_gunzip_dev.hpp): GZB_K lanes per block, each with its share of it and the overlap: 16 x 1024
+        // the decoder in slices (aqc_gunzip_dev.hpp): GZB_K lanes per block, each with its share of it and the overlap: 6 x 2048
         // tokens cover the blocks of zlib (<= 16 K tokens) and of GNU gzip (<= 32 K) with room to spare; a lane that needs more
         // stays unfinished, its block counts as failed, the section ends before it and the host goes on from there
         {
-            static const int n_slices = [] { const char* e = getenv("AQC_GZ_SLICES"); return e ? std::max(1, atoi(e)) : 16; }();
+            static const int n_slices = [] { const char* e = getenv("AQC_GZ_SLICES"); return e ? std::max(1, atoi(e)) : 6; }();
             hipLaunchKernelGGL(gzb_tables_kernel, dim3((cand_cap + GZB_DEC_THREADS - 1) / GZB_DEC_THREADS), dim3(GZB_DEC_THREADS), 0, L.stream, J);
             const dim3 grid((cand_cap * GZB_K + GZB_DEC_THREADS - 1) / GZB_DEC_THREADS);
             for (int sl = 0; sl < n_slices; ++sl) hipLaunchKernelGGL(gzb_decode_kernel, grid, dim3(GZB_DEC_THREADS), 0, L.stream, J);

@@ -368,7 +368,8 @@ void ParallelGunzip::to_pool(const std::shared_ptr<Section>& s) {
 // "none"), which the device cannot take: it goes to the pool at once
 void ParallelGunzip::next_window() {
     const size_t per_group = std::max<size_t>(1, (offload_ ? std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ * 2 / 9)) : section_bytes_) / section_bytes_);
-    win_hi_ = std::min(last_idx_ + 1, win_lo_ + 8 * per_group);
+    static const size_t win_groups = [] { const char* e = getenv("AQC_GZ_WINDOW"); return e ? (size_t)std::max(1, atoi(e)) : (size_t)8; }();
+    win_hi_ = std::min(last_idx_ + 1, win_lo_ + win_groups * per_group);
     pool_next_ = win_lo_;
     dev_hi_ = win_hi_;
     if (win_hi_ == last_idx_ + 1) {
@@ -416,7 +417,8 @@ void ParallelGunzip::top_up(bool need_front) {
         // ... but only while the pool still has more than two groups' worth of sections in front of it: a group takes the device
         // a fixed 100 - 200 ms (a block is decoded by one lane from start to end), and one that is started when the pool is about
         // to arrive makes the consumer wait for it
-        if (!offload_only_ && dev_hi_ - pool_next_ < per_group * 12 / 5) break;
+        static const size_t keep_fifths = [] { const char* e = getenv("AQC_GZ_KEEP"); return e ? (size_t)std::max(0, atoi(e)) : (size_t)12; }();
+        if (!offload_only_ && dev_hi_ - pool_next_ < per_group * keep_fifths / 5) break;
         size_t lo, hi;
         if (offload_only_) { lo = pool_next_; hi = std::min(dev_hi_, lo + per_group); }
         else { hi = dev_hi_; lo = hi > pool_next_ + per_group ? hi - per_group : pool_next_; }

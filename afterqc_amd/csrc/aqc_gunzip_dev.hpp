@@ -72,8 +72,8 @@ constexpr int GZB_E_DIST = 1 << GZB_LROOT, GZB_E_LSORT = GZB_E_DIST + (1 << GZB_
 constexpr int GZB_TAB_WORDS = GZB_TAB_ENTRIES / 2 + 80;          // 32-bit words per candidate: the tables, then the code lengths
 constexpr int GZB_SCAN_THREADS = 256, GZB_SCAN_TILE = GZB_SCAN_THREADS * 16, GZB_TILE_CAND = 16;
 constexpr int GZB_DEC_THREADS = 64;
-constexpr int GZB_K = 16;                          // lanes per block (entry points guessed inside it, see gzb_decode_kernel)
-constexpr uint32_t GZB_OVERLAP_BITS = 8192;        // how far a lane reads into its successor's share to meet its token list
+constexpr int GZB_K = 32;                          // lanes per block (entry points guessed inside it, see gzb_decode_kernel)
+constexpr uint32_t GZB_OVERLAP_BITS = 4096;        // how far a lane reads into its successor's share to meet its token list
 constexpr uint32_t GZB_PLAIN_BITS = 8192;           // a block shorter than this is read by one lane
 constexpr uint32_t GZB_CAND_EXTRA = 4104u + (uint32_t)GZB_K * GZB_OVERLAP_BITS;       // symbol space per candidate beyond ratio_cap x its bytes
 constexpr uint32_t GZB_T_EOB = 0x40000000u, GZB_T_JUNK = 0x20000000u;
@@ -891,7 +891,8 @@ __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
 // tokens at a time.  Where the chunk reaches into the next lane's share every lane looks its token's bit position up in that
 // lane's list (a binary search); the first lane that finds it is where the two reading frames have met: the tokens before it
 // are applied and the walk goes on in the next list.  Output positions come from a lane scan, the chunk's literals are stored
-// at once, its matches applied in order with the 64 lanes sharing each copy (a copy that overlaps itself repeats its period).
+// at once, then the matches that copy from before the chunk all together, then the few that copy from the chunk itself in
+// order with the 64 lanes sharing each copy (a copy that overlaps itself repeats its period).
 // A wave's loads and stores to global memory are performed in issue order, so a copy sees what the one before it wrote.
 constexpr int GZB_EXP_WAVES = 4;
 __global__ __launch_bounds__(64 * GZB_EXP_WAVES) void gzb_expand_kernel(GzbJob J) {
@@ -946,13 +947,59 @@ __global__ __launch_bounds__(64 * GZB_EXP_WAVES) void gzb_expand_kernel(GzbJob J
         if (op + total > cap) { fl = GZB_F_OVERFLOW; break; }
         const uint32_t opos = op + inc - len;
         if (use && lit) out[opos] = (uint16_t)(t & 0xffu);
-        unsigned long long mm = __ballot(use && !lit);
         if (__ballot(use && !lit && (int)opos - (int)((t & 0x7fffu) + 1u) < -32768)) { fl = GZB_F_ERROR; break; }
+        // The chunk's matches.  Most of them copy from before the chunk (its output is a few hundred symbols, FASTQ's distances
+        // are thousands): those do not depend on anything this chunk writes and are done TOGETHER — their symbols numbered
+        // through by a second lane scan, 64 of them per step whichever match they belong to (found by a search over the lanes'
+        // running sums), four steps' loads in flight before the first store.  (One match at a time, the lanes sharing its copy:
+        // a trip to the cache per match, 12 us per chunk, most lanes idle.)
+        const uint32_t dd = (t & 0x7fffu) + 1u;
+        const bool is_match = use && !lit;
+        const bool indep_ok = is_match && ((int)opos - (int)dd + (int)gzb_min(len, dd) <= (int)op);
+        uint32_t isum = indep_ok ? len : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)isum, d, 64);
+            if (lane >= d) isum += o;
+        }
+        const uint32_t itotal = (uint32_t)__builtin_amdgcn_readlane((int)isum, 63);
+        const uint32_t iex = isum - (indep_ok ? len : 0u);
+        for (uint32_t j0 = 0; j0 < itotal; j0 += 256u) {
+            uint32_t dst_at[4];
+            int src_at[4];
+            uint16_t val[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t j = j0 + 64u * (uint32_t)r + (uint32_t)lane;
+                // the first lane whose running sum exceeds j owns symbol j
+                uint32_t own = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const uint32_t probe = own + (uint32_t)step - 1u;
+                    const uint32_t v = (uint32_t)__shfl((int)isum, (int)probe, 64);
+                    if (v <= j) own += (uint32_t)step;
+                }
+                own &= 63u;
+                const uint32_t o_pos = (uint32_t)__shfl((int)opos, (int)own, 64), o_dd = (uint32_t)__shfl((int)dd, (int)own, 64),
+                               o_ex = (uint32_t)__shfl((int)iex, (int)own, 64);
+                const uint32_t rel = j - o_ex;
+                dst_at[r] = j < itotal ? o_pos + rel : 0xffffffffu;
+                src_at[r] = (int)o_pos - (int)o_dd + (int)(rel < o_dd ? rel : rel % o_dd);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                val[r] = (dst_at[r] != 0xffffffffu && src_at[r] >= 0) ? out[src_at[r]] : (uint16_t)(GZB_MARKER | (uint32_t)(32768 + src_at[r]));
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (dst_at[r] != 0xffffffffu) out[dst_at[r]] = val[r];
+        }
+        // the others (their source lies in this chunk's output) in order, the lanes sharing each copy
+        unsigned long long mm = __ballot(is_match && !indep_ok);
         while (mm) {
             const int l = __ffsll((long long)mm) - 1;
             mm &= mm - 1;
             const uint32_t m_len = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
-            const uint32_t m_dd = ((uint32_t)__builtin_amdgcn_readlane((int)t, l) & 0x7fffu) + 1u;
+            const uint32_t m_dd = (uint32_t)__builtin_amdgcn_readlane((int)dd, l);
             const uint32_t m_pos = (uint32_t)__builtin_amdgcn_readlane((int)opos, l);
             const int src = (int)m_pos - (int)m_dd;
             for (uint32_t j0 = 0; j0 < m_len; j0 += 64u) {
