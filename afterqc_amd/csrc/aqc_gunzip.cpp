@@ -188,7 +188,12 @@ void run_sections(const uint8_t* data, size_t size, const std::shared_ptr<Parall
 ParallelGunzip::ParallelGunzip(const uint8_t* data, size_t size, aqc_host::Pool* pool, int inflight, size_t section_bytes, SectionOffload* offload,
                                bool offload_only)
     : data_(data), size_(size), pool_(pool), inflight_(inflight < 1 ? 1 : inflight), section_bytes_(section_bytes < (64u << 10) ? (64u << 10) : section_bytes),
-      offload_(offload), offload_only_(offload_only && offload), sh_(new Shared()) {}
+      offload_(offload), offload_only_(offload_only && offload), sh_(new Shared()) {
+    // the hybrid schedule's two numbers: groups per window, and how many fifths of a group the pool must still have
+    // in front of it for the device to be given another one
+    if (const char* e = getenv("AQC_GZ_WINDOW")) win_groups_ = (size_t)std::max(1, atoi(e));
+    if (const char* e = getenv("AQC_GZ_KEEP")) keep_fifths_ = (size_t)std::max(0, atoi(e));
+}
 
 ParallelGunzip::~ParallelGunzip() {
     // speculative sections still running hold their own references; wait for them (they read data_)
@@ -368,8 +373,7 @@ void ParallelGunzip::to_pool(const std::shared_ptr<Section>& s) {
 // "none"), which the device cannot take: it goes to the pool at once
 void ParallelGunzip::next_window() {
     const size_t per_group = std::max<size_t>(1, (offload_ ? std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ * 2 / 9)) : section_bytes_) / section_bytes_);
-    static const size_t win_groups = [] { const char* e = getenv("AQC_GZ_WINDOW"); return e ? (size_t)std::max(1, atoi(e)) : (size_t)8; }();
-    win_hi_ = std::min(last_idx_ + 1, win_lo_ + win_groups * per_group);
+    win_hi_ = std::min(last_idx_ + 1, win_lo_ + win_groups_ * per_group);
     pool_next_ = win_lo_;
     dev_hi_ = win_hi_;
     if (win_hi_ == last_idx_ + 1) {
@@ -417,8 +421,7 @@ void ParallelGunzip::top_up(bool need_front) {
         // ... but only while the pool still has more than two groups' worth of sections in front of it: a group takes the device
         // a fixed 100 - 200 ms (a block is decoded by one lane from start to end), and one that is started when the pool is about
         // to arrive makes the consumer wait for it
-        static const size_t keep_fifths = [] { const char* e = getenv("AQC_GZ_KEEP"); return e ? (size_t)std::max(0, atoi(e)) : (size_t)12; }();
-        if (!offload_only_ && dev_hi_ - pool_next_ < per_group * keep_fifths / 5) break;
+        if (!offload_only_ && dev_hi_ - pool_next_ < per_group * keep_fifths_ / 5) break;
         size_t lo, hi;
         if (offload_only_) { lo = pool_next_; hi = std::min(dev_hi_, lo + per_group); }
         else { hi = dev_hi_; lo = hi > pool_next_ + per_group ? hi - per_group : pool_next_; }

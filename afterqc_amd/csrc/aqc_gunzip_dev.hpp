@@ -256,13 +256,16 @@ GZB_HD inline uint32_t gzb_kraft9(uint32_t i) {
     for (int f = 0; f < 3; ++f) { const uint32_t l = (i >> (3 * f)) & 7u; k += l ? 128u >> l : 0u; }
     return k;
 }
-// the code-length code of the header at bit p must be complete: Kraft sum of its `hclen` 3-bit lengths
-GZB_HD inline bool gzb_kraft_ok(const uint8_t* comp, uint32_t p, uint32_t hclen, const uint8_t* kraft9) {
-    unsigned long long v = gzb_peek(comp, p + 17u);
+// the code-length code of the header at bit p must be complete: Kraft sum of its `hclen` 3-bit lengths (v: the 64 bits of the
+// stream from bit p + 17 on)
+GZB_HD inline bool gzb_kraft_ok_v(unsigned long long v, uint32_t hclen, const uint8_t* kraft9) {
     v &= (1ull << (3u * hclen)) - 1ull;
     const uint32_t kraft = (uint32_t)kraft9[v & 511u] + kraft9[(v >> 9) & 511u] + kraft9[(v >> 18) & 511u] + kraft9[(v >> 27) & 511u] +
                            kraft9[(v >> 36) & 511u] + kraft9[(v >> 45) & 511u] + kraft9[(v >> 54) & 511u];
     return kraft == 128u;
+}
+GZB_HD inline bool gzb_kraft_ok(const uint8_t* comp, uint32_t p, uint32_t hclen, const uint8_t* kraft9) {
+    return gzb_kraft_ok_v(gzb_peek(comp, p + 17u), hclen, kraft9);
 }
 
 // One lane's tables: entry e at base[e * S] (S = 64 on the device: see GZB_E_*; 1 on the host).
@@ -677,14 +680,17 @@ __global__ __launch_bounds__(GZB_SCAN_THREADS) void gzb_scan_kernel(GzbJob J) {
     // (a lane pops its own survivors: every iteration of these loops does useful work on most lanes)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        // (the 57 bits the test looks at, from 17 to 48 bits behind this word's start, are in the lane's registers: a survivor
+        //  costs no trip to memory — there are a dozen per lane)
         const unsigned long long v64 = ((unsigned long long)d[i + 1] << 32) | d[i];
+        const unsigned long long hi64 = ((unsigned long long)d[i + 3 < 8 ? i + 3 : 7] << 32) | d[i + 2];
         uint32_t mm = m[i];
         while (mm) {
             const uint32_t bit = (uint32_t)__builtin_ctz(mm);
             mm &= mm - 1;
-            const uint32_t p = (byte0 + 4u * (uint32_t)i) * 8u + bit;
             const uint32_t hclen = ((uint32_t)(v64 >> (bit + 13u)) & 15u) + 4u;
-            if (gzb_kraft_ok(J.comp, p, hclen, s_kraft)) k2[i] |= 1u << bit;
+            const uint32_t o = bit + 17u;                                       // 17 .. 48
+            if (gzb_kraft_ok_v((v64 >> o) | (hi64 << (64u - o)), hclen, s_kraft)) k2[i] |= 1u << bit;
         }
     }
 #pragma unroll

@@ -169,6 +169,7 @@ private:
     // (dev_hi_) — the consumer commits in index order, so it reaches a device group only after everything the pool did in
     // front of it, which is as long as the device can possibly be given; the two meet wherever their speeds put them.
     size_t start_idx_ = 0, last_idx_ = 0, win_lo_ = 0, win_hi_ = 0, pool_next_ = 0, dev_hi_ = 0;
+    size_t win_groups_ = 8, keep_fifths_ = 12;       // AQC_GZ_WINDOW / AQC_GZ_KEEP (read when the decoder is made)
     uint64_t start_bit0_ = 0;
     uint64_t cur_bit_ = 0;                         // everything before this bit is decoded and committed
     bool started_ = false, done_ = false, bad_ = false;

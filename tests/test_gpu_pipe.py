@@ -273,11 +273,13 @@ def test_pipe_single_member_gzip_input_is_shared_with_the_device(tmp_path):
 
     os.environ["AQC_GZ_GROUP"] = str(16 << 20)       # (a 40 MB file: one group of 64 sections per mate, a third of the file)
     os.environ["AQC_GZ_DEVICE_MIN"] = "0"        # (files this small are normally left to the pool)
+    os.environ["AQC_GZ_KEEP"] = "5"              # (... and the pool's head start of 32 sections is a sixth of them: one group in front of it will do)
     try:
         sections, from_device, text_bytes, device_bytes = gz_run("gzdev")
     finally:
         del os.environ["AQC_GZ_GROUP"]
         del os.environ["AQC_GZ_DEVICE_MIN"]
+        del os.environ["AQC_GZ_KEEP"]
     assert sections > 20 and from_device > 0.3 * sections and device_bytes > 0.2 * text_bytes, (sections, from_device, text_bytes, device_bytes)
     os.environ["AQC_GZ_DEVICE_IN"] = "0"
     try:
