@@ -230,6 +230,9 @@ GZB_HD inline bool gzb_header(const uint8_t* comp, uint32_t limit_bit, uint32_t 
             kdist += (rep - nl) * k;
             if (rep > nl) maxd = gzb_max(maxd, val);
             if (i <= 256u && i + rep > 256u) has_eob = true;
+            // (an over-subscribed code is no code: what is not a header gets here within a few dozen lengths — the scan's
+            //  lanes that parse run in step with the slowest of them, which used to be the full 300 lengths)
+            if (klit > 32768u || kdist > 32768u) return false;
         }
         if (lens)
             for (uint32_t k = 0; k < rep; ++k) lens[i + k] = (uint8_t)val;
