@@ -62,10 +62,12 @@ struct GzJob {
     uint64_t* total;
 };
 
-__device__ __constant__ uint16_t GZ_LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ __constant__ uint8_t GZ_LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ __constant__ uint16_t GZ_DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__device__ __constant__ uint8_t GZ_DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+// base value and number of extra bits of length symbol 257 + i / distance symbol i (RFC 1951 3.2.5) in closed form: a table in
+// constant memory indexed per lane is a vector load from memory per token (measured on the inflate side, aqc_gunzip_dev.hpp)
+__device__ __forceinline__ int gz_len_extra(int i) { return (i < 8 || i == 28) ? 0 : (i - 4) >> 2; }
+__device__ __forceinline__ int gz_len_base(int i) { return i == 28 ? 258 : i < 8 ? 3 + i : 3 + ((4 + (i & 3)) << ((i - 4) >> 2)); }
+__device__ __forceinline__ int gz_dist_extra(int i) { return i < 4 ? 0 : (i - 2) >> 1; }
+__device__ __forceinline__ int gz_dist_base(int i) { return i < 4 ? 1 + i : 1 + ((2 + (i & 1)) << ((i - 2) >> 1)); }
 
 // length 3..258 -> length symbol - 257; distance 1..32768 -> distance symbol (closed forms: no tables)
 __device__ __forceinline__ int gz_len_sym(int len) {
@@ -101,7 +103,7 @@ struct GzSinkSize {
     __device__ __forceinline__ void lit(uint32_t b) { bits += lc[b] >> 16; }
     __device__ __forceinline__ void match(int len, int dist) {
         const int ls = gz_len_sym(len), ds = gz_dist_sym(dist);
-        bits += (lc[257 + ls] >> 16) + GZ_LEN_EXTRA[ls] + (dc[ds] >> 16) + GZ_DIST_EXTRA[ds];
+        bits += (lc[257 + ls] >> 16) + gz_len_extra(ls) + (dc[ds] >> 16) + gz_dist_extra(ds);
     }
 };
 struct GzSinkEmit {
@@ -127,9 +129,9 @@ struct GzSinkEmit {
         const int ls = gz_len_sym(len), ds = gz_dist_sym(dist);
         const uint32_t a = lc[257 + ls], d = dc[ds];
         put(a & 0xffffu, (int)(a >> 16));
-        if (GZ_LEN_EXTRA[ls]) put((uint32_t)(len - GZ_LEN_BASE[ls]), GZ_LEN_EXTRA[ls]);
+        if (gz_len_extra(ls)) put((uint32_t)(len - gz_len_base(ls)), gz_len_extra(ls));
         put(d & 0xffffu, (int)(d >> 16));
-        if (GZ_DIST_EXTRA[ds]) put((uint32_t)(dist - GZ_DIST_BASE[ds]), GZ_DIST_EXTRA[ds]);
+        if (gz_dist_extra(ds)) put((uint32_t)(dist - gz_dist_base(ds)), gz_dist_extra(ds));
     }
     __device__ __forceinline__ void finish() { if (nacc > 0) atomicOr(&out[w], (uint32_t)acc); }
 };
@@ -153,7 +155,7 @@ __device__ __forceinline__ void gz_tokenize(const uint8_t* s, int a, int b, int 
                 int gain;
                 if (EXACT) {
                     const int lsym = gz_len_sym(r);
-                    gain = r * (int)(lc[c0] >> 16) - (int)((lc[257 + lsym] >> 16) + GZ_LEN_EXTRA[lsym] + (dc[0] >> 16));
+                    gain = r * (int)(lc[c0] >> 16) - (int)((lc[257 + lsym] >> 16) + gz_len_extra(lsym) + (dc[0] >> 16));
                 } else gain = r >= 5 ? r : 0;
                 if (gain > best_gain) { best_gain = gain; best_len = r; best_dist = 1; }
             }
@@ -170,7 +172,7 @@ __device__ __forceinline__ void gz_tokenize(const uint8_t* s, int a, int b, int 
                     int gain;
                     if (EXACT) {
                         const int lsym = gz_len_sym(m), dsym = gz_dist_sym(dist);
-                        gain = lit_bits - (int)((lc[257 + lsym] >> 16) + GZ_LEN_EXTRA[lsym] + (dc[dsym] >> 16) + GZ_DIST_EXTRA[dsym]);
+                        gain = lit_bits - (int)((lc[257 + lsym] >> 16) + gz_len_extra(lsym) + (dc[dsym] >> 16) + gz_dist_extra(dsym));
                     } else gain = m >= 6 ? m : 0;
                     if (gain > best_gain) { best_gain = gain; best_len = m; best_dist = dist; }
                 }
