@@ -136,12 +136,41 @@ struct GzSinkEmit {
     __device__ __forceinline__ void finish() { if (nacc > 0) atomicOr(&out[w], (uint32_t)acc); }
 };
 
+// What the size pass decided, for the emit pass: bit i of `start` = a token begins at byte a + i of the segment (its length is the
+// distance to the next one: 1 = literal, >= 3 = match), bit i of `col` = that match copies the column four lines up (else the
+// byte before: distance 1), bit i of `nl` = byte a + i is a line end.  Four 64-bit words each, never indexed by a variable (that
+// would put them in scratch memory): the emit pass costs a few instructions per TOKEN instead of the whole search per byte again.
+struct GzTokMask {
+    unsigned long long start[4] = {0, 0, 0, 0}, col[4] = {0, 0, 0, 0}, nl[4] = {0, 0, 0, 0};
+};
+__device__ __forceinline__ void gz_mask_set(unsigned long long (&m)[4], int i) {
+    const unsigned long long bit = 1ull << (i & 63);
+    const int w = i >> 6;
+    m[0] |= w == 0 ? bit : 0ull; m[1] |= w == 1 ? bit : 0ull; m[2] |= w == 2 ? bit : 0ull; m[3] |= w == 3 ? bit : 0ull;
+}
+__device__ __forceinline__ bool gz_mask_test(const unsigned long long (&m)[4], int i) {
+    const int w = i >> 6;
+    const unsigned long long v = w == 0 ? m[0] : w == 1 ? m[1] : w == 2 ? m[2] : m[3];
+    return (v >> (i & 63)) & 1ull;
+}
+// set bits below position i
+__device__ __forceinline__ int gz_mask_count_below(const unsigned long long (&m)[4], int i) {
+    int c = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int k = i - 64 * w;                          // bits of word w below i: all (k >= 64), none (k <= 0), the low k
+        const unsigned long long v = k >= 64 ? m[w] : k <= 0 ? 0ull : m[w] & ((1ull << k) - 1ull);
+        c += __popcll(v);
+    }
+    return c;
+}
+
 // Tokens of the segment s[a, b) of a member's text s[0, n): the same decisions whatever the sink.  EXACT: matches are judged
 // by the code lengths (size / emit passes, which therefore agree); otherwise by fixed thresholds (the sampling pass, before a
 // code exists).  ls[0 .. n_lines) = line starts (ls[l + 1] - 1 is line l's '\n'), line = index of the line position `a` is in.
-template <bool EXACT, class Sink>
+template <bool EXACT, class Sink, bool REC = false>
 __device__ __forceinline__ void gz_tokenize(const uint8_t* s, int a, int b, int line, const uint16_t* ls, int n_lines, bool use_lines,
-                                            const uint32_t* lc, const uint32_t* dc, Sink& sink) {
+                                            const uint32_t* lc, const uint32_t* dc, Sink& sink, GzTokMask* rec = nullptr) {
     int p = a;
     while (p < b) {
         const uint32_t c0 = s[p];
@@ -178,18 +207,56 @@ __device__ __forceinline__ void gz_tokenize(const uint8_t* s, int a, int b, int 
                 }
             }
         }
+        if (REC) {
+            gz_mask_set(rec->start, p - a);
+            if (best_len && best_dist != 1) gz_mask_set(rec->col, p - a);
+        }
         if (best_len) {
             sink.match(best_len, best_dist);
             if (use_lines)
-                for (int i = 0; i < best_len; ++i) line += s[p + i] == '\n' ? 1 : 0;
+                for (int i = 0; i < best_len; ++i) {
+                    const bool e = s[p + i] == '\n';
+                    line += e ? 1 : 0;
+                    if (REC && e) gz_mask_set(rec->nl, p + i - a);
+                }
             p += best_len;
         } else {
             sink.lit(c0);
-            line += (use_lines && c0 == '\n') ? 1 : 0;
+            const bool e = use_lines && c0 == '\n';
+            line += e ? 1 : 0;
+            if (REC && e) gz_mask_set(rec->nl, p - a);
             ++p;
         }
         if (line >= n_lines) line = n_lines - 1;       // (cannot happen: kept so that a bad table can never index past ls)
     }
+}
+
+// The emit pass: the tokens the size pass recorded, replayed.  line_a = the line byte `a` is in.
+template <class Sink>
+__device__ __forceinline__ void gz_replay(const uint8_t* s, int a, int b, int line_a, const uint16_t* ls, const GzTokMask& M, Sink& sink) {
+    const int nseg = b - a;
+    int prev = -1;                       // start of the token waiting for its end
+    auto emit = [&](int at, int len) {
+        if (len == 1) { sink.lit(s[a + at]); return; }
+        int dist = 1;
+        if (gz_mask_test(M.col, at)) {
+            const int p = a + at;
+            const int line = line_a + gz_mask_count_below(M.nl, at);
+            dist = p - ((int)ls[line - 4] + (p - (int)ls[line]));
+        }
+        sink.match(len, dist);
+    };
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        unsigned long long m = M.start[w];
+        while (m) {
+            const int at = 64 * w + (int)__builtin_ctzll(m);
+            m &= m - 1;
+            if (prev >= 0) emit(prev, at - prev);
+            prev = at;
+        }
+    }
+    if (prev >= 0) emit(prev, nseg - prev);
 }
 
 // text of one member into LDS + its line table.  The member's n bytes are RIGHT-aligned in the 256 x 255 grid: thread t owns
@@ -294,7 +361,8 @@ __global__ __launch_bounds__(GZ_THREADS) void gz_encode_kernel(GzJob J) {
     gz_stage_member(S, J.text[q] + off, n, a, b, line, use_lines);
     // ---- sizes -> positions
     GzSinkSize sz{lc, dc};
-    gz_tokenize<true>(S.text, a, b, line, S.ls, (int)S.n_lines, use_lines, lc, dc, sz);
+    GzTokMask tm;
+    gz_tokenize<true, GzSinkSize, true>(S.text, a, b, line, S.ls, (int)S.n_lines, use_lines, lc, dc, sz, &tm);
     uint32_t total_bits;
     const uint32_t my_bit = gz_block_excl_scan(sz.bits, S.scan, total_bits);
     const uint32_t hdr_bits = cb.hdr_bits;
@@ -312,7 +380,7 @@ __global__ __launch_bounds__(GZ_THREADS) void gz_encode_kernel(GzJob J) {
         __syncthreads();
         GzSinkEmit em{lc, dc, dwords, (hdr_bits + my_bit) >> 5};
         em.nacc = (int)((hdr_bits + my_bit) & 31u);
-        gz_tokenize<true>(S.text, a, b, line, S.ls, (int)S.n_lines, use_lines, lc, dc, em);
+        gz_replay(S.text, a, b, line, S.ls, tm, em);
         if (threadIdx.x == GZ_THREADS - 1) em.put(eob & 0xffffu, (int)(eob >> 16));       // end of block, behind the last segment
         em.finish();
         // the shared block header: whole words stored, the last (partial) one OR-ed in
