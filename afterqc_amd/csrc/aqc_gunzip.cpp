@@ -506,7 +506,15 @@ bool ParallelGunzip::member_end(uint64_t& bit) {
 // fold the finished events, in order, into the running member CRC; wait_all: wait for every translation task first
 void ParallelGunzip::drain_events(bool wait_all) {
     std::unique_lock<std::mutex> lk(sh_->mu);
-    if (wait_all) sh_->cv.wait(lk, [&] { return sh_->pending == 0; });
+    if (wait_all && pool_) {
+        // the consumer does not sleep while its translation pieces queue up behind the pool's sections: it takes pieces itself
+        while (sh_->pending != 0) {
+            lk.unlock();
+            const bool did = pool_->help_front();
+            lk.lock();
+            if (!did && sh_->pending != 0) sh_->cv.wait_for(lk, std::chrono::microseconds(100));
+        }
+    } else if (wait_all) sh_->cv.wait(lk, [&] { return sh_->pending == 0; });
     if (sh_->pending != 0) return;
     if (sh_->marker_error) fail("corrupt gzip data: a back-reference reaches before the start of its member");
     while (!sh_->events.empty()) {

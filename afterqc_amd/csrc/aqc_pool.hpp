@@ -1,9 +1,12 @@
 // aqc_pool.hpp — the I/O-side thread pool of the whole-input pipe (host code only): pread pieces, newline counts, inflate /
 // deflate of independent blocks, the speculative sections of the parallel gunzip.
 //   parallel_for   blocking, the caller works too; its jobs go to the FRONT lane (short, somebody waits for them)
-//   submit         fire and forget; `background` jobs (long speculative work: the gunzip sections) have a lane of their own.
-//                  A free worker serves the lanes in turn — front, background, front, ... — so that neither the gzip writers'
-//                  deflate batches nor the readers' inflate sections can starve the other
+//   submit         fire and forget; `background` jobs (long speculative work: the gunzip sections) have a lane of their own,
+//                  served only while the front lane is empty: a front job is short and somebody WAITS for it (the gunzip
+//                  consumer for the translation of the sections it just committed); a section is work for later.  (The lanes
+//                  used to be served in turn: every other visit of a worker then cost the waiting consumer a 7 ms section —
+//                  up to a section per worker and chunk, which is what held `.gz -> .gz` at 33 Mreads/s whoever decoded.)
+//   help_front     the caller runs one queued front job itself instead of sleeping until a worker gets to it
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -51,6 +54,19 @@ public:
             (background ? bg_ : q_).push_back(std::move(job));
         }
         cv_.notify_one();
+    }
+
+    // one front job, if there is one, on the calling thread
+    bool help_front() {
+        std::function<void()> job;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (q_.empty()) return false;
+            job = std::move(q_.front());
+            q_.pop_front();
+        }
+        job();
+        return true;
     }
 
     // run fn(i) for i in [0, n) on the pool and wait for all of them
@@ -105,7 +121,7 @@ private:
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return stop_ || !q_.empty() || !bg_.empty(); });
-                const bool take_bg = !bg_.empty() && (q_.empty() || (turn_++ & 1));
+                const bool take_bg = !bg_.empty() && q_.empty();
                 if (take_bg) { job = std::move(bg_.front()); bg_.pop_front(); }
                 else if (!q_.empty()) { job = std::move(q_.front()); q_.pop_front(); }
                 else if (stop_) return;
@@ -119,7 +135,6 @@ private:
     std::mutex mu_;
     std::condition_variable cv_;
     bool stop_ = false;
-    unsigned turn_ = 0;
 };
 
 }  // namespace aqc_host
