@@ -1145,7 +1145,7 @@ public:
     }
 
 private:
-    static constexpr int N_LANES = 2, N_ARENAS = 5;
+    static constexpr int N_LANES = 3, N_ARENAS = 8;
     struct Group {
         const uint8_t* data; size_t size; int n;
         std::vector<uint64_t> nominal, stop;

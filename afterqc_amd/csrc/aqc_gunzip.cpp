@@ -372,7 +372,7 @@ void ParallelGunzip::to_pool(const std::shared_ptr<Section>& s) {
 // the next window of section indices: [win_lo_, win_hi_); the file's last section runs to the end of the file (its stop bit is
 // "none"), which the device cannot take: it goes to the pool at once
 void ParallelGunzip::next_window() {
-    const size_t per_group = std::max<size_t>(1, (offload_ ? std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ * 2 / 9)) : section_bytes_) / section_bytes_);
+    const size_t per_group = std::max<size_t>(1, (offload_ ? std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ / 6)) : section_bytes_) / section_bytes_);
     win_hi_ = std::min(last_idx_ + 1, win_lo_ + win_groups_ * per_group);
     pool_next_ = win_lo_;
     dev_hi_ = win_hi_;
@@ -404,7 +404,7 @@ void ParallelGunzip::top_up(bool need_front) {
         size_t on_pool = 0, on_device = 0;
         for (auto& kv : q_) (kv.second->offloaded ? on_device : on_pool)++;
         const bool front_missing = need_front && (q_.empty() || q_.begin()->first >= lowest_uncreated());
-        const size_t per_group = std::max<size_t>(1, (offload_ ? (offload_only_ ? offload_->group_bytes() : std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ * 2 / 9)))
+        const size_t per_group = std::max<size_t>(1, (offload_ ? (offload_only_ ? offload_->group_bytes() : std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ / 6)))
                                                                : section_bytes_) / section_bytes_);
         // The pool's share, from the bottom of the window up: the sections the consumer wants next.  (With a device decoder it
         // may work twice as far ahead: it is the only one feeding the consumer while a device group is under way.)
@@ -672,36 +672,48 @@ size_t ParallelGunzip::read(uint8_t* dst, size_t want) {
             cur_bit_ = (uint64_t)h * 8;
         }
     }
+    auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (out < want && !bad_ && !done_) {
-        if (bridge_state_ && bridge_state_->active) { bridge(0, dst, out, want); continue; }
+        if (bridge_state_ && bridge_state_->active) { const uint64_t t0 = now_us(); bridge(0, dst, out, want); us_bridge += now_us() - t0; continue; }
         // the lowest section in the queue may be committed next only if every section below it has been created (the device's
         // groups come from the top of the window: there may be a gap below them that nobody has been given yet)
+        uint64_t t0 = now_us();
         for (bool need = false;; need = true) {
             top_up(need);
             if (!q_.empty() && q_.begin()->first < lowest_uncreated()) break;
             if (lowest_uncreated() > last_idx_) break;            // nothing left to create
             if (need) std::this_thread::sleep_for(std::chrono::microseconds(50));      // (offload_only: a device lane is about to be free)
         }
-        if (q_.empty()) { bridge(UINT64_MAX, dst, out, want); continue; }
+        uint64_t t1 = now_us();
+        us_top_up += t1 - t0;
+        if (q_.empty()) { bridge(UINT64_MAX, dst, out, want); us_bridge += now_us() - t1; continue; }
         std::shared_ptr<Section> f = q_.begin()->second;
         {
             GZ_PROF(4);
             std::unique_lock<std::mutex> lk(f->mu);
             f->cv.wait(lk, [&] { return f->done; });
         }
+        t0 = now_us();
+        (f->offloaded ? us_wait_device : us_wait_pool) += t0 - t1;
         const bool usable = f->found && !f->error;
         if (usable && f->start_bit == cur_bit_) {
             GZ_PROF(5);
             accept(*f, dst, out, want);
             q_.erase(q_.begin());
+            us_accept += now_us() - t0;
         } else if (usable && f->start_bit > cur_bit_) {
             bridge(f->start_bit, dst, out, want);
+            us_bridge += now_us() - t0;
         } else {
             q_.erase(q_.begin());
             sections_discarded++;
         }
     }
-    drain_events(true);
+    {
+        const uint64_t t0 = now_us();
+        drain_events(true);
+        us_drain += now_us() - t0;
+    }
     if (bad_) return 0;
     return out;
 }

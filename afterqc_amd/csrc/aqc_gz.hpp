@@ -130,6 +130,9 @@ public:
     // statistics
     uint64_t sections_accepted = 0, sections_discarded = 0, bridged_bytes = 0, total_out = 0;
     uint64_t sections_offloaded = 0, offloaded_accepted = 0, offloaded_bytes = 0;      // handed to the device / committed from it / their text
+    // where the consumer's wall time inside read() went, microseconds: waiting for a section of the pool / of the device to be
+    // decoded, waiting for (and helping with) the translation of what it committed, handing out work, committing, bridging
+    uint64_t us_wait_pool = 0, us_wait_device = 0, us_drain = 0, us_top_up = 0, us_accept = 0, us_bridge = 0;
 
     struct Section;
     struct Shared;
@@ -169,7 +172,7 @@ private:
     // (dev_hi_) — the consumer commits in index order, so it reaches a device group only after everything the pool did in
     // front of it, which is as long as the device can possibly be given; the two meet wherever their speeds put them.
     size_t start_idx_ = 0, last_idx_ = 0, win_lo_ = 0, win_hi_ = 0, pool_next_ = 0, dev_hi_ = 0;
-    size_t win_groups_ = 8, keep_fifths_ = 12;       // AQC_GZ_WINDOW / AQC_GZ_KEEP (read when the decoder is made)
+    size_t win_groups_ = 8, keep_fifths_ = 2;        // AQC_GZ_WINDOW / AQC_GZ_KEEP (read when the decoder is made)
     uint64_t start_bit0_ = 0;
     uint64_t cur_bit_ = 0;                         // everything before this bit is decoded and committed
     bool started_ = false, done_ = false, bad_ = false;

@@ -316,6 +316,9 @@ struct GzSource : Source {
                 fprintf(stderr, "pipe: gunzip — %llu sections committed (%llu from the device of %llu handed to it), %llu discarded, %.1f MB of %.1f MB decoded sequentially\n",
                         (unsigned long long)pg->sections_accepted, (unsigned long long)pg->offloaded_accepted, (unsigned long long)pg->sections_offloaded,
                         (unsigned long long)pg->sections_discarded, 1e-6 * (double)pg->bridged_bytes, 1e-6 * (double)pg->total_out);
+            if (getenv("AQC_PIPE_DEBUG"))
+                fprintf(stderr, "pipe: gunzip consumer, ms inside read() — waiting for a pool section %.1f, for a device section %.1f, for the translation of what it committed %.1f, handing out work %.1f, committing %.1f, decoding sequentially %.1f\n",
+                        pg->us_wait_pool / 1e3, pg->us_wait_device / 1e3, pg->us_drain / 1e3, pg->us_top_up / 1e3, pg->us_accept / 1e3, pg->us_bridge / 1e3);
         }
         pg.reset();
         if (map) munmap((void*)map, size);
@@ -679,7 +682,7 @@ struct Run {
                 const char* e = getenv("AQC_GZ_DEVICE_IN");
                 if (!(e && e[0] == '0') && !P->gz_offload_tried[f] && !P->ctx.empty()) {      // (set up with the first .gz input of this file slot)
                     P->gz_offload_tried[f] = true;
-                    size_t group = 192u << 20;
+                    size_t group = 96u << 20;
                     if (const char* g = getenv("AQC_GZ_GROUP")) group = (size_t)std::max(1ll, atoll(g));
                     P->gz_offload[f].reset(aqcgz::make_device_offload(aqc_device_index(P->ctx[(size_t)f % P->ctx.size()]), group));
                 }
