@@ -45,6 +45,17 @@ def test_device_gunzip_logic_on_the_cpu(tmp_path):
     assert "all device-gunzip logic checks passed" in out.stdout
 
 
+def test_pool_lane_policy(tmp_path):
+    """csrc/aqc_pool.hpp: queued front jobs (somebody waits for them: the gunzip consumer's translation pieces) are all started
+    before any further background job (speculative sections); help_front() lets the waiting thread run them itself;
+    parallel_for completes with every worker stuck in background work (tests/native/pool_selftest.cpp)"""
+    exe = str(tmp_path / "pool_selftest")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "native", "pool_selftest.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
+    assert "all pool checks passed" in out.stdout
+
+
 def _read_all(path, section=0, threads=4, piece=1 << 20):
     s = capi.NativeSource(path, True, io_threads=threads, gz_section_bytes=section)
     out = bytearray()
