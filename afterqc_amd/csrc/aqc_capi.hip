@@ -1145,7 +1145,9 @@ public:
     }
 
 private:
-    static constexpr int N_LANES = 3, N_ARENAS = 8;
+    // (two lanes: one group is uploaded / downloaded while the other decodes; a third gave nothing measurable (gpurun_out/r4c30) and
+    //  a lane's device buffers are ~15 GB for groups of 96 MiB: symbol and token space for 12 x expansion)
+    static constexpr int N_LANES = 2, N_ARENAS = 6;
     struct Group {
         const uint8_t* data; size_t size; int n;
         std::vector<uint64_t> nominal, stop;
