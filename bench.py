@@ -23,7 +23,7 @@ Other numbers on the same JSON line (never `value`):
                                on the slot's stream, algorithmic bytes 4L+56 per pair.
   pinned_to_pinned_mreads_s    the pipe fed from / fetched into page-locked host memory (PCIe inclusive, no files)
   file_to_file_gz              the pipe .gz -> .gz: ONE-member `gzip -2` inputs decoded by the host pool AND the GPU (groups of sections,
-                               a lane per deflate block: aqc_gunzip_dev.hpp; `gunzip_text_share_from_device`), .gz members built on the device (--gz-runs; by default two runs when the input is the 1-GPU one)
+                               a lane per deflate block: aqc_gunzip_dev.hpp; `gunzip_text_share_from_device`), .gz members built on the device (--gz-runs; by default three runs when the input is the 1-GPU one)
   file_to_gz                   plain FASTQ in, .gz out (the outputs a third of the size: the file writers are not the bound)
   multi_input_file_to_file     K (--inputs, default 2) independent inputs through K pipes at once on the same GPU: the reference's own
                                parallelism is one seqFilter per input file (after.py:168-171), and K inputs write 4 K files
@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--chunk-records", type=int, default=1 << 17, help="records per chunk of the pipe")
     ap.add_argument("--pipe-runs", type=int, default=3, help="timed runs of the pinned->pinned pipe (0 = skip)")
     ap.add_argument("--device-steps", type=int, default=10, help="timed steps of the HBM-resident device pipeline (0 = skip)")
-    ap.add_argument("--gz-runs", type=int, default=-1, help="timed .gz -> .gz runs of the pipe (0 = skip; default: 2 for the 1-GPU input, where making "
+    ap.add_argument("--gz-runs", type=int, default=-1, help="timed .gz -> .gz runs of the pipe (0 = skip; default: 3 for the 1-GPU input, where making "
                     "the inputs with gzip -2 takes ~20 s, else 0)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with two rocprofv3 --pmc child runs (quote profiles/hbm_traffic.json)")
     ap.add_argument("--device-only", action="store_true", help="profiling runs (rocprofv3): only the HBM-resident device step, no pipe "
@@ -440,7 +440,7 @@ def main():
                             os.unlink(pth)
         # ---- the same through gzip both ways: one-member inputs decoded by the host pool (the box's CPU quota is the bound),
         # .gz members built on the device
-        gz_runs = args.gz_runs if args.gz_runs >= 0 else (2 if copies == 1 and shutil.which("gzip") else 0)
+        gz_runs = args.gz_runs if args.gz_runs >= 0 else (3 if copies == 1 and shutil.which("gzip") else 0)
         if gz_runs > 0 and rank == 0 and not args.device_only:
             import subprocess
             gz_paths = [p + ".gz" for p in paths]
