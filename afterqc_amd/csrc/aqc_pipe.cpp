@@ -556,6 +556,7 @@ struct aqc_pipe {
     // page-locked arenas are as expensive to set up as a whole run)
     std::unique_ptr<aqcgz::SectionOffload> gz_offload[2];
     bool gz_offload_tried[2] = {false, false};
+    bool gz_offload_warm[2] = {false, false};       // the decoder of this file slot has run before: its device buffers and page-locked arenas exist
 };
 
 namespace {
@@ -686,11 +687,18 @@ struct Run {
                     if (const char* g = getenv("AQC_GZ_GROUP")) group = (size_t)std::max(1ll, atoll(g));
                     P->gz_offload[f].reset(aqcgz::make_device_offload(aqc_device_index(P->ctx[(size_t)f % P->ctx.size()]), group));
                 }
-                // (a device group costs ~50 ms whatever its size: files the pool finishes sooner than that are left to the pool)
-                size_t dev_min = 48u << 20;
+                // Which files the device is asked for.  Its first use in a process costs what a run of 10 M reads takes: ~15 GB of
+                // device buffers per lane, gigabytes of page-locked arenas, and their release at the end (measured through the CLI,
+                // gpurun_out/r4c32: pass 2 of a fresh process 0.35 s with the pool alone, 0.72 s with the device's help — while the
+                // same input in a warm pipe takes 0.24 s against 0.33).  So a COLD decoder is only started for an input big enough
+                // to pay that back (>= 4 GiB compressed), a warm one — the pipe object has decoded a .gz input of this slot with it
+                // before: a service, a folder of files, bench.py — takes every file the pool would need longer for than a group
+                // takes the device (48 MiB).  AQC_GZ_DEVICE_MIN=<bytes> sets the limit for both.
+                size_t dev_min = P->gz_offload_warm[f] ? (size_t)(48u << 20) : (size_t)4 << 30;
                 if (const char* m = getenv("AQC_GZ_DEVICE_MIN")) dev_min = (size_t)std::max(0ll, atoll(m));
                 struct stat gst;
-                const bool big = stat(io->in_path[f], &gst) == 0 && (size_t)gst.st_size >= dev_min;
+                const bool big = P->gz_offload[f] && stat(io->in_path[f], &gst) == 0 && (size_t)gst.st_size >= dev_min;
+                if (big && !(e && e[0] == '0')) P->gz_offload_warm[f] = true;
                 src.reset(new GzSource(io->in_path[f], P->pool.get(), 0, (big && !(e && e[0] == '0')) ? P->gz_offload[f].get() : nullptr));
             }
             else src.reset(new FileSource(io->in_path[f], P->pool.get()));
