@@ -1,7 +1,7 @@
-// aqc_gunzip_dev.hpp — gzip INPUT decoded on the device (round 4): one LANE per DEFLATE BLOCK (fastq.py:23-24 upstream: gzip.open +
-// readline on the one CPU thread).
+// aqc_gunzip_dev.hpp — gzip INPUT decoded on the device (round 4): the unit of work is the DEFLATE BLOCK, read by 32 lanes
+// (fastq.py:23-24 upstream: gzip.open + readline on the one CPU thread).
 //
-// Why a lane per block.  Huffman decoding is one dependency chain per stream — bit position -> table entry -> next bit
+// Why the block.  Huffman decoding is one dependency chain per stream — bit position -> table entry -> next bit
 // position — and nothing inside a block breaks it.  Round 3's decoder gave a whole WAVE to one stream (64 lanes guessing token
 // starts, a scalar walk picking the real ones): 5 tokens per ~4,800-cycle round, 4 MB/s per wave, 2.75 GB/s per GPU.  But one
 // gzip stream is tens of thousands of blocks (zlib closes a block every 16 K tokens: ~110 KB of FASTQ text at level 6), every
@@ -15,12 +15,18 @@
 //                       must parse and form a complete literal/length code with an end-of-block symbol and a usable distance code.
 //   gzb_compact_kernel  the per-tile hits become one sorted candidate list; a candidate's output space is sized from the
 //                       compressed bytes up to the next candidate.
-//   gzb_decode_kernel   a LANE per candidate: builds its own tables (12-bit literal/length and 10-bit distance roots, 16-bit
-//                       entries; longer codes: canonical search) and turns its block into TOKENS (literal | length, distance) the
-//                       way a CPU thread reads a Huffman stream — a 64-bit bit buffer whose next word is always on its way, one
-//                       table look-up per code — in slices of a few hundred tokens per launch.  Thousands of lanes at once.
-//   gzb_expand_kernel   a WAVE per block applies the tokens: literals of 64 tokens stored at once, every match copied by the
-//                       64 lanes together, into 16-bit SYMBOLS (>= 0x8000: "byte j of the 32 KiB before this BLOCK").
+//   gzb_tables_kernel   a lane per candidate builds the block's tables (11-bit literal/length and 10-bit distance roots, 16-bit
+//                       entries; longer codes: canonical search) and plans where its GZB_K = 32 lanes start and stop.
+//   gzb_decode_kernel   a lane per (candidate, entry point) turns its stretch of the block into TOKENS (literal | length,
+//                       distance; each with the bit it starts at) the way a CPU thread reads a Huffman stream — from a GUESSED
+//                       bit inside the block: what follows a bit position depends on nothing but the tables, and Huffman
+//                       streams re-synchronise within tens of tokens, so each lane reads on into its successor's share.
+//                       Tables and a window of the stream in LDS, in slices of 2048 tokens per launch.
+//   gzb_expand_kernel   a WAVE per block stitches the lanes' lists together — lane k + 1's list takes over at the first bit
+//                       position both lists hold a token at: found by search, never assumed, so the block is exact or counts
+//                       as failed — and applies the tokens, 64 at a time: literals stored at once, the matches that copy from
+//                       before the chunk all together, the others one by one with the 64 lanes sharing the copy; into 16-bit
+//                       SYMBOLS (>= 0x8000: "byte j of the 32 KiB before this BLOCK").
 //   gzb_chain_kernel    a lane per SECTION (the host's unit of work, aqc_gunzip.cpp): from the first candidate at or behind the
 //                       section's nominal start it follows  end of block == start of a candidate  until the section's stop bit;
 //                       stored blocks (pigz's sync markers) are stepped over in place.  A false candidate never chains up.
@@ -62,11 +68,11 @@ GZB_HD inline uint32_t gzb_rev(uint32_t c, uint32_t len) {
 
 constexpr uint32_t GZB_MARKER = 0x8000u;
 constexpr int GZB_LROOT = 11, GZB_DROOT = 10;
-// A lane's decoding tables, 16-bit entries: literal/length root (2^12), distance root (2^10), symbols sorted by code (288 + 32),
-// codes per length (16 + 16), in the candidate's own 11 KiB of global memory (with its 320 code lengths behind them).  Roots this
-// wide make a code longer than the root — the canonical search, a dozen dependent loads — a rarity: with 9 bits SOME lane of a
-// wave needed it in most iterations, and the whole wave waits for it.  (The tables were in LDS for a while, round 4's second
-// version, 124 KiB per wave: no faster, and a decoder that fills a CU's LDS keeps the filter's kernels off that CU.)
+// A block's decoding tables, 16-bit entries: literal/length root (2^11), distance root (2^10), symbols sorted by code (288 + 32),
+// codes per length (16 + 16), in the candidate's own 7 KiB of global memory (with its 320 code lengths behind them); the token
+// kernel copies them into LDS (two blocks' tables per workgroup of 64 lanes: 14 KiB).  Roots this wide make a code longer than
+// the root — the canonical search, a dozen dependent look-ups — a rarity: with 9 bits SOME lane of a wave needed it in most
+// iterations, and the whole wave waits for it.
 constexpr int GZB_E_DIST = 1 << GZB_LROOT, GZB_E_LSORT = GZB_E_DIST + (1 << GZB_DROOT), GZB_E_DSORT = GZB_E_LSORT + 288, GZB_E_LCOUNT = GZB_E_DSORT + 32,
               GZB_E_DCOUNT = GZB_E_LCOUNT + 16, GZB_TAB_ENTRIES = GZB_E_DCOUNT + 16;
 constexpr int GZB_TAB_WORDS = GZB_TAB_ENTRIES / 2 + 80;          // 32-bit words per candidate: the tables, then the code lengths
