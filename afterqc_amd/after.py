@@ -58,7 +58,7 @@ OPTIONS = [
     ("", "--mask_mismatch", dict(action="store_true", default=False, help="set the qual num to 0 for mismatched base pairs in overlapped areas to mask them out")),
     ("", "--no_overlap", dict(action="store_true", default=False, help="disable overlap analysis (usually much faster with this option)")),
     ("-z", "--gzip", dict(action="store_true", default=False, help="force gzip compression for output, even the input is not gzip compressed")),
-    ("", "--compression", dict(type="int", default=2, help="set compression level (0~9) for gzip output, default is 2 (0 = best speed, 9 = best compression).")),
+    ("", "--compression", dict(type="int", default=2, help="set compression level (0~9) for gzip output, default is 2 (0 = best speed, 9 = best compression).  Here: 1-9 all use the GPU's encoder (ratio about zlib level 2-3); 0 writes stored members; AQC_GZ_DEVICE=0 builds the files on the host at a speed / ratio that follows the level")),
 ]
 
 
