@@ -314,7 +314,7 @@ int main(int argc, char** argv) {
     }
     if (argc > 2) {
         const std::vector<uint8_t> gz = slurp(argv[1]), text = slurp(argv[2]);
-        g_max_slices = 16; g_slice_tokens = 1024;
+        g_max_slices = 6; g_slice_tokens = 2048;          // (DeviceInflate::run_group's defaults)
         const bool ok = run_case(argv[1], gz, text, argc > 3 ? (size_t)atol(argv[3]) : 65536, argc > 4 ? (size_t)atol(argv[4]) : 1 << 20, 4, true, argc > 5 ? (uint32_t)atoi(argv[5]) : 12);
         return ok ? 0 : 1;
     }

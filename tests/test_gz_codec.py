@@ -45,6 +45,30 @@ def test_device_gunzip_logic_on_the_cpu(tmp_path):
     assert "all device-gunzip logic checks passed" in out.stdout
 
 
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_device_gunzip_logic_on_gnu_gzip_files(tmp_path, level):
+    """files written by the `gzip` PROGRAM (GNU gzip closes a block every 32 K tokens, twice zlib's) through the same CPU emulation
+    of the device decoder in its file mode, which runs with the kernels' own budget (6 slices of 2048 tokens per lane, 12 x symbol
+    space): byte-identical, and the emulated device supplied sections"""
+    import shutil
+    if not shutil.which("gzip"):
+        pytest.skip("no gzip program")
+    exe = str(tmp_path / "gzb_selftest")
+    src = [os.path.join(ROOT, "tests", "native", "gzb_selftest.cpp")] + [os.path.join(ROOT, "afterqc_amd", "csrc", f) for f in ("aqc_inflate.cpp", "aqc_gunzip.cpp")]
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wno-stringop-overflow"] + src + ["-lz", "-o", exe])
+    d = synth.make_pairs(30000, 150, seed=300 + level, dirty=True)
+    buf, n = synth.render_fastq_fixed(d["seq1"], d["qual1"], 1)
+    plain = str(tmp_path / "t.fq")
+    with open(plain, "wb") as f:
+        f.write(memoryview(buf)[:n])
+    with open(plain + ".gz", "wb") as g:
+        subprocess.check_call(["gzip", "-%d" % level, "-c", plain], stdout=g)
+    out = subprocess.run([exe, plain + ".gz", plain, str(256 << 10), str(2 << 20), "12"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
+    line = out.stdout.strip().splitlines()[-1]
+    assert " ok " in line and "failed 0" in line, line
+
+
 def test_pool_lane_policy(tmp_path):
     """csrc/aqc_pool.hpp: queued front jobs (somebody waits for them: the gunzip consumer's translation pieces) are all started
     before any further background job (speculative sections); help_front() lets the waiting thread run them itself;
