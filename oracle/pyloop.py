@@ -101,6 +101,13 @@ def overlap_hm(r1, r2):
     return 0, 0, 0
 
 
+def change_string(s, pos, val):
+    """util.py:236-239: list assignment — a negative position counts from the end, one outside the string raises IndexError"""
+    lst = list(s)
+    lst[pos] = val
+    return "".join(lst)
+
+
 def process_pair(s1, q1, s2, q2, opt):
     """preprocesser.py:436-631 for one record without barcode / bubble.  `opt`: dict with the option names of the CLI.
     Returns dict(flag, seq1, qual1, seq2, qual2, offset, overlap_len, distance, edits=[(o, kind, base, qual)])"""
@@ -154,25 +161,24 @@ def process_pair(s1, q1, s2, q2, opt):
                     fixed = False
                     if ord(qa) - 33 >= 30 and ord(qb) - 33 <= 14:
                         if not opt["no_correction"]:
-                            p = len(s2) - o - 1
-                            s2 = s2[:p] + COMP[b1] + s2[p + 1:]
-                            q2 = q2[:p] + qa + q2[p + 1:]
+                            # (:578-579: EACH string by its own end — they differ when the quality line is not as long as the
+                            #  sequence line, which the reference never checks)
+                            s2 = change_string(s2, -o - 1, COMP[b1])
+                            q2 = change_string(q2, -o - 1, qa)
                             res["edits"].append((o, EDIT_FIX_R2, COMP[b1], qa))
                             corrected += 1
                             fixed = True
                     elif ord(qb) - 33 >= 30 and ord(qa) - 33 <= 14:
                         if not opt["no_correction"]:
-                            p = len(s1) - overlap_len + o
-                            s1 = s1[:p] + b2 + s1[p + 1:]
-                            q1 = q1[:p] + qb + q1[p + 1:]
+                            s1 = change_string(s1, len(s1) - overlap_len + o, b2)           # :586-587
+                            q1 = change_string(q1, len(q1) - overlap_len + o, qb)
                             res["edits"].append((o, EDIT_FIX_R1, b2, qb))
                             corrected += 1
                             fixed = True
                     if not fixed:
                         if opt["mask_mismatch"]:
-                            p1, p2 = len(q1) - overlap_len + o, len(q2) - o - 1
-                            q1 = q1[:p1] + "!" + q1[p1 + 1:]
-                            q2 = q2[:p2] + "!" + q2[p2 + 1:]
+                            q2 = change_string(q2, -o - 1, "!")                                # :594-595
+                            q1 = change_string(q1, len(q1) - overlap_len + o, "!")
                             res["edits"].append((o, EDIT_MASK, "\0", "!"))
                             masked += 1
                         else:
