@@ -190,6 +190,63 @@ def process_pair(s1, q1, s2, q2, opt):
     return done(GOOD)
 
 
+class CycleQC:
+    """qualitycontrol.py:73-156 without the k-mer dictionary: the per-cycle accumulators of statRead and what qc() derives from
+    them (the lists the stats JSON carries, squeezed to the read length, preprocesser.py:703-740)."""
+    MAX_LEN = 1000                                                                              # qualitycontrol.py:20
+
+    def __init__(self):
+        n = self.MAX_LEN
+        self.total_num = [0] * n
+        self.total_qual = [0] * n
+        self.base_counts = dict((b, [0] * n) for b in ALL_BASES)
+        self.base_total_qual = dict((b, [0] * n) for b in ALL_BASES)
+        self.total_discontinuity = [0] * n
+
+    def stat_read(self, seq, qual):
+        """:73-110.  The position is COUNTED before the quality is looked at; a quality line that has no character there
+        (IndexError, swallowed at :84) skips everything else of the position — quality sum, base count, discontinuity."""
+        seqlen = len(seq)
+        for i in range(seqlen):
+            self.total_num[i] += 1
+            if i >= len(qual):
+                continue
+            qnum = ord(qual[i]) - 33
+            self.total_qual[i] += qnum
+            b = seq[i]
+            if b in ALL_BASES:
+                self.base_counts[b][i] += 1
+                self.base_total_qual[b][i] += qnum
+            left, right = i - 2, i + 3
+            if left < 0:
+                left, right = 0, 5
+            elif right >= seqlen:
+                right, left = seqlen, seqlen - 5
+            self.total_discontinuity[i] += sum(1 for j in range(left, right - 1) if seq[j] != seq[j + 1])
+
+    def derived(self):
+        """:124-156 + squeeze(): read length = first cycle without any A/T/C/G; then the four lists of the stats JSON"""
+        read_len = 0
+        for pos in range(self.MAX_LEN):
+            if not any(self.base_counts[b][pos] > 0 for b in ALL_BASES):
+                read_len = pos
+                break
+        percents = dict((b, [0.0] * read_len) for b in ALL_BASES)
+        gc = [0.0] * read_len
+        mean_qual = [0.0] * read_len
+        base_mean_qual = dict((b, [0.0] * read_len) for b in ALL_BASES)
+        for pos in range(read_len):
+            total = sum(self.base_counts[b][pos] for b in ALL_BASES)
+            for b in ALL_BASES:
+                percents[b][pos] = float(self.base_counts[b][pos]) / float(total)
+            gc[pos] = float(self.base_counts["G"][pos] + self.base_counts["C"][pos]) / float(total)
+            mean_qual[pos] = float(self.total_qual[pos]) / float(self.total_num[pos])
+            for b in ALL_BASES:
+                if self.base_counts[b][pos] > 0:
+                    base_mean_qual[b][pos] = float(self.base_total_qual[b][pos]) / float(self.base_counts[b][pos])
+        return {"readlen": read_len, "base_content": percents, "gc_content": gc, "mean_quality": mean_qual, "base_quality": base_mean_qual}
+
+
 def options_from_config(cfg):
     """the fields of afterqc_amd.capi.Config this restatement consults"""
     return dict((k, int(getattr(cfg, k))) for k in (

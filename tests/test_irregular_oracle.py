@@ -66,6 +66,12 @@ def test_pyloop_equals_the_reference_on_irregular_records(case):
     assert irregular >= 1
     out = {"good/R1.good.fq": [], "good/R2.good.fq": [], "bad/R1.bad.fq": [], "bad/R2.bad.fq": []}
     died = None
+    # statRead (qualitycontrol.py:73-110) over the raw reads (pre-filter: the 24-record file is sampled whole, :352-355) and over
+    # the GOOD reads as the loop leaves them (post-filter, preprocesser.py:619-622)
+    qc = dict((k, pyloop.CycleQC()) for k in ("read1_prefilter", "read2_prefilter", "read1_postfilter", "read2_postfilter"))
+    for a, b in zip(r1, r2):
+        qc["read1_prefilter"].stat_read(a[1], a[3])
+        qc["read2_prefilter"].stat_read(b[1], b[3])
     for i, (a, b) in enumerate(zip(r1, r2)):
         try:
             res = pyloop.process_pair(a[1], a[3], b[1], b[3], opt)
@@ -77,6 +83,9 @@ def test_pyloop_equals_the_reference_on_irregular_records(case):
         if flag != pyloop.GOOD:                                  # preprocesser.py:206-220: the flag goes into the name
             n1, n2 = "@" + FLAG_NAME[flag] + n1[1:], "@" + FLAG_NAME[flag] + n2[1:]
         where = "good" if flag == pyloop.GOOD else "bad"
+        if flag == pyloop.GOOD:
+            qc["read1_postfilter"].stat_read(res["seq1"], res["qual1"])
+            qc["read2_postfilter"].stat_read(res["seq2"], res["qual2"])
         out["%s/R1.%s.fq" % (where, where)].append("%s\n%s\n%s\n%s\n" % (n1, res["seq1"], a[2], res["qual1"]))
         out["%s/R2.%s.fq" % (where, where)].append("%s\n%s\n%s\n%s\n" % (n2, res["seq2"], b[2], res["qual2"]))
     if c["returncode"] != 0:
@@ -88,6 +97,20 @@ def test_pyloop_equals_the_reference_on_irregular_records(case):
         assert died is None
     for name, want in c["files"].items():
         assert "".join(out[name]) == want, (case, name)
+    if c["returncode"] == 0:
+        summ = c["stat"]["afterqc_main_summary"]
+        assert summ["total_reads"] == 24 and summ["good_reads"] == len(out["good/R1.good.fq"]) and summ["bad_reads"] == len(out["bad/R1.bad.fq"])
+        assert summ["bad_reads_with_low_quality"] == sum(1 for x in out["bad/R1.bad.fq"] if x.startswith("@BADLQC"))
+        # good_bases: the SEQUENCE lines of the good reads 1, whatever their quality lines are (preprocesser.py:621-623: read 2's
+        # are only added when there is an index-2 file — an upstream quirk the product keeps too)
+        assert summ["good_bases"] == sum(len(x.split("\n")[1]) for x in out["good/R1.good.fq"])
+    if c["returncode"] == 0:
+        # the per-cycle lists of the stats JSON, to the last bit: positions a short quality line does not cover are counted in the
+        # mean quality's denominator and nowhere else
+        for key, q in qc.items():
+            d = q.derived()
+            for section in ("mean_quality", "gc_content", "base_content", "base_quality"):
+                assert d[section] == c["stat"][section][key], (case, section, key)
     if c["returncode"] == 0:
         # some of the irregular records really went through the correction walk with shifted quality indices
         changed = sum(1 for k, (a, b) in enumerate(zip(r1, r2)) if (len(a[1]) != len(a[3]) or len(b[1]) != len(b[3])) and
