@@ -38,7 +38,11 @@ K_FILTER_OVERLAP, K_QC_STAT, N_KERNELS = 0, 1, 2
 UINT64_MAX = (1 << 64) - 1
 
 ERRORS = {-1: "HIP runtime error", -2: "bad argument", -3: "read longer than AQC_MAX_READ_LEN", -4: "no gfx950 device",
-          -5: "bad call sequence", -6: "byte outside the reference's COMP alphabet", -7: "unsupported option value"}
+          -5: "bad call sequence", -6: "byte outside the reference's COMP alphabet", -7: "unsupported option value",
+          -8: "quality line too short for the overlap walk (IndexError upstream)"}
+ERR_ARG, ERR_ALPHABET, ERR_INDEX = -2, -6, -8
+# errors that end the reference's run AT A RECORD (an exception inside its loop): the records before it were written
+RECORD_ERRORS = (ERR_ARG, ERR_ALPHABET, ERR_INDEX)
 
 # numpy view of struct aqc_result (packed, 32 bytes)
 EDIT_DTYPE = np.dtype([("o", "<u2"), ("kind", "u1"), ("base", "u1"), ("qual", "u1")])
@@ -73,7 +77,7 @@ class BatchStruct(C.Structure):
                 ("seq2", C.c_void_p), ("qual2", C.c_void_p), ("off2", C.c_void_p), ("qoff2", C.c_void_p),
                 ("len2", C.c_void_p), ("bytes2", C.c_uint64), ("qbytes2", C.c_uint64),
                 ("aux_lane", C.c_void_p), ("aux_tile", C.c_void_p), ("aux_x", C.c_void_p), ("aux_y", C.c_void_p),
-                ("aux_ok", C.c_void_p)]
+                ("aux_ok", C.c_void_p), ("qlen1", C.c_void_p), ("qlen2", C.c_void_p)]
 
 
 def _ptr(a):
@@ -154,6 +158,7 @@ class Batch:
         self.first_index = first_index
         self.seq1 = self.qual1 = self.off1 = self.len1 = self.qoff1 = None
         self.seq2 = self.qual2 = self.off2 = self.len2 = self.qoff2 = None
+        self.qlen1 = self.qlen2 = None     # lengths of the quality strings where some differ from the reads' (None: all equal)
         self.aux = None  # (lane, tile, x, y, ok) int32 x4 + uint8
         self._keep = None
 
@@ -233,15 +238,19 @@ class Batch:
     def from_raw(cls, rb1, rb2=None, first_index=0):
         """Zero-copy view of framed FASTQ text (afterqc_amd.fastq.RawBatch): the text chunk is the arena."""
         b = cls(rb1.n, first_index)
-        if not np.array_equal(rb1.seq_len, rb1.qual_len):
-            raise ValueError("malformed FASTQ: sequence and quality lines differ in length (read 1)")
         b.seq1 = b.qual1 = rb1.text
         b.off1, b.qoff1, b.len1 = rb1.seq_off, rb1.qual_off, rb1.seq_len
+        # a quality line that is not as long as its sequence line is no error upstream (fastq.py:37-49 does not look): the
+        # quality strings travel with lengths of their own (aqc_batch.qlen1 / qlen2)
+        irregular = not np.array_equal(rb1.seq_len, rb1.qual_len)
         if rb2 is not None:
-            if not np.array_equal(rb2.seq_len, rb2.qual_len):
-                raise ValueError("malformed FASTQ: sequence and quality lines differ in length (read 2)")
             b.seq2 = b.qual2 = rb2.text
             b.off2, b.qoff2, b.len2 = rb2.seq_off, rb2.qual_off, rb2.seq_len
+            irregular = irregular or not np.array_equal(rb2.seq_len, rb2.qual_len)
+        if irregular:
+            b.qlen1 = np.ascontiguousarray(rb1.qual_len, dtype=np.uint32)
+            if rb2 is not None:
+                b.qlen2 = np.ascontiguousarray(rb2.qual_len, dtype=np.uint32)
         return b
 
     def set_aux(self, lane, tile, x, y, ok):
@@ -269,17 +278,20 @@ class Batch:
         s.qbytes2 = 0 if self.qual2 is None else self.qual2.size
         if self.aux is not None:
             s.aux_lane, s.aux_tile, s.aux_x, s.aux_y, s.aux_ok = (_ptr(a) for a in self.aux)
+        s.qlen1, s.qlen2 = _ptr(self.qlen1), _ptr(self.qlen2)
         return s
 
     def read1(self, i):
         o = int(self.off1[i]); l = int(self.len1[i])
         q = o if self.qoff1 is None else int(self.qoff1[i])
-        return self.seq1[o:o + l].tobytes(), self.qual1[q:q + l].tobytes()
+        ql = l if self.qlen1 is None else int(self.qlen1[i])
+        return self.seq1[o:o + l].tobytes(), self.qual1[q:q + ql].tobytes()
 
     def read2(self, i):
         o = int(self.off2[i]); l = int(self.len2[i])
         q = o if self.qoff2 is None else int(self.qoff2[i])
-        return self.seq2[o:o + l].tobytes(), self.qual2[q:q + l].tobytes()
+        ql = l if self.qlen2 is None else int(self.qlen2[i])
+        return self.seq2[o:o + l].tobytes(), self.qual2[q:q + ql].tobytes()
 
 
 class AqcError(RuntimeError):
@@ -315,6 +327,8 @@ def load_library():
     lib.aqc_run.argtypes = [P, C.c_int, C.c_uint64]
     lib.aqc_qc_stat.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int]
     lib.aqc_fetch_results.argtypes = [P, C.c_int, P, C.c_uint64]
+    lib.aqc_fetch_quality_views.argtypes = [P, C.c_int, C.c_int, P, C.c_uint64]
+    lib.aqc_error_record.argtypes = [P, C.c_int, C.POINTER(C.c_uint64)]
     lib.aqc_sync.argtypes = [P, C.c_int]
     lib.aqc_last_deferred.argtypes = [P, C.c_int, P, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.aqc_last_deferred.restype = C.c_int
@@ -380,9 +394,9 @@ def load_library():
                  "aqc_run", "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_timing_reset",
                  "aqc_timing_mean", "aqc_get_counters", "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers",
                  "aqc_overlap", "aqc_read_stats", "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain",
-                 "aqc_fetch_text"):
+                 "aqc_fetch_text", "aqc_fetch_quality_views", "aqc_error_record"):
         getattr(lib, name).restype = C.c_int
-    if lib.aqc_abi_version() != 1:
+    if lib.aqc_abi_version() != 2:
         raise RuntimeError("libafterqc_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -390,7 +404,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_device_index", "aqc_device_numa_node", "aqc_device_numa_node_of", "aqc_bind_thread_to_node", "aqc_last_error", "aqc_create", "aqc_destroy",
                     "aqc_device_name", "aqc_set_config", "aqc_set_circles", "aqc_reset_stats", "aqc_upload", "aqc_run",
-                    "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_last_deferred", "aqc_kernel_ms", "aqc_timing_reset",
+                    "aqc_qc_stat", "aqc_fetch_results", "aqc_fetch_quality_views", "aqc_error_record", "aqc_sync", "aqc_last_deferred", "aqc_kernel_ms", "aqc_timing_reset",
                     "aqc_timing_mean", "aqc_get_counters",
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
                     "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_fetch_streams", "aqc_compress", "aqc_fetch_gz", "aqc_gunzip_dev", "aqc_host_alloc",
@@ -471,6 +485,19 @@ class Engine:
 
     def sync(self, slot):
         self._check(self.lib.aqc_sync(self.h, slot))
+
+    def fetch_quality_views(self, slot, mate):
+        """(start, length) of the quality-string slice that goes with the final read of every record of the slot"""
+        out = np.zeros(self.slot_n[slot], dtype=np.uint32)
+        self._check(self.lib.aqc_fetch_quality_views(self.h, slot, mate, _ptr(out), self.slot_n[slot]))
+        return (out & 0xffff).astype(np.int64), (out >> 16).astype(np.int64)
+
+    def error_record(self, slot):
+        """after an AqcError whose code is in RECORD_ERRORS: the index (in the slot) of the earliest record at which the
+        reference's run would have died, or None when the error is not tied to a record"""
+        rec = C.c_uint64(0)
+        self._check(self.lib.aqc_error_record(self.h, slot, C.byref(rec)))
+        return None if rec.value == UINT64_MAX else int(rec.value)
 
     def last_deferred(self, slot, want_indices=False):
         """records of the slot's last run() that the lane-per-read kernel handed to the general kernel"""

@@ -75,7 +75,10 @@ struct DevBuf {
 struct Slot {
     hipStream_t stream = nullptr;
     int* status = nullptr;           // first device-side error raised by this slot's kernels (one word per slot: the slots
-                                     // of a context may be driven from different host threads)
+                                     // of a context may be driven from different host threads); 16 bytes: the word, and at
+                                     // byte 8 DevStats::err_key (the earliest record at which upstream's run would have died)
+    uint64_t err_record = UINT64_MAX; // ... as the last check_status read it (aqc_error_record)
+    DevBuf qlen[2], qview[2];        // quality-line lengths of an uploaded batch (aqc_batch::qlen*), final quality views of LEN_IRR records
     DevBuf seq1, qual1, off1, qoff1, len1, seq2, qual2, off2, qoff2, len2, aux[5], results;
     DevBuf deferred, n_deferred;     // records the lane-per-read kernel hands to the general kernel
     DevBuf off_stage;                // the caller's 64-bit offsets on their way to the 32-bit device form
@@ -181,15 +184,32 @@ struct aqc_ctx {
     char name[256] = "";
 };
 
+struct StatusWords { int status; int pad_; unsigned long long err_key; };
+static const StatusWords STATUS_CLEAR{0, 0, ~0ull};
+static unsigned long long* err_key_of(const Slot& sl) { return reinterpret_cast<unsigned long long*>(sl.status + 2); }
+
 static int check_status(Slot& sl) {
-    int st = 0;
-    HIP_TRY(hipMemcpyAsync(&st, sl.status, sizeof(int), hipMemcpyDeviceToHost, sl.stream));
+    StatusWords w{0, 0, ~0ull};
+    HIP_TRY(hipMemcpyAsync(&w, sl.status, sizeof(w), hipMemcpyDeviceToHost, sl.stream));
     HIP_TRY(hipStreamSynchronize(sl.stream));
+    int st = w.status;
     if (st != 0) {
-        (void)hipMemsetAsync(sl.status, 0, sizeof(int), sl.stream);
+        (void)hipMemcpyAsync(sl.status, &STATUS_CLEAR, sizeof(STATUS_CLEAR), hipMemcpyHostToDevice, sl.stream);
         (void)hipStreamSynchronize(sl.stream);
+        sl.err_record = UINT64_MAX;
+        if (w.err_key != ~0ull) {
+            // an exception inside upstream's loop: the run ends at the EARLIEST record that raises, whatever raised first here
+            sl.err_record = w.err_key >> 8;
+            st = -(int)(w.err_key & 0xffu);
+            const char* what = st == AQC_ERR_ALPHABET ? "a base outside the reference's COMP table reached the correction walk (KeyError upstream)"
+                             : st == AQC_ERR_INDEX ? "the overlap walk read a quality line beyond its length — the line is shorter than its sequence line (IndexError upstream)"
+                             : st == AQC_ERR_ARG ? "a name field the bubble filter converts with int() is not a number (ValueError upstream)"
+                                                 : "device-side error";
+            return fail(st, "%s; record %llu of the chunk — the run ends there, the records before it are valid (aqc_error_record)", what,
+                        (unsigned long long)sl.err_record);
+        }
         const char* what = st == AQC_ERR_ALPHABET ? "a base outside the reference's COMP table reached the correction walk (KeyError upstream)"
-                         : st == AQC_ERR_READ_TOO_LONG ? "a read is longer than AQC_MAX_READ_LEN"
+                         : st == AQC_ERR_READ_TOO_LONG ? "a read (or its quality line) is longer than AQC_MAX_READ_LEN"
                          : st == AQC_ERR_ARG ? "a read shorter than 5 bases reached statRead (IndexError upstream)"
                          : st == AQC_ERR_UNSUPPORTED ? "device limit exceeded (k-mer table full or string longer than 64)"
                                                      : "device-side error";
@@ -266,8 +286,8 @@ int aqc_create(int device, int n_slots, aqc_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->ovl_hist, sizeof(unsigned long long) * AQC_QC_COLS));
     HIP_TRY(hipMalloc((void**)&c->dist_hist, sizeof(unsigned long long) * AQC_QC_COLS));
     for (auto& s : c->slots) {
-        HIP_TRY(hipMalloc((void**)&s.status, sizeof(int)));
-        HIP_TRY(hipMemset(s.status, 0, sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&s.status, sizeof(StatusWords)));
+        HIP_TRY(hipMemcpy(s.status, &STATUS_CLEAR, sizeof(STATUS_CLEAR), hipMemcpyHostToDevice));
     }
     for (int k = 0; k < 4; k++)
         HIP_TRY(hipMalloc((void**)&c->qc[k].acc, sizeof(unsigned long long) * AQC_QC_ROWS * AQC_QC_COLS));
@@ -282,7 +302,7 @@ void aqc_destroy(aqc_ctx* c) {
     for (auto& s : c->slots) {
         DevBuf* bufs[] = {&s.seq1, &s.qual1, &s.off1, &s.qoff1, &s.len1, &s.seq2, &s.qual2, &s.off2, &s.qoff2, &s.len2,
                           &s.aux[0], &s.aux[1], &s.aux[2], &s.aux[3], &s.aux[4], &s.results,
-                          &s.deferred, &s.n_deferred, &s.off_stage,
+                          &s.deferred, &s.n_deferred, &s.off_stage, &s.qlen[0], &s.qlen[1], &s.qview[0], &s.qview[1],
                           &s.t_line_end[0], &s.t_line_end[1], &s.t_tile[0], &s.t_tile[1], &s.t_name_off[0], &s.t_name_off[1],
                           &s.t_name_len[0], &s.t_name_len[1], &s.t_plus_off[0], &s.t_plus_off[1], &s.t_plus_len[0], &s.t_plus_len[1],
                           &s.t_qual_len[0], &s.t_qual_len[1], &s.t_scratch, &s.f_pos, &s.f_tile, &s.f_plan, &s.f_over, &s.f_out[0], &s.f_out[1], &s.f_out[2],
@@ -416,7 +436,7 @@ int aqc_reset_stats(aqc_ctx* c) {
     HIP_TRY(hipMemset(c->counters, 0, sizeof(unsigned long long) * (AQC_N_COUNTERS + 16)));
     HIP_TRY(hipMemset(c->ovl_hist, 0, sizeof(unsigned long long) * AQC_QC_COLS));
     HIP_TRY(hipMemset(c->dist_hist, 0, sizeof(unsigned long long) * AQC_QC_COLS));
-    for (auto& sl : c->slots) HIP_TRY(hipMemset(sl.status, 0, sizeof(int)));
+    for (auto& sl : c->slots) { HIP_TRY(hipMemcpy(sl.status, &STATUS_CLEAR, sizeof(STATUS_CLEAR), hipMemcpyHostToDevice)); sl.err_record = UINT64_MAX; }
     for (int k = 0; k < 4; k++) {
         HIP_TRY(hipMemset(c->qc[k].acc, 0, sizeof(unsigned long long) * AQC_QC_ROWS * AQC_QC_COLS));
         c->qc[k].last_end = 0;
@@ -522,6 +542,22 @@ static int fill_slot(aqc_ctx* c, Slot& s, const aqc_batch* b, bool need_qual, bo
         v.aux_ok = (const uint8_t*)s.aux[4].p;
     }
     if (s.results.reserve(sizeof(aqc_result) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    if (b->qlen1 && need_qual) {
+        // quality strings with lengths of their own: the mates that differ are marked in the device copy of their length words
+        if (paired && !b->qlen2) return fail(AQC_ERR_ARG, "batch: qlen1 without qlen2");
+        const uint32_t* ql[2] = {b->qlen1, b->qlen2};
+        DevBuf* lens[2] = {&s.len1, &s.len2};
+        for (int k = 0; k < (paired ? 2 : 1); ++k) {
+            if ((rc = up(s.qlen[k], ql[k], sizeof(uint32_t) * n, s.stream))) return rc;
+            if (s.qview[k].reserve(sizeof(uint32_t) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+            if (n) hipLaunchKernelGGL(mark_irregular_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s.stream, (uint32_t*)lens[k]->p,
+                                      (const uint32_t*)s.qlen[k].p, n);
+        }
+        HIP_TRY(hipGetLastError());
+        v.qlen1 = (const uint32_t*)s.qlen[0].p; v.qview1 = (uint32_t*)s.qview[0].p;
+        if (paired) { v.qlen2 = (const uint32_t*)s.qlen[1].p; v.qview2 = (uint32_t*)s.qview[1].p; }
+        else { v.qlen2 = v.qlen1; v.qview2 = v.qview1; }
+    }
     uint32_t mx = 0;
     for (uint64_t i = 0; i < n; i++) {
         if (b->len1[i] > mx) mx = b->len1[i];
@@ -573,7 +609,8 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
     if (s->n == 0) { s->ran = true; return 0; }
     aqc_config cfg = c->cfg;
     if (!cfg.paired) cfg.no_overlap = 1;
-    DevStats st{c->counters, c->ovl_hist, c->dist_hist, s->status};
+    DevStats st{c->counters, c->ovl_hist, c->dist_hist, s->status, err_key_of(*s)};
+    s->err_record = UINT64_MAX;
     if (s->qc.pending()) HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_qc, 0));      // (statRead of the previous run still reads the results)
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_FILTER_OVERLAP, 0), s->stream));
     // lane-per-pair kernel whenever its preconditions hold; the general wave-per-record kernel otherwise
@@ -828,11 +865,9 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
         if (fits) break;
     }
     // 3. lock-step record count (preprocesser.py:412-429)
+    // (a record whose quality line is not as long as its sequence line is a record like any other: fastq.py:37-49 does not look,
+    //  and every later stage keeps a view per string — LEN_IRR in aqc_kernels.hpp)
     const uint64_t n = fo.n;
-    for (int k = 0; k < nf; k++)
-        if (fo.first_mismatch[k] < n)
-            return fail(AQC_ERR_ARG, "malformed FASTQ: sequence and quality lines differ in length (read %d, record %u of the chunk)", k + 1,
-                        fo.first_mismatch[k]);
     memset(info, 0, sizeof(*info));
     info->n = n;
     info->avail1 = fo.avail[0];
@@ -851,6 +886,15 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
         v.off2 = (const uint32_t*)s->off2.p; v.qoff2 = (const uint32_t*)s->qoff2.p; v.len2 = (const uint32_t*)s->len2.p;
     }
     if (s->results.reserve(sizeof(aqc_result) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    {
+        // the quality lines' own lengths (frame_records_kernel) and room for the final quality views of the marked records
+        // (written by the verdict kernels for those records only: no traffic for a regular chunk)
+        const bool any_irr = fo.first_mismatch[0] < n || (paired && fo.first_mismatch[1] < n);
+        for (int k = 0; k < nf; k++)
+            if (any_irr && s->qview[k].reserve(sizeof(uint32_t) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+        v.qlen1 = (const uint32_t*)s->t_qual_len[0].p; v.qview1 = (uint32_t*)s->qview[0].p;
+        v.qlen2 = paired ? (const uint32_t*)s->t_qual_len[1].p : v.qlen1; v.qview2 = paired ? (uint32_t*)s->qview[1].p : v.qview1;
+    }
     if (bubble) {
         v.aux_lane = (const int32_t*)s->aux[0].p; v.aux_tile = (const int32_t*)s->aux[1].p;
         v.aux_x = (const int32_t*)s->aux[2].p; v.aux_y = (const int32_t*)s->aux[3].p; v.aux_ok = (const uint8_t*)s->aux[4].p;
@@ -916,6 +960,7 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
         v.f[k].plus_off = (const uint32_t*)s->t_plus_off[k].p;
         v.f[k].plus_len = (const uint32_t*)s->t_plus_len[k].p;
         v.f[k].qual_len = (const uint32_t*)s->t_qual_len[k].p;
+        v.f[k].qview = (const uint32_t*)s->qview[k].p;
     }
     // streams q = file * 3 + {0 good, 1 bad, 2 overlap}: per-tile byte sums -> tile bases (one launch each), the
     // per-record offsets are formed inside the writer
@@ -1548,6 +1593,31 @@ int aqc_fetch_results(aqc_ctx* c, int slot, aqc_result* out, uint64_t n) {
     if (n) HIP_TRY(hipMemcpyAsync(out, s->results.p, sizeof(aqc_result) * n, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(slot_sync(*s));
     return check_status(*s);
+}
+
+int aqc_fetch_quality_views(aqc_ctx* c, int slot, int mate, uint32_t* out, uint64_t n) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!s->ran) return fail(AQC_ERR_STATE, "aqc_fetch_quality_views before aqc_run");
+    if (n > s->n || !out || mate < 0 || mate > 1 || (mate == 1 && !s->paired)) return fail(AQC_ERR_ARG, "aqc_fetch_quality_views: bad arguments");
+    if (n == 0) return 0;
+    if (s->off_stage.reserve(sizeof(uint32_t) * n)) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    hipLaunchKernelGGL(quality_views_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, s->view, (const aqc_result*)s->results.p, mate,
+                       (uint32_t*)s->off_stage.p, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, s->off_stage.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(slot_sync(*s));
+    return 0;
+}
+
+int aqc_error_record(aqc_ctx* c, int slot, uint64_t* record) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!record) return fail(AQC_ERR_ARG, "aqc_error_record: null argument");
+    *record = s->err_record;
+    return 0;
 }
 
 int aqc_last_deferred(aqc_ctx* c, int slot, uint32_t* idx, uint64_t cap, uint64_t* n) {

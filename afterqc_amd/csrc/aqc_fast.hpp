@@ -141,6 +141,10 @@ __device__ __forceinline__ void trim_view(int len, int front, int tail, int& st,
     nl = max(end - st, 0);
 }
 
+// the length this kernel works with: a mate marked LEN_IRR (its quality line has a length of its own: the general kernel's
+// business) counts as EMPTY — one v_max per lane and batch; phase 1 then sees padding only and never forms an address from it
+__device__ __forceinline__ uint32_t lane_len(uint32_t len_word) { return (uint32_t)max((int)len_word, 0); }
+
 template <int NW, bool PAIRED>
 struct FastWaveLds {
     static constexpr int PPW = PAIRED ? 32 : 64;               // records per wave batch
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT
     if (cur < n_batches && cur * PPW + p < n_rec) {
         const uint32_t r0 = cur * PPW + p;
         m_o = role ? fb.off2[r0] : fb.off1[r0];
-        m_l = role ? fb.len2[r0] : fb.len1[r0];
+        m_l = lane_len(role ? fb.len2[r0] : fb.len1[r0]);
         m_q = role ? qo2[r0] : qo1[r0];
     }
     while (cur < n_batches) {
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT
             m_o = m_l = m_q = 0;
             if (nxt < n_batches && nrec < n_rec) {
                 m_o = role ? fb.off2[nrec] : fb.off1[nrec];
-                m_l = role ? fb.len2[nrec] : fb.len1[nrec];
+                m_l = lane_len(role ? fb.len2[nrec] : fb.len1[nrec]);
                 m_q = role ? qo2[nrec] : qo1[nrec];
             }
         }
@@ -559,6 +563,8 @@ __global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT
         PROF(0);
 
         // ------------------------------------------------------------------ phase 2: lane per read
+        // (a mate whose quality line has a length of its own — LEN_IRR in its length word, aqc_kernels.hpp — arrives here with
+        //  length 0, see lane_len: the pair goes to the general kernel like an empty read)
         const int L1 = (int)pr[WL::D_L1];
         const int L2 = PAIRED ? (int)pr[WL::D_L2] : 0;
         const bool accum = valid && rec < accum_limit;
@@ -759,6 +765,7 @@ __global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT
                 int code = AQC_ERR_ARG;
                 asm volatile("" : "+v"(code));                      // (built here, not hoisted out of the loop as a register pair)
                 atomicCAS(R->st.status, 0, code);
+                atomicMin(R->st.err_key, ((unsigned long long)rec << 8) | (unsigned long long)(unsigned int)(-code));
             }
             else if (ok) {
                 const int ln = R->fb.aux_lane[rec], tl = R->fb.aux_tile[rec], x = R->fb.aux_x[rec], y = R->fb.aux_y[rec];

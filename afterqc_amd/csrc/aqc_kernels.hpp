@@ -26,7 +26,15 @@ struct DevBatch {
     const uint8_t* aux_ok;
     uint64_t n;
     uint64_t first_index;
+    // Records whose QUALITY line is not as long as their SEQUENCE line (the reference never compares the two: fastq.py:37-49
+    // hands the lines over as they are, preprocesser.py:19-28 slices each string by its own length, :565-568 index each quality
+    // string from its own end).  Such a mate carries LEN_IRR in its len word; qlen holds the quality line's length (low 31
+    // bits; NULL: the batch has no such record) and the general kernel leaves the FINAL quality view of both mates of such a
+    // record in qview (start | length << 16, relative to the quality line) for the writer and the post-filter statRead.
+    const uint32_t *qlen1, *qlen2;
+    uint32_t *qview1, *qview2;
 };
+constexpr uint32_t LEN_IRR = 0x80000000u, LEN_MASK = 0x7fffffffu;
 
 struct DevCircles {
     const double *cx, *cy, *cr;
@@ -39,7 +47,16 @@ struct DevStats {
     unsigned long long* ovl_hist;   // [AQC_QC_COLS]
     unsigned long long* dist_hist;  // [AQC_QC_COLS]
     int* status;                    // first error code raised on the device (0 = ok)
+    // errors that END THE RUN AT A RECORD upstream (an exception inside the loop of preprocesser.py:411-631: KeyError of
+    // util.complement / the error matrix, IndexError of a quality string too short for the walk, int() of a name field):
+    // min over (record << 8 | -code), so that the host learns the EARLIEST such record — everything before it was written
+    // upstream when the exception flew (~0 = none)
+    unsigned long long* err_key;
 };
+__device__ __forceinline__ void raise_at_record(const DevStats& st, uint64_t rec, int code) {
+    atomicCAS(st.status, 0, code);
+    atomicMin(st.err_key, ((unsigned long long)rec << 8) | (unsigned long long)(unsigned int)(-code));
+}
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -314,23 +331,34 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
     uint8_t* c2 = w.c2;   // complement-or-N of s2, same orientation
     const bool paired = cfg.paired != 0;
     {
-        const int L1 = (int)b.len1[rec];
-        const int L2 = paired ? (int)b.len2[rec] : 0;
-        if (L1 > AQC_MAX_READ_LEN || L2 > AQC_MAX_READ_LEN) {
+        const uint32_t l1w = b.len1[rec], l2w = paired ? b.len2[rec] : 0u;
+        const int L1 = (int)(l1w & LEN_MASK);
+        const int L2 = (int)(l2w & LEN_MASK);
+        // a quality line that is not as long as its sequence line (either mate): every string keeps its own view
+        const bool irr = b.qlen1 != nullptr && ((l1w | l2w) & LEN_IRR) != 0u;
+        const int QL1 = irr ? (int)(b.qlen1[rec] & LEN_MASK) : L1;
+        const int QL2 = (irr && paired) ? (int)(b.qlen2[rec] & LEN_MASK) : L2;
+        if (L1 > AQC_MAX_READ_LEN || L2 > AQC_MAX_READ_LEN || QL1 > AQC_MAX_READ_LEN || QL2 > AQC_MAX_READ_LEN) {
             if (lane == 0) atomicCAS(st.status, 0, AQC_ERR_READ_TOO_LONG);
             return;
         }
         stage(s1, b.seq1 + b.off1[rec], L1);
-        stage(q1, b.qual1 + (b.qoff1 ? b.qoff1[rec] : b.off1[rec]), L1);
+        stage(q1, b.qual1 + (b.qoff1 ? b.qoff1[rec] : b.off1[rec]), QL1);
         if (paired) {
             stage(s2, b.seq2 + b.off2[rec], L2);
-            stage(q2, b.qual2 + (b.qoff2 ? b.qoff2[rec] : b.off2[rec]), L2);
+            stage(q2, b.qual2 + (b.qoff2 ? b.qoff2[rec] : b.off2[rec]), QL2);
             for (int i = lane; i < L2; i += WAVE) c2[i] = comp_or_n(b.seq2[b.off2[rec] + i]);
         }
         // (wave-private LDS region: no barrier needed, the compiler orders LDS ops of one wave)
         __builtin_amdgcn_wave_barrier();
 
         int a1 = 0, len1 = L1, a2 = 0, len2 = L2;     // current views: s1[a1 .. a1+len1), s2[a2 .. a2+len2)
+        // ... and of the quality strings: q1[qa1 .. qa1+ql1), q2[qa2 .. qa2+ql2).  Every slice upstream is a python slice of
+        // EACH string (preprocesser.py:19-28,521-524, barcodeprocesser.py:42-43,66-69): the same cut applied to a string of
+        // another length.  For a regular record they stay equal to the sequence views.
+        int qa1 = 0, ql1 = QL1, qa2 = 0, ql2 = QL2;
+        auto cut_front = [](int& a, int& l, int k) { const int m = min(k, l); a += m; l -= m; };      // s[k:]
+        auto cut_tail = [](int& l, int k) { if (k > 0) l = max(l - k, 0); };                          // s[:-k]  (k > 0)
         int flag = -1;
         int offset = 0, ovl = 0, dist = 0, n_edits = 0;
         uint8_t bcode = 0;
@@ -350,6 +378,7 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
                 if (!paired) {
                     const int rm = vl + bl;   // single-end moves the design length (preprocesser.py:444)
                     a1 += min(rm, len1); len1 = max(len1 - rm, 0);
+                    cut_front(qa1, ql1, rm);
                 } else {
                     const int b2 = detect_barcode_wave(s2, len2, bl, cfg.barcode_verify, vl);
                     if (b2 == 0) flag = AQC_BADBCD2;
@@ -365,8 +394,10 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
                         __builtin_amdgcn_wave_barrier();
                         a1 += vl + b1; len1 -= vl + b1;
                         a2 += vl + b2; len2 -= vl + b2;
+                        cut_front(qa1, ql1, vl + b1); cut_front(qa2, ql2, vl + b2);
                         const int cut = clean_barcode_tail_wave(s1 + a1, len1, s2 + a2, len2, rs1, b1 + vl, rs2, b2 + vl);
                         len1 -= cut; len2 -= cut;
+                        cut_tail(ql1, cut); cut_tail(ql2, cut);
                     }
                 }
             }
@@ -377,18 +408,24 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
             int stt = min(cfg.trim_front, len1);
             int nl = max(end - stt, 0);
             a1 += stt; len1 = nl;
+            {
+                const int qend = cfg.trim_tail > 0 ? max(ql1 - cfg.trim_tail, 0) : ql1, qst = min(cfg.trim_front, ql1);
+                qa1 += qst; ql1 = max(qend - qst, 0);
+            }
             if (len1 < 5) flag = AQC_BADTRIM1;
             else if (paired) {
                 end = cfg.trim_tail2 > 0 ? max(len2 - cfg.trim_tail2, 0) : len2;
                 stt = min(cfg.trim_front2, len2);
                 nl = max(end - stt, 0);
                 a2 += stt; len2 = nl;
+                const int qend = cfg.trim_tail2 > 0 ? max(ql2 - cfg.trim_tail2, 0) : ql2, qst = min(cfg.trim_front2, ql2);
+                qa2 += qst; ql2 = max(qend - qst, 0);
                 if (len2 < 5) flag = AQC_BADTRIM2;
             }
         }
         // ---- bubble (preprocesser.py:469-473)
         if (flag < 0 && cfg.debubble && b.aux_ok && b.aux_ok[rec]) {
-            if (b.aux_ok[rec] == 2) atomicCAS(st.status, 0, AQC_ERR_ARG);     // int() raises upstream (preprocesser.py:187-192)
+            if (b.aux_ok[rec] == 2) { if (lane == 0) raise_at_record(st, rec, AQC_ERR_ARG); }     // int() raises upstream (preprocesser.py:187-192)
             else if (in_bubble_wave(b.aux_lane[rec], b.aux_tile[rec], b.aux_x[rec], b.aux_y[rec], circ)) flag = AQC_BADBBL;
         }
         // ---- length (preprocesser.py:476-479)
@@ -401,7 +438,7 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
         }
         // ---- low quality: only read 1 is tested (preprocesser.py:498, upstream quirk)
         if (flag < 0 && cfg.unqualified_base_limit > 0) {
-            if (low_quality_wave(q1 + a1, len1, cfg.qualified_quality_phred) > cfg.unqualified_base_limit) flag = AQC_BADLQC;
+            if (low_quality_wave(q1 + qa1, ql1, cfg.qualified_quality_phred) > cfg.unqualified_base_limit) flag = AQC_BADLQC;      // (the QUALITY line is what is counted, :61-68)
         }
         // ---- N (preprocesser.py:504-512)
         if (flag < 0 && cfg.n_base_limit > 0) {
@@ -415,6 +452,7 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
             ovl0 = ovl;
             if (offset < 0 && ovl > 30) {
                 len1 = ovl; len2 = ovl;                      // all four strings := [0:overlap_len]
+                ql1 = min(ql1, ovl); ql2 = min(ql2, ovl);
                 c_adapter_base = 2 * (-offset); c_adapter_read = 1;
                 if (len1 < cfg.seq_len_req) { flag = AQC_BADLEN; offset = 0; ovl = 0; dist = 0; }   // record carries no overlap
                 else overlap_hm_wave(s1 + a1, len1, c2 + a2, len2, offset, ovl, dist);
@@ -424,7 +462,77 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
                 if (dist > 3) flag = AQC_BADDIFF;
                 else if (ovl > 30) {
                     c_overlapped = 1;
-                    if (dist > 0) {
+                    if (dist > 0 && irr) {
+                        // The walk of preprocesser.py:563-598 for a record whose quality views differ from its sequence views,
+                        // as upstream runs it: one position after the other, every string indexed from ITS OWN end
+                        // (r1[3][len(r1[3]) - overlap_len + o] with python's wrap for a negative index, r2[3][-o-1]), the
+                        // quality strings edited in place — a wrapped index can meet a position a later step reads again.
+                        // An index outside a string is upstream's IndexError: the run ends at this record.  One lane; such
+                        // records are rare.
+                        int handled = 0, err = 0;
+                        if (lane == 0) {
+                            const uint8_t* S1 = s1 + a1;
+                            const uint8_t* S2 = s2 + a2;
+                            uint8_t* Q1 = q1 + qa1;
+                            uint8_t* Q2 = q2 + qa2;
+                            for (int o = 0; o < ovl && handled < dist; ++o) {
+                                const uint8_t bA = S1[len1 - ovl + o];
+                                const uint8_t r2o = S2[len2 - 1 - o];
+                                const uint8_t bB = comp_strict(r2o);
+                                if (bB == 0) { err = AQC_ERR_ALPHABET; break; }            // util.complement (:565)
+                                int i1 = ql1 - ovl + o;
+                                if (i1 < 0) i1 += ql1;                                      // python: a negative index counts from the end
+                                const int i2 = ql2 - 1 - o;
+                                if (i1 < 0 || i2 < 0) { err = AQC_ERR_INDEX; break; }      // IndexError (:566-567)
+                                const int qa = Q1[i1], qb = Q2[i2];
+                                if (bA == bB) continue;
+                                bool fixed = false;
+                                if (qa - 33 >= 30 && qb - 33 <= 14) {
+                                    const uint8_t cA = comp_strict(bA);
+                                    if (bA != 'N' && bB != 'N') {
+                                        const int i0 = base_idx(cA), ix = base_idx(r2o);
+                                        if (cA == 0 || i0 < 0 || ix < 0) { err = AQC_ERR_ALPHABET; break; }
+                                        em[handled] = i0 * 4 + ix;
+                                    }
+                                    if (!cfg.no_correction) {
+                                        if (cA == 0) { err = AQC_ERR_ALPHABET; break; }
+                                        edits[n_edits] = aqc_edit{(uint16_t)o, AQC_EDIT_FIX_R2, cA, (uint8_t)qa};
+                                        Q2[i2] = (uint8_t)qa;
+                                        n_edits++; c_corrected++; fixed = true;
+                                    }
+                                } else if (qb - 33 >= 30 && qa - 33 <= 14) {
+                                    if (bA != 'N' && bB != 'N') {
+                                        const int i0 = base_idx(bB), ix = base_idx(bA);
+                                        if (i0 < 0 || ix < 0) { err = AQC_ERR_ALPHABET; break; }
+                                        em[handled] = i0 * 4 + ix;
+                                    }
+                                    if (!cfg.no_correction) {
+                                        edits[n_edits] = aqc_edit{(uint16_t)o, AQC_EDIT_FIX_R1, bB, (uint8_t)qb};
+                                        Q1[i1] = (uint8_t)qb;
+                                        n_edits++; c_corrected++; fixed = true;
+                                    }
+                                }
+                                if (!fixed) {
+                                    if (cfg.mask_mismatch) {
+                                        edits[n_edits] = aqc_edit{(uint16_t)o, AQC_EDIT_MASK, 0, (uint8_t)'!'};
+                                        Q2[i2] = (uint8_t)'!'; Q1[i1] = (uint8_t)'!';
+                                        n_edits++; c_masked++;
+                                    } else c_skipped++;
+                                }
+                                handled++;
+                            }
+                            if (err) raise_at_record(st, rec, err);
+                        }
+                        // (lane 0 writes the result record and the counters; the other lanes only need the verdict)
+                        handled = __shfl(handled, 0, WAVE);
+                        if (handled == dist) {
+                            if (c_corrected > 0) c_read_corrected = 1;
+                        } else {
+                            flag = AQC_BADMISMATCH;
+                            em[0] = em[1] = em[2] = -1;
+                            c_corrected = c_masked = c_skipped = 0;
+                        }
+                    } else if (dist > 0) {
                         // the tail-anchored walk of preprocesser.py:563-598
                         int handled = 0;
                         bool bad_alpha = false;
@@ -486,7 +594,7 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
                             const unsigned long long visited = (handled >= dist) ? ((last == 63) ? ~0ull : ((2ull << last) - 1)) : ~0ull;
                             if (inval & visited) bad_alpha = true;
                         }
-                        if (bad_alpha && lane == 0) atomicCAS(st.status, 0, AQC_ERR_ALPHABET);
+                        if (bad_alpha && lane == 0) raise_at_record(st, rec, AQC_ERR_ALPHABET);
                         if (handled == dist) {
                             if (c_corrected > 0) c_read_corrected = 1;
                         } else {
@@ -510,6 +618,10 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
             r.edits[0] = edits[0]; r.edits[1] = edits[1]; r.edits[2] = edits[2];
             r.barcode = bcode;
             results[rec] = r;
+            if (irr) {
+                b.qview1[rec] = (uint32_t)qa1 | ((uint32_t)ql1 << 16);
+                if (paired) b.qview2[rec] = (uint32_t)qa2 | ((uint32_t)ql2 << 16);
+            }
             if (accum) {
                 unsigned long long* C = acc.counters;
                 atomicAdd(&C[AQC_C_TOTAL_READS], 1ull);
@@ -679,6 +791,7 @@ __device__ __forceinline__ void kmer_slot2(const KmerTable& t, unsigned long lon
 struct ReadDesc {
     unsigned long long s, q;
     int len;
+    int qlen;                // length of the quality view (== len unless the record's quality line has a length of its own)
     unsigned int e[3];
 };
 
@@ -687,20 +800,26 @@ __device__ __forceinline__ ReadDesc lane_desc(const DevBatch& b, int mate, uint6
     ReadDesc d;
     d.s = d.q = 0ull;
     d.len = -1;
+    d.qlen = -1;
     d.e[0] = d.e[1] = d.e[2] = 0xffff0000u;
     if (!valid) return d;
     int len, st = 0;
+    uint32_t lw;
     if (mate == 0) {
-        len = (int)b.len1[rec];
+        lw = b.len1[rec];
         const uint64_t o = b.off1[rec];
         d.s = (unsigned long long)(b.seq1 + o);
         d.q = (unsigned long long)(b.qual1 + (b.qoff1 ? b.qoff1[rec] : o));
     } else {
-        len = (int)b.len2[rec];
+        lw = b.len2[rec];
         const uint64_t o = b.off2[rec];
         d.s = (unsigned long long)(b.seq2 + o);
         d.q = (unsigned long long)(b.qual2 + (b.qoff2 ? b.qoff2[rec] : o));
     }
+    len = (int)(lw & LEN_MASK);
+    // this mate's quality line has a length of its own: its view comes from qlen (raw read) / qview (final read)
+    const bool irr = (lw & LEN_IRR) != 0u && b.qlen1 != nullptr;
+    int qst = 0, qlen = irr ? (int)((mate == 0 ? b.qlen1[rec] : b.qlen2[rec]) & LEN_MASK) : len;
     if (post) {
         // the 32-byte verdict record as two 16-byte loads; fields by shifts (aqc_result is packed, see the header)
         const uint4* rp = reinterpret_cast<const uint4*>(results + rec);
@@ -710,6 +829,11 @@ __device__ __forceinline__ ReadDesc lane_desc(const DevBatch& b, int mate, uint6
         const int len1 = (int)(w0.y & 0xffffu), len2 = (int)(w0.z & 0xffffu), ovl = (int)(w0.w & 0xffffu);
         st = mate == 0 ? (int)(w0.x >> 16) : (int)(w0.y >> 16);
         len = mate == 0 ? len1 : len2;
+        qst = st; qlen = len;
+        if (irr) {
+            const uint32_t qv = mate == 0 ? b.qview1[rec] : b.qview2[rec];
+            qst = (int)(qv & 0xffffu); qlen = (int)(qv >> 16);
+        }
         const unsigned long long e_lo = ((unsigned long long)w1.y << 32) | w1.x, e_hi = ((unsigned long long)w1.w << 32) | w1.z;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
@@ -728,8 +852,9 @@ __device__ __forceinline__ ReadDesc lane_desc(const DevBatch& b, int mate, uint6
         }
     }
     d.s += (unsigned int)st;
-    d.q += (unsigned int)st;
+    d.q += (unsigned int)(post ? qst : 0);
     d.len = len;
+    d.qlen = qlen;
     return d;
 }
 
@@ -744,6 +869,7 @@ __device__ __forceinline__ ReadDesc bcast_desc(const ReadDesc& d, int j) {
     o.s = readlane64(d.s, j);
     o.q = readlane64(d.q, j);
     o.len = __builtin_amdgcn_readlane(d.len, j);
+    o.qlen = __builtin_amdgcn_readlane(d.qlen, j);
     o.e[0] = (unsigned int)__builtin_amdgcn_readlane((int)d.e[0], j);
     o.e[1] = (unsigned int)__builtin_amdgcn_readlane((int)d.e[1], j);
     o.e[2] = (unsigned int)__builtin_amdgcn_readlane((int)d.e[2], j);
@@ -762,6 +888,23 @@ __device__ __forceinline__ uint32_t load4(const uint8_t* p, int x, int len, uint
 
 // the walk's edits that fall into the dword at byte offset x (d is wave-uniform, so the outer tests are scalar)
 __device__ __forceinline__ void apply_edits(const ReadDesc& d, int x, uint32_t& ws, uint32_t& wq) {
+    if (d.qlen != d.len) {
+        // a quality view of its own length: the walk indexed it from ITS end (preprocesser.py:566-567) — position + (qlen - len),
+        // a negative index wrapped the python way; edits in order, a later one wins (d is wave-uniform: scalar branches)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const unsigned int ed = d.e[e];
+            if ((ed >> 16) != 0xffffu) {
+                const unsigned int rel = (ed >> 16) - (unsigned int)x;
+                if (rel < 4u && ((ed >> 8) & 0xffu)) ws = (ws & ~(0xffu << (8u * rel))) | (((ed >> 8) & 0xffu) << (8u * rel));
+                int qp = (int)(ed >> 16) + d.qlen - d.len;
+                if (qp < 0) qp += d.qlen;
+                const unsigned int relq = (unsigned int)(qp - x);
+                if (qp >= 0 && relq < 4u) wq = (wq & ~(0xffu << (8u * relq))) | ((ed & 0xffu) << (8u * relq));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 3; ++e) {
         const unsigned int ed = d.e[e];
@@ -809,6 +952,7 @@ struct QcLds {
 __device__ __forceinline__ void qc_accumulate_read(const ReadDesc& cur, uint32_t ws, uint32_t wq, const QcLds& L, int kmer_len) {
     const int lane = lane_id();
     const int len = cur.len;
+    const int qlen = cur.qlen;               // (the pass-0 dword of qualities was loaded against it)
     const int cols = L.cols, cq = L.cols >> 2;
     unsigned int* const accs = L.accs;
     unsigned int* const gch = L.gch;
@@ -819,7 +963,7 @@ __device__ __forceinline__ void qc_accumulate_read(const ReadDesc& cur, uint32_t
     unsigned int d_head = 0, d_tail = 0;      // discontinuity of cycle 2 / cycle len-3: the clamped windows
     for (int base0 = 0; base0 < len; base0 += 4 * WAVE) {
         const int x = base0 + 4 * lane;
-        if (base0 > 0) { ws = load4(gs, x, len, 0); wq = load4(gq, x, len, 0); }
+        if (base0 > 0) { ws = load4(gs, x, len, 0); wq = load4(gq, x, qlen, 0); }
         apply_edits(cur, x, ws, wq);
         uint32_t prev = __shfl_up(ws, 1), next = __shfl_down(ws, 1);
         if (base0 > 0 && lane == 0) { uint32_t dq = 0; prev = load4(gs, x - 4, len, 0); apply_edits(cur, x - 4, prev, dq); }
@@ -841,16 +985,27 @@ __device__ __forceinline__ void qc_accumulate_read(const ReadDesc& cur, uint32_t
         const uint32_t codes = (ws >> 1) & 0x03030303u;
         const uint32_t bad = __builtin_amdgcn_perm(0u, CODE_TO_BASE, codes) ^ ws;       // 0 where the byte is A/C/G/T
         const uint32_t nz = nonzero_bytes(bad);                                         // 0x80 per foreign byte
-        const uint32_t foreign = nz | (nz - (nz >> 7));                                 // 0xff per foreign byte
+        uint32_t foreign = nz | (nz - (nz >> 7));                                       // 0xff per foreign byte
+        uint32_t qn4 = wq - 0x21212121u;                                                // (qualities are >= '!' in FASTQ)
+        unsigned int dkeep = 0xfffu;
+        if (qlen < len) {
+            // A quality line shorter than the read (qualitycontrol.py:81-88): totalNum[i] is counted, then qual[i] raises and the
+            // rest of the position is skipped — no quality sum, no base count, no G/C, no discontinuity.  In these accumulators
+            // that is a "foreign" base of quality 0 (row 4 only feeds the total_num / total_qual column sums).
+            const int qin = min(max(qlen - x, 0), 4);
+            const uint32_t qm = qin >= 4 ? 0xffffffffu : ((1u << (8 * qin)) - 1u);
+            foreign |= ~qm;
+            qn4 &= qm;
+            dkeep = qin >= 4 ? 0xfffu : ((1u << (3 * qin)) - 1u);
+        }
         // code (A0 C1 T2 G3) -> row (A0 T1 C2 G3); foreign -> 4
         const uint32_t rows4 = (__builtin_amdgcn_perm(0u, 0x03010200u, codes) & ~foreign) | (0x04040404u & foreign);
-        const uint32_t qn4 = wq - 0x21212121u;                                          // (qualities are >= '!' in FASTQ)
         const int nin = min(max(len - x, 0), 4);                                        // cycles of this lane inside the read
         if (base0 == 0 && lane == 0) dpk = (dpk & ~0x3fu) | d_head | (d_head << 3);     // cycles 0, 1: window [0, 5)
         {
             const int over = min(max(x + 3 - (len - 3), 0), 4);                         // cycles beyond len-3: window [len-5, len)
             const unsigned int m = over ? (0xfffu << (3 * (4 - over))) & 0xfffu : 0u;
-            dpk = (dpk & ~m) | ((d_tail * 0x249u) & m);
+            dpk = ((dpk & ~m) | ((d_tail * 0x249u) & m)) & dkeep;
         }
         const unsigned int col0 = (unsigned int)lane + (unsigned int)(base0 >> 2);
         // G / C among the lane's cycles inside the read (C = code 1, G = code 3: low code bit), not foreign
@@ -903,7 +1058,7 @@ __global__ __launch_bounds__(QC_BLOCK) void qc_stat_kernel(DevBatch b, int mate,
         uint32_t pre_s = 0, pre_q = 0;
         if (usable(cur)) {
             pre_s = load4(reinterpret_cast<const uint8_t*>(cur.s), 4 * lane, cur.len, 0);
-            pre_q = load4(reinterpret_cast<const uint8_t*>(cur.q), 4 * lane, cur.len, 0);
+            pre_q = load4(reinterpret_cast<const uint8_t*>(cur.q), 4 * lane, cur.qlen, 0);
         }
         for (int r = 0; r < nr; ++r) {
             uint32_t ws = pre_s, wq = pre_q;
@@ -912,7 +1067,7 @@ __global__ __launch_bounds__(QC_BLOCK) void qc_stat_kernel(DevBatch b, int mate,
                 nxt = bcast_desc(mine, r + 1);
                 if (usable(nxt)) {
                     pre_s = load4(reinterpret_cast<const uint8_t*>(nxt.s), 4 * lane, nxt.len, 0);
-                    pre_q = load4(reinterpret_cast<const uint8_t*>(nxt.q), 4 * lane, nxt.len, 0);
+                    pre_q = load4(reinterpret_cast<const uint8_t*>(nxt.q), 4 * lane, nxt.qlen, 0);
                 }
             }
             const int len = cur.len;
@@ -1043,7 +1198,7 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
             uint32_t pre = PAD, pre_q = 0;
             if (qc_usable(cur) || usable(cur)) {
                 pre = load4(reinterpret_cast<const uint8_t*>(cur.s), 4 * lane, cur.len, PAD);
-                if (fused) pre_q = load4(reinterpret_cast<const uint8_t*>(cur.q), 4 * lane, cur.len, 0);
+                if (fused) pre_q = load4(reinterpret_cast<const uint8_t*>(cur.q), 4 * lane, cur.qlen, 0);
             }
             KPROF(1);
             for (int r = 0; r < nr; ++r) {
@@ -1054,7 +1209,7 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
                     nxt = bcast_desc(mine, r + 1);
                     if (qc_usable(nxt) || usable(nxt)) {
                         pre = load4(reinterpret_cast<const uint8_t*>(nxt.s), 4 * lane, nxt.len, PAD);
-                        if (fused) pre_q = load4(reinterpret_cast<const uint8_t*>(nxt.q), 4 * lane, nxt.len, 0);
+                        if (fused) pre_q = load4(reinterpret_cast<const uint8_t*>(nxt.q), 4 * lane, nxt.qlen, 0);
                     }
                 }
                 if (fused) {
@@ -1254,7 +1409,7 @@ __global__ __launch_bounds__(BLOCK) void overlap_seam_kernel(DevBatch b, int32_t
     const int lane = lane_id(), wave = threadIdx.x / WAVE;
     const uint64_t rec = (uint64_t)blockIdx.x * WPB + wave;
     if (rec >= b.n) return;
-    const int L1 = (int)b.len1[rec], L2 = (int)b.len2[rec];
+    const int L1 = (int)(b.len1[rec] & LEN_MASK), L2 = (int)(b.len2[rec] & LEN_MASK);
     stage(lds[wave][0], b.seq1 + b.off1[rec], L1);
     for (int i = lane; i < L2; i += WAVE) lds[wave][1][i] = comp_or_n(b.seq2[b.off2[rec] + i]);
     __builtin_amdgcn_wave_barrier();
@@ -1269,7 +1424,7 @@ __global__ __launch_bounds__(BLOCK) void read_stats_seam_kernel(DevBatch b, int 
     const int lane = lane_id(), wave = threadIdx.x / WAVE;
     const uint64_t rec = (uint64_t)blockIdx.x * WPB + wave;
     if (rec >= b.n) return;
-    const int L1 = (int)b.len1[rec];
+    const int L1 = (int)(b.len1[rec] & LEN_MASK);
     stage(lds[wave][0], b.seq1 + b.off1[rec], L1);
     stage(lds[wave][1], b.qual1 + (b.qoff1 ? b.qoff1[rec] : b.off1[rec]), L1);
     __builtin_amdgcn_wave_barrier();
@@ -1282,7 +1437,7 @@ __global__ __launch_bounds__(BLOCK) void read_stats_seam_kernel(DevBatch b, int 
 __global__ void edit_distance_seam_kernel(DevBatch b, int32_t* dist, int* status) {
     const uint64_t rec = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (rec >= b.n) return;
-    const int la = (int)b.len1[rec], lb = (int)b.len2[rec];
+    const int la = (int)(b.len1[rec] & LEN_MASK), lb = (int)(b.len2[rec] & LEN_MASK);
     const uint8_t* a = b.seq1 + b.off1[rec];
     const uint8_t* c = b.seq2 + b.off2[rec];
     // the bit-vector form needs the pattern in one 64-bit word; Levenshtein is symmetric
@@ -1294,6 +1449,22 @@ __global__ void edit_distance_seam_kernel(DevBatch b, int32_t* dist, int* status
 }
 
 // the caller's 64-bit byte offsets (struct aqc_batch) -> the 32-bit device form
+// an uploaded batch whose quality strings have lengths of their own (aqc_batch::qlen*): mark the mates that differ
+__global__ void mark_irregular_kernel(uint32_t* __restrict__ len, const uint32_t* __restrict__ qlen, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && qlen[i] != len[i]) len[i] |= LEN_IRR;
+}
+
+// aqc_fetch_quality_views: the slice of the quality string that goes with the final read of every record
+__global__ void quality_views_kernel(DevBatch b, const aqc_result* __restrict__ results, int mate, uint32_t* __restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t lw = mate == 0 ? b.len1[i] : b.len2[i];
+    if ((lw & LEN_IRR) && b.qlen1) { out[i] = mate == 0 ? b.qview1[i] : b.qview2[i]; return; }
+    const aqc_result r = results[i];
+    out[i] = mate == 0 ? ((uint32_t)r.start1 | ((uint32_t)r.len1 << 16)) : ((uint32_t)r.start2 | ((uint32_t)r.len2 << 16));
+}
+
 __global__ void narrow_offsets_kernel(const uint64_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (uint32_t)in[i];

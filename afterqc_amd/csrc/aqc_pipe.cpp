@@ -536,6 +536,7 @@ struct OutChunk {
     bool gz = false;
     uint64_t n = 0;
     bool last = false;
+    bool fatal = false;          // upstream's run ends behind this chunk's n records (Run::dies_at_record)
 };
 
 }  // namespace
@@ -572,6 +573,10 @@ struct Run {
     std::mutex err_mu;
     std::string err;
     int err_code = 0;
+    // the run ends at a record (dies_at_record): the earliest chunk that says so, and what it said
+    uint64_t fatal_chunk = UINT64_MAX;
+    std::string fatal_err;
+    int fatal_code = 0;
 
     // reader -> dispatcher
     std::unique_ptr<BQueue<InChunk>> inq[2];
@@ -872,7 +877,8 @@ struct Run {
                 stop_all();
                 return;
             }
-            const uint64_t n = info.n;
+            uint64_t n = info.n;
+            bool fatal = false;       // upstream's run ends inside this chunk (an exception in its loop): records [0, n) are written, then the pipe stops
             if ((rc = aqc_run(c, slot, UINT64_MAX))) { fail(rc, "aqc_run: %s", aqc_last_error()); return; }
             // post-filter QC while TOTAL_READS < qc_sample (preprocesser.py:624-627), issued in chunk order
             const uint64_t g0 = ch.first_index;
@@ -890,7 +896,7 @@ struct Run {
                 qc_next = j.idx + 1;
                 lk.unlock();
                 qc_cv.notify_all();
-                if (rc) { fail(rc, "aqc_qc_stat: %s", aqc_last_error()); return; }
+                if (rc && !dies_at_record(c, slot, rc, j.idx, n, fatal)) { fail(rc, "aqc_qc_stat: %s", aqc_last_error()); return; }
             } else {
                 // (chunks behind the sample never wait; the turn counter is passed on by the ones before)
                 std::lock_guard<std::mutex> g(qc_mu);
@@ -898,51 +904,89 @@ struct Run {
             }
             OutChunk oc;
             oc.idx = j.idx;
-            oc.n = n;
             oc.last = j.last;
             oc.worker = wid;
             if (!opt->no_output) {
-                if ((rc = aqc_format(c, slot, n, opt->store_overlap, oc.sizes))) { fail(rc, "aqc_format: %s", aqc_last_error()); return; }
-                ns_kernels += now_ns() - tt;
-                tt = now_ns();
-                // wait for the writer to hand this buffer set back
-                {
-                    std::unique_lock<std::mutex> lk(set_mu);
-                    set_cv.wait(lk, [&] { return abort || set_free[wid * 2 + set]; });
-                    if (abort) return;
-                    set_free[wid * 2 + set] = 0;
+                bool have_set = false, in_gate = false;
+                // (a second round only when the device reports, as late as the download, that upstream's run ends at a record of
+                //  this chunk: the records before it are formatted again on their own)
+                for (int round = 0; ; ++round) {
+                    const char* where = "aqc_format";
+                    rc = aqc_format(c, slot, n, opt->store_overlap, oc.sizes);
+                    if (!rc && !have_set) {
+                        ns_kernels += now_ns() - tt;
+                        tt = now_ns();
+                        // wait for the writer to hand this buffer set back
+                        std::unique_lock<std::mutex> lk(set_mu);
+                        set_cv.wait(lk, [&] { return abort || set_free[wid * 2 + set]; });
+                        if (abort) return;
+                        set_free[wid * 2 + set] = 0;
+                        have_set = true;
+                        ns_wait_set += now_ns() - tt;
+                        tt = now_ns();
+                    }
+                    // .gz output: the members are made on the device (aqc_gzdev.hpp) and come back compressed — no host CPU for
+                    // deflate, a third of the bytes over PCIe.  --compression 0 (stored) and AQC_GZ_DEVICE=0 keep the host codec.
+                    oc.gz = gz_on_device;
+                    if (!rc && oc.gz) { where = "aqc_compress"; rc = aqc_compress(c, slot, io->gzip_level, oc.gz_sizes); }
+                    if (!rc) {
+                        if (!in_gate && !gate_enter(dg, j.ticket, (uint64_t)P->slots)) return;
+                        in_gate = true;
+                        // the six streams with one wait (aqc_fetch_streams)
+                        uint8_t* dstq[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                        uint64_t capq[6] = {0, 0, 0, 0, 0, 0};
+                        for (int q = 0; q < 6; ++q) {
+                            if (!oc.sizes[q]) continue;
+                            HostBuf& hb = P->wbufs[wid].out[set][q];
+                            hb.ensure(oc.gz ? oc.gz_sizes[q] : oc.sizes[q]);
+                            if (!hb.p) { gate_leave(dg); fail(AQC_ERR_HIP, "page-locked allocation failed"); return; }
+                            dstq[q] = hb.p; capq[q] = hb.cap;
+                        }
+                        where = "fetching the output streams";
+                        rc = aqc_fetch_streams(c, slot, oc.gz ? 1 : 0, dstq, capq);
+                    }
+                    if (!rc) break;
+                    if (round == 0 && !fatal && dies_at_record(c, slot, rc, j.idx, n, fatal)) continue;
+                    if (in_gate) gate_leave(dg);
+                    fail(rc, "%s: %s", where, aqc_last_error());
+                    return;
                 }
-                ns_wait_set += now_ns() - tt;
-                tt = now_ns();
-                // .gz output: the members are made on the device (aqc_gzdev.hpp) and come back compressed — no host CPU for
-                // deflate, a third of the bytes over PCIe.  --compression 0 (stored) and AQC_GZ_DEVICE=0 keep the host codec.
-                oc.gz = gz_on_device;
-                if (oc.gz && (rc = aqc_compress(c, slot, io->gzip_level, oc.gz_sizes))) { fail(rc, "aqc_compress: %s", aqc_last_error()); return; }
-                if (!gate_enter(dg, j.ticket, (uint64_t)P->slots)) return;
-                // the six streams with one wait (aqc_fetch_streams)
-                uint8_t* dstq[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-                uint64_t capq[6] = {0, 0, 0, 0, 0, 0};
-                for (int q = 0; q < 6; ++q) {
-                    if (!oc.sizes[q]) continue;
-                    HostBuf& hb = P->wbufs[wid].out[set][q];
-                    hb.ensure(oc.gz ? oc.gz_sizes[q] : oc.sizes[q]);
-                    if (!hb.p) { gate_leave(dg); fail(AQC_ERR_HIP, "page-locked allocation failed"); return; }
-                    dstq[q] = hb.p; capq[q] = hb.cap;
-                }
-                rc = aqc_fetch_streams(c, slot, oc.gz ? 1 : 0, dstq, capq);
-                gate_leave(dg);
-                if (rc) { fail(rc, "fetching the output streams: %s", aqc_last_error()); return; }
+                if (in_gate) gate_leave(dg);
                 ns_fetch += now_ns() - tt;
                 oc.set = set;
                 set ^= 1;
             } else {
                 if (!gate_enter(dg, j.ticket, (uint64_t)P->slots)) return;
                 gate_leave(dg);
-                if ((rc = aqc_sync(c, slot))) { fail(rc, "aqc_sync: %s", aqc_last_error()); return; }
+                if ((rc = aqc_sync(c, slot)) && !dies_at_record(c, slot, rc, j.idx, n, fatal)) { fail(rc, "aqc_sync: %s", aqc_last_error()); return; }
             }
+            oc.n = n;
+            oc.fatal = fatal;
+            if (fatal) oc.last = true;
             records += n;
-            if (!outq.push(oc)) return;
+            if (!outq.push(oc) || fatal) return;
         }
+    }
+
+    // An exception INSIDE upstream's loop (KeyError / IndexError of the overlap walk, int() of a name field) ends its run at that
+    // record with everything before it written.  The device reports the earliest such record of the chunk (aqc_error_record): the
+    // chunk is cut there and becomes the run's last one — the writer commits it in its turn, then the pipe stops and aqc_pipe_run
+    // returns the error.  (Chunks are committed in order: a death in a later chunk never overtakes an earlier chunk's records.)
+    bool dies_at_record(aqc_ctx* c, int slot, int rc, uint64_t chunk_idx, uint64_t& n, bool& fatal) {
+        if (rc != AQC_ERR_INDEX && rc != AQC_ERR_ALPHABET && rc != AQC_ERR_ARG) return false;
+        uint64_t rec = UINT64_MAX;
+        if (aqc_error_record(c, slot, &rec) || rec == UINT64_MAX || rec >= n) return false;
+        {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (fatal_chunk == UINT64_MAX || chunk_idx < fatal_chunk) {
+                fatal_chunk = chunk_idx;
+                fatal_err = aqc_last_error();
+                fatal_code = rc;
+            }
+        }
+        n = rec;
+        fatal = true;
+        return true;
     }
 
     // ---- writer: commit in chunk order ------------------------------------------------------------------------------------
@@ -1035,12 +1079,24 @@ struct Run {
                 }
                 res->chunks += 1;
                 ++next;
+                if (cur.fatal) fatal_commit = cm;
                 if (cur.last) { done = true; break; }
             }
         }
         outq.close();
         for (int q = 0; q < 6; ++q) fileq[q]->close();
+        if (fatal_commit) {
+            // upstream died inside this chunk: everything up to the record is on its way to the files; once it is there the
+            // rest of the pipe (readers, workers with later chunks) is stopped and the run reports the error
+            while (!abort && fatal_commit->remaining.load() > 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+            {
+                std::lock_guard<std::mutex> g(err_mu);
+                if (err.empty()) { err = fatal_err; err_code = fatal_code; }
+            }
+            stop_all();
+        }
     }
+    std::shared_ptr<Commit> fatal_commit;
 };
 
 }  // namespace

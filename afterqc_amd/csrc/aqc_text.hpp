@@ -373,7 +373,9 @@ __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t*
             b = nl_at + 1u;
         }
         out.name_off[r] = s[0]; out.name_len[r] = l[0];
-        out.seq_off[r] = s[1];  out.seq_len[r] = l[1];
+        // a quality line of another length than its sequence line: the reference does not mind (fastq.py:37-49 hands the lines
+        // over as they are) — the record is marked, every later stage keeps a view per string (aqc_kernels.hpp, LEN_IRR)
+        out.seq_off[r] = s[1];  out.seq_len[r] = l[1] | (l[1] != l[3] ? LEN_IRR : 0u);
         out.plus_off[r] = s[2]; out.plus_len[r] = l[2];
         out.qual_off[r] = s[3]; out.qual_len[r] = l[3] | tail_nl;
     }
@@ -436,7 +438,7 @@ __global__ void frame_finish_kernel(const unsigned long long* __restrict__ d_tot
         const unsigned long long end = (unsigned long long)(e & LINE_POS) + 1;
         o.consumed[k] = end < bytes[k] ? end : bytes[k];
     }
-    o.next_len1 = o.avail[0] > n ? seq_len0[n] : 0u;
+    o.next_len1 = o.avail[0] > n ? (seq_len0[n] & LEN_MASK) : 0u;
     *out = o;
 }
 
@@ -525,10 +527,26 @@ __device__ __constant__ int FLAG_TEXT_LEN[AQC_N_FLAGS] = {4, 7, 7, 8, 8, 6, 6, 6
 struct TextFile {
     const uint8_t* text;
     const uint32_t *seq_off, *qual_off;
-    const uint32_t *seq_len;
+    const uint32_t *seq_len;      // bit 31 (LEN_IRR): the quality line has a length of its own -> qual_len / qview
     const uint32_t *name_off, *name_len, *plus_off, *plus_len;
     const uint32_t *qual_len;     // bit 31: the quality line's '\n' follows it directly (frame_records_kernel)
+    const uint32_t *qview;        // final quality view (start | length << 16) of the records marked LEN_IRR, left by the verdict kernels
 };
+
+// The slice of the QUALITY line that record r of this file writes, when that line is not as long as the sequence line (LEN_IRR):
+// every slice upstream is a python slice of each string by its own length, the final view is what the verdict kernel left in
+// qview; getOverlap (preprocesser.py:78-84) takes r[3][len(r[3]) - overlap_len:] — a NEGATIVE start counts from the end.
+__device__ __forceinline__ void irregular_quality_slice(const TextFile& tf, uint64_t r, int plain, int overlap_pass, int ovl, int& qst, int& qlen) {
+    if (plain) { qst = 0; qlen = (int)(tf.qual_len[r] & LEN_MASK); return; }
+    const uint32_t qv = tf.qview[r];
+    const int vs = (int)(qv & 0xffffu), vl = (int)(qv >> 16);
+    qst = vs; qlen = vl;
+    if (overlap_pass) {
+        const int k = vl - ovl;
+        if (k >= 0) { qst = vs + k; qlen = ovl; }
+        else if (-k <= vl) { qst = vs + vl + k; qlen = -k; }
+    }
+}
 
 struct FormatView {
     TextFile f[2];
@@ -579,11 +597,12 @@ __device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int f
     const int flag = (int)(w0.x & 0xffu);
     const TextFile& t = v.f[file];
     uint32_t len = file == 0 ? (w0.y & 0xffffu) : (w0.z & 0xffffu);
-    if (v.plain) len = t.seq_len[r];                        // index records go out whole
+    const uint32_t slw = t.seq_len[r];
+    if (v.plain) len = slw & LEN_MASK;                      // index records go out whole
     uint32_t nlen = t.name_len[r];
     if (v.barcode && !v.plain) {
         const uint32_t bc = reinterpret_cast<const uint8_t*>(v.results + r)[31];
-        const int b = moved_barcode_len(v, file, flag, bc, t.seq_len[r]);
+        const int b = moved_barcode_len(v, file, flag, bc, slw & LEN_MASK);
         if (b >= 0) {
             // name[str.find(':'):] — find() == -1 slices the last character
             const uint8_t* name = t.text + t.name_off[r];
@@ -594,12 +613,27 @@ __device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int f
         }
     }
     const uint32_t body = nlen + t.plus_len[r] + 4u;
-    sz[0] = flag == AQC_GOOD ? body + 2u * len : 0u;
-    sz[1] = flag == AQC_GOOD ? 0u : body + (uint32_t)FLAG_TEXT_LEN[flag] + 2u * len;
+    uint32_t qlen = len;                                    // the quality line written beside `len` bases
+    if (slw & LEN_IRR) {
+        int qs_, ql_;
+        irregular_quality_slice(t, r, v.plain, 0, 0, qs_, ql_);
+        qlen = (uint32_t)ql_;
+    }
+    sz[0] = flag == AQC_GOOD ? body + len + qlen : 0u;
+    sz[1] = flag == AQC_GOOD ? 0u : body + (uint32_t)FLAG_TEXT_LEN[flag] + len + qlen;
     sz[2] = 0u;
     if (v.store_overlap) {
         const uint4 w1 = *(reinterpret_cast<const uint4*>(v.results + r) + 1);
-        if (in_overlap_stream(v, w0, w1)) sz[2] = body + 2u * (v.plain ? len : (w0.w & 0xffffu));   // getOverlap: the last overlap_len bases
+        if (in_overlap_stream(v, w0, w1)) {
+            const uint32_t olen = v.plain ? len : (w0.w & 0xffffu);                                   // getOverlap: the last overlap_len bases
+            uint32_t oq = v.plain ? qlen : olen;
+            if ((slw & LEN_IRR) && !v.plain) {
+                int qs_, ql_;
+                irregular_quality_slice(t, r, 0, 1, (int)olen, qs_, ql_);
+                oq = (uint32_t)ql_;
+            }
+            sz[2] = body + olen + oq;
+        }
     }
 }
 
@@ -711,7 +745,8 @@ __device__ inline void fmt_build(const FormatView& v, uint64_t r, int file, int 
     const int len1 = (int)(w0.y & 0xffffu), len2 = (int)(w0.z & 0xffffu), ovl = (int)(w0.w & 0xffffu);
     const TextFile& tf = v.f[file];
     const uint32_t name_off = tf.name_off[r], seq_off = tf.seq_off[r], plus_off = tf.plus_off[r], qual_off = tf.qual_off[r];
-    const int nlen = (int)tf.name_len[r], plen = (int)tf.plus_len[r], slen = (int)tf.seq_len[r];
+    const uint32_t slw = tf.seq_len[r];
+    const int nlen = (int)tf.name_len[r], plen = (int)tf.plus_len[r], slen = (int)(slw & LEN_MASK);
     // the slice of the original read that is written: the final read, or its last overlap_len bases (getOverlap)
     const int cut = v.plain ? 0 : (overlap_pass ? (file == 0 ? len1 : len2) - ovl : 0);
     const int st = v.plain ? 0 : (file == 0 ? (int)(w0.x >> 16) : (int)(w0.y >> 16)) + cut;
@@ -741,8 +776,15 @@ __device__ inline void fmt_build(const FormatView& v, uint64_t r, int file, int 
     fmt_add(t, o, plen, plus_off);
     fmt_add(t, o, 1, qual_off == plus_off + (uint32_t)plen + 1 ? plus_off + (uint32_t)plen : NL);
     const int qual_dst = o;
-    fmt_add(t, o, len, qual_off + (uint32_t)st);
-    fmt_add(t, o, 1, (st + len == slen && (tf.qual_len[r] >> 31)) ? qual_off + (uint32_t)slen : NL);
+    // the quality line: the same slice as the bases, unless this record's quality line has a length of its own
+    int qst = st, qlen = len, qline = slen;
+    const bool irr = (slw & LEN_IRR) != 0u;
+    if (irr) {
+        qline = (int)(tf.qual_len[r] & LEN_MASK);
+        irregular_quality_slice(tf, r, v.plain, overlap_pass, ovl, qst, qlen);
+    }
+    fmt_add(t, o, qlen, qual_off + (uint32_t)qst);
+    fmt_add(t, o, 1, (qst + qlen == qline && (tf.qual_len[r] >> 31)) ? qual_off + (uint32_t)qline : NL);
     if (o > 0xffff) { atomicCAS(status, 0, AQC_ERR_UNSUPPORTED); t.stream = 0xff; return; }      // (a 64 KiB FASTQ record)
     t.total = (uint16_t)o;
     int items = 0;
@@ -757,6 +799,26 @@ __device__ inline void fmt_build(const FormatView& v, uint64_t r, int file, int 
         const int oo = (int)(x & 0xffffu);
         const uint32_t kind = (uint32_t)(x >> 16) & 0xffu, base = (uint32_t)(x >> 24) & 0xffu, qual = (uint32_t)(x >> 32) & 0xffu;
         const int pp = (file == 0 ? len1 - ovl + oo : len2 - 1 - oo) - cut;
+        if (irr) {
+            // each string was edited at its OWN index (preprocesser.py:575-576,583-584,591-592): the bases at pp, the quality
+            // view (start vs, length vl) at vl - overlap_len + o (a negative index wraps) resp. vl - 1 - o; two edits may meet
+            // in one quality character — the later one stands
+            const uint32_t qv = tf.qview[r];
+            const int vs = (int)(qv & 0xffffu), vl = (int)(qv >> 16);
+            int iq = file == 0 ? vl - ovl + oo : vl - 1 - oo;
+            if (iq < 0) iq += vl;
+            const int qp = vs + iq - qst;                    // in the slice that is written
+            const bool mine = (kind == AQC_EDIT_FIX_R1 && file == 0) || (kind == AQC_EDIT_FIX_R2 && file == 1);
+            if (mine && base && pp >= 0 && pp < len) t.patch[t.n_patch++] = (uint32_t)(seq_dst + pp) | (base << 16);
+            if ((mine || kind == AQC_EDIT_MASK) && iq >= 0 && qp >= 0 && qp < qlen) {
+                const uint32_t at = (uint32_t)(qual_dst + qp), val = kind == AQC_EDIT_MASK ? (uint32_t)'!' : qual;
+                bool merged = false;
+                for (int k = 0; k < (int)t.n_patch; ++k)
+                    if ((t.patch[k] & 0xffffu) == at) { t.patch[k] = at | (val << 16); merged = true; }
+                if (!merged) t.patch[t.n_patch++] = at | (val << 16);
+            }
+            continue;
+        }
         if (pp < 0 || pp >= len) continue;
         if (kind == AQC_EDIT_MASK) t.patch[t.n_patch++] = (uint32_t)(qual_dst + pp) | ((uint32_t)'!' << 16);
         else if ((kind == AQC_EDIT_FIX_R1 && file == 0) || (kind == AQC_EDIT_FIX_R2 && file == 1)) {

@@ -204,8 +204,9 @@ class _TextSink:
 
     N_SETS = 3
 
-    def __init__(self, eng, writers, n_slots):
+    def __init__(self, eng, writers, n_slots, store_overlap=False):
         self.eng = eng
+        self.store_overlap = store_overlap
         self.writers = writers                       # per file (good, bad, overlap); None = not written
         self.sets = [[None] * 6 for _ in range(self.N_SETS)]
         self.set_free = [threading.Semaphore(1) for _ in range(self.N_SETS)]
@@ -213,6 +214,8 @@ class _TextSink:
         self.fq = queue.Queue()
         self.wq = queue.Queue()
         self.err = None
+        self.death = None                            # upstream's run ends inside a chunk (death_record): raised once all is written
+        self.dead = False
         self.fetcher = threading.Thread(target=self._fetch, daemon=True)
         self.writer = threading.Thread(target=self._write, daemon=True)
         self.fetcher.start()
@@ -225,24 +228,39 @@ class _TextSink:
             if job is None:
                 self.wq.put(None)
                 return
-            slot, sizes = job
+            slot, sizes = job[0], job[1]
+            died = len(job) > 2 and job[2]           # (the main loop cut this chunk at the record upstream dies at)
+
+            def fetch_all(sizes):
+                for q, nbytes in enumerate(sizes):
+                    if q // 3 >= len(self.writers) or nbytes == 0 or self.writers[q // 3][q % 3] is None:
+                        continue
+                    buf = self.sets[which][q]
+                    if buf is None or buf.nbytes < nbytes:
+                        if buf is not None:
+                            buf.free()
+                        buf = self.sets[which][q] = self.eng.host_buffer(nbytes + nbytes // 4 + 4096)
+                    self.eng.fetch_text(slot, q // 3, q % 3, buf.array, buf.nbytes)
+
             try:
                 self.set_free[which].acquire()           # the writer is done with this buffer set
                 if self.err is None:
-                    for q, nbytes in enumerate(sizes):
-                        if q // 3 >= len(self.writers) or nbytes == 0 or self.writers[q // 3][q % 3] is None:
-                            continue
-                        buf = self.sets[which][q]
-                        if buf is None or buf.nbytes < nbytes:
-                            if buf is not None:
-                                buf.free()
-                            buf = self.sets[which][q] = self.eng.host_buffer(nbytes + nbytes // 4 + 4096)
-                        self.eng.fetch_text(slot, q // 3, q % 3, buf.array, buf.nbytes)
+                    try:
+                        fetch_all(sizes)
+                    except capi.AqcError as e:
+                        # an exception inside upstream's loop: its run ends at that record, what came before is written
+                        k = death_record(self.eng, slot, e)
+                        if k is None:
+                            raise
+                        sizes = self.eng.format(slot, k, self.store_overlap)
+                        fetch_all(sizes)
+                        self.death = e
+                        died = True
             except BaseException as e:
                 self.err = e
             finally:
                 self.slot_free[slot].release()           # the slot may take the next chunk
-                self.wq.put((which, list(sizes)))
+                self.wq.put((which, list(sizes), died))
                 which = (which + 1) % self.N_SETS
 
     def _write(self):
@@ -250,9 +268,11 @@ class _TextSink:
             job = self.wq.get()
             if job is None:
                 return
-            which, sizes = job
+            which, sizes, died = job
             try:
-                if self.err is None:
+                if self.err is None and not self.dead:
+                    if died:
+                        self.dead = True                 # this chunk is the last one written
                     for q, nbytes in enumerate(sizes):
                         if nbytes and q // 3 < len(self.writers) and self.writers[q // 3][q % 3] is not None:
                             self.writers[q // 3][q % 3].write_bytes(self.sets[which][q].view[:nbytes])
@@ -271,8 +291,10 @@ class _TextSink:
     def release_slot(self, slot):
         self.slot_free[slot].release()
 
-    def emit(self, slot, sizes):
-        self.fq.put((slot, list(sizes)))
+    def emit(self, slot, sizes, death=None):
+        if death is not None:
+            self.death = death
+        self.fq.put((slot, list(sizes), death is not None))
 
     def close(self):
         self.fq.put(None)
@@ -284,6 +306,17 @@ class _TextSink:
                     b.free()
         if self.err is not None:
             raise self.err
+        if self.death is not None:
+            raise self.death
+
+
+def death_record(eng, slot, e):
+    """An exception INSIDE the reference's loop (KeyError / IndexError of the overlap walk, int() of a name field) ends its run
+    at that record, with everything before it written.  -> the index of that record in the slot, or None when the error is
+    not of that kind."""
+    if isinstance(e, capi.AqcError) and e.code in capi.RECORD_ERRORS and hasattr(eng, "error_record"):
+        return eng.error_record(slot)
+    return None
 
 
 class seqFilter:
@@ -459,22 +492,25 @@ class seqFilter:
                 self.timing["pipe_fallback"] = True
                 for e in self._engines():
                     e.reset_stats()
-        if extra_bases is not None:
-            pass
-        elif self.text_path and (has_i1 or has_i2):
-            outs = _Outputs(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, opt.compression)
-            extra_bases = self._run_text_indexed(eng, opt, outs, paired)
-        elif self.text_path:
-            outs = _Outputs(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, opt.compression)
-            extra_bases = self._run_text(eng, opt, outs, paired)
-        else:
-            outs = _Outputs(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, opt.compression)
-            readers, extra_bases = self._run_host(eng, opt, outs, paired, files)
-        for r in readers:
-            if r is not None:
-                r.close()
-        if outs is not None:
-            outs.close()
+        try:
+            if extra_bases is not None:
+                pass
+            elif self.text_path and (has_i1 or has_i2):
+                outs = _Outputs(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, opt.compression)
+                extra_bases = self._run_text_indexed(eng, opt, outs, paired)
+            elif self.text_path:
+                outs = _Outputs(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, opt.compression)
+                extra_bases = self._run_text(eng, opt, outs, paired)
+            else:
+                outs = _Outputs(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, opt.compression)
+                readers, extra_bases = self._run_host(eng, opt, outs, paired, files)
+        finally:
+            # (also when the run ends in an exception: what was written up to the record upstream dies at stays written)
+            for r in readers:
+                if r is not None:
+                    r.close()
+            if outs is not None:
+                outs.close()
         self.timing["pass2_s"] = time.perf_counter() - t_p2
         self.timing["pass2_cpu_s"] = sum(os.times()[:2]) - cpu_p2          # user + system, all threads: how many cores pass 2 kept busy
 
@@ -540,6 +576,11 @@ class seqFilter:
             res = pipe.run(files[:nfiles], outputs, gzip_in=[f.endswith(".gz") for f in files[:nfiles]], gzip_out=gzip_out,
                            gzip_level=opt.compression, chunk_records=self.chunk_records, qc_sample=opt.qc_sample,
                            store_overlap=bool(opt.store_overlap) and paired)
+        except capi.AqcError as e:
+            # (an exception inside upstream's loop — capi.RECORD_ERRORS — ends the run at that record: the pipe has written
+            #  everything before it and says so; there is nothing to rerun)
+            self.used_pipe = e.code in capi.RECORD_ERRORS
+            raise
         finally:
             pipe.close()
         self.used_pipe = not res.anomaly
@@ -620,25 +661,34 @@ class seqFilter:
                             inputs[k].grow(cur)
                         inputs[k].carry(cur, state[k][2], fills[k][0], fills[k][1], state[k][1] or (k != 0 and done[k]))
                 if n:
-                    limit = UNLIMITED
-                    if opt.qc_only:
-                        eng.run(0, 0)
-                        flags = eng.fetch_results(0)[:n]["flag"]
-                        hit = np.flatnonzero((flags == capi.GOOD) & (total + 1 + np.arange(n) >= opt.qc_sample))
-                        if len(hit):
-                            n = int(hit[0]) + 1
-                            stop = True
-                        limit = n
-                    eng.run(0, limit)
-                    n_qc = n if opt.qc_sample <= 0 else max(0, min(n, opt.qc_sample - 1 - total))
-                    if n_qc > 0:
-                        eng.qc_stat(0, capi.QC_R1_POST, 0, 0, n_qc, 1)
-                        if paired:
-                            eng.qc_stat(0, capi.QC_R2_POST, 1, 0, n_qc, 1)
-                    eng.sync(0)
+                    death = None
+                    try:
+                        limit = UNLIMITED
+                        if opt.qc_only:
+                            eng.run(0, 0)
+                            flags = eng.fetch_results(0)[:n]["flag"]
+                            hit = np.flatnonzero((flags == capi.GOOD) & (total + 1 + np.arange(n) >= opt.qc_sample))
+                            if len(hit):
+                                n = int(hit[0]) + 1
+                                stop = True
+                            limit = n
+                        eng.run(0, limit)
+                        n_qc = n if opt.qc_sample <= 0 else max(0, min(n, opt.qc_sample - 1 - total))
+                        if n_qc > 0:
+                            eng.qc_stat(0, capi.QC_R1_POST, 0, 0, n_qc, 1)
+                            if paired:
+                                eng.qc_stat(0, capi.QC_R2_POST, 1, 0, n_qc, 1)
+                        eng.sync(0)
+                    except capi.AqcError as e:
+                        k = death_record(eng, 0, e)          # upstream's run ends at that record, what came before is written
+                        if k is None or k >= n:
+                            raise
+                        n, death = k, e
                     if not opt.qc_only:
                         write_streams(0, groups[0], eng.format(0, n, bool(opt.store_overlap)))
                         write_streams(1, groups[1], eng.format_plain(1, 0, n, bool(opt.store_overlap)))
+                    if death is not None:
+                        raise death
                     total += n
                 if stop:
                     break
@@ -694,9 +744,22 @@ class seqFilter:
                 eng.qc_stat(slot, capi.QC_R1_POST, 0, 0, n_qc, 1)
                 if paired:
                     eng.qc_stat(slot, capi.QC_R2_POST, 1, 0, n_qc, 1)
-            results = eng.fetch_results(slot)[:n]
+            death = None
+            try:
+                results = eng.fetch_results(slot)[:n]
+            except capi.AqcError as e:
+                k = death_record(eng, slot, e)               # upstream's run ends at that record, what came before is written
+                if k is None or k >= n:
+                    raise
+                n, death = k, e
+                results = eng.fetch_results(slot)[:n]
             if not opt.qc_only:
-                self._write(outs, rbs, results, n)
+                qviews = None
+                if batch.qlen1 is not None:
+                    qviews = [eng.fetch_quality_views(slot, 0), eng.fetch_quality_views(slot, 1) if paired else None]
+                self._write(outs, rbs, results, n, qviews)
+            if death is not None:
+                raise death
             total += n
         return readers, extra_bases
 
@@ -709,7 +772,7 @@ class seqFilter:
         files = [opt.read1_file] + ([opt.read2_file] if paired else [])
         inputs = [_TextInput(eng, f, self.chunk_bytes) for f in files]
         n_slots = min(2, getattr(eng, "n_slots", 1))
-        sink = _TextSink(eng, [(outs.good[k], outs.bad[k], outs.overlap[k]) for k in range(len(files))], n_slots)
+        sink = _TextSink(eng, [(outs.good[k], outs.bad[k], outs.overlap[k]) for k in range(len(files))], n_slots, bool(opt.store_overlap))
         total = 0
         extra_bases = 0
         slot = 0
@@ -744,31 +807,42 @@ class seqFilter:
                             inp.grow(cur)                                  # not even one record fits the buffer
                         inp.carry(cur, consumed[k], fills[k][0], fills[k][1], eofs[k] or (k == 1 and done2))
                 if n:
-                    limit = capi.UINT64_MAX
+                    death = None
+                    try:
+                        limit = capi.UINT64_MAX
+                        if opt.qc_only:
+                            # --qc_only stops at the first good record whose 1-based index reaches qc_sample (:630-631):
+                            # verdicts first (nothing accumulated), then the accumulating run up to that record
+                            eng.run(slot, 0)
+                            flags = eng.fetch_results(slot)[:n]["flag"]
+                            hit = np.flatnonzero((flags == capi.GOOD) & (total + 1 + np.arange(n) >= opt.qc_sample))
+                            if len(hit):
+                                n = int(hit[0]) + 1
+                                stop = True
+                            limit = n
+                        eng.run(slot, limit)
+                        # post-filter QC on good records while TOTAL_READS < qc_sample (preprocesser.py:624-627)
+                        n_qc = n if opt.qc_sample <= 0 else max(0, min(n, opt.qc_sample - 1 - total))
+                        if n_qc > 0:
+                            eng.qc_stat(slot, capi.QC_R1_POST, 0, 0, n_qc, 1)
+                            if paired:
+                                eng.qc_stat(slot, capi.QC_R2_POST, 1, 0, n_qc, 1)
+                            eng.sync(slot)       # the sampling kernels share per-context scratch: never two chunks at once
+                        if opt.qc_only:
+                            eng.sync(slot)
+                    except capi.AqcError as e:
+                        # an exception inside upstream's loop ends its run AT that record: what came before is written
+                        k = death_record(eng, slot, e)
+                        if k is None or k >= n:
+                            raise
+                        n, death, stop = k, e, True
                     if opt.qc_only:
-                        # --qc_only stops at the first good record whose 1-based index reaches qc_sample (:630-631):
-                        # verdicts first (nothing accumulated), then the accumulating run up to that record
-                        eng.run(slot, 0)
-                        flags = eng.fetch_results(slot)[:n]["flag"]
-                        hit = np.flatnonzero((flags == capi.GOOD) & (total + 1 + np.arange(n) >= opt.qc_sample))
-                        if len(hit):
-                            n = int(hit[0]) + 1
-                            stop = True
-                        limit = n
-                    eng.run(slot, limit)
-                    # post-filter QC on good records while TOTAL_READS < qc_sample (preprocesser.py:624-627)
-                    n_qc = n if opt.qc_sample <= 0 else max(0, min(n, opt.qc_sample - 1 - total))
-                    if n_qc > 0:
-                        eng.qc_stat(slot, capi.QC_R1_POST, 0, 0, n_qc, 1)
-                        if paired:
-                            eng.qc_stat(slot, capi.QC_R2_POST, 1, 0, n_qc, 1)
-                        eng.sync(slot)       # the sampling kernels share per-context scratch: never two chunks at once
-                    if opt.qc_only:
-                        eng.sync(slot)
                         sink.release_slot(slot)
+                        if death is not None:
+                            raise death
                     else:
                         sizes = eng.format(slot, n, bool(opt.store_overlap))
-                        sink.emit(slot, sizes)   # (the fetch thread releases the slot)
+                        sink.emit(slot, sizes, death)   # (the fetch thread releases the slot)
                     total += n
                 else:
                     sink.release_slot(slot)
@@ -783,7 +857,9 @@ class seqFilter:
         return extra_bases
 
     # ---- output formatting (writeReads, preprocesser.py:206-232; fastq.Writer.writeLines) ------------
-    def _write(self, outs, rbs, results, n):
+    def _write(self, outs, rbs, results, n, qviews=None):
+        """qviews: per mate (starts, lengths) of the quality-string slices (Engine.fetch_quality_views) when some record's quality
+        line is not as long as its sequence line; None: the slices of the reads"""
         opt = self.options
         paired = self.paired
         vlen = len(opt.barcode_verify)
@@ -809,22 +885,26 @@ class seqFilter:
                     b2 = (bc >> 4) - 2 + bl
                     name2 = b"@" + s2[0:b2] + name2[name2.find(b":"):]
             st, ln = int(r["start1"]), int(r["len1"])
-            s1 = bytearray(s1[st:st + ln]); q1 = bytearray(q1[st:st + ln])
+            qs, ql = (st, ln) if qviews is None else (int(qviews[0][0][i]), int(qviews[0][1][i]))
+            s1 = bytearray(s1[st:st + ln]); q1 = bytearray(q1[qs:qs + ql])
             if paired:
                 st2, ln2 = int(r["start2"]), int(r["len2"])
-                s2 = bytearray(s2[st2:st2 + ln2]); q2 = bytearray(q2[st2:st2 + ln2])
+                qs2, ql2 = (st2, ln2) if qviews is None else (int(qviews[1][0][i]), int(qviews[1][1][i]))
+                s2 = bytearray(s2[st2:st2 + ln2]); q2 = bytearray(q2[qs2:qs2 + ql2])
             ov = int(r["overlap_len"])
             ne = int(r["n_edits"])
             corrected = 0
+            # (each string is edited at its OWN index, preprocesser.py:575-592: the quality strings from their own ends — the
+            #  same positions as the bases' unless a quality line has a length of its own; a negative index wraps, as upstream)
             for k in range(ne):
                 e = r["edits"][k]
                 o = int(e["o"]); kind = int(e["kind"])
                 if kind == capi.EDIT_FIX_R2:
-                    s2[ln2 - 1 - o] = int(e["base"]); q2[ln2 - 1 - o] = int(e["qual"]); corrected += 1
+                    s2[ln2 - 1 - o] = int(e["base"]); q2[len(q2) - 1 - o] = int(e["qual"]); corrected += 1
                 elif kind == capi.EDIT_FIX_R1:
-                    s1[ln - ov + o] = int(e["base"]); q1[ln - ov + o] = int(e["qual"]); corrected += 1
+                    s1[ln - ov + o] = int(e["base"]); q1[len(q1) - ov + o] = int(e["qual"]); corrected += 1
                 else:
-                    q2[ln2 - 1 - o] = 33; q1[ln - ov + o] = 33
+                    q2[len(q2) - 1 - o] = 33; q1[len(q1) - ov + o] = 33
             which = 0 if flag == capi.GOOD else 1
             if which == 1:
                 fb = FLAG_BYTES[flag]
@@ -835,8 +915,8 @@ class seqFilter:
                 dist = int(r["distance"])
                 if dist == 0 or dist == corrected:
                     # getOverlap (preprocesser.py:78-84): the last overlap_len bases of both reads
-                    chunks[0][2].append(name1 + b"\n" + bytes(s1[ln - ov:]) + b"\n" + p1 + b"\n" + bytes(q1[ln - ov:]) + b"\n")
-                    chunks[1][2].append(name2 + b"\n" + bytes(s2[ln2 - ov:]) + b"\n" + p2 + b"\n" + bytes(q2[ln2 - ov:]) + b"\n")
+                    chunks[0][2].append(name1 + b"\n" + bytes(s1[ln - ov:]) + b"\n" + p1 + b"\n" + bytes(q1[len(q1) - ov:]) + b"\n")
+                    chunks[1][2].append(name2 + b"\n" + bytes(s2[ln2 - ov:]) + b"\n" + p2 + b"\n" + bytes(q2[len(q2) - ov:]) + b"\n")
                     for k, rbx in ((2, rbi1), (3, rbi2)):
                         if rbx is not None:
                             chunks[k][2].append(b"\n".join(rbx.record(i)) + b"\n")

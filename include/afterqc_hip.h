@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AQC_ABI_VERSION 1
+#define AQC_ABI_VERSION 2
 
 /* longest read the reference's QC can hold (qualitycontrol.py:23 MAX_LEN = 1000) */
 #define AQC_MAX_READ_LEN 1000
@@ -44,6 +44,8 @@ extern "C" {
 #define AQC_ERR_STATE -5        /* call sequence error (e.g. results of a slot that never ran) */
 #define AQC_ERR_ALPHABET -6     /* a byte the reference would raise KeyError on (util.py:27,36-37) */
 #define AQC_ERR_UNSUPPORTED -7  /* option value outside what the device path implements */
+#define AQC_ERR_INDEX -8        /* the overlap walk indexed a quality string outside its length (IndexError upstream,
+                                   preprocesser.py:566-567: a quality line shorter than the overlap it is read in) */
 
 /* record verdicts == the reference's flag strings (preprocesser.py:436-614); AQC_GOOD = written to good/ */
 enum aqc_flag {
@@ -150,6 +152,12 @@ typedef struct aqc_batch {
     const int32_t* aux_x;
     const int32_t* aux_y;
     const uint8_t* aux_ok;
+    /* lengths of the QUALITY strings where they are not the reads' (NULL: qlen == len for every record).  The reference never
+     * compares the two lines of a record (fastq.py:37-49): each string is sliced, counted and indexed by its own length
+     * (preprocesser.py:19-28,61-76,565-568, qualitycontrol.py:81-88), and so it is here; aqc_fetch_quality_views returns the
+     * slices of the quality strings that go with start1/len1, start2/len2 of the result records. */
+    const uint32_t* qlen1;
+    const uint32_t* qlen2;
 } aqc_batch;
 
 /* scalar counters of preprocesser.py:378-409 (+ the 12-cell error matrix, init_error_matrix :125-132) */
@@ -241,6 +249,18 @@ int aqc_last_deferred(aqc_ctx* ctx, int slot, uint32_t* idx, uint64_t cap, uint6
 /* wait for the slot and copy its n result records to `out` */
 int aqc_fetch_results(aqc_ctx* ctx, int slot, aqc_result* out, uint64_t n);
 int aqc_sync(aqc_ctx* ctx, int slot);
+/* The slice of mate's (0 / 1) QUALITY string that the final read of each record keeps: out[i] = start | length << 16.  It is
+ * (start, len) of the result record unless the record's quality line is not as long as its sequence line — then every slice
+ * of preprocesser.py:19-28,521-524 / barcodeprocesser.py:42-43,66-69 was taken of a string of another length, and the walk's
+ * edits (aqc_edit.o) touched the quality string at length - overlap_len + o (mate 0; a negative index wraps the python way) /
+ * length - 1 - o (mate 1) of THIS slice. */
+int aqc_fetch_quality_views(aqc_ctx* ctx, int slot, int mate, uint32_t* out, uint64_t n);
+/* An exception INSIDE the reference's loop ends its run at that record, everything before it having been written: KeyError of
+ * util.complement / the error matrix (AQC_ERR_ALPHABET), IndexError of the walk on a short quality line (AQC_ERR_INDEX), int() of
+ * a name field for the bubble filter (AQC_ERR_ARG).  After a call on the slot returned one of those, *record is the index in
+ * the slot of the EARLIEST record that raises (UINT64_MAX: the error is not tied to a record).  The results of the records
+ * before it are valid: aqc_format(ctx, slot, *record, ...) builds exactly what upstream had written when it died. */
+int aqc_error_record(aqc_ctx* ctx, int slot, uint64_t* record);
 /* duration in ms of the last launch of each kernel on this slot (valid after aqc_sync) */
 int aqc_kernel_ms(aqc_ctx* ctx, int slot, float* ms /* [AQC_N_KERNELS] */);
 /* HIP-event timing over a region: aqc_timing_reset() starts collecting one event pair per kernel

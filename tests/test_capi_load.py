@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "missing export " + s
     assert sorted(capi.EXPORTED_SYMBOLS) == syms
-    assert lib.aqc_abi_version() == 1
+    assert lib.aqc_abi_version() == 2          # (2: aqc_batch.qlen1 / qlen2, AQC_ERR_INDEX, aqc_fetch_quality_views, aqc_error_record)
 
 
 def test_loads_the_way_the_reference_loads_libed():
@@ -44,7 +44,7 @@ def test_loads_the_way_the_reference_loads_libed():
 def test_struct_layouts_match_header():
     assert capi.RESULT_DTYPE.itemsize == 32
     assert ctypes.sizeof(capi.Config) == 18 * 4 + 32 + 2 * 4
-    assert ctypes.sizeof(capi.BatchStruct) == 8 * 2 + 8 * 7 * 2 + 8 * 5
+    assert ctypes.sizeof(capi.BatchStruct) == 8 * 2 + 8 * 7 * 2 + 8 * 5 + 8 * 2
     assert capi.N_COUNTERS == 4 + 12 + 10 + 16
     assert ctypes.sizeof(capi.TextChunk) == 8 * 4 + 4 * 2 + 8 * 2          # struct aqc_text_chunk
     assert ctypes.sizeof(capi.FrameInfo) == 8 * 5 + 4 * 4                  # struct aqc_frame_info
