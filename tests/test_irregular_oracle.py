@@ -4,8 +4,8 @@ loop (oracle/pyloop.py).  The reference never compares the two lengths: every st
 length (preprocesser.py:19-28, 61-76, 565-568 — negative indices wrap the Python way), the record is written through, and
 when the overlap walk reaches a position the quality line does not have the run dies with IndexError.
 
-The PRODUCT does not do this yet — aqc_frame reports such a record as a loud error — so there is no `-m gpu`
-counterpart; this test pins the oracle side, so that the device work has something exact to be compared with."""
+The product does the same on the device: tests/test_gpu_irregular.py (-m gpu) runs every case of the fixture through the HIP
+path.  This test pins the pure-Python restatement on the CPU (the paired cases without barcodes: pyloop has no barcode stage)."""
 import gzip
 import json
 import os
@@ -27,7 +27,7 @@ def _cases():
 def _options(argv):
     """after.py:17-92's defaults for what the loop consults, then the case's flags"""
     opt = dict(trim_front=0, trim_tail=0, seq_len_req=35, poly_size_limit=35, allow_mismatch_in_poly=2, qualified_quality_phred=15,
-               unqualified_base_limit=60, n_base_limit=5, no_overlap=0, no_correction=0, mask_mismatch=0)
+               unqualified_base_limit=60, n_base_limit=5, no_overlap=0, no_correction=0, mask_mismatch=0, store_overlap=0)
     it = iter(argv)
     for a in it:
         if a in ("-1", "-2"):
@@ -44,6 +44,8 @@ def _options(argv):
             opt["mask_mismatch"] = 1
         elif a == "--no_correction":
             opt["no_correction"] = 1
+        elif a == "--store_overlap":
+            opt["store_overlap"] = 1 if next(it) == "on" else 0
         else:
             raise AssertionError("flag not modelled: " + a)
     opt["trim_front2"], opt["trim_tail2"] = opt["trim_front"], opt["trim_tail"]          # after.py:205-206 (trim_pair_same)
@@ -56,7 +58,7 @@ def _records(text):
     return [lines[k:k + 4] for k in range(0, len(lines) - 1, 4)]
 
 
-@pytest.mark.parametrize("case", [c["case"] for c in _cases()])
+@pytest.mark.parametrize("case", [c["case"] for c in _cases() if c.get("kind", "pairs") in ("pairs", "adapter")])
 def test_pyloop_equals_the_reference_on_irregular_records(case):
     c = [x for x in _cases() if x["case"] == case][0]
     opt = _options(c["argv"])
@@ -64,7 +66,7 @@ def test_pyloop_equals_the_reference_on_irregular_records(case):
     assert len(r1) == len(r2) == 24
     irregular = sum(1 for a, b in zip(r1, r2) if len(a[1]) != len(a[3]) or len(b[1]) != len(b[3]))
     assert irregular >= 1
-    out = {"good/R1.good.fq": [], "good/R2.good.fq": [], "bad/R1.bad.fq": [], "bad/R2.bad.fq": []}
+    out = {"good/R1.good.fq": [], "good/R2.good.fq": [], "bad/R1.bad.fq": [], "bad/R2.bad.fq": [], "overlap/R1.overlap.fq": [], "overlap/R2.overlap.fq": []}
     died = None
     # statRead (qualitycontrol.py:73-110) over the raw reads (pre-filter: the 24-record file is sampled whole, :352-355) and over
     # the GOOD reads as the loop leaves them (post-filter, preprocesser.py:619-622)
@@ -86,6 +88,14 @@ def test_pyloop_equals_the_reference_on_irregular_records(case):
         if flag == pyloop.GOOD:
             qc["read1_postfilter"].stat_read(res["seq1"], res["qual1"])
             qc["read2_postfilter"].stat_read(res["seq2"], res["qual2"])
+        if flag == pyloop.GOOD and opt["store_overlap"] and res["overlap_len"] > 30:
+            # getOverlap (preprocesser.py:78-84,614-616): the last overlap_len characters of EACH string — a start index below
+            # zero (a quality line shorter than the overlap) counts from the end
+            corrected = sum(1 for e in res["edits"] if e[1] in (pyloop.EDIT_FIX_R1, pyloop.EDIT_FIX_R2))
+            if res["distance"] == 0 or res["distance"] == corrected:
+                ov = res["overlap_len"]
+                for m, nm, sq, pl, ql in ((1, n1, res["seq1"], a[2], res["qual1"]), (2, n2, res["seq2"], b[2], res["qual2"])):
+                    out["overlap/R%d.overlap.fq" % m].append("%s\n%s\n%s\n%s\n" % (nm, sq[len(sq) - ov:], pl, ql[len(ql) - ov:]))
         out["%s/R1.%s.fq" % (where, where)].append("%s\n%s\n%s\n%s\n" % (n1, res["seq1"], a[2], res["qual1"]))
         out["%s/R2.%s.fq" % (where, where)].append("%s\n%s\n%s\n%s\n" % (n2, res["seq2"], b[2], res["qual2"]))
     if c["returncode"] != 0:
