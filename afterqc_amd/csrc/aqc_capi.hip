@@ -835,11 +835,12 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
                           (uint32_t*)s->t_name_len[k].p, (uint32_t*)s->t_plus_off[k].p, (uint32_t*)s->t_plus_len[k].p,
                           (uint32_t*)s->t_qual_len[k].p};
             hipLaunchKernelGGL(frame_records_kernel, dim3((unsigned)((m + TXT_BLOCK - 1) / TXT_BLOCK)), dim3(TXT_BLOCK), 0, s->stream,
-                               (const uint8_t*)tbase[k], (const uint32_t*)s->t_line_end[k].p, (const unsigned long long*)(d_tot + k), virt[k], ff, d_meta + k);
+                               (const uint8_t*)tbase[k], (const uint32_t*)s->t_line_end[k].p, (const unsigned long long*)(d_tot + k), virt[k], ff, d_meta + k, (uint64_t)cap[k]);
         }
         hipLaunchKernelGGL(frame_finish_kernel, dim3(1), dim3(1), 0, s->stream, (const unsigned long long*)d_tot, (const FrameMeta*)d_meta,
                            (const uint32_t*)s->t_line_end[0].p, (const uint32_t*)(paired ? s->t_line_end[1].p : s->t_line_end[0].p), (const uint32_t*)s->len1.p,
-                           virt[0], virt[1], (unsigned long long)bytes[0], (unsigned long long)bytes[1], nf, (unsigned long long)ch->max_records, d_out);
+                           virt[0], virt[1], (unsigned long long)bytes[0], (unsigned long long)bytes[1], nf, (unsigned long long)ch->max_records, d_out,
+                           (unsigned long long)cap[0], (unsigned long long)cap[1]);
         if (bubble) {
             // lane / tile / x / y out of the R1 names (preprocesser.py:180-192) for the bubble filter
             for (int k = 0; k < 5; k++)

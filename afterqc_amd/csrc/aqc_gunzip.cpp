@@ -417,6 +417,13 @@ void ParallelGunzip::top_up(bool need_front) {
         }
         // The device's share: a GROUP of sections whenever it is free — from the TOP of the window down, so that the consumer,
         // who commits in index order, gets there last (offload_only: from the bottom up, nobody else feeds the consumer)
+        if (offload_ && offload_only_ && front_missing && on_device == 0 && !offload_->ready()) {
+            // Nothing of this stream is with the device and it still takes no work: it has given up (a failed hipMalloc of its lane
+            // buffers, any HIP error — DeviceInflate::broken_).  With the device as the ONLY decoder nobody would ever make the
+            // section the consumer waits for (round-4 advisory: aqc_gunzip_dev hung here): the host takes over from this section on.
+            offload_only_ = false;
+            continue;
+        }
         if (!offload_ || on_device >= 4 * per_group || !offload_->ready()) break;
         // ... but only while the pool still has more than two groups' worth of sections in front of it: a group takes the device
         // a fixed 100 - 200 ms (a block is decoded by one lane from start to end), and one that is started when the pool is about

@@ -338,9 +338,12 @@ struct FramedFile {
 //  the file's unterminated last line ends at this virtual line end — readline() returns it — which is line number *d_total)
 __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t* __restrict__ text,
                                                                   const uint32_t* __restrict__ line_end, const unsigned long long* __restrict__ d_total,
-                                                                  uint32_t virt_end, FramedFile out, FrameMeta* __restrict__ meta) {
-    const uint64_t real = *d_total;
-    const uint64_t n_rec = (real + (virt_end ? 1u : 0u)) / 4;
+                                                                  uint32_t virt_end, FramedFile out, FrameMeta* __restrict__ meta, uint64_t cap) {
+    // (`cap`: entries the line table holds.  The index pass COUNTS every line and writes the first `cap`: when a chunk of very
+    //  short lines overflows the table the host indexes it again with the exact size — until then nothing beyond the table may
+    //  be read, and no record beyond it written: the output arrays are sized for cap / 4 records — round-4 advisory)
+    const uint64_t real = *d_total < cap ? *d_total : cap;
+    const uint64_t n_rec = (real + ((virt_end && *d_total <= cap) ? 1u : 0u)) / 4;
     if ((uint64_t)blockIdx.x * TXT_BLOCK >= n_rec) return;          // (the grid is sized for the most lines the chunk could hold)
     const uint64_t r = (uint64_t)blockIdx.x * TXT_BLOCK + threadIdx.x;
     const bool in = r < n_rec;
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t*
     uint4 le4 = make_uint4(0, 0, 0, 0);
     if (in) {
         le4 = reinterpret_cast<const uint4*>(line_end)[r];
-        if (virt_end && 4 * r + 3 == real) le4.w = virt_end;         // (a virtual line can only be the last line of the last record)
+        if (virt_end && 4 * r + 3 == real && *d_total <= cap) le4.w = virt_end;         // (a virtual line can only be the last line of the last record)
     }
     uint32_t before = (uint32_t)__shfl_up((int)le4.w, 1, WAVE);
     if (lane == 0) before = (in && r > 0) ? line_end[4 * r - 1] : 0u;
@@ -413,7 +416,9 @@ struct FrameOut {
 
 __global__ void frame_finish_kernel(const unsigned long long* __restrict__ d_total, const FrameMeta* __restrict__ meta, const uint32_t* __restrict__ line_end0,
                                     const uint32_t* __restrict__ line_end1, const uint32_t* __restrict__ seq_len0, uint32_t virt0, uint32_t virt1,
-                                    unsigned long long bytes0, unsigned long long bytes1, int nf, unsigned long long max_records, FrameOut* __restrict__ out) {
+                                    unsigned long long bytes0, unsigned long long bytes1, int nf, unsigned long long max_records, FrameOut* __restrict__ out,
+                                    unsigned long long cap0, unsigned long long cap1) {
+    const unsigned long long cap[2] = {cap0, cap1};
     const uint32_t* const le[2] = {line_end0, line_end1};
     const uint32_t virt[2] = {virt0, virt1};
     const unsigned long long bytes[2] = {bytes0, bytes1};
@@ -421,7 +426,8 @@ __global__ void frame_finish_kernel(const unsigned long long* __restrict__ d_tot
     unsigned long long nrec[2] = {0, 0};
     for (int k = 0; k < nf; ++k) {
         o.lines[k] = d_total[k] + (virt[k] ? 1u : 0u);
-        nrec[k] = o.lines[k] / 4;
+        // (a table that overflowed: the host sees lines > cap and frames the chunk again; what is reported until then stays inside it)
+        nrec[k] = (d_total[k] <= cap[k] ? o.lines[k] : cap[k]) / 4;
         o.avail[k] = meta[k].first_empty < nrec[k] ? meta[k].first_empty : nrec[k];
         o.eof[k] = meta[k].first_empty < nrec[k] ? 1u : 0u;
         o.first_mismatch[k] = meta[k].first_mismatch;

@@ -34,13 +34,25 @@ struct CpuOffload : aqcgz::SectionOffload {
     uint32_t slice_tokens = 300, max_slices = 1u << 20;
     uint64_t groups = 0, sections = 0, found = 0, candidates = 0, false_ends = 0, spec_lanes = 0, failed_blocks = 0, stitched_blocks = 0;
     std::vector<std::vector<uint16_t>*> live;
+    // break_after >= 0: the "device" fails on its (break_after + 1)-th group — the group's sections come back empty, as
+    // DeviceInflate hands them back after a HIP error — and takes no work from then on (ready() == false)
+    long break_after = -1;
+    bool broken = false;
     explicit CpuOffload(size_t g) : group(g) {}
     size_t group_bytes() const override { return group; }
-    bool ready() override { return true; }
+    bool ready() override { return !broken; }
     void release(void* token) override { delete (std::vector<uint16_t>*)token; }
 
     bool submit(const uint8_t* data, size_t size, int n, const uint64_t* nominal, const uint64_t* stop, const uint8_t* exact,
                 std::function<void(int, const aqcgz::OffloadResult&)> done) override {
+        if (broken) return false;
+        if (break_after >= 0 && (long)groups >= break_after) {
+            broken = true;
+            ++groups;
+            aqcgz::OffloadResult none;
+            std::thread([n, done, none] { for (int k = 0; k < n; ++k) done(k, none); }).detach();
+            return true;
+        }
         const uint64_t SLACK = 256u << 10;
         const uint64_t byte0 = (nominal[0] >> 3) & ~(uint64_t)15;
         const uint64_t end_byte = std::min<uint64_t>(size, (stop[n - 1] >> 3) + 1 + SLACK);
@@ -253,9 +265,11 @@ int failures = 0;
 uint32_t g_max_slices = 1u << 20, g_slice_tokens = 300;      // (a case may cut the decoder off: unfinished blocks then go to the host)
 
 // decode gz through ParallelGunzip with the CPU emulation of the device as its offloader; returns the offloader's counters
+long g_break_after = -1;
 bool run_case(const char* what, const std::vector<uint8_t>& gz, const std::vector<uint8_t>& text, size_t section, size_t group, int threads, bool want_device,
               uint32_t ratio_cap = 20, uint32_t cand_div = 4096, bool expect_fail = false, bool hybrid = false) {
     CpuOffload off(group);
+    off.break_after = g_break_after;
     off.ratio_cap = ratio_cap; off.cand_div = cand_div; off.max_slices = g_max_slices; off.slice_tokens = g_slice_tokens;
     aqc_host::Pool pool(threads);
     std::vector<uint8_t> out(text.size() + 65536);
@@ -397,6 +411,16 @@ int main(int argc, char** argv) {
         run_case("hybrid: one byte damaged", bad, big, 64 << 10, 256 << 10, 3, false, 20, 4096, true, true);
         const std::vector<uint8_t> small = fastq_like(300, 13);
         run_case("hybrid: 100 KB file", gz_of(small, 6, Z_DEFAULT_STRATEGY), small, 64 << 10, 256 << 10, 2, false, 20, 4096, false, true);
+        // the device gives up (its first / its third group fails, it takes no more work): the host decodes on, in both modes — the
+        // device-only mode used to wait forever for a section nobody would make (round-4 advisory)
+        g_break_after = 0;
+        run_case("device breaks at group 1 (device only)", g6, big, 64 << 10, 256 << 10, 3, false);
+        run_case("device breaks at group 1 (device only, no pool)", g6, big, 64 << 10, 256 << 10, 0, false);
+        run_case("device breaks at group 1 (hybrid)", g6, big, 64 << 10, 256 << 10, 3, false, 20, 4096, false, true);
+        g_break_after = 2;
+        run_case("device breaks at group 3 (device only)", g6, big, 64 << 10, 256 << 10, 3, true);
+        run_case("device breaks at group 3 (hybrid)", g1, big, 128 << 10, 1 << 20, 2, false, 20, 4096, false, true);
+        g_break_after = -1;
     }
     if (failures) { printf("%d FAILED\n", failures); return 1; }
     printf("all device-gunzip logic checks passed\n");
