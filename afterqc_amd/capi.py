@@ -50,6 +50,22 @@ RESULT_DTYPE = np.dtype([("flag", "u1"), ("n_edits", "u1"), ("start1", "<u2"), (
                          ("len2", "<u2"), ("offset", "<i2"), ("overlap_len", "<u2"), ("distance", "<u2"),
                          ("edits", EDIT_DTYPE, (3,)), ("barcode", "u1")])
 assert RESULT_DTYPE.itemsize == 32
+SPAN_EVENT_DTYPE = np.dtype([("in_start", "<u4"), ("in_len", "<u4"), ("out_len", "<u4")])      # struct aqc_span_event
+
+
+def assemble_spans(chunk, end, events, stream0):
+    """The good output of one file from an aqc_format_spans result: the chunk's own bytes between the events, the rebuilt records
+    (stream 0, in order) at them — what aqc_pipe_run's file writers do with writev (include/afterqc_hip.h)."""
+    out = []
+    cursor = poff = 0
+    for e in events:
+        a, ln, ol = int(e["in_start"]), int(e["in_len"]), int(e["out_len"])
+        out.append(bytes(chunk[cursor:a]))
+        out.append(bytes(stream0[poff:poff + ol]))
+        poff += ol
+        cursor = a + ln
+    out.append(bytes(chunk[cursor:end]))
+    return b"".join(out)
 
 
 class Config(C.Structure):
@@ -327,6 +343,9 @@ def load_library():
     lib.aqc_run.argtypes = [P, C.c_int, C.c_uint64]
     lib.aqc_qc_stat.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int]
     lib.aqc_fetch_results.argtypes = [P, C.c_int, P, C.c_uint64]
+    lib.aqc_format_spans.argtypes = [P, C.c_int, C.c_uint64, C.c_int32, P, P]
+    lib.aqc_fetch_span_events.argtypes = [P, C.c_int, C.c_int, P, C.c_uint64]
+    lib.aqc_span_end.argtypes = [P, C.c_int, C.c_uint64, P]
     lib.aqc_fetch_quality_views.argtypes = [P, C.c_int, C.c_int, P, C.c_uint64]
     lib.aqc_error_record.argtypes = [P, C.c_int, C.POINTER(C.c_uint64)]
     lib.aqc_sync.argtypes = [P, C.c_int]
@@ -394,7 +413,7 @@ def load_library():
                  "aqc_run", "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_timing_reset",
                  "aqc_timing_mean", "aqc_get_counters", "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers",
                  "aqc_overlap", "aqc_read_stats", "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain",
-                 "aqc_fetch_text", "aqc_fetch_quality_views", "aqc_error_record"):
+                 "aqc_fetch_text", "aqc_fetch_quality_views", "aqc_error_record", "aqc_format_spans", "aqc_fetch_span_events", "aqc_span_end"):
         getattr(lib, name).restype = C.c_int
     if lib.aqc_abi_version() != 2:
         raise RuntimeError("libafterqc_hip.so ABI version mismatch")
@@ -407,7 +426,7 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_device_index", "
                     "aqc_qc_stat", "aqc_fetch_results", "aqc_fetch_quality_views", "aqc_error_record", "aqc_sync", "aqc_last_deferred", "aqc_kernel_ms", "aqc_timing_reset",
                     "aqc_timing_mean", "aqc_get_counters",
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
-                    "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain", "aqc_fetch_text", "aqc_fetch_streams", "aqc_compress", "aqc_fetch_gz", "aqc_gunzip_dev", "aqc_host_alloc",
+                    "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_spans", "aqc_fetch_span_events", "aqc_span_end", "aqc_format_plain", "aqc_fetch_text", "aqc_fetch_streams", "aqc_compress", "aqc_fetch_gz", "aqc_gunzip_dev", "aqc_host_alloc",
                     "aqc_host_free",
                     "aqc_pipe_create", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
                     "aqc_host_count_newlines", "aqc_bgzf_compress", "aqc_pipe_split",
@@ -574,6 +593,24 @@ class Engine:
         sizes = np.zeros(6, dtype=np.uint64)
         self._check(self.lib.aqc_format(self.h, slot, int(n), 1 if store_overlap else 0, _ptr(sizes)))
         return [int(x) for x in sizes]
+
+    def format_spans(self, slot, n, store_overlap=False):
+        """aqc_format_spans: like format(), but the good records that go out as their own bytes are left out of stream 0;
+        -> (bytes per stream, events per file)"""
+        sizes = (C.c_uint64 * 6)()
+        n_ev = (C.c_uint64 * 2)()
+        self._check(self.lib.aqc_format_spans(self.h, slot, n, 1 if store_overlap else 0, sizes, n_ev))
+        return [int(x) for x in sizes], [int(x) for x in n_ev]
+
+    def fetch_span_events(self, slot, file, n_events):
+        ev = np.zeros(max(n_events, 1), dtype=SPAN_EVENT_DTYPE)
+        self._check(self.lib.aqc_fetch_span_events(self.h, slot, file, _ptr(ev), n_events))
+        return ev[:n_events]
+
+    def span_end(self, slot, n):
+        end = (C.c_uint64 * 2)()
+        self._check(self.lib.aqc_span_end(self.h, slot, n, end))
+        return [int(x) for x in end]
 
     def format_plain(self, slot, verdict_slot, n, store_overlap=False):
         """index files: whole records of `slot`, routed / renamed by the verdicts of `verdict_slot`"""

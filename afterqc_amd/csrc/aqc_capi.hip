@@ -85,7 +85,9 @@ struct Slot {
     // text in / text out (aqc_frame, aqc_format): per file the line table and the name / strand-line descriptors
     DevBuf t_line_end[2], t_tile[2], t_name_off[2], t_name_len[2], t_plus_off[2], t_plus_len[2], t_qual_len[2];
     DevBuf t_scratch;              // FrameMeta[2] + scan totals
-    DevBuf f_pos, f_tile, f_plan, f_over, f_out[6];
+    DevBuf f_pos, f_tile, f_plan, f_over, f_out[6], f_events[2];
+    uint64_t n_events[2] = {0, 0};    // aqc_format_spans: events per file
+    uint64_t consumed[2] = {0, 0};    // bytes of each file's chunk that the framed records take
     uint64_t f_bytes[6] = {0, 0, 0, 0, 0, 0};
     // gzip members built on the device (aqc_compress)
     DevBuf g_stage, g_sizes, g_offsets, g_total, g_hist, g_code, g_packed[6];
@@ -305,7 +307,7 @@ void aqc_destroy(aqc_ctx* c) {
                           &s.deferred, &s.n_deferred, &s.off_stage, &s.qlen[0], &s.qlen[1], &s.qview[0], &s.qview[1],
                           &s.t_line_end[0], &s.t_line_end[1], &s.t_tile[0], &s.t_tile[1], &s.t_name_off[0], &s.t_name_off[1],
                           &s.t_name_len[0], &s.t_name_len[1], &s.t_plus_off[0], &s.t_plus_off[1], &s.t_plus_len[0], &s.t_plus_len[1],
-                          &s.t_qual_len[0], &s.t_qual_len[1], &s.t_scratch, &s.f_pos, &s.f_tile, &s.f_plan, &s.f_over, &s.f_out[0], &s.f_out[1], &s.f_out[2],
+                          &s.t_qual_len[0], &s.t_qual_len[1], &s.t_scratch, &s.f_pos, &s.f_tile, &s.f_plan, &s.f_over, &s.f_events[0], &s.f_events[1], &s.f_out[0], &s.f_out[1], &s.f_out[2],
                           &s.f_out[3], &s.f_out[4], &s.f_out[5], &s.g_stage, &s.g_sizes, &s.g_offsets, &s.g_total, &s.g_hist, &s.g_code,
                           &s.g_packed[0], &s.g_packed[1], &s.g_packed[2], &s.g_packed[3], &s.g_packed[4], &s.g_packed[5]};
         for (DevBuf* b : bufs) b->release();
@@ -910,6 +912,7 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
     const uint32_t h_next = fo.next_len1;
     info->consumed1 = consumed[0];
     info->consumed2 = consumed[1];
+    s->consumed[0] = consumed[0]; s->consumed[1] = consumed[1];
     info->next_len1 = h_next;
     s->framed = true;
     s->last_chunk = *ch;
@@ -927,7 +930,7 @@ int aqc_reframe(aqc_ctx* c, int slot, aqc_frame_info* info) {
     return frame_impl(c, slot, &ch, info, true);
 }
 
-static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]) {
+static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6], bool spans = false) {
     Slot* s;
     int rc = get_slot(c, slot, &s);
     if (rc) return rc;
@@ -947,6 +950,10 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
     v.barcode = c->cfg.barcode ? 1 : 0;
     v.barcode_length = c->cfg.barcode_length;
     v.store_overlap = (store_overlap && vs->paired) ? 1 : 0;
+    v.spans = (spans && !plain) ? 1 : 0;
+    v.consumed[0] = (uint32_t)s->consumed[0]; v.consumed[1] = (uint32_t)s->consumed[1];
+    v.n_framed = s->n;
+    s->n_events[0] = s->n_events[1] = 0;
     const DevBuf* sl[2] = {&s->len1, &s->len2};
     const DevBuf* arena[2] = {&s->seq1, &s->seq2};
     const DevBuf* so[2] = {&s->off1, &s->off2};
@@ -966,18 +973,24 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
     // streams q = file * 3 + {0 good, 1 bad, 2 overlap}: per-tile byte sums -> tile bases (one launch each), the
     // per-record offsets are formed inside the writer
     const uint64_t n_tiles = n ? (n + FMT_TILE - 1) / FMT_TILE : 1;
-    if (s->f_tile.reserve(sizeof(unsigned long long) * 6 * n_tiles) || s->t_scratch.reserve(256))
+    if (s->f_tile.reserve(sizeof(unsigned long long) * FMT_STREAMS * n_tiles) || s->t_scratch.reserve(256))
         return fail(AQC_ERR_HIP, "hipMalloc failed");
     unsigned long long* d_tot = (unsigned long long*)((uint8_t*)s->t_scratch.p + 128);
-    HIP_TRY(hipMemsetAsync(s->f_tile.p, 0, sizeof(unsigned long long) * 6 * n_tiles, s->stream));
+    HIP_TRY(hipMemsetAsync(s->f_tile.p, 0, sizeof(unsigned long long) * FMT_STREAMS * n_tiles, s->stream));
     if (n) hipLaunchKernelGGL(fmt_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles, (unsigned long long*)s->f_tile.p);
-    hipLaunchKernelGGL(fmt_tile_bases_kernel, dim3(6), dim3(TXT_BLOCK), 0, s->stream, (unsigned long long*)s->f_tile.p, n_tiles, d_tot);
+    hipLaunchKernelGGL(fmt_tile_bases_kernel, dim3(v.spans ? FMT_STREAMS : 6), dim3(TXT_BLOCK), 0, s->stream, (unsigned long long*)s->f_tile.p, n_tiles, d_tot);
     HIP_TRY(hipGetLastError());
     bool live[6];
     for (int q = 0; q < 6; q++) live[q] = (q < 3 || s->paired) && (q % 3 != 2 || v.store_overlap);
-    unsigned long long h_tot[6] = {0, 0, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(h_tot), hipMemcpyDeviceToHost, s->stream));
+    unsigned long long h_tot[FMT_STREAMS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long) * (v.spans ? FMT_STREAMS : 6), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (v.spans) {
+        for (int f = 0; f < (s->paired ? 2 : 1); ++f) {
+            s->n_events[f] = h_tot[FMT_EVENT_STREAM + f];
+            if (s->f_events[f].reserve(sizeof(SpanEvent) * (s->n_events[f] + 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+        }
+    }
     FormatOut outs{};
     for (int q = 0; q < 6; q++) {
         s->f_bytes[q] = live[q] ? h_tot[q] : 0;
@@ -1001,8 +1014,10 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
             HIP_TRY(hipMemsetAsync(d_ngen, 0, sizeof(unsigned int) * GEN_LISTS, s->stream));
             hipLaunchKernelGGL(fmt_plan_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles,
                                (const unsigned long long*)s->f_tile.p, pass, s->status, (uint4*)s->f_plan.p,
-                               (uint4*)((uint8_t*)s->f_plan.p + plan0_bytes), (FmtTask*)s->f_over.p, (uint32_t*)s->f_pos.p, d_ngen, gen_cap);
-            hipLaunchKernelGGL(fmt_copy_whole_kernel, dim3(copy_blocks), dim3(COPY_BLOCK), 0, s->stream, v, n_tasks, (const uint4*)s->f_plan.p, outs);
+                               (uint4*)((uint8_t*)s->f_plan.p + plan0_bytes), (FmtTask*)s->f_over.p, (uint32_t*)s->f_pos.p, d_ngen, gen_cap,
+                               (SpanEvent*)s->f_events[0].p, (SpanEvent*)s->f_events[1].p);
+            // (spans mode: the records this kernel would copy stay where they are, in the caller's chunk)
+            if (!v.spans) hipLaunchKernelGGL(fmt_copy_whole_kernel, dim3(copy_blocks), dim3(COPY_BLOCK), 0, s->stream, v, n_tasks, (const uint4*)s->f_plan.p, outs);
             // GEN_LISTS x k workgroups; k from the worst case, at most 32 per list
             uint64_t per_list = (gen_cap + GEN_ROUND - 1) / GEN_ROUND;
             if (per_list > 32) per_list = 32;
@@ -1491,6 +1506,49 @@ int aqc_gunzip_dev(int device, const uint8_t* gz, uint64_t size, uint8_t* out, u
 
 int aqc_format(aqc_ctx* c, int slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]) {
     return format_impl(c, slot, slot, n, store_overlap, bytes_out);
+}
+
+int aqc_format_spans(aqc_ctx* c, int slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6], uint64_t n_events[2]) {
+    if (!n_events) return fail(AQC_ERR_ARG, "aqc_format_spans: null argument");
+    const int rc = format_impl(c, slot, slot, n, store_overlap, bytes_out, true);
+    if (rc) return rc;
+    n_events[0] = c->slots[slot].n_events[0];
+    n_events[1] = c->slots[slot].n_events[1];
+    return 0;
+}
+
+int aqc_span_end(aqc_ctx* c, int slot, uint64_t n, uint64_t end[2]) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!s->framed || !end || n > s->n) return fail(AQC_ERR_ARG, "aqc_span_end: bad arguments");
+    for (int f = 0; f < 2; ++f) {
+        end[f] = 0;
+        if (f == 1 && !s->paired) break;
+        if (n == s->n) { end[f] = s->consumed[f]; continue; }
+        uint32_t off = 0;               // record n begins where record n - 1 ends
+        HIP_TRY(hipMemcpyAsync(&off, (const uint32_t*)s->t_name_off[f].p + n, sizeof(off), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        end[f] = off;
+    }
+    return 0;
+}
+
+int aqc_fetch_span_events(aqc_ctx* c, int slot, int file, aqc_span_event* dst, uint64_t cap) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!s->formatted) return fail(AQC_ERR_STATE, "aqc_fetch_span_events before aqc_format_spans");
+    if (file < 0 || file > 1) return fail(AQC_ERR_ARG, "aqc_fetch_span_events: bad file");
+    static_assert(sizeof(aqc_span_event) == sizeof(SpanEvent), "host and device event layouts must agree");
+    const uint64_t ne = s->n_events[file];
+    if (ne > cap) return fail(AQC_ERR_ARG, "aqc_fetch_span_events: %llu events do not fit %llu", (unsigned long long)ne, (unsigned long long)cap);
+    if (ne) {
+        if (!dst) return fail(AQC_ERR_ARG, "aqc_fetch_span_events: null destination");
+        HIP_TRY(hipMemcpyAsync(dst, s->f_events[file].p, sizeof(SpanEvent) * ne, hipMemcpyDeviceToHost, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return check_status(*s);
 }
 
 int aqc_format_plain(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]) {

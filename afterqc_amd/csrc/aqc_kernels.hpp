@@ -35,6 +35,10 @@ struct DevBatch {
     uint32_t *qview1, *qview2;
 };
 constexpr uint32_t LEN_IRR = 0x80000000u, LEN_MASK = 0x7fffffffu;
+// the quality-length words of a framed chunk (frame_records_kernel) carry two flags above the length: the quality line ends right
+// at its '\n' (nothing stripped), and ALL FOUR lines of the record do — the record stands in the chunk exactly as a writer would
+// write it
+constexpr uint32_t QLEN_TAILNL = 0x80000000u, QLEN_CONTIG = 0x40000000u, QLEN_MASK = 0x3fffffffu;
 
 struct DevCircles {
     const double *cx, *cy, *cr;
@@ -336,8 +340,8 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
         const int L2 = (int)(l2w & LEN_MASK);
         // a quality line that is not as long as its sequence line (either mate): every string keeps its own view
         const bool irr = b.qlen1 != nullptr && ((l1w | l2w) & LEN_IRR) != 0u;
-        const int QL1 = irr ? (int)(b.qlen1[rec] & LEN_MASK) : L1;
-        const int QL2 = (irr && paired) ? (int)(b.qlen2[rec] & LEN_MASK) : L2;
+        const int QL1 = irr ? (int)(b.qlen1[rec] & QLEN_MASK) : L1;
+        const int QL2 = (irr && paired) ? (int)(b.qlen2[rec] & QLEN_MASK) : L2;
         if (L1 > AQC_MAX_READ_LEN || L2 > AQC_MAX_READ_LEN || QL1 > AQC_MAX_READ_LEN || QL2 > AQC_MAX_READ_LEN) {
             if (lane == 0) atomicCAS(st.status, 0, AQC_ERR_READ_TOO_LONG);
             return;
@@ -819,7 +823,7 @@ __device__ __forceinline__ ReadDesc lane_desc(const DevBatch& b, int mate, uint6
     len = (int)(lw & LEN_MASK);
     // this mate's quality line has a length of its own: its view comes from qlen (raw read) / qview (final read)
     const bool irr = (lw & LEN_IRR) != 0u && b.qlen1 != nullptr;
-    int qst = 0, qlen = irr ? (int)((mate == 0 ? b.qlen1[rec] : b.qlen2[rec]) & LEN_MASK) : len;
+    int qst = 0, qlen = irr ? (int)((mate == 0 ? b.qlen1[rec] : b.qlen2[rec]) & QLEN_MASK) : len;
     if (post) {
         // the 32-byte verdict record as two 16-byte loads; fields by shifts (aqc_result is packed, see the header)
         const uint4* rp = reinterpret_cast<const uint4*>(results + rec);

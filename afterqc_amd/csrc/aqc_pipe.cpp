@@ -24,6 +24,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -495,6 +496,21 @@ struct OutFile {
         }
         return true;
     }
+    // the same for a list of pieces (writev, IOV_MAX at a time; pieces of length 0 are the caller's business)
+    bool appendv(std::vector<struct iovec>& iov) {
+        size_t i = 0;
+        while (i < iov.size()) {
+            const int cnt = (int)std::min<size_t>(iov.size() - i, 1024);
+            ssize_t w = ::writev(fd, iov.data() + i, cnt);
+            if (w <= 0) return false;
+            pos += (uint64_t)w;
+            while (w > 0 && i < iov.size()) {
+                if ((size_t)w >= iov[i].iov_len) { w -= (ssize_t)iov[i].iov_len; ++i; }
+                else { iov[i].iov_base = (uint8_t*)iov[i].iov_base + w; iov[i].iov_len -= (size_t)w; w = 0; }
+            }
+        }
+        return true;
+    }
     void close_() {
         if (fd >= 0) close(fd);
         fd = -1;
@@ -537,6 +553,17 @@ struct OutChunk {
     uint64_t n = 0;
     bool last = false;
     bool fatal = false;          // upstream's run ends behind this chunk's n records (Run::dies_at_record)
+    // plain-text output WITHOUT the copy nobody needs (aqc_format_spans): the good records that go out as their own bytes are
+    // written straight from the chunk's input buffer, which therefore lives until the chunk is committed; sizes[0] / sizes[3]
+    // are then only the rebuilt good records, good_total what the good files really get
+    struct Spans {
+        std::vector<aqc_span_event> ev[2];
+        const uint8_t* in[2] = {nullptr, nullptr};
+        uint64_t end[2] = {0, 0};            // chunk bytes up to the end of record n - 1
+        uint64_t good_total[2] = {0, 0};
+    };
+    std::shared_ptr<Spans> spans;
+    int in_buf[2] = {-1, -1};    // input ring buffers this chunk still holds (spans mode), -1: none
 };
 
 }  // namespace
@@ -620,6 +647,7 @@ struct Run {
     std::condition_variable set_cv;
     std::vector<char> set_free;        // [worker * 2 + set]
     bool gz_on_device = false;
+    bool spans_on = false;             // plain-text output: good records that go out as their own bytes are written from the input buffers
     // QC turn taking (post-filter sampling must be issued in chunk order, see aqc_qc_stat's time keys)
     std::mutex qc_mu;
     std::condition_variable qc_cv;
@@ -853,6 +881,7 @@ struct Run {
         }
         Job j;
         int set = 0;
+        const bool use_spans = spans_on;
         while (!abort && jobq[ci]->pop(j)) {
             aqc_text_chunk ch{};
             ch.text1 = j.c[0].data; ch.bytes1 = j.c[0].bytes; ch.final1 = j.c[0].final ? 1 : 0;
@@ -868,12 +897,15 @@ struct Run {
             gate_leave(ug);
             ns_frame += now_ns() - tt;
             tt = now_ns();
-            // the text has left the host buffers
-            for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf);
+            // the text has left the host buffers — which are free again, unless the good records are going to be written from
+            // them (spans mode: they are released when the chunk has been committed)
+            if (!use_spans || rc) for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf);
             if (rc) { fail(rc, "aqc_frame: %s", aqc_last_error()); return; }
+            auto drop_input = [&] { if (use_spans) for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf); };
             const uint64_t expect = j.c[0].lines / 4;
             if (info.n != expect || info.eof1 || info.eof2 || info.avail1 != expect || (nf == 2 && info.avail2 != expect)) {
                 anomaly = true;           // an empty line / a blank-only line inside: the serial path knows what to do
+                drop_input();
                 stop_all();
                 return;
             }
@@ -910,9 +942,10 @@ struct Run {
                 bool have_set = false, in_gate = false;
                 // (a second round only when the device reports, as late as the download, that upstream's run ends at a record of
                 //  this chunk: the records before it are formatted again on their own)
+                uint64_t n_ev[2] = {0, 0};
                 for (int round = 0; ; ++round) {
                     const char* where = "aqc_format";
-                    rc = aqc_format(c, slot, n, opt->store_overlap, oc.sizes);
+                    rc = use_spans ? aqc_format_spans(c, slot, n, opt->store_overlap, oc.sizes, n_ev) : aqc_format(c, slot, n, opt->store_overlap, oc.sizes);
                     if (!rc && !have_set) {
                         ns_kernels += now_ns() - tt;
                         tt = now_ns();
@@ -944,10 +977,37 @@ struct Run {
                         }
                         where = "fetching the output streams";
                         rc = aqc_fetch_streams(c, slot, oc.gz ? 1 : 0, dstq, capq);
+                        if (!rc && use_spans) {
+                            // where the rebuilt and the bad records stood: everything between them is written from the input buffer
+                            auto sp = std::make_shared<OutChunk::Spans>();
+                            for (int f = 0; f < nf && !rc; ++f) {
+                                sp->ev[f].resize((size_t)n_ev[f]);
+                                rc = aqc_fetch_span_events(c, slot, f, sp->ev[f].data(), n_ev[f]);
+                                sp->in[f] = j.c[f].data;
+                                sp->end[f] = n == info.n ? (f == 0 ? info.consumed1 : info.consumed2) : 0;
+                                oc.in_buf[f] = j.c[f].buf;
+                            }
+                            if (!rc && n != info.n) {
+                                // (the chunk was cut at the record upstream dies at: the last piece ends where that record begins)
+                                uint64_t e2[2] = {0, 0};
+                                rc = aqc_span_end(c, slot, n, e2);
+                                sp->end[0] = e2[0]; sp->end[1] = e2[1];
+                            }
+                            for (int f = 0; f < nf && !rc; ++f) {
+                                uint64_t cursor = 0, total = 0;
+                                for (const aqc_span_event& e : sp->ev[f]) {
+                                    total += (e.in_start - cursor) + e.out_len;
+                                    cursor = (uint64_t)e.in_start + e.in_len;
+                                }
+                                sp->good_total[f] = total + (sp->end[f] > cursor ? sp->end[f] - cursor : 0);
+                            }
+                            oc.spans = sp;
+                        }
                     }
                     if (!rc) break;
                     if (round == 0 && !fatal && dies_at_record(c, slot, rc, j.idx, n, fatal)) continue;
                     if (in_gate) gate_leave(dg);
+                    drop_input();
                     fail(rc, "%s: %s", where, aqc_last_error());
                     return;
                 }
@@ -1014,6 +1074,7 @@ struct Run {
     std::unique_ptr<BQueue<std::shared_ptr<Commit>>> fileq[6];
 
     void release_set(const OutChunk& oc) {
+        for (int f = 0; f < 2; ++f) release_ring(f, oc.in_buf[f]);       // (spans mode: the chunk's input buffers were its good records)
         if (oc.set < 0) return;
         {
             std::lock_guard<std::mutex> g(set_mu);
@@ -1027,7 +1088,22 @@ struct Run {
         while (fileq[q]->pop(cm)) {
             const OutChunk& oc = cm->oc;
             const uint64_t tw = now_ns();
-            if (!abort && oc.sizes[q]) {
+            if (!abort && oc.spans && q % 3 == 0) {
+                // the good file of input q / 3: the chunk's own bytes between the events, the rebuilt records (stream 0) at them
+                const OutChunk::Spans& sp = *oc.spans;
+                const int f = q / 3;
+                const uint8_t* patch = oc.sizes[q] ? P->wbufs[oc.worker].out[oc.set][q].p : nullptr;
+                std::vector<struct iovec> iov;
+                iov.reserve(2 * sp.ev[f].size() + 1);
+                uint64_t cursor = 0, poff = 0;
+                for (const aqc_span_event& e : sp.ev[f]) {
+                    if (e.in_start > cursor) iov.push_back({(void*)(sp.in[f] + cursor), (size_t)(e.in_start - cursor)});
+                    if (e.out_len) { iov.push_back({(void*)(patch + poff), (size_t)e.out_len}); poff += e.out_len; }
+                    cursor = (uint64_t)e.in_start + e.in_len;
+                }
+                if (sp.end[f] > cursor) iov.push_back({(void*)(sp.in[f] + cursor), (size_t)(sp.end[f] - cursor)});
+                if (!iov.empty() && !out[q].appendv(iov)) fail(AQC_ERR_ARG, "write error on output %d (disk full?)", q);
+            } else if (!abort && oc.sizes[q]) {
                 const uint8_t* p = P->wbufs[oc.worker].out[oc.set][q].p;
                 bool ok = true;
                 if (!io->gzip_out) ok = out[q].append(p, (size_t)oc.sizes[q]);
@@ -1067,15 +1143,17 @@ struct Run {
                 auto cm = std::make_shared<Commit>();
                 cm->oc = cur;
                 int live = 0;
+                uint64_t to_file[6];
                 for (int q = 0; q < 6; ++q) {
-                    res->bytes_out[q] += cur.sizes[q];
-                    if (cur.set >= 0 && cur.sizes[q] && out[q].fd >= 0) ++live;
+                    to_file[q] = (cur.spans && q % 3 == 0) ? cur.spans->good_total[q / 3] : cur.sizes[q];
+                    res->bytes_out[q] += to_file[q];
+                    if (cur.set >= 0 && to_file[q] && out[q].fd >= 0) ++live;
                 }
                 if (live == 0 || abort) release_set(cur);
                 else {
                     cm->remaining = live;
                     for (int q = 0; q < 6; ++q)
-                        if (cur.sizes[q] && out[q].fd >= 0) fileq[q]->push(cm);
+                        if (to_file[q] && out[q].fd >= 0) fileq[q]->push(cm);
                 }
                 res->chunks += 1;
                 ++next;
@@ -1143,7 +1221,9 @@ int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_
         if (const char* e = getenv("AQC_IO_THREADS")) io_threads = std::min(256, atoi(e));
     p->io_threads = io_threads > 0 ? io_threads : (int)dflt;
     p->pool.reset(new Pool(p->io_threads));
-    const int ring = n_ctx * slots_per_ctx + 2;
+    // input buffers: one per slot + two being filled — and, when the good records are written straight from them (spans mode), the
+    // two chunks per slot worker that may wait for their turn at the files (buffers are page-locked when first used, not before)
+    const int ring = n_ctx * slots_per_ctx * 3 + 2;
     for (int f = 0; f < 2; ++f) p->in_buf[f].resize(ring);
     p->wbufs.resize((size_t)n_ctx * slots_per_ctx);
     *out = p;
@@ -1206,6 +1286,12 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
     {
         const char* e = getenv("AQC_GZ_DEVICE");
         R.gz_on_device = io->gzip_out && io->gzip_level >= 1 && !opt->no_output && !(e && e[0] == '0');
+    }
+    {
+        // plain-text outputs: the good records that go out as their own bytes never leave the host (aqc_format_spans); .gz output
+        // needs the whole text on the device, where its members are built.  AQC_SPANS=0: every record is formatted and fetched.
+        const char* e = getenv("AQC_SPANS");
+        R.spans_on = !io->gzip_out && !opt->no_output && !(e && e[0] == '0');
     }
     const bool dbg = getenv("AQC_PIPE_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "pipe: outputs open at %.4f s\n", now_s() - t0);

@@ -331,7 +331,7 @@ struct FramedFile {
     uint32_t* name_len;
     uint32_t* plus_off;
     uint32_t* plus_len;
-    uint32_t* qual_len;      // bit 31: the byte behind the (stripped) quality line is its '\n'
+    uint32_t* qual_len;      // QLEN_TAILNL: the byte behind the (stripped) quality line is its '\n'; QLEN_CONTIG: that holds for all four lines
 };
 
 // (the number of lines comes from the index pass's device-side total: nothing of it goes through the host first.  virt_end != 0:
@@ -359,6 +359,7 @@ __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t*
     const uint32_t le[4] = {le4.x, le4.y, le4.z, le4.w};
     uint32_t s[4] = {0, 0, 0, 0}, l[4] = {1, 1, 1, 1};
     uint32_t tail_nl = 0;                                   // the quality line ends right at its '\n' (nothing stripped)
+    bool all_nl = true;                                     // ... and so do the other three lines
     if (in) {
         uint32_t b = r == 0 ? 0u : (before & LINE_POS) + 1u;
 #pragma unroll
@@ -372,7 +373,8 @@ __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t*
             }
             s[k] = b;
             l[k] = e - b;
-            if (k == 3) tail_nl = at_nl ? 0x80000000u : 0u;
+            all_nl = all_nl && at_nl;
+            if (k == 3) tail_nl = at_nl ? QLEN_TAILNL : 0u;
             b = nl_at + 1u;
         }
         out.name_off[r] = s[0]; out.name_len[r] = l[0];
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t*
         // over as they are) — the record is marked, every later stage keeps a view per string (aqc_kernels.hpp, LEN_IRR)
         out.seq_off[r] = s[1];  out.seq_len[r] = l[1] | (l[1] != l[3] ? LEN_IRR : 0u);
         out.plus_off[r] = s[2]; out.plus_len[r] = l[2];
-        out.qual_off[r] = s[3]; out.qual_len[r] = l[3] | tail_nl;
+        out.qual_off[r] = s[3]; out.qual_len[r] = min(l[3], QLEN_MASK) | tail_nl | (all_nl ? QLEN_CONTIG : 0u);
     }
     // chunk-wide reductions: at most one atomic per workgroup and only when it has something to say.  (Same-address
     // atomics serialise in L2 at ~8 ns each; the running maximum is read with an L2-coherent load — a plain load is served
@@ -543,7 +545,7 @@ struct TextFile {
 // every slice upstream is a python slice of each string by its own length, the final view is what the verdict kernel left in
 // qview; getOverlap (preprocesser.py:78-84) takes r[3][len(r[3]) - overlap_len:] — a NEGATIVE start counts from the end.
 __device__ __forceinline__ void irregular_quality_slice(const TextFile& tf, uint64_t r, int plain, int overlap_pass, int ovl, int& qst, int& qlen) {
-    if (plain) { qst = 0; qlen = (int)(tf.qual_len[r] & LEN_MASK); return; }
+    if (plain) { qst = 0; qlen = (int)(tf.qual_len[r] & QLEN_MASK); return; }
     const uint32_t qv = tf.qview[r];
     const int vs = (int)(qv & 0xffffu), vl = (int)(qv >> 16);
     qst = vs; qlen = vl;
@@ -564,7 +566,41 @@ struct FormatView {
     int plain;            // index files (-7 / -5): records are written whole (no trim, no edits, no barcode move); only
                           // the verdicts — of the read pairs in `results` — route them and rename the bad ones
     int verdict_paired;   // the verdicts belong to read PAIRS (overlap stream exists)
+    int spans;            // aqc_format_spans: good records that go out as their own bytes are NOT copied (they already stand in the
+                          // chunk the caller framed): stream 0 holds only the good records that had to be rebuilt, and every
+                          // record that is not such a "whole" record leaves an event (SpanEvent) saying where it stood
+    uint32_t consumed[2]; // bytes of each file's chunk that the framed records take (the end of the last record)
+    uint64_t n_framed;    // records framed into the slot (>= the n being formatted)
 };
+
+// event k of a file = the k-th record (in order) that is bad or had to be rebuilt: it stood at chunk bytes [in_start, in_start +
+// in_len) and contributes out_len bytes to stream 0 (0: a bad record).  The good output of the file is, in order: the chunk's
+// bytes up to event 0 | out_len bytes of stream 0 | the chunk's bytes behind event 0 up to event 1 | ... up to the end of record n - 1.
+struct SpanEvent { uint32_t in_start, in_len, out_len; };
+
+// A good record that is written as its own bytes: not trimmed, not renamed, no edit of the walk in this mate, and all four lines
+// followed directly by their '\n' in the chunk (QLEN_CONTIG) — the bulk of a run without trimming.
+__device__ __forceinline__ bool record_is_whole(const FormatView& v, const TextFile& t, uint64_t r, int file, const uint4& w0) {
+    if (v.plain || v.barcode || (int)(w0.x & 0xffu) != AQC_GOOD) return false;
+    const uint32_t slw = t.seq_len[r];
+    const uint32_t st = file == 0 ? (w0.x >> 16) : (w0.y >> 16), len = file == 0 ? (w0.y & 0xffffu) : (w0.z & 0xffffu);
+    if (st != 0u || len != slw) return false;                      // (a mate marked LEN_IRR never equals its length word)
+    if (!(t.qual_len[r] & QLEN_CONTIG)) return false;
+    const int n_edits = (int)((w0.x >> 8) & 0xffu);
+    if (n_edits) {
+        const uint4 w1 = *(reinterpret_cast<const uint4*>(v.results + r) + 1);
+        const unsigned long long e_lo = ((unsigned long long)w1.y << 32) | w1.x, e_hi = ((unsigned long long)w1.w << 32) | w1.z;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            if (e < n_edits) {
+                const int bit = 40 * e + 16;                       // the edit's kind byte
+                const unsigned int kind = (unsigned int)((bit < 64 ? e_lo >> bit : e_hi >> (bit - 64)) & 0xffu);
+                if (kind == AQC_EDIT_MASK || (kind == AQC_EDIT_FIX_R1 && file == 0) || (kind == AQC_EDIT_FIX_R2 && file == 1)) return false;
+            }
+        }
+    }
+    return true;
+}
 
 // does record r go to the overlap stream?  paired, GOOD, overlap_len > 30 and every mismatch of the overlap was
 // corrected (distance == 0 or distance == corrected bases, preprocesser.py:614)
@@ -598,10 +634,17 @@ __device__ __forceinline__ int moved_barcode_len(const FormatView& v, int file, 
 
 // bytes of (file, stream) that record r contributes: the sizes of all three streams of one file at once
 // (sz[0] good, sz[1] bad, sz[2] overlap); the name's first ':' is only searched when a barcode was moved
-__device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int file, uint32_t sz[3]) {
+__device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int file, uint32_t sz[3], uint32_t& event) {
     const uint4 w0 = *reinterpret_cast<const uint4*>(v.results + r);
     const int flag = (int)(w0.x & 0xffu);
     const TextFile& t = v.f[file];
+    event = 0u;
+    bool whole = false;                                     // spans mode: the record stays where it is, stream 0 does not get it
+    if (v.spans) {
+        whole = record_is_whole(v, t, r, file, w0);
+        event = whole ? 0u : 1u;
+        if (whole && !v.store_overlap) { sz[0] = sz[1] = sz[2] = 0u; return; }
+    }
     uint32_t len = file == 0 ? (w0.y & 0xffffu) : (w0.z & 0xffffu);
     const uint32_t slw = t.seq_len[r];
     if (v.plain) len = slw & LEN_MASK;                      // index records go out whole
@@ -625,7 +668,7 @@ __device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int f
         irregular_quality_slice(t, r, v.plain, 0, 0, qs_, ql_);
         qlen = (uint32_t)ql_;
     }
-    sz[0] = flag == AQC_GOOD ? body + len + qlen : 0u;
+    sz[0] = (flag == AQC_GOOD && !whole) ? body + len + qlen : 0u;
     sz[1] = flag == AQC_GOOD ? 0u : body + (uint32_t)FLAG_TEXT_LEN[flag] + len + qlen;
     sz[2] = 0u;
     if (v.store_overlap) {
@@ -644,6 +687,8 @@ __device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int f
 }
 
 constexpr int FMT_TILE = 128;           // records per workgroup (one thread per record in the sizing phase)
+constexpr int FMT_STREAMS = 8;          // file * 3 + {good, bad, overlap}, then (spans mode) the two files' event counts
+constexpr int FMT_EVENT_STREAM = 6;
 
 // per-tile byte sums of the six streams (file * 3 + stream): tile_sum[q * n_tiles + tile]
 __global__ __launch_bounds__(FMT_TILE) void fmt_tile_sums_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
@@ -652,12 +697,17 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_tile_sums_kernel(FormatView v, u
     const uint64_t r = (uint64_t)blockIdx.x * FMT_TILE + threadIdx.x;
     const int nfiles = v.paired ? 2 : 1;
     for (int file = 0; file < nfiles; ++file) {
-        uint32_t sz[3] = {0, 0, 0};
-        if (r < n) fmt_sizes(v, r, file, sz);
+        uint32_t sz[3] = {0, 0, 0}, ev = 0;
+        if (r < n) fmt_sizes(v, r, file, sz, ev);
         for (int st = 0; st < (v.store_overlap ? 3 : 2); ++st) {
             unsigned long long total;
             (void)block_excl_scan((unsigned long long)sz[st], lds, total);
             if (threadIdx.x == 0) tile_sum[(uint64_t)(file * 3 + st) * n_tiles + blockIdx.x] = total;
+        }
+        if (v.spans) {                                      // streams 6, 7: the files' event counts
+            unsigned long long total;
+            (void)block_excl_scan((unsigned long long)ev, lds, total);
+            if (threadIdx.x == 0) tile_sum[(uint64_t)(FMT_EVENT_STREAM + file) * n_tiles + blockIdx.x] = total;
         }
     }
 }
@@ -786,7 +836,7 @@ __device__ inline void fmt_build(const FormatView& v, uint64_t r, int file, int 
     int qst = st, qlen = len, qline = slen;
     const bool irr = (slw & LEN_IRR) != 0u;
     if (irr) {
-        qline = (int)(tf.qual_len[r] & LEN_MASK);
+        qline = (int)(tf.qual_len[r] & QLEN_MASK);
         irregular_quality_slice(tf, r, v.plain, overlap_pass, ovl, qst, qlen);
     }
     fmt_add(t, o, qlen, qual_off + (uint32_t)qst);
@@ -875,7 +925,8 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
                                                             const unsigned long long* __restrict__ tile_base, int overlap_pass,
                                                             int* __restrict__ status, uint4* __restrict__ plan0, uint4* __restrict__ plan_gen,
                                                             FmtTask* __restrict__ over, uint32_t* __restrict__ gen_list,
-                                                            unsigned int* __restrict__ n_gen, uint64_t gen_cap) {
+                                                            unsigned int* __restrict__ n_gen, uint64_t gen_cap,
+                                                            SpanEvent* __restrict__ events0, SpanEvent* __restrict__ events1) {
     __shared__ unsigned long long lds[4];
     __shared__ FmtTask tasks[FMT_TILE];
     const int nfiles = v.paired ? 2 : 1;
@@ -885,10 +936,26 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
         t.stream = 0xff;
         t.total = 0;
         uint32_t sz[3] = {0, 0, 0};
+        uint32_t event = 0;                     // spans mode, main pass: this record is not one that stays where it is
         if (r < n) {
-            fmt_build(v, r, file, overlap_pass, t, status);
+            // (spans mode: a whole record needs no piece list — it is not copied — except for the overlap stream's slice of it)
+            const bool whole = v.spans && !overlap_pass && record_is_whole(v, v.f[file], r, file, *reinterpret_cast<const uint4*>(v.results + r));
+            if (!whole) fmt_build(v, r, file, overlap_pass, t, status);
+            event = (v.spans && !overlap_pass && !whole) ? 1u : 0u;
             if (!overlap_pass) sz[t.stream == 1 ? 1 : 0] = t.stream == 0xff ? 0u : (uint32_t)t.total;
             else sz[2] = t.stream == 2 ? (uint32_t)t.total : 0u;
+        }
+        if (v.spans && !overlap_pass) {
+            // the event list of the file, in record order: where the record stood in the chunk, what it gives to stream 0
+            unsigned long long te;
+            const unsigned long long ee = block_excl_scan((unsigned long long)event, lds, te);
+            if (event) {
+                const TextFile& tf = v.f[file];
+                const uint32_t a = tf.name_off[r];
+                const uint32_t b = r + 1 < v.n_framed ? tf.name_off[r + 1] : v.consumed[file];
+                SpanEvent* const ev = file == 0 ? events0 : events1;
+                ev[tile_base[(uint64_t)(FMT_EVENT_STREAM + file) * n_tiles + blockIdx.x] + ee] = SpanEvent{a, b - a, t.stream == 0 ? (uint32_t)t.total : 0u};
+            }
         }
         unsigned int pos;
         bool general = false;
@@ -948,8 +1015,9 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
                     over[ti] = t;
                 }
             }
-            const bool whole = plan_is_whole(q[0]);
-            plan0[ti] = q[0];
+            // (spans mode: no whole-record copy kernel runs — whatever has a plan goes to the general kernel, and nobody reads plan0)
+            const bool whole = !v.spans && plan_is_whole(q[0]);
+            if (!v.spans) plan0[ti] = q[0];
             general = q[0].y != PLAN_SKIP && !whole;
         }
         // the records fmt_copy_whole_kernel does not take are listed (one atomic per wave) for the general copy kernel

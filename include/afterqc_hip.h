@@ -324,6 +324,28 @@ int aqc_reframe(aqc_ctx* ctx, int slot, aqc_frame_info* info);
  * mismatches were all corrected (getOverlap, preprocesser.py:78-84,614-616).
  * bytes_out[file * 3 + stream], stream 0 good / 1 bad / 2 overlap.  Index files are not handled here (host side). */
 int aqc_format(aqc_ctx* ctx, int slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6]);
+/* aqc_format WITHOUT the copies nobody needs.  A good record that is written as its own bytes — not trimmed, not renamed, no edit of
+ * the walk in it, every line followed directly by its '\n': the bulk of a run without trimming — already stands in the chunk the
+ * caller handed to aqc_frame; seqFilter.writeReads (preprocesser.py:206-232) would write those very bytes.  aqc_format_spans leaves
+ * such records OUT of the good streams (stream 0 of a file then holds only the good records that had to be rebuilt: trimmed,
+ * corrected, renamed) and makes an EVENT per file for every other record of [0, n), in record order: where the record stood in
+ * the chunk and what it gives to stream 0.  The good output of a file is then, in order:
+ *     chunk bytes [0, e0.in_start) | e0.out_len bytes of stream 0 | chunk bytes [e0.in_start + e0.in_len, e1.in_start) | e1.out_len
+ *     bytes of stream 0 | ... | chunk bytes from behind the last event up to the end of record n - 1 (consumed1 / consumed2 of
+ *     aqc_frame_info when n is the slot's record count)
+ * — byte for byte what aqc_format + aqc_fetch_text(file, 0) hand out.  The bad and overlap streams are as with aqc_format.
+ * aqc_pipe_run writes plain-text outputs this way (writev from its page-locked input buffers): PCIe carries the good records one
+ * way only.  n_events[file] events; fetch them with aqc_fetch_span_events, the streams with aqc_fetch_streams / aqc_fetch_text. */
+typedef struct aqc_span_event {
+    uint32_t in_start; /* the record's first byte in its chunk */
+    uint32_t in_len;   /* the chunk bytes it takes (up to the next record's first byte) */
+    uint32_t out_len;  /* the bytes it contributes to stream 0, in order (0: a bad record) */
+} aqc_span_event;
+int aqc_format_spans(aqc_ctx* ctx, int slot, uint64_t n, int32_t store_overlap, uint64_t bytes_out[6], uint64_t n_events[2]);
+int aqc_fetch_span_events(aqc_ctx* ctx, int slot, int file, aqc_span_event* dst, uint64_t cap);
+/* the chunk bytes of each file up to the end of record n - 1 of a framed slot (n == the slot's record count: consumed1 / consumed2):
+ * where the last piece of an aqc_format_spans output ends when only the first n records are written */
+int aqc_span_end(aqc_ctx* ctx, int slot, uint64_t n, uint64_t end[2]);
 /* index files (-7 / -5, preprocesser.py:222-232): the n records framed into `slot` are written WHOLE, routed and (when
  * bad) renamed by the verdicts of the read records of `verdict_slot` (same chunk, same n); the overlap stream takes
  * the whole record wherever the reads' overlap record is written (preprocesser.py:616). */
