@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with two rocprofv3 --pmc child runs (quote profiles/hbm_traffic.json)")
     ap.add_argument("--device-only", action="store_true", help="profiling runs (rocprofv3): only the HBM-resident device step, no pipe "
                     "runs; `value` is then the device step and says so")
+    ap.add_argument("--text-step-only", action="store_true", help="with --device-only: skip the aqc_format_spans variant of the device step (profiles of the text step alone)")
+    ap.add_argument("--spans-step-only", action="store_true", help="with --device-only: run only the aqc_format_spans variant of the device step in the timed region (profiles)")
     ap.add_argument("--slots", type=int, default=3, help="slots (chunks in flight) per context of the pipe")
     ap.add_argument("--inputs", type=int, default=2, help="K > 1: also run K independent file pairs through K pipes at once on the same GPU(s) — the "
                     "reference's own fan-out, one seqFilter per input (after.py:168-171) — reported as multi_input_file_to_file (never `value`); 0 / 1 = skip")
@@ -217,7 +219,7 @@ def main():
         eng.sync(sl)
     t_up = time.perf_counter() - t_up          # host -> HBM + first framing (reported)
 
-    def step():
+    def step(spans=False):
         total = [0] * 6
         for sl, (lo, hi) in enumerate(res_n):
             eng.reframe(sl)
@@ -227,7 +229,13 @@ def main():
                 eng.qc_stat(sl, capi.QC_R1_POST, 0, 0, n_qc, 1)
                 if paired:
                     eng.qc_stat(sl, capi.QC_R2_POST, 1, 0, n_qc, 1)
-            sz = eng.format(sl, hi - lo, False)     # (returns once the sizes are known; the writer kernel is still queued)
+            # (returns once the sizes are known; the writer kernels are still queued)
+            if spans:
+                # what aqc_pipe_run does for plain-text outputs: the good records that go out as their own bytes are not copied
+                # (they are written from the host's input buffer), stream 0 holds only the rebuilt ones + the event list
+                sz, _ = eng.format_spans(sl, hi - lo, False)
+            else:
+                sz = eng.format(sl, hi - lo, False)
             total = [a + b for a, b in zip(total, sz)]
         return total
 
@@ -243,12 +251,21 @@ def main():
     for sl in range(n_res):
         eng.timing_reset(sl)
     t0 = time.perf_counter()
-    for _ in range(dsteps):
+    for _ in range(dsteps if not args.spans_step_only else 0):
         sizes = step()
     sync_all()
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     dev_elapsed = max_over_ranks(time.perf_counter() - t0)
+    # ... and the same step the way the pipe runs it for plain-text outputs (aqc_format_spans)
+    spans_sizes = step(True)
+    sync_all()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(dsteps if not args.text_step_only else 0):
+        spans_sizes = step(True)
+    sync_all()
+    spans_elapsed = max_over_ranks(time.perf_counter() - t0)
     kms, klaunch = eng.timing_mean(0)
     for sl in range(1, n_res):
         k2, l2 = eng.timing_mean(sl)
@@ -338,6 +355,27 @@ def main():
         best = min(ts)
         pinned = {"mreads_s": round(reads_per_gpu / best / 1e6, 2), "seconds": round(best, 4), "runs": len(ts), "contexts": n_ctx,
                   "gb_s_each_way": round(text_in / best / 1e9, 2), "chunk_records": K}
+        # ... and with AQC_SPANS=1 (opt-in, see aqc_pipe.cpp): the good records that go out as their own bytes are neither copied on the
+        # device nor downloaded — the text goes up, only the bad / rebuilt records and the event lists come back
+        old_spans = os.environ.get("AQC_SPANS")
+        os.environ["AQC_SPANS"] = "1"
+        try:
+            ts = []
+            for it in range(args.pipe_runs + 1):
+                reset_all()
+                t1 = time.perf_counter()
+                pr = pipe.run(inputs, outputs=None, chunk_records=K, qc_sample=args.qc_sample)
+                dt = time.perf_counter() - t1
+                assert not pr.anomaly and int(pr.records) == n_rec
+                if it:
+                    ts.append(dt)
+            pinned["spans_mreads_s"] = round(reads_per_gpu / min(ts) / 1e6, 2)
+            pinned["spans_gb_s_up"] = round(text_in / min(ts) / 1e9, 2)
+        finally:
+            if old_spans is None:
+                os.environ.pop("AQC_SPANS", None)
+            else:
+                os.environ["AQC_SPANS"] = old_spans
 
     # ---- C. file -> pipe -> file: THE METRIC.  W warm-up runs, then K timed runs, each bracketed by a barrier + device
     #      synchronisation on both sides; the previous run's output files are unlinked between runs (not timed: dropping
@@ -543,6 +581,11 @@ def main():
                      "qc_stat_ms_per_call": round(float(kms[capi.K_QC_STAT]), 4),
                      "measured_in": "the device-step loop of this run (HIP events on the slot's stream)"},
         "device_step_mreads_s": round(dev_value, 2),
+        "device_step_spans": {"ms_per_step": round(1000.0 * spans_elapsed / dsteps, 4), "mreads_s": round(reads_per_gpu * world / max(spans_elapsed / dsteps, 1e-9) / 1e6, 2),
+                              "rebuilt_good_and_bad_text_gb_per_gpu": round(sum(spans_sizes) / 1e9, 4),
+                              "what": "the device step as aqc_pipe_run issues it for plain-text outputs: aqc_reframe -> aqc_run -> aqc_qc_stat -> aqc_format_spans "
+                                      "— good records that go out as their own bytes are not copied on the device (the file writers take them from the "
+                                      "page-locked input buffer), only the bad / trimmed / corrected records are formatted"},
         "device_step": {"ms_per_step": round(dev_ms, 4), "steps": dsteps, "text_in_gb_per_gpu": round(text_in / 1e9, 3),
                         "text_out_gb_per_gpu": round(text_out / 1e9, 3), "step_text_gb_s": round((text_in + text_out) / (dev_ms * 1e-3) / 1e9, 1),
                         "what": "text resident in HBM -> aqc_reframe -> aqc_run -> aqc_qc_stat -> aqc_format (no PCIe, no files), every rank on its own GPU"},

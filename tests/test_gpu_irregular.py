@@ -32,6 +32,7 @@ MODES = {
     "pipe": dict(use_text_path=True, use_pipe=True),
     "pipe_small_chunks": dict(use_text_path=True, use_pipe=True, chunk_records=5, pipe_slots=3),
     "pipe_two_contexts": dict(use_text_path=True, use_pipe=True, chunk_records=7, devices=[0, 0], own_engines=True),
+    "pipe_spans": dict(use_text_path=True, use_pipe=True, chunk_records=6, pipe_slots=2, spans=True),      # AQC_SPANS=1 (aqc_format_spans)
 }
 
 
@@ -63,12 +64,21 @@ def _run(case, tmp_path, engine, mode, info):
         kw = dict(MODES[mode])
         if kw.pop("own_engines", False):
             engine = None
+        spans = kw.pop("spans", False)
+        old_spans = os.environ.get("AQC_SPANS")
+        if spans:
+            os.environ["AQC_SPANS"] = "1"
         flt = preprocesser.seqFilter(options, engine=engine, **kw)
         try:
             stat = flt.run()
         finally:
             info["used_pipe"] = flt.used_pipe
             info["text_path"] = getattr(flt, "text_path", None)
+            if spans:
+                if old_spans is None:
+                    os.environ.pop("AQC_SPANS", None)
+                else:
+                    os.environ["AQC_SPANS"] = old_spans
     finally:
         os.chdir(cwd)
     return stat

@@ -29,7 +29,9 @@ MODES = {"text": dict(use_text_path=True, use_pipe=False), "text_tiny_chunks": d
 # statistics are summed on the host
 PIPE_MODES = {"pipe": dict(use_text_path=True, use_pipe=True),
               "pipe_small_chunks": dict(use_text_path=True, use_pipe=True, chunk_records=257, pipe_slots=3),
-              "pipe_two_contexts": dict(use_text_path=True, use_pipe=True, chunk_records=300, devices=[0, 0], own_engines=True)}
+              "pipe_two_contexts": dict(use_text_path=True, use_pipe=True, chunk_records=300, devices=[0, 0], own_engines=True),
+              # AQC_SPANS=1: plain-text good files written from the pipe's input buffers (aqc_format_spans), rebuilt records between them
+              "pipe_spans": dict(use_text_path=True, use_pipe=True, chunk_records=211, pipe_slots=3, spans=True)}
 
 
 def run_case(name, tmp_path, engine, mode="text", info=None):
@@ -51,8 +53,19 @@ def run_case(name, tmp_path, engine, mode="text", info=None):
         kw = dict(MODES[mode] if mode in MODES else PIPE_MODES[mode])
         if kw.pop("own_engines", False):
             engine = None                                                        # the filter creates one engine per device
-        flt = preprocesser.seqFilter(options, engine=engine, **kw)              # what after.processOptions does
-        stat = flt.run()
+        spans = kw.pop("spans", False)
+        old_spans = os.environ.get("AQC_SPANS")
+        if spans:
+            os.environ["AQC_SPANS"] = "1"
+        try:
+            flt = preprocesser.seqFilter(options, engine=engine, **kw)          # what after.processOptions does
+            stat = flt.run()
+        finally:
+            if spans:
+                if old_spans is None:
+                    os.environ.pop("AQC_SPANS", None)
+                else:
+                    os.environ["AQC_SPANS"] = old_spans
         if info is not None:
             info["text_path"] = flt.text_path
             info["used_pipe"] = flt.used_pipe
