@@ -169,6 +169,7 @@ struct QcDev {
 
 struct aqc_ctx {
     bool force_generic = false;
+    bool qc_inline = false;       // AQC_QC_STREAM=0: statRead kernels on the slot's stream instead of the context's QC stream
     int device = 0;
     int n_slots = 0;
     std::vector<Slot> slots;
@@ -275,6 +276,8 @@ int aqc_create(int device, int n_slots, aqc_ctx** out) {
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char* fg = getenv("AQC_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
+    const char* qi = getenv("AQC_QC_STREAM");
+    c->qc_inline = qi && qi[0] == '0';
     HIP_TRY(hipFuncSetAttribute((const void*)kmer_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KMER_FUSED_LDS_BYTES));
     HIP_TRY(hipStreamCreateWithFlags(&c->qc_stream, hipStreamNonBlocking));
     for (auto& s : c->slots) {
@@ -694,9 +697,11 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
     // the statRead kernels go to the context's QC stream, behind everything queued on the slot's stream so far (text, results):
     // a few thousand latency-bound waves that overlap with the slot's bandwidth-bound kernels (the formatter) instead of
     // holding them up.  The slot is "in sync" again only when they are done too (slot_sync).
-    hipStream_t qs = c->qc_stream;
+    // (AQC_QC_STREAM=0: on the slot's own stream, one kernel after the other — for profiles: beside the formatter a statRead kernel's
+    //  start-to-end time is mostly the wait for free wave slots, e.g. 1.38 ms for a kernel whose waves live 0.06 ms)
+    hipStream_t qs = c->qc_inline ? s->stream : c->qc_stream;
     HIP_TRY(hipEventRecord(s->ev_main, s->stream));
-    HIP_TRY(hipStreamWaitEvent(qs, s->ev_main, 0));
+    if (!c->qc_inline) HIP_TRY(hipStreamWaitEvent(qs, s->ev_main, 0));
     HIP_TRY(hipEventRecord(launch_event(*s, AQC_K_QC_STAT, 0), qs));
     // LDS sized by the longest read of the slot: many resident workgroups for short reads
     const uint32_t mx = s->raw_max_len ? s->raw_max_len : AQC_MAX_READ_LEN;

@@ -647,6 +647,13 @@ struct Run {
     std::condition_variable set_cv;
     std::vector<char> set_free;        // [worker * 2 + set]
     bool gz_on_device = false;
+    int io_node = -1;                  // the NUMA node every context's GPU hangs off (-1: they differ, or unknown): readers, the dispatcher, the
+                                       // commit thread and the file writers run there too, next to the rings they fill and drain
+    void bind_io_thread(const char* what) {
+        const int bound = aqc_bind_thread_to_node(io_node);
+        if (getenv("AQC_PIPE_DEBUG"))
+            fprintf(stderr, "pipe: %s thread — NUMA node %d, %s\n", what, io_node, bound ? "bound to that node's CPUs" : "not bound (contexts on several nodes, single node, unknown, or AQC_PIPE_NUMA=0)");
+    }
     bool spans_on = false;             // plain-text output: good records that go out as their own bytes are written from the input buffers
     // QC turn taking (post-filter sampling must be issued in chunk order, see aqc_qc_stat's time keys)
     std::mutex qc_mu;
@@ -708,6 +715,7 @@ struct Run {
 
     // ---- reader: chunks of exactly K records -------------------------------------------------------------------------
     void reader(int f) {
+        bind_io_thread(f == 0 ? "reader (file 1)" : "reader (file 2)");     // (the ring buffers it allocates are first touched here)
         const bool mem = io->in_mem[f] != nullptr;
         std::unique_ptr<Source> src;
         if (!mem) {
@@ -838,6 +846,7 @@ struct Run {
 
     // ---- dispatcher: pair the chunks, deal them round robin ---------------------------------------------------------------
     void dispatcher() {
+        bind_io_thread("dispatcher");
         for (uint64_t idx = 0; !abort; ++idx) {
             Job j;
             j.idx = idx;
@@ -1084,6 +1093,7 @@ struct Run {
     }
 
     void file_writer(int q) {
+        bind_io_thread("file writer");
         std::shared_ptr<Commit> cm;
         while (fileq[q]->pop(cm)) {
             const OutChunk& oc = cm->oc;
@@ -1131,6 +1141,7 @@ struct Run {
     }
 
     void writer() {
+        bind_io_thread("commit");
         std::map<uint64_t, OutChunk> pending;
         uint64_t next = 0;
         OutChunk oc;
@@ -1270,6 +1281,10 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
         }
         for (size_t k = 0; k < devs.size(); ++k) { R.up_gate.emplace_back(new Run::Gate()); R.down_gate.emplace_back(new Run::Gate()); }
         R.group_tickets.assign(devs.size(), 0);
+        // one node for the I/O threads when every context's GPU hangs off the same one
+        R.io_node = aqc_device_numa_node(P->ctx[0]);
+        for (int i = 1; i < P->n_ctx; ++i)
+            if (aqc_device_numa_node(P->ctx[i]) != R.io_node) R.io_node = -1;
     }
     if (!opt->no_output) {
         for (int q = 0; q < 6; ++q) {

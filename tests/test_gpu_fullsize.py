@@ -140,3 +140,32 @@ def test_bench_two_ranks_shared_gpu(tmp_path):
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
     assert "cpu_baseline" not in out          # rank 0 at N=1 only
     assert abs(out["value"] - 2 * 2 * 500000 / (out["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * out["value"]
+    # BOTH shapes in one line: `value` = one input dealt over the two ranks' devices (two output files: flat by design), and
+    # multi_input_file_to_file = one input PER rank, every rank its own pipe over its own files, at once (the shape that scales)
+    assert "one input" in out["config"]["parallelism"] or "ONE input" in out["config"]["parallelism"], out["config"]
+    mi = out["multi_input_file_to_file"]
+    assert mi and mi["inputs"] == 2 and mi["output_files"] == 8 and mi["mreads_s"] > 0, mi
+
+
+def test_config4_size_soak_one_input_of_100M_reads(tmp_path):
+    """BASELINE config 4 at its stated size on one GPU (tools/soak_config4.py: ONE input of 10 x the 5 M-pair block = 100 M reads,
+    two 17 GB files, over two contexts on GPU 0): every output file equals the block's output x 10 byte for byte, counters and
+    histograms are 10 x the block's, the post-filter QC rows the block's, record indices beyond 2^32 give the same bytes.  The
+    inputs live in /dev/shm (35 GB would not fit beside 34 GB of outputs on the boxes' 79 GB disks) and are clean when the run
+    starts; the run's rate is printed, and must not fall back to the write-back-throttled 20 Mreads/s of round 4's soak."""
+    import shutil
+    in_dir = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 45e9 else None
+    copies = 10 if in_dir and shutil.disk_usage(str(tmp_path)).free > 45e9 else 3
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "soak_config4.py"), "--copies", str(copies), "--devices", "0,0", "--dir", str(tmp_path)]
+    if in_dir:
+        cmd += ["--in-dir", in_dir]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    log = json.loads(p.stdout[p.stdout.index("{"):])
+    assert log["ok"] and log["copies"] == copies and log["reads"] == 2 * 5_000_000 * copies
+    assert log["counters_equal_copies_x_block"] and log["histograms_equal_copies_x_block"] and log["post_filter_qc_rows_equal_block"]
+    assert all(v["equals_block_output_x_copies"] for v in log["outputs"].values())
+    assert log["indices_beyond_2_32"]["identical_outputs_and_counters"]
+    print("soak:", json.dumps(log["run"]))
+    if copies == 10:
+        assert log["largest_output_gib"] > 15 and log["run"]["mreads_s"] > 28, log["run"]

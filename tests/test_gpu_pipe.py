@@ -71,6 +71,26 @@ def test_one_million_pairs_over_four_contexts_on_one_device(tmp_path):
     assert a_stat["afterqc_main_summary"]["total_reads"] == n
 
 
+def test_two_million_pairs_over_eight_contexts_on_one_device(tmp_path):
+    """what an 8-GPU node sets up, on one device: AQC_DEVICES=0,0,0,0,0,0,0,0 — eight contexts, 24 slot workers, one pair of DMA
+    gates, the I/O threads bound to the (one) NUMA node of all eight — over ONE 2 M-pair input: byte-identical outputs and an
+    identical statistics JSON to the one-context run"""
+    work = str(tmp_path)
+    n = 2_000_000
+    d = synth.make_pairs(n, 150, seed=8888, workers=8)
+    r1, r2 = os.path.join(work, "R1.fq"), os.path.join(work, "R2.fq")
+    synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
+    synth.write_fastq_fixed(r2, d["seq2"], d["qual2"], 2)
+    del d
+    extra = ["-f", "0", "-t", "0"]
+    a_files, a_stat, a = run(work, r1, r2, extra, tag="one", use_pipe=True, devices=[0], chunk_records=1 << 15)
+    b_files, b_stat, b = run(work, r1, r2, extra, tag="eight", use_pipe=True, devices=[0] * 8, chunk_records=5000, pipe_slots=3)
+    assert a.used_pipe and b.used_pipe
+    assert a_files == b_files
+    assert a_stat == b_stat
+    assert a_stat["afterqc_main_summary"]["total_reads"] == n
+
+
 def test_pipe_gzip_in_and_out(tmp_path):
     """.gz in (our own BGZF-style multi-member files: inflated member-parallel; and a single-member stream) -> .gz out"""
     import gzip

@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--devices", default="0,0")
     ap.add_argument("--chunk-records", type=int, default=1 << 17)
     ap.add_argument("--dir", default=None)
+    ap.add_argument("--in-dir", default=None, help="where the big INPUT pair goes (default: --dir).  /dev/shm keeps 35 GB off a small disk")
+    ap.add_argument("--no-sync", action="store_true", help="do not sync() the inputs before the timed run (round 4's soak: the run then starts with 35 GB of "
+                    "dirty input pages and is throttled to the disk's write-back rate once its own outputs push the cgroup over its dirty limit)")
     args = ap.parse_args()
     import numpy as np
     from afterqc_amd import capi, synth
@@ -55,7 +58,7 @@ def main():
         free = shutil.disk_usage(work).free
         copies = args.copies
         # inputs + outputs (~ the same size) + the one-block reference run
-        while copies > 1 and (2 * copies + 2) * block_bytes * 1.05 > free:
+        while copies > 1 and ((1 if args.in_dir else 2) * copies + 2) * block_bytes * 1.05 > free:
             copies -= 1
         if copies != args.copies:
             print("soak: only %.0f GB free in %s: %d copies instead of %d" % (free / 1e9, work, copies, args.copies), flush=True)
@@ -113,12 +116,22 @@ def main():
 
         # ---- COPIES blocks as ONE input over the contexts of --devices
         big_in, big_out = names("big")
+        in_work = None
+        if args.in_dir:
+            in_work = tempfile.mkdtemp(prefix="aqc_soak_in_", dir=args.in_dir)
+            big_in = [os.path.join(in_work, os.path.basename(p)) for p in big_in]
         tw = time.time()
         for p, (buf, nb) in zip(big_in, block):
             with open(p, "wb") as f:
                 for _ in range(copies):
                     f.write(memoryview(buf)[:nb])
         log["write_inputs_s"] = round(time.time() - tw, 1)
+        if not args.no_sync:
+            ts = time.time()
+            os.sync()              # the inputs are clean when the run starts, as a user's files are
+            log["sync_inputs_s"] = round(time.time() - ts, 1)
+        with open("/proc/meminfo") as f:
+            log["dirty_kb_before_run"] = int([ln.split()[1] for ln in f if ln.startswith("Dirty:")][0])
         devs = [int(x) for x in args.devices.split(",")]
         engines = []
         for g in devs:
@@ -172,6 +185,8 @@ def main():
             e.close()
     finally:
         shutil.rmtree(work, ignore_errors=True)
+        if args.in_dir and 'in_work' in dir() and in_work:
+            shutil.rmtree(in_work, ignore_errors=True)
     log["total_s"] = round(time.time() - t0, 1)
     log["ok"] = bool(ok)
     print(json.dumps(log, indent=1))
