@@ -691,7 +691,7 @@ class Pipe:
                 b = src.encode() if isinstance(src, str) else src
                 keep.append(b)
                 io.in_path[k] = b
-                io.gzip_in[k] = 1 if gzip_in[k] else 0
+                io.gzip_in[k] = int(gzip_in[k]) if gzip_in[k] else 0        # 1 gzip, 2 bzip2
             else:
                 arr, nbytes = src
                 keep.append(arr)
@@ -723,7 +723,7 @@ class NativeSource:
 
     def __init__(self, path, gzip_in, io_threads=0, gz_section_bytes=0):
         self.lib = load_library()
-        self.h = self.lib.aqc_source_open2(path.encode() if isinstance(path, str) else path, 1 if gzip_in else 0, int(io_threads),
+        self.h = self.lib.aqc_source_open2(path.encode() if isinstance(path, str) else path, int(gzip_in) if gzip_in else 0, int(io_threads),
                                            int(gz_section_bytes))
         if not self.h:
             raise IOError("cannot open " + str(path))
@@ -790,7 +790,7 @@ def pipe_split(source, chunk_records, gzip_in=False, io_threads=4, cap=1 << 16):
         b = source.encode()
         keep.append(b)
         io.in_path[0] = b
-        io.gzip_in[0] = 1 if gzip_in else 0
+        io.gzip_in[0] = int(gzip_in) if gzip_in else 0        # 1 gzip, 2 bzip2
     else:
         arr = np.frombuffer(source, dtype=np.uint8) if len(source) else np.zeros(1, dtype=np.uint8)
         keep.append(arr)

@@ -21,6 +21,7 @@
 // empty line inside.  Anything else (fastq.py:44-47's "empty line ends the file", mates of different lengths, ...)
 // is detected from the frame info and reported as `anomaly`; the caller then reruns the input through the serial
 // chunk loop, which reproduces the reference's reader semantics case by case.
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -248,6 +249,174 @@ struct FileSource : Source {
         if (err) { bad = true; return 0; }
         pos += take;
         return take;
+    }
+};
+
+// A bzip2 file (fastq.py:25-26: bz2.BZ2File upstream).  libbz2 does the decoding — loaded at run time (dlopen: the image carries the
+// library Python's bz2 module links, not its header) — on threads of its own, so that the pipe's readers, GPUs and writers work
+// while it does: the file is mapped and cut at its STREAM starts ("BZh1".."BZh9" + the block magic, byte aligned: pbzip2 and
+// concatenated files have many, plain bzip2 one); a producer thread decodes windows of streams in parallel on the pool and queues
+// their text in order.  A file that ends inside a stream, or that libbz2 rejects, is an error.  (Every stream is decoded, as
+// python 3's BZ2File does — the path the serial loop takes for .bz2; python 2's reads only the first, qualitycontrol.py:77-78
+// warns about pbzip2 files.)
+struct Bz2Api {
+    struct Stream {
+        char* next_in; unsigned int avail_in, total_in_lo32, total_in_hi32;
+        char* next_out; unsigned int avail_out, total_out_lo32, total_out_hi32;
+        void* state; void* (*bzalloc)(void*, int, int); void (*bzfree)(void*, void*); void* opaque;
+    };
+    int (*init)(Stream*, int, int) = nullptr;
+    int (*step)(Stream*) = nullptr;
+    int (*end)(Stream*) = nullptr;
+    bool ok = false;
+    Bz2Api() {
+        void* h = nullptr;
+        for (const char* name : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return;
+        init = (int (*)(Stream*, int, int))dlsym(h, "BZ2_bzDecompressInit");
+        step = (int (*)(Stream*))dlsym(h, "BZ2_bzDecompress");
+        end = (int (*)(Stream*))dlsym(h, "BZ2_bzDecompressEnd");
+        ok = init && step && end;
+    }
+    static const Bz2Api& get() { static Bz2Api api; return api; }
+};
+
+struct Bz2Source : Source {
+    int fd = -1;
+    Pool* pool;
+    const uint8_t* map = nullptr;
+    size_t size = 0;
+    std::atomic<bool> bad{false}, stop{false};
+    char err[200] = "";
+    std::mutex err_mu;
+    std::vector<size_t> starts;                 // stream starts + the file's size
+    std::thread producer;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::vector<uint8_t>> q;         // decoded text, in order
+    size_t q_bytes = 0, front_off = 0;
+    bool done = false;
+
+    void fail(const char* msg) {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (!bad) snprintf(err, sizeof(err), "%s", msg);
+        bad = true;
+    }
+    Bz2Source(const char* path, Pool* p) : pool(p) {
+        fd = open(path, O_RDONLY);
+        if (fd < 0) { fail("cannot open the file"); return; }
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { fail("not a regular file"); return; }
+        size = (size_t)st.st_size;
+        if (!Bz2Api::get().ok) { fail("libbz2 could not be loaded (dlopen libbz2.so.1.0)"); return; }
+        if (size) {
+            void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { fail("cannot map the file"); return; }
+            map = (const uint8_t*)m;
+            (void)madvise(m, size, MADV_SEQUENTIAL);
+            if (size < 10 || memcmp(map, "BZh", 3) != 0) { fail("not a bzip2 file"); return; }
+        }
+        producer = std::thread([this] { produce(); });
+    }
+    ~Bz2Source() override {
+        stop = true;
+        cv.notify_all();
+        if (producer.joinable()) producer.join();
+        if (map) munmap((void*)map, size);
+        if (fd >= 0) close(fd);
+    }
+    bool failed() const override { return bad; }
+    const char* why() const override { return err; }
+
+    static bool stream_start(const uint8_t* p) {
+        static const uint8_t blk[6] = {0x31, 0x41, 0x59, 0x26, 0x53, 0x59}, eos[6] = {0x17, 0x72, 0x45, 0x38, 0x50, 0x90};
+        return p[0] == 'B' && p[1] == 'Z' && p[2] == 'h' && p[3] >= '1' && p[3] <= '9' && (memcmp(p + 4, blk, 6) == 0 || memcmp(p + 4, eos, 6) == 0);
+    }
+    // one stream -> text; false: libbz2 rejected it or it ends early
+    bool decode(size_t a, size_t b, std::vector<uint8_t>& out) {
+        const Bz2Api& api = Bz2Api::get();
+        Bz2Api::Stream z{};
+        if (api.init(&z, 0, 0) != 0) return false;
+        out.resize(std::max<size_t>(1u << 20, (b - a) * 5));
+        size_t produced = 0;
+        z.next_in = (char*)(map + a);
+        size_t in_left = b - a;
+        bool ok = false;
+        for (;;) {
+            if (z.avail_in == 0 && in_left) { z.avail_in = (unsigned)std::min<size_t>(in_left, 1u << 30); in_left -= z.avail_in; }
+            if (out.size() - produced < (1u << 16)) out.resize(out.size() + out.size() / 2);
+            z.next_out = (char*)out.data() + produced;
+            const size_t room = std::min<size_t>(out.size() - produced, 1u << 30);
+            z.avail_out = (unsigned)room;
+            const int rc = api.step(&z);
+            produced += room - z.avail_out;
+            if (rc == 4) { ok = z.avail_in == 0 && in_left == 0; break; }          // BZ_STREAM_END (and nothing behind it inside this piece)
+            if (rc != 0 || (z.avail_in == 0 && in_left == 0 && z.avail_out != 0)) break;   // error, or the stream ends early
+            if (stop) break;
+        }
+        api.end(&z);
+        out.resize(produced);
+        return ok;
+    }
+    void produce() {
+        // stream starts: byte aligned (a stream is padded to a whole byte); ten fixed bytes make a chance hit a 2^-80 event
+        if (size) {
+            const size_t nb = (size + (4u << 20) - 1) / (4u << 20);
+            std::vector<std::vector<size_t>> hits(nb);
+            pool->parallel_for(nb, [&](size_t i) {
+                const size_t lo = i * (4u << 20), hi = std::min(size, lo + (4u << 20));
+                for (size_t o = lo; o < hi && o + 10 <= size; ++o) {
+                    const uint8_t* hit = (const uint8_t*)memchr(map + o, 'B', hi - o);
+                    if (!hit) break;
+                    o = (size_t)(hit - map);
+                    if (o + 10 <= size && stream_start(map + o)) hits[i].push_back(o);
+                }
+            });
+            for (auto& h : hits) starts.insert(starts.end(), h.begin(), h.end());
+            if (starts.empty() || starts[0] != 0) { fail("not a bzip2 file"); starts.clear(); }
+            starts.push_back(size);
+        }
+        const size_t window = (size_t)std::max(2, pool->size());
+        for (size_t k = 0; k + 1 < starts.size() && !stop && !bad; k += window) {
+            const size_t n = std::min(window, starts.size() - 1 - k);
+            std::vector<std::vector<uint8_t>> outs(n);
+            std::vector<char> good(n, 0);
+            pool->parallel_for(n, [&](size_t i) { good[i] = decode(starts[k + i], starts[k + i + 1], outs[i]) ? 1 : 0; });
+            for (size_t i = 0; i < n && !bad; ++i) {
+                if (!good[i]) { fail("corrupt or truncated bzip2 stream"); break; }
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || q_bytes < (1u << 30); });
+                if (stop) break;
+                q_bytes += outs[i].size();
+                q.push_back(std::move(outs[i]));
+                lk.unlock();
+                cv.notify_all();
+            }
+        }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            done = true;
+        }
+        cv.notify_all();
+    }
+    size_t read(uint8_t* dst, size_t want) override {
+        size_t got = 0;
+        while (got < want) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !q.empty() || done || bad; });
+            if (bad) return 0;
+            if (q.empty()) break;                                  // done
+            std::vector<uint8_t>& f = q.front();
+            const size_t take = std::min(want - got, f.size() - front_off);
+            lk.unlock();
+            memcpy(dst + got, f.data() + front_off, take);         // (the front buffer is only ever popped by this thread)
+            got += take;
+            lk.lock();
+            front_off += take;
+            if (front_off == f.size()) { q_bytes -= f.size(); q.pop_front(); front_off = 0; lk.unlock(); cv.notify_all(); }
+        }
+        return bad ? 0 : got;
     }
 };
 
@@ -719,7 +888,8 @@ struct Run {
         const bool mem = io->in_mem[f] != nullptr;
         std::unique_ptr<Source> src;
         if (!mem) {
-            if (io->gzip_in[f]) {
+            if (io->gzip_in[f] == 2) src.reset(new Bz2Source(io->in_path[f], P->pool.get()));
+            else if (io->gzip_in[f]) {
                 // gzip input: the GPUs take groups of sections off the pool's hands (file f -> the device of context f % n)
                 const char* e = getenv("AQC_GZ_DEVICE_IN");
                 if (!(e && e[0] == '0') && !P->gz_offload_tried[f] && !P->ctx.empty()) {      // (set up with the first .gz input of this file slot)
@@ -1392,7 +1562,8 @@ aqc_source* aqc_source_open2(const char* path, int32_t gzip, int32_t io_threads,
     aqc_source* s = new aqc_source();
     unsigned hc = std::thread::hardware_concurrency();
     s->pool.reset(new Pool(io_threads > 0 ? io_threads : (int)std::min(16u, std::max(2u, hc / 4))));
-    if (gzip) s->src.reset(new GzSource(path, s->pool.get(), (size_t)gz_section_bytes));
+    if (gzip == 2) s->src.reset(new Bz2Source(path, s->pool.get()));
+    else if (gzip) s->src.reset(new GzSource(path, s->pool.get(), (size_t)gz_section_bytes));
     else s->src.reset(new FileSource(path, s->pool.get()));
     if (s->src->failed()) { delete s; return nullptr; }
     return s;

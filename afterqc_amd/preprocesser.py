@@ -482,8 +482,7 @@ class seqFilter:
         outs = None
         extra_bases = None
         readers = []
-        if (self.text_path and self.use_pipe and not (has_i1 or has_i2) and not opt.qc_only and isinstance(eng, capi.Engine)
-                and not any(f is not None and f.endswith(".bz2") for f in files)):
+        if self.text_path and self.use_pipe and not (has_i1 or has_i2) and not opt.qc_only and isinstance(eng, capi.Engine):
             extra_bases = self._run_pipe(opt, files, good_dir, bad_dir, overlap_dir, gzip_out, paired)
             if extra_bases is None:
                 # not the regular shape (empty line inside, mates of different lengths, ...): start over, chunk by chunk
@@ -573,7 +572,8 @@ class seqFilter:
         engines = self._engines(all_devices=True)
         pipe = capi.Pipe(engines, slots=min([self.pipe_slots] + [e.n_slots for e in engines]), io_threads=self.io_threads)
         try:
-            res = pipe.run(files[:nfiles], outputs, gzip_in=[f.endswith(".gz") for f in files[:nfiles]], gzip_out=gzip_out,
+            # (fastq.py:23-26: .gz through gzip.open, .bz2 through bz2.BZ2File upstream — here the pipe's own decoders: 1 gzip, 2 bzip2)
+            res = pipe.run(files[:nfiles], outputs, gzip_in=[1 if f.endswith(".gz") else 2 if f.endswith(".bz2") else 0 for f in files[:nfiles]], gzip_out=gzip_out,
                            gzip_level=opt.compression, chunk_records=self.chunk_records, qc_sample=opt.qc_sample,
                            store_overlap=bool(opt.store_overlap) and paired)
         except capi.AqcError as e:

@@ -407,7 +407,8 @@ typedef struct aqc_pipe_io {
     const uint8_t* in_mem[2];      /* alternative to a path: the FASTQ text in host memory (page-locked memory from
                                       aqc_host_alloc is used in place, zero copy) */
     uint64_t in_mem_bytes[2];
-    int32_t gzip_in[2];            /* the file is a gzip stream (fastq.py:23-24) */
+    int32_t gzip_in[2];            /* 1: the file is a gzip stream (fastq.py:23-24); 2: a bzip2 file (fastq.py:25-26; decoded by libbz2, loaded at run
+                                      time, on the pipe's own threads: every stream of the file, streams in parallel) */
     const char* out_path[2][3];    /* per input: good / bad / overlap output file, NULL = that stream is dropped */
     int32_t gzip_out;              /* write .gz (preprocesser.py:318-321) */
     int32_t gzip_level;            /* --compression */
@@ -446,7 +447,7 @@ const char* aqc_pipe_last_error(void);
  * aqc_source_read fills dst with the next `want` decompressed bytes and returns their number (< want only at the end of
  * the stream, -1 on a read / format error: aqc_source_error says which). */
 typedef struct aqc_source aqc_source;
-aqc_source* aqc_source_open(const char* path, int32_t gzip, int32_t io_threads);
+aqc_source* aqc_source_open(const char* path, int32_t gzip, int32_t io_threads);      /* gzip: 0 plain, 1 gzip, 2 bzip2 */
 /* gz_section_bytes: compressed bytes per speculative section (0: chosen from the file size; AQC_GZ_SECTION overrides) */
 aqc_source* aqc_source_open2(const char* path, int32_t gzip, int32_t io_threads, uint64_t gz_section_bytes);
 int64_t aqc_source_read(aqc_source* s, uint8_t* dst, uint64_t want);

@@ -187,3 +187,51 @@ def test_deflate_block_and_crc_through_the_c_abi():
         b = rng.integers(0, 256, n, dtype=np.uint8)
         c0 = int(rng.integers(0, 1 << 32))
         assert lib.aqc_gz_crc32(c0, b.ctypes.data, n) == zlib.crc32(b.tobytes(), c0)
+
+
+def _read_all_bz2(path, threads=4, piece=777777):
+    s = capi.NativeSource(path, 2, io_threads=threads)
+    out = bytearray()
+    buf = bytearray(piece)
+    try:
+        while True:
+            k = s.readinto(buf)
+            out += buf[:k]
+            if k < piece:
+                break
+        return bytes(out)
+    finally:
+        s.close()
+
+
+def test_bzip2_input_through_the_pipes_own_source(tmp_path):
+    """fastq.py:25-26 opens .bz2 inputs with bz2.BZ2File; here libbz2 (loaded at run time) decodes on the pipe's own threads
+    (csrc/aqc_pipe.cpp, Bz2Source): a plain bzip2 file (one stream), a pbzip2-style file (many streams, decoded in parallel,
+    delivered in order), an empty stream in between, levels 1 and 9 — byte for byte what python's bz2 module makes of them; a
+    truncated file, a corrupted block and a file that is no bzip2 file are errors, never a clean end of input"""
+    import bz2
+    text = _fastq_text(30000, 12)
+    one = bz2.compress(text, 9)
+    pieces = [text[i:i + 700001] for i in range(0, len(text), 700001)]
+    many = b"".join(bz2.compress(p, 1 if k % 2 else 9) for k, p in enumerate(pieces))
+    with_empty = bz2.compress(pieces[0]) + bz2.compress(b"") + bz2.compress(b"".join(pieces[1:]))
+    for name, data, want in (("one", one, text), ("many", many, text), ("with_empty", with_empty, text), ("empty", bz2.compress(b""), b"")):
+        p = str(tmp_path / (name + ".fq.bz2"))
+        with open(p, "wb") as f:
+            f.write(data)
+        assert bz2.decompress(data) == want
+        assert _read_all_bz2(p) == want, name
+        assert _read_all_bz2(p, threads=1, piece=4096 if len(want) < (1 << 20) else 1 << 20) == want, name
+    bad = bytearray(one)
+    bad[len(one) // 2] ^= 0x55
+    for name, data in (("truncated", one[:len(one) * 2 // 3]), ("flipped", bytes(bad)), ("not_bzip2", b"@r\nACGT\n+\nIIII\n" * 100),
+                       ("many_truncated", many[:len(many) - 1000])):
+        p = str(tmp_path / (name + ".fq.bz2"))
+        with open(p, "wb") as f:
+            f.write(data)
+        with pytest.raises(IOError):
+            _read_all_bz2(p)
+    # ... and the reader half of the pipe over it: chunks of exactly K records, the same bytes (CRC-32 of the concatenated chunks)
+    p = str(tmp_path / "many.fq.bz2")
+    nbytes, lines, crc = capi.pipe_split(p, 4096, gzip_in=2)
+    assert sum(nbytes) == len(text) and sum(lines) == text.count(b"\n") and all(x == 4 * 4096 for x in lines[:-1]) and crc == (zlib.crc32(text) & 0xffffffff)
