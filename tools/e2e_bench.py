@@ -37,11 +37,12 @@ def main():
     ap.add_argument("--gz-level", type=int, default=6, help="level of the single-member .gz inputs (gzip's default: 6)")
     ap.add_argument("--bgzf", action="store_true", help="with --gz: inputs as BGZF-style independent 64 KiB members instead (the pipe's own "
                     "writer's format; member-parallel inflate)")
+    ap.add_argument("--bz2", action="store_true", help="bzip2 inputs (fastq.py:25-26): plain text first, then the bzip2 program; outputs are plain text")
     ap.add_argument("--config5", action="store_true", help="config-5 flavour: 2x250 bp + 17 bp barcode/verify prefix, file names with 'barcode', --debubble with a circles.csv")
     args = ap.parse_args()
     from afterqc_amd import after, preprocesser, synth
     os.makedirs(args.dir, exist_ok=True)
-    ext = ".fq.gz" if args.gz else ".fq"
+    ext = ".fq.gz" if args.gz else ".fq.bz2" if args.bz2 else ".fq"
     stem = "barcode_" if args.config5 else ""
     r1, r2 = os.path.join(args.dir, stem + "R1" + ext), os.path.join(args.dir, stem + "R2" + ext)
     t = time.perf_counter()
@@ -69,11 +70,22 @@ def main():
         for pr, plain in jobs:
             assert pr.wait() == 0
             os.unlink(plain)
+    elif args.bz2:
+        import subprocess
+        jobs = []
+        for path, mate in ((r1, 1),) + (() if args.single else ((r2, 2),)):
+            plain = path[:-4]
+            synth.write_fastq_fixed(plain, d["seq%d" % mate], d["qual%d" % mate], mate)
+            jobs.append((subprocess.Popen(["bzip2", "-k", "-f", plain]), plain))
+        for pr, plain in jobs:
+            assert pr.wait() == 0
+            os.unlink(plain)
     else:
         synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
         if not args.single:
             synth.write_fastq_fixed(r2, d["seq2"], d["qual2"], 2)
     del d
+    os.sync()          # the inputs are clean when the run starts, as a user's files are (dirty input pages count against the run's own write-back budget)
     gen_s = time.perf_counter() - t
     argv = ["-1", r1] + ([] if args.single else ["-2", r2]) + ["-f", "0", "-t", "0", "-g", os.path.join(args.dir, "good"),
                                                               "-b", os.path.join(args.dir, "bad"), "-r", os.path.join(args.dir, "QC")]
