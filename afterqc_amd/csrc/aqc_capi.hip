@@ -78,6 +78,7 @@ struct Slot {
                                      // of a context may be driven from different host threads); 16 bytes: the word, and at
                                      // byte 8 DevStats::err_key (the earliest record at which upstream's run would have died)
     uint64_t err_record = UINT64_MAX; // ... as the last check_status read it (aqc_error_record)
+    bool has_irregular = false;      // some record of the slot has a quality line that is not as long as its sequence line
     DevBuf qlen[2], qview[2];        // quality-line lengths of an uploaded batch (aqc_batch::qlen*), final quality views of LEN_IRR records
     DevBuf seq1, qual1, off1, qoff1, len1, seq2, qual2, off2, qoff2, len2, aux[5], results;
     DevBuf deferred, n_deferred;     // records the lane-per-read kernel hands to the general kernel
@@ -547,6 +548,7 @@ static int fill_slot(aqc_ctx* c, Slot& s, const aqc_batch* b, bool need_qual, bo
         v.aux_ok = (const uint8_t*)s.aux[4].p;
     }
     if (s.results.reserve(sizeof(aqc_result) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
+    s.has_irregular = b->qlen1 != nullptr && need_qual;
     if (b->qlen1 && need_qual) {
         // quality strings with lengths of their own: the mates that differ are marked in the device copy of their length words
         if (paired && !b->qlen2) return fail(AQC_ERR_ARG, "batch: qlen1 without qlen2");
@@ -726,9 +728,11 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
     const uint64_t max_rounds = 512;                       // 64 MiB of slices at most per launch
     const uint64_t rounds_per_block = (max_rounds + c->n_cu - 1) / c->n_cu;
     const bool fused = cols <= KMER_FUSED_MAX_COLS && rounds_per_block * rpr_max <= (uint64_t)QC_MAX_READS_PER_BLOCK;
-    if (!fused)
+    // (fused: the reads whose quality line has a length of its own — a slot that has any: s->has_irregular — get their per-cycle rows
+    //  from this kernel too, and only those; their k-mers are counted with everybody else's)
+    if (!fused || s->has_irregular)
         hipLaunchKernelGGL(qc_stat_kernel, dim3((unsigned)blocks), dim3(QC_BLOCK), lds, qs, s->view, mate, first, count, post,
-                           (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, s->status, cols);
+                           (const aqc_result*)s->results.p, c->cfg.qc_kmer, q.acc, s->status, cols, fused ? 1 : 0);
     // k-mer dictionary: LDS-resident u16 counters, rounds of <= 65535 k-mers per workgroup, slices reduced afterwards
     {
         uint64_t done = 0;
@@ -898,6 +902,7 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
         // the quality lines' own lengths (frame_records_kernel) and room for the final quality views of the marked records
         // (written by the verdict kernels for those records only: no traffic for a regular chunk)
         const bool any_irr = fo.first_mismatch[0] < n || (paired && fo.first_mismatch[1] < n);
+        s->has_irregular = any_irr;
         for (int k = 0; k < nf; k++)
             if (any_irr && s->qview[k].reserve(sizeof(uint32_t) * (n ? n : 1))) return fail(AQC_ERR_HIP, "hipMalloc failed");
         v.qlen1 = (const uint32_t*)s->t_qual_len[0].p; v.qview1 = (uint32_t*)s->qview[0].p;

@@ -891,8 +891,11 @@ __device__ __forceinline__ uint32_t load4(const uint8_t* p, int x, int len, uint
 }
 
 // the walk's edits that fall into the dword at byte offset x (d is wave-uniform, so the outer tests are scalar)
+// (IRR: the caller may meet reads whose quality view has a length of its own — qc_stat_kernel; the fused k-mer kernel, which runs at
+//  its register limit, leaves such reads' per-cycle statistics to that kernel and only ever needs the bases here)
+template <bool IRR>
 __device__ __forceinline__ void apply_edits(const ReadDesc& d, int x, uint32_t& ws, uint32_t& wq) {
-    if (d.qlen != d.len) {
+    if (IRR && d.qlen != d.len) {
         // a quality view of its own length: the walk indexed it from ITS end (preprocesser.py:566-567) — position + (qlen - len),
         // a negative index wrapped the python way; edits in order, a later one wins (d is wave-uniform: scalar branches)
 #pragma unroll
@@ -953,10 +956,11 @@ struct QcLds {
 // (bytes 4*lane .. 4*lane+3, zero beyond the read), without the walk's edits.
 // Column i lives at word (i & 3) * (cols / 4) + (i >> 2): the four cycles a lane owns are cols/4 words apart and
 // neighbouring lanes hit neighbouring banks (the natural layout would be a 4-way bank conflict on every add).
+template <bool IRR>
 __device__ __forceinline__ void qc_accumulate_read(const ReadDesc& cur, uint32_t ws, uint32_t wq, const QcLds& L, int kmer_len) {
     const int lane = lane_id();
     const int len = cur.len;
-    const int qlen = cur.qlen;               // (the pass-0 dword of qualities was loaded against it)
+    const int qlen = IRR ? cur.qlen : cur.len;               // (the pass-0 dword of qualities was loaded against it)
     const int cols = L.cols, cq = L.cols >> 2;
     unsigned int* const accs = L.accs;
     unsigned int* const gch = L.gch;
@@ -968,10 +972,10 @@ __device__ __forceinline__ void qc_accumulate_read(const ReadDesc& cur, uint32_t
     for (int base0 = 0; base0 < len; base0 += 4 * WAVE) {
         const int x = base0 + 4 * lane;
         if (base0 > 0) { ws = load4(gs, x, len, 0); wq = load4(gq, x, qlen, 0); }
-        apply_edits(cur, x, ws, wq);
+        apply_edits<IRR>(cur, x, ws, wq);
         uint32_t prev = __shfl_up(ws, 1), next = __shfl_down(ws, 1);
-        if (base0 > 0 && lane == 0) { uint32_t dq = 0; prev = load4(gs, x - 4, len, 0); apply_edits(cur, x - 4, prev, dq); }
-        if (base0 + 4 * WAVE < len && lane == WAVE - 1) { uint32_t dq = 0; next = load4(gs, x + 4, len, 0); apply_edits(cur, x + 4, next, dq); }
+        if (base0 > 0 && lane == 0) { uint32_t dq = 0; prev = load4(gs, x - 4, len, 0); apply_edits<false>(cur, x - 4, prev, dq); }
+        if (base0 + 4 * WAVE < len && lane == WAVE - 1) { uint32_t dq = 0; next = load4(gs, x + 4, len, 0); apply_edits<false>(cur, x + 4, next, dq); }
         // bytes x-2 .. x+5 ; byte k of (v ^ v >> 8) is non-zero iff bases x-2+k and x-1+k differ
         const uint32_t vlo = __builtin_amdgcn_alignbit(ws, prev, 16), vhi = __builtin_amdgcn_alignbit(next, ws, 16);
         const uint32_t tlo = nonzero_bytes(vlo ^ __builtin_amdgcn_alignbit(vhi, vlo, 8));
@@ -986,31 +990,32 @@ __device__ __forceinline__ void qc_accumulate_read(const ReadDesc& cur, uint32_t
         // the lane's four cycles at once: accumulator row per base (A T C G = 0..3, anything else 4), quality - 33 per
         // byte, the clamped discontinuity windows patched into the packed fields; then per cycle only two field
         // extractions, one multiply-add for the address and the atomics remain
-        const uint32_t codes = (ws >> 1) & 0x03030303u;
-        const uint32_t bad = __builtin_amdgcn_perm(0u, CODE_TO_BASE, codes) ^ ws;       // 0 where the byte is A/C/G/T
-        const uint32_t nz = nonzero_bytes(bad);                                         // 0x80 per foreign byte
-        uint32_t foreign = nz | (nz - (nz >> 7));                                       // 0xff per foreign byte
-        uint32_t qn4 = wq - 0x21212121u;                                                // (qualities are >= '!' in FASTQ)
-        unsigned int dkeep = 0xfffu;
-        if (qlen < len) {
-            // A quality line shorter than the read (qualitycontrol.py:81-88): totalNum[i] is counted, then qual[i] raises and the
-            // rest of the position is skipped — no quality sum, no base count, no G/C, no discontinuity.  In these accumulators
-            // that is a "foreign" base of quality 0 (row 4 only feeds the total_num / total_qual column sums).
-            const int qin = min(max(qlen - x, 0), 4);
-            const uint32_t qm = qin >= 4 ? 0xffffffffu : ((1u << (8 * qin)) - 1u);
-            foreign |= ~qm;
-            qn4 &= qm;
-            dkeep = qin >= 4 ? 0xfffu : ((1u << (3 * qin)) - 1u);
-        }
-        // code (A0 C1 T2 G3) -> row (A0 T1 C2 G3); foreign -> 4
-        const uint32_t rows4 = (__builtin_amdgcn_perm(0u, 0x03010200u, codes) & ~foreign) | (0x04040404u & foreign);
-        const int nin = min(max(len - x, 0), 4);                                        // cycles of this lane inside the read
         if (base0 == 0 && lane == 0) dpk = (dpk & ~0x3fu) | d_head | (d_head << 3);     // cycles 0, 1: window [0, 5)
         {
             const int over = min(max(x + 3 - (len - 3), 0), 4);                         // cycles beyond len-3: window [len-5, len)
             const unsigned int m = over ? (0xfffu << (3 * (4 - over))) & 0xfffu : 0u;
-            dpk = ((dpk & ~m) | ((d_tail * 0x249u) & m)) & dkeep;
+            dpk = (dpk & ~m) | ((d_tail * 0x249u) & m);
         }
+        if (IRR && qlen < len) {
+            // A quality line shorter than the read (qualitycontrol.py:81-88): totalNum[i] is counted, then qual[i] raises and the
+            // rest of the position is skipped — no quality sum, no base count, no G/C, no discontinuity.  In these accumulators
+            // that is a "foreign" base (byte 0: row 4, which only feeds the total_num / total_qual column sums) of quality '!' = 0
+            // whose discontinuity is dropped; the discontinuities of the cycles before it were formed from the real bases above.
+            // (Edited in place: the kernels that inline this run at their register limit.)
+            const int qin = min(max(qlen - x, 0), 4);
+            const uint32_t qm = qin >= 4 ? 0xffffffffu : ((1u << (8 * qin)) - 1u);
+            ws &= qm;
+            wq = (wq & qm) | (0x21212121u & ~qm);
+            dpk &= qin >= 4 ? 0xfffu : ((1u << (3 * qin)) - 1u);
+        }
+        const uint32_t codes = (ws >> 1) & 0x03030303u;
+        const uint32_t bad = __builtin_amdgcn_perm(0u, CODE_TO_BASE, codes) ^ ws;       // 0 where the byte is A/C/G/T
+        const uint32_t nz = nonzero_bytes(bad);                                         // 0x80 per foreign byte
+        const uint32_t foreign = nz | (nz - (nz >> 7));                                 // 0xff per foreign byte
+        // code (A0 C1 T2 G3) -> row (A0 T1 C2 G3); foreign -> 4
+        const uint32_t rows4 = (__builtin_amdgcn_perm(0u, 0x03010200u, codes) & ~foreign) | (0x04040404u & foreign);
+        const uint32_t qn4 = wq - 0x21212121u;                                          // (qualities are >= '!' in FASTQ)
+        const int nin = min(max(len - x, 0), 4);                                        // cycles of this lane inside the read
         const unsigned int col0 = (unsigned int)lane + (unsigned int)(base0 >> 2);
         // G / C among the lane's cycles inside the read (C = code 1, G = code 3: low code bit), not foreign
         const uint32_t gcm = codes & 0x01010101u & ~foreign & (nin >= 4 ? 0x01010101u : ((1u << (8 * nin)) - 1u));
@@ -1036,7 +1041,9 @@ __device__ __forceinline__ void qc_accumulate_read(const ReadDesc& cur, uint32_t
 __global__ __launch_bounds__(QC_BLOCK) void qc_stat_kernel(DevBatch b, int mate, uint64_t first, uint64_t count, int post,
                                                            const aqc_result* __restrict__ results, int kmer_len,
                                                            unsigned long long* __restrict__ qc /* [QC_ROWS*QC_COLS] */,
-                                                           int* status, int cols) {
+                                                           int* status, int cols, int only_irr) {
+    // (only_irr: the reads whose quality view has a length of its own, and nothing else — the fused k-mer kernel has left exactly
+    //  those reads' per-cycle statistics to this one)
     // dynamic LDS, sized by the longest read of the batch (cols = multiple of 64 <= 1024)
     extern __shared__ __attribute__((aligned(16))) unsigned int qc_smem[];
     unsigned int* const accs = qc_smem;                               // accs[row * cols + i]
@@ -1053,10 +1060,13 @@ __global__ __launch_bounds__(QC_BLOCK) void qc_stat_kernel(DevBatch b, int mate,
         if (threadIdx.x == 0) atomicCAS(status, 0, AQC_ERR_STATE);
         return;
     }
-    auto usable = [&](const ReadDesc& d) { return d.len >= 5 && d.len <= AQC_MAX_READ_LEN && d.len <= cols; };
+    auto usable = [&](const ReadDesc& d) { return d.len >= 5 && d.len <= AQC_MAX_READ_LEN && d.len <= cols && (!only_irr || d.qlen != d.len); };
     for (uint64_t kb = (uint64_t)blockIdx.x * QC_WPB + wave; kb < count; kb += nwaves * WAVE) {
         const uint64_t myk = kb + (uint64_t)lane * nwaves;
-        const ReadDesc mine = lane_desc(b, mate, first + myk, myk < count, post, results);
+        const DevBatch __attribute__((address_space(4)))* kb_args = (const DevBatch __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kb_args));          // (read where it is used, not held across the loop: see kmer_count_kernel)
+        const DevBatch bb = *kb_args;
+        const ReadDesc mine = lane_desc(bb, mate, first + myk, myk < count, post, results);
         const int nr = (int)min((uint64_t)WAVE, (count - kb + nwaves - 1) / nwaves);
         ReadDesc cur = bcast_desc(mine, 0);
         uint32_t pre_s = 0, pre_q = 0;
@@ -1075,9 +1085,10 @@ __global__ __launch_bounds__(QC_BLOCK) void qc_stat_kernel(DevBatch b, int mate,
                 }
             }
             const int len = cur.len;
-            if (len > AQC_MAX_READ_LEN || len > cols) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_READ_TOO_LONG); }
+            if (only_irr) { }                                                                    // (the fused kernel has reported these)
+            else if (len > AQC_MAX_READ_LEN || len > cols) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_READ_TOO_LONG); }
             else if (len < 5 && len > 0) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_ARG); }   // IndexError upstream (:106-107)
-            if (usable(cur)) qc_accumulate_read(cur, ws, wq, QcLds{accs, gch, scal, cols}, kmer_len);
+            if (usable(cur)) qc_accumulate_read<true>(cur, ws, wq, QcLds{accs, gch, scal, cols}, kmer_len);
             cur = nxt;
         }
     }
@@ -1182,7 +1193,8 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
     const uint32_t imask = (1u << (2 * kmer_len)) - 1u, kbits = (1u << kmer_len) - 1u;
     unsigned long long* const my_first = kt.dense_first + (size_t)xcc_id() * DENSE_ENTRIES;
     auto usable = [&](const ReadDesc& d) { return d.len >= 5 && d.len <= AQC_MAX_READ_LEN && d.len > kmer_len; };
-    auto qc_usable = [&](const ReadDesc& d) { return fused && d.len >= 5 && d.len <= AQC_MAX_READ_LEN && d.len <= cols; };
+    // (a read whose quality view has a length of its own is left to qc_stat_kernel's only_irr pass: its per-cycle statistics, not its k-mers)
+    auto qc_usable = [&](const ReadDesc& d) { return fused && d.len >= 5 && d.len <= AQC_MAX_READ_LEN && d.len <= cols && d.qlen == d.len; };
     KPROF_DECL
     // every dense k-mer already has a first-seen time from an earlier launch: nothing this launch sees can be earlier
     const bool complete = __syncthreads_and(threadIdx.x < (int)(DENSE_ENTRIES / KRED_ENTRIES) ? (int)kt.complete[threadIdx.x] : 1) != 0;
@@ -1196,7 +1208,12 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
         const uint64_t r_hi = min(r_lo + reads_per_round, count);
         for (uint64_t kb = r_lo + wave; kb < r_hi; kb += (uint64_t)KMER_WPB * WAVE) {
             const uint64_t myk = kb + (uint64_t)lane * KMER_WPB;
-            const ReadDesc mine = lane_desc(b, mate, first + myk, myk < r_hi, post, results);
+            // (the batch descriptor — twenty pointers — is read from the kernarg segment where it is used, once per 64 reads: held in
+            //  scalar registers across the loop it was most of this kernel's SGPR spills)
+            const DevBatch __attribute__((address_space(4)))* kb_args = (const DevBatch __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kb_args));
+            const DevBatch bb = *kb_args;
+            const ReadDesc mine = lane_desc(bb, mate, first + myk, myk < r_hi, post, results);
             const int nr = (int)min((uint64_t)WAVE, (r_hi - kb + KMER_WPB - 1) / KMER_WPB);
             ReadDesc cur = bcast_desc(mine, 0);
             uint32_t pre = PAD, pre_q = 0;
@@ -1222,7 +1239,7 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
                     else if (len < 5 && len > 0) { if (lane == 0) atomicCAS(status, 0, AQC_ERR_ARG); }   // IndexError upstream (:106-107)
                     if (qc_usable(cur)) {
                         // (the bases beyond the read are 'A' here, 0 in qc_stat_kernel: neither is ever looked at)
-                        qc_accumulate_read(cur, ws, wq0, qlds, kmer_len);
+                        qc_accumulate_read<false>(cur, ws, wq0, qlds, kmer_len);
                     }
                 }
                 if (usable(cur)) {
@@ -1234,7 +1251,7 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
                         const int x = base0 + 4 * lane;
                         if (base0 > 0) ws = load4(reinterpret_cast<const uint8_t*>(cur.s), x, len, PAD);
                         uint32_t dq = 0;
-                        apply_edits(cur, x, ws, dq);
+                        apply_edits<false>(cur, x, ws, dq);                                           // (only the bases matter here)
                         const uint32_t codes = (ws >> 1) & 0x03030303u;
                         const uint32_t bad = __builtin_amdgcn_perm(0u, CODE_TO_BASE, codes) ^ ws;    // 0 where the byte is A/C/G/T
                         const uint32_t c8 = (codes | (codes >> 6) | (codes >> 12) | (codes >> 18)) & 0xffu;

@@ -1433,9 +1433,25 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
     R.res = res;
     R.nf = (io->in_path[1] || io->in_mem[1]) ? 2 : 1;
     R.K = opt->chunk_records ? opt->chunk_records : (1u << 17);
+    {
+        // AQC_SPANS=1, plain-text outputs: the good records that go out as their own bytes never leave the host (aqc_format_spans):
+        // no copy on the device (the device step of 10 M reads 4.7 -> 3.2 ms, 17.6 -> 10.5 GB of HBM traffic), no download
+        // (pinned -> pinned 100 -> 159 Mreads/s) — and the good files are written with writev from the input buffers, a piece per run
+        // of such records.  OFF by default, because of what that costs on the hosts measured so far: a run of whole records is
+        // ~3 - 4 KB in the bench workload (one record in ten is bad, trimmed or corrected), an iovec costs the kernel ~60 ns
+        // (tools/ubench/writev_rate.cpp: 9.2 - 9.9 GB/s against write()'s 11 - 12), and a one-input run is bound by exactly
+        // those two file writers: file -> file 0.18 -> 0.23 s (profiles/r05_spans_ab.txt).  It pays where PCIe is the bound.
+        // (.gz output needs the whole text on the device, where its members are built.)
+        const char* e = getenv("AQC_SPANS");
+        R.spans_on = !io->gzip_out && !opt->no_output && e && e[0] == '1';
+    }
     for (int f = 0; f < R.nf; ++f) {
         R.inq[f].reset(new BQueue<InChunk>(2));
-        R.ring_free[f].assign(P->in_buf[f].size(), 1);
+        // (the whole ring only when chunks keep their input buffers until they are written — spans mode; else one buffer per slot + two:
+        //  every buffer used is a buffer page-locked, which a one-shot run pays for)
+        const size_t use = R.spans_on ? P->in_buf[f].size() : std::min(P->in_buf[f].size(), (size_t)(P->n_ctx * P->slots + 2));
+        R.ring_free[f].assign(P->in_buf[f].size(), 0);
+        for (size_t i = 0; i < use; ++i) R.ring_free[f][i] = 1;
     }
     for (int i = 0; i < P->n_ctx; ++i) R.jobq.emplace_back(new BQueue<Run::Job>((size_t)P->slots));
     R.set_free.assign(P->wbufs.size() * 2, 1);
@@ -1471,18 +1487,6 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
     {
         const char* e = getenv("AQC_GZ_DEVICE");
         R.gz_on_device = io->gzip_out && io->gzip_level >= 1 && !opt->no_output && !(e && e[0] == '0');
-    }
-    {
-        // AQC_SPANS=1, plain-text outputs: the good records that go out as their own bytes never leave the host (aqc_format_spans):
-        // no copy on the device (the device step of 10 M reads 4.7 -> 3.2 ms, 17.6 -> 10.5 GB of HBM traffic), no download
-        // (pinned -> pinned 100 -> 159 Mreads/s) — and the good files are written with writev from the input buffers, a piece per run
-        // of such records.  OFF by default, because of what that costs on the hosts measured so far: a run of whole records is
-        // ~3 - 4 KB in the bench workload (one record in ten is bad, trimmed or corrected), an iovec costs the kernel ~60 ns
-        // (tools/ubench/writev_rate.cpp: 9.2 - 9.9 GB/s against write()'s 11 - 12), and a one-input run is bound by exactly
-        // those two file writers: file -> file 0.18 -> 0.23 s (profiles/r05_spans_ab.txt).  It pays where PCIe is the bound.
-        // (.gz output needs the whole text on the device, where its members are built.)
-        const char* e = getenv("AQC_SPANS");
-        R.spans_on = !io->gzip_out && !opt->no_output && e && e[0] == '1';
     }
     const bool dbg = getenv("AQC_PIPE_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "pipe: outputs open at %.4f s\n", now_s() - t0);
