@@ -1063,9 +1063,13 @@ __global__ __launch_bounds__(QC_BLOCK) void qc_stat_kernel(DevBatch b, int mate,
     auto usable = [&](const ReadDesc& d) { return d.len >= 5 && d.len <= AQC_MAX_READ_LEN && d.len <= cols && (!only_irr || d.qlen != d.len); };
     for (uint64_t kb = (uint64_t)blockIdx.x * QC_WPB + wave; kb < count; kb += nwaves * WAVE) {
         const uint64_t myk = kb + (uint64_t)lane * nwaves;
+#if defined(__HIP_DEVICE_COMPILE__)
         const DevBatch __attribute__((address_space(4)))* kb_args = (const DevBatch __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kb_args));          // (read where it is used, not held across the loop: see kmer_count_kernel)
-        const DevBatch bb = *kb_args;
+        const DevBatch bb = *kb_args;              // (the batch descriptor is the kernel's first argument)
+#else
+        const DevBatch bb = b;
+#endif
         const ReadDesc mine = lane_desc(bb, mate, first + myk, myk < count, post, results);
         const int nr = (int)min((uint64_t)WAVE, (count - kb + nwaves - 1) / nwaves);
         ReadDesc cur = bcast_desc(mine, 0);
@@ -1210,9 +1214,13 @@ __global__ __launch_bounds__(KMER_BLOCK) void kmer_count_kernel(DevBatch b, int 
             const uint64_t myk = kb + (uint64_t)lane * KMER_WPB;
             // (the batch descriptor — twenty pointers — is read from the kernarg segment where it is used, once per 64 reads: held in
             //  scalar registers across the loop it was most of this kernel's SGPR spills)
+#if defined(__HIP_DEVICE_COMPILE__)
             const DevBatch __attribute__((address_space(4)))* kb_args = (const DevBatch __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kb_args));
-            const DevBatch bb = *kb_args;
+            const DevBatch bb = *kb_args;              // (the batch descriptor is the kernel's first argument)
+#else
+            const DevBatch bb = b;
+#endif
             const ReadDesc mine = lane_desc(bb, mate, first + myk, myk < r_hi, post, results);
             const int nr = (int)min((uint64_t)WAVE, (r_hi - kb + KMER_WPB - 1) / KMER_WPB);
             ReadDesc cur = bcast_desc(mine, 0);
