@@ -381,7 +381,7 @@ __global__ __launch_bounds__(TXT_BLOCK) void frame_records_kernel(const uint8_t*
         // a quality line of another length than its sequence line: the reference does not mind (fastq.py:37-49 hands the lines
         // over as they are) — the record is marked, every later stage keeps a view per string (aqc_kernels.hpp, LEN_IRR)
         out.seq_off[r] = s[1];  out.seq_len[r] = l[1] | (l[1] != l[3] ? LEN_IRR : 0u);
-        out.plus_off[r] = s[2]; out.plus_len[r] = l[2];
+        out.plus_off[r] = s[2]; out.plus_len[r] = l[2] | (l[1] != l[3] ? LEN_IRR : 0u);      // (the mark once more, where the writer's sizing pass reads anyway)
         out.qual_off[r] = s[3]; out.qual_len[r] = min(l[3], QLEN_MASK) | tail_nl | (all_nl ? QLEN_CONTIG : 0u);
     }
     // chunk-wide reductions: at most one atomic per workgroup and only when it has something to say.  (Same-address
@@ -536,7 +536,7 @@ struct TextFile {
     const uint8_t* text;
     const uint32_t *seq_off, *qual_off;
     const uint32_t *seq_len;      // bit 31 (LEN_IRR): the quality line has a length of its own -> qual_len / qview
-    const uint32_t *name_off, *name_len, *plus_off, *plus_len;
+    const uint32_t *name_off, *name_len, *plus_off, *plus_len;      // plus_len: bit 31 = LEN_IRR again
     const uint32_t *qual_len;     // bit 31: the quality line's '\n' follows it directly (frame_records_kernel)
     const uint32_t *qview;        // final quality view (start | length << 16) of the records marked LEN_IRR, left by the verdict kernels
 };
@@ -646,7 +646,9 @@ __device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int f
         if (whole && !v.store_overlap) { sz[0] = sz[1] = sz[2] = 0u; return; }
     }
     uint32_t len = file == 0 ? (w0.y & 0xffffu) : (w0.z & 0xffffu);
-    const uint32_t slw = t.seq_len[r];
+    const uint32_t plw = t.plus_len[r];
+    // (the sequence line's own length only where it is needed: index records, the barcode move, a quality line of another length)
+    const uint32_t slw = (v.plain || v.barcode || (plw & LEN_IRR)) ? t.seq_len[r] : 0u;
     if (v.plain) len = slw & LEN_MASK;                      // index records go out whole
     uint32_t nlen = t.name_len[r];
     if (v.barcode && !v.plain) {
@@ -661,7 +663,7 @@ __device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int f
             nlen = 1u + (uint32_t)b + (nlen - cpos);
         }
     }
-    const uint32_t body = nlen + t.plus_len[r] + 4u;
+    const uint32_t body = nlen + (plw & LEN_MASK) + 4u;
     uint32_t qlen = len;                                    // the quality line written beside `len` bases
     if (slw & LEN_IRR) {
         int qs_, ql_;
@@ -802,7 +804,7 @@ __device__ inline void fmt_build(const FormatView& v, uint64_t r, int file, int 
     const TextFile& tf = v.f[file];
     const uint32_t name_off = tf.name_off[r], seq_off = tf.seq_off[r], plus_off = tf.plus_off[r], qual_off = tf.qual_off[r];
     const uint32_t slw = tf.seq_len[r];
-    const int nlen = (int)tf.name_len[r], plen = (int)tf.plus_len[r], slen = (int)(slw & LEN_MASK);
+    const int nlen = (int)tf.name_len[r], plen = (int)(tf.plus_len[r] & LEN_MASK), slen = (int)(slw & LEN_MASK);
     // the slice of the original read that is written: the final read, or its last overlap_len bases (getOverlap)
     const int cut = v.plain ? 0 : (overlap_pass ? (file == 0 ? len1 : len2) - ovl : 0);
     const int st = v.plain ? 0 : (file == 0 ? (int)(w0.x >> 16) : (int)(w0.y >> 16)) + cut;
