@@ -1435,7 +1435,7 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
     R.K = opt->chunk_records ? opt->chunk_records : (1u << 17);
     {
         // AQC_SPANS=1, plain-text outputs: the good records that go out as their own bytes never leave the host (aqc_format_spans):
-        // no copy on the device (the device step of 10 M reads 4.7 -> 3.2 ms, 17.6 -> 10.5 GB of HBM traffic), no download
+        // no copy on the device (the device step of 10 M reads 4.7 -> 3.2 ms, 17.6 -> 10.8 GB of HBM traffic), no download
         // (pinned -> pinned 100 -> 159 Mreads/s) — and the good files are written with writev from the input buffers, a piece per run
         // of such records.  OFF by default, because of what that costs on the hosts measured so far: a run of whole records is
         // ~3 - 4 KB in the bench workload (one record in ten is bad, trimmed or corrected), an iovec costs the kernel ~60 ns
