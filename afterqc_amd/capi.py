@@ -346,6 +346,7 @@ def load_library():
     lib.aqc_format_spans.argtypes = [P, C.c_int, C.c_uint64, C.c_int32, P, P]
     lib.aqc_fetch_span_events.argtypes = [P, C.c_int, C.c_int, P, C.c_uint64]
     lib.aqc_span_end.argtypes = [P, C.c_int, C.c_uint64, P]
+    lib.aqc_format_fused.argtypes = [P, C.c_int]
     lib.aqc_fetch_quality_views.argtypes = [P, C.c_int, C.c_int, P, C.c_uint64]
     lib.aqc_error_record.argtypes = [P, C.c_int, C.POINTER(C.c_uint64)]
     lib.aqc_sync.argtypes = [P, C.c_int]
@@ -413,7 +414,7 @@ def load_library():
                  "aqc_run", "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_timing_reset",
                  "aqc_timing_mean", "aqc_get_counters", "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers",
                  "aqc_overlap", "aqc_read_stats", "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain",
-                 "aqc_fetch_text", "aqc_fetch_quality_views", "aqc_error_record", "aqc_format_spans", "aqc_fetch_span_events", "aqc_span_end"):
+                 "aqc_fetch_text", "aqc_fetch_quality_views", "aqc_error_record", "aqc_format_spans", "aqc_fetch_span_events", "aqc_span_end", "aqc_format_fused"):
         getattr(lib, name).restype = C.c_int
     if lib.aqc_abi_version() != 2:
         raise RuntimeError("libafterqc_hip.so ABI version mismatch")
@@ -426,7 +427,7 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_device_index", "
                     "aqc_qc_stat", "aqc_fetch_results", "aqc_fetch_quality_views", "aqc_error_record", "aqc_sync", "aqc_last_deferred", "aqc_kernel_ms", "aqc_timing_reset",
                     "aqc_timing_mean", "aqc_get_counters",
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
-                    "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_spans", "aqc_fetch_span_events", "aqc_span_end", "aqc_format_plain", "aqc_fetch_text", "aqc_fetch_streams", "aqc_compress", "aqc_fetch_gz", "aqc_gunzip_dev", "aqc_host_alloc",
+                    "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_spans", "aqc_fetch_span_events", "aqc_span_end", "aqc_format_fused", "aqc_format_plain", "aqc_fetch_text", "aqc_fetch_streams", "aqc_compress", "aqc_fetch_gz", "aqc_gunzip_dev", "aqc_host_alloc",
                     "aqc_host_free",
                     "aqc_pipe_create", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
                     "aqc_host_count_newlines", "aqc_bgzf_compress", "aqc_pipe_split",
@@ -606,6 +607,13 @@ class Engine:
         ev = np.zeros(max(n_events, 1), dtype=SPAN_EVENT_DTYPE)
         self._check(self.lib.aqc_fetch_span_events(self.h, slot, file, _ptr(ev), n_events))
         return ev[:n_events]
+
+    def format_fused(self, slot):
+        """did the slot's last format() take the placement the verdict kernel made (AQC_FUSED=1)?"""
+        rc = self.lib.aqc_format_fused(self.h, slot)
+        if rc < 0:
+            self._check(rc)
+        return rc == 1
 
     def span_end(self, slot, n):
         end = (C.c_uint64 * 2)()

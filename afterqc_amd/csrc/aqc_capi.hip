@@ -86,7 +86,11 @@ struct Slot {
     // text in / text out (aqc_frame, aqc_format): per file the line table and the name / strand-line descriptors
     DevBuf t_line_end[2], t_tile[2], t_name_off[2], t_name_len[2], t_plus_off[2], t_plus_len[2], t_qual_len[2];
     DevBuf t_scratch;              // FrameMeta[2] + scan totals
-    DevBuf f_pos, f_tile, f_plan, f_over, f_out[6], f_events[2];
+    DevBuf f_pos, f_tile, f_plan, f_patch, f_over, f_out[6], f_events[2];
+    // AQC_FUSED=1: the verdict kernel placed the slot's records in their streams and copied the whole good ones (aqc_fast.hpp, FUSE)
+    DevBuf fz_state, fz_rec[2], fz_misc;      // look-back words per batch; position words per record; ticket | abort | totals[4]
+    bool fused = false;                       // ... for the records the slot holds now (aqc_format checks fz_misc's abort word)
+    bool formatted_fused = false;             // the last aqc_format took that placement (aqc_format_fused)
     uint64_t n_events[2] = {0, 0};    // aqc_format_spans: events per file
     uint64_t consumed[2] = {0, 0};    // bytes of each file's chunk that the framed records take
     uint64_t f_bytes[6] = {0, 0, 0, 0, 0, 0};
@@ -170,6 +174,7 @@ struct QcDev {
 
 struct aqc_ctx {
     bool force_generic = false;
+    bool fuse_opt = false;        // AQC_FUSED=1: 2 x <=160 pairs framed on the device take the verdict kernel that also places and copies
     bool qc_inline = false;       // AQC_QC_STREAM=0: statRead kernels on the slot's stream instead of the context's QC stream
     int device = 0;
     int n_slots = 0;
@@ -222,12 +227,15 @@ static int check_status(Slot& sl) {
     return 0;
 }
 
-template <int NW, bool PAIRED, int WPBT, bool BARCODE>
-static void launch_fast(aqc_ctx* c, Slot* s, const aqc_config& cfg, const DevStats& st, uint64_t accum_limit) {
-    constexpr uint64_t per_block = (uint64_t)WPBT * FastWaveLds<NW, PAIRED>::PPW;
+#ifndef AQC_FUSE_WPBT
+#define AQC_FUSE_WPBT 12
+#endif
+template <int NW, bool PAIRED, int WPBT, bool BARCODE, bool FUSE = false>
+static void launch_fast(aqc_ctx* c, Slot* s, const aqc_config& cfg, const DevStats& st, uint64_t accum_limit, const FuseArgs* fz = nullptr) {
+    constexpr uint64_t per_block = (uint64_t)WPBT * FastWaveLds<NW, PAIRED, FUSE>::PPW;
     uint64_t blocks = (s->n + per_block - 1) / per_block;
     // persistent grid: as many workgroups as the LDS footprint lets a CU hold; batches are grid-strided
-    const size_t lds = sizeof(FastWaveLds<NW, PAIRED>) * WPBT + sizeof(BlockAcc) + 64 + 17 * 16;
+    const size_t lds = sizeof(FastWaveLds<NW, PAIRED, FUSE>) * WPBT + sizeof(BlockAcc) + 64 + 17 * 16 + (FUSE ? 16 * 8 : 0);
     uint64_t per_cu = (160 * 1024) / lds;
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
@@ -239,7 +247,8 @@ static void launch_fast(aqc_ctx* c, Slot* s, const aqc_config& cfg, const DevSta
     FastArgs K;
     K.fb = s->view; K.cfg = cfg; K.circ = c->circles; K.results = (aqc_result*)s->results.p; K.st = st; K.accum_limit = accum_limit;
     K.deferred = (uint32_t*)s->deferred.p; K.n_deferred = (unsigned int*)s->n_deferred.p;
-    hipLaunchKernelGGL((fast_filter_overlap_kernel<NW, PAIRED, WPBT, BARCODE>), dim3((unsigned)blocks), dim3(WPBT * WAVE), 0, s->stream, K);
+    K.fz = fz ? *fz : FuseArgs{};
+    hipLaunchKernelGGL((fast_filter_overlap_kernel<NW, PAIRED, WPBT, BARCODE, FUSE>), dim3((unsigned)blocks), dim3(WPBT * WAVE), 0, s->stream, K);
 }
 
 extern "C" {
@@ -277,6 +286,8 @@ int aqc_create(int device, int n_slots, aqc_ctx** out) {
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const char* fg = getenv("AQC_FORCE_GENERIC");
     c->force_generic = fg && fg[0] == '1';
+    const char* fu = getenv("AQC_FUSED");
+    c->fuse_opt = fu && fu[0] == '1';
     const char* qi = getenv("AQC_QC_STREAM");
     c->qc_inline = qi && qi[0] == '0';
     HIP_TRY(hipFuncSetAttribute((const void*)kmer_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)KMER_FUSED_LDS_BYTES));
@@ -311,7 +322,7 @@ void aqc_destroy(aqc_ctx* c) {
                           &s.deferred, &s.n_deferred, &s.off_stage, &s.qlen[0], &s.qlen[1], &s.qview[0], &s.qview[1],
                           &s.t_line_end[0], &s.t_line_end[1], &s.t_tile[0], &s.t_tile[1], &s.t_name_off[0], &s.t_name_off[1],
                           &s.t_name_len[0], &s.t_name_len[1], &s.t_plus_off[0], &s.t_plus_off[1], &s.t_plus_len[0], &s.t_plus_len[1],
-                          &s.t_qual_len[0], &s.t_qual_len[1], &s.t_scratch, &s.f_pos, &s.f_tile, &s.f_plan, &s.f_over, &s.f_events[0], &s.f_events[1], &s.f_out[0], &s.f_out[1], &s.f_out[2],
+                          &s.t_qual_len[0], &s.t_qual_len[1], &s.t_scratch, &s.f_pos, &s.f_tile, &s.f_plan, &s.f_patch, &s.fz_state, &s.fz_rec[0], &s.fz_rec[1], &s.fz_misc, &s.f_over, &s.f_events[0], &s.f_events[1], &s.f_out[0], &s.f_out[1], &s.f_out[2],
                           &s.f_out[3], &s.f_out[4], &s.f_out[5], &s.g_stage, &s.g_sizes, &s.g_offsets, &s.g_total, &s.g_hist, &s.g_code,
                           &s.g_packed[0], &s.g_packed[1], &s.g_packed[2], &s.g_packed[3], &s.g_packed[4], &s.g_packed[5]};
         for (DevBuf* b : bufs) b->release();
@@ -613,6 +624,7 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
     if (!c->has_cfg) return fail(AQC_ERR_STATE, "aqc_run before aqc_set_config");
     if (c->cfg.paired && !s->paired) return fail(AQC_ERR_STATE, "config says paired but the slot holds single-end records");
     if (c->cfg.debubble && c->circles.n > 0 && !s->view.aux_ok) return fail(AQC_ERR_ARG, "debubble needs the aux_* arrays");
+    s->fused = false;
     if (s->n == 0) { s->ran = true; return 0; }
     aqc_config cfg = c->cfg;
     if (!cfg.paired) cfg.no_overlap = 1;
@@ -640,7 +652,27 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
     } else {
         if (s->deferred.reserve(sizeof(uint32_t) * (s->n + 1)) || s->n_deferred.reserve(sizeof(unsigned int)))
             return fail(AQC_ERR_HIP, "hipMalloc failed");
-        if (s->max_len <= 160) {
+        // AQC_FUSED=1: pairs of device-framed text whose records are plain four-line text are placed in their output
+        // streams by the verdict kernel itself, which also copies the good records that go out as their own bytes
+        const bool fuse_ok = c->fuse_opt && s->framed && cfg.paired && !cfg.barcode && s->max_len <= 160 && cfg.unqualified_base_limit > 0 &&
+                             !s->has_irregular && s->consumed[0] + 16 * s->n < (1ull << 31) && s->consumed[1] + 16 * s->n < (1ull << 31);      // (31-bit stream offsets; a bad record grows by its flag text)
+        if (fuse_ok) {
+            constexpr uint64_t PPW = FastWaveLds<10, true, true>::PPW;
+            const uint64_t n_batches = (s->n + PPW - 1) / PPW;
+            if (s->fz_state.reserve(16 * n_batches) || s->fz_rec[0].reserve(4 * s->n) || s->fz_rec[1].reserve(4 * s->n) || s->fz_misc.reserve(64) ||
+                s->f_out[0].reserve(s->consumed[0] + 64) || s->f_out[3].reserve(s->consumed[1] + 64))
+                return fail(AQC_ERR_HIP, "hipMalloc failed");
+            HIP_TRY(hipMemsetAsync(s->fz_state.p, 0, 16 * n_batches, s->stream));
+            HIP_TRY(hipMemsetAsync(s->fz_misc.p, 0, 64, s->stream));
+            FuseArgs fz{};
+            fz.name_off1 = (const uint32_t*)s->t_name_off[0].p; fz.name_off2 = (const uint32_t*)s->t_name_off[1].p;
+            fz.out1 = (uint8_t*)s->f_out[0].p; fz.out2 = (uint8_t*)s->f_out[3].p;
+            fz.fstate1 = (uint32_t*)s->fz_rec[0].p; fz.fstate2 = (uint32_t*)s->fz_rec[1].p;
+            fz.state = (unsigned long long*)s->fz_state.p;
+            fz.ticket = (unsigned int*)s->fz_misc.p; fz.abort = (int*)s->fz_misc.p + 1; fz.totals = (unsigned long long*)s->fz_misc.p + 1;
+            launch_fast<10, true, AQC_FUSE_WPBT, false, true>(c, s, cfg, st, accum_limit, &fz);
+            s->fused = true;
+        } else if (s->max_len <= 160) {
             if (cfg.paired) { if (cfg.barcode) launch_fast<10, true, 16, true>(c, s, cfg, st, accum_limit); else launch_fast<10, true, 16, false>(c, s, cfg, st, accum_limit); }
             else { if (cfg.barcode) launch_fast<10, false, 12, true>(c, s, cfg, st, accum_limit); else launch_fast<10, false, 12, false>(c, s, cfg, st, accum_limit); }
         } else if (s->max_len <= 256) {
@@ -782,6 +814,7 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
     HIP_TRY(slot_sync(*s));
     s->framed = s->formatted = false;
     s->ran = false;
+    s->fused = false;
     DevBuf* arena[2] = {&s->seq1, &s->seq2};
     DevBuf* seq_off[2] = {&s->off1, &s->off2};
     DevBuf* qual_off[2] = {&s->qoff1, &s->qoff2};
@@ -983,18 +1016,36 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
     // streams q = file * 3 + {0 good, 1 bad, 2 overlap}: per-tile byte sums -> tile bases (one launch each), the
     // per-record offsets are formed inside the writer
     const uint64_t n_tiles = n ? (n + FMT_TILE - 1) / FMT_TILE : 1;
-    if (s->f_tile.reserve(sizeof(unsigned long long) * FMT_STREAMS * n_tiles) || s->t_scratch.reserve(256))
-        return fail(AQC_ERR_HIP, "hipMalloc failed");
-    unsigned long long* d_tot = (unsigned long long*)((uint8_t*)s->t_scratch.p + 128);
-    HIP_TRY(hipMemsetAsync(s->f_tile.p, 0, sizeof(unsigned long long) * FMT_STREAMS * n_tiles, s->stream));
-    if (n) hipLaunchKernelGGL(fmt_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles, (unsigned long long*)s->f_tile.p);
-    hipLaunchKernelGGL(fmt_tile_bases_kernel, dim3(v.spans ? FMT_STREAMS : 6), dim3(TXT_BLOCK), 0, s->stream, (unsigned long long*)s->f_tile.p, n_tiles, d_tot);
-    HIP_TRY(hipGetLastError());
     bool live[6];
     for (int q = 0; q < 6; q++) live[q] = (q < 3 || s->paired) && (q % 3 != 2 || v.store_overlap);
     unsigned long long h_tot[FMT_STREAMS] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long) * (v.spans ? FMT_STREAMS : 6), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    // the verdict kernel may have done the placement already (AQC_FUSED=1, all n records of the slot, the two-stream case): its totals
+    // stand in for the sums / bases passes — unless it gave the placement up (a deferred pair, a record that is not plain text)
+    if (s->fused && !plain && !spans && !v.store_overlap && n == s->n && n > 0) {
+        unsigned long long misc[5];
+        HIP_TRY(hipMemcpyAsync(misc, s->fz_misc.p, sizeof(misc), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if ((misc[0] >> 32) == 0) {
+            v.fused = 1;
+            v.fstate[0] = (const uint32_t*)s->fz_rec[0].p; v.fstate[1] = (const uint32_t*)s->fz_rec[1].p;
+            v.fbatch = (const unsigned long long*)s->fz_state.p;
+            v.fbatch_shift = 5;
+            static_assert(FastWaveLds<10, true, true>::PPW == 32, "fbatch_shift");
+            h_tot[0] = misc[1]; h_tot[3] = misc[2]; h_tot[1] = misc[3]; h_tot[4] = misc[4];
+        }
+    }
+    if (!v.fused) {
+        s->fused = false;          // (whatever this call writes into the good streams replaces what the verdict kernel left there)
+        if (s->f_tile.reserve(sizeof(unsigned long long) * FMT_STREAMS * n_tiles) || s->t_scratch.reserve(256))
+            return fail(AQC_ERR_HIP, "hipMalloc failed");
+        unsigned long long* d_tot = (unsigned long long*)((uint8_t*)s->t_scratch.p + 128);
+        HIP_TRY(hipMemsetAsync(s->f_tile.p, 0, sizeof(unsigned long long) * FMT_STREAMS * n_tiles, s->stream));
+        if (n) hipLaunchKernelGGL(fmt_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles, (unsigned long long*)s->f_tile.p);
+        hipLaunchKernelGGL(fmt_tile_bases_kernel, dim3(v.spans ? FMT_STREAMS : 6), dim3(TXT_BLOCK), 0, s->stream, (unsigned long long*)s->f_tile.p, n_tiles, d_tot);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long) * (v.spans ? FMT_STREAMS : 6), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
     if (v.spans) {
         for (int f = 0; f < (s->paired ? 2 : 1); ++f) {
             s->n_events[f] = h_tot[FMT_EVENT_STREAM + f];
@@ -1015,23 +1066,32 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
         const uint64_t gen_cap = ((n_tiles + GEN_LISTS - 1) / GEN_LISTS) * FMT_TILE * (s->paired ? 2 : 1);     // worst case: every record
         // plans: one 16-byte word per (record, file), dense; the six words of the records the general kernel takes, in list order
         const uint64_t plan0_bytes = (16 * n_tasks + 255) / 256 * 256;
-        if (s->f_plan.reserve(plan0_bytes + 16 * PLAN_Q * gen_cap * GEN_LISTS) || s->f_over.reserve(sizeof(FmtTask) * n_tasks) ||
-            s->f_pos.reserve(4 * gen_cap * GEN_LISTS + sizeof(unsigned int) * GEN_LISTS + 64))
+        if (s->f_plan.reserve(plan0_bytes + 16 * PLAN_Q * gen_cap * GEN_LISTS) || s->f_patch.reserve(16 * n_tasks + 32 * gen_cap * GEN_LISTS) || s->f_over.reserve(sizeof(FmtTask) * n_tasks) ||
+            s->f_pos.reserve(4 * gen_cap * GEN_LISTS + 2 * sizeof(unsigned int) * GEN_LISTS + 64))
             return fail(AQC_ERR_HIP, "hipMalloc failed");
+        // f_pos: the general kernel's lists | the lengths of those and of the lists of one-piece plans of a spans / fused format;
+        // f_patch: the patch words of the dense plan0 | those listed plans (two words each, in list order)
+        uint4* d_wplan = (uint4*)((uint8_t*)s->f_patch.p + 16 * n_tasks);
         unsigned int* d_ngen = (unsigned int*)((uint8_t*)s->f_pos.p + 4 * gen_cap * GEN_LISTS);
+        unsigned int* d_nwhole = d_ngen + GEN_LISTS;
+        const bool sparse = v.spans || v.fused;
         const unsigned copy_blocks = (unsigned)((n_tasks + (COPY_BLOCK / 32) * FMT_UNROLL - 1) / ((COPY_BLOCK / 32) * FMT_UNROLL));
         for (int pass = 0; pass < (v.store_overlap ? 2 : 1); ++pass) {
-            HIP_TRY(hipMemsetAsync(d_ngen, 0, sizeof(unsigned int) * GEN_LISTS, s->stream));
+            HIP_TRY(hipMemsetAsync(d_ngen, 0, 2 * sizeof(unsigned int) * GEN_LISTS, s->stream));
             hipLaunchKernelGGL(fmt_plan_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles,
-                               (const unsigned long long*)s->f_tile.p, pass, s->status, (uint4*)s->f_plan.p,
-                               (uint4*)((uint8_t*)s->f_plan.p + plan0_bytes), (FmtTask*)s->f_over.p, (uint32_t*)s->f_pos.p, d_ngen, gen_cap,
+                               (const unsigned long long*)s->f_tile.p, pass, s->status, (uint4*)s->f_plan.p, (uint4*)s->f_patch.p,
+                               (uint4*)((uint8_t*)s->f_plan.p + plan0_bytes), (FmtTask*)s->f_over.p, (uint32_t*)s->f_pos.p, d_ngen, gen_cap, d_wplan, d_nwhole, outs,
                                (SpanEvent*)s->f_events[0].p, (SpanEvent*)s->f_events[1].p);
-            // (spans mode: the records this kernel would copy stay where they are, in the caller's chunk)
-            if (!v.spans) hipLaunchKernelGGL(fmt_copy_whole_kernel, dim3(copy_blocks), dim3(COPY_BLOCK), 0, s->stream, v, n_tasks, (const uint4*)s->f_plan.p, outs);
+            // (spans / fused mode: what stays in the caller's chunk / what the verdict kernel copied has no plan; the records that are their
+            //  own bytes but for the walk's byte patches are still this kernel's)
             // GEN_LISTS x k workgroups; k from the worst case, at most 32 per list
             uint64_t per_list = (gen_cap + GEN_ROUND - 1) / GEN_ROUND;
             if (per_list > 32) per_list = 32;
             if (per_list < 1) per_list = 1;
+            if (!sparse) hipLaunchKernelGGL(fmt_copy_whole_kernel, dim3(copy_blocks), dim3(COPY_BLOCK), 0, s->stream, v, n_tasks, (const uint4*)s->f_plan.p,
+                                            (const uint4*)s->f_patch.p, outs);
+            else hipLaunchKernelGGL(fmt_copy_whole_list_kernel, dim3((unsigned)(GEN_LISTS * per_list)), dim3(COPY_BLOCK), 0, s->stream, v, (const uint4*)d_wplan, outs,
+                                    (const unsigned int*)d_nwhole, gen_cap);
             hipLaunchKernelGGL(fmt_copy_kernel, dim3((unsigned)(GEN_LISTS * per_list)), dim3(COPY_BLOCK), 0, s->stream, v,
                                (const uint4*)((uint8_t*)s->f_plan.p + plan0_bytes), (const FmtTask*)s->f_over.p, outs, (const uint32_t*)s->f_pos.p,
                                (const unsigned int*)d_ngen, gen_cap);
@@ -1039,6 +1099,7 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
         HIP_TRY(hipGetLastError());
     }
     s->formatted = true;
+    s->formatted_fused = v.fused != 0;
     s->compressed = false;
     return 0;
 }
@@ -1525,6 +1586,14 @@ int aqc_format_spans(aqc_ctx* c, int slot, uint64_t n, int32_t store_overlap, ui
     n_events[0] = c->slots[slot].n_events[0];
     n_events[1] = c->slots[slot].n_events[1];
     return 0;
+}
+
+int aqc_format_fused(aqc_ctx* c, int slot) {
+    Slot* s;
+    int rc = get_slot(c, slot, &s);
+    if (rc) return rc;
+    if (!s->formatted) return fail(AQC_ERR_STATE, "aqc_format_fused before aqc_format");
+    return s->formatted_fused ? 1 : 0;
 }
 
 int aqc_span_end(aqc_ctx* c, int slot, uint64_t n, uint64_t end[2]) {

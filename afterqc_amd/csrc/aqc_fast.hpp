@@ -80,6 +80,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
                max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
+__device__ __forceinline__ void store16f(uint8_t* p, uint4 v) { __builtin_memcpy(p, &v, 16); }
 __device__ __forceinline__ int wave_sum_u(int v) {
     v += dpp_move<0xB1>(v);
     v += dpp_move<0x4E>(v);
@@ -145,7 +146,7 @@ __device__ __forceinline__ void trim_view(int len, int front, int tail, int& st,
 // business) counts as EMPTY — one v_max per lane and batch; phase 1 then sees padding only and never forms an address from it
 __device__ __forceinline__ uint32_t lane_len(uint32_t len_word) { return (uint32_t)max((int)len_word, 0); }
 
-template <int NW, bool PAIRED>
+template <int NW, bool PAIRED, bool FUSE = false>
 struct FastWaveLds {
     static constexpr int PPW = PAIRED ? 32 : 64;               // records per wave batch
     static constexpr int GUARD = (PAIRED ? 4 : 2) * NW;        // 5 zero words behind the planes
@@ -153,9 +154,15 @@ struct FastWaveLds {
     // the record's descriptor lives in its row too: one row address serves the planes and these (immediate offsets)
     static constexpr int D_O1 = LQ0 + (NW + 1) / 2, D_L1 = D_O1 + 1, D_Q1 = D_O1 + 2, D_O2 = D_O1 + 3, D_L2 = D_O1 + 4, D_Q2 = D_O1 + 5;
     static constexpr int D_EXO = D_O1 + 6, D_LQ = D_O1 + 7;    // alphabet verdict (non-zero: defer), read 1's low-quality count
-    static constexpr int STRIDE = (D_O1 + 8) | 1;              // odd: conflict-free lane-strided access
+    // FUSE (the kernel also places every record and copies the whole ones): where each mate's record starts in its text
+    // (bit 31: all four lines end right at their '\n')
+    static constexpr int D_N1 = D_O1 + 8, D_N2 = D_O1 + 9;
+    static constexpr int STRIDE = (D_O1 + (FUSE ? 10 : 8)) | 1;   // odd: conflict-free lane-strided access
     uint32_t planes[PPW][STRIDE];
     uint8_t stage[16 * NW + 16];
+    // FUSE: the batch whose records are copied one batch later (by then its predecessors have long published their sums): per
+    // record and file the first byte in the text | copied here << 31, and its length | offset inside the batch's bytes << 16
+    uint32_t pend[FUSE ? 2 : 1][FUSE ? 4 * PPW : 1];
 };
 
 // reverse the order of the thirty-two 2-bit fields of a 64-bit value given as (w0 = fields 0..15, w1 = fields 16..31)
@@ -254,6 +261,22 @@ struct BarcodeCodes {
 // word, the statistics arrays — is read from the kernarg segment where it is used (R->field, an s_load): held in SGPRs
 // across the loop those ~40 values pushed the kernel past the 102 it has, and the spill code (v_writelane / v_readlane
 // + hazard nops) was ~6 % of all vector instructions issued.
+// FUSE: what the verdict kernel needs to place every record of the chunk in its output stream and to copy the good records that
+// go out as their own bytes itself.  Batches are committed in index order: a batch publishes the bytes it adds to
+// the four streams (good / bad of either file) and looks back over its predecessors' (decoupled look-back, as text_index_kernel).
+struct FuseArgs {
+    const uint32_t *name_off1, *name_off2;       // where each record starts in its file's text
+    uint8_t *out1, *out2;                        // the good streams
+    uint32_t *fstate1, *fstate2;                 // per record and file: position in its stream | FUSE_WHOLE (already written here)
+    unsigned long long* state;                   // [2 * batches]: flag (2 bits) | good1 (31) | good2 (31), flag | bad1 | bad2
+    unsigned int* ticket;                        // rounds handed out (a round = WPBT consecutive batches)
+    int* abort;                                  // != 0: this placement is void — a deferred pair, a record that is not contiguous text, a
+                                                 // look-back that ran out of patience: the host formats the chunk the other way
+    unsigned long long* totals;                  // [4] bytes of good1, good2, bad1, bad2
+};
+constexpr uint32_t FUSE_WHOLE = 0x80000000u, FUSE_POS = 0x7fffffffu, FUSE_PATCH = 0x40000000u;
+constexpr unsigned long long FUSE_FLAG_A = 1ull << 62, FUSE_FLAG_P = 2ull << 62;
+
 struct FastArgs {
     DevBatch fb;
     aqc_config cfg;
@@ -263,32 +286,42 @@ struct FastArgs {
     uint64_t accum_limit;
     uint32_t* deferred;
     unsigned int* n_deferred;
+    FuseArgs fz;
 };
 typedef const FastArgs __attribute__((address_space(4))) * FastArgsRare;
+#ifndef AQC_FUSE_UNROLL
+#define AQC_FUSE_UNROLL 12
+#endif
+#ifndef AQC_FUSE_ABL
+#define AQC_FUSE_ABL 0          // measurement builds only: 1 no copy, 2 no stores, 4 no loads, 8 no look-back
+#endif
 
 // (one workgroup of WPBT waves per CU — its LDS rows allow no second one — is WPBT / 4 waves per SIMD: that is the occupancy the
 //  register budget is sized for: 128 VGPRs for the 16-wave 2 x 150 variant, 168 for the 12-wave ones)
-template <int NW, bool PAIRED, int WPBT, bool BARCODE>
+template <int NW, bool PAIRED, int WPBT, bool BARCODE, bool FUSE = false>
 __global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT + 3) / 4 : AQC_MIN_WAVES) void fast_filter_overlap_kernel(FastArgs K) {
+    static_assert(!FUSE || (PAIRED && !BARCODE), "the fused variant is the plain paired one");
     const DevBatch& fb = K.fb;
     const aqc_config& cfg = K.cfg;
     aqc_result* __restrict__ const results = K.results;
     const uint64_t accum_limit = K.accum_limit;
     FastArgsRare R = (FastArgsRare)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(R));                   // opaque: nothing read through R is hoisted out of its branch
-    using WL = FastWaveLds<NW, PAIRED>;
+    using WL = FastWaveLds<NW, PAIRED, FUSE>;
     constexpr int PPW = WL::PPW;
     constexpr int ITERS = PPW * NW / WAVE;        // 16-byte chunk tasks per lane and string kind
     static_assert(PPW * NW % WAVE == 0 && (!PAIRED || NW % 2 == 0), "chunk tasks must tile the wave");
     __shared__ WL wls[WPBT];
     __shared__ BlockAcc acc;
     __shared__ unsigned int batch_ticket;
+    __shared__ unsigned long long round_slot[16];  // FUSE: (local round + 1) << 32 | the global round it was given
     __shared__ uint4 mtab[17];                    // mtab[nb]: byte mask of the first nb bytes of a 16-byte chunk
     // (lane from mbcnt, wave in a scalar register: nothing derived from the work-item id has to survive the main loop)
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     for (int i = threadIdx.x; i < (int)(sizeof(BlockAcc) / 4); i += WPBT * WAVE) ((unsigned int*)&acc)[i] = 0;
-    if (threadIdx.x == 0) batch_ticket = WPBT;      // tickets 0 .. WPBT-1 are the waves' first batches
+    if (threadIdx.x == 0) batch_ticket = FUSE ? 0u : (unsigned int)WPBT;      // tickets 0 .. WPBT-1 are the waves' first batches
+    if (FUSE && threadIdx.x < 16) round_slot[threadIdx.x] = 0ull;
     if (threadIdx.x < 17) {
         const int nb = threadIdx.x;
         uint32_t m[4];
@@ -375,8 +408,29 @@ __global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT
     // (the workgroup's column rotates with t, so that its batches are spread over all memory channels)
     // (record and batch numbers are 32-bit: a batch's byte offsets are, so it has fewer than 2^32 records)
     auto batch_of = [&](uint32_t t) -> uint32_t { return gridDim.x * t + (blockIdx.x + 61u * t) % gridDim.x; };
+    // FUSE: batches are committed in INDEX order, so they are handed out in index order too: the workgroup takes a ROUND of WPBT
+    // consecutive batches with one global ticket and its waves take one each (whoever draws a round's first local ticket fetches
+    // the global one; the others wait for it in LDS).  A batch only ever waits for batches with lower indices, which running
+    // waves hold: no deadlock whatever else occupies the chip.
+    auto fdraw = [&]() -> uint32_t {
+        uint32_t b = 0;
+        if (lane == 0) {
+            const uint32_t t = atomicAdd(&batch_ticket, 1u);
+            const uint32_t j = t / WPBT, w = t % WPBT;
+            unsigned long long slot;
+            if (w == 0) {
+                const unsigned int g = atomicAdd(R->fz.ticket, 1u);
+                slot = ((unsigned long long)(j + 1u) << 32) | g;
+                __hip_atomic_store(&round_slot[j & 15u], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                do { slot = __hip_atomic_load(&round_slot[j & 15u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while ((uint32_t)(slot >> 32) != j + 1u);
+            }
+            b = (uint32_t)slot * (uint32_t)WPBT + w;
+        }
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    };
     const uint32_t n_rec = (uint32_t)fb.n;
-    uint32_t cur = batch_of((uint32_t)wave);
+    uint32_t cur = FUSE ? fdraw() : batch_of((uint32_t)wave);
     // chunk task `it` of this lane: chunk t = it * 64 + lane of the batch, i.e. chunk t % NW of record t / NW — ten
     // neighbouring lanes cover one read, every load instruction of the wave reads 6.4 whole reads (dense in memory: dealing
     // each lane the chunks of its OWN pair costs a third fewer instructions and runs slower, its loads touch 32 lines
@@ -390,12 +444,129 @@ __global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT
         task[it] = (uint32_t)((t / NW) * (WL::STRIDE * 4)) | ((uint32_t)(t % NW) << 16);
     }
     // the descriptor of this lane's read in the NEXT batch is fetched one iteration ahead
-    uint32_t m_o = 0, m_l = 0, m_q = 0;
+    uint32_t m_o = 0, m_l = 0, m_q = 0, m_n = 0;
+    // (FUSE: the record's first byte in its text, and in bit 31 whether all four lines end right at their '\n' — QLEN_CONTIG)
+    auto start_word = [&](uint32_t r) -> uint32_t {
+        const uint32_t n0 = role ? R->fz.name_off2[r] : R->fz.name_off1[r];
+        const uint32_t qw = role ? R->fb.qlen2[r] : R->fb.qlen1[r];
+        return (n0 & FUSE_POS) | ((qw & QLEN_CONTIG) ? FUSE_WHOLE : 0u);
+    };
+    // FUSE: a batch's place — its predecessors' sums — is looked up, and its whole records are copied, TWO iterations after its
+    // verdicts (behind the NEXT-but-one batch's phase 1): by then every batch drawn before it has published its sums and the
+    // look-back does not wait.  (Committed on the spot, every wave ran at the pace of the slowest of the ~3000 batches in flight
+    // before it: the kernel took twice as long.)  Two batches wait at any time: the older one (its look-back window is loaded at
+    // the top of the iteration, under phase 1's loads) and the newer one; their record lists alternate between L.pend[0 / 1].
+    struct FusePending { uint32_t b; unsigned long long wa, wb; int mx; };     // batch (0xffffffff: none), its sums, its longest whole record
+    FusePending fz_old{0xffffffffu, 0, 0, 0}, fz_new{0xffffffffu, 0, 0, 0};
+    uint32_t fz_iter = 0;                                                      // iterations done: L.pend[fz_iter & 1] is the older batch's / the next to fill
+    unsigned long long fz_sa = 0, fz_sb = 0;                                   // the older batch's first look-back window, per lane
+    auto fuse_peek = [&](const FusePending& P) {
+        const long long idx = (long long)P.b - 1 - lane;
+        fz_sa = fz_sb = FUSE_FLAG_P;                                           // before batch 0: prefix 0
+        if (P.b != 0xffffffffu && idx >= 0) {
+            fz_sa = __hip_atomic_load(&R->fz.state[2 * idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fz_sb = __hip_atomic_load(&R->fz.state[2 * idx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    auto fuse_finish = [&](const FusePending& P, const uint32_t* pend_list, bool peeked) {
+        // ---- the batch's place: its predecessors' sums (decoupled look-back; batches are handed out in index order)
+        unsigned long long* const stt = R->fz.state;
+        uint32_t bg1 = 0, bg2 = 0, bb1 = 0, bb2 = 0;
+        bool dead = false;
+        long long j = (AQC_FUSE_ABL & 8) ? -1ll : (long long)P.b - 1;
+        unsigned int spins = 0;
+        while (j >= 0) {
+            const long long idx = j - lane;
+            unsigned long long sa = FUSE_FLAG_P, sb = FUSE_FLAG_P;            // before batch 0: prefix 0
+            if (peeked) { sa = fz_sa; sb = fz_sb; }
+            else if (idx >= 0) {
+                sa = __hip_atomic_load(&stt[2 * idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sb = __hip_atomic_load(&stt[2 * idx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            peeked = false;
+            // (the two words of a batch are stored one after the other: seen in different states, they are not there yet)
+            const unsigned int fl = (sa >> 62) == (sb >> 62) ? (unsigned int)(sa >> 62) : 0u;
+            const unsigned long long pnd = __ballot(fl == 0u), pfx = __ballot(fl == 2u);
+            const int fp = pfx ? __ffsll((long long)pfx) - 1 : 63;
+            const unsigned long long upto = fp == 63 ? ~0ull : ((2ull << fp) - 1ull);
+            if (pnd & upto) {
+                // somebody before us is not there yet.  Patience has an end: a look-back that cannot finish voids the
+                // placement (the host formats the chunk the other way) instead of hanging the device.
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 1023u) == 0u && (spins > (1u << 22) || __hip_atomic_load(R->fz.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    if (lane == 0) atomicExch(R->fz.abort, 1);
+                    dead = true;
+                    break;
+                }
+                continue;
+            }
+            const bool in = lane <= fp;
+            bg1 += (uint32_t)wave_sum_u(in ? (int)((sa >> 31) & 0x7fffffffull) : 0);
+            bg2 += (uint32_t)wave_sum_u(in ? (int)(sa & 0x7fffffffull) : 0);
+            bb1 += (uint32_t)wave_sum_u(in ? (int)((sb >> 31) & 0x7fffffffull) : 0);
+            bb2 += (uint32_t)wave_sum_u(in ? (int)(sb & 0x7fffffffull) : 0);
+            if (pfx) break;
+            j -= WAVE;
+        }
+        if (dead) return;
+        const uint32_t ig1 = bg1 + (uint32_t)(P.wa >> 31), ig2 = bg2 + (uint32_t)(P.wa & 0x7fffffffull);
+        const uint32_t ib1 = bb1 + (uint32_t)(P.wb >> 31), ib2 = bb2 + (uint32_t)(P.wb & 0x7fffffffull);
+        if (lane == 0) {
+            __hip_atomic_store(&stt[2 * (size_t)P.b], FUSE_FLAG_P | ((unsigned long long)(ig1 & FUSE_POS) << 31) | (ig2 & FUSE_POS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&stt[2 * (size_t)P.b + 1], FUSE_FLAG_P | ((unsigned long long)(ib1 & FUSE_POS) << 31) | (ib2 & FUSE_POS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (P.b + 1 == n_batches) {
+                unsigned long long* tt = R->fz.totals;
+                tt[0] = ig1; tt[1] = ig2; tt[2] = ib1; tt[3] = ib2;
+            }
+        }
+        if (P.mx == 0 || (AQC_FUSE_ABL & 1)) return;
+        // ---- the whole records, copied with fresh loads (the chunks phase 1 loaded were packed and dropped long ago — keeping 60
+        // registers of text alive through phase 2 costs the kernel a wave per SIMD; the text is some microseconds old and still in
+        // the last-level cache): the batch's 64 records x XW sixteen-byte windows, window w of a record = its bytes
+        // [min(16 w, len - 16), + 16), dealt to the lanes window-fastest (a wave instruction moves 1 KiB of neighbouring bytes).
+        // Records of up to 384 bytes — 2 x 150 with names of up to 80 — go in ONE round: 24 loads per lane in flight, then 24 stores
+        // (this is the point of the iteration where the registers are free: phase 1's are dead, phase 2's not yet alive).
+        // (the window numbers only depend on the lane: re-opened per batch behind an opaque barrier, or the compiler keeps every
+        //  address of the loop below across the whole batch loop — in scratch)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        uint8_t* const o1 = R->fz.out1 + bg1;
+        uint8_t* const o2 = R->fz.out2 + bg2;
+        auto copy_pass = [&](auto xw_c, auto u_c) {
+            constexpr int XW = decltype(xw_c)::value, U = decltype(u_c)::value;
+            for (int t0 = 0; t0 < 2 * PPW * XW; t0 += WAVE * U) {
+                uint4 xv[U];
+                uint32_t xd[U];                        // offset from the batch's place | file << 31; 0xffffffff: nothing to store
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int t = t0 + u * WAVE + lane_o;
+                    const int rr = t / XW, w = t % XW;
+                    const uint32_t w0 = pend_list[2 * rr], w1 = pend_list[2 * rr + 1];
+                    const int n0 = (int)(w0 & FUSE_POS), ln0 = (int)(w1 & 0xffffu);
+                    const bool ok = (w0 >> 31) != 0u && 16 * w < ln0;
+                    const int o = ok ? min(16 * w, ln0 - 16) : 0;
+                    xd[u] = ok ? (((w1 >> 16) + (uint32_t)o) | ((uint32_t)(rr & 1) << 31)) : 0xffffffffu;
+                    if (AQC_FUSE_ABL & 4) xv[u] = make_uint4(w0, w1, (uint32_t)t, 0u);
+                    else xv[u] = load16u(((rr & 1) ? fb.seq2 : fb.seq1) + (uint32_t)(ok ? n0 + o : 0));
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint8_t* const d = ((xd[u] >> 31) ? o2 : o1) + (xd[u] & FUSE_POS);
+                    if (AQC_FUSE_ABL & 2) { if (xd[u] != 0xffffffffu && xv[u].x == 0x12345678u && xv[u].w == 0x9abcdef0u) store16f(d, xv[u]); }
+                    else if (xd[u] != 0xffffffffu) store16f(d, xv[u]);
+                }
+            }
+        };
+        if (P.mx <= 384) copy_pass(std::integral_constant<int, 24>{}, std::integral_constant<int, AQC_FUSE_UNROLL>{});
+        else copy_pass(std::integral_constant<int, 64>{}, std::integral_constant<int, 16>{});
+        __builtin_amdgcn_wave_barrier();
+    };
     if (cur < n_batches && cur * PPW + p < n_rec) {
         const uint32_t r0 = cur * PPW + p;
         m_o = role ? fb.off2[r0] : fb.off1[r0];
         m_l = lane_len(role ? fb.len2[r0] : fb.len1[r0]);
         m_q = role ? qo2[r0] : qo1[r0];
+        if (FUSE) m_n = start_word(r0);
     }
     while (cur < n_batches) {
         // The options are read where they are used, from the kernarg segment through a pointer that is opaque per batch
@@ -409,19 +580,24 @@ __global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT
         const uint32_t base = cur * PPW;
         // exactly ONE batch of lookahead (its descriptors travel while this batch is processed): a slow wave never sits
         // on more than one batch the faster waves could have taken
-        const uint32_t nxt = batch_of((uint32_t)__builtin_amdgcn_readfirstlane((int)draw()));
+        const uint32_t nxt = FUSE ? fdraw() : batch_of((uint32_t)__builtin_amdgcn_readfirstlane((int)draw()));
         const uint32_t rec = base + p;
         const bool valid = rec < n_rec;
         // ------------------------------------------------------------------ phase 1: load + pack
         if (role == 0) { pr[WL::D_O1] = m_o; pr[WL::D_L1] = m_l; pr[WL::D_Q1] = m_q; pr[WL::D_EXO] = 0; pr[WL::D_LQ] = 0; }
         else { pr[WL::D_O2] = m_o; pr[WL::D_L2] = m_l; pr[WL::D_Q2] = m_q; }
+        if (FUSE) {
+            pr[role ? WL::D_N2 : WL::D_N1] = m_n;
+            fuse_peek(fz_old);                        // (two 8-byte loads per lane, in flight under phase 1's)
+        }
         {
             const uint32_t nrec = nxt * PPW + p;
-            m_o = m_l = m_q = 0;
+            m_o = m_l = m_q = m_n = 0;
             if (nxt < n_batches && nrec < n_rec) {
                 m_o = role ? fb.off2[nrec] : fb.off1[nrec];
                 m_l = lane_len(role ? fb.len2[nrec] : fb.len1[nrec]);
                 m_q = role ? qo2[nrec] : qo1[nrec];
+                if (FUSE) m_n = start_word(nrec);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -557,6 +733,12 @@ __global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT
         }
 #undef AQC_TASK_ROW
         __builtin_amdgcn_wave_barrier();
+        // FUSE: the batch of two iterations ago gets its place and its whole records are copied (memory work, still at phase 1's
+        // priority; the list it was kept in is the one this iteration fills at its end)
+        if (FUSE && fz_old.b != 0xffffffffu) {
+            fuse_finish(fz_old, L.pend[fz_iter & 1u], true);
+            fz_old.b = 0xffffffffu;
+        }
         // phase 2 is pure arithmetic on LDS: run it ahead of the waves that are still waiting for their chunk loads (a wave
         // back in phase 1 drops to priority 0 again) — measured -3 % on the 2 x 150 workload, interleaved A/B on one box
         __builtin_amdgcn_s_setprio(AQC_PRIO2);
@@ -1247,6 +1429,59 @@ __global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT
         }
         __builtin_amdgcn_wave_barrier();
         PROF(7);
+        // ------------------------------------------------------------------ FUSE: place every record, copy the whole ones
+        if (FUSE) {
+            // (the walker holds the pair's last word on verdict and edits; everything else of the post-processing is identical
+            //  on both lanes of a pair)
+            // (every lane takes what the lane that wrote the pair's result holds)
+            const int pf = xchg(flag), pn = xchg(n_edits), pa1 = xchg(a1), pl1 = xchg(len1), pa2 = xchg(a2), pl2 = xchg(len2);
+            const bool take = walk_pair ? !walker : role == 1;
+            const int flagF = take ? pf : flag, neF = take ? pn : n_edits;
+            const int fa1 = take ? pa1 : a1, fl1 = take ? pl1 : len1, fa2 = take ? pa2 : a2, fl2 = take ? pl2 : len2;
+            const uint32_t nw = pr[role ? WL::D_N2 : WL::D_N1];
+            const int startO = (int)(nw & FUSE_POS);
+            const int Qo = (int)pr[role ? WL::D_Q2 : WL::D_Q1];
+            const int endO = Qo + Lown + 1;                       // one past the '\n' of the quality line
+            const int recLen = endO - startO;
+            const int st = role ? fa2 : fa1, ln = role ? fl2 : fl1;
+            const bool live = valid && !defer;
+            // what this scheme cannot place: a pair the general kernel still has to decide, a record that is not four lines of
+            // contiguous text (stripped blanks: the writer rebuilds it from pieces), records beyond the packed sums' range
+            const bool odd = valid && (defer || !(nw >> 31) || recLen < 48 || recLen > 1000);
+            // (a pair the correction walk edited is still its own bytes but for up to six of them: copied here like the others — a
+            //  dense stream of stores — and patched byte by byte by the writer's plan pass, which sees FUSE_PATCH.  Copying those
+            //  records later, 8 % of them scattered over the stream, ran at a third of the dense rate.)
+            const bool whole = live && !odd && flagF == AQC_GOOD && st == 0 && ln == Lown;
+            // bytes the record adds to its stream: its own bytes, or name + strand line + 4 newlines + the final view twice
+            // (+ the flag text in the name of a bad record: "@" + FLAG + name[1:], preprocesser.py:213-219)
+            const int flen = (int)((0xB76666688774ull >> (4 * (flagF & 15))) & 15ull);
+            const int szr = whole ? recLen : (recLen - 2 * Lown) + 2 * ln + (flagF == AQC_GOOD ? 0 : flen);
+            const uint32_t gsz = (live && !odd && flagF == AQC_GOOD) ? (uint32_t)szr : 0u, bsz = (live && !odd && flagF != AQC_GOOD) ? (uint32_t)szr : 0u;
+            const int packed = (int)(gsz | (bsz << 16));
+            const int s_lo = role ? 0 : packed, s_hi = role ? packed : 0;      // file 1's sums in one word, file 2's in the other
+            const int i_lo = wave_incl_sum(s_lo, lane), i_hi = wave_incl_sum(s_hi, lane);
+            const uint32_t t_lo = (uint32_t)__builtin_amdgcn_readlane(i_lo, 63), t_hi = (uint32_t)__builtin_amdgcn_readlane(i_hi, 63);
+            const uint32_t ex = (uint32_t)(role ? i_hi - s_hi : i_lo - s_lo);
+            const uint32_t ag1 = t_lo & 0xffffu, ab1 = t_lo >> 16, ag2 = t_hi & 0xffffu, ab2 = t_hi >> 16;
+            if (__ballot(odd) && lane == 0) atomicExch(R->fz.abort, 1);
+            // ---- the batch's sums go out at once (state A); its place — its predecessors' sums — is looked up and its whole
+            //      records are copied two iterations later (fuse_finish, above)
+            const unsigned long long wa = ((unsigned long long)ag1 << 31) | ag2, wb = ((unsigned long long)ab1 << 31) | ab2;
+            if (lane == 0) {
+                __hip_atomic_store(&R->fz.state[2 * (size_t)cur], FUSE_FLAG_A | wa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&R->fz.state[2 * (size_t)cur + 1], FUSE_FLAG_A | wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // every record's offset inside its batch's share of its stream; the host-side writer adds the batch's place
+            if (live && !odd) (role ? R->fz.fstate2 : R->fz.fstate1)[rec] = (flagF == AQC_GOOD ? (ex & 0xffffu) : (ex >> 16)) | (whole ? FUSE_WHOLE : 0u) | ((whole && neF > 0) ? FUSE_PATCH : 0u);
+            const int mx = wave_max_i(whole ? recLen : 0);
+            uint32_t* const pl = L.pend[fz_iter & 1u];             // (the batch that had this list was finished behind this iteration's phase 1)
+            pl[2 * lane] = (uint32_t)startO | (whole ? FUSE_WHOLE : 0u);
+            pl[2 * lane + 1] = (uint32_t)recLen | ((ex & 0xffffu) << 16);
+            fz_old = fz_new;
+            fz_new = FusePending{cur, wa, wb, mx};
+            ++fz_iter;
+            __builtin_amdgcn_wave_barrier();
+        }
         // ------------------------------------------------------------------ deferred pairs: queued for the general kernel
         {
             const unsigned long long dmask = __ballot(valid && defer && role == 0);
@@ -1262,6 +1497,14 @@ __global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT
         PROF(8);
         if (++since_flush == 64 || nxt >= n_batches) flush_totals();     // (also the wave's last batch: the only copy of the flush)
         cur = nxt;
+    }
+    if (FUSE) {
+        // the two batches still waiting, the older first (a loop that stays a loop: one more copy of fuse_finish, not two)
+#pragma nounroll
+        for (uint32_t k = 0; k < 2u; ++k) {
+            const FusePending P = k == 0u ? fz_old : fz_new;
+            if (P.b != 0xffffffffu) fuse_finish(P, L.pend[(fz_iter + k) & 1u], false);
+        }
     }
     PROF_FLUSH;
 #ifdef AQC_PROFILE

@@ -571,7 +571,14 @@ struct FormatView {
                           // record that is not such a "whole" record leaves an event (SpanEvent) saying where it stood
     uint32_t consumed[2]; // bytes of each file's chunk that the framed records take (the end of the last record)
     uint64_t n_framed;    // records framed into the slot (>= the n being formatted)
+    int fused;            // the verdict kernel placed every record itself and copied the whole good ones (aqc_fast.hpp, FUSE): fstate[file][r] =
+                          // the record's offset inside its batch's share of its stream | bit 31: already written; fbatch[2 b], [2 b + 1] =
+                          // the bytes of the good / bad streams up to and including batch b (2 bits of state | file 0: 31 bits | file 1: 31 bits)
+    const uint32_t* fstate[2];
+    const unsigned long long* fbatch;
+    int fbatch_shift;     // records per batch = 1 << fbatch_shift
 };
+constexpr uint32_t FMT_FUSED_DONE = 0x80000000u, FMT_FUSED_PATCH = 0x40000000u, FMT_FUSED_OFF = 0xffffu;      // (bit 30: written, but for the walk's byte patches)
 
 // event k of a file = the k-th record (in order) that is bad or had to be rebuilt: it stood at chunk bytes [in_start, in_start +
 // in_len) and contributes out_len bytes to stream 0 (0: a bad record).  The good output of the file is, in order: the chunk's
@@ -918,16 +925,19 @@ constexpr int PLAN_Q = 6;                    // 16-byte words per plan
 constexpr int PLAN_MAXP = 8;
 constexpr int GEN_PASSES = 2;                // work items per lane of the general copy kernel (32 lanes per record)
 
-// the plans fmt_copy_whole_kernel takes: one piece of 16..512 bytes from the text, no patches
+// the plans fmt_copy_whole_kernel takes: one piece of 16..512 bytes from the text — the record's own bytes — with up to four
+// byte patches (a pair the correction walk edited is still its own bytes but for those: ~8 % of the records of a 2 x 150 run,
+// which used to go through the general kernel, 0.7 of the text step's 4.6 ms)
 __device__ __forceinline__ bool plan_is_whole(const uint4& q0) {
-    return (q0.y & 0xffffff00u) == 0x100u && !(q0.z & FMT_LIT_BIT) && (q0.w & 0xffffu) >= 16u && (q0.w & 0xffffu) <= 512u;
+    return (q0.y & 0xff00ff00u) == 0x100u && ((q0.y >> 16) & 0xffu) <= 4u && !(q0.z & FMT_LIT_BIT) && (q0.w & 0xffffu) >= 16u && (q0.w & 0xffffu) <= 512u;
 }
 
 __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
                                                             const unsigned long long* __restrict__ tile_base, int overlap_pass,
-                                                            int* __restrict__ status, uint4* __restrict__ plan0, uint4* __restrict__ plan_gen,
+                                                            int* __restrict__ status, uint4* __restrict__ plan0, uint4* __restrict__ plan_patch, uint4* __restrict__ plan_gen,
                                                             FmtTask* __restrict__ over, uint32_t* __restrict__ gen_list,
                                                             unsigned int* __restrict__ n_gen, uint64_t gen_cap,
+                                                            uint4* __restrict__ whole_plan, unsigned int* __restrict__ n_whole, FormatOut outs,
                                                             SpanEvent* __restrict__ events0, SpanEvent* __restrict__ events1) {
     __shared__ unsigned long long lds[4];
     __shared__ FmtTask tasks[FMT_TILE];
@@ -941,7 +951,9 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
         uint32_t event = 0;                     // spans mode, main pass: this record is not one that stays where it is
         if (r < n) {
             // (spans mode: a whole record needs no piece list — it is not copied — except for the overlap stream's slice of it)
-            const bool whole = v.spans && !overlap_pass && record_is_whole(v, v.f[file], r, file, *reinterpret_cast<const uint4*>(v.results + r));
+            const uint32_t fs = v.fused ? v.fstate[file][r] : 0u;
+            const bool whole = v.fused ? (fs & (FMT_FUSED_DONE | FMT_FUSED_PATCH)) == FMT_FUSED_DONE
+                                       : v.spans && !overlap_pass && record_is_whole(v, v.f[file], r, file, *reinterpret_cast<const uint4*>(v.results + r));
             if (!whole) fmt_build(v, r, file, overlap_pass, t, status);
             event = (v.spans && !overlap_pass && !whole) ? 1u : 0u;
             if (!overlap_pass) sz[t.stream == 1 ? 1 : 0] = t.stream == 0xff ? 0u : (uint32_t)t.total;
@@ -960,11 +972,25 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
             }
         }
         unsigned int pos;
-        bool general = false;
+        bool general = false, listed_whole = false;
         uint4 q[PLAN_Q];
 #pragma unroll
         for (int k = 0; k < PLAN_Q; ++k) q[k] = make_uint4(0, 0, 0, 0);
-        if (!overlap_pass) {
+        if (v.fused) {
+            // (placed by the verdict kernel: no scans, no tile bases)
+            pos = 0u;
+            if (r < n && t.stream != 0xff) {
+                const uint64_t b = r >> v.fbatch_shift;
+                const unsigned long long w = b ? v.fbatch[2 * (b - 1) + (t.stream == 1 ? 1 : 0)] : 0ull;
+                pos = (unsigned int)((file == 0 ? (w >> 31) : w) & 0x7fffffffull) + (v.fstate[file][r] & FMT_FUSED_OFF);
+                if (v.fstate[file][r] & FMT_FUSED_DONE) {
+                    // the verdict kernel wrote the record's own bytes; the walk's edits go on top (its launch is long complete)
+                    uint8_t* const rec_out = outs.p[file * 3] + pos;
+                    for (int e = 0; e < (int)t.n_patch; ++e) rec_out[t.patch[e] & 0xffffu] = (uint8_t)(t.patch[e] >> 16);
+                    t.stream = 0xff;
+                }
+            }
+        } else if (!overlap_pass) {
             // good and bad records interleave: two scans, each record keeps the offset of the stream it goes to
             unsigned long long tg, tb;
             const unsigned long long eg = block_excl_scan((unsigned long long)sz[0], lds, tg);
@@ -1017,10 +1043,18 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
                     over[ti] = t;
                 }
             }
-            // (spans mode: no whole-record copy kernel runs — whatever has a plan goes to the general kernel, and nobody reads plan0)
-            const bool whole = !v.spans && plan_is_whole(q[0]);
-            if (!v.spans) plan0[ti] = q[0];
+            // (spans / fused mode: the records that stay where they are / that the verdict kernel copied have no plan: PLAN_SKIP)
+            // Text mode: nearly every record is one piece — fmt_copy_whole_kernel walks the dense plan0.  Spans / fused mode: few
+            // are left (the pairs the walk edited) — their plans are LISTED (q0 with the file in bit 24 | the patches) and
+            // fmt_copy_whole_list_kernel walks the lists (a dense walk over 10 M mostly empty plans cost 0.8 ms).
+            const bool whole = plan_is_whole(q[0]);
+            const bool sparse = v.spans || v.fused;
+            if (!sparse) {
+                plan0[ti] = q[0];
+                if (whole && (q[0].y & 0x00ff0000u)) plan_patch[ti] = q[5];        // (written and read for the patched records only)
+            }
             general = q[0].y != PLAN_SKIP && !whole;
+            listed_whole = sparse && whole;
         }
         // the records fmt_copy_whole_kernel does not take are listed (one atomic per wave) for the general copy kernel
         {
@@ -1041,6 +1075,20 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
                 }
             }
         }
+        {
+            const unsigned long long wm = __ballot(listed_whole);
+            if (wm) {
+                unsigned int base = 0;
+                const unsigned int lj = blockIdx.x % GEN_LISTS;
+                if (lane_id() == 0) base = atomicAdd(&n_whole[lj], (unsigned int)__popcll(wm));
+                base = (unsigned int)__shfl((int)base, 0, WAVE);
+                if (listed_whole) {
+                    const uint64_t slot = (uint64_t)lj * gen_cap + base + (unsigned int)__popcll(wm & ((1ull << lane_id()) - 1ull));
+                    whole_plan[2 * slot] = make_uint4(q[0].x, q[0].y | ((uint32_t)file << 24), q[0].z, q[0].w);
+                    whole_plan[2 * slot + 1] = q[5];
+                }
+            }
+        }
         __syncthreads();            // (tasks[] is reused for the second file)
     }
 }
@@ -1054,34 +1102,96 @@ constexpr int COPY_BLOCK = 256;
 // Records that are ONE piece (untrimmed, unedited, not renamed: the bulk of a -f 0 -t 0 run): 32 lanes, window
 // min(16 * lane, len - 16), load, store — as lean as a copy gets (tools/ubench/copy_rate.hip: this shape moves 6.9 GB in
 // 1.4 ms without the plan read, 1.6 ms with it).
-__global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_kernel(FormatView v, uint64_t n_tasks, const uint4* __restrict__ plan,
-                                                                   FormatOut outs) {
-    const int nfiles = v.paired ? 2 : 1;
-    const int lane32 = threadIdx.x & 31;
-    const uint64_t hw = ((uint64_t)blockIdx.x * COPY_BLOCK + threadIdx.x) >> 5;
-    const uint64_t t_first = hw * FMT_UNROLL;
-    uint4 pa[FMT_UNROLL];
-#pragma unroll
-    for (int u = 0; u < FMT_UNROLL; ++u) {
-        const uint64_t ti = t_first + u;
-        pa[u] = make_uint4(0, PLAN_SKIP, 0, 0);
-        if (ti < n_tasks) pa[u] = plan[ti];
-    }
+// pa[u]: the plan's first word (PLAN_SKIP: nothing), file[u]: its file, pq[u]: where its patch word stands
+__device__ __forceinline__ void copy_whole_tasks(const FormatView& v, const uint4 (&pa)[FMT_UNROLL], const int (&file_of)[FMT_UNROLL], const uint4* const (&pq)[FMT_UNROLL],
+                                                 const FormatOut& outs, int lane32) {
     uint4 val[FMT_UNROLL];
     uint8_t* dptr[FMT_UNROLL];
     bool on[FMT_UNROLL];
 #pragma unroll
     for (int u = 0; u < FMT_UNROLL; ++u) {
-        const int file = nfiles == 2 ? (int)((t_first + u) & 1) : 0;
+        const int file = file_of[u];
         const int len = (int)(pa[u].w & 0xffffu);
         on[u] = plan_is_whole(pa[u]) && lane32 < ((len + 15) >> 4);
         const int off = min(16 * lane32, len - 16);
         dptr[u] = outs.p[file * 3 + (int)(pa[u].y & 0xffu)] + pa[u].x + off;
         if (on[u]) val[u] = load16u_t(v.f[file].text + pa[u].z + off);
     }
+    // the correction walk's edits: byte patches applied in registers (windows that overlap carry the same patch)
+    uint32_t any_patch = 0;
+#pragma unroll
+    for (int u = 0; u < FMT_UNROLL; ++u) any_patch |= on[u] ? (pa[u].y >> 16) & 0xffu : 0u;
+    if (__ballot(any_patch != 0)) {
+#pragma unroll
+        for (int u = 0; u < FMT_UNROLL; ++u) {
+            const uint32_t np = on[u] ? (pa[u].y >> 16) & 0xffu : 0u;
+            if (np) {
+                const uint4 q5 = *pq[u];
+                const uint32_t pt[4] = {q5.x, q5.y, q5.z, q5.w};
+                const uint32_t wpos = (uint32_t)min(16 * lane32, (int)(pa[u].w & 0xffffu) - 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t i = (pt[e] & 0xffffu) - wpos;
+                    const bool hit = (uint32_t)e < np && i < 16u;
+                    const uint32_t sh = (i & 3u) * 8u, m = hit ? 0xffu << sh : 0u, cb = hit ? ((pt[e] >> 16) & 0xffu) << sh : 0u;
+                    const uint32_t wd = i >> 2;
+                    val[u].x = wd == 0 ? (val[u].x & ~m) | cb : val[u].x;
+                    val[u].y = wd == 1 ? (val[u].y & ~m) | cb : val[u].y;
+                    val[u].z = wd == 2 ? (val[u].z & ~m) | cb : val[u].z;
+                    val[u].w = wd == 3 ? (val[u].w & ~m) | cb : val[u].w;
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int u = 0; u < FMT_UNROLL; ++u)
         if (on[u]) store16u(dptr[u], val[u]);
+}
+
+__global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_kernel(FormatView v, uint64_t n_tasks, const uint4* __restrict__ plan,
+                                                                   const uint4* __restrict__ plan_patch, FormatOut outs) {
+    const int nfiles = v.paired ? 2 : 1;
+    const int lane32 = threadIdx.x & 31;
+    const uint64_t hw = ((uint64_t)blockIdx.x * COPY_BLOCK + threadIdx.x) >> 5;
+    uint4 pa[FMT_UNROLL];
+    int file_of[FMT_UNROLL];
+    const uint4* pq[FMT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < FMT_UNROLL; ++u) {
+        const uint64_t ti = hw * FMT_UNROLL + u;
+        pa[u] = make_uint4(0, PLAN_SKIP, 0, 0);
+        if (ti < n_tasks) pa[u] = plan[ti];
+        file_of[u] = nfiles == 2 ? (int)(ti & 1) : 0;
+        pq[u] = plan_patch + ti;
+    }
+    copy_whole_tasks(v, pa, file_of, pq, outs, lane32);
+}
+
+// ... the same for the LISTED one-piece records of a spans / fused format (fmt_plan_kernel): workgroup b walks list b % GEN_LISTS, whose
+// plans stand in list order (two 16-byte words each: one coalesced load per round, then the text)
+__global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_list_kernel(FormatView v, const uint4* __restrict__ whole_plans, FormatOut outs,
+                                                                        const unsigned int* __restrict__ n_whole, uint64_t gen_cap) {
+    const int lane32 = threadIdx.x & 31, hwi = threadIdx.x >> 5;
+    const unsigned int lj = blockIdx.x % GEN_LISTS;
+    const uint4* wp = whole_plans + 2 * (uint64_t)lj * gen_cap;
+    const uint32_t n_list = n_whole[lj];
+    constexpr uint32_t PER_WG = (COPY_BLOCK / 32) * FMT_UNROLL;
+    const uint32_t stride = (gridDim.x / GEN_LISTS) * PER_WG;
+    for (uint32_t r0 = (blockIdx.x / GEN_LISTS) * PER_WG; r0 < n_list; r0 += stride) {
+        uint4 pa[FMT_UNROLL];
+        int file_of[FMT_UNROLL];
+        const uint4* pq[FMT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FMT_UNROLL; ++u) {
+            const uint32_t idx = r0 + (uint32_t)(hwi * FMT_UNROLL + u);
+            pa[u] = make_uint4(0, PLAN_SKIP, 0, 0);
+            if (idx < n_list) pa[u] = wp[2 * (uint64_t)idx];
+            file_of[u] = (int)((pa[u].y >> 24) & 1u);
+            if (pa[u].y != PLAN_SKIP) pa[u].y &= ~(1u << 24);
+            pq[u] = wp + 2 * (uint64_t)min(idx, n_list - 1u) + 1;
+        }
+        copy_whole_tasks(v, pa, file_of, pq, outs, lane32);
+    }
 }
 
 // Everything else, from the plan kernel's lists: 32 lanes per plan, two plans in flight per half-wave, a lane owns one work

@@ -26,4 +26,4 @@ def test_e2e_pipe_on_gpu(name, mode, tmp_path, e2e, gpu_engine):
     info = {}
     work, stat = run_case(name, tmp_path, gpu_engine, mode, info)
     check_case(name, work, stat, e2e)
-    assert info["used_pipe"] == (name in PIPE_CASES), (name, info)
+    assert info["used_pipe"] == (name in PIPE_CASES and PIPE_MODES[mode]["use_pipe"]), (name, info)

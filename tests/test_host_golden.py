@@ -31,7 +31,11 @@ PIPE_MODES = {"pipe": dict(use_text_path=True, use_pipe=True),
               "pipe_small_chunks": dict(use_text_path=True, use_pipe=True, chunk_records=257, pipe_slots=3),
               "pipe_two_contexts": dict(use_text_path=True, use_pipe=True, chunk_records=300, devices=[0, 0], own_engines=True),
               # AQC_SPANS=1: plain-text good files written from the pipe's input buffers (aqc_format_spans), rebuilt records between them
-              "pipe_spans": dict(use_text_path=True, use_pipe=True, chunk_records=211, pipe_slots=3, spans=True)}
+              "pipe_spans": dict(use_text_path=True, use_pipe=True, chunk_records=211, pipe_slots=3, spans=True),
+              # AQC_FUSED=1 (read when the context is created: the filter makes its own): where the chunk allows it the verdict kernel
+              # places the records and copies the whole good ones itself; every other case must come out the same through the fallback
+              "pipe_fused": dict(use_text_path=True, use_pipe=True, chunk_records=263, pipe_slots=3, own_engines=True, fused=True),
+              "text_fused": dict(use_text_path=True, use_pipe=False, own_engines=True, fused=True)}
 
 
 def run_case(name, tmp_path, engine, mode="text", info=None):
@@ -53,19 +57,20 @@ def run_case(name, tmp_path, engine, mode="text", info=None):
         kw = dict(MODES[mode] if mode in MODES else PIPE_MODES[mode])
         if kw.pop("own_engines", False):
             engine = None                                                        # the filter creates one engine per device
-        spans = kw.pop("spans", False)
-        old_spans = os.environ.get("AQC_SPANS")
-        if spans:
-            os.environ["AQC_SPANS"] = "1"
+        env = {"AQC_SPANS": "1"} if kw.pop("spans", False) else {}
+        if kw.pop("fused", False):
+            env["AQC_FUSED"] = "1"
+        old_env = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
         try:
             flt = preprocesser.seqFilter(options, engine=engine, **kw)          # what after.processOptions does
             stat = flt.run()
         finally:
-            if spans:
-                if old_spans is None:
-                    os.environ.pop("AQC_SPANS", None)
+            for k, v in old_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
                 else:
-                    os.environ["AQC_SPANS"] = old_spans
+                    os.environ[k] = v
         if info is not None:
             info["text_path"] = flt.text_path
             info["used_pipe"] = flt.used_pipe
