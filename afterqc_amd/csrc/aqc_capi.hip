@@ -1075,12 +1075,15 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
         unsigned int* d_ngen = (unsigned int*)((uint8_t*)s->f_pos.p + 4 * gen_cap * GEN_LISTS);
         unsigned int* d_nwhole = d_ngen + GEN_LISTS;
         const bool sparse = v.spans || v.fused;
-        const unsigned copy_blocks = (unsigned)((n_tasks + (COPY_BLOCK / 32) * FMT_UNROLL - 1) / ((COPY_BLOCK / 32) * FMT_UNROLL));
+        unsigned copy_blocks = (unsigned)((n_tasks + (COPY_BLOCK / 32) * FMT_UNROLL - 1) / ((COPY_BLOCK / 32) * FMT_UNROLL));
+#ifdef AQC_COPY_PERSIST
+        if (copy_blocks > (unsigned)c->n_cu * AQC_COPY_PERSIST) copy_blocks = (unsigned)c->n_cu * AQC_COPY_PERSIST;
+#endif
         for (int pass = 0; pass < (v.store_overlap ? 2 : 1); ++pass) {
             HIP_TRY(hipMemsetAsync(d_ngen, 0, 2 * sizeof(unsigned int) * GEN_LISTS, s->stream));
             hipLaunchKernelGGL(fmt_plan_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles,
                                (const unsigned long long*)s->f_tile.p, pass, s->status, (uint4*)s->f_plan.p, (uint4*)s->f_patch.p,
-                               (uint4*)((uint8_t*)s->f_plan.p + plan0_bytes), (FmtTask*)s->f_over.p, (uint32_t*)s->f_pos.p, d_ngen, gen_cap, d_wplan, d_nwhole, outs,
+                               (uint4*)((uint8_t*)s->f_plan.p + plan0_bytes), (FmtTask*)s->f_over.p, (uint32_t*)s->f_pos.p, d_ngen, gen_cap, d_wplan, d_nwhole, outs.p[0], outs.p[3],
                                (SpanEvent*)s->f_events[0].p, (SpanEvent*)s->f_events[1].p);
             // (spans / fused mode: what stays in the caller's chunk / what the verdict kernel copied has no plan; the records that are their
             //  own bytes but for the walk's byte patches are still this kernel's)

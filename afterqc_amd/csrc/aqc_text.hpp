@@ -937,7 +937,7 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
                                                             int* __restrict__ status, uint4* __restrict__ plan0, uint4* __restrict__ plan_patch, uint4* __restrict__ plan_gen,
                                                             FmtTask* __restrict__ over, uint32_t* __restrict__ gen_list,
                                                             unsigned int* __restrict__ n_gen, uint64_t gen_cap,
-                                                            uint4* __restrict__ whole_plan, unsigned int* __restrict__ n_whole, FormatOut outs,
+                                                            uint4* __restrict__ whole_plan, unsigned int* __restrict__ n_whole, uint8_t* __restrict__ good0, uint8_t* __restrict__ good1,
                                                             SpanEvent* __restrict__ events0, SpanEvent* __restrict__ events1) {
     __shared__ unsigned long long lds[4];
     __shared__ FmtTask tasks[FMT_TILE];
@@ -985,7 +985,7 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
                 pos = (unsigned int)((file == 0 ? (w >> 31) : w) & 0x7fffffffull) + (v.fstate[file][r] & FMT_FUSED_OFF);
                 if (v.fstate[file][r] & FMT_FUSED_DONE) {
                     // the verdict kernel wrote the record's own bytes; the walk's edits go on top (its launch is long complete)
-                    uint8_t* const rec_out = outs.p[file * 3] + pos;
+                    uint8_t* const rec_out = (file == 0 ? good0 : good1) + pos;
                     for (int e = 0; e < (int)t.n_patch; ++e) rec_out[t.patch[e] & 0xffffu] = (uint8_t)(t.patch[e] >> 16);
                     t.stream = 0xff;
                 }
@@ -1152,19 +1152,22 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_kernel(FormatView v
                                                                    const uint4* __restrict__ plan_patch, FormatOut outs) {
     const int nfiles = v.paired ? 2 : 1;
     const int lane32 = threadIdx.x & 31;
-    const uint64_t hw = ((uint64_t)blockIdx.x * COPY_BLOCK + threadIdx.x) >> 5;
-    uint4 pa[FMT_UNROLL];
-    int file_of[FMT_UNROLL];
-    const uint4* pq[FMT_UNROLL];
+    // (grid-strided: the host launches one workgroup per 32 records, or — AQC_COPY_PERSIST builds — a fixed grid that loops)
+    const uint64_t n_hw = ((uint64_t)gridDim.x * COPY_BLOCK) >> 5;
+    for (uint64_t hw = ((uint64_t)blockIdx.x * COPY_BLOCK + threadIdx.x) >> 5; hw * FMT_UNROLL < n_tasks; hw += n_hw) {
+        uint4 pa[FMT_UNROLL];
+        int file_of[FMT_UNROLL];
+        const uint4* pq[FMT_UNROLL];
 #pragma unroll
-    for (int u = 0; u < FMT_UNROLL; ++u) {
-        const uint64_t ti = hw * FMT_UNROLL + u;
-        pa[u] = make_uint4(0, PLAN_SKIP, 0, 0);
-        if (ti < n_tasks) pa[u] = plan[ti];
-        file_of[u] = nfiles == 2 ? (int)(ti & 1) : 0;
-        pq[u] = plan_patch + ti;
+        for (int u = 0; u < FMT_UNROLL; ++u) {
+            const uint64_t ti = hw * FMT_UNROLL + u;
+            pa[u] = make_uint4(0, PLAN_SKIP, 0, 0);
+            if (ti < n_tasks) pa[u] = plan[ti];
+            file_of[u] = nfiles == 2 ? (int)(ti & 1) : 0;
+            pq[u] = plan_patch + ti;
+        }
+        copy_whole_tasks(v, pa, file_of, pq, outs, lane32);
     }
-    copy_whole_tasks(v, pa, file_of, pq, outs, lane32);
 }
 
 // ... the same for the LISTED one-piece records of a spans / fused format (fmt_plan_kernel): workgroup b walks list b % GEN_LISTS, whose

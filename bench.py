@@ -62,7 +62,7 @@ def hbm_traffic(args, n_rec, live):
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 d = os.path.join(tmp, counter)
                 cmd = [rp, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--device-only",
-                       "--device-steps", "3", "--cpu-sample", "0", "--workload", args.workload, "--pairs", str(int(n_rec))]
+                       "--device-steps", "3", "--cpu-sample", "0", "--no-fused-step", "--workload", args.workload, "--pairs", str(int(n_rec))]
                 subprocess.run(cmd, cwd=tmp, env=dict(os.environ, AQC_BENCH_CHILD="1", TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                timeout=150, check=True)
                 tot, cnt = 0.0, 0
@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--device-steps", type=int, default=10, help="timed steps of the HBM-resident device pipeline (0 = skip)")
     ap.add_argument("--gz-runs", type=int, default=-1, help="timed .gz -> .gz runs of the pipe (0 = skip; default: 3 for the 1-GPU input, where making "
                     "the inputs with gzip -2 takes ~20 s, else 0)")
+    ap.add_argument("--no-fused-step", action="store_true", help="skip the AQC_FUSED=1 variant of the device step (a second context on the same GPU)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with two rocprofv3 --pmc child runs (quote profiles/hbm_traffic.json)")
     ap.add_argument("--device-only", action="store_true", help="profiling runs (rocprofv3): only the HBM-resident device step, no pipe "
                     "runs; `value` is then the device step and says so")
@@ -268,6 +269,56 @@ def main():
         spans_sizes = step(True)
     sync_all()
     spans_elapsed = max_over_ranks(time.perf_counter() - t0)
+    # ... and the text step on a context created with AQC_FUSED=1 (opt-in): aqc_run's verdict kernel places every record
+    # and copies the whole good ones itself, aqc_format rebuilds the rest.  Same bytes; reported beside the default step.
+    fused = None
+    if paired and args.workload == "config3" and not args.spans_step_only and not args.no_fused_step:
+        old_f = os.environ.get("AQC_FUSED")
+        os.environ["AQC_FUSED"] = "1"
+        try:
+            eng_f = capi.Engine(device_index, max(1, n_res))
+        finally:
+            if old_f is None:
+                os.environ.pop("AQC_FUSED", None)
+            else:
+                os.environ["AQC_FUSED"] = old_f
+        eng_f.set_config(cfg)
+        eng_f.reset_stats()
+        for sl, (lo, hi) in enumerate(res_n):
+            views = [(t[0].array[lo * w:], (hi - lo) * w) for t in texts]
+            eng_f.frame(sl, views[0][0], views[0][1], True, views[1][0], views[1][1], True, first_index=first_index + lo)
+
+        def step_fused():
+            total, taken = [0] * 6, True
+            for sl, (lo, hi) in enumerate(res_n):
+                eng_f.reframe(sl)
+                eng_f.run(sl)
+                n_qc = (hi - lo) if args.qc_sample <= 0 else max(0, min(hi - lo, args.qc_sample - 1 - (first_index + lo)))
+                if n_qc > 0:
+                    eng_f.qc_stat(sl, capi.QC_R1_POST, 0, 0, n_qc, 1)
+                    eng_f.qc_stat(sl, capi.QC_R2_POST, 1, 0, n_qc, 1)
+                sz = eng_f.format(sl, hi - lo, False)
+                taken = taken and eng_f.format_fused(sl)
+                total = [a + b for a, b in zip(total, sz)]
+            return total, taken
+
+        for _ in range(2):
+            fused_sizes, fused_taken = step_fused()
+        for sl in range(n_res):
+            eng_f.sync(sl)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(dsteps):
+            fused_sizes, fused_taken = step_fused()
+        for sl in range(n_res):
+            eng_f.sync(sl)
+        fused_elapsed = max_over_ranks(time.perf_counter() - t0)
+        fused = {"ms_per_step": round(1000.0 * fused_elapsed / dsteps, 4), "mreads_s": round(reads_per_gpu * world / max(fused_elapsed / dsteps, 1e-9) / 1e6, 2),
+                 "placement_taken": bool(fused_taken), "same_sizes_as_device_step": [int(x) for x in fused_sizes] == [int(x) for x in sizes] if not args.spans_step_only else None,
+                 "what": "the text step on a context created with AQC_FUSED=1: fast_filter_overlap_kernel<10,true,12,false,true> gives every record its place "
+                         "(in-batch scans + decoupled look-back over the batches) and copies the good records that go out as their own bytes; aqc_format "
+                         "patches / rebuilds the rest (no sizing passes, no whole-record copy kernel)"}
+        eng_f.close()
     kms, klaunch = eng.timing_mean(0)
     for sl in range(1, n_res):
         k2, l2 = eng.timing_mean(sl)
@@ -684,6 +735,7 @@ def main():
                               "what": "the device step as aqc_pipe_run issues it for plain-text outputs: aqc_reframe -> aqc_run -> aqc_qc_stat -> aqc_format_spans "
                                       "— good records that go out as their own bytes are not copied on the device (the file writers take them from the "
                                       "page-locked input buffer), only the bad / trimmed / corrected records are formatted"},
+        "device_step_fused": fused,
         "device_step": {"ms_per_step": round(dev_ms, 4), "steps": dsteps, "text_in_gb_per_gpu": round(text_in / 1e9, 3),
                         "text_out_gb_per_gpu": round(text_out / 1e9, 3), "step_text_gb_s": round((text_in + text_out) / (dev_ms * 1e-3) / 1e9, 1),
                         "what": "text resident in HBM -> aqc_reframe -> aqc_run -> aqc_qc_stat -> aqc_format (no PCIe, no files), every rank on its own GPU"},

@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out; W=${1:-config3}; P=5000000; [ $W = config5 ] && P=3000000
 DST=${2:-gpurun_out/profile_summary_$W.txt}
 # EXTRA: more bench.py flags, e.g. --spans-step-only / --text-step-only (which variant of the device step the timed region runs)
-B="python $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --device-only --device-steps 10 --workload $W --pairs $P --no-pmc $EXTRA"
+B="python $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --device-only --device-steps 10 --workload $W --pairs $P --no-pmc --no-fused-step $EXTRA"
 rm -rf $OUT/prof_kt $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -o kt -- $B > /dev/null 2>&1)
 (cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -o f -- $B > /dev/null 2>&1)

@@ -3,7 +3,7 @@
 set -u
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
-B="python $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --device-only --device-steps 10 --workload config3 --pairs 5000000 --no-pmc"
+B="python $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 --device-only --device-steps 10 --workload config3 --pairs 5000000 --no-pmc --no-fused-step"
 for v in text spans ${KT_FUSED:+fused}; do
   rm -rf $OUT/kt_$v
   case $v in
