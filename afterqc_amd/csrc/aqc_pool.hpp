@@ -6,7 +6,9 @@
 //                  consumer for the translation of the sections it just committed); a section is work for later.  (The lanes
 //                  used to be served in turn: every other visit of a worker then cost the waiting consumer a 7 ms section —
 //                  up to a section per worker and chunk, which is what held `.gz -> .gz` at 33 Mreads/s whoever decoded.)
-//   help_front     the caller runs one queued front job itself instead of sleeping until a worker gets to it
+//   help_front     the caller runs one queued front job itself instead of sleeping until a worker gets to it — a job somebody
+//                  SUBMITTED, never the helper closure of another thread's parallel_for (that one loops until its whole batch
+//                  is done: the gunzip consumer would sit in a writer's deflate batch while its own data is ready)
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -51,7 +53,8 @@ public:
         if (th_.empty()) { job(); return; }
         {
             std::lock_guard<std::mutex> g(mu_);
-            (background ? bg_ : q_).push_back(std::move(job));
+            if (background) bg_.push_back(std::move(job));
+            else q_.push_back(Job{std::move(job), false});
         }
         cv_.notify_one();
     }
@@ -61,9 +64,11 @@ public:
         std::function<void()> job;
         {
             std::lock_guard<std::mutex> g(mu_);
-            if (q_.empty()) return false;
-            job = std::move(q_.front());
-            q_.pop_front();
+            auto it = q_.begin();
+            while (it != q_.end() && it->batch_helper) ++it;
+            if (it == q_.end()) return false;
+            job = std::move(it->fn);
+            q_.erase(it);
         }
         job();
         return true;
@@ -90,7 +95,7 @@ public:
         {
             std::lock_guard<std::mutex> g(mu_);
             for (size_t k = 0; k < helpers; ++k)
-                q_.push_back([b] {
+                q_.push_back(Job{[b] {
                     for (;;) {
                         const size_t i = b->next.fetch_add(1);
                         if (i >= b->n) break;
@@ -100,7 +105,7 @@ public:
                             b->cv.notify_all();
                         }
                     }
-                });
+                }, true});
         }
         cv_.notify_all();
         // the caller works too
@@ -123,7 +128,7 @@ private:
                 cv_.wait(lk, [&] { return stop_ || !q_.empty() || !bg_.empty(); });
                 const bool take_bg = !bg_.empty() && q_.empty();
                 if (take_bg) { job = std::move(bg_.front()); bg_.pop_front(); }
-                else if (!q_.empty()) { job = std::move(q_.front()); q_.pop_front(); }
+                else if (!q_.empty()) { job = std::move(q_.front().fn); q_.pop_front(); }
                 else if (stop_) return;
                 else continue;
             }
@@ -131,7 +136,12 @@ private:
         }
     }
     std::vector<std::thread> th_;
-    std::deque<std::function<void()>> q_, bg_;
+    struct Job {
+        std::function<void()> fn;
+        bool batch_helper;      // a parallel_for helper: runs until its batch is done (workers only, see help_front)
+    };
+    std::deque<Job> q_;
+    std::deque<std::function<void()>> bg_;
     std::mutex mu_;
     std::condition_variable cv_;
     bool stop_ = false;

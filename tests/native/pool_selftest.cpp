@@ -2,7 +2,8 @@
 //   * front jobs overtake queued background jobs: with every worker busy and both lanes full, all front jobs are started
 //     before any further background job is;
 //   * help_front() runs a queued front job on the calling thread and reports an empty lane;
-//   * parallel_for still completes with the pool saturated by background jobs.
+//   * parallel_for still completes with the pool saturated by background jobs;
+//   * help_front() never runs the helper closure of another thread's parallel_for.
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -56,6 +57,34 @@ int main() {
         printf("parallel_for under saturation: sum %ld  %s\n", sum.load(), ok2 ? "ok" : "FAIL");
         if (!ok2) ++failures;
         gate = 1;
+    }
+    {
+        // help_front never takes the helper closure of somebody else's parallel_for (it would sit in that batch until it is done):
+        // with the workers stuck, a thread in a long parallel_for has its helpers queued; the main thread's help_front must find only
+        // the job that was SUBMITTED — and report an empty lane afterwards although the helpers are still there.
+        aqc_host::Pool pool(2);
+        std::atomic<int> gate{0}, started{0}, batch_gate{0}, in_batch{0}, submitted_ran{0};
+        for (int i = 0; i < 2; ++i) pool.submit([&] { started++; while (!gate.load()) std::this_thread::sleep_for(microseconds(50)); }, true);
+        while (started.load() < 2) std::this_thread::sleep_for(microseconds(50));
+        const std::thread::id me = std::this_thread::get_id();
+        std::atomic<int> batch_on_me{0};
+        std::thread other([&] {
+            pool.parallel_for(8, [&](size_t) {
+                in_batch++;
+                if (std::this_thread::get_id() == me) batch_on_me++;
+                while (!batch_gate.load()) std::this_thread::sleep_for(microseconds(50));
+            });
+        });
+        while (in_batch.load() < 1) std::this_thread::sleep_for(microseconds(50));       // (its helpers are queued, it works on index 0)
+        pool.submit([&] { submitted_ran++; }, false);
+        int helped = 0;
+        while (pool.help_front()) ++helped;
+        const bool ok = helped == 1 && submitted_ran.load() == 1 && batch_on_me.load() == 0;
+        printf("help_front leaves parallel_for helpers alone: helped %d, batch indices run by the helper %d  %s\n", helped, batch_on_me.load(), ok ? "ok" : "FAIL");
+        if (!ok) ++failures;
+        batch_gate = 1;
+        gate = 1;
+        other.join();
     }
     if (failures) { printf("%d pool checks FAILED\n", failures); return 1; }
     printf("all pool checks passed\n");
