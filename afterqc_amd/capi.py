@@ -128,7 +128,7 @@ class PipeOpts(C.Structure):
 class PipeResult(C.Structure):
     """struct aqc_pipe_result"""
     _fields_ = [("records", C.c_uint64), ("chunks", C.c_uint64), ("bytes_out", C.c_uint64 * 6), ("anomaly", C.c_int32),
-                ("pad_", C.c_int32), ("seconds", C.c_double)] + [(k, C.c_double) for k in (
+                ("fused_chunks", C.c_int32), ("seconds", C.c_double)] + [(k, C.c_double) for k in (
                     "t_read", "t_count", "t_wait_ring", "t_frame", "t_kernels", "t_wait_set", "t_fetch", "t_write")]
 
     def breakdown(self):

@@ -722,6 +722,7 @@ struct OutChunk {
     uint64_t n = 0;
     bool last = false;
     bool fatal = false;          // upstream's run ends behind this chunk's n records (Run::dies_at_record)
+    bool fused = false;          // its records were placed by the verdict kernel (AQC_FUSED=1: aqc_format_fused)
     // plain-text output WITHOUT the copy nobody needs (aqc_format_spans): the good records that go out as their own bytes are
     // written straight from the chunk's input buffer, which therefore lives until the chunk is committed; sizes[0] / sizes[3]
     // are then only the rebuilt good records, good_total what the good files really get
@@ -1125,6 +1126,7 @@ struct Run {
                 for (int round = 0; ; ++round) {
                     const char* where = "aqc_format";
                     rc = use_spans ? aqc_format_spans(c, slot, n, opt->store_overlap, oc.sizes, n_ev) : aqc_format(c, slot, n, opt->store_overlap, oc.sizes);
+                    if (!rc) oc.fused = aqc_format_fused(c, slot) == 1;
                     if (!rc && !have_set) {
                         ns_kernels += now_ns() - tt;
                         tt = now_ns();
@@ -1337,6 +1339,7 @@ struct Run {
                         if (to_file[q] && out[q].fd >= 0) fileq[q]->push(cm);
                 }
                 res->chunks += 1;
+                res->fused_chunks += cur.fused ? 1 : 0;
                 ++next;
                 if (cur.fatal) fatal_commit = cm;
                 if (cur.last) { done = true; break; }

@@ -588,6 +588,7 @@ class seqFilter:
             return None
         self.timing["pipe_s"] = res.seconds
         self.timing["pipe_threads"] = res.breakdown()
+        self.timing["pipe_chunks"] = (int(res.chunks), int(res.fused_chunks))       # (all, placed by the verdict kernel: AQC_FUSED=1)
         return 0
 
     # ---- pass 2, text path with index files (-7 / -5): four lock-stepped inputs, two device slots ---------------------

@@ -434,7 +434,7 @@ typedef struct aqc_pipe_result {
     uint64_t chunks;
     uint64_t bytes_out[6];         /* [file * 3 + stream] */
     int32_t anomaly;               /* the input is not of the regular shape: outputs and statistics are incomplete */
-    int32_t pad_;
+    int32_t fused_chunks;          /* chunks whose records the verdict kernel placed itself (contexts created with AQC_FUSED=1) */
     double seconds;
     /* where the time went, summed over the threads of each kind (seconds): reader file reads / newline counts / waits for a
      * free input buffer; slot workers in aqc_frame (upload + framing) / run + QC + format / waits for an output buffer set /

@@ -124,3 +124,35 @@ def test_fused_then_partial_and_span_formats(gpu_engine, fused_engine):
             assert fetch(eng, 0, sz_b, q) == fetch(ref, 0, sz_a, q), (m, store, q)
     eng.reset_stats()
     ref.reset_stats()
+
+
+def test_fused_contexts_sharing_one_device_through_the_pipe(tmp_path):
+    """four contexts on ONE device, all created with AQC_FUSED=1, over one 600 k-pair input: their verdict kernels — persistent grids
+    with in-order look-backs — compete for the same CUs (a workgroup of one only starts where a workgroup of another has finished),
+    the chunks are 20 000 records: byte-identical files and an identical statistics JSON to the plain one-context run"""
+    from test_gpu_pipe import run
+    work = str(tmp_path)
+    n = 600_000
+    d = synth.make_pairs(n, 150, seed=7813, workers=4)
+    r1, r2 = os.path.join(work, "R1.fq"), os.path.join(work, "R2.fq")
+    synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
+    synth.write_fastq_fixed(r2, d["seq2"], d["qual2"], 2)
+    del d
+    extra = ["-f", "0", "-t", "0"]
+    a_files, a_stat, a = run(work, r1, r2, extra, tag="plain", use_pipe=True, devices=[0], chunk_records=1 << 15)
+    old = os.environ.get("AQC_FUSED")
+    os.environ["AQC_FUSED"] = "1"
+    try:
+        b_files, b_stat, b = run(work, r1, r2, extra, tag="fused4", use_pipe=True, devices=[0] * 4, chunk_records=20000, pipe_slots=3)
+    finally:
+        if old is None:
+            os.environ.pop("AQC_FUSED", None)
+        else:
+            os.environ["AQC_FUSED"] = old
+    assert a.used_pipe and b.used_pipe
+    assert a_files == b_files
+    assert a_stat == b_stat
+    assert a_stat["afterqc_main_summary"]["total_reads"] == n
+    chunks, fused_chunks = b.timing["pipe_chunks"]
+    assert chunks >= n // 20000 and fused_chunks == chunks, (chunks, fused_chunks)       # (no pair of this input is deferred)
+    assert a.timing["pipe_chunks"][1] == 0
