@@ -654,8 +654,7 @@ int aqc_run(aqc_ctx* c, int slot, uint64_t accum_limit) {
             return fail(AQC_ERR_HIP, "hipMalloc failed");
         // AQC_FUSED=1: pairs of device-framed text whose records are plain four-line text are placed in their output
         // streams by the verdict kernel itself, which also copies the good records that go out as their own bytes
-        const bool fuse_ok = c->fuse_opt && s->framed && cfg.paired && !cfg.barcode && s->max_len <= 160 && cfg.unqualified_base_limit > 0 &&
-                             !s->has_irregular && s->consumed[0] + 16 * s->n < (1ull << 31) && s->consumed[1] + 16 * s->n < (1ull << 31);      // (31-bit stream offsets; a bad record grows by its flag text)
+        const bool fuse_ok = c->fuse_opt && s->framed && cfg.paired && !cfg.barcode && s->max_len <= 160 && !s->has_irregular && s->consumed[0] + 16 * s->n < (1ull << 31) && s->consumed[1] + 16 * s->n < (1ull << 31);      // (31-bit stream offsets; a bad record grows by its flag text)
         if (fuse_ok) {
             constexpr uint64_t PPW = FastWaveLds<10, true, true>::PPW;
             const uint64_t n_batches = (s->n + PPW - 1) / PPW;

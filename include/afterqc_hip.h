@@ -346,8 +346,8 @@ int aqc_fetch_span_events(aqc_ctx* ctx, int slot, int file, aqc_span_event* dst,
 /* the chunk bytes of each file up to the end of record n - 1 of a framed slot (n == the slot's record count: consumed1 / consumed2):
  * where the last piece of an aqc_format_spans output ends when only the first n records are written */
 int aqc_span_end(aqc_ctx* ctx, int slot, uint64_t n, uint64_t end[2]);
-/* AQC_FUSED=1 in the environment of aqc_create (opt-in): for 2 x <= 160 pairs framed by aqc_frame, without barcodes and
- * with the low-quality filter on, aqc_run's verdict kernel also places every record in its output stream and copies the good
+/* AQC_FUSED=1 in the environment of aqc_create (opt-in): for 2 x <= 160 pairs framed by aqc_frame, without barcodes,
+ * aqc_run's verdict kernel also places every record in its output stream and copies the good
  * records that go out as their own bytes; aqc_format(n = all records, store_overlap = 0) then only rebuilds the rest.  Same bytes
  * either way (seqFilter.writeReads, preprocesser.py:206-232).  1: the slot's last aqc_format took that placement, 0: it did not
  * (not eligible, or the kernel gave the placement up: a deferred pair, CR LF / blank-padded lines), < 0: error. */

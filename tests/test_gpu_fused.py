@@ -57,7 +57,8 @@ CASES = {
     "strict_quality": (dict(qualified_quality_phred=36, unqualified_base_limit=20), dict(), 5000, True),
     "ragged": (dict(), dict(ragged=True), 5000, None),          # (reads under 5 / 31 bases defer: either way is right)
     "crlf_lines": (dict(), dict(crlf_every=5), 2000, False),
-    "no_quality_filter": (dict(unqualified_base_limit=0), dict(), 2000, False),
+    "no_quality_filter": (dict(unqualified_base_limit=0), dict(), 2000, True),
+    "exotic_base": (dict(), dict(), 3000, False),               # (one '.' among the bases: that pair is the general kernel's, the chunk the other writer's)
 }
 
 
@@ -65,6 +66,10 @@ CASES = {
 def test_fused_placement_equals_the_two_step_writer(case, gpu_engine, fused_engine):
     opts, tk, n, must = CASES[case]
     t1, t2 = texts(n, 7300 + len(case), **tk)
+    if case == "exotic_base":
+        rec = t1.index(b"\n@SIM", len(t1) // 2) + 1                            # a record in the middle of file 1 ...
+        at = t1.index(b"\n", rec) + 21                                         # ... base 20 of its sequence line
+        t1 = t1[:at] + b"." + t1[at + 1:]
     n_a, want, cnt_a, _ = six_streams(gpu_engine, t1, t2, cfg_default(**opts))
     assert not gpu_engine.format_fused(0)
     n_b, got, cnt_b, deferred = six_streams(fused_engine, t1, t2, cfg_default(**opts))
@@ -72,6 +77,8 @@ def test_fused_placement_equals_the_two_step_writer(case, gpu_engine, fused_engi
     if must is not None:
         # (a chunk with a pair the general kernel has to finish is not placed by the verdict kernel)
         assert fused_engine.format_fused(0) == (must and deferred == 0), (case, deferred)
+    if case == "exotic_base":
+        assert deferred >= 1
     for q in range(6):
         assert got[q] == want[q], (case, q, len(got[q]), len(want[q]))
     assert (cnt_a == cnt_b).all()
