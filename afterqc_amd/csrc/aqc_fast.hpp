@@ -267,8 +267,10 @@ struct BarcodeCodes {
 struct FuseArgs {
     const uint32_t *name_off1, *name_off2;       // where each record starts in its file's text
     uint8_t *out1, *out2;                        // the good streams
-    uint32_t *fstate1, *fstate2;                 // per record and file: position in its stream | FUSE_WHOLE (already written here)
-    unsigned long long* state;                   // [2 * batches]: flag (2 bits) | good1 (31) | good2 (31), flag | bad1 | bad2
+    uint32_t *fstate1, *fstate2;                 // per record and file: offset inside its batch's share of its stream (16 bits) | FUSE_WHOLE (its own
+                                                 // bytes, written here) | FUSE_PATCH (... but for the walk's byte patches, which the plan pass stores)
+    unsigned long long* state;                   // [2 * batches]: flag (2 bits) | good1 (31) | good2 (31), flag | bad1 | bad2: the batch's sums (A), then
+                                                 // — final — the streams' bytes up to and including the batch (P): the plan pass reads those
     unsigned int* ticket;                        // rounds handed out (a round = WPBT consecutive batches)
     int* abort;                                  // != 0: this placement is void — a deferred pair, a record that is not contiguous text, a
                                                  // look-back that ran out of patience: the host formats the chunk the other way
