@@ -1223,8 +1223,11 @@ public:
         cv_.notify_all();
         for (auto& l : lanes_) if (l.th.joinable()) l.th.join();
         (void)hipSetDevice(device_);
+        const double t0 = now_s();
         for (auto& l : lanes_) { l.release(); if (l.stage) aqc_host_free(l.stage); }
+        const double t1 = now_s();
         for (auto& a : arenas_) if (a.p) aqc_host_free(a.p);
+        if (debug()) fprintf(stderr, "[gz dev %d] tear-down: lanes %.3f s, arenas %.3f s\n", device_, t1 - t0, now_s() - t1);
     }
     bool start() {
         if (hipSetDevice(device_) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -1282,6 +1285,9 @@ private:
     // (two lanes: one group is uploaded / downloaded while the other decodes; a third gave nothing measurable (gpurun_out/r4c30) and
     //  a lane's device buffers are ~15 GB for groups of 96 MiB: symbol and token space for 12 x expansion)
     static constexpr int N_LANES = 2, N_ARENAS = 6;
+    // AQC_GZ_DEBUG=1: what the decoder's set-up and tear-down cost (device buffers, page-locked staging and arenas), on stderr
+    static bool debug() { static const bool d = getenv("AQC_GZ_DEBUG") && getenv("AQC_GZ_DEBUG")[0] == '1'; return d; }
+    static double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
     struct Group {
         const uint8_t* data; size_t size; int n;
         std::vector<uint64_t> nominal, stop;
@@ -1356,7 +1362,9 @@ private:
                     lk.unlock();
                     if (a.p) aqc_host_free(a.p);
                     const size_t want = need + need / 4 + (8u << 20);
+                    const double t0 = now_s();
                     a.p = (uint8_t*)aqc_host_alloc(want);
+                    if (debug()) fprintf(stderr, "[gz dev %d] arena %d: %.0f MiB page-locked in %.3f s\n", device_, pick, want / 1048576.0, now_s() - t0);
                     a.cap = a.p ? want : 0;
                     lk.lock();
                     if (!a.p) { a.filling = false; return -1; }
@@ -1382,6 +1390,7 @@ private:
         const uint32_t s_symcap = (uint32_t)std::min<uint64_t>((sec_max * 24 + (2u << 20) + 7) & ~(uint64_t)7, 0xfffffff0u);
         const uint64_t s_sym_total = (uint64_t)span * 12 + (uint64_t)n * 64 + (1u << 20);
         const uint64_t blk_sym_cap = gzb_sym_budget(span, GZB_RATIO_CAP);
+        const double t_res0 = now_s();
         if (L.comp.reserve(span + 512) || L.tile_cnt.reserve(4ull * n_tiles) || L.tile_cand.reserve(4ull * n_tiles * GZB_TILE_CAND) || L.n_cand.reserve(64) ||
             L.c_start.reserve(4ull * cand_cap) || L.c_end.reserve(4ull * cand_cap) || L.c_nsym.reserve(4ull * cand_cap) || L.c_flags.reserve(4ull * cand_cap) ||
             L.c_symoff.reserve(8ull * cand_cap) || L.c_symcap.reserve(4ull * cand_cap) || L.blk_sym.reserve(2ull * blk_sym_cap + 64) ||
@@ -1390,12 +1399,21 @@ private:
             L.tables.reserve(4ull * cand_cap * GZB_TAB_WORDS) || L.s_in.reserve(12ull * n) || L.s_out.reserve(16ull * n) || L.s_off.reserve(8ull * (n + 1)) ||
             L.s_blocks.reserve(12ull * n * GZB_SEC_BLOCKS) || L.s_sym.reserve(2ull * s_sym_total + 64))
             return false;
+        if (debug()) {
+            size_t tot = 0;
+            DevBuf* b[] = {&L.comp, &L.tile_cnt, &L.tile_cand, &L.n_cand, &L.c_start, &L.c_end, &L.c_nsym, &L.c_flags, &L.c_symoff, &L.c_symcap, &L.blk_sym, &L.tables, &L.blk_tp, &L.c_lanes, &L.l_u32, &L.s_in, &L.s_out, &L.s_blocks, &L.s_sym, &L.s_off};
+            for (DevBuf* x : b) tot += x->cap;
+            fprintf(stderr, "[gz dev %d] group of %.1f MiB compressed, %d sections: device buffers now %.2f GiB (blk_sym %.2f, blk_tp %.2f, s_sym %.2f, tables %.2f, l_u32 %.2f), reserve %.3f s\n", device_,
+                    span / 1048576.0, n, tot / 1073741824.0, L.blk_sym.cap / 1073741824.0, L.blk_tp.cap / 1073741824.0, L.s_sym.cap / 1073741824.0, L.tables.cap / 1073741824.0, L.l_u32.cap / 1073741824.0, now_s() - t_res0);
+        }
         // the compressed bytes: out of the (pageable, possibly not yet faulted-in) file mapping into page-locked memory with a few
         // threads side by side, then one DMA — a copy straight from the mapping runs at the page-fault rate of one thread
         if (L.stage_cap < span) {
             if (L.stage) aqc_host_free(L.stage);
             L.stage_cap = span + span / 8 + (1u << 20);
+            const double t0 = now_s();
             L.stage = (uint8_t*)aqc_host_alloc(L.stage_cap);
+            if (debug()) fprintf(stderr, "[gz dev %d] stage: %.0f MiB page-locked in %.3f s\n", device_, L.stage_cap / 1048576.0, now_s() - t0);
             if (!L.stage) { L.stage_cap = 0; return false; }
         }
         {
