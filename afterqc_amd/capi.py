@@ -106,6 +106,11 @@ class TextChunk(C.Structure):
                 ("final1", C.c_int32), ("final2", C.c_int32), ("max_records", C.c_uint64), ("first_index", C.c_uint64)]
 
 
+class TextExtent(C.Structure):
+    """struct aqc_text_extent: a stretch of a chunk whose bytes are in device memory already (aqc_frame_mixed)"""
+    _fields_ = [("offset", C.c_uint64), ("bytes", C.c_uint64), ("device_text", C.c_void_p)]
+
+
 class FrameInfo(C.Structure):
     """struct aqc_frame_info"""
     _fields_ = [("n", C.c_uint64), ("avail1", C.c_uint64), ("avail2", C.c_uint64), ("consumed1", C.c_uint64),
@@ -128,7 +133,7 @@ class PipeOpts(C.Structure):
 class PipeResult(C.Structure):
     """struct aqc_pipe_result"""
     _fields_ = [("records", C.c_uint64), ("chunks", C.c_uint64), ("bytes_out", C.c_uint64 * 6), ("anomaly", C.c_int32),
-                ("fused_chunks", C.c_int32), ("seconds", C.c_double)] + [(k, C.c_double) for k in (
+                ("fused_chunks", C.c_int32), ("extra_bases", C.c_uint64), ("seconds", C.c_double)] + [(k, C.c_double) for k in (
                     "t_read", "t_count", "t_wait_ring", "t_frame", "t_kernels", "t_wait_set", "t_fetch", "t_write")]
 
     def breakdown(self):
@@ -363,6 +368,9 @@ def load_library():
     lib.aqc_read_stats.argtypes = [P, C.POINTER(BatchStruct), C.c_int32, C.c_int32, C.c_int32, P, P, P]
     lib.aqc_edit_distance.argtypes = [P, C.POINTER(BatchStruct), P]
     lib.aqc_frame.argtypes = [P, C.c_int, C.POINTER(TextChunk), C.POINTER(FrameInfo)]
+    lib.aqc_frame_mixed.argtypes = [P, C.c_int, C.POINTER(TextChunk), C.POINTER(TextExtent), C.c_uint64, C.c_uint8, C.POINTER(TextExtent), C.c_uint64, C.c_uint8,
+                                    C.POINTER(FrameInfo)]
+    lib.aqc_frame_mixed.restype = C.c_int
     lib.aqc_reframe.argtypes = [P, C.c_int, C.POINTER(FrameInfo)]
     lib.aqc_reframe.restype = C.c_int
     lib.aqc_format.argtypes = [P, C.c_int, C.c_uint64, C.c_int32, P]
@@ -413,10 +421,10 @@ def load_library():
     for name in ("aqc_create", "aqc_device_name", "aqc_set_config", "aqc_set_circles", "aqc_reset_stats", "aqc_upload",
                  "aqc_run", "aqc_qc_stat", "aqc_fetch_results", "aqc_sync", "aqc_kernel_ms", "aqc_timing_reset",
                  "aqc_timing_mean", "aqc_get_counters", "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers",
-                 "aqc_overlap", "aqc_read_stats", "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_plain",
+                 "aqc_overlap", "aqc_read_stats", "aqc_edit_distance", "aqc_frame", "aqc_frame_mixed", "aqc_reframe", "aqc_format", "aqc_format_plain",
                  "aqc_fetch_text", "aqc_fetch_quality_views", "aqc_error_record", "aqc_format_spans", "aqc_fetch_span_events", "aqc_span_end", "aqc_format_fused"):
         getattr(lib, name).restype = C.c_int
-    if lib.aqc_abi_version() != 2:
+    if lib.aqc_abi_version() != 3:
         raise RuntimeError("libafterqc_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -427,7 +435,7 @@ EXPORTED_SYMBOLS = ["aqc_abi_version", "aqc_device_count", "aqc_device_index", "
                     "aqc_qc_stat", "aqc_fetch_results", "aqc_fetch_quality_views", "aqc_error_record", "aqc_sync", "aqc_last_deferred", "aqc_kernel_ms", "aqc_timing_reset",
                     "aqc_timing_mean", "aqc_get_counters",
                     "aqc_get_histograms", "aqc_get_qc", "aqc_get_kmers", "aqc_overlap", "aqc_read_stats",
-                    "aqc_edit_distance", "aqc_frame", "aqc_reframe", "aqc_format", "aqc_format_spans", "aqc_fetch_span_events", "aqc_span_end", "aqc_format_fused", "aqc_format_plain", "aqc_fetch_text", "aqc_fetch_streams", "aqc_compress", "aqc_fetch_gz", "aqc_gunzip_dev", "aqc_host_alloc",
+                    "aqc_edit_distance", "aqc_frame", "aqc_frame_mixed", "aqc_reframe", "aqc_format", "aqc_format_spans", "aqc_fetch_span_events", "aqc_span_end", "aqc_format_fused", "aqc_format_plain", "aqc_fetch_text", "aqc_fetch_streams", "aqc_compress", "aqc_fetch_gz", "aqc_gunzip_dev", "aqc_host_alloc",
                     "aqc_host_free",
                     "aqc_pipe_create", "aqc_pipe_destroy", "aqc_pipe_run", "aqc_pipe_last_error",
                     "aqc_host_count_newlines", "aqc_bgzf_compress", "aqc_pipe_split",

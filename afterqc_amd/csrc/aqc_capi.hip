@@ -206,7 +206,10 @@ static int check_status(Slot& sl) {
         (void)hipMemcpyAsync(sl.status, &STATUS_CLEAR, sizeof(STATUS_CLEAR), hipMemcpyHostToDevice, sl.stream);
         (void)hipStreamSynchronize(sl.stream);
         sl.err_record = UINT64_MAX;
-        if (w.err_key != ~0ull) {
+        // (a hard device error raised first — a read beyond AQC_MAX_READ_LEN, a device limit — is reported as what it is: the records
+        //  in front of a record-tied error are NOT valid then, and aqc_error_record stays unset; round-5 advisory)
+        const bool record_kind = st == AQC_ERR_INDEX || st == AQC_ERR_ALPHABET || st == AQC_ERR_ARG;
+        if (w.err_key != ~0ull && record_kind) {
             // an exception inside upstream's loop: the run ends at the EARLIEST record that raises, whatever raised first here
             sl.err_record = w.err_key >> 8;
             st = -(int)(w.err_key & 0xffu);
@@ -798,7 +801,8 @@ int aqc_qc_stat(aqc_ctx* c, int slot, int which, int mate, uint64_t first, uint6
 }
 
 // ---- text in / text out -----------------------------------------------------------------------------------------
-static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* info, bool resident) {
+struct FrameExtents { const aqc_text_extent* ext[2]; uint64_t n[2]; uint8_t last[2]; };
+static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* info, bool resident, const FrameExtents* fx = nullptr) {
     Slot* s;
     int rc = get_slot(c, slot, &s);
     if (rc) return rc;
@@ -830,7 +834,20 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
         const size_t slack = IDX_TILE + 64;
         if (arena[k]->reserve(TEXT_FRONT + bytes[k] + slack)) return fail(AQC_ERR_HIP, "hipMalloc of %llu bytes failed", (unsigned long long)bytes[k]);
         tbase[k] = (uint8_t*)arena[k]->p + TEXT_FRONT;
-        if (!resident) {
+        if (!resident && fx && fx->n[k]) {
+            // parts of the chunk are in this device's memory already (aqc_frame_mixed): those move inside HBM, the rest comes up
+            uint64_t cur = 0;
+            for (uint64_t e = 0; e < fx->n[k]; ++e) {
+                const aqc_text_extent& x = fx->ext[k][e];
+                if (x.offset < cur || x.offset + x.bytes > bytes[k] || !x.device_text) return fail(AQC_ERR_ARG, "aqc_frame_mixed: extents must be sorted, disjoint and inside the chunk");
+                if (x.offset > cur) HIP_TRY(hipMemcpyAsync(tbase[k] + cur, text[k] + cur, x.offset - cur, hipMemcpyHostToDevice, s->stream));
+                if (x.bytes) HIP_TRY(hipMemcpyAsync(tbase[k] + x.offset, x.device_text, x.bytes, hipMemcpyDeviceToDevice, s->stream));
+                cur = x.offset + x.bytes;
+            }
+            if (bytes[k] > cur) HIP_TRY(hipMemcpyAsync(tbase[k] + cur, text[k] + cur, bytes[k] - cur, hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(hipMemsetAsync(tbase[k] + bytes[k], 0, slack, s->stream));
+            s->last_byte[k] = bytes[k] ? fx->last[k] : (uint8_t)'\n';
+        } else if (!resident) {
             if (bytes[k]) HIP_TRY(hipMemcpyAsync(tbase[k], text[k], bytes[k], hipMemcpyHostToDevice, s->stream));
             HIP_TRY(hipMemsetAsync(tbase[k] + bytes[k], 0, slack, s->stream));
             s->last_byte[k] = bytes[k] ? text[k][bytes[k] - 1] : (uint8_t)'\n';
@@ -962,6 +979,13 @@ static int frame_impl(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_
 }
 
 int aqc_frame(aqc_ctx* c, int slot, const aqc_text_chunk* ch, aqc_frame_info* info) { return frame_impl(c, slot, ch, info, false); }
+
+int aqc_frame_mixed(aqc_ctx* c, int slot, const aqc_text_chunk* ch, const aqc_text_extent* ext1, uint64_t n_ext1, uint8_t last1,
+                    const aqc_text_extent* ext2, uint64_t n_ext2, uint8_t last2, aqc_frame_info* info) {
+    if ((n_ext1 && !ext1) || (n_ext2 && !ext2)) return fail(AQC_ERR_ARG, "aqc_frame_mixed: null extent list");
+    const FrameExtents fx{{ext1, ext2}, {n_ext1, ch && ch->text2 ? n_ext2 : 0}, {last1, last2}};
+    return frame_impl(c, slot, ch, info, false, &fx);
+}
 
 int aqc_reframe(aqc_ctx* c, int slot, aqc_frame_info* info) {
     Slot* s;
@@ -1202,19 +1226,35 @@ int aqc_fetch_gz(aqc_ctx* c, int slot, int file, int stream, uint8_t* dst, uint6
 
 // ---- gzip input on the device (aqc_gunzip_dev.hpp) ------------------------------------------------------------------------------
 // DeviceInflate: the SectionOffload of aqc_gz.hpp.  A group of consecutive sections = one window of the compressed file = one
-// pass of scan -> compact -> decode -> chain -> gather on one of two LANES (own thread, own stream, own device buffers: a group
-// is uploaded while the other decodes).  The symbols come back into page-locked arenas that the sections keep until the host
-// has translated them.
+// pass of scan -> compact -> decode -> chain -> gather.
+//
+// Round 6.  (1) What a group needs on the device is sized by NEED, not by the worst case: symbols for 6 x its compressed bytes
+// (FASTQ expands 3 - 5 x; rounds 4 - 5: 12 x), token entries for 1 per compressed byte + 512 per lane (FASTQ: 0.5 - 0.6 per byte;
+// they used to share the symbols' 12 x), one set of decode buffers per decoder instead of one per lane — 2.3 GB for groups of 62 MiB where there were
+// two lanes of 9.5 - 10 GB — and they are allocated in the BACKGROUND when the stream announces its group size (prepare()):
+// ready() stays false until they exist, so the pool keeps every section until then and nobody waits for a hipMalloc (16 ms per
+// GB).  A group that overflows the lean budget comes back short, the host decodes what is missing, and the budgets double for the
+// groups after it.  (2) The two lane threads share the decode buffers: one copies its group's compressed bytes out of the file
+// mapping into its page-locked stage while the other's kernels run.  (3) RESIDENT results (the default): the sections' symbols
+// stay in HBM, in a result set the sections hold until they are dropped; when the consumer arrives with the window before a run
+// of them, resolve() turns the symbols into text and computes the CRC-32 of every section there (gzb_windows_kernel,
+// gzb_resolve_kernel, gzb_crc_kernel) and fetch() copies text straight to where the consumer wants it.  PCIe carries one byte per
+// byte of text instead of two, and the host's 2.2 CPU-seconds per 10 M reads of marker translation + CRC-32 are gone.
+// AQC_GZ_RESIDENT=0: the symbols come back into page-locked arenas and the host translates them, as in rounds 4 - 5.
 namespace {
 
 std::atomic<uint64_t> g_gzb_stats[8];
+std::atomic<uint64_t> g_gzb_resolve_stats[4];       // runs resolved, their sections, microseconds in resolve(), bytes of text resolved
 
 constexpr size_t GZB_SLACK = 4u << 20;              // compressed bytes uploaded behind the last section's stop bit (its last block ends there)
-constexpr uint32_t GZB_RATIO_CAP = 12;
 
 class DeviceInflate : public aqcgz::SectionOffload {
 public:
-    DeviceInflate(int device, size_t group_bytes) : device_(device), group_bytes_(std::min<size_t>(std::max<size_t>(group_bytes, 1u << 20), 448u << 20)) {}
+    DeviceInflate(int device, size_t group_bytes) : device_(device), group_bytes_(std::min<size_t>(std::max<size_t>(group_bytes, 1u << 20), 448u << 20)) {
+        if (const char* e = getenv("AQC_GZ_RESIDENT")) resident_ = e[0] != '0';
+        if (const char* e = getenv("AQC_GZ_RATIO")) ratio_ = (uint32_t)std::max(2, std::min(64, atoi(e)));
+        if (const char* e = getenv("AQC_GZ_TOK_RATIO")) tok_ratio_ = (uint32_t)std::max(1, std::min(16, atoi(e)));
+    }
     ~DeviceInflate() override {
         {
             std::lock_guard<std::mutex> g(mu_);
@@ -1224,30 +1264,54 @@ public:
         for (auto& l : lanes_) if (l.th.joinable()) l.th.join();
         (void)hipSetDevice(device_);
         const double t0 = now_s();
-        for (auto& l : lanes_) { l.release(); if (l.stage) aqc_host_free(l.stage); }
+        if (dev_.stream) (void)hipStreamSynchronize(dev_.stream);
+        if (rs_stream_) (void)hipStreamSynchronize(rs_stream_);
+        dev_.release();
+        for (auto& r : res_) { r.sym.release(); r.text.release(); }
+        rs_wins_.release(); rs_tab_.release(); rs_crc_tab_.release();
+        if (rs_stream_) (void)hipStreamDestroy(rs_stream_);
+        for (auto& l : lanes_) if (l.stage) aqc_host_free(l.stage);
+        if (rs_pin_) aqc_host_free(rs_pin_);
         const double t1 = now_s();
         for (auto& a : arenas_) if (a.p) aqc_host_free(a.p);
-        if (debug()) fprintf(stderr, "[gz dev %d] tear-down: lanes %.3f s, arenas %.3f s\n", device_, t1 - t0, now_s() - t1);
+        if (debug()) fprintf(stderr, "[gz dev %d] tear-down: device buffers + stages %.3f s, arenas %.3f s\n", device_, t1 - t0, now_s() - t1);
     }
     bool start() {
         if (hipSetDevice(device_) != hipSuccess) { (void)hipGetLastError(); return false; }
-        // (the lowest stream priority: where a decoder slice and a kernel of the filter compete for the chip, the filter goes first)
+        // (the lowest stream priority: where a decoder slice and a kernel of the filter compete for the chip, the filter goes first;
+        //  the resolve stream, which the consumer WAITS for, gets the highest)
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        if (const char* e = getenv("AQC_GZ_PRIO")) { if (e[0] == '0') prio_lo = 0; else if (e[0] == '2') prio_lo = prio_hi; }      // (experiments: 0 normal, 2 highest)
-        for (auto& l : lanes_) {
-            if (hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, prio_lo) != hipSuccess) return false;
-            for (auto& e : l.ev) if (hipEventCreate(&e) != hipSuccess) return false;
-        }
+        int prio_dec = prio_lo;
+        if (const char* e = getenv("AQC_GZ_PRIO")) { if (e[0] == '0') prio_dec = 0; else if (e[0] == '2') prio_dec = prio_hi; }      // (experiments: 0 normal, 2 highest)
+        if (hipStreamCreateWithPriority(&dev_.stream, hipStreamNonBlocking, prio_dec) != hipSuccess) return false;
+        for (auto& e : dev_.ev) if (hipEventCreate(&e) != hipSuccess) return false;
+        if (hipStreamCreateWithPriority(&rs_stream_, hipStreamNonBlocking, prio_hi) != hipSuccess) return false;
         for (int i = 0; i < N_LANES; ++i) lanes_[i].th = std::thread([this, i] { loop(i); });
         return true;
     }
     size_t group_bytes() const override { return group_bytes_; }
     bool ready() override {
         std::lock_guard<std::mutex> g(mu_);
-        if (broken_ || stop_) return false;
+        if (broken_ || stop_ || !prepared_) return false;
         for (auto& l : lanes_) if (!l.job) return true;
         return false;
+    }
+    bool gave_up() override {
+        std::lock_guard<std::mutex> g(mu_);
+        return broken_ || stop_;
+    }
+    // the stream's groups will be about this big: the decode buffers are set up by a lane thread, ready() is false until they are
+    void prepare(size_t group_bytes) override {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            const size_t want = std::min(group_bytes, group_bytes_);
+            if (prepared_ && want <= prepared_for_) return;
+            if (want > prepare_want_) prepare_want_ = want;
+            // (a decoder that has worked before takes groups at once and grows its buffers on the way, as it always did)
+            if (prepared_for_ == 0 && !prepare_busy_) prepared_ = false;
+        }
+        cv_.notify_all();
     }
     bool submit(const uint8_t* data, size_t size, int n, const uint64_t* nominal, const uint64_t* stop, const uint8_t* exact,
                 std::function<void(int, const aqcgz::OffloadResult&)> done) override {
@@ -1275,16 +1339,141 @@ public:
         Token* t = (Token*)token;
         {
             std::lock_guard<std::mutex> g(mu_);
-            arenas_[t->arena].refs--;
+            if (t->res >= 0) res_[t->res].refs--;
+            else arenas_[t->arena].refs--;
         }
         cv_.notify_all();
         delete t;
     }
 
+    // ---- resident results: the consumer has arrived with the window before a run of this decoder's sections ----------------------
+    const uint8_t* text_ptr(void* token, int* device) override {
+        const Token* t = (const Token*)token;
+        if (t->res < 0) return nullptr;
+        Res& R = res_[t->res];
+        if (t->k < 0 || (size_t)t->k >= R.nsym.size()) return nullptr;
+        if (device) *device = device_;
+        return (const uint8_t*)R.text.p + R.off[(size_t)t->k];
+    }
+    int resolve(void* const* tokens, int n, const uint8_t* win, size_t wlen, uint32_t* crc, uint8_t* tail, size_t* tail_len, uint32_t* piece_nl) override {
+        if (n <= 0 || wlen > GZB_WINDOW) return -2;
+        const double t0 = now_s();
+        std::lock_guard<std::mutex> rg(rs_mu_);
+        if (hipSetDevice(device_) != hipSuccess) { (void)hipGetLastError(); return -2; }
+        const Token* t0k = (const Token*)tokens[0];
+        if (t0k->res < 0) return -2;
+        Res& R = res_[t0k->res];
+        // the run's table: first symbol and length of each section, then the CRC pieces (64 KiB, right-aligned in their section)
+        uint32_t n_pieces = 0, max_n = 0;
+        uint64_t total = 0;
+        for (int k = 0; k < n; ++k) {
+            const Token* t = (const Token*)tokens[k];
+            if (t->res != t0k->res || t->k < 0 || (size_t)t->k >= R.nsym.size()) return -2;
+            const uint32_t ns = R.nsym[(size_t)t->k];
+            n_pieces += (ns + GZB_CRC_PIECE - 1u) / GZB_CRC_PIECE;
+            max_n = std::max(max_n, ns);
+            total += ns;
+        }
+        // device side of the table: off[n] (u64) | nsym[n] | piece_sec[P] | piece_idx[P] | piece_crc[P] | piece_nl[P] | bad
+        const size_t o_nsym = 8ull * n, o_psec = o_nsym + 4ull * n, o_pidx = o_psec + 4ull * n_pieces, o_pcrc = o_pidx + 4ull * n_pieces, o_pnl = o_pcrc + 4ull * n_pieces,
+                     o_bad = o_pnl + 4ull * n_pieces;
+        const size_t tab_bytes = (o_bad + 4 + 15) & ~(size_t)15;
+        const size_t pin_need = tab_bytes + GZB_WINDOW * 2;
+        if (rs_pin_cap_ < pin_need) {
+            if (rs_pin_) aqc_host_free(rs_pin_);
+            rs_pin_cap_ = pin_need + pin_need / 2 + (1u << 20);
+            rs_pin_ = (uint8_t*)aqc_host_alloc(rs_pin_cap_);
+            if (!rs_pin_) { rs_pin_cap_ = 0; return -2; }
+        }
+        if (rs_tab_.reserve(tab_bytes) || rs_wins_.reserve((size_t)(n + 1) * GZB_WINDOW)) { (void)hipGetLastError(); return -2; }
+        if (!rs_crc_tab_.p) {
+            uint32_t tab[GZB_CRC_TAB_WORDS];
+            auto advance = [](uint32_t x, uint64_t len) { return (uint32_t)crc32_combine((uLong)x, 0UL, (z_off_t)len); };
+            gzb_crc_tables(tab, advance);
+            for (int j = 0; j < 32; ++j) adv_piece_[j] = advance(1u << j, GZB_CRC_PIECE);
+            if (rs_crc_tab_.reserve(sizeof(tab)) || hipMemcpy(rs_crc_tab_.p, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); rs_crc_tab_.release(); return -2; }
+        }
+        uint8_t* const pin = rs_pin_;
+        uint64_t* const h_off = (uint64_t*)pin;
+        uint32_t* const h_nsym = (uint32_t*)(pin + o_nsym);
+        uint32_t* const h_psec = (uint32_t*)(pin + o_psec);
+        uint32_t* const h_pidx = (uint32_t*)(pin + o_pidx);
+        {
+            uint32_t p = 0;
+            for (int k = 0; k < n; ++k) {
+                const Token* t = (const Token*)tokens[k];
+                h_off[k] = R.off[(size_t)t->k];
+                h_nsym[k] = R.nsym[(size_t)t->k];
+                const uint32_t cnt = (h_nsym[k] + GZB_CRC_PIECE - 1u) / GZB_CRC_PIECE;
+                for (uint32_t i = 0; i < cnt; ++i, ++p) { h_psec[p] = (uint32_t)k; h_pidx[p] = i; }
+            }
+            *(uint32_t*)(pin + o_bad) = 0;
+        }
+        uint8_t* const h_win = pin + tab_bytes;                 // the window before the run, right-aligned; behind it the one behind the run comes back
+        memset(h_win, 0, GZB_WINDOW - wlen);
+        if (wlen) memcpy(h_win + GZB_WINDOW - wlen, win, wlen);
+        GzbResolveJob J{};
+        uint8_t* const dtab = (uint8_t*)rs_tab_.p;
+        J.sym = (const uint16_t*)R.sym.p; J.text = (uint8_t*)R.text.p; J.wins = (uint8_t*)rs_wins_.p;
+        J.off = (const uint64_t*)dtab; J.nsym = (const uint32_t*)(dtab + o_nsym); J.n_run = (uint32_t)n;
+        J.valid0 = (uint32_t)(GZB_WINDOW - wlen); J.bad = (uint32_t*)(dtab + o_bad);
+        J.piece_sec = (const uint32_t*)(dtab + o_psec); J.piece_idx = (const uint32_t*)(dtab + o_pidx); J.piece_crc = (uint32_t*)(dtab + o_pcrc);
+        J.piece_nl = (uint32_t*)(dtab + o_pnl);
+        J.n_pieces = n_pieces; J.crc_tab = (const uint32_t*)rs_crc_tab_.p;
+        bool ok = hipMemcpyAsync(dtab, pin, tab_bytes, hipMemcpyHostToDevice, rs_stream_) == hipSuccess &&
+                  hipMemcpyAsync(rs_wins_.p, h_win, GZB_WINDOW, hipMemcpyHostToDevice, rs_stream_) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(gzb_windows_kernel, dim3(1), dim3(GZB_WIN_THREADS), 0, rs_stream_, J);
+            if (max_n) hipLaunchKernelGGL(gzb_resolve_kernel, dim3((max_n + GZB_RES_THREADS * 16 - 1) / (GZB_RES_THREADS * 16), (unsigned)n), dim3(GZB_RES_THREADS), 0, rs_stream_, J);
+            if (n_pieces) hipLaunchKernelGGL(gzb_crc_kernel, dim3(n_pieces), dim3(GZB_CRC_THREADS), 0, rs_stream_, J);
+            ok = hipGetLastError() == hipSuccess &&
+                 hipMemcpyAsync(pin + o_pcrc, dtab + o_pcrc, 8ull * n_pieces + 4, hipMemcpyDeviceToHost, rs_stream_) == hipSuccess &&
+                 hipMemcpyAsync(h_win + GZB_WINDOW, (uint8_t*)rs_wins_.p + (size_t)n * GZB_WINDOW, GZB_WINDOW, hipMemcpyDeviceToHost, rs_stream_) == hipSuccess &&
+                 hipStreamSynchronize(rs_stream_) == hipSuccess;
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> g(mu_);
+            broken_ = true;
+            return -2;
+        }
+        if (*(const uint32_t*)(pin + o_bad)) return aqcgz::GZ_ERR_DATA;
+        {
+            auto advance = [](uint32_t x, uint64_t len) { return (uint32_t)crc32_combine((uLong)x, 0UL, (z_off_t)len); };
+            const uint32_t* pc = (const uint32_t*)(pin + o_pcrc);
+            for (int k = 0; k < n; ++k) {
+                const uint32_t cnt = (h_nsym[k] + GZB_CRC_PIECE - 1u) / GZB_CRC_PIECE;
+                crc[k] = gzb_crc_fold(pc, cnt, h_nsym[k], adv_piece_, advance);
+                pc += cnt;
+            }
+            if (piece_nl) memcpy(piece_nl, pin + o_pnl, 4ull * n_pieces);
+        }
+        const size_t tl = (size_t)std::min<uint64_t>(GZB_WINDOW, wlen + total);
+        memcpy(tail, h_win + 2 * GZB_WINDOW - tl, tl);
+        *tail_len = tl;
+        g_gzb_resolve_stats[0] += 1; g_gzb_resolve_stats[1] += (uint64_t)n; g_gzb_resolve_stats[2] += (uint64_t)((now_s() - t0) * 1e6); g_gzb_resolve_stats[3] += total;
+        return 0;
+    }
+    bool fetch(void* token, size_t off, size_t len, uint8_t* dst) override {
+        const Token* t = (const Token*)token;
+        if (t->res < 0) return false;
+        Res& R = res_[t->res];
+        if (t->k < 0 || (size_t)t->k >= R.nsym.size() || off + len > R.nsym[(size_t)t->k]) return false;
+        if (!len) return true;
+        if (hipSetDevice(device_) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipMemcpyAsync(dst, (const uint8_t*)R.text.p + R.off[(size_t)t->k] + off, len, hipMemcpyDeviceToHost, rs_stream_) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return true;
+    }
+    bool fetch_wait() override {
+        if (hipSetDevice(device_) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipStreamSynchronize(rs_stream_) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return true;
+    }
+
 private:
-    // (two lanes: one group is uploaded / downloaded while the other decodes; a third gave nothing measurable (gpurun_out/r4c30) and
-    //  a lane's device buffers are ~15 GB for groups of 96 MiB: symbol and token space for 12 x expansion)
-    static constexpr int N_LANES = 2, N_ARENAS = 6;
+    // (two lane threads share ONE set of decode buffers: a group's compressed bytes are copied out of the file mapping into the
+    //  lane's stage while the other lane's kernels run; the device part of a group takes the set for itself)
+    static constexpr int N_LANES = 2, N_ARENAS = 6, N_RES = 12;
     // AQC_GZ_DEBUG=1: what the decoder's set-up and tear-down cost (device buffers, page-locked staging and arenas), on stderr
     static bool debug() { static const bool d = getenv("AQC_GZ_DEBUG") && getenv("AQC_GZ_DEBUG")[0] == '1'; return d; }
     static double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
@@ -1294,26 +1483,78 @@ private:
         std::vector<uint8_t> exact;
         std::function<void(int, const aqcgz::OffloadResult&)> done;
     };
-    struct Token { int arena; };
+    struct Token { int arena; int res; int k; };
     struct Arena { uint8_t* p = nullptr; size_t cap = 0; int refs = 0; bool filling = false; };
+    // a group's symbols and, once resolved, its text (text[i] = the byte of symbol i): kept until the last of its sections is dropped
+    struct Res {
+        DevBuf sym, text;
+        std::vector<uint64_t> off;
+        std::vector<uint32_t> nsym;
+        int refs = 0;
+        bool filling = false;
+    };
     struct Lane {
         std::thread th;
-        hipStream_t stream = nullptr;
-        hipEvent_t ev[7] = {};
         std::unique_ptr<Group> job;
-        DevBuf comp, tile_cnt, tile_cand, n_cand, c_start, c_end, c_nsym, c_flags, c_symoff, c_symcap, blk_sym, tables, blk_tp, c_lanes, l_u32;
-        DevBuf s_in, s_out, s_blocks, s_sym, s_off;
         uint8_t* stage = nullptr;          // page-locked copy of the group's compressed bytes (the file itself is a pageable mapping)
         size_t stage_cap = 0;
+    };
+    struct DevSet {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev[7] = {};
+        DevBuf comp, tile_cnt, tile_cand, n_cand, c_start, c_end, c_nsym, c_flags, c_symoff, c_symcap, c_tokoff, c_tokcap, blk_sym, tables, blk_tp, c_lanes, l_u32;
+        DevBuf s_in, s_out, s_blocks, s_sym, s_off;
+        std::vector<DevBuf*> all() {
+            return {&comp, &tile_cnt, &tile_cand, &n_cand, &c_start, &c_end, &c_nsym, &c_flags, &c_symoff, &c_symcap, &c_tokoff, &c_tokcap, &blk_sym, &tables, &blk_tp, &c_lanes, &l_u32,
+                    &s_in, &s_out, &s_blocks, &s_sym, &s_off};
+        }
+        size_t bytes() { size_t t = 0; for (DevBuf* x : all()) t += x->cap; return t; }
         void release() {
-            if (stream) (void)hipStreamSynchronize(stream);
-            DevBuf* b[] = {&comp, &tile_cnt, &tile_cand, &n_cand, &c_start, &c_end, &c_nsym, &c_flags, &c_symoff, &c_symcap, &blk_sym, &tables, &blk_tp, &c_lanes, &l_u32, &s_in, &s_out, &s_blocks, &s_sym, &s_off};
-            for (DevBuf* x : b) x->release();
+            for (DevBuf* x : all()) x->release();
             for (auto& e : ev) if (e) (void)hipEventDestroy(e);
             if (stream) (void)hipStreamDestroy(stream);
             stream = nullptr;
         }
     };
+    struct Sizes { uint32_t n_tiles, cand_cap, s_symcap; uint64_t blk_sym_cap, blk_tp_cap, s_sym_total; };
+    Sizes sizes_for(size_t span, int n, uint64_t sec_max, uint32_t last_bit) const {
+        Sizes z;
+        z.n_tiles = (uint32_t)(((size_t)(last_bit >> 3) + 1 + GZB_SCAN_TILE - 1) / GZB_SCAN_TILE);
+        z.cand_cap = (uint32_t)(span / 4096 + 256);
+        z.s_symcap = (uint32_t)std::min<uint64_t>((sec_max * 2 * ratio_ + (2u << 20) + 7) & ~(uint64_t)7, 0xfffffff0u);
+        z.blk_sym_cap = gzb_sym_budget(span, ratio_);
+        z.blk_tp_cap = gzb_tok_budget(span, tok_ratio_, overlap_tokens_);
+        z.s_sym_total = (uint64_t)span * ratio_ + (uint64_t)n * 64 + (1u << 20);
+        return z;
+    }
+    // the decode buffers for a window of `span` compressed bytes in n sections (grow only; dev_mu_ held)
+    bool reserve_devset(size_t span, int n, const Sizes& z) {
+        DevSet& D = dev_;
+        const double t0 = now_s();
+        const size_t before = D.bytes();
+        if (D.comp.reserve(span + 512) || D.tile_cnt.reserve(4ull * z.n_tiles) || D.tile_cand.reserve(4ull * z.n_tiles * GZB_TILE_CAND) || D.n_cand.reserve(64) ||
+            D.c_start.reserve(4ull * z.cand_cap) || D.c_end.reserve(4ull * z.cand_cap) || D.c_nsym.reserve(4ull * z.cand_cap) || D.c_flags.reserve(4ull * z.cand_cap) ||
+            D.c_symoff.reserve(8ull * z.cand_cap) || D.c_symcap.reserve(4ull * z.cand_cap) || D.c_tokoff.reserve(8ull * z.cand_cap) || D.c_tokcap.reserve(4ull * z.cand_cap) ||
+            D.blk_sym.reserve(2ull * z.blk_sym_cap + 64) || D.blk_tp.reserve(8ull * z.blk_tp_cap + 512) || D.c_lanes.reserve(4ull * z.cand_cap) ||
+            D.l_u32.reserve(5ull * 4ull * z.cand_cap * GZB_K) || D.tables.reserve(4ull * z.cand_cap * GZB_TAB_WORDS) || D.s_in.reserve(12ull * n) || D.s_out.reserve(16ull * n) ||
+            D.s_off.reserve(8ull * (n + 1)) || D.s_blocks.reserve(12ull * n * GZB_SEC_BLOCKS) || (!resident_ && D.s_sym.reserve(2ull * z.s_sym_total + 64)))
+            return false;
+        if (debug() && D.bytes() != before)
+            fprintf(stderr, "[gz dev %d] decode buffers for %.1f MiB compressed in %d sections (symbols %u x, tokens %u per byte): %.2f GiB (blk_sym %.2f, blk_tp %.2f, tables %.2f, s_sym %.2f), reserve %.3f s\n",
+                    device_, span / 1048576.0, n, ratio_, tok_ratio_, D.bytes() / 1073741824.0, D.blk_sym.cap / 1073741824.0, D.blk_tp.cap / 1073741824.0, D.tables.cap / 1073741824.0,
+                    D.s_sym.cap / 1073741824.0, now_s() - t0);
+        return true;
+    }
+    bool reserve_stage(Lane& L, size_t span) {
+        if (L.stage_cap >= span) return true;
+        if (L.stage) aqc_host_free(L.stage);
+        L.stage_cap = span + span / 8 + (1u << 20);
+        const double t0 = now_s();
+        L.stage = (uint8_t*)aqc_host_alloc(L.stage_cap);
+        if (debug()) fprintf(stderr, "[gz dev %d] stage: %.0f MiB page-locked in %.3f s\n", device_, L.stage_cap / 1048576.0, now_s() - t0);
+        if (!L.stage) { L.stage_cap = 0; return false; }
+        return true;
+    }
 
     void loop(int li) {
         Lane& L = lanes_[li];
@@ -1321,11 +1562,42 @@ private:
         (void)aqc_bind_thread_to_node(aqc_device_numa_node_of(device_));       // (the staging copies and the arenas' first touch happen here)
         for (;;) {
             Group* gr = nullptr;
+            size_t prep = 0;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return stop_ || L.job; });
+                cv_.wait(lk, [&] { return stop_ || L.job || (!prepare_busy_ && prepare_want_ > prepared_for_); });
                 if (stop_ && !L.job) return;
-                gr = L.job.get();
+                if (L.job) gr = L.job.get();
+                else { prep = prepare_want_; prepare_busy_ = true; }
+            }
+            if (!gr) {
+                // the stream has announced its groups: the decode buffers, this lane's stage (the other lane makes its own with its
+                // first group) and the first result set, before the first group is accepted
+                const size_t span = prep + GZB_SLACK + (1u << 20);
+                const int n = (int)(prep / (256u << 10)) + 8;
+                bool ok;
+                {
+                    std::lock_guard<std::mutex> dg(dev_mu_);
+                    ok = reserve_devset(span, n, sizes_for(span, n, 2u << 20, (uint32_t)std::min<uint64_t>((uint64_t)span * 8, 0xffffffffu)));
+                }
+                ok = ok && reserve_stage(L, span);
+                if (ok && resident_) {
+                    // three result sets of a typical group's size (FASTQ expands 3 - 5 x) — the consumer is seldom further behind;
+                    // more are made when they are needed, which then costs the lane that needs one 16 ms per GB
+                    int got[3] = {-1, -1, -1};
+                    for (int& ri : got) ri = take_res((uint64_t)prep * 4);
+                    std::lock_guard<std::mutex> g(mu_);
+                    for (int ri : got) if (ri >= 0) res_[ri].filling = false;
+                }
+                {
+                    std::lock_guard<std::mutex> g(mu_);
+                    prepare_busy_ = false;
+                    prepared_for_ = std::max(prepared_for_, prep);
+                    prepared_ = true;
+                    if (!ok) { (void)hipGetLastError(); broken_ = true; }
+                }
+                cv_.notify_all();
+                continue;
             }
             if (!run_group(L, *gr)) {
                 // the device path failed for this group: the sections come back empty, the host decodes that stretch itself
@@ -1338,6 +1610,8 @@ private:
             {
                 std::lock_guard<std::mutex> g(mu_);
                 L.job.reset();
+                prepared_ = true;            // (a decoder that has run a group has its buffers)
+                if (prepared_for_ == 0) prepared_for_ = 1;
             }
         }
     }
@@ -1375,6 +1649,38 @@ private:
             cv_.wait(lk);
         }
     }
+    // a free result set for `need` symbols (waits for one; the best fit, else an empty one, else the smallest grows).  The consumer
+    // holds at most four groups' worth of sections of a stream (ParallelGunzip::top_up), the chunks on their way to the slots a few
+    // more (the pipe's ring: five chunks of ~45 MB), and there are two lanes: twelve never run out.
+    int take_res(uint64_t need) {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            int best = -1, empty = -1, small = -1;
+            for (int i = 0; i < N_RES; ++i) {
+                Res& r = res_[i];
+                if (r.refs || r.filling) continue;
+                if (!r.sym.p) { if (empty < 0) empty = i; continue; }
+                if (r.sym.cap >= 2 * need + 64 && r.text.cap >= need + 64) { if (best < 0 || r.sym.cap < res_[best].sym.cap) best = i; }
+                else if (small < 0 || r.sym.cap > res_[small].sym.cap) small = i;
+            }
+            const int pick = best >= 0 ? best : (empty >= 0 ? empty : small);
+            if (pick >= 0) {
+                Res& r = res_[pick];
+                r.filling = true;
+                if (r.sym.cap < 2 * need + 64 || r.text.cap < need + 64) {
+                    lk.unlock();
+                    const double t0 = now_s();
+                    const bool bad = r.sym.reserve(2 * need + 64) || r.text.reserve(need + 64);
+                    if (debug()) fprintf(stderr, "[gz dev %d] result set %d: %.2f GiB (symbols + text of %.0f M symbols) in %.3f s\n", device_, pick, (r.sym.cap + r.text.cap) / 1073741824.0, need / 1e6, now_s() - t0);
+                    lk.lock();
+                    if (bad) { (void)hipGetLastError(); r.filling = false; return -1; }
+                }
+                return pick;
+            }
+            if (stop_) return -1;
+            cv_.wait(lk);
+        }
+    }
 
 #define GZB_TRY(expr) do { if ((expr) != hipSuccess) return false; } while (0)
     bool run_group(Lane& L, Group& G) {
@@ -1383,39 +1689,12 @@ private:
         const uint64_t end_byte = std::min<uint64_t>(G.size, (G.stop[n - 1] >> 3) + 1 + GZB_SLACK);
         const size_t span = (size_t)(end_byte - byte0);
         const uint32_t first_bit = (uint32_t)(G.nominal[0] - byte0 * 8), last_bit = (uint32_t)std::min<uint64_t>(G.stop[n - 1] - byte0 * 8, (uint64_t)span * 8);
-        const uint32_t n_tiles = (uint32_t)(((size_t)(last_bit >> 3) + 1 + GZB_SCAN_TILE - 1) / GZB_SCAN_TILE);
-        const uint32_t cand_cap = (uint32_t)(span / 4096 + 256);
         uint64_t sec_max = 0;
         for (int k = 0; k < n; ++k) sec_max = std::max<uint64_t>(sec_max, (G.stop[k] - G.nominal[k]) >> 3);
-        const uint32_t s_symcap = (uint32_t)std::min<uint64_t>((sec_max * 24 + (2u << 20) + 7) & ~(uint64_t)7, 0xfffffff0u);
-        const uint64_t s_sym_total = (uint64_t)span * 12 + (uint64_t)n * 64 + (1u << 20);
-        const uint64_t blk_sym_cap = gzb_sym_budget(span, GZB_RATIO_CAP);
-        const double t_res0 = now_s();
-        if (L.comp.reserve(span + 512) || L.tile_cnt.reserve(4ull * n_tiles) || L.tile_cand.reserve(4ull * n_tiles * GZB_TILE_CAND) || L.n_cand.reserve(64) ||
-            L.c_start.reserve(4ull * cand_cap) || L.c_end.reserve(4ull * cand_cap) || L.c_nsym.reserve(4ull * cand_cap) || L.c_flags.reserve(4ull * cand_cap) ||
-            L.c_symoff.reserve(8ull * cand_cap) || L.c_symcap.reserve(4ull * cand_cap) || L.blk_sym.reserve(2ull * blk_sym_cap + 64) ||
-            L.blk_tp.reserve(4ull * blk_sym_cap + 512) || L.c_lanes.reserve(4ull * cand_cap) ||
-            L.l_u32.reserve(5ull * 4ull * cand_cap * GZB_K) ||
-            L.tables.reserve(4ull * cand_cap * GZB_TAB_WORDS) || L.s_in.reserve(12ull * n) || L.s_out.reserve(16ull * n) || L.s_off.reserve(8ull * (n + 1)) ||
-            L.s_blocks.reserve(12ull * n * GZB_SEC_BLOCKS) || L.s_sym.reserve(2ull * s_sym_total + 64))
-            return false;
-        if (debug()) {
-            size_t tot = 0;
-            DevBuf* b[] = {&L.comp, &L.tile_cnt, &L.tile_cand, &L.n_cand, &L.c_start, &L.c_end, &L.c_nsym, &L.c_flags, &L.c_symoff, &L.c_symcap, &L.blk_sym, &L.tables, &L.blk_tp, &L.c_lanes, &L.l_u32, &L.s_in, &L.s_out, &L.s_blocks, &L.s_sym, &L.s_off};
-            for (DevBuf* x : b) tot += x->cap;
-            fprintf(stderr, "[gz dev %d] group of %.1f MiB compressed, %d sections: device buffers now %.2f GiB (blk_sym %.2f, blk_tp %.2f, s_sym %.2f, tables %.2f, l_u32 %.2f), reserve %.3f s\n", device_,
-                    span / 1048576.0, n, tot / 1073741824.0, L.blk_sym.cap / 1073741824.0, L.blk_tp.cap / 1073741824.0, L.s_sym.cap / 1073741824.0, L.tables.cap / 1073741824.0, L.l_u32.cap / 1073741824.0, now_s() - t_res0);
-        }
         // the compressed bytes: out of the (pageable, possibly not yet faulted-in) file mapping into page-locked memory with a few
-        // threads side by side, then one DMA — a copy straight from the mapping runs at the page-fault rate of one thread
-        if (L.stage_cap < span) {
-            if (L.stage) aqc_host_free(L.stage);
-            L.stage_cap = span + span / 8 + (1u << 20);
-            const double t0 = now_s();
-            L.stage = (uint8_t*)aqc_host_alloc(L.stage_cap);
-            if (debug()) fprintf(stderr, "[gz dev %d] stage: %.0f MiB page-locked in %.3f s\n", device_, L.stage_cap / 1048576.0, now_s() - t0);
-            if (!L.stage) { L.stage_cap = 0; return false; }
-        }
+        // threads side by side, then one DMA — a copy straight from the mapping runs at the page-fault rate of one thread.  (Before
+        // the decode buffers are taken: the other lane's kernels run meanwhile.)
+        if (!reserve_stage(L, span)) return false;
         {
             const int T = span > (8u << 20) ? 4 : 1;
             std::vector<std::thread> th;
@@ -1432,78 +1711,117 @@ private:
             sin[n + k] = (uint32_t)std::min<uint64_t>(G.stop[k] - byte0 * 8, (uint64_t)span * 8);
             sin[2 * n + k] = G.exact[k];
         }
-        GZB_TRY(hipEventRecord(L.ev[0], L.stream));
-        GZB_TRY(hipMemcpyAsync(L.comp.p, L.stage, span, hipMemcpyHostToDevice, L.stream));
-        GZB_TRY(hipMemsetAsync((uint8_t*)L.comp.p + span, 0, 512, L.stream));       // (the lanes' stream windows read up to 200 bytes ahead)
-        GZB_TRY(hipMemcpyAsync(L.s_in.p, sin.data(), 12ull * n, hipMemcpyHostToDevice, L.stream));
+        std::unique_lock<std::mutex> dg(dev_mu_);
+        DevSet& D = dev_;
+      for (int attempt = 0;; ++attempt) {
+        const Sizes z = sizes_for(span, n, sec_max, last_bit);
+        if (!reserve_devset(span, n, z)) return false;
+        GZB_TRY(hipEventRecord(D.ev[0], D.stream));
+        GZB_TRY(hipMemcpyAsync(D.comp.p, L.stage, span, hipMemcpyHostToDevice, D.stream));
+        GZB_TRY(hipMemsetAsync((uint8_t*)D.comp.p + span, 0, 512, D.stream));       // (the lanes' stream windows read up to 200 bytes ahead)
+        GZB_TRY(hipMemcpyAsync(D.s_in.p, sin.data(), 12ull * n, hipMemcpyHostToDevice, D.stream));
         GzbJob J{};
-        J.comp = (const uint8_t*)L.comp.p; J.comp_bytes = (uint32_t)span; J.scan_byte0 = 0; J.first_bit = first_bit; J.last_bit = last_bit;
-        J.n_tiles = n_tiles; J.tile_cnt = (uint32_t*)L.tile_cnt.p; J.tile_cand = (uint32_t*)L.tile_cand.p;
-        J.cand_cap = cand_cap; J.n_cand = (uint32_t*)L.n_cand.p;
-        J.c_start = (uint32_t*)L.c_start.p; J.c_end = (uint32_t*)L.c_end.p; J.c_nsym = (uint32_t*)L.c_nsym.p; J.c_flags = (uint32_t*)L.c_flags.p;
-        J.c_symoff = (uint64_t*)L.c_symoff.p; J.c_symcap = (uint32_t*)L.c_symcap.p; J.blk_sym = (uint16_t*)L.blk_sym.p; J.blk_sym_cap = blk_sym_cap;
-        J.ratio_cap = GZB_RATIO_CAP; J.tables = (uint32_t*)L.tables.p; J.blk_tp = (unsigned long long*)L.blk_tp.p;
-        J.c_lanes = (uint32_t*)L.c_lanes.p;
-        J.l_p = (uint32_t*)L.l_u32.p; J.l_stop = J.l_p + (size_t)cand_cap * GZB_K; J.l_start = J.l_stop + (size_t)cand_cap * GZB_K;
-        J.l_ntok = J.l_start + (size_t)cand_cap * GZB_K; J.l_flags = J.l_ntok + (size_t)cand_cap * GZB_K;
+        J.comp = (const uint8_t*)D.comp.p; J.comp_bytes = (uint32_t)span; J.scan_byte0 = 0; J.first_bit = first_bit; J.last_bit = last_bit;
+        J.n_tiles = z.n_tiles; J.tile_cnt = (uint32_t*)D.tile_cnt.p; J.tile_cand = (uint32_t*)D.tile_cand.p;
+        J.cand_cap = z.cand_cap; J.n_cand = (uint32_t*)D.n_cand.p;
+        J.c_start = (uint32_t*)D.c_start.p; J.c_end = (uint32_t*)D.c_end.p; J.c_nsym = (uint32_t*)D.c_nsym.p; J.c_flags = (uint32_t*)D.c_flags.p;
+        J.c_symoff = (uint64_t*)D.c_symoff.p; J.c_symcap = (uint32_t*)D.c_symcap.p; J.blk_sym = (uint16_t*)D.blk_sym.p; J.blk_sym_cap = z.blk_sym_cap;
+        J.c_tokoff = (uint64_t*)D.c_tokoff.p; J.c_tokcap = (uint32_t*)D.c_tokcap.p; J.blk_tp_cap = z.blk_tp_cap; J.tok_ratio = tok_ratio_; J.overlap_tokens = overlap_tokens_;
+        J.ratio_cap = ratio_; J.tables = (uint32_t*)D.tables.p; J.blk_tp = (unsigned long long*)D.blk_tp.p;
+        J.c_lanes = (uint32_t*)D.c_lanes.p;
+        J.l_p = (uint32_t*)D.l_u32.p; J.l_stop = J.l_p + (size_t)z.cand_cap * GZB_K; J.l_start = J.l_stop + (size_t)z.cand_cap * GZB_K;
+        J.l_ntok = J.l_start + (size_t)z.cand_cap * GZB_K; J.l_flags = J.l_ntok + (size_t)z.cand_cap * GZB_K;
         {
             static const uint32_t slice = [] { const char* e = getenv("AQC_GZ_SLICE"); return e ? (uint32_t)std::max(16, atoi(e)) : 2048u; }();
             J.slice_tokens = slice;
         }
-        J.n_sec = (uint32_t)n; J.s_nominal = (const uint32_t*)L.s_in.p; J.s_stop = J.s_nominal + n; J.s_exact = J.s_nominal + 2 * n;
-        J.s_start = (uint32_t*)L.s_out.p; J.s_end = J.s_start + n; J.s_nsym = J.s_start + 2 * n; J.s_nblk = J.s_start + 3 * n;
-        J.s_blocks = (uint32_t*)L.s_blocks.p; J.s_off = (uint64_t*)L.s_off.p; J.s_sym = (uint16_t*)L.s_sym.p; J.s_sym_total = s_sym_total; J.s_symcap = s_symcap;
-        GZB_TRY(hipEventRecord(L.ev[1], L.stream));
-        hipLaunchKernelGGL(gzb_scan_kernel, dim3(n_tiles), dim3(GZB_SCAN_THREADS), 0, L.stream, J);
-        hipLaunchKernelGGL(gzb_compact_kernel, dim3(1), dim3(1024), 0, L.stream, J);
-        GZB_TRY(hipEventRecord(L.ev[2], L.stream));
+        J.n_sec = (uint32_t)n; J.s_nominal = (const uint32_t*)D.s_in.p; J.s_stop = J.s_nominal + n; J.s_exact = J.s_nominal + 2 * n;
+        J.s_start = (uint32_t*)D.s_out.p; J.s_end = J.s_start + n; J.s_nsym = J.s_start + 2 * n; J.s_nblk = J.s_start + 3 * n;
+        J.s_blocks = (uint32_t*)D.s_blocks.p; J.s_off = (uint64_t*)D.s_off.p; J.s_sym = (uint16_t*)D.s_sym.p; J.s_symcap = z.s_symcap;
+        // (resident: the result set is taken once the sections' sizes are known, so every section that chained up has its place)
+        J.s_sym_total = resident_ ? ~0ull >> 2 : z.s_sym_total;
+        GZB_TRY(hipEventRecord(D.ev[1], D.stream));
+        hipLaunchKernelGGL(gzb_scan_kernel, dim3(z.n_tiles), dim3(GZB_SCAN_THREADS), 0, D.stream, J);
+        hipLaunchKernelGGL(gzb_compact_kernel, dim3(1), dim3(1024), 0, D.stream, J);
+        GZB_TRY(hipEventRecord(D.ev[2], D.stream));
         // the decoder in slices (aqc_gunzip_dev.hpp): GZB_K lanes per block, each with its share of it and the overlap: 6 x 2048
         // tokens cover the blocks of zlib (<= 16 K tokens) and of GNU gzip (<= 32 K) with room to spare; a lane that needs more
         // stays unfinished, its block counts as failed, the section ends before it and the host goes on from there
         {
             static const int n_slices = [] { const char* e = getenv("AQC_GZ_SLICES"); return e ? std::max(1, atoi(e)) : 6; }();
-            hipLaunchKernelGGL(gzb_tables_kernel, dim3((cand_cap + GZB_DEC_THREADS - 1) / GZB_DEC_THREADS), dim3(GZB_DEC_THREADS), 0, L.stream, J);
-            const dim3 grid((cand_cap * GZB_K + GZB_DEC_THREADS - 1) / GZB_DEC_THREADS);
-            for (int sl = 0; sl < n_slices; ++sl) hipLaunchKernelGGL(gzb_decode_kernel, grid, dim3(GZB_DEC_THREADS), 0, L.stream, J);
+            hipLaunchKernelGGL(gzb_tables_kernel, dim3((z.cand_cap + GZB_DEC_THREADS - 1) / GZB_DEC_THREADS), dim3(GZB_DEC_THREADS), 0, D.stream, J);
+            const dim3 grid((z.cand_cap * GZB_K + GZB_DEC_THREADS - 1) / GZB_DEC_THREADS);
+            for (int sl = 0; sl < n_slices; ++sl) hipLaunchKernelGGL(gzb_decode_kernel, grid, dim3(GZB_DEC_THREADS), 0, D.stream, J);
             // phase 2: a wave per block stitches its lanes' lists together and applies the tokens
-            hipLaunchKernelGGL(gzb_expand_kernel, dim3((cand_cap + GZB_EXP_WAVES - 1) / GZB_EXP_WAVES), dim3(64 * GZB_EXP_WAVES), 0, L.stream, J);
+            hipLaunchKernelGGL(gzb_expand_kernel, dim3((z.cand_cap + GZB_EXP_WAVES - 1) / GZB_EXP_WAVES), dim3(64 * GZB_EXP_WAVES), 0, D.stream, J);
         }
-        GZB_TRY(hipEventRecord(L.ev[3], L.stream));
-        hipLaunchKernelGGL(gzb_chain_kernel, dim3((n + 63) / 64), dim3(64), 0, L.stream, J);
-        hipLaunchKernelGGL(gzb_place_kernel, dim3(1), dim3(1), 0, L.stream, J);
-        hipLaunchKernelGGL(gzb_gather_kernel, dim3(n), dim3(GZB_GATHER_THREADS), 0, L.stream, J);
-        GZB_TRY(hipEventRecord(L.ev[4], L.stream));
+        GZB_TRY(hipEventRecord(D.ev[3], D.stream));
+        hipLaunchKernelGGL(gzb_chain_kernel, dim3((n + 63) / 64), dim3(64), 0, D.stream, J);
+        hipLaunchKernelGGL(gzb_place_kernel, dim3(1), dim3(1), 0, D.stream, J);
         GZB_TRY(hipGetLastError());
-        // what each section became (start, end, symbols) and where its symbols are; then ALL symbols with one copy
+        // what each section became (start, end, symbols) and where its symbols go
         std::vector<uint32_t> sout(4 * (size_t)n);
         std::vector<uint64_t> soff((size_t)n + 1);
-        GZB_TRY(hipMemcpyAsync(sout.data(), L.s_out.p, 16ull * n, hipMemcpyDeviceToHost, L.stream));
-        GZB_TRY(hipMemcpyAsync(soff.data(), L.s_off.p, 8ull * (n + 1), hipMemcpyDeviceToHost, L.stream));
-        GZB_TRY(hipStreamSynchronize(L.stream));
-        const size_t need = (size_t)soff[n] * 2;
+        GZB_TRY(hipMemcpyAsync(sout.data(), D.s_out.p, 16ull * n, hipMemcpyDeviceToHost, D.stream));
+        GZB_TRY(hipMemcpyAsync(soff.data(), D.s_off.p, 8ull * (n + 1), hipMemcpyDeviceToHost, D.stream));
+        GZB_TRY(hipStreamSynchronize(D.stream));
         int live = 0;
         for (int k = 0; k < n; ++k) if (sout[k] != GZB_NONE && sout[2 * n + k] != 0) ++live;
-        int ai = -1;
-        bool ok = true;
-        if (need && live) {
-            ai = take_arena(need);
-            if (ai < 0) return false;
-            ok = hipEventRecord(L.ev[6], L.stream) == hipSuccess &&
-                 hipMemcpyAsync(arenas_[ai].p, L.s_sym.p, need, hipMemcpyDeviceToHost, L.stream) == hipSuccess;
-        } else ok = hipEventRecord(L.ev[6], L.stream) == hipSuccess;
-        ok = ok && hipEventRecord(L.ev[5], L.stream) == hipSuccess && hipStreamSynchronize(L.stream) == hipSuccess;
-        if (ai >= 0) {
+        // A group that comes back short on the lean budgets (symbols 6 x, one token per compressed byte) is decoded once more with
+        // room to spare, and so is every group after it (once per decoder: an input that compresses 6 x and better, or is nearly
+        // all literals, is rare — and says so here; what is still missing then is not a matter of space, and the host's)
+        if (live < n && !grown_) {
+            grown_ = true;
             {
+                std::lock_guard<std::mutex> g(mu_);
+                ratio_ = std::max(ratio_, 12u);
+                tok_ratio_ = std::max(tok_ratio_, 6u);
+                overlap_tokens_ = std::max(overlap_tokens_, 2048u);
+            }
+            if (debug()) fprintf(stderr, "[gz dev %d] %d of %d sections came back empty: symbol space %u x, %u tokens per byte from now on; the group is decoded again\n", device_, n - live, n, ratio_, tok_ratio_);
+            if (attempt == 0) continue;
+        }
+        int ai = -1, ri = -1;
+        bool ok = true;
+        if (resident_) {
+            if (soff[n] && live) {
+                ri = take_res(soff[n]);
+                if (ri < 0) return false;
+                J.s_sym = (uint16_t*)res_[ri].sym.p;
+                hipLaunchKernelGGL(gzb_gather_kernel, dim3(n), dim3(GZB_GATHER_THREADS), 0, D.stream, J);
+            }
+            ok = hipEventRecord(D.ev[4], D.stream) == hipSuccess && hipEventRecord(D.ev[6], D.stream) == hipSuccess && hipEventRecord(D.ev[5], D.stream) == hipSuccess &&
+                 hipGetLastError() == hipSuccess && hipStreamSynchronize(D.stream) == hipSuccess;
+            if (ri >= 0) {
+                std::lock_guard<std::mutex> g(mu_);
+                Res& R = res_[ri];
+                R.filling = false;
+                R.refs = ok ? live : 0;
+                R.off.assign(soff.begin(), soff.begin() + n);
+                R.nsym.assign(sout.begin() + 2 * n, sout.begin() + 3 * n);
+            }
+        } else {
+            hipLaunchKernelGGL(gzb_gather_kernel, dim3(n), dim3(GZB_GATHER_THREADS), 0, D.stream, J);
+            ok = hipEventRecord(D.ev[4], D.stream) == hipSuccess;
+            const size_t need = (size_t)soff[n] * 2;
+            if (ok && need && live) {
+                ai = take_arena(need);
+                if (ai < 0) return false;
+                ok = hipEventRecord(D.ev[6], D.stream) == hipSuccess &&
+                     hipMemcpyAsync(arenas_[ai].p, D.s_sym.p, need, hipMemcpyDeviceToHost, D.stream) == hipSuccess;
+            } else ok = ok && hipEventRecord(D.ev[6], D.stream) == hipSuccess;
+            ok = ok && hipEventRecord(D.ev[5], D.stream) == hipSuccess && hipStreamSynchronize(D.stream) == hipSuccess;
+            if (ai >= 0) {
                 std::lock_guard<std::mutex> g(mu_);
                 arenas_[ai].filling = false;
                 arenas_[ai].refs = ok ? live : 0;
             }
-            if (!ok) cv_.notify_all();
         }
-        if (!ok) return false;
+        if (!ok) { cv_.notify_all(); return false; }
         float ms[5] = {0, 0, 0, 0, 0};
-        for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], L.ev[i], L.ev[i + 1]);
-        (void)hipEventElapsedTime(&ms[4], L.ev[6], L.ev[5]);       // (the symbols' copy alone: getting an arena is host time)
+        for (int i = 0; i < 4; ++i) (void)hipEventElapsedTime(&ms[i], D.ev[i], D.ev[i + 1]);
+        (void)hipEventElapsedTime(&ms[4], D.ev[6], D.ev[5]);       // (the symbols' copy alone: getting an arena is host time)
+        dg.unlock();
         g_gzb_stats[0] += (uint64_t)(ms[1] * 1000); g_gzb_stats[1] += (uint64_t)(ms[2] * 1000); g_gzb_stats[2] += (uint64_t)(ms[3] * 1000);
         g_gzb_stats[3] += (uint64_t)(ms[0] * 1000); g_gzb_stats[4] += (uint64_t)(ms[4] * 1000); g_gzb_stats[5] += 1; g_gzb_stats[6] += (uint64_t)n; g_gzb_stats[7] += (uint64_t)live;
         for (int k = 0; k < n; ++k) {
@@ -1512,23 +1830,39 @@ private:
                 r.found = true;
                 r.start_bit = byte0 * 8 + sout[k];
                 r.end_bit = byte0 * 8 + sout[n + k];
-                r.sym = (const uint16_t*)arenas_[ai].p + soff[k];
                 r.n_sym = sout[2 * n + k];
-                r.token = new Token{ai};
+                if (resident_) { r.resident = true; r.token = new Token{-1, ri, k}; }
+                else { r.sym = (const uint16_t*)arenas_[ai].p + soff[k]; r.token = new Token{ai, -1, k}; }
             }
             G.done(k, r);
         }
         return true;
+      }
     }
 #undef GZB_TRY
 
     int device_;
     size_t group_bytes_;
+    bool resident_ = true;
+    uint32_t ratio_ = 6, tok_ratio_ = 1, overlap_tokens_ = GZB_OVERLAP_TOKENS;
+    bool grown_ = false;
     std::mutex mu_;
     std::condition_variable cv_;
     bool stop_ = false, broken_ = false;
+    bool prepared_ = true, prepare_busy_ = false;       // (prepared_: false between prepare() and the moment the buffers it asked for exist)
+    size_t prepare_want_ = 0, prepared_for_ = 0;
     Lane lanes_[N_LANES];
+    std::mutex dev_mu_;
+    DevSet dev_;
     Arena arenas_[N_ARENAS];
+    Res res_[N_RES];
+    // resolve() / fetch(): the consumer's side
+    std::mutex rs_mu_;
+    hipStream_t rs_stream_ = nullptr;
+    DevBuf rs_wins_, rs_tab_, rs_crc_tab_;
+    uint8_t* rs_pin_ = nullptr;
+    size_t rs_pin_cap_ = 0;
+    uint32_t adv_piece_[32] = {};
 };
 
 }  // namespace
@@ -1542,6 +1876,9 @@ SectionOffload* make_device_offload(int device, size_t group_bytes) {
 }
 void device_offload_stats(uint64_t out[8]) {
     for (int i = 0; i < 8; ++i) out[i] = g_gzb_stats[i].load();
+}
+void device_resolve_stats(uint64_t out[4]) {
+    for (int i = 0; i < 4; ++i) out[i] = g_gzb_resolve_stats[i].load();
 }
 }  // namespace aqcgz
 extern "C" {

@@ -165,6 +165,12 @@ struct ParallelGunzip::Section {
     const uint16_t* ext_sym = nullptr;
     void* ext_token = nullptr;
     SectionOffload* ext_owner = nullptr;
+    // ... whose symbols stay there (OffloadResult::resident): the decoder resolves them once the consumer knows the window before the
+    // run this section belongs to, and hands out bytes
+    bool resident = false, resolved = false;
+    uint64_t group_id = 0;                      // the group it was submitted with
+    uint32_t crc = 0;                           // CRC-32 of its bytes (resolved)
+    std::vector<uint32_t> piece_nl;             // line feeds per NL_PIECE piece (resolved)
     struct MemberEnd { size_t out_pos; uint32_t crc, isize; };
     std::vector<MemberEnd> ends;
     std::mutex mu;
@@ -196,6 +202,7 @@ ParallelGunzip::ParallelGunzip(const uint8_t* data, size_t size, aqc_host::Pool*
 }
 
 ParallelGunzip::~ParallelGunzip() {
+    if (fetch_dirty_ && offload_) (void)offload_->fetch_wait();      // (copies out of sections that are about to be released)
     // speculative sections still running hold their own references; wait for them (they read data_)
     for (auto& kv : q_) {
         const std::shared_ptr<Section>& s = kv.second;
@@ -393,6 +400,10 @@ void ParallelGunzip::top_up(bool need_front) {
         if (size_ > 64 && (size_ - 65) / section_bytes_ > start_idx_) last_idx_ = (size_ - 65) / section_bytes_;
         win_lo_ = start_idx_;
         next_window();
+        if (offload_) {
+            const size_t per_group = std::max<size_t>(1, (offload_only_ ? offload_->group_bytes() : std::min(offload_->group_bytes(), std::max<size_t>(16u << 20, size_ / 6))) / section_bytes_);
+            offload_->prepare(per_group * section_bytes_);
+        }
     }
     for (;;) {
         if (pool_next_ >= dev_hi_) {                          // this window is handed out
@@ -417,10 +428,11 @@ void ParallelGunzip::top_up(bool need_front) {
         }
         // The device's share: a GROUP of sections whenever it is free — from the TOP of the window down, so that the consumer,
         // who commits in index order, gets there last (offload_only: from the bottom up, nobody else feeds the consumer)
-        if (offload_ && offload_only_ && front_missing && on_device == 0 && !offload_->ready()) {
-            // Nothing of this stream is with the device and it still takes no work: it has given up (a failed hipMalloc of its lane
-            // buffers, any HIP error — DeviceInflate::broken_).  With the device as the ONLY decoder nobody would ever make the
-            // section the consumer waits for (round-4 advisory: aqc_gunzip_dev hung here): the host takes over from this section on.
+        if (offload_ && offload_only_ && front_missing && on_device == 0 && offload_->gave_up()) {
+            // The device has given up (a failed hipMalloc of its lane buffers, any HIP error — DeviceInflate::broken_).  With the
+            // device as the ONLY decoder nobody would ever make the section the consumer waits for (round-4 advisory:
+            // aqc_gunzip_dev hung here): the host takes over from this section on.  (A decoder that is merely busy — the other
+            // input's group, its buffers still being set up — is waited for: round-5 advisory.)
             offload_only_ = false;
             continue;
         }
@@ -441,8 +453,10 @@ void ParallelGunzip::top_up(bool need_front) {
         if (group.empty()) continue;
         std::vector<uint64_t> nominal(group.size()), stop(group.size());
         std::vector<uint8_t> exact(group.size());
+        ++group_seq_;
         for (size_t k = 0; k < group.size(); ++k) {
             group[k]->offloaded = true;
+            group[k]->group_id = group_seq_;
             nominal[k] = group[k]->nominal_bit; stop[k] = group[k]->stop_bit; exact[k] = group[k]->known_start ? 1 : 0;
         }
         SectionOffload* const off = offload_;
@@ -452,6 +466,7 @@ void ParallelGunzip::top_up(bool need_front) {
             s.start_bit = r.start_bit;
             s.end_bit = r.end_bit;
             s.ext_sym = r.sym;
+            s.resident = r.resident;
             s.n_out = r.n_sym;
             s.ext_token = r.token;
             s.ext_owner = off;
@@ -613,6 +628,91 @@ void ParallelGunzip::accept(Section& s, uint8_t* dst, size_t& out, size_t want) 
     if (s.offloaded) { offloaded_accepted++; offloaded_bytes += n; }
 }
 
+// The front section's symbols are with the decoder (resident): take the RUN it begins — the sections of its group behind it that
+// chain on, each starting at the bit its predecessor ended on — and have the decoder resolve the run's markers against the window
+// the consumer has just arrived with, CRC-32 per section included.  false: nothing of the run can be used (the decoder failed);
+// its sections are dropped and the stretch is decoded here.
+bool ParallelGunzip::resolve_run() {
+    std::vector<std::shared_ptr<Section>> run;
+    uint64_t bit = cur_bit_;
+    const uint64_t gid = q_.begin()->second->group_id;
+    for (auto& kv : q_) {
+        const std::shared_ptr<Section>& s = kv.second;
+        if (!s->offloaded || s->group_id != gid) break;
+        {
+            std::unique_lock<std::mutex> lk(s->mu);           // (a group's sections are handed back one after the other, microseconds apart)
+            s->cv.wait(lk, [&] { return s->done; });
+        }
+        if (!s->found || s->error || !s->resident || s->resolved || s->start_bit != bit) break;
+        run.push_back(s);
+        bit = s->end_bit;
+    }
+    if (run.empty()) return false;
+    std::vector<void*> tokens(run.size());
+    std::vector<uint32_t> crc(run.size());
+    size_t pieces = 0;
+    for (size_t k = 0; k < run.size(); ++k) { tokens[k] = run[k]->ext_token; pieces += (run[k]->n_out + NL_PIECE - 1) / NL_PIECE; }
+    std::vector<uint32_t> piece_nl(pieces);
+    run_tail_.resize(WINDOW);
+    size_t tail_len = 0;
+    const int rc = offload_->resolve(tokens.data(), (int)run.size(), window_.data(), window_.size(), crc.data(), run_tail_.data(), &tail_len, piece_nl.data());
+    if (rc == GZ_ERR_DATA) { fail("corrupt gzip data: a back-reference reaches before the start of its member"); return false; }
+    if (rc != 0) {
+        for (auto& s : run) { q_.erase(s->index); sections_discarded++; }
+        return false;
+    }
+    run_tail_.resize(tail_len);
+    run_last_ = run.back().get();
+    size_t p0 = 0;
+    for (size_t k = 0; k < run.size(); ++k) {
+        const size_t cnt = (run[k]->n_out + NL_PIECE - 1) / NL_PIECE;
+        run[k]->resolved = true;
+        run[k]->crc = crc[k];
+        run[k]->piece_nl.assign(piece_nl.begin() + (long)p0, piece_nl.begin() + (long)(p0 + cnt));
+        p0 += cnt;
+    }
+    return true;
+}
+
+// [sec_off, sec_off + len) of a resolved resident section belongs at dst_off of the caller's buffer: listed, not copied — when the
+// caller takes segments and the text is in device memory
+bool ParallelGunzip::push_segment(const std::shared_ptr<Section>& sp, size_t sec_off, size_t len, size_t dst_off) {
+    if (!segs_) return false;
+    int dev = -1;
+    const uint8_t* p = offload_->text_ptr(sp->ext_token, &dev);
+    if (!p) return false;
+    DevSegment g;
+    g.dst_off = dst_off; g.len = len; g.dev = p + sec_off; g.device = dev; g.sec_off = sec_off; g.sec_len = sp->n_out;
+    g.piece_nl = sp->piece_nl.data(); g.token = sp->ext_token; g.owner = offload_; g.keep = sp;
+    segs_->push_back(std::move(g));
+    return true;
+}
+
+// a resolved resident section: its bytes come straight from the decoder (fetch) or stay with it (a segment), its CRC-32 is known
+void ParallelGunzip::accept_resident(const std::shared_ptr<Section>& sp, uint8_t* dst, size_t& out, size_t want) {
+    Section& s = *sp;
+    const size_t n = s.n_out;
+    const size_t to_dst = std::min(n, want - out);
+    if (to_dst && !push_segment(sp, 0, to_dst, out)) {
+        if (!offload_->fetch(s.ext_token, 0, to_dst, dst + out)) fail("device gunzip: copying a section's text failed");
+        fetch_dirty_ = true;
+        fetch_keep_.push_back(sp);                                 // (its text must stay where it is until the copy has landed)
+    }
+    if (to_dst < n) { pend_sec_ = sp; pend_off_ = to_dst; }        // the rest with the next read()
+    {
+        std::lock_guard<std::mutex> g(sh_->mu);
+        sh_->events.push_back(Event{0, s.crc, (uint64_t)n});
+    }
+    if (&s == run_last_) { window_.assign(run_tail_.begin(), run_tail_.end()); run_last_ = nullptr; }
+    out += to_dst;
+    total_out += n;
+    cur_bit_ = s.end_bit;
+    sections_accepted++;
+    offloaded_accepted++;
+    offloaded_bytes += n;
+    resident_bytes += n;
+}
+
 // sequential decoding from cur_bit_ with the window known, one buffer-full per call, until a block boundary at or behind
 // `until_bit` (what could not be taken from the speculative sections: a gap before a section's start, a section that did
 // not chain up, the whole stream when no block start is recognised)
@@ -661,7 +761,9 @@ void ParallelGunzip::bridge(uint64_t until_bit, uint8_t* dst, size_t& out, size_
     fail("corrupt or truncated gzip data");
 }
 
-size_t ParallelGunzip::read(uint8_t* dst, size_t want) {
+size_t ParallelGunzip::read(uint8_t* dst, size_t want, std::vector<DevSegment>* segs) {
+    segs_ = segs;
+    struct SegsOff { std::vector<DevSegment>*& p; ~SegsOff() { p = nullptr; } } segs_off{segs_};
     size_t out = 0;
     if (spill_lo_ < spill_.size()) {
         const size_t k = std::min(want, spill_.size() - spill_lo_);
@@ -670,6 +772,23 @@ size_t ParallelGunzip::read(uint8_t* dst, size_t want) {
         out = k;
         if (spill_lo_ == spill_.size()) { spill_.clear(); spill_lo_ = 0; }
         if (out == want) return out;
+    }
+    auto finish_fetches = [&] {
+        if (fetch_dirty_) { fetch_dirty_ = false; if (!offload_->fetch_wait()) fail("device gunzip: copying a section's text failed"); }
+        fetch_keep_.clear();
+    };
+    if (pend_sec_) {
+        // what is left of the resident section the last call ended in
+        const size_t k = std::min(want - out, pend_sec_->n_out - pend_off_);
+        if (k && !push_segment(pend_sec_, pend_off_, k, out)) {
+            if (!offload_->fetch(pend_sec_->ext_token, pend_off_, k, dst + out)) fail("device gunzip: copying a section's text failed");
+            fetch_dirty_ = true;
+            fetch_keep_.push_back(pend_sec_);
+        }
+        pend_off_ += k;
+        out += k;
+        if (pend_off_ == pend_sec_->n_out) { finish_fetches(); pend_sec_.reset(); pend_off_ = 0; }
+        if (out == want || bad_) { finish_fetches(); return bad_ ? 0 : out; }
     }
     if (!started_ && !bad_ && !done_) {
         if (size_ == 0) done_ = true;
@@ -703,7 +822,17 @@ size_t ParallelGunzip::read(uint8_t* dst, size_t want) {
         t0 = now_us();
         (f->offloaded ? us_wait_device : us_wait_pool) += t0 - t1;
         const bool usable = f->found && !f->error;
-        if (usable && f->start_bit == cur_bit_) {
+        if (usable && f->start_bit == cur_bit_ && f->resident) {
+            if (!f->resolved) {
+                const bool ok = resolve_run();
+                us_resolve += now_us() - t0;
+                if (!ok) continue;                  // (failed: bad_ is set; or the run was dropped: the loop bridges the stretch)
+                t0 = now_us();
+            }
+            accept_resident(f, dst, out, want);
+            q_.erase(q_.begin());
+            us_accept += now_us() - t0;
+        } else if (usable && f->start_bit == cur_bit_) {
             GZ_PROF(5);
             accept(*f, dst, out, want);
             q_.erase(q_.begin());
@@ -718,6 +847,7 @@ size_t ParallelGunzip::read(uint8_t* dst, size_t want) {
     }
     {
         const uint64_t t0 = now_us();
+        finish_fetches();
         drain_events(true);
         us_drain += now_us() - t0;
     }

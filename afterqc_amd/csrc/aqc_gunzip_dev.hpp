@@ -81,7 +81,9 @@ constexpr int GZB_DEC_THREADS = 64;
 constexpr int GZB_K = 32;                          // lanes per block (entry points guessed inside it, see gzb_decode_kernel)
 constexpr uint32_t GZB_OVERLAP_BITS = 4096;        // how far a lane reads into its successor's share to meet its token list
 constexpr uint32_t GZB_PLAIN_BITS = 8192;           // a block shorter than this is read by one lane
-constexpr uint32_t GZB_CAND_EXTRA = 4104u + (uint32_t)GZB_K * GZB_OVERLAP_BITS;       // symbol space per candidate beyond ratio_cap x its bytes
+constexpr uint32_t GZB_SYM_EXTRA = 4104u;           // symbol space per candidate beyond ratio_cap x its bytes
+constexpr uint32_t GZB_OVERLAP_TOKENS = 512u;       // token entries a lane has for what it reads of its successor's share (8 bits a token: FASTQ's tokens take ~16 — its bases go out as
+                                                    // matches of 7 - 8, measured 0.5 - 0.6 tokens per compressed byte at every level; less: overflow, the group is decoded again with more)
 constexpr uint32_t GZB_T_EOB = 0x40000000u, GZB_T_JUNK = 0x20000000u;
 constexpr int GZB_SEC_BLOCKS = 4096;                // chain entries per section (3 words each)
 constexpr int GZB_GATHER_THREADS = 1024;
@@ -108,8 +110,14 @@ struct GzbJob {
     uint32_t* c_symcap;
     uint16_t* blk_sym;
     uint64_t blk_sym_cap;        // symbols
-    unsigned long long* blk_tp;  // tokens of candidate c at [c_symoff[c] / 2, + c_symcap[c] / 2), GZB_K equal shares for its GZB_K lanes: the token in the
+    unsigned long long* blk_tp;  // tokens of candidate c at [c_tokoff[c], + c_tokcap[c]), GZB_K equal shares for its GZB_K lanes: the token in the
                                  // low word, the bit it starts at in the high one (one store per token)
+    uint64_t* c_tokoff;          // [cand_cap]
+    uint32_t* c_tokcap;          // [cand_cap] a multiple of GZB_K
+    uint64_t blk_tp_cap;         // entries
+    uint32_t overlap_tokens;     // token entries a lane has for what it reads of its successor's share (GZB_OVERLAP_TOKENS; more for streams of literals)
+    uint32_t tok_ratio;          // token entries per compressed byte (round 6: no longer tied to the symbol space — tokens are bounded by
+                                 // the compressed bits, symbols by the text: sized together they cost 12 x 6 bytes per compressed byte)
     uint32_t* c_lanes;           // [cand_cap] lanes that read this block: GZB_K from guessed entry points, or 1 (plain)
     uint32_t* l_p;               // [cand_cap * GZB_K] per lane: bit position reached ...
     uint32_t* l_stop;            //   ... where it stops (a lane reads on behind its share until it has met its successor's list)
@@ -504,8 +512,8 @@ GZB_HD inline void gzb_plan_lanes(const GzbJob& J, uint32_t c, uint32_t n, uint3
 // this block".  Returns the block's flags; n_sym / end_bit as gzb_chain_section wants them.
 GZB_HD inline uint32_t gzb_stitch_expand(const GzbJob& J, uint32_t c, uint32_t& n_sym, uint32_t& end_bit) {
     const uint32_t lanes = J.c_lanes[c], cap = J.c_symcap[c];
-    const uint32_t share = (cap / 2u) / (uint32_t)GZB_K;
-    const unsigned long long* const tp0 = J.blk_tp + J.c_symoff[c] / 2;
+    const uint32_t share = J.c_tokcap[c] / (uint32_t)GZB_K;
+    const unsigned long long* const tp0 = J.blk_tp + J.c_tokoff[c];
     uint16_t* const out = J.blk_sym + J.c_symoff[c];
     for (uint32_t k = 0; k < lanes; ++k)
         if (J.l_flags[c * GZB_K + k] != 0u) return J.l_flags[c * GZB_K + k] == GZB_F_MORE ? GZB_F_OVERFLOW : J.l_flags[c * GZB_K + k];
@@ -542,14 +550,18 @@ GZB_HD inline uint32_t gzb_stitch_expand(const GzbJob& J, uint32_t c, uint32_t& 
     return 0;
 }
 
-// symbol space of candidate c of n: ratio_cap x the compressed bytes up to the next candidate (the last one: to the window's end),
-// and what its lanes' overlaps need: the tokens live in half as many 64-bit entries, a lane's share of them must hold the
-// tokens of its share of the block AND of GZB_OVERLAP_BITS more (two bits a token are assumed; less: overflow, the host's)
-GZB_HD inline uint64_t gzb_sym_budget(uint64_t span, uint32_t ratio_cap) { return span * ratio_cap + (span / 16384u + 32u) * (uint64_t)GZB_CAND_EXTRA; }
-GZB_HD inline uint32_t gzb_symcap_of(const GzbJob& J, uint32_t c, uint32_t n) {
+// symbol space of candidate c of n: ratio_cap x the compressed bytes up to the next candidate (the last one: to the window's end);
+// token space: tok_ratio entries per compressed byte, and per lane GZB_OVERLAP_TOKENS more for what it reads of its successor's
+// share.  Whatever does not fit overflows, and that block's section is the host's.  (Budgets: a candidate per 16 KiB at most.)
+GZB_HD inline uint64_t gzb_sym_budget(uint64_t span, uint32_t ratio_cap) { return span * ratio_cap + (span / 16384u + 32u) * (uint64_t)GZB_SYM_EXTRA; }
+GZB_HD inline uint64_t gzb_tok_budget(uint64_t span, uint32_t tok_ratio, uint32_t overlap_tokens) { return span * tok_ratio + (span / 16384u + 32u) * (uint64_t)(GZB_K * overlap_tokens + 64u); }
+GZB_HD inline uint32_t gzb_cand_span(const GzbJob& J, uint32_t c, uint32_t n) {
     const uint32_t nxt = c + 1 < n ? J.c_start[c + 1] : J.comp_bytes * 8u;
-    const uint32_t span = gzb_min((nxt - J.c_start[c] + 7u) >> 3, 2u << 20);        // (a block of more than 2 MiB: overflow, host)
-    return ((span * J.ratio_cap + GZB_CAND_EXTRA - 8u) + 7u) & ~7u;
+    return gzb_min((nxt - J.c_start[c] + 7u) >> 3, 2u << 20);        // (a block of more than 2 MiB: overflow, host)
+}
+GZB_HD inline uint32_t gzb_symcap_of(const GzbJob& J, uint32_t c, uint32_t n) { return ((gzb_cand_span(J, c, n) * J.ratio_cap + GZB_SYM_EXTRA - 8u) + 7u) & ~7u; }
+GZB_HD inline uint32_t gzb_tokcap_of(const GzbJob& J, uint32_t c, uint32_t n) {
+    return (gzb_cand_span(J, c, n) * J.tok_ratio + (uint32_t)GZB_K * J.overlap_tokens + 2u * (uint32_t)GZB_K - 1u) & ~((uint32_t)GZB_K - 1u);
 }
 
 // the usable candidate that starts exactly at bit x (GZB_NONE: none)
@@ -655,7 +667,200 @@ GZB_HD inline uint16_t gzb_rebase(uint32_t x, uint32_t off, const uint16_t* dst)
     return (uint16_t)x;
 }
 
+// ---- RESIDENT results (round 6): markers resolved and CRC-32 computed where the symbols are --------------------------------------
+// A run = consecutive sections of one group, each starting at the bit its predecessor ended on.  Section k's markers point into
+// W_k, the 32 KiB of output before it: W_0 comes from the consumer (it has committed everything in front of the run), W_{k+1} is
+// the last 32 KiB of (W_k ++ text_k).  gzb_window_byte yields the windows one after the other — the only sequential part, 32 KiB
+// per section — and with every W_k at hand each symbol of the run resolves on its own (gzb_resolve_sym).  A window entry below
+// `valid` does not exist (the member began less than 32 KiB before): a marker that points there is corrupt data.
+constexpr uint32_t GZB_WINDOW = 32768u;
+constexpr uint32_t GZB_CRC_PIECE = 65536u, GZB_CRC_THREADS = 256u, GZB_CRC_SLOT = GZB_CRC_PIECE / GZB_CRC_THREADS;
+struct GzbResolveJob {
+    const uint16_t* sym;         // the group's symbols (gzb_gather's output)
+    uint8_t* text;               // text[i] = the byte of symbol i
+    uint8_t* wins;               // [n_run + 1][GZB_WINDOW]: wins[0] the window before the run (right-aligned), wins[k + 1] the one behind section k
+    const uint64_t* off;         // [n_run] first symbol of each section of the run
+    const uint32_t* nsym;        // [n_run]
+    uint32_t n_run;
+    uint32_t valid0;             // entries [0, valid0) of wins[0] do not exist
+    uint32_t* bad;               // [0] set to 1 by a marker that points at a byte that does not exist
+    // CRC-32: pieces of GZB_CRC_PIECE bytes, RIGHT-aligned in their section (only a section's first piece is short: leading zeros do
+    // not disturb a raw CRC); piece p belongs to section piece_sec[p] and is that section's piece_idx[p]-th of piece_cnt
+    const uint32_t* piece_sec;
+    const uint32_t* piece_idx;
+    uint32_t* piece_crc;         // raw CRC (register starts at 0, no final complement) of each piece
+    uint32_t* piece_nl;          // line feeds in each piece (the pipe cuts its chunks at the 4K-th one without looking at the text)
+    uint32_t n_pieces;
+    const uint32_t* crc_tab;     // [GZB_CRC_TAB_WORDS] (gzb_crc_tables)
+};
+// entries of W_k that do not exist, given W_0's
+GZB_HD inline uint32_t gzb_window_valid(const GzbResolveJob& R, uint32_t k) {
+    uint32_t v = R.valid0;
+    for (uint32_t i = 0; i < k && v; ++i) v = R.nsym[i] >= v ? 0u : v - R.nsym[i];
+    return v;
+}
+// W_{k+1}[j] from W_k (w: GZB_WINDOW bytes) and section k's last symbols; *bad |= 1 on a marker into the void
+GZB_HD inline uint8_t gzb_window_byte(const GzbResolveJob& R, uint32_t k, uint32_t j, const uint8_t* w, uint32_t valid, uint32_t* bad) {
+    const uint32_t n = R.nsym[k];
+    if (n < GZB_WINDOW && j < GZB_WINDOW - n) return w[j + n];
+    const uint32_t i = n >= GZB_WINDOW ? n - GZB_WINDOW + j : j - (GZB_WINDOW - n);
+    const uint32_t v = R.sym[R.off[k] + i];
+    if (v & GZB_MARKER) {
+        const uint32_t q = v & 0x7fffu;
+        if (q < valid) *bad = 1u;
+        return w[q];
+    }
+    return (uint8_t)v;
+}
+GZB_HD inline uint8_t gzb_resolve_sym(uint32_t v, const uint8_t* w, uint32_t valid, uint32_t* bad) {
+    if (v & GZB_MARKER) {
+        const uint32_t q = v & 0x7fffu;
+        if (q < valid) *bad = 1u;
+        return w[q];
+    }
+    return (uint8_t)v;
+}
+// raw CRC of slot t of piece (section k, index pi of cnt): bytes [lo, lo + GZB_CRC_SLOT) of the section's text, bytes before the
+// section's start counting as zeros (lo may be < 0 in a section's first piece).  Four bytes per step (slicing: tab = T0 T1 T2 T3,
+// 256 words each — T0 the byte table, T_{i+1}[x] = T0[T_i[x] & 255] ^ T_i[x] >> 8): one dependent table look-up per word, not per byte.
+typedef uint32_t gzb_u32_unaligned __attribute__((aligned(1)));
+GZB_HD inline uint32_t gzb_crc_slot(const uint8_t* text, uint32_t n, uint32_t cnt, uint32_t pi, uint32_t t, const uint32_t* tab, uint32_t* nl) {
+    const long long lo = (long long)n - (long long)(cnt - pi) * GZB_CRC_PIECE + (long long)t * GZB_CRC_SLOT;
+    uint32_t c = 0, lf = 0;
+    for (uint32_t b = 0; b < GZB_CRC_SLOT; b += 4u) {
+        const long long p = lo + b;
+        uint32_t x = 0;
+        if (p >= 0) x = *reinterpret_cast<const gzb_u32_unaligned*>(text + p);
+        else if (p > -4) for (int q = (int)-p; q < 4; ++q) x |= (uint32_t)text[p + q] << (8 * q);
+        {
+            // line feeds among the four bytes (a byte that does not exist is 0, never 0x0a)
+            const uint32_t y = x ^ 0x0a0a0a0au;
+            const uint32_t z = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);      // 0x80 in every zero byte of y
+#if defined(__HIP_DEVICE_COMPILE__)
+            lf += (uint32_t)__popc(z);
+#else
+            lf += (uint32_t)__builtin_popcount(z);
+#endif
+        }
+        c ^= x;
+        c = tab[768u + (c & 0xffu)] ^ tab[512u + ((c >> 8) & 0xffu)] ^ tab[256u + ((c >> 16) & 0xffu)] ^ tab[c >> 24];
+    }
+    *nl = lf;
+    return c;
+}
+constexpr uint32_t GZB_CRC_TAB_WORDS = 1024u + 8u * 32u;    // T0..T3, then [8][32]: "advance the register by GZB_CRC_SLOT << k zero bytes", column j = image of bit j
+// left ++ right, where right is `GZB_CRC_SLOT << level` bytes long: the left register advanced over them, then added
+GZB_HD inline uint32_t gzb_crc_join(uint32_t left, uint32_t right, int level, const uint32_t* tab) {
+    const uint32_t* M = tab + 1024 + 32 * level;
+    uint32_t r = right;
+    for (int j = 0; j < 32; ++j) r ^= ((left >> j) & 1u) ? M[j] : 0u;
+    return r;
+}
+// the tables: `advance(x, n)` = the CRC register x after n zero bytes (zlib: crc32_combine(x, 0, n))
+template <class Advance>
+inline void gzb_crc_tables(uint32_t* tab, Advance advance) {
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t v = i;
+        for (int k = 0; k < 8; ++k) v = (v >> 1) ^ (0xEDB88320u & (0u - (v & 1u)));
+        tab[i] = v;
+    }
+    for (int s = 1; s < 4; ++s)
+        for (uint32_t i = 0; i < 256; ++i) tab[256 * s + i] = tab[tab[256 * (s - 1) + i] & 0xffu] ^ (tab[256 * (s - 1) + i] >> 8);
+    for (int k = 0; k < 8; ++k)
+        for (int j = 0; j < 32; ++j) tab[1024 + 32 * k + j] = advance(1u << j, (uint64_t)GZB_CRC_SLOT << k);
+}
+// a section's CRC-32 from its pieces' raw CRCs (in order): the register advanced over each next piece, then the start value
+// 0xffffffff advanced over the whole section and the final complement (crc32(M) = raw(M) ^ ~advance(~0, |M|))
+template <class Advance>
+inline uint32_t gzb_crc_fold(const uint32_t* piece, uint32_t cnt, uint64_t n, const uint32_t* adv_piece /* [32]: advance by GZB_CRC_PIECE, by column */, Advance advance) {
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        uint32_t a = 0;
+        for (int j = 0; j < 32; ++j) a ^= ((r >> j) & 1u) ? adv_piece[j] : 0u;
+        r = a ^ piece[i];
+    }
+    return r ^ ~advance(0xffffffffu, n);
+}
+
 #if defined(__HIPCC__)
+// the windows, one after the other: ONE workgroup, W_k in LDS
+constexpr int GZB_WIN_THREADS = 1024;
+__global__ __launch_bounds__(GZB_WIN_THREADS) void gzb_windows_kernel(GzbResolveJob R) {
+    __shared__ uint8_t s_w[GZB_WINDOW];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t j = tid * 16u; j < GZB_WINDOW; j += GZB_WIN_THREADS * 16u) *reinterpret_cast<uint4*>(s_w + j) = *reinterpret_cast<const uint4*>(R.wins + j);
+    __syncthreads();
+    uint32_t valid = R.valid0, bad = 0;
+    for (uint32_t k = 0; k < R.n_run; ++k) {
+        uint8_t v[GZB_WINDOW / GZB_WIN_THREADS];
+#pragma unroll
+        for (uint32_t r = 0; r < GZB_WINDOW / GZB_WIN_THREADS; ++r) v[r] = gzb_window_byte(R, k, tid + r * GZB_WIN_THREADS, s_w, valid, &bad);
+        __syncthreads();
+        uint8_t* const out = R.wins + (size_t)(k + 1) * GZB_WINDOW;
+#pragma unroll
+        for (uint32_t r = 0; r < GZB_WINDOW / GZB_WIN_THREADS; ++r) { s_w[tid + r * GZB_WIN_THREADS] = v[r]; out[tid + r * GZB_WIN_THREADS] = v[r]; }
+        __syncthreads();
+        const uint32_t n = R.nsym[k];
+        valid = n >= valid ? 0u : valid - n;
+    }
+    if (bad) R.bad[0] = 1u;
+}
+// every symbol of the run on its own: 16 per thread, blockIdx.y = section
+constexpr int GZB_RES_THREADS = 256;
+__global__ __launch_bounds__(GZB_RES_THREADS) void gzb_resolve_kernel(GzbResolveJob R) {
+    const uint32_t k = blockIdx.y;
+    const uint32_t n = R.nsym[k];
+    const uint32_t i0 = (blockIdx.x * (uint32_t)GZB_RES_THREADS + threadIdx.x) * 16u;
+    if (i0 >= n) return;
+    const uint8_t* const w = R.wins + (size_t)k * GZB_WINDOW;
+    const uint32_t valid = gzb_window_valid(R, k);
+    const uint16_t* const s = R.sym + R.off[k] + i0;        // (section starts are multiples of 32 symbols: 16-byte loads and stores)
+    uint8_t* const d = R.text + R.off[k] + i0;
+    const uint4 a = reinterpret_cast<const uint4*>(s)[0], b = reinterpret_cast<const uint4*>(s)[1];
+    const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t bad = 0, o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t b0 = gzb_resolve_sym(x[2 * q] & 0xffffu, w, valid, &bad), b1 = gzb_resolve_sym(x[2 * q] >> 16, w, valid, &bad),
+                       b2 = gzb_resolve_sym(x[2 * q + 1] & 0xffffu, w, valid, &bad), b3 = gzb_resolve_sym(x[2 * q + 1] >> 16, w, valid, &bad);
+        o[q] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    }
+    // (symbols behind the section's end are padding: whatever they resolve to is never read, and never counts as corrupt)
+    if (i0 + 16u <= n) { if (bad) R.bad[0] = 1u; *reinterpret_cast<uint4*>(d) = make_uint4(o[0], o[1], o[2], o[3]); }
+    else {
+        uint32_t bad2 = 0;
+        for (uint32_t i = 0; i < n - i0; ++i) d[i] = gzb_resolve_sym(s[i], w, valid, &bad2);
+        if (bad2) R.bad[0] = 1u;
+    }
+}
+// raw CRC of every piece: a thread per slot, then a tree of joins
+__global__ __launch_bounds__(GZB_CRC_THREADS) void gzb_crc_kernel(GzbResolveJob R) {
+    __shared__ uint32_t s_tab[GZB_CRC_TAB_WORDS];
+    __shared__ uint32_t s_part[GZB_CRC_THREADS];
+    __shared__ uint32_t s_nl;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < GZB_CRC_TAB_WORDS; i += GZB_CRC_THREADS) s_tab[i] = R.crc_tab[i];
+    if (tid == 0) s_nl = 0;
+    __syncthreads();
+    const uint32_t p = blockIdx.x, k = R.piece_sec[p], n = R.nsym[k];
+    const uint32_t cnt = (n + GZB_CRC_PIECE - 1u) / GZB_CRC_PIECE;
+    uint32_t lf = 0;
+    s_part[tid] = gzb_crc_slot(R.text + R.off[k], n, cnt, R.piece_idx[p], tid, s_tab, &lf);
+    if (lf) atomicAdd(&s_nl, lf);
+    __syncthreads();
+#pragma unroll 1
+    for (int level = 0; level < 8; ++level) {
+        const uint32_t step = 1u << level;
+        const bool active = (tid & (2u * step - 1u)) == 0u;
+        uint32_t r = 0;
+        if (active) r = gzb_crc_join(s_part[tid], s_part[tid + step], level, s_tab);
+        __syncthreads();
+        if (active) s_part[tid] = r;
+        __syncthreads();
+    }
+    if (tid == 0) { R.piece_crc[p] = s_part[0]; R.piece_nl[p] = s_nl; }
+}
+
 // ---- every block start of the batch -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GZB_SCAN_THREADS) void gzb_scan_kernel(GzbJob J) {
     __shared__ uint8_t s_kraft[512];
@@ -765,11 +970,13 @@ __global__ __launch_bounds__(1024) void gzb_compact_kernel(GzbJob J) {
     const uint32_t n = s_total;
     const uint32_t per2 = (n + 1023u) / 1024u;
     const uint32_t c0 = gzb_min(n, tid * per2), c1 = gzb_min(n, c0 + per2);
-    unsigned long long sum = 0;
+    unsigned long long sum = 0, tsum = 0;
     for (uint32_t c = c0; c < c1; ++c) {
-        const uint32_t cap = gzb_symcap_of(J, c, n);
+        const uint32_t cap = gzb_symcap_of(J, c, n), tcap = gzb_tokcap_of(J, c, n);
         J.c_symcap[c] = cap;
+        J.c_tokcap[c] = tcap;
         sum += cap;
+        tsum += tcap;
     }
     s_part64[tid] = sum;
     __syncthreads();
@@ -780,12 +987,24 @@ __global__ __launch_bounds__(1024) void gzb_compact_kernel(GzbJob J) {
     }
     __syncthreads();
     unsigned long long o = s_part64[tid];
+    __syncthreads();
+    s_part64[tid] = tsum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; ++i) { const unsigned long long c = s_part64[i]; s_part64[i] = run; run += c; }
+        if (run > J.blk_tp_cap) J.n_cand[1] = 1;
+    }
+    __syncthreads();
+    unsigned long long to = s_part64[tid];
     for (uint32_t c = c0; c < c1; ++c) {
-        const uint32_t cap = J.c_symcap[c];
+        const uint32_t cap = J.c_symcap[c], tcap = J.c_tokcap[c];
         J.c_symoff[c] = o;
-        // candidates that do not fit the symbol buffer are not decoded (their sections fall back to the host)
-        if (o + cap > J.blk_sym_cap) J.c_symcap[c] = 0;
+        J.c_tokoff[c] = to;
+        // candidates that do not fit the symbol / token buffer are not decoded (their sections fall back to the host)
+        if (o + cap > J.blk_sym_cap || to + tcap > J.blk_tp_cap) J.c_symcap[c] = 0;
         o += cap;
+        to += tcap;
     }
 }
 
@@ -890,8 +1109,8 @@ __global__ __launch_bounds__(GZB_DEC_THREADS) void gzb_decode_kernel(GzbJob J) {
     if (!live) return;
     const uint32_t lanes = J.c_lanes[c];
     const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(s_tab[threadIdx.x / (uint32_t)GZB_K])};
-    const uint32_t share = (J.c_symcap[c] / 2u) / (uint32_t)GZB_K;
-    const size_t at = J.c_symoff[c] / 2 + (size_t)k * share;
+    const uint32_t share = J.c_tokcap[c] / (uint32_t)GZB_K;
+    const size_t at = J.c_tokoff[c] + (size_t)k * share;
     uint32_t p = J.l_p[i], nt = J.l_ntok[i];
     GzbInLds in;
     in.comp16 = reinterpret_cast<const uint4*>(J.comp);
@@ -915,8 +1134,8 @@ __global__ __launch_bounds__(64 * GZB_EXP_WAVES) void gzb_expand_kernel(GzbJob J
     const int lane = (int)(threadIdx.x & 63u);
     if (c >= J.n_cand[0] || J.c_flags[c] != 0u) return;
     const uint32_t lanes = J.c_lanes[c], cap = J.c_symcap[c];
-    const uint32_t share = (cap / 2u) / (uint32_t)GZB_K;
-    const unsigned long long* const tp0 = J.blk_tp + J.c_symoff[c] / 2;
+    const uint32_t share = J.c_tokcap[c] / (uint32_t)GZB_K;
+    const unsigned long long* const tp0 = J.blk_tp + J.c_tokoff[c];
     uint16_t* const out = J.blk_sym + J.c_symoff[c];
     uint32_t fl = 0;
     for (uint32_t q = 0; q < lanes; ++q) {

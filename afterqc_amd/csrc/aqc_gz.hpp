@@ -93,28 +93,72 @@ uint32_t crc32_combine_fast(uint32_t crc1, uint32_t crc2, uint64_t len2);
 // GROUP of consecutive sections is handed over at once; each comes back as what a pool thread would have produced — the block
 // boundary it starts at, the one it ends at, its symbols — or as "nothing found".  The consumer's commit rule does not care who
 // decoded a section, so exactness does not depend on the device being right, only speed does.
+//
+// RESIDENT results (round 6): the symbols of a section STAY with the decoder (sym == nullptr, resident == true) — in HBM — and
+// the consumer, once it has committed everything in front of a run of chained sections and therefore knows the 32 KiB before
+// it, has the decoder resolve the run's markers and compute each section's CRC-32 where the symbols are (resolve()).  The
+// host then sees bytes, not symbols: fetch() copies a piece of a resolved section's text wherever the consumer wants it
+// (the pipe: straight into the page-locked chunk buffer), and neither the translation nor the checksum costs a CPU cycle.
+constexpr size_t NL_PIECE = 65536;      // resolve() counts a resident section's line feeds in pieces of this size, RIGHT-aligned in the section
+                                        // (only the first piece is short): piece j of a section of n bytes ends at n - (pieces - 1 - j) * NL_PIECE
+// A stretch of a caller's buffer whose bytes are NOT written there because they are text in device memory (a resolved resident
+// section, or part of one): ParallelGunzip::read(dst, want, &segments).  The pipe hands such stretches to aqc_frame_mixed, which
+// copies them inside the device; PCIe never sees them.
+struct DevSegment {
+    size_t dst_off = 0, len = 0;        // where in the caller's buffer the bytes belong
+    const uint8_t* dev = nullptr;       // the bytes
+    int device = -1;                    // ... on this device
+    size_t sec_off = 0, sec_len = 0;    // which part of its section this is: [sec_off, sec_off + len) of sec_len bytes
+    const uint32_t* piece_nl = nullptr; // line feeds per NL_PIECE piece of the section (see above)
+    void* token = nullptr;              // SectionOffload::fetch(token, offset in the section, ...) still works
+    class SectionOffload* owner = nullptr;
+    std::shared_ptr<void> keep;         // the section: its text stays where it is while somebody holds this
+};
 struct OffloadResult {
     bool found = false;
     uint64_t start_bit = 0, end_bit = 0;
     const uint16_t* sym = nullptr;      // n_sym symbols, markers relative to the section's start; valid until release(token)
     size_t n_sym = 0;
     void* token = nullptr;
+    bool resident = false;              // the symbols are with the decoder: resolve() + fetch() instead of `sym`
 };
 class SectionOffload {
 public:
     virtual ~SectionOffload() {}
     virtual size_t group_bytes() const = 0;          // compressed bytes it likes to take per group
     virtual bool ready() = 0;                        // would submit() be accepted right now?  (never blocks)
+    // groups of about `group_bytes` compressed bytes are going to be submitted: set up what that needs (device buffers) in the
+    // background; ready() stays false until it exists, so that nobody waits for a group that waits for an allocation
+    virtual void prepare(size_t group_bytes) { (void)group_bytes; }
+    // the decoder no longer takes work and never will again (as opposed to "busy right now")
+    virtual bool gave_up() { return false; }
     // n consecutive sections of data[0, size): search from nominal[k] (exact[k]: the section must start AT it), stop at the first
     // block boundary at or behind stop[k].  done(k, result) is called exactly once per section, from another thread.
     virtual bool submit(const uint8_t* data, size_t size, int n, const uint64_t* nominal, const uint64_t* stop, const uint8_t* exact,
                         std::function<void(int, const OffloadResult&)> done) = 0;
-    virtual void release(void* token) = 0;           // the symbols of one result are no longer needed
+    virtual void release(void* token) = 0;           // the symbols (and the text) of one result are no longer needed
+    // Resident results only.  tokens[0, n): consecutive sections of ONE group, each starting at the bit its predecessor ended on;
+    // win[0, wlen): the <= 32 KiB of the member's output right before tokens[0]'s first symbol.  Resolves every marker, leaves
+    // crc[k] = CRC-32 of section k's bytes and tail[0, *tail_len) = the last <= 32 KiB of the member's output behind the run.
+    // Returns 0, GZ_ERR_DATA (a marker points before the member's start: corrupt data) or -2 (the decoder failed: nothing of
+    // these sections can be used).
+    // piece_nl (may be null): line feeds of every NL_PIECE piece of every section, in order (sum of ceil(bytes / NL_PIECE) entries).
+    virtual int resolve(void* const* tokens, int n, const uint8_t* win, size_t wlen, uint32_t* crc, uint8_t* tail, size_t* tail_len, uint32_t* piece_nl) {
+        (void)tokens; (void)n; (void)win; (void)wlen; (void)crc; (void)tail; (void)tail_len; (void)piece_nl;
+        return -2;
+    }
+    // where a resolved section's text is (nullptr: not in device memory)
+    virtual const uint8_t* text_ptr(void* token, int* device) { (void)token; (void)device; return nullptr; }
+    // bytes [off, off + len) of a resolved section -> dst (queued; fetch_wait() returns once every queued copy has landed)
+    virtual bool fetch(void* token, size_t off, size_t len, uint8_t* dst) { (void)token; (void)off; (void)len; (void)dst; return false; }
+    virtual bool fetch_wait() { return false; }
 };
 // the device decoder of GPU `device` (aqc_capi.hip); nullptr when it cannot be set up
 SectionOffload* make_device_offload(int device, size_t group_bytes);
 // kernel / copy microseconds of every device decoder of the process so far: scan, decode, chain + gather, H2D, D2H, groups, sections given, sections found
 void device_offload_stats(uint64_t out[8]);
+// resident results (round 6): runs resolved on the devices, their sections, microseconds inside resolve(), bytes of text resolved
+void device_resolve_stats(uint64_t out[4]);
 
 class ParallelGunzip {
 public:
@@ -124,15 +168,18 @@ public:
     ParallelGunzip(const uint8_t* data, size_t size, aqc_host::Pool* pool, int inflight, size_t section_bytes, SectionOffload* offload = nullptr,
                    bool offload_only = false);
     ~ParallelGunzip();
-    size_t read(uint8_t* dst, size_t want);
+    // segs != nullptr: text that is in device memory (resolved resident sections) is not copied to dst — its place there stays
+    // unwritten and is listed in *segs (appended, in order of dst_off) instead
+    size_t read(uint8_t* dst, size_t want, std::vector<DevSegment>* segs = nullptr);
     bool failed() const { return bad_; }
     const char* error() const { return err_; }
     // statistics
     uint64_t sections_accepted = 0, sections_discarded = 0, bridged_bytes = 0, total_out = 0;
     uint64_t sections_offloaded = 0, offloaded_accepted = 0, offloaded_bytes = 0;      // handed to the device / committed from it / their text
+    uint64_t resident_bytes = 0;                   // of offloaded_bytes: text whose markers and CRC-32 the device resolved (no host translation)
     // where the consumer's wall time inside read() went, microseconds: waiting for a section of the pool / of the device to be
     // decoded, waiting for (and helping with) the translation of what it committed, handing out work, committing, bridging
-    uint64_t us_wait_pool = 0, us_wait_device = 0, us_drain = 0, us_top_up = 0, us_accept = 0, us_bridge = 0;
+    uint64_t us_wait_pool = 0, us_wait_device = 0, us_drain = 0, us_top_up = 0, us_accept = 0, us_bridge = 0, us_resolve = 0;
 
     struct Section;
     struct Shared;
@@ -145,6 +192,8 @@ private:
     };
     void top_up(bool need_front = false);
     void accept(Section& s, uint8_t* dst, size_t& out, size_t want);
+    bool resolve_run();
+    void accept_resident(const std::shared_ptr<Section>& s, uint8_t* dst, size_t& out, size_t want);
     void bridge(uint64_t until_bit, uint8_t* dst, size_t& out, size_t want);
     void emit(const uint8_t* p, size_t n, uint8_t* dst, size_t& out, size_t want);
     bool member_end(uint64_t& bit);      // trailer + next header at byte-aligned `bit`; false: no further member
@@ -166,6 +215,17 @@ private:
     std::shared_ptr<Shared> sh_;
     std::map<size_t, std::shared_ptr<Section>> q_;  // created and not yet committed, by section index
     std::shared_ptr<Section> unlaunched_;          // the last pool section, while it waits for a partner (sections are decoded in pairs)
+    // resident sections (their symbols stay with the decoder): the run resolved last — its last section and the window behind it —,
+    // the section a read() ended in the middle of, and whether copies are still on their way into the caller's buffer
+    uint64_t group_seq_ = 0;
+    Section* run_last_ = nullptr;
+    std::vector<uint8_t> run_tail_;
+    std::shared_ptr<Section> pend_sec_;
+    size_t pend_off_ = 0;
+    bool fetch_dirty_ = false;
+    std::vector<DevSegment>* segs_ = nullptr;      // (for the duration of a read())
+    bool push_segment(const std::shared_ptr<Section>& sp, size_t sec_off, size_t len, size_t dst_off);
+    std::vector<std::shared_ptr<Section>> fetch_keep_;
     // Section indices: start_idx_ is the section that begins at the stream's known first block, index i > start_idx_ is searched
     // from byte i * section_bytes on, last_idx_ runs to the end of the file.  They are handed out window by window
     // ([win_lo_, win_hi_)): the POOL takes them from the bottom up (pool_next_), the DEVICE in groups from the top down

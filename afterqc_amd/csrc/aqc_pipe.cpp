@@ -299,9 +299,15 @@ struct Bz2Source : Source {
     bool done = false;
 
     void fail(const char* msg) {
-        std::lock_guard<std::mutex> g(err_mu);
-        if (!bad) snprintf(err, sizeof(err), "%s", msg);
-        bad = true;
+        {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (!bad) snprintf(err, sizeof(err), "%s", msg);
+        }
+        {
+            std::lock_guard<std::mutex> g(mu);
+            bad = true;
+        }
+        cv.notify_all();
     }
     Bz2Source(const char* path, Pool* p) : pool(p) {
         fd = open(path, O_RDONLY);
@@ -320,7 +326,10 @@ struct Bz2Source : Source {
         producer = std::thread([this] { produce(); });
     }
     ~Bz2Source() override {
-        stop = true;
+        {
+            std::lock_guard<std::mutex> g(mu);          // (under the lock the producer evaluates its wait predicate with: no lost wake-up)
+            stop = true;
+        }
         cv.notify_all();
         if (producer.joinable()) producer.join();
         if (map) munmap((void*)map, size);
@@ -333,31 +342,60 @@ struct Bz2Source : Source {
         static const uint8_t blk[6] = {0x31, 0x41, 0x59, 0x26, 0x53, 0x59}, eos[6] = {0x17, 0x72, 0x45, 0x38, 0x50, 0x90};
         return p[0] == 'B' && p[1] == 'Z' && p[2] == 'h' && p[3] >= '1' && p[3] <= '9' && (memcmp(p + 4, blk, 6) == 0 || memcmp(p + 4, eos, 6) == 0);
     }
-    // one stream -> text; false: libbz2 rejected it or it ends early
-    bool decode(size_t a, size_t b, std::vector<uint8_t>& out) {
+    // one stream -> text; false: libbz2 rejected it or it ends early.  *garbage: bytes follow the stream's end inside [a, b) that
+    // are not a stream — python's BZ2File reads up to there and ignores the rest of the FILE (its _compression.DecompressReader
+    // treats data that does not decompress as trailing garbage), so the caller stops behind this stream.
+    // sink != nullptr: the text is handed over in pieces of PIECE bytes as they fill (a big stream never sits in memory whole:
+    // round-5 advisory — a plain `bzip2` file is ONE stream, and the queue's 1 GiB bound only counted whole streams)
+    static constexpr size_t PIECE = 16u << 20;
+    bool decode(size_t a, size_t b, std::vector<uint8_t>& out, bool* garbage, const std::function<bool(std::vector<uint8_t>&&)>* sink = nullptr) {
         const Bz2Api& api = Bz2Api::get();
         Bz2Api::Stream z{};
         if (api.init(&z, 0, 0) != 0) return false;
-        out.resize(std::max<size_t>(1u << 20, (b - a) * 5));
+        out.resize(sink ? PIECE : std::max<size_t>(1u << 20, (b - a) * 5));
         size_t produced = 0;
         z.next_in = (char*)(map + a);
         size_t in_left = b - a;
         bool ok = false;
         for (;;) {
             if (z.avail_in == 0 && in_left) { z.avail_in = (unsigned)std::min<size_t>(in_left, 1u << 30); in_left -= z.avail_in; }
-            if (out.size() - produced < (1u << 16)) out.resize(out.size() + out.size() / 2);
+            if (out.size() - produced < (1u << 16)) {
+                if (sink) {
+                    out.resize(produced);
+                    if (!(*sink)(std::move(out))) break;                       // (stopped)
+                    out = std::vector<uint8_t>(PIECE);
+                    produced = 0;
+                } else out.resize(out.size() + out.size() / 2);
+            }
             z.next_out = (char*)out.data() + produced;
             const size_t room = std::min<size_t>(out.size() - produced, 1u << 30);
             z.avail_out = (unsigned)room;
             const int rc = api.step(&z);
             produced += room - z.avail_out;
-            if (rc == 4) { ok = z.avail_in == 0 && in_left == 0; break; }          // BZ_STREAM_END (and nothing behind it inside this piece)
+            if (rc == 4) {                                                      // BZ_STREAM_END
+                ok = true;
+                if (garbage) *garbage = z.avail_in != 0 || in_left != 0;
+                break;
+            }
             if (rc != 0 || (z.avail_in == 0 && in_left == 0 && z.avail_out != 0)) break;   // error, or the stream ends early
             if (stop) break;
         }
         api.end(&z);
         out.resize(produced);
+        if (ok && sink && produced) ok = (*sink)(std::move(out));
         return ok;
+    }
+    // decoded text into the queue, in order; false: the reader has gone
+    bool enqueue(std::vector<uint8_t>&& text) {
+        if (text.empty()) return true;
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop.load() || q_bytes < (1u << 30); });
+        if (stop) return false;
+        q_bytes += text.size();
+        q.push_back(std::move(text));
+        lk.unlock();
+        cv.notify_all();
+        return true;
     }
     void produce() {
         // stream starts: byte aligned (a stream is padded to a whole byte); ten fixed bytes make a chance hit a 2^-80 event
@@ -377,22 +415,32 @@ struct Bz2Source : Source {
             if (starts.empty() || starts[0] != 0) { fail("not a bzip2 file"); starts.clear(); }
             starts.push_back(size);
         }
+        // small streams (pbzip2's blocks: <= 900 KB of text each) are decoded whole, a window of them in parallel on the pool; a
+        // big one — the single stream of a plain `bzip2` file — is decoded here, piece by piece, straight into the queue
         const size_t window = (size_t)std::max(2, pool->size());
-        for (size_t k = 0; k + 1 < starts.size() && !stop && !bad; k += window) {
-            const size_t n = std::min(window, starts.size() - 1 - k);
+        const size_t BIG = 8u << 20;
+        bool cut = false;                         // garbage behind a stream: python's reader ends the file there
+        for (size_t k = 0; k + 1 < starts.size() && !stop && !bad && !cut;) {
+            if (starts[k + 1] - starts[k] > BIG) {
+                std::vector<uint8_t> out;
+                bool garbage = false;
+                const std::function<bool(std::vector<uint8_t>&&)> sink = [this](std::vector<uint8_t>&& t) { return enqueue(std::move(t)); };
+                if (!decode(starts[k], starts[k + 1], out, &garbage, &sink)) { if (!stop) fail("corrupt or truncated bzip2 stream"); break; }
+                cut = garbage;
+                ++k;
+                continue;
+            }
+            size_t n = 0;
+            while (n < window && k + n + 1 < starts.size() && starts[k + n + 1] - starts[k + n] <= BIG) ++n;
             std::vector<std::vector<uint8_t>> outs(n);
-            std::vector<char> good(n, 0);
-            pool->parallel_for(n, [&](size_t i) { good[i] = decode(starts[k + i], starts[k + i + 1], outs[i]) ? 1 : 0; });
+            std::vector<char> good(n, 0), junk(n, 0);
+            pool->parallel_for(n, [&](size_t i) { bool g = false; good[i] = decode(starts[k + i], starts[k + i + 1], outs[i], &g) ? 1 : 0; junk[i] = g ? 1 : 0; });
             for (size_t i = 0; i < n && !bad; ++i) {
                 if (!good[i]) { fail("corrupt or truncated bzip2 stream"); break; }
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || q_bytes < (1u << 30); });
-                if (stop) break;
-                q_bytes += outs[i].size();
-                q.push_back(std::move(outs[i]));
-                lk.unlock();
-                cv.notify_all();
+                if (!enqueue(std::move(outs[i]))) break;
+                if (junk[i]) { cut = true; break; }
             }
+            k += n;
         }
         {
             std::lock_guard<std::mutex> g(mu);
@@ -487,8 +535,8 @@ struct GzSource : Source {
                         (unsigned long long)pg->sections_accepted, (unsigned long long)pg->offloaded_accepted, (unsigned long long)pg->sections_offloaded,
                         (unsigned long long)pg->sections_discarded, 1e-6 * (double)pg->bridged_bytes, 1e-6 * (double)pg->total_out);
             if (getenv("AQC_PIPE_DEBUG"))
-                fprintf(stderr, "pipe: gunzip consumer, ms inside read() — waiting for a pool section %.1f, for a device section %.1f, for the translation of what it committed %.1f, handing out work %.1f, committing %.1f, decoding sequentially %.1f\n",
-                        pg->us_wait_pool / 1e3, pg->us_wait_device / 1e3, pg->us_drain / 1e3, pg->us_top_up / 1e3, pg->us_accept / 1e3, pg->us_bridge / 1e3);
+                fprintf(stderr, "pipe: gunzip consumer, ms inside read() — waiting for a pool section %.1f, for a device section %.1f, for the device to resolve a run %.1f (%.1f MB of text resolved there), for the translation of what it committed + the copies from the device %.1f, handing out work %.1f, committing %.1f, decoding sequentially %.1f\n",
+                        pg->us_wait_pool / 1e3, pg->us_wait_device / 1e3, pg->us_resolve / 1e3, 1e-6 * (double)pg->resident_bytes, pg->us_drain / 1e3, pg->us_top_up / 1e3, pg->us_accept / 1e3, pg->us_bridge / 1e3);
         }
         pg.reset();
         if (map) munmap((void*)map, size);
@@ -508,6 +556,16 @@ struct GzSource : Source {
         if (size == 0) return 0;
         if (bgzf) return read_bgzf(dst, want);
         const size_t got = pg->read(dst, want);
+        if (pg->failed()) { fail(pg->error()); return 0; }
+        return got;
+    }
+
+    // read(), but text that is in device memory stays there and is listed in *segs (one-member files with a device decoder only)
+    bool takes_segments() const { return mapped && !bgzf && pg != nullptr && size != 0; }
+    size_t read_segments(uint8_t* dst, size_t want, std::vector<aqcgz::DevSegment>* segs) {
+        if (bad) return 0;
+        if (!takes_segments()) return read(dst, want);
+        const size_t got = pg->read(dst, want, segs);
         if (pg->failed()) { fail(pg->error()); return 0; }
         return got;
     }
@@ -710,6 +768,10 @@ struct InChunk {
     uint64_t bytes = 0, lines = 0;
     bool final = false;
     int buf = -1;        // index into the file's buffer ring (-1: zero-copy view of a memory source)
+    // stretches of the chunk whose bytes are NOT in `data` but in the memory of the device the chunk is dealt to (a .gz input
+    // decoded there: aqc_frame_mixed), sorted by offset; they hold their sections — and so the text — until the chunk is framed
+    std::shared_ptr<std::vector<aqcgz::DevSegment>> ext;
+    uint8_t last_byte = '\n';
 };
 
 struct OutChunk {
@@ -825,6 +887,21 @@ struct Run {
             fprintf(stderr, "pipe: %s thread — NUMA node %d, %s\n", what, io_node, bound ? "bound to that node's CPUs" : "not bound (contexts on several nodes, single node, unknown, or AQC_PIPE_NUMA=0)");
     }
     bool spans_on = false;             // plain-text output: good records that go out as their own bytes are written from the input buffers
+    // End of input inside the pipe (fastq.py:37-49, preprocesser.py:412-429).  A chunk is RUN only once every chunk before it has been
+    // framed and found to continue the input: the chunk in which the input ends (an empty line, a partial last record, a mate file
+    // that is shorter) becomes the run's last, chunks behind it are dropped before anything of them reaches a counter.
+    std::mutex fr_mu;
+    std::condition_variable fr_cv;
+    uint64_t framed_next = 0, end_chunk = UINT64_MAX;
+    std::atomic<bool> ended{false};        // the input has ended in a chunk: readers and the dispatcher stop feeding
+    uint64_t extra_bases = 0;
+    void end_input() {
+        ended = true;
+        for (int f = 0; f < 2; ++f) {
+            if (inq[f]) inq[f]->close();
+            ring_cv[f].notify_all();
+        }
+    }
     // QC turn taking (post-filter sampling must be issued in chunk order, see aqc_qc_stat's time keys)
     std::mutex qc_mu;
     std::condition_variable qc_cv;
@@ -857,6 +934,7 @@ struct Run {
         for (int q = 0; q < 6; ++q) if (fileq[q]) fileq[q]->close();
         set_cv.notify_all();
         qc_cv.notify_all();
+        fr_cv.notify_all();
         for (auto& g : up_gate) { std::lock_guard<std::mutex> lk(g->mu); g->cv.notify_all(); }
         for (auto& g : down_gate) { std::lock_guard<std::mutex> lk(g->mu); g->cv.notify_all(); }
     }
@@ -865,12 +943,12 @@ struct Run {
         std::unique_lock<std::mutex> lk(ring_mu[f]);
         int got = -1;
         ring_cv[f].wait(lk, [&] {
-            if (abort) return true;
+            if (abort || ended) return true;
             for (size_t i = 0; i < ring_free[f].size(); ++i)
                 if (ring_free[f][i]) { got = (int)i; return true; }
             return false;
         });
-        if (abort || got < 0) return -1;
+        if (abort || ended || got < 0) return -1;
         ring_free[f][got] = 0;
         return got;
     }
@@ -889,29 +967,46 @@ struct Run {
         const bool mem = io->in_mem[f] != nullptr;
         std::unique_ptr<Source> src;
         if (!mem) {
+            if (io->gzip_in[f] == 2 && !Bz2Api::get().ok) {
+                // no libbz2 to load: not an error of the input — the caller's serial loop reads .bz2 through python's own module
+                anomaly = true;
+                stop_all();
+                return;
+            }
             if (io->gzip_in[f] == 2) src.reset(new Bz2Source(io->in_path[f], P->pool.get()));
             else if (io->gzip_in[f]) {
                 // gzip input: the GPUs take groups of sections off the pool's hands (file f -> the device of context f % n)
                 const char* e = getenv("AQC_GZ_DEVICE_IN");
                 if (!(e && e[0] == '0') && !P->gz_offload_tried[f] && !P->ctx.empty()) {      // (set up with the first .gz input of this file slot)
                     P->gz_offload_tried[f] = true;
-                    size_t group = 96u << 20;
+                    size_t group = 96u << 20;       // (measured, warm pipe, 0.59 GB inputs: groups of 16 / 32 / 96 MiB = 34 / 38 / 42.5 Mreads/s — profiles/r06_gz_hbm_ab.txt)
                     if (const char* g = getenv("AQC_GZ_GROUP")) group = (size_t)std::max(1ll, atoll(g));
                     P->gz_offload[f].reset(aqcgz::make_device_offload(aqc_device_index(P->ctx[(size_t)f % P->ctx.size()]), group));
                 }
-                // Which files the device is asked for.  Its first use in a process costs what a run of 10 M reads takes: ~15 GB of
-                // device buffers per lane, gigabytes of page-locked arenas, and their release at the end (measured through the CLI,
-                // gpurun_out/r4c32: pass 2 of a fresh process 0.35 s with the pool alone, 0.72 s with the device's help — while the
-                // same input in a warm pipe takes 0.24 s against 0.33).  So a COLD decoder is only started for an input big enough
-                // to pay that back (>= 4 GiB compressed), a warm one — the pipe object has decoded a .gz input of this slot with it
-                // before: a service, a folder of files, bench.py — takes every file the pool would need longer for than a group
-                // takes the device (48 MiB).  AQC_GZ_DEVICE_MIN=<bytes> sets the limit for both.
-                size_t dev_min = P->gz_offload_warm[f] ? (size_t)(48u << 20) : (size_t)4 << 30;
+                // Which files the device is asked for.  Until round 5 its first use in a process cost more than a run of 10 M reads
+                // takes (~40 GB of device buffers sized for the worst case, hipMalloc at 16 ms per GB, with the consumer waiting for
+                // the groups the allocating lanes had been handed: profiles/r05_gz_cold_decoder.txt), so a cold decoder was kept for
+                // inputs of >= 4 GiB.  Round 6: buffers by need (2 - 3 GB for groups of 62 MiB), set up in the background while the
+                // pool keeps every section (SectionOffload::prepare), markers + CRC-32 resolved on the device — a cold decoder is
+                // started for every input of >= 256 MiB compressed (about 5 M reads: below that the run is over before the ~5 GB of
+                // buffers and result sets exist — a fresh process breaks even near 0.5 GB, profiles/r06_gz_cold.txt), a warm one — the pipe object has decoded a .gz input of this slot with it before: a service, a folder of
+                // files, bench.py — for everything the pool would need longer for than a group takes the device (48 MiB).
+                // AQC_GZ_DEVICE_MIN=<bytes> sets the limit for both.
+                size_t dev_min = P->gz_offload_warm[f] ? (size_t)(48u << 20) : (size_t)(256u << 20);
                 if (const char* m = getenv("AQC_GZ_DEVICE_MIN")) dev_min = (size_t)std::max(0ll, atoll(m));
                 struct stat gst;
                 const bool big = P->gz_offload[f] && stat(io->in_path[f], &gst) == 0 && (size_t)gst.st_size >= dev_min;
                 if (big && !(e && e[0] == '0')) P->gz_offload_warm[f] = true;
-                src.reset(new GzSource(io->in_path[f], P->pool.get(), 0, (big && !(e && e[0] == '0')) ? P->gz_offload[f].get() : nullptr));
+                const bool use_dev = big && !(e && e[0] == '0');
+                GzSource* gs = new GzSource(io->in_path[f], P->pool.get(), 0, use_dev ? P->gz_offload[f].get() : nullptr);
+                src.reset(gs);
+                // the text of the sections the device decodes stays in HBM and is framed from there (round 6) — for the chunks
+                // that are dealt to the decoder's own device, with plain chunk buffers (the spans mode writes good records FROM them)
+                const char* h = getenv("AQC_GZ_HBM");
+                if (use_dev && !gs->failed() && gs->takes_segments() && !spans_on && !(h && h[0] == '0')) {
+                    reader_gz(f, gs, aqc_device_index(P->ctx[(size_t)f % P->ctx.size()]));
+                    return;
+                }
             }
             else src.reset(new FileSource(io->in_path[f], P->pool.get()));
             if (src->failed()) { fail(AQC_ERR_ARG, "cannot open %s", io->in_path[f]); return; }
@@ -1015,28 +1110,262 @@ struct Run {
         inq[f]->close();
     }
 
+    // ---- reader of a .gz input whose device-decoded text stays in HBM ------------------------------------------------------------
+    // The same chunks of exactly K records, but a chunk under construction is a list of STRETCHES: host bytes (what the pool decoded,
+    // in the ring buffer) and device text (resolved sections of the device decoder, aqcgz::DevSegment: their place in the ring
+    // buffer stays unwritten).  Line feeds: host stretches are counted here, device stretches come with a count per 64 KiB piece
+    // from the kernel that checksummed them (gzb_crc_kernel); the <= 2 pieces a stretch covers only partly, and the piece the
+    // chunk is cut in, are copied down (64 KiB each) and looked at here.  The text itself crosses PCIe only for chunks that go to
+    // ANOTHER device than the decoder's (fetched into the ring buffer, as in rounds 4 - 5).
+    struct Stretch {
+        size_t off = 0, len = 0;          // in the chunk buffer
+        uint64_t nl = 0;
+        bool dev = false;
+        aqcgz::DevSegment d;              // dev: d.sec_off / d.len follow off / len when the stretch is cut
+    };
+    // line feeds of host memory, on the pool when it is worth it
+    uint64_t count_host(const uint8_t* p, size_t n) {
+        if (n < 4 * SUB) return count_nl(p, n);
+        const size_t nb = (n + SUB - 1) / SUB;
+        std::vector<uint32_t> c(nb);
+        P->pool->parallel_for(nb, [&](size_t i) { c[i] = (uint32_t)count_nl(p + i * SUB, std::min(SUB, n - i * SUB)); });
+        uint64_t t = 0;
+        for (auto v : c) t += v;
+        return t;
+    }
+    // piece j of a section of n bytes: [lo, hi)
+    static void piece_range(size_t n, size_t j, size_t& lo, size_t& hi) {
+        const size_t pieces = (n + aqcgz::NL_PIECE - 1) / aqcgz::NL_PIECE;
+        hi = n - (pieces - 1 - j) * aqcgz::NL_PIECE;
+        lo = hi > aqcgz::NL_PIECE ? hi - aqcgz::NL_PIECE : 0;
+    }
+    static size_t piece_of(size_t n, size_t pos) {      // the piece byte `pos` of a section of n bytes lies in
+        const size_t pieces = (n + aqcgz::NL_PIECE - 1) / aqcgz::NL_PIECE;
+        const size_t from_end = (n - 1 - pos) / aqcgz::NL_PIECE;
+        return pieces - 1 - from_end;
+    }
+    // bytes [a, b) of the section behind a device stretch -> host memory `to` (synchronous: a piece at most)
+    static bool fetch_now(const aqcgz::DevSegment& d, size_t a, size_t b, uint8_t* to) {
+        return b <= a || (d.owner->fetch(d.token, a, b - a, to) && d.owner->fetch_wait());
+    }
+    // line feeds of a device stretch: whole pieces from the decoder's counts, partly covered ones copied down (into `tmp`)
+    bool count_dev(const aqcgz::DevSegment& d, uint64_t& nl, std::vector<uint8_t>& tmp) {
+        nl = 0;
+        if (!d.len) return true;
+        const size_t a = d.sec_off, b = d.sec_off + d.len;
+        for (size_t j = piece_of(d.sec_len, a), j1 = piece_of(d.sec_len, b - 1); j <= j1; ++j) {
+            size_t lo, hi;
+            piece_range(d.sec_len, j, lo, hi);
+            if (lo >= a && hi <= b) { nl += d.piece_nl[j]; continue; }
+            const size_t x = std::max(lo, a), y = std::min(hi, b);
+            tmp.resize(aqcgz::NL_PIECE);
+            if (!fetch_now(d, x, y, tmp.data())) return false;
+            nl += count_nl(tmp.data(), y - x);
+        }
+        return true;
+    }
+    // offset, inside a device stretch, just behind its `want`-th line feed (1 <= want <= its count)
+    bool locate_dev(const aqcgz::DevSegment& d, uint64_t want, size_t& pos, std::vector<uint8_t>& tmp) {
+        const size_t a = d.sec_off, b = d.sec_off + d.len;
+        uint64_t seen = 0;
+        for (size_t j = piece_of(d.sec_len, a), j1 = piece_of(d.sec_len, b - 1); j <= j1; ++j) {
+            size_t lo, hi;
+            piece_range(d.sec_len, j, lo, hi);
+            const size_t x = std::max(lo, a), y = std::min(hi, b);
+            const bool whole = lo >= a && hi <= b;
+            if (whole && seen + d.piece_nl[j] < want) { seen += d.piece_nl[j]; continue; }
+            tmp.resize(aqcgz::NL_PIECE);
+            if (!fetch_now(d, x, y, tmp.data())) return false;
+            for (size_t i = 0; i < y - x;) {
+                const uint8_t* q = (const uint8_t*)memchr(tmp.data() + i, '\n', y - x - i);
+                if (!q) break;
+                i = (size_t)(q - tmp.data()) + 1;
+                if (++seen == want) { pos = x + i - a; return true; }
+            }
+        }
+        return false;       // (counts and bytes disagree: cannot happen)
+    }
+
+    void reader_gz(int f, GzSource* src, int dec_device) {
+        const uint64_t want_lines = 4 * K;
+        double est = 360.0;
+        std::vector<Stretch> carry;            // what the previous chunk left behind its cut (offsets from 0)
+        std::vector<uint8_t> carry_host, tmp;  // ... the host bytes of it (carry_host.size() = its whole length; device stretches' places unwritten)
+        bool eof = false;
+        for (uint64_t idx = 0; !abort; ++idx) {
+            // chunk idx goes to context idx % n: only there may its device text stay where it is
+            const bool same_dev = aqc_device_index(P->ctx[(size_t)(idx % jobq.size())]) == dec_device;
+            const uint64_t tw = now_ns();
+            const int bi = acquire_ring(f);
+            ns_wait_ring += now_ns() - tw;
+            if (bi < 0) return;
+            HostBuf& hb = P->in_buf[f][bi];
+            size_t cap = (size_t)(est * 1.02 * (double)K) + (256 << 10);
+            if (cap < carry_host.size() + (1 << 20)) cap = carry_host.size() + (1 << 20);
+            hb.ensure(cap);
+            if (!hb.p) { fail(AQC_ERR_HIP, "page-locked allocation of %zu bytes failed", cap); release_ring(f, bi); return; }
+            std::vector<Stretch> st;
+            size_t fill = carry_host.size();
+            uint64_t lines = 0;
+            if (fill) memcpy(hb.p, carry_host.data(), fill);
+            for (Stretch& c : carry) {
+                if (c.dev && !same_dev) {
+                    // (this chunk goes to another device: its device text comes down after all)
+                    if (!fetch_now(c.d, c.d.sec_off, c.d.sec_off + c.d.len, hb.p + c.off)) { fail(AQC_ERR_HIP, "%s: copying decoded text from the device failed", io->in_path[f]); release_ring(f, bi); return; }
+                    c.dev = false;
+                    c.d = aqcgz::DevSegment();
+                }
+                lines += c.nl;
+                st.push_back(std::move(c));
+            }
+            carry.clear();
+            carry_host.clear();
+            for (;;) {
+                if (lines >= want_lines || eof) break;
+                if (fill >= cap) {
+                    // the records are longer than estimated: a bigger buffer, keep what is there
+                    const size_t ncap = cap + cap / 2 + (4 << 20);
+                    if (ncap > hb.cap) {
+                        HostBuf nbuf;
+                        nbuf.pageable = hb.pageable;
+                        nbuf.ensure(ncap);
+                        if (!nbuf.p) { fail(AQC_ERR_HIP, "page-locked allocation of %zu bytes failed", ncap); release_ring(f, bi); return; }
+                        memcpy(nbuf.p, hb.p, fill);
+                        hb.release();
+                        hb = nbuf;
+                    }
+                    cap = ncap;
+                }
+                const size_t want = std::min(hb.cap, cap) - fill;
+                std::vector<aqcgz::DevSegment> segs;
+                const uint64_t tr = now_ns();
+                const size_t got = src->read_segments(hb.p + fill, want, same_dev ? &segs : nullptr);
+                ns_read += now_ns() - tr;
+                if (src->failed()) { fail(AQC_ERR_ARG, "%s: %s", io->in_path[f], src->why()); release_ring(f, bi); return; }
+                if (got < want) eof = true;
+                // the new bytes as stretches: device segments, host bytes between them
+                const uint64_t tc = now_ns();
+                size_t cur = 0;
+                auto host_part = [&](size_t a, size_t b) {
+                    if (b <= a) return;
+                    Stretch h;
+                    h.off = fill + a; h.len = b - a;
+                    h.nl = count_host(hb.p + h.off, h.len);
+                    lines += h.nl;
+                    st.push_back(std::move(h));
+                };
+                for (aqcgz::DevSegment& g : segs) {
+                    host_part(cur, g.dst_off);
+                    Stretch d;
+                    d.off = fill + g.dst_off; d.len = g.len; d.dev = true;
+                    cur = g.dst_off + g.len;
+                    d.d = std::move(g);
+                    if (!count_dev(d.d, d.nl, tmp)) { fail(AQC_ERR_HIP, "%s: copying decoded text from the device failed", io->in_path[f]); release_ring(f, bi); return; }
+                    lines += d.nl;
+                    st.push_back(std::move(d));
+                }
+                host_part(cur, got);
+                ns_count += now_ns() - tc;
+                fill += got;
+            }
+            // the cut: just behind the 4K-th line feed
+            size_t bytes = fill;
+            if (lines >= want_lines) {
+                uint64_t seen = 0;
+                for (size_t i = 0; i < st.size(); ++i) {
+                    Stretch& x = st[i];
+                    if (seen + x.nl < want_lines) { seen += x.nl; continue; }
+                    size_t pos = 0;      // inside the stretch, behind the line feed
+                    const uint64_t k = want_lines - seen;
+                    if (x.dev) {
+                        if (!locate_dev(x.d, k, pos, tmp)) { fail(AQC_ERR_HIP, "%s: copying decoded text from the device failed", io->in_path[f]); release_ring(f, bi); return; }
+                    } else {
+                        uint64_t c = 0;
+                        const uint8_t* p = hb.p + x.off;
+                        size_t o = 0;
+                        while (o < x.len) {
+                            const uint8_t* q = (const uint8_t*)memchr(p + o, '\n', x.len - o);
+                            if (!q) break;
+                            o = (size_t)(q - p) + 1;
+                            if (++c == k) break;
+                        }
+                        pos = o;
+                    }
+                    bytes = x.off + pos;
+                    // what lies behind the cut is the head of the next chunk
+                    if (pos < x.len) {
+                        Stretch t = x;             // (a copy: its DevSegment holds the section too)
+                        t.off = 0; t.len = x.len - pos; t.nl = x.nl - k;
+                        if (t.dev) { t.d.sec_off += pos; t.d.len = t.len; t.d.dev += pos; t.d.dst_off = 0; }
+                        carry.push_back(std::move(t));
+                        x.len = pos; x.nl = k;
+                        if (x.dev) x.d.len = pos;
+                    }
+                    for (size_t j = i + 1; j < st.size(); ++j) {
+                        Stretch t = std::move(st[j]);
+                        t.off -= bytes;
+                        carry.push_back(std::move(t));
+                    }
+                    st.resize(i + 1);
+                    break;
+                }
+                if (bytes < fill) carry_host.assign(hb.p + bytes, hb.p + fill);
+            }
+            InChunk c;
+            c.idx = idx;
+            c.data = hb.p;
+            c.bytes = bytes;
+            c.lines = std::min<uint64_t>(lines, want_lines);
+            c.final = eof && carry.empty() && carry_host.empty();
+            c.buf = bi;
+            // the chunk's last byte (the framing wants it on the host), and its device stretches for aqc_frame_mixed
+            c.last_byte = '\n';
+            if (bytes) {
+                const Stretch& z = st.back();
+                if (!z.dev) c.last_byte = hb.p[bytes - 1];
+                else if (lines < want_lines) {          // (cut behind a line feed otherwise)
+                    uint8_t b1 = '\n';
+                    if (!fetch_now(z.d, z.d.sec_off + z.d.len - 1, z.d.sec_off + z.d.len, &b1)) { fail(AQC_ERR_HIP, "%s: copying decoded text from the device failed", io->in_path[f]); release_ring(f, bi); return; }
+                    c.last_byte = b1;
+                }
+            }
+            if (c.final && bytes > 0 && c.last_byte != '\n' && lines < want_lines) c.lines += 1;     // unterminated last line
+            for (Stretch& x : st)
+                if (x.dev && x.len) {
+                    if (!c.ext) c.ext = std::make_shared<std::vector<aqcgz::DevSegment>>();
+                    x.d.dst_off = x.off;
+                    c.ext->push_back(std::move(x.d));
+                }
+            if (c.lines >= 4 && c.bytes) est = (double)c.bytes / (double)(c.lines / 4);
+            const bool fin = c.final;
+            if (!inq[f]->push(c)) { release_ring(f, bi); return; }
+            if (fin) break;
+        }
+        inq[f]->close();
+    }
+
     // ---- dispatcher: pair the chunks, deal them round robin ---------------------------------------------------------------
     void dispatcher() {
         bind_io_thread("dispatcher");
-        for (uint64_t idx = 0; !abort; ++idx) {
+        static const uint8_t nothing[1] = {0};
+        bool over[2] = {false, nf < 2};       // the file's final chunk has been dealt (a shorter mate: its partner goes on against nothing)
+        for (uint64_t idx = 0; !abort && !ended; ++idx) {
             Job j;
             j.idx = idx;
-            bool ok = inq[0]->pop(j.c[0]);
-            if (ok && nf == 2) {
-                ok = inq[1]->pop(j.c[1]);
-                if (!ok) release_ring(0, j.c[0].buf);
+            bool got[2] = {false, false};
+            for (int f = 0; f < nf; ++f) {
+                if (!over[f]) got[f] = inq[f]->pop(j.c[f]);
+                if (!got[f]) {
+                    // nothing more of this file: an empty final chunk (upstream's reader returns None from here on)
+                    j.c[f] = InChunk();
+                    j.c[f].idx = idx; j.c[f].data = nothing; j.c[f].final = true;
+                    over[f] = true;
+                } else if (j.c[f].final) over[f] = true;
             }
-            if (!ok) break;
-            // the regular shape: both mates hold the same number of complete records, and end together
-            const uint64_t r1 = j.c[0].lines / 4, r2 = nf == 2 ? j.c[1].lines / 4 : r1;
-            const bool fin1 = j.c[0].final, fin2 = nf == 2 ? j.c[1].final : fin1;
-            if (r1 != r2 || fin1 != fin2 || (!fin1 && r1 != K) || (j.c[0].lines % 4) || (nf == 2 && (j.c[1].lines % 4))) {
-                anomaly = true;
-                for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf);
-                stop_all();
-                return;
-            }
-            j.last = fin1;
+            if (!got[0] && !(nf == 2 && got[1])) break;            // both ran dry (or the pipe is stopping)
+            if (abort || ended) { for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf); break; }
+            // (R1's final chunk ends the loop whatever R2 holds: preprocesser.py:412-415)
+            j.last = j.c[0].final;
             j.ticket = group_tickets[group_of_ctx[idx % jobq.size()]]++;
             if (!jobq[idx % jobq.size()]->push(j)) {
                 for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf);
@@ -1073,7 +1402,16 @@ struct Run {
             Gate& ug = *up_gate[group_of_ctx[ci]];
             Gate& dg = *down_gate[group_of_ctx[ci]];
             if (!gate_enter(ug, j.ticket, (uint64_t)P->slots)) { for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf); return; }
-            int rc = aqc_frame(c, slot, &ch, &info);
+            int rc;
+            if (j.c[0].ext || (nf == 2 && j.c[1].ext)) {
+                // parts of the chunk are text in this device's memory (a .gz input decoded here): they move inside HBM
+                std::vector<aqc_text_extent> ex[2];
+                for (int f = 0; f < nf; ++f)
+                    if (j.c[f].ext)
+                        for (const aqcgz::DevSegment& g : *j.c[f].ext) ex[f].push_back(aqc_text_extent{(uint64_t)g.dst_off, (uint64_t)g.len, g.dev});
+                rc = aqc_frame_mixed(c, slot, &ch, ex[0].data(), ex[0].size(), j.c[0].last_byte, ex[1].data(), ex[1].size(), nf == 2 ? j.c[1].last_byte : (uint8_t)'\n', &info);
+                for (int f = 0; f < nf; ++f) j.c[f].ext.reset();        // (the sections — and their text — are free to go)
+            } else rc = aqc_frame(c, slot, &ch, &info);
             gate_leave(ug);
             ns_frame += now_ns() - tt;
             tt = now_ns();
@@ -1082,14 +1420,43 @@ struct Run {
             if (!use_spans || rc) for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf);
             if (rc) { fail(rc, "aqc_frame: %s", aqc_last_error()); return; }
             auto drop_input = [&] { if (use_spans) for (int f = 0; f < nf; ++f) release_ring(f, j.c[f].buf); };
-            const uint64_t expect = j.c[0].lines / 4;
-            if (info.n != expect || info.eof1 || info.eof2 || info.avail1 != expect || (nf == 2 && info.avail2 != expect)) {
-                anomaly = true;           // an empty line / a blank-only line inside: the serial path knows what to do
-                drop_input();
-                stop_all();
-                return;
+            // Does the input end in this chunk?  The lock step of preprocesser.py:412-429 over what the framing found: R1 is read
+            // first; a reader is dry when its chunk ended (an empty line: eof, or the file's last chunk) and every record it held is
+            // used.  Decided in chunk order, BEFORE the chunk is run: chunks behind the end never touch a counter.
+            {
+                const bool fin1 = j.c[0].final, fin2 = nf == 2 ? j.c[1].final : fin1;
+                const bool done1 = (info.eof1 || fin1) && info.avail1 == info.n;
+                const bool done2 = nf == 2 && (info.eof2 || fin2) && info.avail2 == info.n;
+                const bool stop = done1 || (done2 && info.avail1 > info.n);
+                std::unique_lock<std::mutex> lk(fr_mu);
+                fr_cv.wait(lk, [&] { return abort.load() || framed_next == j.idx; });
+                if (abort) { drop_input(); return; }
+                const bool behind_end = end_chunk != UINT64_MAX;
+                bool foreign = false;
+                if (!behind_end) {
+                    if (stop) {
+                        end_chunk = j.idx;
+                        extra_bases = (!done1 && done2 && info.avail1 > info.n) ? info.next_len1 : 0;
+                        j.last = true;
+                    } else if (info.n != K) foreign = true;      // neither K records nor an end: nothing upstream's reader could have produced from these chunks
+                }
+                framed_next = j.idx + 1;
+                lk.unlock();
+                fr_cv.notify_all();
+                if (foreign) { anomaly = true; drop_input(); stop_all(); return; }
+                if (behind_end) { drop_input(); continue; }          // the input ended before this chunk
+                if (stop) end_input();
             }
             uint64_t n = info.n;
+            if (n == 0) {
+                // the input ended at this chunk's very first record (a mate file that ran dry at a chunk boundary, a partial record):
+                // nothing to run or to write, but the chunk is committed — it is the run's last
+                drop_input();
+                OutChunk oc0;
+                oc0.idx = j.idx; oc0.last = j.last; oc0.worker = wid;
+                if (!outq.push(oc0)) return;
+                continue;
+            }
             bool fatal = false;       // upstream's run ends inside this chunk (an exception in its loop): records [0, n) are written, then the pipe stops
             if ((rc = aqc_run(c, slot, UINT64_MAX))) { fail(rc, "aqc_run: %s", aqc_last_error()); return; }
             // post-filter QC while TOTAL_READS < qc_sample (preprocesser.py:624-627), issued in chunk order
@@ -1309,8 +1676,13 @@ struct Run {
             }
             ns_write += now_ns() - tw;
             if (cm->remaining.fetch_sub(1) == 1) release_set(oc);
+            writes_done.fetch_add(1);
         }
     }
+    // (file, chunk) writes handed to the file writers / finished by them: the run that dies at a record stops the pipe only once
+    // EVERY chunk committed before it has reached its files (round-5 advisory: waiting for the fatal chunk's own files alone let
+    // stop_all() cancel earlier chunks still queued on a file the fatal chunk does not write to)
+    std::atomic<uint64_t> writes_queued{0}, writes_done{0};
 
     void writer() {
         bind_io_thread("commit");
@@ -1336,7 +1708,7 @@ struct Run {
                 else {
                     cm->remaining = live;
                     for (int q = 0; q < 6; ++q)
-                        if (to_file[q] && out[q].fd >= 0) fileq[q]->push(cm);
+                        if (to_file[q] && out[q].fd >= 0) { writes_queued.fetch_add(1); fileq[q]->push(cm); }
                 }
                 res->chunks += 1;
                 res->fused_chunks += cur.fused ? 1 : 0;
@@ -1350,7 +1722,7 @@ struct Run {
         if (fatal_commit) {
             // upstream died inside this chunk: everything up to the record is on its way to the files; once it is there the
             // rest of the pipe (readers, workers with later chunks) is stopped and the run reports the error
-            while (!abort && fatal_commit->remaining.load() > 0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+            while (!abort && (fatal_commit->remaining.load() > 0 || writes_done.load() < writes_queued.load())) std::this_thread::sleep_for(std::chrono::microseconds(200));
             {
                 std::lock_guard<std::mutex> g(err_mu);
                 if (err.empty()) { err = fatal_err; err_code = fatal_code; }
@@ -1536,6 +1908,10 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
             aqcgz::device_offload_stats(ds);
             if (ds[5]) fprintf(stderr, "pipe: device gunzip so far (process-wide) — %llu groups, %llu sections given / %llu found; ms in scan %.1f, decode %.1f, chain + gather %.1f, H2D %.1f, D2H %.1f\n",
                                (unsigned long long)ds[5], (unsigned long long)ds[6], (unsigned long long)ds[7], ds[0] / 1e3, ds[1] / 1e3, ds[2] / 1e3, ds[3] / 1e3, ds[4] / 1e3);
+            uint64_t rs[4];
+            aqcgz::device_resolve_stats(rs);
+            if (rs[0]) fprintf(stderr, "pipe: markers + CRC-32 resolved on the device so far (process-wide) — %llu runs of %llu sections, %.1f MB of text, %.1f ms inside resolve()\n",
+                               (unsigned long long)rs[0], (unsigned long long)rs[1], 1e-6 * (double)rs[3], rs[2] / 1e3);
         }
 #ifdef AQC_GZ_PROFILE
         fprintf(stderr, "pipe: gunzip thread-CPU ms — find %ld, decode (find included) %ld, translate %ld, crc %ld, consumer waiting %ld, accept %ld\n", aqcgz::gz_prof[0].exchange(0) / 1000,
@@ -1548,6 +1924,7 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
     res->t_fetch = 1e-9 * (double)R.ns_fetch.load(); res->t_write = 1e-9 * (double)R.ns_write.load();
     res->t_wait_set = 1e-9 * (double)R.ns_wait_set.load(); res->t_wait_ring = 1e-9 * (double)R.ns_wait_ring.load();
     res->anomaly = R.anomaly ? 1 : 0;
+    res->extra_bases = R.extra_bases;
     res->seconds = now_s() - t0;
     if (!R.err.empty()) {
         std::lock_guard<std::mutex> g(g_pipe_err_mu);

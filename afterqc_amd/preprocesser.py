@@ -558,8 +558,8 @@ class seqFilter:
     # ---- pass 2 through the whole-input pipe (aqc_pipe_run) ---------------------------------------------------------------
     def _run_pipe(self, opt, files, good_dir, bad_dir, overlap_dir, gzip_out, paired):
         """Hands the read file(s) to the C++ pipe: chunks of `chunk_records` records dealt over every engine, outputs written
-        in chunk order by its writer thread.  Returns the extra-bases quirk value (always 0 for the regular inputs the pipe
-        accepts) or None when the pipe met an input of irregular shape (the caller falls back to the serial chunk loop)."""
+        in chunk order by its writer thread.  Returns the extra-bases quirk value (preprocesser.py:416-421) or None when the
+        pipe met an input it cannot chunk (the caller falls back to the serial chunk loop)."""
         nfiles = 2 if paired else 1
         outputs = []
         for k in range(nfiles):
@@ -589,7 +589,9 @@ class seqFilter:
         self.timing["pipe_s"] = res.seconds
         self.timing["pipe_threads"] = res.breakdown()
         self.timing["pipe_chunks"] = (int(res.chunks), int(res.fused_chunks))       # (all, placed by the verdict kernel: AQC_FUSED=1)
-        return 0
+        # (R1's record that upstream had read and counted before a shorter R2 ended its loop, preprocesser.py:416-421: the pipe
+        #  applies fastq.Reader's end-of-file rules itself since round 6)
+        return int(res.extra_bases)
 
     # ---- pass 2, text path with index files (-7 / -5): four lock-stepped inputs, two device slots ---------------------
     def _run_text_indexed(self, eng, opt, outs, paired):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AQC_ABI_VERSION 2
+#define AQC_ABI_VERSION 3
 
 /* longest read the reference's QC can hold (qualitycontrol.py:23 MAX_LEN = 1000) */
 #define AQC_MAX_READ_LEN 1000
@@ -312,6 +312,18 @@ typedef struct aqc_frame_info {
 } aqc_frame_info;
 
 int aqc_frame(aqc_ctx* ctx, int slot, const aqc_text_chunk* chunk, aqc_frame_info* info);
+/* aqc_frame for a chunk PARTS of which are already in this GPU's memory (round 6: a `.gz` input decoded on the device, whose text
+ * never left HBM — gzip.open(...).readline() of fastq.py:23-24,37-49 without the text crossing PCIe twice).  ext1 / ext2: stretches
+ * [offset, offset + bytes) of the chunk of file 1 / 2, sorted by offset, not overlapping, whose bytes are at `device_text` (memory
+ * of ctx's device; the caller keeps it valid until the call returns); text1 / text2 hold every OTHER byte of the chunk at its own
+ * offset (what they hold inside a stretch is ignored).  last1 / last2: the chunk's last byte of each file (the framing needs it on
+ * the host: an unterminated last line of a final chunk is a line).  Everything else as aqc_frame. */
+typedef struct aqc_text_extent {
+    uint64_t offset, bytes;
+    const void* device_text;
+} aqc_text_extent;
+int aqc_frame_mixed(aqc_ctx* ctx, int slot, const aqc_text_chunk* chunk, const aqc_text_extent* ext1, uint64_t n_ext1, uint8_t last1,
+                    const aqc_text_extent* ext2, uint64_t n_ext2, uint8_t last2, aqc_frame_info* info);
 /* the same framing again over the text the slot already holds in HBM (no host copy): line index + record framing of the
  * chunk of the last aqc_frame.  For measurements with the input resident in HBM (bench.py). */
 int aqc_reframe(aqc_ctx* ctx, int slot, aqc_frame_info* info);
@@ -403,9 +415,11 @@ int aqc_edit_distance(aqc_ctx* ctx, const aqc_batch* pairs, int32_t* dist);
  * writes the good / bad / overlap streams in chunk order (fastq.Writer, fastq.py:63-93; .gz output as independent
  * BGZF-compatible members).  The contexts must be configured (aqc_set_config / aqc_set_circles) by the caller, who also
  * merges their statistics afterwards (plain sums).  While a pipe runs, its contexts belong to it.
- * The pipe covers the regular shape of an input (4-line records, mates with equal record counts, no empty line inside);
- * for anything else it stops and sets result->anomaly: rerun the input through the per-chunk calls, which reproduce
- * fastq.Reader's end-of-file rules case by case (fastq.py:37-49, preprocesser.py:412-429). */
+ * End of input as upstream has it (fastq.py:37-49, preprocesser.py:412-429; round 6: inside the pipe): a line that is empty after
+ * rstrip() ends its file there, a trailing partial record is dropped, the first reader to run dry ends the loop — R1 is read first,
+ * so when a shorter R2 ends it, R1's next record has already been counted into TOTAL_BASES (result->extra_bases).  The chunk in which
+ * the input ends is the run's last; chunks behind it are never run.  result->anomaly is left for shapes the chunking itself cannot
+ * describe (a chunk without its records although nothing ended there); callers then rerun the input through the per-chunk calls. */
 typedef struct aqc_pipe aqc_pipe;
 
 typedef struct aqc_pipe_io {
@@ -433,8 +447,10 @@ typedef struct aqc_pipe_result {
     uint64_t records;              /* records processed */
     uint64_t chunks;
     uint64_t bytes_out[6];         /* [file * 3 + stream] */
-    int32_t anomaly;               /* the input is not of the regular shape: outputs and statistics are incomplete */
+    int32_t anomaly;               /* the input is not of a shape the pipe takes: outputs and statistics are incomplete */
     int32_t fused_chunks;          /* chunks whose records the verdict kernel placed itself (contexts created with AQC_FUSED=1) */
+    uint64_t extra_bases;          /* bases of the R1 record upstream had already read (and counted into TOTAL_BASES, preprocesser.py:416-421)
+                                      when a shorter mate file ended its loop; 0 otherwise */
     double seconds;
     /* where the time went, summed over the threads of each kind (seconds): reader file reads / newline counts / waits for a
      * free input buffer; slot workers in aqc_frame (upload + framing) / run + QC + format / waits for an output buffer set /

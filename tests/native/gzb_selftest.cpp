@@ -29,19 +29,119 @@ namespace {
 
 struct CpuOffload : aqcgz::SectionOffload {
     size_t group;
-    uint32_t ratio_cap = 20;
+    uint32_t ratio_cap = 20, tok_ratio = 8, overlap_tokens = 2048;
     uint32_t cand_div = 4096;            // candidate capacity = span / cand_div + 256
     uint32_t slice_tokens = 300, max_slices = 1u << 20;
     uint64_t groups = 0, sections = 0, found = 0, candidates = 0, false_ends = 0, spec_lanes = 0, failed_blocks = 0, stitched_blocks = 0;
     std::vector<std::vector<uint16_t>*> live;
+    std::vector<aqcgz::OffloadResult> pending_results;
     // break_after >= 0: the "device" fails on its (break_after + 1)-th group — the group's sections come back empty, as
     // DeviceInflate hands them back after a HIP error — and takes no work from then on (ready() == false)
     long break_after = -1;
     bool broken = false;
+    // resident mode (round 6): the symbols stay "on the device" — a GroupRes — until the consumer asks for the run to be resolved
+    // (gzb_window_byte / gzb_resolve_sym / gzb_crc_slot + gzb_crc_join, dealt out the way gzb_windows_kernel, gzb_resolve_kernel
+    // and gzb_crc_kernel deal them) and then fetches bytes
+    bool resident = false;
+    uint64_t runs_resolved = 0, sections_resolved = 0;
+    long resolve_breaks_after = -1;       // >= 0: resolve() fails (as after a HIP error) from its (n + 1)-th call on
+    struct GroupRes {
+        std::vector<uint16_t> sym;
+        std::vector<uint8_t> text;
+        std::vector<uint64_t> off;
+        std::vector<uint32_t> nsym;
+    };
+    struct ResTok { std::shared_ptr<GroupRes> g; int k; };
     explicit CpuOffload(size_t g) : group(g) {}
     size_t group_bytes() const override { return group; }
     bool ready() override { return !broken; }
-    void release(void* token) override { delete (std::vector<uint16_t>*)token; }
+    bool gave_up() override { return broken; }
+    void release(void* token) override {
+        if (resident) delete (ResTok*)token;
+        else delete (std::vector<uint16_t>*)token;
+    }
+    const uint8_t* text_ptr(void* token, int* device) override {
+        ResTok* t = (ResTok*)token;
+        if (device) *device = 0;
+        return t->g->text.data() + t->g->off[t->k];
+    }
+    int resolve(void* const* tokens, int n, const uint8_t* win, size_t wlen, uint32_t* crc, uint8_t* tail, size_t* tail_len, uint32_t* piece_nl) override {
+        if (resolve_breaks_after >= 0 && (long)runs_resolved >= resolve_breaks_after) return -2;
+        ++runs_resolved;
+        sections_resolved += (uint64_t)n;
+        GroupRes& G = *((ResTok*)tokens[0])->g;
+        for (int k = 0; k < n; ++k) if (((ResTok*)tokens[k])->g.get() != &G) return -2;
+        std::vector<uint64_t> off((size_t)n);
+        std::vector<uint32_t> nsym((size_t)n);
+        for (int k = 0; k < n; ++k) { const int sk = ((ResTok*)tokens[k])->k; off[k] = G.off[sk]; nsym[k] = G.nsym[sk]; }
+        std::vector<uint8_t> wins((size_t)(n + 1) * GZB_WINDOW, 0);
+        if (wlen) memcpy(wins.data() + GZB_WINDOW - wlen, win, wlen);
+        uint32_t bad = 0;
+        GzbResolveJob R{};
+        R.sym = G.sym.data(); R.text = G.text.data(); R.wins = wins.data(); R.off = off.data(); R.nsym = nsym.data(); R.n_run = (uint32_t)n;
+        R.valid0 = (uint32_t)(GZB_WINDOW - wlen); R.bad = &bad;
+        // gzb_windows_kernel
+        uint32_t valid = R.valid0;
+        std::vector<uint32_t> valids((size_t)n);
+        for (int k = 0; k < n; ++k) {
+            valids[k] = valid;
+            const uint8_t* w = wins.data() + (size_t)k * GZB_WINDOW;
+            uint8_t* o = wins.data() + (size_t)(k + 1) * GZB_WINDOW;
+            for (uint32_t j = 0; j < GZB_WINDOW; ++j) o[j] = gzb_window_byte(R, (uint32_t)k, j, w, valid, &bad);
+            valid = nsym[k] >= valid ? 0u : valid - nsym[k];
+        }
+        // gzb_resolve_kernel
+        for (int k = 0; k < n; ++k) {
+            const uint32_t v = gzb_window_valid(R, (uint32_t)k);
+            if (v != valids[k]) { printf("gzb_window_valid disagrees with the window pass\n"); return -2; }
+            const uint8_t* w = wins.data() + (size_t)k * GZB_WINDOW;
+            for (uint32_t i = 0; i < nsym[k]; ++i) G.text[off[k] + i] = gzb_resolve_sym(G.sym[off[k] + i], w, v, &bad);
+        }
+        if (bad) return aqcgz::GZ_ERR_DATA;
+        // gzb_crc_kernel + the host's fold
+        static std::vector<uint32_t> tab, adv_piece;
+        auto advance = [](uint32_t x, uint64_t len) { return (uint32_t)crc32_combine((uLong)x, 0UL, (z_off_t)len); };
+        if (tab.empty()) {
+            tab.resize(GZB_CRC_TAB_WORDS);
+            gzb_crc_tables(tab.data(), advance);
+            adv_piece.resize(32);
+            for (int j = 0; j < 32; ++j) adv_piece[j] = advance(1u << j, GZB_CRC_PIECE);
+        }
+        for (int k = 0; k < n; ++k) {
+            const uint32_t cnt = (nsym[k] + GZB_CRC_PIECE - 1u) / GZB_CRC_PIECE;
+            std::vector<uint32_t> pieces(cnt);
+            for (uint32_t pi = 0; pi < cnt; ++pi) {
+                uint32_t part[GZB_CRC_THREADS], lines = 0;
+                for (uint32_t t = 0; t < GZB_CRC_THREADS; ++t) { uint32_t lf = 0; part[t] = gzb_crc_slot(G.text.data() + off[k], nsym[k], cnt, pi, t, tab.data(), &lf); lines += lf; }
+                if (piece_nl) *piece_nl++ = lines;
+                for (int level = 0; level < 8; ++level) {
+                    const uint32_t step = 1u << level;
+                    for (uint32_t t = 0; t < GZB_CRC_THREADS; t += 2u * step) part[t] = gzb_crc_join(part[t], part[t + step], level, tab.data());
+                }
+                pieces[pi] = part[0];
+            }
+            crc[k] = gzb_crc_fold(pieces.data(), cnt, nsym[k], adv_piece.data(), advance);
+            if (crc[k] != (uint32_t)crc32(0L, G.text.data() + off[k], nsym[k])) { printf("device CRC of a section differs from zlib's\n"); return -2; }
+        }
+        uint64_t total = 0;
+        for (int k = 0; k < n; ++k) total += nsym[k];
+        const size_t tl = (size_t)std::min<uint64_t>(GZB_WINDOW, wlen + total);
+        memcpy(tail, wins.data() + (size_t)n * GZB_WINDOW + GZB_WINDOW - tl, tl);
+        *tail_len = tl;
+        return 0;
+    }
+    std::vector<std::pair<std::pair<const uint8_t*, uint8_t*>, size_t>> queued;      // fetch(): copies land at fetch_wait(), as a stream's would
+    bool fetch(void* token, size_t off, size_t len, uint8_t* dst) override {
+        ResTok* t = (ResTok*)token;
+        if (off + len > t->g->nsym[t->k]) return false;
+        queued.push_back({{t->g->text.data() + t->g->off[t->k] + off, dst}, len});
+        return true;
+    }
+    bool fetch_wait() override {
+        for (auto& q : queued) memcpy(q.first.second, q.first.first, q.second);
+        queued.clear();
+        return true;
+    }
 
     bool submit(const uint8_t* data, size_t size, int n, const uint64_t* nominal, const uint64_t* stop, const uint8_t* exact,
                 std::function<void(int, const aqcgz::OffloadResult&)> done) override {
@@ -74,7 +174,13 @@ struct CpuOffload : aqcgz::SectionOffload {
         J.blk_sym_cap = gzb_sym_budget(span, ratio_cap);
         std::unique_ptr<uint16_t[]> blk_sym(new uint16_t[J.blk_sym_cap + 64]);
         J.blk_sym = blk_sym.get();
-        std::unique_ptr<unsigned long long[]> blk_tp(new unsigned long long[J.blk_sym_cap / 2 + 64]);
+        J.tok_ratio = tok_ratio;
+        J.overlap_tokens = overlap_tokens;
+        J.blk_tp_cap = gzb_tok_budget(span, tok_ratio, overlap_tokens);
+        std::unique_ptr<unsigned long long[]> blk_tp(new unsigned long long[J.blk_tp_cap + 64]);
+        std::vector<uint64_t> c_tokoff(J.cand_cap);
+        std::vector<uint32_t> c_tokcap(J.cand_cap);
+        J.c_tokoff = c_tokoff.data(); J.c_tokcap = c_tokcap.data();
         std::vector<uint32_t> c_lanes(J.cand_cap), l_u32((size_t)5 * J.cand_cap * GZB_K);
         J.blk_tp = blk_tp.get(); J.c_lanes = c_lanes.data();
         J.l_p = l_u32.data(); J.l_stop = J.l_p + (size_t)J.cand_cap * GZB_K; J.l_start = J.l_stop + (size_t)J.cand_cap * GZB_K;
@@ -126,12 +232,15 @@ struct CpuOffload : aqcgz::SectionOffload {
         n_cand[0] = nc; n_cand[1] = 0;
         candidates += nc;
         {
-            unsigned long long o = 0;
+            unsigned long long o = 0, to = 0;
             for (uint32_t c = 0; c < nc; ++c) {
-                const uint32_t cap = gzb_symcap_of(J, c, nc);
+                const uint32_t cap = gzb_symcap_of(J, c, nc), tcap = gzb_tokcap_of(J, c, nc);
                 c_symoff[c] = o;
-                c_symcap[c] = o + cap > J.blk_sym_cap ? 0u : cap;
+                c_tokoff[c] = to;
+                c_tokcap[c] = tcap;
+                c_symcap[c] = (o + cap > J.blk_sym_cap || to + tcap > J.blk_tp_cap) ? 0u : cap;
                 o += cap;
+                to += tcap;
             }
         }
         // ---- decode: tables per candidate, then GZB_K lanes per candidate in slices, then the stitch
@@ -161,8 +270,8 @@ struct CpuOffload : aqcgz::SectionOffload {
                 const uint32_t lanes = c_lanes[c];
                 if (lanes > 1) ++spec_lanes;
                 const GzbLaneTab<1> T{reinterpret_cast<uint16_t*>(J.tables + (size_t)c * GZB_TAB_WORDS)};
-                const uint32_t share = (c_symcap[c] / 2u) / (uint32_t)GZB_K;
-                const size_t at = c_symoff[c] / 2 + (size_t)k * share;
+                const uint32_t share = c_tokcap[c] / (uint32_t)GZB_K;
+                const size_t at = c_tokoff[c] + (size_t)k * share;
                 uint32_t p = J.l_p[i], nt = J.l_ntok[i];
                 GzbInMem in{J.comp, 0};
                 J.l_flags[i] = gzb_tokenize(in, limit_bit, T, J.blk_tp + at, lanes == 1u ? share * (uint32_t)GZB_K : share, p, nt, J.l_stop[i], slice_tokens, lanes != 1u);
@@ -198,6 +307,12 @@ struct CpuOffload : aqcgz::SectionOffload {
         sections += (uint64_t)n;
         for (int k = 0; k < n; ++k) gzb_chain_section(J, (uint32_t)k);
         gzb_place(J);
+        std::shared_ptr<GroupRes> res;
+        if (resident) {
+            res.reset(new GroupRes());
+            res->off.assign(s_off.begin(), s_off.begin() + n);
+            res->nsym.assign(s_nsym.begin(), s_nsym.end());
+        }
         for (int k = 0; k < n; ++k) {
             aqcgz::OffloadResult r;
             if (s_start[k] != GZB_NONE && s_nsym[k] != 0) {
@@ -211,16 +326,28 @@ struct CpuOffload : aqcgz::SectionOffload {
                         for (uint32_t i = 0; i < c_nsym[w0]; ++i) dst[o + i] = gzb_rebase(s[i], o, dst);
                     }
                 }
-                auto* keep = new std::vector<uint16_t>(dst, dst + s_nsym[k]);
                 r.found = true;
                 r.start_bit = byte0 * 8 + s_start[k];
                 r.end_bit = byte0 * 8 + s_end[k];
-                r.sym = keep->data();
                 r.n_sym = s_nsym[k];
-                r.token = keep;
+                if (!resident) {
+                    auto* keep = new std::vector<uint16_t>(dst, dst + s_nsym[k]);
+                    r.sym = keep->data();
+                    r.token = keep;
+                }
                 ++found;
             }
-            done(k, r);
+            if (!resident) done(k, r);
+            else if (r.found) { r.resident = true; r.token = new ResTok{res, k}; }
+            if (resident) pending_results.push_back(r);
+        }
+        if (resident) {
+            // (the symbols of all sections are final only now: a later section's gather does not touch an earlier one's, but the
+            //  buffer is handed over whole)
+            res->sym.assign(s_sym.begin(), s_sym.begin() + (long)s_off[n] + 64);
+            res->text.assign((size_t)s_off[n] + 64, 0);
+            for (int k = 0; k < n; ++k) done(k, pending_results[(size_t)k]);
+            pending_results.clear();
         }
         return true;
     }
@@ -265,33 +392,68 @@ int failures = 0;
 uint32_t g_max_slices = 1u << 20, g_slice_tokens = 300;      // (a case may cut the decoder off: unfinished blocks then go to the host)
 
 // decode gz through ParallelGunzip with the CPU emulation of the device as its offloader; returns the offloader's counters
-long g_break_after = -1;
+long g_break_after = -1, g_resolve_breaks_after = -1;
+bool g_resident = false;
+int g_case_no = 0;
+uint64_t g_segment_bytes = 0;
+uint32_t g_tok_ratio = 8;
+uint64_t g_sections_resolved = 0;
 bool run_case(const char* what, const std::vector<uint8_t>& gz, const std::vector<uint8_t>& text, size_t section, size_t group, int threads, bool want_device,
               uint32_t ratio_cap = 20, uint32_t cand_div = 4096, bool expect_fail = false, bool hybrid = false) {
     CpuOffload off(group);
+    ++g_case_no;
     off.break_after = g_break_after;
+    off.resident = g_resident;
+    off.resolve_breaks_after = g_resolve_breaks_after;
+    off.tok_ratio = g_tok_ratio;
+    off.overlap_tokens = g_tok_ratio <= 2 ? GZB_OVERLAP_TOKENS : 2048u;       // (the product's lean budget in file mode)
     off.ratio_cap = ratio_cap; off.cand_div = cand_div; off.max_slices = g_max_slices; off.slice_tokens = g_slice_tokens;
     aqc_host::Pool pool(threads);
     std::vector<uint8_t> out(text.size() + 65536);
     size_t produced = 0;
     bool failed = false;
-    uint64_t dev_acc = 0, host_acc = 0, bridged = 0;
+    uint64_t dev_acc = 0, host_acc = 0, bridged = 0, res_bytes = 0, off_bytes = 0;
     {
         aqcgz::ParallelGunzip pg(gz.data(), gz.size(), threads ? &pool : nullptr, 4, section, &off, !hybrid);
         for (;;) {
-            const size_t got = pg.read(out.data() + produced, std::min<size_t>(out.size() - produced, 777777));
+            // resident mode, every other case: the text of resolved sections is LISTED, not copied (what the pipe's reader asks for);
+            // the "device memory" of the emulation is host memory, so the check copies it into place itself — and counts the line
+            // feeds of every whole piece against what resolve() reported
+            std::vector<aqcgz::DevSegment> segs;
+            const bool want_segs = g_resident && (g_case_no & 1);
+            const size_t got = pg.read(out.data() + produced, std::min<size_t>(out.size() - produced, 777777), want_segs ? &segs : nullptr);
             if (pg.failed()) { failed = true; break; }
             if (!got) break;
+            size_t last_end = 0;
+            for (const aqcgz::DevSegment& g : segs) {
+                if (g.dst_off < last_end || g.dst_off + g.len > got || g.sec_off + g.len > g.sec_len || !g.keep) { printf("bad device segment\n"); failed = true; break; }
+                last_end = g.dst_off + g.len;
+                memcpy(out.data() + produced + g.dst_off, g.dev, g.len);
+                g_segment_bytes += g.len;
+                const size_t pieces = (g.sec_len + aqcgz::NL_PIECE - 1) / aqcgz::NL_PIECE;
+                for (size_t j = 0; j < pieces; ++j) {
+                    const size_t hi = g.sec_len - (pieces - 1 - j) * aqcgz::NL_PIECE, lo = hi > aqcgz::NL_PIECE ? hi - aqcgz::NL_PIECE : 0;
+                    if (lo < g.sec_off || hi > g.sec_off + g.len) continue;
+                    const uint8_t* p = g.dev - g.sec_off + lo;
+                    uint32_t c = 0;
+                    for (size_t i = 0; i < hi - lo; ++i) c += p[i] == '\n';
+                    if (c != g.piece_nl[j]) { printf("line feeds of piece %zu: %u counted, %u reported\n", j, c, g.piece_nl[j]); failed = true; }
+                }
+            }
+            if (failed) break;
             produced += got;
         }
         dev_acc = pg.offloaded_accepted; host_acc = pg.sections_accepted - pg.offloaded_accepted; bridged = pg.bridged_bytes;
+        res_bytes = pg.resident_bytes; off_bytes = pg.offloaded_bytes;
     }
+    g_sections_resolved += off.sections_resolved;
     bool ok;
     if (expect_fail) ok = failed;
     else {
         ok = !failed && produced == text.size() && (text.empty() || memcmp(out.data(), text.data(), text.size()) == 0);
         if (ok && want_device && dev_acc == 0) ok = false;
         if (ok && hybrid && want_device && host_acc == 0) ok = false;      // the pool and the device both supplied sections
+        if (ok && g_resident && res_bytes != off_bytes) ok = false;        // resident mode: no device section went through the host's translation
     }
     printf("%-46s %s  gz %8zu -> %9zu B  sec %7zu  device sections %3llu  host %3llu  bridged %9llu B  candidates %llu  groups %llu  stitched %llu  failed %llu\n", what, ok ? "ok  " : "FAIL", gz.size(),
            text.size(), section, (unsigned long long)dev_acc, (unsigned long long)host_acc, (unsigned long long)bridged, (unsigned long long)off.candidates, (unsigned long long)off.groups, (unsigned long long)off.stitched_blocks,
@@ -302,7 +464,7 @@ bool run_case(const char* what, const std::vector<uint8_t>& gz, const std::vecto
 
 }  // namespace
 
-// gzb_selftest FILE.gz TEXT [section [group [ratio_cap]]]: one single-member file through the emulation with the kernels' own slice budget
+// gzb_selftest FILE.gz TEXT [section [group [ratio_cap [tok_ratio]]]]: one single-member file through the emulation with the kernels' own slice budget
 static std::vector<uint8_t> slurp(const char* path) {
     std::vector<uint8_t> v;
     FILE* f = fopen(path, "rb");
@@ -328,10 +490,17 @@ int main(int argc, char** argv) {
     }
     if (argc > 2) {
         const std::vector<uint8_t> gz = slurp(argv[1]), text = slurp(argv[2]);
-        g_max_slices = 6; g_slice_tokens = 2048;          // (DeviceInflate::run_group's defaults)
+        g_max_slices = 6; g_slice_tokens = 2048;          // (DeviceInflate::run_group's defaults: slices, 1 token entry per compressed byte, resident results)
+        g_tok_ratio = argc > 6 ? (uint32_t)atoi(argv[6]) : 1;
+        g_resident = true;
         const bool ok = run_case(argv[1], gz, text, argc > 3 ? (size_t)atol(argv[3]) : 65536, argc > 4 ? (size_t)atol(argv[4]) : 1 << 20, 4, true, argc > 5 ? (uint32_t)atoi(argv[5]) : 12);
         return ok ? 0 : 1;
     }
+    for (int mode = 0; mode < 2; ++mode) {
+    // every case twice: the symbols come back to the host (mode 0, rounds 4 - 5), or stay with the decoder, which resolves their
+    // markers and CRCs when the consumer arrives (mode 1, round 6: what DeviceInflate does)
+    g_resident = mode == 1;
+    printf("---- %s ----\n", g_resident ? "resident results: markers and CRC-32 resolved by the decoder" : "symbols handed back to the host");
     const std::vector<uint8_t> fq = fastq_like(14000, 3);        // ~4.9 MB
     // dynamic-Huffman streams of every level: the device must supply sections
     for (int level : {1, 2, 4, 6, 9}) {
@@ -421,7 +590,25 @@ int main(int argc, char** argv) {
         run_case("device breaks at group 3 (device only)", g6, big, 64 << 10, 256 << 10, 3, true);
         run_case("device breaks at group 3 (hybrid)", g1, big, 128 << 10, 1 << 20, 2, false, 20, 4096, false, true);
         g_break_after = -1;
+        if (g_resident) {
+            // the decoder fails when asked to resolve (a HIP error at that point): the run's sections are dropped, the host decodes the stretch
+            g_resolve_breaks_after = 1;
+            run_case("resolve fails from the 2nd run on (device only)", g6, big, 64 << 10, 256 << 10, 3, true);
+            run_case("resolve fails from the 2nd run on (hybrid)", g6, big, 64 << 10, 256 << 10, 3, true, 20, 4096, false, true);
+            g_resolve_breaks_after = -1;
+            // a member that starts less than 32 KiB before a device section: window entries that do not exist
+            std::vector<uint8_t> cat, text;
+            const std::vector<uint8_t> head = fastq_like(40, 21);
+            const std::vector<uint8_t> g0 = gz_of(head, 6, Z_DEFAULT_STRATEGY);
+            cat.insert(cat.end(), g0.begin(), g0.end()); text.insert(text.end(), head.begin(), head.end());
+            cat.insert(cat.end(), g6.begin(), g6.end()); text.insert(text.end(), big.begin(), big.end());
+            run_case("short member, then a long one", cat, text, 64 << 10, 256 << 10, 3, true);
+        }
     }
+    }
+    if (g_sections_resolved == 0) { printf("no section was ever resolved by the emulated device\n"); ++failures; }
+    if (g_segment_bytes == 0) { printf("no text was ever handed over as a device segment\n"); ++failures; }
+    printf("%.1f MB of text handed over as device segments\n", 1e-6 * (double)g_segment_bytes);
     if (failures) { printf("%d FAILED\n", failures); return 1; }
     printf("all device-gunzip logic checks passed\n");
     return 0;

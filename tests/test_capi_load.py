@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "missing export " + s
     assert sorted(capi.EXPORTED_SYMBOLS) == syms
-    assert lib.aqc_abi_version() == 2          # (2: aqc_batch.qlen1 / qlen2, AQC_ERR_INDEX, aqc_fetch_quality_views, aqc_error_record)
+    assert lib.aqc_abi_version() == 3          # (2: aqc_batch.qlen1 / qlen2, AQC_ERR_INDEX, aqc_fetch_quality_views, aqc_error_record; 3: aqc_frame_mixed)
 
 
 def test_loads_the_way_the_reference_loads_libed():
