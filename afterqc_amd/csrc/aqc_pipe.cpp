@@ -708,14 +708,33 @@ struct GzSource : Source {
 // write()s fills a file at 6 GB/s (tmpfs) .. 11 GB/s (page cache); several threads pwrite()-ing disjoint ranges of the same
 // file, or storing into a shared mapping of it, are 2-5x SLOWER (they fight over the file's page-cache lock).  So every
 // output file gets its own writer thread and sees nothing but big sequential writes.
+//
+// Round 6 (tools/ubench/dma_write_rate.hip, profiles/r06_dma_write_rate.txt: what the round-5 review's "26 % the writers lose" is):
+// two files at once take 9.7 - 10.7 GB/s each whatever the source buffer is — lying still or just filled by a D2H copy, on either
+// socket, in pieces of 1 / 4 / 16 / 45 MiB — and 12.0 - 13.0 GB/s once the file's blocks exist: write() into a fresh file spends a
+// fifth of its time allocating them.  So the writer keeps the file's blocks reserved 1 GiB ahead of its position
+// (fallocate(FALLOC_FL_KEEP_SIZE): the size stays what has been written) and gives back what is left over when it closes.
+// AQC_FALLOC=0 switches that off; a filesystem without fallocate does so by itself.
 struct OutFile {
     int fd = -1;
     uint64_t pos = 0;
+    uint64_t reserved = 0;       // blocks exist up to here
+    int prealloc = 1;            // 0 off, 1 keep-size, 2 size-extending (the file is cut to `pos` when it closes)
     bool open_(const char* path) {
         fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (const char* e = getenv("AQC_FALLOC")) prealloc = e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
+        reserved = 0;
         return fd >= 0;
     }
+    void reserve_ahead(size_t n) {
+        const uint64_t STEP = 1ull << 30;
+        if (!prealloc || pos + n + (STEP >> 2) <= reserved) return;
+        const uint64_t want = std::max<uint64_t>(reserved, pos) , len = std::max<uint64_t>(STEP, pos + n + (STEP >> 2) - want);
+        if (fallocate(fd, prealloc == 1 ? FALLOC_FL_KEEP_SIZE : 0, (off_t)want, (off_t)len) == 0) reserved = want + len;
+        else prealloc = 0;       // (not supported here / no space for the reservation: plain writes will say what is wrong, if anything)
+    }
     bool append(const uint8_t* p, size_t n) {
+        reserve_ahead(n);
         while (n) {
             const ssize_t w = ::write(fd, p, std::min<size_t>(n, 1u << 30));
             if (w <= 0) return false;
@@ -725,6 +744,9 @@ struct OutFile {
     }
     // the same for a list of pieces (writev, IOV_MAX at a time; pieces of length 0 are the caller's business)
     bool appendv(std::vector<struct iovec>& iov) {
+        size_t total = 0;
+        for (const struct iovec& v : iov) total += v.iov_len;
+        reserve_ahead(total);
         size_t i = 0;
         while (i < iov.size()) {
             const int cnt = (int)std::min<size_t>(iov.size() - i, 1024);
@@ -739,7 +761,10 @@ struct OutFile {
         return true;
     }
     void close_() {
-        if (fd >= 0) close(fd);
+        if (fd >= 0) {
+            if (reserved > pos && ftruncate(fd, (off_t)pos) != 0) {}   // (gives the unused reservation back; a size-extending one is cut)
+            close(fd);
+        }
         fd = -1;
     }
 };
@@ -796,6 +821,10 @@ struct OutChunk {
     };
     std::shared_ptr<Spans> spans;
     int in_buf[2] = {-1, -1};    // input ring buffers this chunk still holds (spans mode), -1: none
+    // the good output of file f, put together on the host by the slot worker (spans mode "assemble", the default for plain-text
+    // outputs since round 6): the file writer issues ONE write() of it, as for a stream the device formatted
+    const uint8_t* good_ptr[2] = {nullptr, nullptr};
+    uint64_t good_bytes[2] = {0, 0};
 };
 
 }  // namespace
@@ -810,7 +839,7 @@ struct aqc_pipe {
     // per input file: ring of page-locked chunk buffers
     std::vector<HostBuf> in_buf[2];
     // per worker (ctx, slot): two sets of six output buffers
-    struct WorkerBufs { HostBuf out[2][6]; };
+    struct WorkerBufs { HostBuf out[2][6]; HostBuf good[2][2]; };       // good[set][file]: assembled good output (plain memory)
     std::vector<WorkerBufs> wbufs;
     // per input file: the device decoder of its gzip stream (created with the first .gz input, kept: its device buffers and
     // page-locked arenas are as expensive to set up as a whole run)
@@ -886,7 +915,8 @@ struct Run {
         if (getenv("AQC_PIPE_DEBUG"))
             fprintf(stderr, "pipe: %s thread — NUMA node %d, %s\n", what, io_node, bound ? "bound to that node's CPUs" : "not bound (contexts on several nodes, single node, unknown, or AQC_PIPE_NUMA=0)");
     }
-    bool spans_on = false;             // plain-text output: good records that go out as their own bytes are written from the input buffers
+    bool spans_on = false;             // plain-text output: good records that go out as their own bytes are not copied on the device (aqc_format_spans) ...
+    bool spans_assemble = false;       // ... and the slot worker puts each good file's chunk together on the host (else: the file writers writev the pieces)
     // End of input inside the pipe (fastq.py:37-49, preprocesser.py:412-429).  A chunk is RUN only once every chunk before it has been
     // framed and found to continue the input: the chunk in which the input ends (an empty line, a partial last record, a mate file
     // that is shorter) becomes the run's last, chunks behind it are dropped before anything of them reaches a counter.
@@ -1549,7 +1579,21 @@ struct Run {
                                 }
                                 sp->good_total[f] = total + (sp->end[f] > cursor ? sp->end[f] - cursor : 0);
                             }
-                            oc.spans = sp;
+                            if (!rc && spans_assemble) {
+                                // the good output of each file, put together here: the chunk's own bytes between the events, the rebuilt
+                                // records at them — on the pool, a task per ~1 MiB of output; then the input buffers are free again
+                                for (int f = 0; f < nf; ++f) {
+                                    HostBuf& gb = P->wbufs[wid].good[set][f];
+                                    gb.pageable = true;
+                                    gb.ensure((size_t)sp->good_total[f] + 64);
+                                    if (sp->good_total[f] && !gb.p) { rc = AQC_ERR_HIP; break; }
+                                    assemble_good(*sp, f, oc.sizes[3 * f] ? P->wbufs[wid].out[set][3 * f].p : nullptr, gb.p);
+                                    oc.good_ptr[f] = gb.p;
+                                    oc.good_bytes[f] = sp->good_total[f];
+                                }
+                                if (rc) { gate_leave(dg); drop_input(); fail(AQC_ERR_HIP, "allocation of a good-output buffer failed"); return; }
+                                for (int f = 0; f < nf; ++f) { release_ring(f, j.c[f].buf); oc.in_buf[f] = -1; }
+                            } else oc.spans = sp;
                         }
                     }
                     if (!rc) break;
@@ -1574,6 +1618,39 @@ struct Run {
             records += n;
             if (!outq.push(oc) || fatal) return;
         }
+    }
+
+    // The good output of file f of a chunk formatted by aqc_format_spans -> dst (what capi.assemble_spans does in the tests, and what
+    // the writev of the other spans mode hands the kernel piece by piece): the copies run on the pool, cut into tasks at events.
+    void assemble_good(const OutChunk::Spans& sp, int f, const uint8_t* patch, uint8_t* dst) {
+        const std::vector<aqc_span_event>& ev = sp.ev[f];
+        const uint8_t* in = sp.in[f];
+        const size_t TASK = 1u << 20;
+        // task boundaries: event index, input cursor, output offset, patch offset at the start of each task
+        struct Cut { size_t e; uint64_t cursor, out, poff; };
+        std::vector<Cut> cuts;
+        cuts.push_back(Cut{0, 0, 0, 0});
+        uint64_t cursor = 0, out = 0, poff = 0;
+        for (size_t i = 0; i < ev.size(); ++i) {
+            out += (ev[i].in_start - cursor) + ev[i].out_len;
+            poff += ev[i].out_len;
+            cursor = (uint64_t)ev[i].in_start + ev[i].in_len;
+            if (out - cuts.back().out >= TASK) cuts.push_back(Cut{i + 1, cursor, out, poff});
+        }
+        const uint64_t end = sp.end[f];
+        P->pool->parallel_for(cuts.size(), [&](size_t t) {
+            const Cut& c = cuts[t];
+            const size_t e1 = t + 1 < cuts.size() ? cuts[t + 1].e : ev.size();
+            uint64_t cur = c.cursor, o = c.out, po = c.poff;
+            for (size_t i = c.e; i < e1; ++i) {
+                const uint64_t run = ev[i].in_start - cur;
+                // (a long run of untouched records — a clean chunk has few events — is split so that no task copies much more than the others)
+                if (run) { memcpy(dst + o, in + cur, (size_t)run); o += run; }
+                if (ev[i].out_len) { memcpy(dst + o, patch + po, ev[i].out_len); o += ev[i].out_len; po += ev[i].out_len; }
+                cur = (uint64_t)ev[i].in_start + ev[i].in_len;
+            }
+            if (t + 1 == cuts.size() && end > cur) memcpy(dst + o, in + cur, (size_t)(end - cur));
+        });
     }
 
     // An exception INSIDE upstream's loop (KeyError / IndexError of the overlap walk, int() of a name field) ends its run at that
@@ -1637,7 +1714,10 @@ struct Run {
         while (fileq[q]->pop(cm)) {
             const OutChunk& oc = cm->oc;
             const uint64_t tw = now_ns();
-            if (!abort && oc.spans && q % 3 == 0) {
+            if (!abort && q % 3 == 0 && oc.good_ptr[q / 3]) {
+                // the slot worker has put the chunk's good output together (spans mode "assemble")
+                if (oc.good_bytes[q / 3] && !out[q].append(oc.good_ptr[q / 3], (size_t)oc.good_bytes[q / 3])) fail(AQC_ERR_ARG, "write error on output %d (disk full?)", q);
+            } else if (!abort && oc.spans && q % 3 == 0) {
                 // the good file of input q / 3: the chunk's own bytes between the events, the rebuilt records (stream 0) at them
                 const OutChunk::Spans& sp = *oc.spans;
                 const int f = q / 3;
@@ -1700,7 +1780,7 @@ struct Run {
                 int live = 0;
                 uint64_t to_file[6];
                 for (int q = 0; q < 6; ++q) {
-                    to_file[q] = (cur.spans && q % 3 == 0) ? cur.spans->good_total[q / 3] : cur.sizes[q];
+                    to_file[q] = (q % 3 == 0 && cur.good_ptr[q / 3]) ? cur.good_bytes[q / 3] : (cur.spans && q % 3 == 0) ? cur.spans->good_total[q / 3] : cur.sizes[q];
                     res->bytes_out[q] += to_file[q];
                     if (cur.set >= 0 && to_file[q] && out[q].fd >= 0) ++live;
                 }
@@ -1793,6 +1873,9 @@ void aqc_pipe_destroy(aqc_pipe* p) {
     for (auto& w : p->wbufs)
         for (int s = 0; s < 2; ++s)
             for (int q = 0; q < 6; ++q) w.out[s][q].release();
+    for (auto& w : p->wbufs)
+        for (int s = 0; s < 2; ++s)
+            for (int f = 0; f < 2; ++f) w.good[s][f].release();
     delete p;
 }
 
@@ -1809,22 +1892,33 @@ int aqc_pipe_run(aqc_pipe* P, const aqc_pipe_io* io, const aqc_pipe_opts* opt, a
     R.nf = (io->in_path[1] || io->in_mem[1]) ? 2 : 1;
     R.K = opt->chunk_records ? opt->chunk_records : (1u << 17);
     {
-        // AQC_SPANS=1, plain-text outputs: the good records that go out as their own bytes never leave the host (aqc_format_spans):
-        // no copy on the device (the device step of 10 M reads 4.7 -> 3.2 ms, 17.6 -> 10.8 GB of HBM traffic), no download
-        // (pinned -> pinned 100 -> 159 Mreads/s) — and the good files are written with writev from the input buffers, a piece per run
-        // of such records.  OFF by default, because of what that costs on the hosts measured so far: a run of whole records is
-        // ~3 - 4 KB in the bench workload (one record in ten is bad, trimmed or corrected), an iovec costs the kernel ~60 ns
-        // (tools/ubench/writev_rate.cpp: 9.2 - 9.9 GB/s against write()'s 11 - 12), and a one-input run is bound by exactly
-        // those two file writers: file -> file 0.18 -> 0.23 s (profiles/r05_spans_ab.txt).  It pays where PCIe is the bound.
-        // (.gz output needs the whole text on the device, where its members are built.)
+        // Plain-text outputs, OPT-IN: the good records that go out as their own bytes never leave the host (aqc_format_spans): no copy
+        // on the device (the device step of 10 M reads 4.7 -> 3.2 ms, 17.3 -> 10.7 GB of HBM traffic), no download (3.1 of the
+        // 3.44 GB per 10 M reads stay off PCIe: pinned -> pinned 105 -> 122 - 160 Mreads/s).  Two ways to get them into the good files:
+        //   AQC_SPANS=1  writev (round 5): the file writers writev the pieces straight from the input buffers — no host copy, but a
+        //                run of whole records is 3 - 4 KB in the bench workload and an iovec costs the kernel ~60 ns: 9.2 - 9.9 GB/s
+        //                against write()'s 11 - 12 on a path bound by exactly those two writers (file -> file 0.18 -> 0.23 s,
+        //                profiles/r05_spans_ab.txt);
+        //   AQC_SPANS=2  assemble (round 6): the slot worker puts each good file's chunk together in host memory — the chunk's own
+        //                bytes between the events, the rebuilt records at them, copied on the pool in ~1 MiB tasks — and the file
+        //                writer issues one big write() as it always did.  Tried as the DEFAULT and taken back: interleaved on one
+        //                box the text step gives 50.2 - 51.4 Mreads/s, this 39.6 - 48.2 (two inputs at once: 72 - 76 against 55 - 68;
+        //                the 100 M-read input 19 against 44 - 52; profiles/r06_spans_assemble_ab.txt) — the host copies every
+        //                output byte once more, on the 16 granted CPUs that the readers' and the writers' own copies already
+        //                share, and the writers then read buffers that pool threads of either socket have just written.
+        // So the DEFAULT stays the text step (aqc_format: everything formatted on the device and downloaded): a run is bound by its
+        // two file writers, and the text step is what leaves them alone.  Both spans modes pay where PCIe or the device is the
+        // bound and the host has cycles to spare.  (.gz output needs the whole text on the device, where its members are built; a
+        // .gz input decoded on the device keeps its text in HBM and has no host copy to assemble from.)
         const char* e = getenv("AQC_SPANS");
-        R.spans_on = !io->gzip_out && !opt->no_output && e && e[0] == '1';
+        R.spans_on = !io->gzip_out && !opt->no_output && e && (e[0] == '1' || e[0] == '2');
+        R.spans_assemble = R.spans_on && e[0] == '2';
     }
     for (int f = 0; f < R.nf; ++f) {
         R.inq[f].reset(new BQueue<InChunk>(2));
         // (the whole ring only when chunks keep their input buffers until they are written — spans mode; else one buffer per slot + two:
         //  every buffer used is a buffer page-locked, which a one-shot run pays for)
-        const size_t use = R.spans_on ? P->in_buf[f].size() : std::min(P->in_buf[f].size(), (size_t)(P->n_ctx * P->slots + 2));
+        const size_t use = (R.spans_on && !R.spans_assemble) ? P->in_buf[f].size() : std::min(P->in_buf[f].size(), (size_t)(P->n_ctx * P->slots + 2));
         R.ring_free[f].assign(P->in_buf[f].size(), 0);
         for (size_t i = 0; i < use; ++i) R.ring_free[f][i] = 1;
     }

@@ -147,6 +147,155 @@ def test_bench_two_ranks_shared_gpu(tmp_path):
     assert mi and mi["inputs"] == 2 and mi["output_files"] == 8 and mi["mreads_s"] > 0, mi
 
 
+def _hash_file(path, limit=None):
+    import gzip
+    import hashlib
+    h, n = hashlib.sha256(), 0
+    with (gzip.open(path, "rb") if path.endswith(".gz") else open(path, "rb")) as f:
+        while limit is None or n < limit:
+            piece = f.read(1 << 24 if limit is None else min(1 << 24, limit - n))
+            if not piece:
+                break
+            h.update(piece)
+            n += len(piece)
+    return h.hexdigest(), n
+
+
+def _run_filter(argv, barcode=False, **kw):
+    from afterqc_amd import after, preprocesser
+    options, _ = after.parseCommand(list(argv))
+    after.finalize_options(options)
+    options.barcode = barcode
+    if barcode:
+        options.trim_front = options.trim_front2 = 0
+    flt = preprocesser.seqFilter(options, **kw)
+    stat = flt.run()
+    stat = json.loads(json.dumps(stat))
+    for k in ("good_output_folder", "bad_output_folder", "report_output_folder", "overlap_output_folder", "read1_file", "read2_file", "gzip", "compression"):
+        stat["command"].pop(k, None)
+    return stat, flt
+
+
+def _lines(path):
+    import gzip
+    n = 0
+    with (gzip.open(path, "rb") if path.endswith(".gz") else open(path, "rb")) as f:
+        for piece in iter(lambda: f.read(1 << 24), b""):
+            n += piece.count(b"\n")
+    return n
+
+
+def test_config2_full_size(tmp_path):
+    """BASELINE config 2 at its stated size: 10 M synthetic single-end 1 x 150 reads, quality / N / polyX filter + trim
+    (`-f 5 -t 5 -q 15 -u 60 -p 35 -a 2 -n 5 -s 35`), ONE 3.5 GB FASTQ file through aqc_pipe_run on one MI355X.
+      * oracle window: the first 1 M reads through the ORACLE engine (scalar C restatement of the reference's loop + the
+        reference's writer, serial text loop) — its good and bad files are byte for byte the head of the GPU run's;
+      * conservation: every read goes to exactly one of good / bad, the counters say the same;
+      * split invariance: chunks of 50 000 records dealt over two contexts give the same files and the same statistics JSON
+        as production chunks on one context."""
+    from oracle import oracle
+    work = str(tmp_path)
+    n = 10_000_000
+    d = synth.make_single(n, 150, seed=1002, workers=max(1, (os.cpu_count() or 8) // 2))
+    r1 = os.path.join(work, "R1.fq")
+    synth.write_fastq_fixed(r1, d["seq1"], d["qual1"], 1)
+    w1 = os.path.join(work, "W_R1.fq")
+    n_win = 1_000_000
+    synth.write_fastq_fixed(w1, d["seq1"][:n_win], d["qual1"][:n_win], 1)
+    del d
+    opts = ["-f", "5", "-t", "5", "-q", "15", "-u", "60", "-p", "35", "-a", "2", "-n", "5", "-s", "35"]
+
+    def go(tag, src, **kw):
+        out = os.path.join(work, tag)
+        stat, flt = _run_filter(["-1", src, "-g", os.path.join(out, "good"), "-b", os.path.join(out, "bad"), "-r", os.path.join(out, "QC")] + opts, **kw)
+        return out, stat, flt
+
+    out_a, stat_a, flt_a = go("one", r1, use_pipe=True, devices=[0])
+    assert flt_a.used_pipe
+    s = stat_a["afterqc_main_summary"]
+    good, bad = os.path.join(out_a, "good", "R1.good.fq"), os.path.join(out_a, "bad", "R1.bad.fq")
+    n_good, n_bad = _lines(good) // 4, _lines(bad) // 4
+    assert s["total_reads"] == n and n_good + n_bad == n and s["good_reads"] == n_good and s["bad_reads"] == n_bad, (s, n_good, n_bad)
+    assert 0.5 * n < n_good < n
+    # the oracle's window
+    out_o, stat_o, flt_o = go("oracle", w1, engine=oracle.OracleEngine(), use_text_path=True, use_pipe=False)
+    for name in ("good/W_R1.good.fq", "bad/W_R1.bad.fq"):
+        ho, size = _hash_file(os.path.join(out_o, name))
+        hg, got = _hash_file(os.path.join(out_a, name.replace("W_", "")), limit=size)
+        assert size > 0 and got == size and hg == ho, name
+    assert stat_o["afterqc_main_summary"]["total_reads"] == n_win
+    # split invariance
+    out_b, stat_b, flt_b = go("two", r1, use_pipe=True, devices=[0, 0], chunk_records=50_000, pipe_slots=3)
+    assert flt_b.used_pipe
+    for name in ("good/R1.good.fq", "bad/R1.bad.fq"):
+        assert _hash_file(os.path.join(out_a, name)) == _hash_file(os.path.join(out_b, name)), name
+    assert stat_a == stat_b
+
+
+def test_config5_full_size_gz_in_gz_out(tmp_path):
+    """BASELINE config 5's shape at the size one MI355X is asked for (3 M pairs): paired 2 x 250 + 17-base barcode / verify prefix
+    (2 x 267), barcode mode (file names with `barcode`), bubble filter with a circles.csv, one-member .gz inputs, -z outputs,
+    --store_overlap — through aqc_pipe_run: device gunzip + host pool in, device-built .gz members out.
+      * oracle window: the first 300 k pairs as plain text through the ORACLE engine — its six text streams (good / bad / overlap
+        x two mates) are byte for byte the head of the decompressed GPU outputs;
+      * the same input as plain text in / plain text out gives the same bytes and the same statistics JSON;
+      * conservation over the 3 M pairs."""
+    import shutil
+    from oracle import oracle
+    if not shutil.which("gzip"):
+        pytest.skip("no gzip program")
+    work = str(tmp_path)
+    n, n_win = 3_000_000, 300_000
+    d = synth.make_pairs(n, 250, seed=1005, workers=max(1, (os.cpu_count() or 8) // 2))
+    d = synth.add_barcodes(d, 1005 + 7)
+    r1, r2 = os.path.join(work, "barcode_R1.fq"), os.path.join(work, "barcode_R2.fq")
+    w1, w2 = os.path.join(work, "W", "barcode_R1.fq"), os.path.join(work, "W", "barcode_R2.fq")
+    os.makedirs(os.path.join(work, "W"))
+    for path, wpath, mate in ((r1, w1, 1), (r2, w2, 2)):
+        synth.write_fastq_fixed(path, d["seq%d" % mate], d["qual%d" % mate], mate)
+        synth.write_fastq_fixed(wpath, d["seq%d" % mate][:n_win], d["qual%d" % mate][:n_win], mate)
+    del d
+    os.makedirs(os.path.join(work, "D"))
+    with open(os.path.join(work, "D", "circles.csv"), "w") as f:
+        # names carry tile 1101 -> int(tile[1:]) = 101, lane 1, x = record index, y = index * 7919 % 100000 (synth.render_names)
+        f.write("x,y,radius,lane,tile\n")
+        for k in range(8):
+            f.write("%r,%r,%r,1,101\n" % (25000.0 * (k + 1), 50000.0, 3000.0 + 100.0 * k))
+    jobs = [subprocess.Popen(["gzip", "-1", "-k", p]) for p in (r1, r2)]
+    assert all(j.wait() == 0 for j in jobs)
+    common = ["-f", "0", "-t", "0", "--debubble", "--debubble_dir", os.path.join(work, "D"), "--store_overlap", "on"]
+
+    def go(tag, a, b, extra=(), **kw):
+        out = os.path.join(work, tag)
+        stat, flt = _run_filter(["-1", a, "-2", b, "-g", os.path.join(out, "good"), "-b", os.path.join(out, "bad"), "-r", os.path.join(out, "QC"),
+                                 "--overlap_output_folder", os.path.join(out, "overlap")] + common + list(extra), barcode=True, **kw)
+        return out, stat, flt
+
+    out_g, stat_g, flt_g = go("gz", r1 + ".gz", r2 + ".gz", extra=["-z"], use_pipe=True, devices=[0])
+    assert flt_g.used_pipe
+    names = [(sub, "barcode_R%d.%s.fq" % (m, sub)) for m in (1, 2) for sub in ("good", "bad", "overlap")]
+    s = stat_g["afterqc_main_summary"]
+    n_good = _lines(os.path.join(out_g, "good", "barcode_R1.good.fq.gz")) // 4
+    n_bad = _lines(os.path.join(out_g, "bad", "barcode_R1.bad.fq.gz")) // 4
+    assert s["total_reads"] == n and n_good + n_bad == n and s["good_reads"] == n_good and s["bad_reads"] == n_bad, (s, n_good, n_bad)
+    # plain text in / out: same bytes, same statistics
+    out_p, stat_p, flt_p = go("plain", r1, r2, use_pipe=True, devices=[0])
+    assert flt_p.used_pipe
+    for sub, fn in names:
+        assert _hash_file(os.path.join(out_g, sub, fn + ".gz")) == _hash_file(os.path.join(out_p, sub, fn)), fn
+    assert stat_g == stat_p
+    # the oracle's window: six text streams
+    out_o, stat_o, _ = go("oracle", w1, w2, engine=oracle.OracleEngine(), use_text_path=True, use_pipe=False)
+    checked = 0
+    for sub, fn in names:
+        ho, size = _hash_file(os.path.join(out_o, sub, fn))
+        hg, got = _hash_file(os.path.join(out_p, sub, fn), limit=size)
+        assert got == size and hg == ho, fn
+        checked += size > 0
+    assert checked >= 5, checked          # (good, bad and overlap records of both mates all occur among 300 k pairs)
+    assert stat_o["afterqc_main_summary"]["total_reads"] == n_win
+
+
 def test_config4_size_soak_one_input_of_100M_reads(tmp_path):
     """BASELINE config 4 at its stated size on one GPU (tools/soak_config4.py: ONE input of 10 x the 5 M-pair block = 100 M reads,
     two 17 GB files, over two contexts on GPU 0): every output file equals the block's output x 10 byte for byte, counters and
@@ -155,7 +304,11 @@ def test_config4_size_soak_one_input_of_100M_reads(tmp_path):
     starts; the run's rate is printed, and must not fall back to the write-back-throttled 20 Mreads/s of round 4's soak."""
     import shutil
     in_dir = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 45e9 else None
-    copies = 10 if in_dir and shutil.disk_usage(str(tmp_path)).free > 45e9 else 3
+    copies = 10
+    if not in_dir or shutil.disk_usage(str(tmp_path)).free <= 45e9:
+        # (round-5 review: the soak used to shrink to 3 copies without a word, and no log could tell which size had run)
+        pytest.skip("config 4 at its stated size needs 45 GB free in /dev/shm (inputs) and in %s (outputs): %s / %.0f GB free"
+                    % (tmp_path, "%.0f GB" % (shutil.disk_usage("/dev/shm").free / 1e9) if os.path.isdir("/dev/shm") else "no /dev/shm", shutil.disk_usage(str(tmp_path)).free / 1e9))
     cmd = [sys.executable, os.path.join(ROOT, "tools", "soak_config4.py"), "--copies", str(copies), "--devices", "0,0", "--dir", str(tmp_path)]
     if in_dir:
         cmd += ["--in-dir", in_dir]
@@ -167,5 +320,4 @@ def test_config4_size_soak_one_input_of_100M_reads(tmp_path):
     assert all(v["equals_block_output_x_copies"] for v in log["outputs"].values())
     assert log["indices_beyond_2_32"]["identical_outputs_and_counters"]
     print("soak:", json.dumps(log["run"]))
-    if copies == 10:
-        assert log["largest_output_gib"] > 15 and log["run"]["mreads_s"] > 28, log["run"]
+    assert log["largest_output_gib"] > 15 and log["run"]["mreads_s"] > 28, log["run"]

@@ -106,6 +106,36 @@ def test_fused_long_names_and_many_batches(gpu_engine, fused_engine):
     for q in range(6):
         assert got[q] == want[q], q
     assert (cnt_a == cnt_b).all()
+    # ... and the spans assembly of the same chunk (events crossing the same 9 375 batches)
+    eng = gpu_engine
+    eng.set_config(cfg_default())
+    eng.reset_stats()
+    info = eng.frame(0, pad(t1), len(t1), True, pad(t2), len(t2), True)
+    eng.run(0)
+    sizes, n_ev = eng.format_spans(0, n, False)
+    sp = [fetch(eng, 0, sizes, q) for q in range(6)]
+    end = eng.span_end(0, n)
+    spans_good = [capi.assemble_spans(chunk, end[f], eng.fetch_span_events(0, f, n_ev[f]), sp[3 * f]) for f, chunk in enumerate((t1, t2))]
+    eng.reset_stats()
+    assert spans_good[0] == want[0] and spans_good[1] == want[3] and sp[1] == want[1] and sp[4] == want[4]
+    # All three writers against the ORACLE's streams, not only against each other (round-5 review: the look-back over thousands of
+    # batches had never been checked against anything but the other HIP writer): the scalar C restatement of the reference's
+    # loop + the reference's writeReads (oracle/oracle.py), over the very same 300 000 pairs
+    from oracle import oracle
+    oe = oracle.OracleEngine()
+    oe.set_config(cfg_default())
+    oe.reset_stats()
+    oinfo = oe.frame(0, pad(t1), len(t1), True, pad(t2), len(t2), True)
+    assert int(oinfo.n) == n
+    oe.run(0)
+    osizes = oe.format(0, n, False)
+    for q in range(6):
+        obuf = np.zeros(osizes[q] + 64, dtype=np.uint8)
+        if osizes[q]:
+            oe.fetch_text(0, q // 3, q % 3, obuf, obuf.size)
+        assert obuf[:osizes[q]].tobytes() == want[q], ("oracle", q)
+    assert (np.array(oe.counters()) == cnt_a).all()
+    oe.close()
 
 
 def test_fused_then_partial_and_span_formats(gpu_engine, fused_engine):

@@ -32,6 +32,8 @@ PIPE_MODES = {"pipe": dict(use_text_path=True, use_pipe=True),
               "pipe_two_contexts": dict(use_text_path=True, use_pipe=True, chunk_records=300, devices=[0, 0], own_engines=True),
               # AQC_SPANS=1: plain-text good files written from the pipe's input buffers (aqc_format_spans), rebuilt records between them
               "pipe_spans": dict(use_text_path=True, use_pipe=True, chunk_records=211, pipe_slots=3, spans=True),
+              # AQC_SPANS=2: the same step, the good files' chunks put together on the host by the slot workers (one write() per chunk)
+              "pipe_spans_assemble": dict(use_text_path=True, use_pipe=True, chunk_records=223, pipe_slots=3, spans=2),
               # AQC_FUSED=1 (read when the context is created: the filter makes its own): where the chunk allows it the verdict kernel
               # places the records and copies the whole good ones itself; every other case must come out the same through the fallback
               "pipe_fused": dict(use_text_path=True, use_pipe=True, chunk_records=263, pipe_slots=3, own_engines=True, fused=True),
@@ -57,7 +59,8 @@ def run_case(name, tmp_path, engine, mode="text", info=None):
         kw = dict(MODES[mode] if mode in MODES else PIPE_MODES[mode])
         if kw.pop("own_engines", False):
             engine = None                                                        # the filter creates one engine per device
-        env = {"AQC_SPANS": "1"} if kw.pop("spans", False) else {}
+        sp = kw.pop("spans", False)
+        env = {"AQC_SPANS": "2" if sp == 2 else "1"} if sp else {}
         if kw.pop("fused", False):
             env["AQC_FUSED"] = "1"
         old_env = {k: os.environ.get(k) for k in env}
