@@ -1158,23 +1158,28 @@ int aqc_compress(aqc_ctx* c, int slot, int32_t level, uint64_t gz_bytes_out[6]) 
     static_assert(sizeof(GzCodebookDev) == sizeof(aqcgz::GzCodebook), "host and device codebook layouts must agree");
     GzJob J{};
     uint32_t n_members = 0;
+    // members of 64 x 255 bytes, a wave each (round 6: gz_encode_wave_kernel); AQC_GZ_ENCODER=seg: members of 256 x 255 bytes, a
+    // thread per 255-byte segment (gz_encode_kernel, rounds 3 - 5)
+    static const bool wave_enc = [] { const char* e = getenv("AQC_GZ_ENCODER"); return !(e && e[0] == 's'); }();
+    J.member_text = wave_enc ? (uint32_t)GZW_TEXT : (uint32_t)GZ_TEXT;
+    J.slot_bytes = wave_enc ? (uint32_t)GZW_SLOT : (uint32_t)GZ_SLOT;
     for (int q = 0; q < 6; ++q) {
         J.text[q] = (const uint8_t*)s->f_out[q].p;
         J.bytes[q] = s->f_bytes[q];
         J.first_block[q] = n_members;
-        n_members += (uint32_t)((s->f_bytes[q] + GZ_TEXT - 1) / GZ_TEXT);
+        n_members += (uint32_t)((s->f_bytes[q] + J.member_text - 1) / J.member_text);
         s->g_bytes[q] = 0;
         gz_bytes_out[q] = 0;
     }
     J.first_block[6] = n_members;
     // (`compressed` is set once the streams exist: an error on the way must not let aqc_fetch_gz hand out empty streams)
     if (n_members == 0) { s->compressed = true; return 0; }
-    if (s->g_stage.reserve((size_t)n_members * GZ_SLOT) || s->g_sizes.reserve(4 * (size_t)n_members) || s->g_offsets.reserve(8 * (size_t)n_members) ||
+    if (s->g_stage.reserve((size_t)n_members * J.slot_bytes) || s->g_sizes.reserve(4 * (size_t)n_members) || s->g_offsets.reserve(8 * (size_t)n_members) ||
         s->g_total.reserve(64) || s->g_hist.reserve(6 * 320 * 4) || s->g_code.reserve(6 * sizeof(GzCodebookDev)))
         return fail(AQC_ERR_HIP, "hipMalloc failed");
     for (int q = 0; q < 6; ++q) {
         const uint64_t nb = J.first_block[q + 1] - J.first_block[q];
-        if (s->g_packed[q].reserve(nb * (GZ_TEXT + 31) + 64)) return fail(AQC_ERR_HIP, "hipMalloc failed");
+        if (s->g_packed[q].reserve(nb * (J.member_text + 31) + 64)) return fail(AQC_ERR_HIP, "hipMalloc failed");
         J.packed[q] = (uint8_t*)s->g_packed[q].p;
     }
     J.stage = (uint8_t*)s->g_stage.p; J.sizes = (uint32_t*)s->g_sizes.p; J.offsets = (uint64_t*)s->g_offsets.p; J.total = (uint64_t*)s->g_total.p;
@@ -1192,7 +1197,8 @@ int aqc_compress(aqc_ctx* c, int slot, int32_t level, uint64_t gz_bytes_out[6]) 
         if (!aqcgz::build_codebook(h[q], h[q] + 286, &cb[q])) return fail(AQC_ERR_STATE, "aqc_compress: could not build a Huffman code");
     HIP_TRY(hipMemcpyAsync(s->g_code.p, cb.data(), 6 * sizeof(aqcgz::GzCodebook), hipMemcpyHostToDevice, s->stream));
     // 3. members, their places, the contiguous streams
-    hipLaunchKernelGGL(gz_encode_kernel, dim3(n_members), dim3(GZ_THREADS), 0, s->stream, J);
+    if (wave_enc) hipLaunchKernelGGL(gz_encode_wave_kernel, dim3(n_members), dim3(WAVE), 0, s->stream, J);
+    else hipLaunchKernelGGL(gz_encode_kernel, dim3(n_members), dim3(GZ_THREADS), 0, s->stream, J);
     hipLaunchKernelGGL(gz_offsets_kernel, dim3(6), dim3(GZ_THREADS), 0, s->stream, J);
     hipLaunchKernelGGL(gz_pack_kernel, dim3(n_members), dim3(GZ_THREADS), 0, s->stream, J);
     HIP_TRY(hipGetLastError());

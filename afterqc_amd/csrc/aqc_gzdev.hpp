@@ -57,6 +57,8 @@ struct GzJob {
     const GzCodebookDev* code;   // [6]
     uint32_t* hist;              // [6][320]: 286 literal/length counts, then 30 distance counts
     const GzCrcTables* crc;
+    uint32_t member_text;        // text bytes per member: GZ_TEXT (gz_encode_kernel) or GZW_TEXT (gz_encode_wave_kernel)
+    uint32_t slot_bytes;         // staging bytes per member: GZ_SLOT or GZW_SLOT
     uint8_t* packed[6];          // contiguous streams (gz_pack_kernel)
     uint64_t* offsets;           // [n_members] start of each member inside its packed stream; totals in total[6]
     uint64_t* total;
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(GZ_THREADS) void gz_hist_kernel(GzJob J) {
     __shared__ uint32_t h[320];
     // workgroup (q, k) samples member k * stride of stream q
     const int q = blockIdx.x / GZ_SAMPLES, k = blockIdx.x % GZ_SAMPLES;
-    const uint32_t nb = J.first_block[q + 1] - J.first_block[q];
+    const uint32_t nb = (uint32_t)((J.bytes[q] + GZ_TEXT - 1) / GZ_TEXT);      // (its own pieces of GZ_TEXT bytes, whatever the encoder's members are)
     const uint32_t stride = nb > GZ_SAMPLES ? nb / GZ_SAMPLES : 1u;
     if ((uint32_t)k * stride >= nb) return;
     const uint32_t local = (uint32_t)k * stride;
@@ -462,12 +464,295 @@ __global__ __launch_bounds__(GZ_THREADS) void gz_offsets_kernel(GzJob J) {
 __global__ __launch_bounds__(GZ_THREADS) void gz_pack_kernel(GzJob J) {
     const uint32_t member = blockIdx.x;
     const int q = gz_stream_of(J, member);
-    const uint8_t* src = J.stage + (uint64_t)member * GZ_SLOT + 2;
+    const uint8_t* src = J.stage + (uint64_t)member * J.slot_bytes + 2;
     uint8_t* dst = J.packed[q] + J.offsets[member];
     const int n = (int)J.sizes[member];
     for (int i = threadIdx.x * 16; i < n; i += GZ_THREADS * 16) {
         if (i + 16 <= n) store16u(dst + i, load16u_t(src + i));
         else for (int k = i; k < n; ++k) dst[k] = src[k];
+    }
+}
+
+
+// ---- round 6: one gzip member per WAVE, 64 bytes per step ------------------------------------------------------------------------
+// gz_encode_kernel gives every thread 255 bytes of its own: 64 lanes, each in a state of its own (inside a run, comparing a column,
+// emitting a literal) — the wave executes every path for every step, 142 K vector instructions per wave and 16 KB, and a
+// .gz -> .gz run spends a third of the GPU's time in it (profiles/r06_gz_prof_summary.txt).  Here a wave owns a member of
+// GZW_TEXT = 64 x 255 bytes and walks it in windows of 64 consecutive bytes, a lane per byte:
+//   * what can match — the byte before (runs), the same column four lines up — is one comparison per lane and a ballot: a match's
+//     length is the run of ones in that mask from the lane's bit on (masks of the next four windows are kept ahead, so a match may
+//     be 258 long; a column match ends with its line);
+//   * the greedy parse is a walk over the window's token starts with scalar steps (v_readlane of "my token ends at"); a window
+//     without a match — the bases of a read — takes none: every lane is a literal;
+//   * the tokens' bits are placed by a lane scan of their lengths and OR-ed into a 128-word staging ring in LDS, whole words go out
+//     to the member with one coalesced store per lane.  The wave writes its member front to back: no sizing pass.
+// Same format as before — BGZF-compatible members, ONE final dynamic block with the stream's shared code, stored when that is
+// smaller — with members a quarter the size: +~2.5 % bytes (header and code per 16 KB, no column match in a member's first record).
+constexpr int GZW_TEXT = 64 * 255;               // 16320 text bytes per member
+constexpr int GZW_SLOT = 16896;                  // staging bytes per member (its text stored + headers, and a window's worth of slack)
+constexpr int GZW_MAX_LINES = 512;
+constexpr int GZW_RING = 128;                    // staging words
+
+__device__ __forceinline__ int gzw_ctz64(unsigned long long x) { return x ? (int)__builtin_ctzll(x) : 64; }
+// ones of the masks M[0..5) from bit l of M[0] on, up to the first zero
+__device__ __forceinline__ int gzw_ones_from(const unsigned long long (&M)[5], int l) {
+    int t = gzw_ctz64(~(M[0] >> l) | (l ? 0ull : 0ull));
+    if (l == 0 && M[0] == ~0ull) t = 64;
+    bool go = t >= 64 - l;
+    t = min(t, 64 - l);
+#pragma unroll
+    for (int k = 1; k < 5; ++k) {
+        const int ck = gzw_ctz64(~M[k]);            // (wave-uniform)
+        if (go) { t += ck; go = ck == 64; }
+    }
+    return t;
+}
+// zeros of the masks from bit l of M[0] on, up to the first one (the distance to the next set bit)
+__device__ __forceinline__ int gzw_zeros_from(const unsigned long long (&M)[5], int l) {
+    const unsigned long long x = M[0] >> l;
+    int t = x ? (int)__builtin_ctzll(x) : 64 - l;
+    bool go = x == 0;
+#pragma unroll
+    for (int k = 1; k < 5; ++k) {
+        const int ck = gzw_ctz64(M[k]);
+        if (go) { t += ck; go = ck == 64; }
+    }
+    return t;
+}
+
+struct alignas(16) GzwStage {
+    uint8_t text[GZW_TEXT + 64];
+    uint16_t ls[GZW_MAX_LINES];
+    uint32_t lc[286], dc[30];
+    uint32_t crc_tab[256];
+    uint32_t ring[GZW_RING];
+};
+
+__global__ __launch_bounds__(WAVE) void gz_encode_wave_kernel(GzJob J) {
+    __shared__ GzwStage S;
+    const int lane = (int)threadIdx.x;
+    const uint32_t member = blockIdx.x;
+    const int q = gz_stream_of(J, member);
+    const uint32_t local = member - J.first_block[q];
+    const uint64_t off = (uint64_t)local * GZW_TEXT;
+    const int n = (int)min<uint64_t>(GZW_TEXT, J.bytes[q] - off);
+    const GzCodebookDev& cb = J.code[q];
+    for (int i = lane; i < 286; i += WAVE) S.lc[i] = cb.lit[i];
+    if (lane < 30) S.dc[lane] = cb.dist[lane];
+    for (int i = lane; i < 256; i += WAVE) S.crc_tab[i] = J.crc->byte_table[i];
+    for (int i = lane; i < GZW_RING; i += WAVE) S.ring[i] = 0;
+    {
+        const uint8_t* src = J.text[q] + off;
+        for (int i = lane * 16; i < n; i += WAVE * 16) *reinterpret_cast<uint4*>(S.text + i) = load16u_t(src + i);      // (64 readable bytes follow a stream)
+        // what lies behind the member's end never matches anything
+        for (int i = n + lane; i < ((n + 15) & ~15) + 64 && i < GZW_TEXT + 64; i += WAVE) S.text[i] = 0;
+    }
+    if (lane == 0) S.ls[0] = 0;
+    __syncthreads();
+    uint8_t* const mem = J.stage + (uint64_t)member * GZW_SLOT + 2;         // the member; its deflate data at +18 is 4-byte aligned
+    uint32_t* const dwords = reinterpret_cast<uint32_t*>(mem + 18);
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;     // bits of the lanes before this one
+    // ---- the block header: whole words straight to the member, the partial one opens the ring
+    const uint32_t hdr_bits = cb.hdr_bits;
+    uint32_t bitpos = hdr_bits;
+    for (uint32_t i = (uint32_t)lane; i < (hdr_bits >> 5); i += WAVE) dwords[i] = cb.hdr[i];
+    if (lane == 0 && (hdr_bits & 31u)) S.ring[0] = cb.hdr[hdr_bits >> 5] & ((1u << (hdr_bits & 31u)) - 1u);
+    const uint32_t limit_bits = ((uint32_t)n + 5u) * 8u;                      // beyond this a stored block is smaller
+    bool stored = false;
+    // ---- masks of window f: what matches its predecessor byte, what matches the column four lines up, where lines end
+    unsigned long long M1[5], Mc[5], NL[5];
+    int line_far = 0;                                                        // line of window f's first byte
+    bool use_lines = true;
+    auto far_masks = [&](int f, unsigned long long& m1, unsigned long long& mc, unsigned long long& nlm) {
+        const int p = 64 * f + lane;
+        const bool valid = p < n;
+        const uint32_t c = valid ? S.text[p] : 0u;
+        const uint32_t prev = (valid && p > 0) ? S.text[p - 1] : 0x100u;
+        const bool nl = valid && c == '\n';
+        nlm = __ballot(nl);
+        m1 = __ballot(valid && c == prev);
+        const int line = line_far + __popcll(nlm & lt);
+        // this window's line ends become line starts (a later lane of this very window may need the one an earlier lane writes)
+        if (nl && line + 1 < GZW_MAX_LINES) S.ls[line + 1] = (uint16_t)(p + 1);
+        bool eq = false;
+        if (valid && line >= 4 && line < GZW_MAX_LINES) {
+            const int l0 = (int)S.ls[line], l4 = (int)S.ls[line - 4], l3 = (int)S.ls[line - 3];
+            const int q0 = l4 + (p - l0);
+            eq = q0 < l3 && S.text[q0] == c;
+        }
+        mc = __ballot(eq);
+        line_far += __popcll(nlm);
+        if (line_far >= GZW_MAX_LINES - 1) use_lines = false;               // (too many short lines: no column matches from here on)
+    };
+    const int n_win = (n + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) far_masks(k, M1[k], Mc[k], NL[k]);
+    int line_cur = 0, skip = 0;
+    for (int w = 0; w < n_win && !stored; ++w) {
+        const int p = 64 * w + lane;
+        const bool valid = p < n;
+        if (skip >= 64) skip -= 64;
+        else {
+            const uint32_t c = valid ? S.text[p] : 0u;
+            // ---- the best match at every byte
+            int blen = 1, dist = 0;
+            {
+                const uint32_t lb = S.lc[c] >> 16;
+                const int r = min(gzw_ones_from(M1, lane), 258);
+                int best_gain = 0;
+                if (r >= 3) {
+                    const int lsym = gz_len_sym(r);
+                    const int gain = r * (int)lb - (int)((S.lc[257 + lsym] >> 16) + gz_len_extra(lsym) + (S.dc[0] >> 16));
+                    if (gain > 0) { best_gain = gain; blen = r; dist = 1; }
+                }
+                if (use_lines && ((Mc[0] >> lane) & 1ull)) {
+                    const int m = min(min(gzw_ones_from(Mc, lane), gzw_zeros_from(NL, lane) + 1), 258);
+                    if (m >= 3) {
+                        const int line = line_cur + __popcll(NL[0] & lt);
+                        const int d = (int)S.ls[line] - (int)S.ls[line - 4];
+                        const int lsym = gz_len_sym(m), dsym = gz_dist_sym(d);
+                        // (the literals' bits taken as the first one's: exact for the long matches of a name against the name before
+                        //  it would need the window's prefix sums and four more windows' — the decision is not close there)
+                        const int gain = m * (int)max(lb, 5u) - (int)((S.lc[257 + lsym] >> 16) + gz_len_extra(lsym) + (S.dc[dsym] >> 16) + gz_dist_extra(dsym));
+                        if (gain > best_gain) { best_gain = gain; blen = m; dist = d; }
+                    }
+                }
+            }
+            // ---- the greedy parse: token starts of this window
+            unsigned long long marks;
+            const unsigned long long vmask = __ballot(valid);
+            int e = skip;
+            if (__ballot(valid && blen > 1) == 0ull) {
+                marks = vmask & ~((1ull << skip) - 1ull);                   // literals all the way
+                e = 64;
+            } else {
+                marks = 0;
+                const int last = 64 - (int)__builtin_clzll(vmask | 1ull);    // one behind the last valid lane
+                while (e < last) {
+                    marks |= 1ull << e;
+                    e += __builtin_amdgcn_readlane(blen, e);
+                }
+                if (e < 64) e = 64;                                          // (the member ends inside this window)
+            }
+            skip = e - 64;
+            // ---- the tokens' bits
+            const bool tok = (marks >> lane) & 1ull;
+            unsigned long long bits = 0;
+            uint32_t nb = 0;
+            if (tok) {
+                if (blen == 1) {
+                    const uint32_t a = S.lc[c];
+                    bits = a & 0xffffu; nb = a >> 16;
+                } else {
+                    const int lsym = gz_len_sym(blen), dsym = gz_dist_sym(dist);
+                    const uint32_t a = S.lc[257 + lsym], d = S.dc[dsym];
+                    bits = a & 0xffffu; nb = a >> 16;
+                    const int xl = gz_len_extra(lsym);
+                    bits |= (unsigned long long)(uint32_t)(blen - gz_len_base(lsym)) << nb; nb += (uint32_t)xl;
+                    bits |= (unsigned long long)(d & 0xffffu) << nb; nb += d >> 16;
+                    const int xd = gz_dist_extra(dsym);
+                    bits |= (unsigned long long)(uint32_t)(dist - gz_dist_base(dsym)) << nb; nb += (uint32_t)xd;
+                }
+            }
+            uint32_t inc = nb;
+#pragma unroll
+            for (int dlt = 1; dlt < WAVE; dlt <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)inc, dlt);
+                if (lane >= dlt) inc += o;
+            }
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if (tok) {
+                const uint32_t at = bitpos + inc - nb;
+                const uint32_t wi = (at >> 5) - (bitpos >> 5), sh = at & 31u;
+                const unsigned long long lo = bits << sh;
+                atomicOr(&S.ring[wi], (uint32_t)lo);
+                if (sh + nb > 32u) atomicOr(&S.ring[wi + 1], (uint32_t)(lo >> 32));
+                if (sh + nb > 64u) atomicOr(&S.ring[wi + 2], (uint32_t)(bits >> (64u - sh)));
+            }
+            // whole words leave the ring, the open one moves to its front
+            const uint32_t w0 = bitpos >> 5, w1 = (bitpos + total) >> 5, nfull = w1 - w0;
+            __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0): the ring's atomics are done
+            uint32_t keep[2] = {0, 0};
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t j = (uint32_t)lane + 64u * (uint32_t)r;
+                keep[r] = S.ring[j];
+                if (j < nfull) dwords[w0 + j] = keep[r];
+            }
+            const uint32_t open = nfull < (uint32_t)GZW_RING ? (uint32_t)__builtin_amdgcn_readlane((int)keep[nfull >> 6], (int)(nfull & 63u)) : 0u;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) S.ring[(uint32_t)lane + 64u * (uint32_t)r] = 0;
+            if (lane == 0) S.ring[0] = open;
+            bitpos += total;
+            if (bitpos > limit_bits) stored = true;
+        }
+        // ---- the masks move on by a window
+        line_cur += __popcll(NL[0]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { M1[k] = M1[k + 1]; Mc[k] = Mc[k + 1]; NL[k] = NL[k + 1]; }
+        far_masks(w + 5, M1[4], Mc[4], NL[4]);
+    }
+    uint32_t dbytes;
+    if (!stored) {
+        // end of block, then the open word
+        const uint32_t eob = S.lc[256];
+        if (lane == 0) {
+            const uint32_t sh = bitpos & 31u;
+            const unsigned long long v = (unsigned long long)S.ring[0] | ((unsigned long long)(eob & 0xffffu) << sh);
+            dwords[bitpos >> 5] = (uint32_t)v;
+            if (sh + (eob >> 16) > 32u) dwords[(bitpos >> 5) + 1] = (uint32_t)(v >> 32);
+        }
+        bitpos += eob >> 16;
+        dbytes = (bitpos + 7u) >> 3;
+        stored = dbytes >= (uint32_t)n + 5u;
+    }
+    if (stored) {
+        // incompressible with this code: one stored block (BFINAL = 1, BTYPE = 0, LEN, ~LEN, bytes)
+        dbytes = (uint32_t)n + 5u;
+        if (lane == 0) {
+            mem[18] = 1;
+            mem[19] = (uint8_t)n; mem[20] = (uint8_t)(n >> 8); mem[21] = (uint8_t)~n; mem[22] = (uint8_t)(~n >> 8);
+        }
+        for (int i = lane; i < n; i += WAVE) mem[23 + i] = S.text[i];
+    }
+    // ---- CRC-32 of the member's text: raw CRCs of the 64 grid segments (the first four text bytes complemented), combined
+    uint32_t crc;
+    {
+        const int pad = GZW_TEXT - n;
+        const int a = max(0, lane * GZ_SEG - pad), b = max(0, (lane + 1) * GZ_SEG - pad);
+        uint32_t c = 0;
+        for (int p = a; p < b; ++p) {
+            uint32_t x = S.text[p];
+            if (p < 4) x ^= 0xffu;                          // = starting the register at 0xffffffff, in a form leading zeros do not disturb
+            c = S.crc_tab[(c ^ x) & 0xffu] ^ (c >> 8);
+        }
+#pragma unroll 1
+        for (int k = 0; k < 6; ++k) {
+            const int step = 1 << k;
+            const uint32_t right = (uint32_t)__shfl_down((int)c, step);
+            if ((lane & (2 * step - 1)) == 0) {
+                const uint32_t* M = J.crc->shift[k];
+                uint32_t r = right;
+                for (int j = 0; j < 32; ++j) r ^= ((c >> j) & 1u) ? M[j] : 0u;
+                c = r;
+            }
+        }
+        crc = ~c;
+    }
+    if (lane == 0) {
+        if (n < 4) {
+            uint32_t c = 0xffffffffu;
+            for (int p = 0; p < n; ++p) c = S.crc_tab[(c ^ S.text[p]) & 0xffu] ^ (c >> 8);
+            crc = ~c;
+        }
+        const uint32_t bsize = 18u + dbytes + 8u;
+        static const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        for (int i = 0; i < 16; ++i) mem[i] = hdr[i];
+        mem[16] = (uint8_t)((bsize - 1) & 0xffu);
+        mem[17] = (uint8_t)((bsize - 1) >> 8);
+        uint8_t* t = mem + 18 + dbytes;
+        for (int k = 0; k < 4; ++k) { t[k] = (uint8_t)(crc >> (8 * k)); t[4 + k] = (uint8_t)((uint32_t)n >> (8 * k)); }
+        J.sizes[member] = bsize;
     }
 }
 
