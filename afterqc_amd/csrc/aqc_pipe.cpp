@@ -829,6 +829,16 @@ struct OutChunk {
 
 }  // namespace
 
+// Device decoders of .gz inputs outlive the pipe that made them (round 6): a decoder that has worked holds gigabytes of device
+// buffers and page-locked stages — freeing them took a one-shot CLI run 34 ms of its pass 2 (two decoders, one after the other),
+// and a folder of inputs (after.py -d: a pipe per file) would set them up again for every file.  A pipe that is destroyed hands
+// its decoders back, the next pipe on that device takes them over warm; they are freed when the process ends.
+namespace {
+struct PooledOffload { int device; size_t group; bool warm; std::unique_ptr<aqcgz::SectionOffload> dec; };
+std::mutex g_offload_mu;
+std::vector<PooledOffload> g_offload_pool;
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------------------------
 struct aqc_pipe {
     int n_ctx = 0;
@@ -844,6 +854,8 @@ struct aqc_pipe {
     // per input file: the device decoder of its gzip stream (created with the first .gz input, kept: its device buffers and
     // page-locked arenas are as expensive to set up as a whole run)
     std::unique_ptr<aqcgz::SectionOffload> gz_offload[2];
+    int gz_offload_device[2] = {-1, -1};
+    size_t gz_offload_group[2] = {0, 0};
     bool gz_offload_tried[2] = {false, false};
     bool gz_offload_warm[2] = {false, false};       // the decoder of this file slot has run before: its device buffers and page-locked arenas exist
 };
@@ -1011,18 +1023,33 @@ struct Run {
                     P->gz_offload_tried[f] = true;
                     size_t group = 96u << 20;       // (measured, warm pipe, 0.59 GB inputs: groups of 16 / 32 / 96 MiB = 34 / 38 / 42.5 Mreads/s — profiles/r06_gz_hbm_ab.txt)
                     if (const char* g = getenv("AQC_GZ_GROUP")) group = (size_t)std::max(1ll, atoll(g));
-                    P->gz_offload[f].reset(aqcgz::make_device_offload(aqc_device_index(P->ctx[(size_t)f % P->ctx.size()]), group));
+                    const int dev = aqc_device_index(P->ctx[(size_t)f % P->ctx.size()]);
+                    {
+                        std::lock_guard<std::mutex> g(g_offload_mu);
+                        for (size_t i = 0; i < g_offload_pool.size(); ++i)
+                            if (g_offload_pool[i].device == dev && g_offload_pool[i].group == group) {
+                                P->gz_offload[f] = std::move(g_offload_pool[i].dec);
+                                P->gz_offload_warm[f] = g_offload_pool[i].warm;
+                                g_offload_pool.erase(g_offload_pool.begin() + (long)i);
+                                break;
+                            }
+                    }
+                    if (!P->gz_offload[f]) P->gz_offload[f].reset(aqcgz::make_device_offload(dev, group));
+                    P->gz_offload_device[f] = dev;
+                    P->gz_offload_group[f] = group;
                 }
                 // Which files the device is asked for.  Until round 5 its first use in a process cost more than a run of 10 M reads
                 // takes (~40 GB of device buffers sized for the worst case, hipMalloc at 16 ms per GB, with the consumer waiting for
                 // the groups the allocating lanes had been handed: profiles/r05_gz_cold_decoder.txt), so a cold decoder was kept for
                 // inputs of >= 4 GiB.  Round 6: buffers by need (2 - 3 GB for groups of 62 MiB), set up in the background while the
                 // pool keeps every section (SectionOffload::prepare), markers + CRC-32 resolved on the device — a cold decoder is
-                // started for every input of >= 256 MiB compressed (about 5 M reads: below that the run is over before the ~5 GB of
-                // buffers and result sets exist — a fresh process breaks even near 0.5 GB, profiles/r06_gz_cold.txt), a warm one — the pipe object has decoded a .gz input of this slot with it before: a service, a folder of
+                // started for every input of >= 448 MiB compressed (about 8 M reads).  Measured through the CLI, a fresh process per
+                // run (profiles/r06_gz_cold_cli.txt): 10 M reads in two files of 0.59 GB — pass 2 0.37 - 0.41 s with the device,
+                // 0.40 - 0.47 s with the pool alone; 4 M reads of the config-5 flavour in two files of 0.36 GB — 0.41 against 0.33 s:
+                // a run of a quarter of a second is over before the decoder has paid for its set-up.  A warm one — the pipe object has decoded a .gz input of this slot with it before: a service, a folder of
                 // files, bench.py — for everything the pool would need longer for than a group takes the device (48 MiB).
                 // AQC_GZ_DEVICE_MIN=<bytes> sets the limit for both.
-                size_t dev_min = P->gz_offload_warm[f] ? (size_t)(48u << 20) : (size_t)(256u << 20);
+                size_t dev_min = P->gz_offload_warm[f] ? (size_t)(48u << 20) : (size_t)(448u << 20);
                 if (const char* m = getenv("AQC_GZ_DEVICE_MIN")) dev_min = (size_t)std::max(0ll, atoll(m));
                 struct stat gst;
                 const bool big = P->gz_offload[f] && stat(io->in_path[f], &gst) == 0 && (size_t)gst.st_size >= dev_min;
@@ -1868,6 +1895,13 @@ int aqc_pipe_create(aqc_ctx** ctxs, int32_t n_ctx, int32_t slots_per_ctx, int32_
 
 void aqc_pipe_destroy(aqc_pipe* p) {
     if (!p) return;
+    {
+        // the device decoders stay for the next pipe (g_offload_pool)
+        std::lock_guard<std::mutex> g(g_offload_mu);
+        for (int f = 0; f < 2; ++f)
+            if (p->gz_offload[f] && !p->gz_offload[f]->gave_up() && g_offload_pool.size() < 16)
+                g_offload_pool.push_back(PooledOffload{p->gz_offload_device[f], p->gz_offload_group[f], p->gz_offload_warm[f], std::move(p->gz_offload[f])});
+    }
     for (int f = 0; f < 2; ++f)
         for (auto& b : p->in_buf[f]) b.release();
     for (auto& w : p->wbufs)

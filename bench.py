@@ -634,7 +634,7 @@ def main():
             gz_before = (capi.C.c_uint64 * 4)()
             capi.load_library().aqc_gz_input_stats(capi.C.byref(gz_before))
             # (round 6: the device's share of the gunzip is the DEFAULT for inputs of this size — a decoder is started for every .gz
-            #  input of >= 256 MiB, its buffers set up in the background, markers and CRC-32 resolved on the device; no environment
+            #  input of >= 448 MiB, its buffers set up in the background, markers and CRC-32 resolved on the device; no environment
             #  override is set for the "default" runs below.  The host pool alone, AQC_GZ_DEVICE_IN=0, is timed next to it.)
             ts, ts_host = [], []
             for mode in ("host", "default"):
