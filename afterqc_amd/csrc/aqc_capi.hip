@@ -1039,6 +1039,7 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
     // streams q = file * 3 + {0 good, 1 bad, 2 overlap}: per-tile byte sums -> tile bases (one launch each), the
     // per-record offsets are formed inside the writer
     const uint64_t n_tiles = n ? (n + FMT_TILE - 1) / FMT_TILE : 1;
+    const uint64_t n_super = (n_tiles + FMT_SUPER - 1) / FMT_SUPER;
     bool live[6];
     for (int q = 0; q < 6; q++) live[q] = (q < 3 || s->paired) && (q % 3 != 2 || v.store_overlap);
     unsigned long long h_tot[FMT_STREAMS] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1059,12 +1060,14 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
     }
     if (!v.fused) {
         s->fused = false;          // (whatever this call writes into the good streams replaces what the verdict kernel left there)
-        if (s->f_tile.reserve(sizeof(unsigned long long) * FMT_STREAMS * n_tiles) || s->t_scratch.reserve(256))
+        // f_tile: [FMT_STREAMS x n_tiles] the tiles' prefixes inside their super-tiles | [FMT_STREAMS x n_super] the super-tiles' sums -> bases
+        if (s->f_tile.reserve(sizeof(unsigned long long) * FMT_STREAMS * (n_tiles + n_super)) || s->t_scratch.reserve(256))
             return fail(AQC_ERR_HIP, "hipMalloc failed");
         unsigned long long* d_tot = (unsigned long long*)((uint8_t*)s->t_scratch.p + 128);
-        HIP_TRY(hipMemsetAsync(s->f_tile.p, 0, sizeof(unsigned long long) * FMT_STREAMS * n_tiles, s->stream));
-        if (n) hipLaunchKernelGGL(fmt_tile_sums_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles, (unsigned long long*)s->f_tile.p);
-        hipLaunchKernelGGL(fmt_tile_bases_kernel, dim3(v.spans ? FMT_STREAMS : 6), dim3(TXT_BLOCK), 0, s->stream, (unsigned long long*)s->f_tile.p, n_tiles, d_tot);
+        unsigned long long* d_super = (unsigned long long*)s->f_tile.p + FMT_STREAMS * n_tiles;
+        if (n) hipLaunchKernelGGL(fmt_tile_sums_kernel, dim3((unsigned)n_super), dim3(TXT_BLOCK), 0, s->stream, v, n, n_tiles, n_super, (unsigned long long*)s->f_tile.p, d_super);
+        else HIP_TRY(hipMemsetAsync(s->f_tile.p, 0, sizeof(unsigned long long) * FMT_STREAMS * (n_tiles + n_super), s->stream));
+        hipLaunchKernelGGL(fmt_tile_bases_kernel, dim3(v.spans ? FMT_STREAMS : 6), dim3(TXT_BLOCK), 0, s->stream, d_super, n_super, d_tot);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_tot, d_tot, sizeof(unsigned long long) * (v.spans ? FMT_STREAMS : 6), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1104,20 +1107,32 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
 #endif
         for (int pass = 0; pass < (v.store_overlap ? 2 : 1); ++pass) {
             HIP_TRY(hipMemsetAsync(d_ngen, 0, 2 * sizeof(unsigned int) * GEN_LISTS, s->stream));
-            hipLaunchKernelGGL(fmt_plan_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles,
-                               (const unsigned long long*)s->f_tile.p, pass, s->status, (uint4*)s->f_plan.p, (uint4*)s->f_patch.p,
-                               (uint4*)((uint8_t*)s->f_plan.p + plan0_bytes), (FmtTask*)s->f_over.p, (uint32_t*)s->f_pos.p, d_ngen, gen_cap, d_wplan, d_nwhole, outs.p[0], outs.p[3],
-                               (SpanEvent*)s->f_events[0].p, (SpanEvent*)s->f_events[1].p);
-            // (spans / fused mode: what stays in the caller's chunk / what the verdict kernel copied has no plan; the records that are their
-            //  own bytes but for the walk's byte patches are still this kernel's)
             // GEN_LISTS x k workgroups; k from the worst case, at most 32 per list
             uint64_t per_list = (gen_cap + GEN_ROUND - 1) / GEN_ROUND;
             if (per_list > 32) per_list = 32;
             if (per_list < 1) per_list = 1;
+            // text mode without barcodes, main pass (round 6): place + copy in one kernel, piece lists only for the listed records
+            // (AQC_PLACE_COPY=0: the plan / whole-copy pair of rounds 2 - 5, for A/B measurements)
+            static const bool place_copy = [] { const char* e = getenv("AQC_PLACE_COPY"); return !(e && e[0] == '0'); }();
+            if (place_copy && !sparse && pass == 0 && !v.plain && !v.barcode) {
+                const unsigned long long* tb = (const unsigned long long*)s->f_tile.p;
+                uint4* const pg = (uint4*)((uint8_t*)s->f_plan.p + plan0_bytes);
+                hipLaunchKernelGGL(fmt_place_copy_kernel, dim3((unsigned)n_tiles), dim3(PC_BLOCK), 0, s->stream, v, n, n_tiles, n_super, tb, tb + FMT_STREAMS * n_tiles,
+                                   pg, (uint32_t*)s->f_pos.p, d_ngen, gen_cap, outs);
+                hipLaunchKernelGGL(fmt_plan_listed_kernel, dim3((unsigned)(GEN_LISTS * per_list)), dim3(FMT_TILE), 0, s->stream, v, pg, (FmtTask*)s->f_over.p,
+                                   (const uint32_t*)s->f_pos.p, (const unsigned int*)d_ngen, gen_cap, s->status);
+            } else {
+            hipLaunchKernelGGL(fmt_plan_kernel, dim3((unsigned)n_tiles), dim3(FMT_TILE), 0, s->stream, v, n, n_tiles, n_super,
+                               (const unsigned long long*)s->f_tile.p, (const unsigned long long*)s->f_tile.p + FMT_STREAMS * n_tiles, pass, s->status, (uint4*)s->f_plan.p, (uint4*)s->f_patch.p,
+                               (uint4*)((uint8_t*)s->f_plan.p + plan0_bytes), (FmtTask*)s->f_over.p, (uint32_t*)s->f_pos.p, d_ngen, gen_cap, d_wplan, d_nwhole, outs.p[0], outs.p[3],
+                               (SpanEvent*)s->f_events[0].p, (SpanEvent*)s->f_events[1].p);
+            // (spans / fused mode: what stays in the caller's chunk / what the verdict kernel copied has no plan; the records that are their
+            //  own bytes but for the walk's byte patches are still this kernel's)
             if (!sparse) hipLaunchKernelGGL(fmt_copy_whole_kernel, dim3(copy_blocks), dim3(COPY_BLOCK), 0, s->stream, v, n_tasks, (const uint4*)s->f_plan.p,
                                             (const uint4*)s->f_patch.p, outs);
             else hipLaunchKernelGGL(fmt_copy_whole_list_kernel, dim3((unsigned)(GEN_LISTS * per_list)), dim3(COPY_BLOCK), 0, s->stream, v, (const uint4*)d_wplan, outs,
                                     (const unsigned int*)d_nwhole, gen_cap);
+            }
             hipLaunchKernelGGL(fmt_copy_kernel, dim3((unsigned)(GEN_LISTS * per_list)), dim3(COPY_BLOCK), 0, s->stream, v,
                                (const uint4*)((uint8_t*)s->f_plan.p + plan0_bytes), (const FmtTask*)s->f_over.p, outs, (const uint32_t*)s->f_pos.p,
                                (const unsigned int*)d_ngen, gen_cap);

@@ -16,6 +16,7 @@
 
 #include "afterqc_hip.h"
 #include "aqc_kernels.hpp"
+#include "aqc_fast.hpp"      // the DPP wave sums / scans
 
 namespace aqc {
 
@@ -695,33 +696,63 @@ __device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int f
     }
 }
 
-constexpr int FMT_TILE = 128;           // records per workgroup (one thread per record in the sizing phase)
+constexpr int FMT_TILE = 128;           // records per workgroup of the plan pass (one thread per record)
+constexpr int FMT_SUPER = 8;            // tiles per workgroup of the sizing pass = per entry of the second-level scan
 constexpr int FMT_STREAMS = 8;          // file * 3 + {good, bad, overlap}, then (spans mode) the two files' event counts
 constexpr int FMT_EVENT_STREAM = 6;
 
-// per-tile byte sums of the six streams (file * 3 + stream): tile_sum[q * n_tiles + tile]
-__global__ __launch_bounds__(FMT_TILE) void fmt_tile_sums_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
-                                                                 unsigned long long* __restrict__ tile_sum) {
-    __shared__ unsigned long long lds[4];
-    const uint64_t r = (uint64_t)blockIdx.x * FMT_TILE + threadIdx.x;
+// Sizing pass (round 6: one workgroup per FMT_SUPER tiles, wave sums through DPP, no scans).  A wave takes the 64 records of half a
+// tile; what it leaves behind, per stream q = file * 3 + stream:
+//     tile_sum[q * n_tiles + tile]   the bytes of the tiles BEFORE this one inside its super-tile (a prefix the plan pass adds to ...)
+//     super_sum[q * n_super + s]     ... the bytes of super-tile s, turned into the bytes before it by fmt_tile_bases_kernel
+// (rounds 2 - 5: a workgroup of 128 threads per tile, four block scans of two barriers each to get four sums — 78 k workgroups and
+//  0.26 ms per 10 M reads for 0.1 GB of input; the scan over all 78 k tile sums per stream, six workgroups, was another 0.11 ms)
+__global__ __launch_bounds__(TXT_BLOCK) void fmt_tile_sums_kernel(FormatView v, uint64_t n, uint64_t n_tiles, uint64_t n_super,
+                                                                  unsigned long long* __restrict__ tile_sum, unsigned long long* __restrict__ super_sum) {
+    constexpr int HALVES = FMT_SUPER * FMT_TILE / WAVE;                   // waves' worth of records per super-tile
+    constexpr int ROUNDS = FMT_SUPER * FMT_TILE / TXT_BLOCK;
+    static_assert(FMT_TILE == 2 * WAVE && HALVES * WAVE == ROUNDS * TXT_BLOCK, "a tile is two waves' records");
+    __shared__ uint32_t part[HALVES][FMT_STREAMS];
+    const int lane = lane_id(), wave = threadIdx.x / WAVE;
     const int nfiles = v.paired ? 2 : 1;
-    for (int file = 0; file < nfiles; ++file) {
-        uint32_t sz[3] = {0, 0, 0}, ev = 0;
-        if (r < n) fmt_sizes(v, r, file, sz, ev);
-        for (int st = 0; st < (v.store_overlap ? 3 : 2); ++st) {
-            unsigned long long total;
-            (void)block_excl_scan((unsigned long long)sz[st], lds, total);
-            if (threadIdx.x == 0) tile_sum[(uint64_t)(file * 3 + st) * n_tiles + blockIdx.x] = total;
+    for (int i = threadIdx.x; i < HALVES * FMT_STREAMS; i += TXT_BLOCK) (&part[0][0])[i] = 0u;
+    __syncthreads();
+    const uint64_t r0 = (uint64_t)blockIdx.x * (FMT_SUPER * FMT_TILE);
+#pragma unroll 1
+    for (int it = 0; it < ROUNDS; ++it) {
+        const uint64_t r = r0 + (uint64_t)it * TXT_BLOCK + threadIdx.x;
+        const int half = it * (TXT_BLOCK / WAVE) + wave;
+        if (r0 + (uint64_t)half * WAVE >= n) break;                      // (wave-uniform: nothing of this wave's records exists)
+        for (int file = 0; file < nfiles; ++file) {
+            uint32_t sz[3] = {0, 0, 0}, ev = 0;
+            if (r < n) fmt_sizes(v, r, file, sz, ev);
+            // (a record is < 64 KiB, a wave's sum < 4 MiB: int arithmetic; all 64 lanes are here)
+            const int g = wave_sum_u((int)sz[0]), b = wave_sum_u((int)sz[1]);
+            if (lane == 0) { part[half][file * 3 + 0] = (uint32_t)g; part[half][file * 3 + 1] = (uint32_t)b; }
+            if (v.store_overlap) {
+                const int o = wave_sum_u((int)sz[2]);
+                if (lane == 0) part[half][file * 3 + 2] = (uint32_t)o;
+            }
+            if (v.spans) {                                               // streams 6, 7: the files' event counts
+                const int e = wave_sum_u((int)ev);
+                if (lane == 0) part[half][FMT_EVENT_STREAM + file] = (uint32_t)e;
+            }
         }
-        if (v.spans) {                                      // streams 6, 7: the files' event counts
-            unsigned long long total;
-            (void)block_excl_scan((unsigned long long)ev, lds, total);
-            if (threadIdx.x == 0) tile_sum[(uint64_t)(FMT_EVENT_STREAM + file) * n_tiles + blockIdx.x] = total;
+    }
+    __syncthreads();
+    if (threadIdx.x < FMT_STREAMS) {
+        const int q = threadIdx.x;
+        unsigned long long run = 0;
+        for (int t = 0; t < FMT_SUPER; ++t) {
+            const uint64_t tile = (uint64_t)blockIdx.x * FMT_SUPER + t;
+            if (tile < n_tiles) tile_sum[(uint64_t)q * n_tiles + tile] = run;
+            run += (unsigned long long)part[2 * t][q] + part[2 * t + 1][q];
         }
+        super_sum[(uint64_t)q * n_super + blockIdx.x] = run;
     }
 }
 
-// exclusive scan of each stream's tile sums (workgroup q handles stream q, eight tiles per thread per round); totals to total_out[q]
+// exclusive scan of each stream's super-tile sums (workgroup q handles stream q, eight entries per thread per round); totals to total_out[q]
 __global__ __launch_bounds__(TXT_BLOCK) void fmt_tile_bases_kernel(unsigned long long* __restrict__ tile_sum, uint64_t n_tiles,
                                                                    unsigned long long* __restrict__ total_out) {
     __shared__ unsigned long long lds[4];
@@ -932,17 +963,75 @@ __device__ __forceinline__ bool plan_is_whole(const uint4& q0) {
     return (q0.y & 0xff00ff00u) == 0x100u && ((q0.y >> 16) & 0xffu) <= 4u && !(q0.z & FMT_LIT_BIT) && (q0.w & 0xffffu) >= 16u && (q0.w & 0xffffu) <= 512u;
 }
 
-__global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64_t n, uint64_t n_tiles,
-                                                            const unsigned long long* __restrict__ tile_base, int overlap_pass,
+// the six plan words of a record's piece list `t` placed at `pos` of its stream (layout: above); false: the record does not fit a
+// plan — more than eight pieces, four patches or 64 work items, or a patch inside a piece of < 16 bytes — q[0] then says PLAN_OVER
+// and the caller keeps the full FmtTask in the overflow array
+struct PlanWords { uint4 q0, q1, q2, q3, q4, q5; bool inline_ok; };
+__device__ __forceinline__ PlanWords plan_words(const FmtTask& t, uint32_t pos) {
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    uint4 q0 = zero4, q1 = zero4, q2 = zero4, q3 = zero4, q4 = zero4, q5 = zero4;
+    // inline: up to eight pieces, four byte patches (each inside a piece of >= 16 bytes), 64 work items (1 KiB)
+    bool inline_ok = t.np <= PLAN_MAXP && t.n_patch <= 4 && t.items <= 32 * GEN_PASSES;
+    for (int e = 0; e < (int)t.n_patch && inline_ok; ++e) {
+        const int pp = (int)(t.patch[e] & 0xffffu);
+        int o = 0;
+        for (int k = 0; k < (int)t.np; ++k) {
+            if (pp >= o && pp < o + (int)t.p[k].len && t.p[k].len < 16) inline_ok = false;
+            o += t.p[k].len;
+        }
+    }
+    if (inline_ok) {
+        uint32_t src[PLAN_MAXP], len[PLAN_MAXP], cum[PLAN_MAXP], off[PLAN_MAXP];
+        uint32_t ci = 0, doff = 0;
+        for (int k = 0; k < PLAN_MAXP; ++k) {
+            const bool in = k < (int)t.np;
+            src[k] = in ? t.p[k].src : 0u;
+            len[k] = in ? (uint32_t)t.p[k].len : 0u;
+            off[k] = doff;
+            ci += len[k] >= 16 ? (len[k] + 15) >> 4 : (len[k] > 0 ? 1u : 0u);
+            cum[k] = ci;
+            doff += len[k];
+        }
+        q0 = make_uint4(pos, (uint32_t)t.stream | ((uint32_t)t.np << 8) | ((uint32_t)t.n_patch << 16), src[0], len[0] | (len[1] << 16));
+        q1 = make_uint4(src[1], src[2], src[3], src[4]);
+        q2 = make_uint4(src[5], src[6], src[7], len[2] | (len[3] << 16));
+        q3 = make_uint4(len[4] | (len[5] << 16), len[6] | (len[7] << 16), cum[0] | (cum[1] << 8) | (cum[2] << 16) | (cum[3] << 24),
+                          cum[4] | (cum[5] << 8) | (cum[6] << 16) | (cum[7] << 24));
+        q4 = make_uint4(off[1] | (off[2] << 16), off[3] | (off[4] << 16), off[5] | (off[6] << 16), off[7] | (ci << 16));
+        q5 = make_uint4(t.n_patch > 0 ? t.patch[0] : 0u, t.n_patch > 1 ? t.patch[1] : 0u, t.n_patch > 2 ? t.patch[2] : 0u,
+                          t.n_patch > 3 ? t.patch[3] : 0u);
+    } else q0 = make_uint4(pos, PLAN_OVER | (uint32_t)t.stream, 0, 0);
+    return PlanWords{q0, q1, q2, q3, q4, q5, inline_ok};
+}
+
+// exclusive prefixes of two values per thread over the FMT_TILE threads of a plan workgroup (two waves): DPP lane scans, the other
+// wave's totals through LDS (`lds`: 2 x 2 words of its own per call site — one barrier, none for reuse)
+__device__ __forceinline__ void tile_excl_scan2(uint32_t a, uint32_t b, uint32_t (*lds)[2], uint32_t& ea, uint32_t& eb) {
+    static_assert(FMT_TILE == 2 * WAVE, "two waves per plan workgroup");
+    const int lane = lane_id(), wave = threadIdx.x / WAVE;
+    const int ia = wave_incl_sum((int)a, lane), ib = wave_incl_sum((int)b, lane);
+    if (lane == WAVE - 1) { lds[wave][0] = (uint32_t)ia; lds[wave][1] = (uint32_t)ib; }
+    __syncthreads();
+    ea = (uint32_t)ia - a + (wave ? lds[0][0] : 0u);
+    eb = (uint32_t)ib - b + (wave ? lds[0][1] : 0u);
+}
+
+__global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64_t n, uint64_t n_tiles, uint64_t n_super,
+                                                            const unsigned long long* __restrict__ tile_base, const unsigned long long* __restrict__ super_base, int overlap_pass,
                                                             int* __restrict__ status, uint4* __restrict__ plan0, uint4* __restrict__ plan_patch, uint4* __restrict__ plan_gen,
                                                             FmtTask* __restrict__ over, uint32_t* __restrict__ gen_list,
                                                             unsigned int* __restrict__ n_gen, uint64_t gen_cap,
                                                             uint4* __restrict__ whole_plan, unsigned int* __restrict__ n_whole, uint8_t* __restrict__ good0, uint8_t* __restrict__ good1,
                                                             SpanEvent* __restrict__ events0, SpanEvent* __restrict__ events1) {
     __shared__ unsigned long long lds[4];
+    __shared__ uint32_t lds2[2][2][2];          // [file][wave][good, bad]: tile_excl_scan2
     __shared__ FmtTask tasks[FMT_TILE];
     const int nfiles = v.paired ? 2 : 1;
     const uint64_t r = (uint64_t)blockIdx.x * FMT_TILE + threadIdx.x;
+    // bytes of stream q before this tile: the super-tiles before (fmt_tile_bases_kernel) + the tiles before inside the super-tile
+    auto base_of = [&](int q) -> unsigned long long {
+        return super_base[(uint64_t)q * n_super + blockIdx.x / FMT_SUPER] + tile_base[(uint64_t)q * n_tiles + blockIdx.x];
+    };
     for (int file = 0; file < nfiles; ++file) {
         FmtTask& t = tasks[threadIdx.x];
         t.stream = 0xff;
@@ -968,14 +1057,13 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
                 const uint32_t a = tf.name_off[r];
                 const uint32_t b = r + 1 < v.n_framed ? tf.name_off[r + 1] : v.consumed[file];
                 SpanEvent* const ev = file == 0 ? events0 : events1;
-                ev[tile_base[(uint64_t)(FMT_EVENT_STREAM + file) * n_tiles + blockIdx.x] + ee] = SpanEvent{a, b - a, t.stream == 0 ? (uint32_t)t.total : 0u};
+                ev[base_of(FMT_EVENT_STREAM + file) + ee] = SpanEvent{a, b - a, t.stream == 0 ? (uint32_t)t.total : 0u};
             }
         }
         unsigned int pos;
         bool general = false, listed_whole = false;
-        uint4 q[PLAN_Q];
-#pragma unroll
-        for (int k = 0; k < PLAN_Q; ++k) q[k] = make_uint4(0, 0, 0, 0);
+        const uint4 zero4 = make_uint4(0, 0, 0, 0);
+        uint4 q0 = zero4, q1 = zero4, q2 = zero4, q3 = zero4, q4 = zero4, q5 = zero4;      // (named, not an array: an array of them ended up in scratch)
         if (v.fused) {
             // (placed by the verdict kernel: no scans, no tile bases)
             pos = 0u;
@@ -992,68 +1080,34 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
             }
         } else if (!overlap_pass) {
             // good and bad records interleave: two scans, each record keeps the offset of the stream it goes to
-            unsigned long long tg, tb;
-            const unsigned long long eg = block_excl_scan((unsigned long long)sz[0], lds, tg);
-            const unsigned long long eb = block_excl_scan((unsigned long long)sz[1], lds, tb);
-            const unsigned long long bg = tile_base[(uint64_t)(file * 3 + 0) * n_tiles + blockIdx.x];
-            const unsigned long long bb = tile_base[(uint64_t)(file * 3 + 1) * n_tiles + blockIdx.x];
-            pos = sz[1] ? (unsigned int)(bb + eb) : (unsigned int)(bg + eg);      // (offsets inside a chunk's stream fit 32 bits)
+            uint32_t eg, eb;
+            tile_excl_scan2(sz[0], sz[1], lds2[file], eg, eb);
+            pos = sz[1] ? (unsigned int)(base_of(file * 3 + 1) + eb) : (unsigned int)(base_of(file * 3 + 0) + eg);      // (offsets inside a chunk's stream fit 32 bits)
         } else {
             unsigned long long to;
             const unsigned long long eo = block_excl_scan((unsigned long long)sz[2], lds, to);
-            pos = (unsigned int)(tile_base[(uint64_t)(file * 3 + 2) * n_tiles + blockIdx.x] + eo);
+            pos = (unsigned int)(base_of(file * 3 + 2) + eo);
         }
         if (r < n) {
             const uint64_t ti = r * nfiles + file;
-            q[0] = make_uint4(pos, PLAN_SKIP, 0, 0);
+            q0 = make_uint4(pos, PLAN_SKIP, 0, 0);
             if (t.stream != 0xff) {
                 t.pos = pos;
-                // inline: up to eight pieces, four byte patches (each inside a piece of >= 16 bytes), 64 work items (1 KiB)
-                bool inline_ok = t.np <= PLAN_MAXP && t.n_patch <= 4 && t.items <= 32 * GEN_PASSES;
-                for (int e = 0; e < (int)t.n_patch && inline_ok; ++e) {
-                    const int pp = (int)(t.patch[e] & 0xffffu);
-                    int o = 0;
-                    for (int k = 0; k < (int)t.np; ++k) {
-                        if (pp >= o && pp < o + (int)t.p[k].len && t.p[k].len < 16) inline_ok = false;
-                        o += t.p[k].len;
-                    }
-                }
-                if (inline_ok) {
-                    uint32_t src[PLAN_MAXP], len[PLAN_MAXP], cum[PLAN_MAXP], off[PLAN_MAXP];
-                    uint32_t ci = 0, doff = 0;
-                    for (int k = 0; k < PLAN_MAXP; ++k) {
-                        const bool in = k < (int)t.np;
-                        src[k] = in ? t.p[k].src : 0u;
-                        len[k] = in ? (uint32_t)t.p[k].len : 0u;
-                        off[k] = doff;
-                        ci += len[k] >= 16 ? (len[k] + 15) >> 4 : (len[k] > 0 ? 1u : 0u);
-                        cum[k] = ci;
-                        doff += len[k];
-                    }
-                    q[0] = make_uint4(pos, (uint32_t)t.stream | ((uint32_t)t.np << 8) | ((uint32_t)t.n_patch << 16), src[0], len[0] | (len[1] << 16));
-                    q[1] = make_uint4(src[1], src[2], src[3], src[4]);
-                    q[2] = make_uint4(src[5], src[6], src[7], len[2] | (len[3] << 16));
-                    q[3] = make_uint4(len[4] | (len[5] << 16), len[6] | (len[7] << 16), cum[0] | (cum[1] << 8) | (cum[2] << 16) | (cum[3] << 24),
-                                      cum[4] | (cum[5] << 8) | (cum[6] << 16) | (cum[7] << 24));
-                    q[4] = make_uint4(off[1] | (off[2] << 16), off[3] | (off[4] << 16), off[5] | (off[6] << 16), off[7] | (ci << 16));
-                    q[5] = make_uint4(t.n_patch > 0 ? t.patch[0] : 0u, t.n_patch > 1 ? t.patch[1] : 0u, t.n_patch > 2 ? t.patch[2] : 0u,
-                                      t.n_patch > 3 ? t.patch[3] : 0u);
-                } else {
-                    q[0].y = PLAN_OVER | (uint32_t)t.stream;
-                    over[ti] = t;
-                }
+                const PlanWords pw = plan_words(t, pos);
+                q0 = pw.q0; q1 = pw.q1; q2 = pw.q2; q3 = pw.q3; q4 = pw.q4; q5 = pw.q5;
+                if (!pw.inline_ok) over[ti] = t;
             }
             // (spans / fused mode: the records that stay where they are / that the verdict kernel copied have no plan: PLAN_SKIP)
             // Text mode: nearly every record is one piece — fmt_copy_whole_kernel walks the dense plan0.  Spans / fused mode: few
             // are left (the pairs the walk edited) — their plans are LISTED (q0 with the file in bit 24 | the patches) and
             // fmt_copy_whole_list_kernel walks the lists (a dense walk over 10 M mostly empty plans cost 0.8 ms).
-            const bool whole = plan_is_whole(q[0]);
+            const bool whole = plan_is_whole(q0);
             const bool sparse = v.spans || v.fused;
             if (!sparse) {
-                plan0[ti] = q[0];
-                if (whole && (q[0].y & 0x00ff0000u)) plan_patch[ti] = q[5];        // (written and read for the patched records only)
+                plan0[ti] = q0;
+                if (whole && (q0.y & 0x00ff0000u)) plan_patch[ti] = q5;        // (written and read for the patched records only)
             }
-            general = q[0].y != PLAN_SKIP && !whole;
+            general = q0.y != PLAN_SKIP && !whole;
             listed_whole = sparse && whole;
         }
         // the records fmt_copy_whole_kernel does not take are listed (one atomic per wave) for the general copy kernel
@@ -1070,8 +1124,8 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
                     // the general kernel reads its plans in list order: all six words go where the record is listed
                     const uint64_t slot = (uint64_t)lj * gen_cap + base + (unsigned int)__popcll(gm & ((1ull << lane_id()) - 1ull));
                     gen_list[slot] = (uint32_t)(r * nfiles + file);
-#pragma unroll
-                    for (int k = 0; k < PLAN_Q; ++k) plan_gen[slot * PLAN_Q + k] = q[k];
+                    uint4* const pg = plan_gen + slot * PLAN_Q;
+                    pg[0] = q0; pg[1] = q1; pg[2] = q2; pg[3] = q3; pg[4] = q4; pg[5] = q5;
                 }
             }
         }
@@ -1084,8 +1138,8 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
                 base = (unsigned int)__shfl((int)base, 0, WAVE);
                 if (listed_whole) {
                     const uint64_t slot = (uint64_t)lj * gen_cap + base + (unsigned int)__popcll(wm & ((1ull << lane_id()) - 1ull));
-                    whole_plan[2 * slot] = make_uint4(q[0].x, q[0].y | ((uint32_t)file << 24), q[0].z, q[0].w);
-                    whole_plan[2 * slot + 1] = q[5];
+                    whole_plan[2 * slot] = make_uint4(q0.x, q0.y | ((uint32_t)file << 24), q0.z, q0.w);
+                    whole_plan[2 * slot + 1] = q5;
                 }
             }
         }
@@ -1375,6 +1429,165 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
                 }
             }
         }
+    }
+}
+
+// ---- round 6: the text mode's default writer — place + copy in one kernel, piece lists only for the records that need them ------
+// (rounds 2 - 5: fmt_plan_kernel built the piece list of EVERY record — fmt_build, a 116-byte task in LDS, six plan words — wrote a
+//  16-byte plan per record and file to HBM, and fmt_copy_whole_kernel read it back: 0.31 + 2.06 ms and 0.64 GB of plan traffic per
+//  10 M reads, although 97 % of the records of a run without trimming go out as their own bytes.)
+// A workgroup takes a tile of FMT_TILE records, thread = (record, file):
+//   1. the record's bytes in its streams (fmt_sizes — the sizing pass's routine, so the two agree by construction), two DPP scans
+//      per file, the tile's bases -> the record's place;
+//   2. a good record that is its own bytes (record_is_whole's conditions, but edits of the walk in this mate become <= 4 byte
+//      patches): its plan word (+ patch word) stays in LDS;  every other record is LISTED for fmt_plan_listed_kernel with its place;
+//   3. the workgroup copies its own-bytes records: 32 lanes per record, four records in flight per half-wave (copy_whole_tasks).
+// fmt_plan_listed_kernel then builds the piece lists / plans of the listed records only (thread = list entry), fmt_copy_kernel
+// copies them as before.  Barcode runs (every name rewritten), index files, the overlap pass, spans and fused formats keep
+// fmt_plan_kernel.
+__device__ __forceinline__ int own_bytes_patches(const uint4& w0, const uint4& w1, int file, int len, int seq_dst, int qual_dst, uint32_t (&patch)[6]) {
+    // fmt_build's edit loop for a record whose quality line is as long as its sequence line, written from base 0 (cut == 0)
+    const int n_edits = (int)((w0.x >> 8) & 0xffu);
+    const int len1 = (int)(w0.y & 0xffffu), len2 = (int)(w0.z & 0xffffu), ovl = (int)(w0.w & 0xffffu);
+    const unsigned long long e_lo = ((unsigned long long)w1.y << 32) | w1.x, e_hi = ((unsigned long long)w1.w << 32) | w1.z;
+    int np = 0;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        if (e >= n_edits) break;
+        const int bit = 40 * e;
+        unsigned long long x = bit < 64 ? e_lo >> bit : 0ull;
+        if (bit + 40 > 64) x |= bit < 64 ? e_hi << (64 - bit) : e_hi >> (bit - 64);
+        const int oo = (int)(x & 0xffffu);
+        const uint32_t kind = (uint32_t)(x >> 16) & 0xffu, base = (uint32_t)(x >> 24) & 0xffu, qual = (uint32_t)(x >> 32) & 0xffu;
+        const int pp = file == 0 ? len1 - ovl + oo : len2 - 1 - oo;
+        if (pp < 0 || pp >= len) continue;
+        if (kind == AQC_EDIT_MASK) patch[np++] = (uint32_t)(qual_dst + pp) | ((uint32_t)'!' << 16);
+        else if ((kind == AQC_EDIT_FIX_R1 && file == 0) || (kind == AQC_EDIT_FIX_R2 && file == 1)) {
+            if (base) patch[np++] = (uint32_t)(seq_dst + pp) | (base << 16);
+            patch[np++] = (uint32_t)(qual_dst + pp) | (qual << 16);
+        }
+    }
+    return np;
+}
+
+constexpr int PC_BLOCK = 2 * FMT_TILE;       // thread = (record of the tile, file)
+static_assert(PC_BLOCK == COPY_BLOCK, "the copy phase is fmt_copy_whole_kernel's");
+
+__global__ __launch_bounds__(PC_BLOCK) void fmt_place_copy_kernel(FormatView v, uint64_t n, uint64_t n_tiles, uint64_t n_super,
+                                                                   const unsigned long long* __restrict__ tile_base, const unsigned long long* __restrict__ super_base,
+                                                                   uint4* __restrict__ plan_gen, uint32_t* __restrict__ gen_list, unsigned int* __restrict__ n_gen,
+                                                                   uint64_t gen_cap, FormatOut outs) {
+    __shared__ uint4 s_q0[PC_BLOCK], s_q5[PC_BLOCK];
+    __shared__ uint32_t s_tot[PC_BLOCK / WAVE][2];
+    const int nfiles = v.paired ? 2 : 1;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    const int file = wave >> 1;                                           // waves 0, 1: the tile's records of file 0; waves 2, 3: of file 1
+    const uint64_t r = (uint64_t)blockIdx.x * FMT_TILE + (threadIdx.x & (FMT_TILE - 1));
+    const bool have = file < nfiles && r < n;
+    uint32_t sz[3] = {0, 0, 0}, ev = 0;
+    uint4 q0 = make_uint4(0, PLAN_SKIP, 0, 0), q5 = make_uint4(0, 0, 0, 0);
+    bool own = false;
+    uint32_t own_src = 0, n_patch = 0;
+    if (have) {
+        fmt_sizes(v, r, file, sz, ev);
+        const TextFile& tf = v.f[file];
+        const uint4 w0 = *reinterpret_cast<const uint4*>(v.results + r);
+        const uint32_t slw = tf.seq_len[r];
+        const uint32_t st = file == 0 ? (w0.x >> 16) : (w0.y >> 16), len = file == 0 ? (w0.y & 0xffffu) : (w0.z & 0xffffu);
+        // its own bytes: good, the whole read (a mate marked LEN_IRR never equals its length word), every line followed directly by
+        // its '\n' — then sz[0] = name + bases + strand line + qualities + 4 is the distance from its name to behind its last '\n'
+        if ((int)(w0.x & 0xffu) == AQC_GOOD && st == 0u && len == slw && (tf.qual_len[r] & QLEN_CONTIG) && sz[0] >= 16u && sz[0] <= 512u) {
+            own = true;
+            own_src = tf.name_off[r];
+            if ((w0.x >> 8) & 0xffu) {
+                const uint4 w1 = *(reinterpret_cast<const uint4*>(v.results + r) + 1);
+                const int nlen = (int)tf.name_len[r], plen = (int)(tf.plus_len[r] & LEN_MASK);
+                uint32_t patch[6] = {0, 0, 0, 0, 0, 0};
+                n_patch = (uint32_t)own_bytes_patches(w0, w1, file, (int)len, nlen + 1, nlen + 1 + (int)len + 1 + plen + 1, patch);
+                q5 = make_uint4(patch[0], patch[1], patch[2], patch[3]);
+                own = n_patch <= 4u;                                      // (three corrections in one mate: the general kernel's overflow path)
+            }
+        }
+    }
+    // the record's place: exclusive prefixes over the tile's records of this file (two waves), good and bad apart
+    const int ig = wave_incl_sum((int)sz[0], lane), ib = wave_incl_sum((int)sz[1], lane);
+    if (lane == WAVE - 1) { s_tot[wave][0] = (uint32_t)ig; s_tot[wave][1] = (uint32_t)ib; }
+    __syncthreads();
+    uint32_t pos = 0;
+    if (have) {
+        const int q = file * 3 + (sz[1] ? 1 : 0);
+        const unsigned long long base = super_base[(uint64_t)q * n_super + blockIdx.x / FMT_SUPER] + tile_base[(uint64_t)q * n_tiles + blockIdx.x];
+        const uint32_t ex = sz[1] ? (uint32_t)ib - sz[1] + ((wave & 1) ? s_tot[wave - 1][1] : 0u) : (uint32_t)ig - sz[0] + ((wave & 1) ? s_tot[wave - 1][0] : 0u);
+        pos = (uint32_t)(base + ex);                                      // (offsets inside a chunk's stream fit 32 bits)
+        if (own) q0 = make_uint4(pos, 0x100u | (n_patch << 16), own_src, sz[0]);      // stream 0, one piece: what fmt_build + plan_words make of it
+    }
+    s_q0[threadIdx.x] = q0;
+    s_q5[threadIdx.x] = q5;
+    // everything else is listed for fmt_plan_listed_kernel, with its place (one atomic per wave; the lists: see fmt_plan_kernel)
+    {
+        const bool general = have && !own;
+        const unsigned long long gm = __ballot(general);
+        if (gm) {
+            unsigned int b0 = 0;
+            const unsigned int lj = blockIdx.x % GEN_LISTS;
+            if (lane == 0) b0 = atomicAdd(&n_gen[lj], (unsigned int)__popcll(gm));
+            b0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)b0);
+            if (general) {
+                const uint64_t slot = (uint64_t)lj * gen_cap + b0 + (unsigned int)__popcll(gm & ((1ull << lane) - 1ull));
+                gen_list[slot] = (uint32_t)(r * nfiles + file);
+                plan_gen[slot * PLAN_Q] = make_uint4(pos, PLAN_SKIP, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    // the copy: a half-wave per record, FMT_UNROLL records in flight, plans and patch words from LDS
+    const int lane32 = threadIdx.x & 31, hwi = threadIdx.x >> 5;
+    const int n_plans = nfiles * FMT_TILE;
+    constexpr int PER_ROUND = (PC_BLOCK / 32) * FMT_UNROLL;
+#pragma unroll 1
+    for (int p0 = 0; p0 < n_plans; p0 += PER_ROUND) {
+        uint4 pa[FMT_UNROLL];
+        int file_of[FMT_UNROLL];
+        const uint4* pq[FMT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FMT_UNROLL; ++u) {
+            const int p = p0 + hwi * FMT_UNROLL + u;                      // (< PC_BLOCK: a single-end tile's upper half says PLAN_SKIP)
+            pa[u] = s_q0[p];
+            file_of[u] = p / FMT_TILE;
+            pq[u] = &s_q5[p];
+        }
+        copy_whole_tasks(v, pa, file_of, pq, outs, lane32);
+    }
+}
+
+// the piece lists and plans of the records fmt_place_copy_kernel listed: workgroup b works on list b % GEN_LISTS, thread = entry
+__global__ __launch_bounds__(FMT_TILE) void fmt_plan_listed_kernel(FormatView v, uint4* __restrict__ plan_gen, FmtTask* __restrict__ over,
+                                                                   const uint32_t* __restrict__ gen_lists, const unsigned int* __restrict__ n_gen,
+                                                                   uint64_t gen_cap, int* __restrict__ status) {
+    __shared__ FmtTask tasks[FMT_TILE];
+    const int nfiles = v.paired ? 2 : 1;
+    const unsigned int lj = blockIdx.x % GEN_LISTS;
+    const uint32_t n_list = n_gen[lj];
+    const uint32_t stride = (gridDim.x / GEN_LISTS) * FMT_TILE;
+    FmtTask& t = tasks[threadIdx.x];
+    for (uint32_t i = (blockIdx.x / GEN_LISTS) * FMT_TILE + threadIdx.x; i < n_list; i += stride) {
+        const uint64_t slot = (uint64_t)lj * gen_cap + i;
+        const uint64_t ti = gen_lists[slot];
+        const uint32_t pos = plan_gen[slot * PLAN_Q].x;
+        const uint64_t r = nfiles == 2 ? ti >> 1 : ti;
+        const int file = nfiles == 2 ? (int)(ti & 1) : 0;
+        fmt_build(v, r, file, 0, t, status);
+        const uint4 zero4 = make_uint4(0, 0, 0, 0);
+        uint4 q0 = make_uint4(pos, PLAN_SKIP, 0, 0), q1 = zero4, q2 = zero4, q3 = zero4, q4 = zero4, q5 = zero4;
+        if (t.stream != 0xff) {
+            t.pos = pos;
+            const PlanWords pw = plan_words(t, pos);
+            q0 = pw.q0; q1 = pw.q1; q2 = pw.q2; q3 = pw.q3; q4 = pw.q4; q5 = pw.q5;
+            if (!pw.inline_ok) over[ti] = t;
+        }
+        uint4* const pg = plan_gen + slot * PLAN_Q;
+        pg[0] = q0; pg[1] = q1; pg[2] = q2; pg[3] = q3; pg[4] = q4; pg[5] = q5;
     }
 }
 
