@@ -324,7 +324,8 @@ struct WaveLds {
     uint8_t *rs1, *rs2;                // 2 x 64 bytes (barcode readStart strings)
 };
 
-__device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, const aqc_config& cfg, const DevCircles& circ,
+template <class Cfg>      // aqc_config, or aqc_config in the kernarg segment (address space 4: its fields are scalar loads where they are used)
+__device__ __forceinline__ void process_record_wave(const DevBatch& b, uint64_t rec, const Cfg& cfg, const DevCircles& circ,
                                            const WaveLds& w, aqc_result* __restrict__ results, BlockAcc& acc,
                                            const DevStats& st, bool accum) {
     const int lane = lane_id();
@@ -366,11 +367,19 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
         int flag = -1;
         int offset = 0, ovl = 0, dist = 0, n_edits = 0;
         uint8_t bcode = 0;
-        aqc_edit edits[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         // counters this record contributes (wave-uniform values, committed by lane 0)
         int c_adapter_base = 0, c_adapter_read = 0, c_overlapped = 0, c_corrected = 0, c_masked = 0, c_skipped = 0;
         int c_read_corrected = 0, ovl0 = -1, dist_final = -1;
         int em[3] = {-1, -1, -1};
+        // (written through constant indices only, so that both arrays stay in registers: indexed by n_edits / handled they lived in
+        //  20 bytes of scratch — round 5 review)
+        unsigned long long ed0 = 0, ed1 = 0, ed2 = 0;      // o | kind << 16 | base << 24 | qual << 32
+        auto put_edit = [&](int k, const aqc_edit& e) {
+            const unsigned long long x = (unsigned long long)e.o | ((unsigned long long)e.kind << 16) | ((unsigned long long)e.base << 24) | ((unsigned long long)e.qual << 32);
+            ed0 = k == 0 ? x : ed0; ed1 = k == 1 ? x : ed1; ed2 = k >= 2 ? x : ed2;
+        };
+        auto get_edit = [](unsigned long long x) { return aqc_edit{(uint16_t)(x & 0xffffu), (uint8_t)(x >> 16), (uint8_t)(x >> 24), (uint8_t)(x >> 32)}; };
+        auto put_em = [&](int k, int val) { em[0] = k == 0 ? val : em[0]; em[1] = k == 1 ? val : em[1]; em[2] = k >= 2 ? val : em[2]; };
 
         // ---- barcode (preprocesser.py:436-452)
         if (cfg.barcode) {
@@ -496,11 +505,11 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
                                     if (bA != 'N' && bB != 'N') {
                                         const int i0 = base_idx(cA), ix = base_idx(r2o);
                                         if (cA == 0 || i0 < 0 || ix < 0) { err = AQC_ERR_ALPHABET; break; }
-                                        em[handled] = i0 * 4 + ix;
+                                        put_em(handled, i0 * 4 + ix);
                                     }
                                     if (!cfg.no_correction) {
                                         if (cA == 0) { err = AQC_ERR_ALPHABET; break; }
-                                        edits[n_edits] = aqc_edit{(uint16_t)o, AQC_EDIT_FIX_R2, cA, (uint8_t)qa};
+                                        put_edit(n_edits, aqc_edit{(uint16_t)o, AQC_EDIT_FIX_R2, cA, (uint8_t)qa});
                                         Q2[i2] = (uint8_t)qa;
                                         n_edits++; c_corrected++; fixed = true;
                                     }
@@ -508,17 +517,17 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
                                     if (bA != 'N' && bB != 'N') {
                                         const int i0 = base_idx(bB), ix = base_idx(bA);
                                         if (i0 < 0 || ix < 0) { err = AQC_ERR_ALPHABET; break; }
-                                        em[handled] = i0 * 4 + ix;
+                                        put_em(handled, i0 * 4 + ix);
                                     }
                                     if (!cfg.no_correction) {
-                                        edits[n_edits] = aqc_edit{(uint16_t)o, AQC_EDIT_FIX_R1, bB, (uint8_t)qb};
+                                        put_edit(n_edits, aqc_edit{(uint16_t)o, AQC_EDIT_FIX_R1, bB, (uint8_t)qb});
                                         Q1[i1] = (uint8_t)qb;
                                         n_edits++; c_corrected++; fixed = true;
                                     }
                                 }
                                 if (!fixed) {
                                     if (cfg.mask_mismatch) {
-                                        edits[n_edits] = aqc_edit{(uint16_t)o, AQC_EDIT_MASK, 0, (uint8_t)'!'};
+                                        put_edit(n_edits, aqc_edit{(uint16_t)o, AQC_EDIT_MASK, 0, (uint8_t)'!'});
                                         Q2[i2] = (uint8_t)'!'; Q1[i1] = (uint8_t)'!';
                                         n_edits++; c_masked++;
                                     } else c_skipped++;
@@ -567,28 +576,28 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
                                         const uint8_t cA = comp_strict(bA);
                                         const int i0 = base_idx(cA), i1 = base_idx(r2o);
                                         if (cA == 0 || i0 < 0 || i1 < 0) bad_alpha = true;
-                                        else em[handled] = i0 * 4 + i1;          // err[comp(b1)][comp(b2)]
+                                        else put_em(handled, i0 * 4 + i1);          // err[comp(b1)][comp(b2)]
                                     }
                                     if (!cfg.no_correction) {
                                         const uint8_t cA = comp_strict(bA);
                                         if (cA == 0) bad_alpha = true;
-                                        edits[n_edits] = aqc_edit{(uint16_t)oo, AQC_EDIT_FIX_R2, cA, (uint8_t)qa};
+                                        put_edit(n_edits, aqc_edit{(uint16_t)oo, AQC_EDIT_FIX_R2, cA, (uint8_t)qa});
                                         n_edits++; c_corrected++; fixed = true;
                                     }
                                 } else if (qb - 33 >= 30 && qa - 33 <= 14) {
                                     if (bA != 'N' && bB != 'N') {
                                         const int i0 = base_idx(bB), i1 = base_idx(bA);
                                         if (i0 < 0 || i1 < 0) bad_alpha = true;
-                                        else em[handled] = i0 * 4 + i1;          // err[b2][b1]
+                                        else put_em(handled, i0 * 4 + i1);          // err[b2][b1]
                                     }
                                     if (!cfg.no_correction) {
-                                        edits[n_edits] = aqc_edit{(uint16_t)oo, AQC_EDIT_FIX_R1, bB, (uint8_t)qb};
+                                        put_edit(n_edits, aqc_edit{(uint16_t)oo, AQC_EDIT_FIX_R1, bB, (uint8_t)qb});
                                         n_edits++; c_corrected++; fixed = true;
                                     }
                                 }
                                 if (!fixed) {
                                     if (cfg.mask_mismatch) {
-                                        edits[n_edits] = aqc_edit{(uint16_t)oo, AQC_EDIT_MASK, 0, (uint8_t)'!'};
+                                        put_edit(n_edits, aqc_edit{(uint16_t)oo, AQC_EDIT_MASK, 0, (uint8_t)'!'});
                                         n_edits++; c_masked++;
                                     } else c_skipped++;
                                 }
@@ -619,7 +628,7 @@ __device__ inline void process_record_wave(const DevBatch& b, uint64_t rec, cons
             r.start1 = (uint16_t)a1; r.len1 = (uint16_t)len1;
             r.start2 = (uint16_t)a2; r.len2 = (uint16_t)len2;
             r.offset = (int16_t)offset; r.overlap_len = (uint16_t)ovl; r.distance = (uint16_t)dist;
-            r.edits[0] = edits[0]; r.edits[1] = edits[1]; r.edits[2] = edits[2];
+            r.edits[0] = get_edit(ed0); r.edits[1] = get_edit(ed1); r.edits[2] = get_edit(ed2);
             r.barcode = bcode;
             results[rec] = r;
             if (irr) {
@@ -672,6 +681,16 @@ __device__ inline void flush_block_acc(BlockAcc& acc, const DevStats& st, int ti
     }
 }
 
+// the leading arguments of the two kernels below as they stand in the kernarg segment (each at its natural alignment)
+struct FilterArgs {
+    DevBatch b;
+    aqc_config cfg;
+    DevCircles circ;
+    aqc_result* results;
+    DevStats st;
+    uint64_t accum_limit;
+};
+
 __global__ __launch_bounds__(BLOCK) void filter_overlap_kernel(DevBatch b, aqc_config cfg, DevCircles circ,
                                                                aqc_result* __restrict__ results, DevStats st,
                                                                uint64_t accum_limit) {
@@ -683,8 +702,22 @@ __global__ __launch_bounds__(BLOCK) void filter_overlap_kernel(DevBatch b, aqc_c
     __syncthreads();
     const WaveLds w{lds[wave][0], lds[wave][1], lds[wave][2], lds[wave][3], lds[wave][4], rsbuf[wave][0], rsbuf[wave][1]};
     const uint64_t nwaves = (uint64_t)gridDim.x * WPB;
-    for (uint64_t rec = (uint64_t)blockIdx.x * WPB + wave; rec < b.n; rec += nwaves)
+    const uint64_t n_rec = b.n;
+    for (uint64_t rec = (uint64_t)blockIdx.x * WPB + wave; rec < n_rec; rec += nwaves) {
+        // (the arguments — forty pointers and the configuration — are read from the kernarg segment where a record is worked on, not
+        //  held in scalar registers across the loop: qc_stat_kernel's trick, round 5)
+#if defined(__HIP_DEVICE_COMPILE__)
+        const FilterArgs __attribute__((address_space(4)))* ka = (const FilterArgs __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const DevBatch bb = ka->b;
+        const DevCircles ci = ka->circ;
+        const DevStats ss = ka->st;
+        // (the configuration is read in place: barcode_verify is indexed at run time, a copy would live in scratch)
+        process_record_wave(bb, rec, ka->cfg, ci, w, ka->results, acc, ss, rec < ka->accum_limit);
+#else
         process_record_wave(b, rec, cfg, circ, w, results, acc, st, rec < accum_limit);
+#endif
+    }
     __syncthreads();
     flush_block_acc(acc, st);
 }
@@ -707,7 +740,17 @@ __global__ __launch_bounds__(BLOCK) void filter_overlap_list_kernel(DevBatch b, 
     const unsigned int nwaves = gridDim.x * WPB;
     for (unsigned int i = blockIdx.x * WPB + wave; i < n; i += nwaves) {
         const uint64_t rec = list[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+        const FilterArgs __attribute__((address_space(4)))* ka = (const FilterArgs __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const DevBatch bb = ka->b;
+        const DevCircles ci = ka->circ;
+        const DevStats ss = ka->st;
+        // (the configuration is read in place: barcode_verify is indexed at run time, a copy would live in scratch)
+        process_record_wave(bb, rec, ka->cfg, ci, w, ka->results, acc, ss, rec < ka->accum_limit);
+#else
         process_record_wave(b, rec, cfg, circ, w, results, acc, st, rec < accum_limit);
+#endif
     }
     __syncthreads();
     flush_block_acc(acc, st);

@@ -640,6 +640,26 @@ __device__ __forceinline__ int moved_barcode_len(const FormatView& v, int file, 
     return min(max(b, 0), (int)seq_len);
 }
 
+// name.find(':') over a name of nlen bytes, 16 bytes per step (an unaligned 16-byte load, the exact zero-byte test on name ^ "::::"); nlen - 1
+// when there is none — find() == -1 slices the last character (barcodeprocesser.py:41).  Reads up to 15 bytes behind the name: text.
+// (rounds 2 - 5: a byte load per character — the sizing pass of a barcode run took 0.35 ms per 6 M records, six times the plain run's)
+__device__ __forceinline__ uint32_t find_colon(const uint8_t* name, uint32_t nlen) {
+    for (uint32_t i = 0; i < nlen; i += 16u) {
+        const uint4 v = load16u(name + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        unsigned long long z[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t x0 = w[2 * h] ^ 0x3a3a3a3au, x1 = w[2 * h + 1] ^ 0x3a3a3a3au;
+            const uint32_t z0 = ~(((x0 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x0) & 0x80808080u, z1 = ~(((x1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x1) & 0x80808080u;
+            z[h] = ((unsigned long long)z1 << 32) | z0;
+        }
+        const uint32_t at = z[0] ? (uint32_t)(__builtin_ctzll(z[0]) >> 3) : z[1] ? 8u + (uint32_t)(__builtin_ctzll(z[1]) >> 3) : 16u;
+        if (at < 16u && i + at < nlen) return i + at;
+    }
+    return nlen - 1u;
+}
+
 // bytes of (file, stream) that record r contributes: the sizes of all three streams of one file at once
 // (sz[0] good, sz[1] bad, sz[2] overlap); the name's first ':' is only searched when a barcode was moved
 __device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int file, uint32_t sz[3], uint32_t& event) {
@@ -664,10 +684,7 @@ __device__ __forceinline__ void fmt_sizes(const FormatView& v, uint64_t r, int f
         const int b = moved_barcode_len(v, file, flag, bc, slw & LEN_MASK);
         if (b >= 0) {
             // name[str.find(':'):] — find() == -1 slices the last character
-            const uint8_t* name = t.text + t.name_off[r];
-            uint32_t cpos = nlen - 1;
-            for (uint32_t i = 0; i < nlen; ++i)
-                if (name[i] == ':') { cpos = i; break; }
+            const uint32_t cpos = find_colon(t.text + t.name_off[r], nlen);
             nlen = 1u + (uint32_t)b + (nlen - cpos);
         }
     }
@@ -850,12 +867,7 @@ __device__ inline void fmt_build(const FormatView& v, uint64_t r, int file, int 
     const int flen = t.stream == 1 ? FLAG_TEXT_LEN[flag] : 0;
     // barcode moved into the name: '@' + [FLAG] + bases[0:mb] + name[cpos:]  (name[str.find(':'):]; find() == -1 slices the last character)
     const int mb = (v.barcode && !v.plain) ? moved_barcode_len(v, file, flag, w1.w >> 24, (uint32_t)slen) : -1;
-    int cpos = nlen - 1;
-    if (mb >= 0) {
-        const uint8_t* name = tf.text + name_off;
-        for (int i = 0; i < nlen; ++i)
-            if (name[i] == ':') { cpos = i; break; }
-    }
+    const int cpos = mb >= 0 ? (int)find_colon(tf.text + name_off, (uint32_t)nlen) : nlen - 1;
     const uint32_t NL = FMT_LIT_BIT | (12 * 16);
     int o = 0;
     // "@" + FLAG + name[1:] for a bad record (preprocesser.py:213-219), the name itself for a good one
@@ -1286,6 +1298,8 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
         if (threadIdx.x < cnt * PLAN_Q) s_plan[threadIdx.x] = pg[(uint64_t)r0 * PLAN_Q + threadIdx.x];
         if (threadIdx.x < cnt) s_ti[threadIdx.x] = gen_list[r0 + threadIdx.x];
         __syncthreads();
+        // (round 6, measured and left out: the next round's plans prefetched into registers while this round is worked on — 84 instead of
+        //  79 registers, a wave less per SIMD: config 5 2.32 -> 2.41 ms, config 3 unchanged)
         constexpr int NWIN = GEN_U * GEN_PASSES;          // windows in flight per lane: plan u, pass j -> slot u * GEN_PASSES + j
         uint4 val[NWIN];
         uint32_t so[NWIN], dof[NWIN], mw[NWIN];           // source offset (FMT_LIT_BIT: literal table), offset in the output stream,

@@ -397,6 +397,13 @@ def test_pipe_single_member_gzip_input_is_shared_with_the_device(tmp_path, size)
         os.environ["AQC_GZ_KEEP"] = "5"              # (... and the pool's head start of 32 sections is a sixth of them: one group in front of it will do)
     try:
         sections, from_device, text_bytes, device_bytes = gz_run("gzdev")
+        # (small_forced is a race by construction: a 40 MB file is inflated by the pool in ~20 ms, about the time a decoder whose buffers
+        #  have to be re-made for this group size needs to get ready — seen to lose on 2 of 8 boxes.  The decoders outlive the pipe, so
+        #  a second run finds them warm; every run's bytes are checked)
+        for _ in range(2):
+            if big or from_device > 0:
+                break
+            sections, from_device, text_bytes, device_bytes = gz_run("gzdev")
     finally:
         for k in ("AQC_GZ_GROUP", "AQC_GZ_DEVICE_MIN", "AQC_GZ_KEEP"):
             os.environ.pop(k, None)
