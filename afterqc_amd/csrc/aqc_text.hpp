@@ -1169,13 +1169,14 @@ constexpr int COPY_BLOCK = 256;
 // min(16 * lane, len - 16), load, store — as lean as a copy gets (tools/ubench/copy_rate.hip: this shape moves 6.9 GB in
 // 1.4 ms without the plan read, 1.6 ms with it).
 // pa[u]: the plan's first word (PLAN_SKIP: nothing), file[u]: its file, pq[u]: where its patch word stands
-__device__ __forceinline__ void copy_whole_tasks(const FormatView& v, const uint4 (&pa)[FMT_UNROLL], const int (&file_of)[FMT_UNROLL], const uint4* const (&pq)[FMT_UNROLL],
+template <int NU>
+__device__ __forceinline__ void copy_whole_tasks(const FormatView& v, const uint4 (&pa)[NU], const int (&file_of)[NU], const uint4* const (&pq)[NU],
                                                  const FormatOut& outs, int lane32) {
-    uint4 val[FMT_UNROLL];
-    uint8_t* dptr[FMT_UNROLL];
-    bool on[FMT_UNROLL];
+    uint4 val[NU];
+    uint8_t* dptr[NU];
+    bool on[NU];
 #pragma unroll
-    for (int u = 0; u < FMT_UNROLL; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int file = file_of[u];
         const int len = (int)(pa[u].w & 0xffffu);
         on[u] = plan_is_whole(pa[u]) && lane32 < ((len + 15) >> 4);
@@ -1186,10 +1187,10 @@ __device__ __forceinline__ void copy_whole_tasks(const FormatView& v, const uint
     // the correction walk's edits: byte patches applied in registers (windows that overlap carry the same patch)
     uint32_t any_patch = 0;
 #pragma unroll
-    for (int u = 0; u < FMT_UNROLL; ++u) any_patch |= on[u] ? (pa[u].y >> 16) & 0xffu : 0u;
+    for (int u = 0; u < NU; ++u) any_patch |= on[u] ? (pa[u].y >> 16) & 0xffu : 0u;
     if (__ballot(any_patch != 0)) {
 #pragma unroll
-        for (int u = 0; u < FMT_UNROLL; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const uint32_t np = on[u] ? (pa[u].y >> 16) & 0xffu : 0u;
             if (np) {
                 const uint4 q5 = *pq[u];
@@ -1210,7 +1211,7 @@ __device__ __forceinline__ void copy_whole_tasks(const FormatView& v, const uint
         }
     }
 #pragma unroll
-    for (int u = 0; u < FMT_UNROLL; ++u)
+    for (int u = 0; u < NU; ++u)
         if (on[u]) store16u(dptr[u], val[u]);
 }
 
@@ -1485,6 +1486,10 @@ __device__ __forceinline__ int own_bytes_patches(const uint4& w0, const uint4& w
 }
 
 constexpr int PC_BLOCK = 2 * FMT_TILE;       // thread = (record of the tile, file)
+#ifndef AQC_PC_UNROLL
+#define AQC_PC_UNROLL 4
+#endif
+constexpr int PC_UNROLL = AQC_PC_UNROLL;     // records in flight per half-wave in the copy phase
 static_assert(PC_BLOCK == COPY_BLOCK, "the copy phase is fmt_copy_whole_kernel's");
 
 __global__ __launch_bounds__(PC_BLOCK) void fmt_place_copy_kernel(FormatView v, uint64_t n, uint64_t n_tiles, uint64_t n_super,
@@ -1558,15 +1563,15 @@ __global__ __launch_bounds__(PC_BLOCK) void fmt_place_copy_kernel(FormatView v, 
     // the copy: a half-wave per record, FMT_UNROLL records in flight, plans and patch words from LDS
     const int lane32 = threadIdx.x & 31, hwi = threadIdx.x >> 5;
     const int n_plans = nfiles * FMT_TILE;
-    constexpr int PER_ROUND = (PC_BLOCK / 32) * FMT_UNROLL;
+    constexpr int PER_ROUND = (PC_BLOCK / 32) * PC_UNROLL;
 #pragma unroll 1
     for (int p0 = 0; p0 < n_plans; p0 += PER_ROUND) {
-        uint4 pa[FMT_UNROLL];
-        int file_of[FMT_UNROLL];
-        const uint4* pq[FMT_UNROLL];
+        uint4 pa[PC_UNROLL];
+        int file_of[PC_UNROLL];
+        const uint4* pq[PC_UNROLL];
 #pragma unroll
-        for (int u = 0; u < FMT_UNROLL; ++u) {
-            const int p = p0 + hwi * FMT_UNROLL + u;                      // (< PC_BLOCK: a single-end tile's upper half says PLAN_SKIP)
+        for (int u = 0; u < PC_UNROLL; ++u) {
+            const int p = p0 + hwi * PC_UNROLL + u;                       // (< PC_BLOCK: a single-end tile's upper half says PLAN_SKIP)
             pa[u] = s_q0[p];
             file_of[u] = p / FMT_TILE;
             pq[u] = &s_q5[p];
