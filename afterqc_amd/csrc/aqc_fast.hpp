@@ -144,7 +144,11 @@ __device__ __forceinline__ void trim_view(int len, int front, int tail, int& st,
 
 // the length this kernel works with: a mate marked LEN_IRR (its quality line has a length of its own: the general kernel's
 // business) counts as EMPTY — one v_max per lane and batch; phase 1 then sees padding only and never forms an address from it
+#ifdef AQC_NO_IRR_VMAX      // measurement builds only (tools/build_ablate.sh): the kernel without that v_max — wrong for irregular records
+__device__ __forceinline__ uint32_t lane_len(uint32_t len_word) { return len_word; }
+#else
 __device__ __forceinline__ uint32_t lane_len(uint32_t len_word) { return (uint32_t)max((int)len_word, 0); }
+#endif
 
 template <int NW, bool PAIRED, bool FUSE = false>
 struct FastWaveLds {

@@ -188,26 +188,30 @@ __global__ __launch_bounds__(TXT_BLOCK) void text_index_kernel(IndexFile f0, Ind
     const uint32_t tile = s_tile;
     const IndexFile& f = tile >= f1.tile0 && f1.tiles ? f1 : f0;
     const uint32_t lt = tile - f.tile0;                                   // tile within the file
-    const int lane = lane_id(), wave = threadIdx.x / WAVE;
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     const uint64_t wbase = (uint64_t)lt * IDX_TILE + (uint64_t)wave * (WAVE * 16 * IDX_P);
     const uint64_t lbase = wbase + (uint64_t)lane * 16;
     // (the buffer is zero-filled for more than a tile behind the text; loads are still bounded by the text's end)
-    uint32_t carry_in = (wbase > 0 && wbase <= f.bytes && lane == 0) ? (f.text[wbase - 1] < 0x21 ? 1u : 0u) : 0u;
+    // (round 6: a wave whose 32 KiB lie inside the text — all but a file's last — loads and masks without looking at the text's end;
+    //  "the byte before is blank" comes from a ballot of the lanes' last bytes instead of a lane shift through LDS; the lane scans
+    //  of the emit pass are DPP scans: 146 -> ~115 instructions per 16 bytes of an instruction-bound kernel)
+    const bool full = wbase + (uint64_t)(WAVE * 16 * IDX_P) <= f.bytes;          // (wave-uniform)
+    uint32_t carry_in = (wbase > 0 && wbase <= f.bytes) ? (f.text[wbase - 1] < 0x21 ? 1u : 0u) : 0u;      // (wave-uniform too)
     uint32_t mine = 0;                            // newlines in this lane's pieces
     uint4 v[IDX_K];
+    auto load_piece = [&](int p) -> uint4 {
+        const uint64_t q = lbase + (uint64_t)p * (WAVE * 16);
+        if (full) return *reinterpret_cast<const uint4*>(f.text + q);
+        return q < f.bytes ? *reinterpret_cast<const uint4*>(f.text + q) : make_uint4(0, 0, 0, 0);
+    };
 #pragma unroll
-    for (int k = 0; k < IDX_K; ++k) {
-        const uint64_t q = lbase + (uint64_t)k * (WAVE * 16);
-        v[k] = q < f.bytes ? *reinterpret_cast<const uint4*>(f.text + q) : make_uint4(0, 0, 0, 0);
-    }
+    for (int k = 0; k < IDX_K; ++k) v[k] = load_piece(k);
 #pragma unroll 1
     for (int sub = 0; sub < IDX_SUB; ++sub) {
         uint4 nx[IDX_K];
 #pragma unroll
-        for (int k = 0; k < IDX_K; ++k) {         // the next sub-tile is on its way while this one is worked on
-            const uint64_t q = lbase + (uint64_t)((sub + 1) * IDX_K + k) * (WAVE * 16);
-            nx[k] = (sub + 1 < IDX_SUB && q < f.bytes) ? *reinterpret_cast<const uint4*>(f.text + q) : make_uint4(0, 0, 0, 0);
-        }
+        for (int k = 0; k < IDX_K; ++k)          // the next sub-tile is on its way while this one is worked on
+            nx[k] = sub + 1 < IDX_SUB ? load_piece((sub + 1) * IDX_K + k) : make_uint4(0, 0, 0, 0);
         uint32_t nlp = 0, wsp = 0;
 #pragma unroll
         for (int k = 0; k < IDX_K; ++k) {
@@ -215,14 +219,15 @@ __global__ __launch_bounds__(TXT_BLOCK) void text_index_kernel(IndexFile f0, Ind
             uint32_t nl, bl;
             piece_masks(v[k], nl, bl);
             // mask the bytes behind the end of the text (the last piece may be partial)
-            const uint64_t q = lbase + (uint64_t)p * (WAVE * 16);
-            if (q + 16 > f.bytes) { const uint32_t keep = q >= f.bytes ? 0u : ((1u << (f.bytes - q)) - 1u); nl &= keep; }
+            if (!full) {
+                const uint64_t q = lbase + (uint64_t)p * (WAVE * 16);
+                if (q + 16 > f.bytes) { const uint32_t keep = q >= f.bytes ? 0u : ((1u << (f.bytes - q)) - 1u); nl &= keep; }
+            }
             // "the byte before is blank": this piece's flags moved up one byte; the byte before the piece is the last byte
             // of the piece of the lane before (same p), for lane 0 of the last lane's piece of p - 1
-            const uint32_t top = bl >> 15;
-            uint32_t prev = (uint32_t)__shfl_up((int)top, 1, WAVE);
-            if (lane == 0) prev = carry_in;
-            carry_in = (uint32_t)__builtin_amdgcn_readlane((int)top, WAVE - 1);          // (only lane 0 uses it)
+            const unsigned long long tops = __ballot((bl >> 15) != 0u);
+            const uint32_t prev = (uint32_t)((((tops << 1) | carry_in) >> lane) & 1ull);
+            carry_in = (uint32_t)(tops >> (WAVE - 1));
             const uint32_t ws = ((bl << 1) | prev) & 0xffffu;
             mine += (uint32_t)__popc(nl);
             if (k & 1) {
@@ -233,9 +238,7 @@ __global__ __launch_bounds__(TXT_BLOCK) void text_index_kernel(IndexFile f0, Ind
 #pragma unroll
         for (int k = 0; k < IDX_K; ++k) v[k] = nx[k];
     }
-    uint32_t wtot = mine;
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) wtot += (uint32_t)__shfl_xor((int)wtot, sft, WAVE);
+    const uint32_t wtot = (uint32_t)wave_sum_u((int)mine);
     if (lane == 0) s_wave_tot[wave] = wtot;
     __syncthreads();
     unsigned long long total = 0, wave_off = 0;
@@ -288,12 +291,7 @@ __global__ __launch_bounds__(TXT_BLOCK) void text_index_kernel(IndexFile f0, Ind
     for (int j = 0; j < IDX_P / 2; ++j) {
         const uint32_t nlp = s_nl[j][threadIdx.x], wsp = s_ws[j][threadIdx.x];
         const uint32_t own = (uint32_t)__popc(nlp & 0xffffu) | ((uint32_t)__popc(nlp >> 16) << 16);
-        uint32_t c = own;                             // inclusive lane scan, two rows at once
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)c, d, WAVE);
-            if (lane >= d) c += o;
-        }
+        const uint32_t c = (uint32_t)wave_incl_sum((int)own, lane);      // inclusive lane scan, two rows at once (each < 2^11)
         const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)c, WAVE - 1);
         const uint32_t ex = c - own;
 #pragma unroll

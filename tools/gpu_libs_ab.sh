@@ -1,7 +1,7 @@
 #!/bin/bash
 # the device step of config 3 with the tree's library and every build/ablate/*.so (tools/build_ablate.sh), interleaved twice
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for f in afterqc_amd/csrc/libafterqc_hip.so build/ablate/*.so; do
   AQC_LIB=$PWD/$f python bench.py --cpu-sample 0 --device-only --device-steps 10 --no-pmc --no-fused-step --text-step-only "$@" 2>/dev/null | python -c "
 import json,sys
