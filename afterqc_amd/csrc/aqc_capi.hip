@@ -1128,9 +1128,11 @@ static int format_impl(aqc_ctx* c, int slot, int verdict_slot, uint64_t n, int32
                                (SpanEvent*)s->f_events[0].p, (SpanEvent*)s->f_events[1].p);
             // (spans / fused mode: what stays in the caller's chunk / what the verdict kernel copied has no plan; the records that are their
             //  own bytes but for the walk's byte patches are still this kernel's)
-            if (!sparse) hipLaunchKernelGGL(fmt_copy_whole_kernel, dim3(copy_blocks), dim3(COPY_BLOCK), 0, s->stream, v, n_tasks, (const uint4*)s->f_plan.p,
-                                            (const uint4*)s->f_patch.p, outs);
-            else hipLaunchKernelGGL(fmt_copy_whole_list_kernel, dim3((unsigned)(GEN_LISTS * per_list)), dim3(COPY_BLOCK), 0, s->stream, v, (const uint4*)d_wplan, outs,
+            // (a barcode run has no one-piece record: fmt_plan_kernel writes no dense plans and nothing walks them)
+            if (!sparse) {
+                if (!(v.barcode && !v.plain)) hipLaunchKernelGGL(fmt_copy_whole_kernel, dim3(copy_blocks), dim3(COPY_BLOCK), 0, s->stream, v, n_tasks, (const uint4*)s->f_plan.p,
+                                                                 (const uint4*)s->f_patch.p, outs);
+            } else hipLaunchKernelGGL(fmt_copy_whole_list_kernel, dim3((unsigned)(GEN_LISTS * per_list)), dim3(COPY_BLOCK), 0, s->stream, v, (const uint4*)d_wplan, outs,
                                     (const unsigned int*)d_nwhole, gen_cap);
             }
             hipLaunchKernelGGL(fmt_copy_kernel, dim3((unsigned)(GEN_LISTS * per_list)), dim3(COPY_BLOCK), 0, s->stream, v,

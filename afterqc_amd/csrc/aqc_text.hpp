@@ -1111,9 +1111,13 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
             // Text mode: nearly every record is one piece — fmt_copy_whole_kernel walks the dense plan0.  Spans / fused mode: few
             // are left (the pairs the walk edited) — their plans are LISTED (q0 with the file in bit 24 | the patches) and
             // fmt_copy_whole_list_kernel walks the lists (a dense walk over 10 M mostly empty plans cost 0.8 ms).
-            const bool whole = plan_is_whole(q0);
+            // (a barcode run has no one-piece record — every good name is rewritten, every bad one flagged: no dense plans, and the
+            //  host does not launch the kernel that would walk them: 0.33 ms per 6 M records of config 5 for nothing; should a plan
+            //  be one piece after all it goes the general way)
+            const bool no_dense = v.barcode && !v.plain;
+            const bool whole = plan_is_whole(q0) && !no_dense;
             const bool sparse = v.spans || v.fused;
-            if (!sparse) {
+            if (!sparse && !no_dense) {
                 plan0[ti] = q0;
                 if (whole && (q0.y & 0x00ff0000u)) plan_patch[ti] = q5;        // (written and read for the patched records only)
             }
