@@ -300,11 +300,25 @@ __global__ __launch_bounds__(TXT_BLOCK) void text_index_kernel(IndexFile f0, Ind
             const uint32_t ws = h ? (wsp >> 16) : (wsp & 0xffffu);
             unsigned long long i = run + (h ? (ex >> 16) : (ex & 0xffffu));
             const uint32_t q = (uint32_t)lbase + (uint32_t)(2 * j + h) * (WAVE * 16);      // (chunks are < 2 GiB)
-            while (m) {
+            // (a lane's 16 bytes hold at most two line ends but for one-base lines: two predicated stores, then the loop for the rest)
+            if (m) {
                 const int bit = __builtin_ctz(m);
                 if (i < f.cap) f.line_end[i] = (q + (uint32_t)bit) | (((ws >> bit) & 1u) ? LINE_WS : 0u);
-                ++i;
                 m &= m - 1;
+                if (m) {
+                    const int bit2 = __builtin_ctz(m);
+                    if (i + 1 < f.cap) f.line_end[i + 1] = (q + (uint32_t)bit2) | (((ws >> bit2) & 1u) ? LINE_WS : 0u);
+                    m &= m - 1;
+                }
+                i += 2;
+            }
+            if (__ballot(m != 0u)) {
+                while (m) {
+                    const int bit = __builtin_ctz(m);
+                    if (i < f.cap) f.line_end[i] = (q + (uint32_t)bit) | (((ws >> bit) & 1u) ? LINE_WS : 0u);
+                    ++i;
+                    m &= m - 1;
+                }
             }
             run += h ? (last >> 16) : (last & 0xffffu);
         }
