@@ -50,6 +50,9 @@ constexpr int NONE_CAND = 0x7fffffff;
 // 16 bytes from an arbitrarily aligned address: one global_load_dwordx4
 __device__ __forceinline__ uint4 load16u(const uint8_t* p) {
     uint4 v;
+#if defined(AQC_ABL) && (AQC_ABL & 128)
+    p = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)15);      // (ablation: what would loads on the 16-byte grid give?)
+#endif
     __builtin_memcpy(&v, p, 16);
     return v;
 }
@@ -251,7 +254,7 @@ __device__ __forceinline__ uint32_t mm_word(uint32_t mlo0, uint32_t mlo1, uint32
 #ifndef AQC_ABL
 #define AQC_ABL 0      // ablation builds only (tools/gpu_ablate.sh; results are WRONG, only instruction counts / times mean anything):
                        // 1 no alphabet validation, 2 no length masks, 4 no polyX screen, 8 no diagonal scan, 16 no correction walk,
-                       // 32 no N count, 64 no phase 1 packing (loads only)
+                       // 32 no N count, 64 no phase 1 packing (loads only), 128 every 16-byte load moved down to the 16-byte grid
 #endif
 
 // what the barcode stage needs of aqc_config, decoded once per kernel (uniform): verify as 2-bit codes

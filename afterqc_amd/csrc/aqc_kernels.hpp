@@ -1188,7 +1188,8 @@ __device__ unsigned long long g_kprof[16];
 #define KPROF_FLUSH
 #endif
 
-constexpr int KMER_BLOCK = 1024;
+constexpr int KMER_BLOCK = 1024;                // (round 6: 512 threads at <= 128 registers, to leave room for the writer's kernels beside it, measured slower —
+                                                //  the step 3.90 - 3.95 -> 4.10 - 4.22 ms, the k-mer launches 0.265 -> 0.35 ms: profiles/r06_copy_window_grid.txt)
 constexpr int KMER_WPB = KMER_BLOCK / WAVE;
 constexpr int KMER_EXQ = 1536;                  // LDS queue of k-mers bound for the open-addressing table (24 KiB)
 constexpr size_t KMER_LDS_BYTES = DENSE_ENTRIES * 2 + (size_t)KMER_EXQ * 16 + 16;

@@ -822,6 +822,21 @@ __device__ __forceinline__ uint4 load16u_t(const uint8_t* p) {
 // that are neighbours in the text as well are merged while the list is built, so an untrimmed good record is ONE piece
 // (the record's own bytes), a tail-trimmed one three, a renamed (bad) one two more.
 constexpr int FMT_MAXP = 10;
+#ifndef AQC_GEN_ALIGN
+#define AQC_GEN_ALIGN 1       // the general copy kernel's pieces of >= GRID_MIN bytes: windows on the source's grid, one work item more per piece
+#endif
+#ifndef AQC_GEN_SMALL
+#define AQC_GEN_SMALL 1       // the general copy kernel's pieces of < 16 bytes: loaded with the windows, stored straight-line (0: rounds 2 - 5, a branch per size)
+#endif
+#ifndef AQC_GEN_PREFETCH
+#define AQC_GEN_PREFETCH 0
+#endif
+constexpr uint32_t GRID_MIN = 48;
+// work items of a piece of `len` bytes in the general copy kernel: a short piece is one, a long one a 16-byte window per item —
+// on the source's grid (head window + aligned windows, the last one end-aligned) that is one more than len / 16 rounded up
+__host__ __device__ constexpr uint32_t piece_items(uint32_t len) {
+    return len >= 16u ? ((len + 15u) >> 4) + ((AQC_GEN_ALIGN && len >= GRID_MIN) ? 1u : 0u) : (len > 0u ? 1u : 0u);
+}
 constexpr uint32_t FMT_LIT_BIT = 0x80000000u;
 struct FmtPiece {
     uint32_t src;          // byte offset from the file's text base; FMT_LIT_BIT: offset into FMT_LIT instead
@@ -908,7 +923,7 @@ __device__ inline void fmt_build(const FormatView& v, uint64_t r, int file, int 
     if (o > 0xffff) { atomicCAS(status, 0, AQC_ERR_UNSUPPORTED); t.stream = 0xff; return; }      // (a 64 KiB FASTQ record)
     t.total = (uint16_t)o;
     int items = 0;
-    for (int k = 0; k < t.np; ++k) items += t.p[k].len >= 16 ? (t.p[k].len + 15) >> 4 : 1;
+    for (int k = 0; k < t.np; ++k) items += (int)piece_items(t.p[k].len);
     t.items = (uint16_t)items;
     // the walk's edits in this mate's slice coordinates -> byte patches of the output record
     const unsigned long long e_lo = ((unsigned long long)w1.y << 32) | w1.x, e_hi = ((unsigned long long)w1.w << 32) | w1.z;
@@ -1012,7 +1027,7 @@ __device__ __forceinline__ PlanWords plan_words(const FmtTask& t, uint32_t pos) 
             src[k] = in ? t.p[k].src : 0u;
             len[k] = in ? (uint32_t)t.p[k].len : 0u;
             off[k] = doff;
-            ci += len[k] >= 16 ? (len[k] + 15) >> 4 : (len[k] > 0 ? 1u : 0u);
+            ci += piece_items(len[k]);
             cum[k] = ci;
             doff += len[k];
         }
@@ -1180,6 +1195,9 @@ __global__ __launch_bounds__(FMT_TILE) void fmt_plan_kernel(FormatView v, uint64
 #endif
 constexpr int FMT_UNROLL = AQC_FMT_UNROLL;
 constexpr int COPY_BLOCK = 256;
+#ifndef AQC_COPY_ALIGN
+#define AQC_COPY_ALIGN 2      // window grid of the whole-record copy: 0 none (rounds 2 - 5), 1 the destination's, 2 the source's (copy_whole_tasks)
+#endif
 
 // Records that are ONE piece (untrimmed, unedited, not renamed: the bulk of a -f 0 -t 0 run): 32 lanes, window
 // min(16 * lane, len - 16), load, store — as lean as a copy gets (tools/ubench/copy_rate.hip: this shape moves 6.9 GB in
@@ -1195,10 +1213,28 @@ __device__ __forceinline__ void copy_whole_tasks(const FormatView& v, const uint
     for (int u = 0; u < NU; ++u) {
         const int file = file_of[u];
         const int len = (int)(pa[u].w & 0xffffu);
-        on[u] = plan_is_whole(pa[u]) && lane32 < ((len + 15) >> 4);
-        const int off = min(16 * lane32, len - 16);
-        dptr[u] = outs.p[file * 3 + (int)(pa[u].y & 0xffu)] + pa[u].x + off;
-        if (on[u]) val[u] = load16u_t(v.f[file].text + pa[u].z + off);
+        uint8_t* const d0 = outs.p[file * 3 + (int)(pa[u].y & 0xffu)] + pa[u].x;
+        const uint8_t* const s0 = v.f[file].text + pa[u].z;
+        int nw = (len + 15) >> 4;
+        int off = 16 * lane32;
+#if AQC_COPY_ALIGN
+        // round 6: the windows stand on the 16-byte grid of the SOURCE (AQC_COPY_ALIGN 2; 1: of the destination, measured slower than no
+        // grid at all — profiles/r06_copy_window_grid.txt): lane 0 takes the record's first 16 bytes wherever they stand, lane k >= 1 the
+        // k-th aligned window behind them, the last window end-aligned as before.  A wave's load instruction then touches every 64-byte
+        // line once (off the grid each quad of lanes straddles two).  A record of > 496 bytes off the grid would take 33 windows: it
+        // keeps the plain ones
+        {
+            const int a = (16 - (int)((AQC_COPY_ALIGN == 1 ? (uintptr_t)d0 : (uintptr_t)s0) & 15u)) & 15;
+            const int nwa = 1 + ((len - a + 15) >> 4);
+            const bool grid = a != 0 && nwa <= 32;
+            nw = grid ? nwa : nw;
+            off = grid && lane32 ? a + 16 * (lane32 - 1) : off;
+        }
+#endif
+        on[u] = plan_is_whole(pa[u]) && lane32 < nw;
+        off = min(off, len - 16);
+        dptr[u] = d0 + off;
+        if (on[u]) val[u] = load16u_t(s0 + off);
     }
     // the correction walk's edits: byte patches applied in registers (windows that overlap carry the same patch)
     uint32_t any_patch = 0;
@@ -1211,7 +1247,7 @@ __device__ __forceinline__ void copy_whole_tasks(const FormatView& v, const uint
             if (np) {
                 const uint4 q5 = *pq[u];
                 const uint32_t pt[4] = {q5.x, q5.y, q5.z, q5.w};
-                const uint32_t wpos = (uint32_t)min(16 * lane32, (int)(pa[u].w & 0xffffu) - 16);
+                const uint32_t wpos = (uint32_t)(dptr[u] - (outs.p[file_of[u] * 3 + (int)(pa[u].y & 0xffu)] + pa[u].x));      // (the window's place in the record)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t i = (pt[e] & 0xffffu) - wpos;
@@ -1309,11 +1345,30 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
     const uint4* pg = plan_gen + (uint64_t)lj * gen_cap * PLAN_Q;
     const uint32_t n_list = n_gen[lj];
     const uint32_t stride = (gridDim.x / GEN_LISTS) * GEN_ROUND;
+#if AQC_GEN_PREFETCH
+    // the next round's plans are on their way while this round is worked on (one 16-byte word and one list entry per thread)
+    uint4 nx_plan = make_uint4(0, 0, 0, 0);
+    uint32_t nx_ti = 0;
+    auto fetch_round = [&](uint32_t r0) {
+        if (r0 < n_list) {
+            const uint32_t cnt = min((uint32_t)GEN_ROUND, n_list - r0);
+            if (threadIdx.x < cnt * PLAN_Q) nx_plan = pg[(uint64_t)r0 * PLAN_Q + threadIdx.x];
+            if (threadIdx.x < cnt) nx_ti = gen_list[r0 + threadIdx.x];
+        }
+    };
+    fetch_round((blockIdx.x / GEN_LISTS) * GEN_ROUND);
+#endif
     for (uint32_t r0 = (blockIdx.x / GEN_LISTS) * GEN_ROUND; r0 < n_list; r0 += stride) {
         const uint32_t cnt = min((uint32_t)GEN_ROUND, n_list - r0);
         __syncthreads();                                     // (the previous round's plans are no longer read)
+#if AQC_GEN_PREFETCH
+        if (threadIdx.x < cnt * PLAN_Q) s_plan[threadIdx.x] = nx_plan;
+        if (threadIdx.x < cnt) s_ti[threadIdx.x] = nx_ti;
+        fetch_round(r0 + stride);
+#else
         if (threadIdx.x < cnt * PLAN_Q) s_plan[threadIdx.x] = pg[(uint64_t)r0 * PLAN_Q + threadIdx.x];
         if (threadIdx.x < cnt) s_ti[threadIdx.x] = gen_list[r0 + threadIdx.x];
+#endif
         __syncthreads();
         // (round 6, measured and left out: the next round's plans prefetched into registers while this round is worked on — 84 instead of
         //  79 registers, a wave less per SIMD: config 5 2.32 -> 2.41 ms, config 3 unchanged)
@@ -1323,6 +1378,8 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
                                                           // mode | position in the record << 5 | file * 3 + stream << 21 | file << 24
                                                           // (mode: 0 nothing, 16 a window, 1..15 a short piece of that many bytes)
         uint32_t more = 0;                                // bit u: plan u lives in the overflow array
+        const uint8_t* const tp0 = s_ptr[6];
+        const uint8_t* const tp1 = s_ptr[7];
         // (straight-line on purpose: with a branch per plan / window the instruction stream was one saveexec - branch - nop
         //  sequence after the other and the kernel spent its time on instruction latency)
 #pragma unroll
@@ -1354,15 +1411,23 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
                 const int dst_off = k == 0 ? 0 : (int)((ow >> (16 * ((k - 1) & 1))) & 0xffffu);
                 const uint32_t sk = k == 0 ? q0.z : k == 1 ? q1.x : k == 2 ? q1.y : k == 3 ? q1.z : k == 4 ? q1.w : k == 5 ? q2.x : k == 6 ? q2.y : q2.z;
                 // a long piece: my 16-byte window of it, the last one aligned to the piece's end; a short piece: all of it
-                const int off = lk >= 16 ? min(16 * ((int)item - first_item), lk - 16) : 0;
+                int off = 16 * ((int)item - first_item);
+#if AQC_GEN_ALIGN
+                // (round 6) a piece of >= GRID_MIN bytes has one item more (piece_items): its first window where the piece starts, the
+                // others on the 16-byte grid of the SOURCE, so that a load instruction touches each 64-byte line once
+                {
+                    const uint32_t tb = (uint32_t)(uintptr_t)(file ? tp1 : tp0);
+                    const int a = (int)((0u - (tb + sk)) & 15u);
+                    off = (lk >= (int)GRID_MIN && !(sk & FMT_LIT_BIT) && off) ? off - 16 + a : off;
+                }
+#endif
+                off = lk >= 16 ? min(off, lk - 16) : 0;
                 so[w] = sk + (uint32_t)off;
                 dof[w] = q0.x + (uint32_t)(dst_off + off);
                 mw[w] = on ? ((uint32_t)min(lk, 16) | ((uint32_t)(dst_off + off) << 5) | (fs << 21) | (file << 24)) : 0u;
             }
         }
         const uint8_t* const lit = &FMT_LIT[0][0];
-        const uint8_t* const tp0 = s_ptr[6];
-        const uint8_t* const tp1 = s_ptr[7];
         auto src_of = [&](int w) -> const uint8_t* {
             const uint8_t* base = ((mw[w] >> 24) & 1u) ? tp1 : tp0;
             base = (so[w] & FMT_LIT_BIT) ? lit : base;
@@ -1374,7 +1439,11 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
 #pragma unroll
         for (int w = 0; w < NWIN; ++w) {
             const uint32_t md = mw[w] & 31u;
+#if AQC_GEN_SMALL
+            val[w] = load16u_t(md ? src_of(w) : tp0);        // (a short piece's 16 bytes too: the text is padded, a literal is a 16-byte row)
+#else
             val[w] = load16u_t(md == 16u ? src_of(w) : tp0);
+#endif
             any_small |= (md - 1u) < 15u ? 1u : 0u;
         }
         // the correction walk's edits: byte patches applied in registers (windows that overlap carry the same patch)
@@ -1416,6 +1485,27 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
 #pragma unroll
         for (int w = 0; w < NWIN; ++w)
             if ((mw[w] & 31u) == 16u) store16u(dst_of(w), val[w]);
+#if AQC_GEN_SMALL
+        // pieces of 1..15 bytes — a literal '@', a moved barcode, a stray newline: their bytes came with the windows' loads; 8 + 4 + 2 + 1
+        // bytes stored as the length's bits say.  (Rounds 2 - 5 copied them behind the windows, a branch per size class with its own
+        // load -> store round trip: two or three memory latencies per round of a barcode run, where every record has two of them.)
+        if (__ballot(any_small != 0)) {
+#pragma unroll
+            for (int w = 0; w < NWIN; ++w) {
+                const uint32_t md = mw[w] & 31u;
+                const bool sm = (md - 1u) < 15u;
+                uint8_t* const d = dst_of(w);
+                const uint32_t i2 = (md >> 2) & 3u;
+                uint32_t vx = val[w].x, vy = val[w].y, vz = val[w].z, vw = val[w].w;
+                asm volatile("" : "+v"(vx), "+v"(vy), "+v"(vz), "+v"(vw));      // (values, not addresses: a select of loads would put val[] into scratch)
+                const uint32_t pick = i2 == 0u ? vx : i2 == 1u ? vy : i2 == 2u ? vz : vw;      // the word of byte (md & 12)
+                if (sm && (md & 8u)) { const uint2 t8 = make_uint2(vx, vy); __builtin_memcpy(d, &t8, 8); }
+                if (sm && (md & 4u)) { const uint32_t t4 = (md & 8u) ? vz : vx; __builtin_memcpy(d + (md & 8u), &t4, 4); }
+                if (sm && (md & 2u)) { const uint16_t t2 = (uint16_t)pick; __builtin_memcpy(d + (md & 12u), &t2, 2); }
+                if (sm && (md & 1u)) d[md & 14u] = (uint8_t)(pick >> ((md & 2u) * 8u));
+            }
+        }
+#else
         if (__ballot(any_small != 0)) {                    // pieces of 1..15 bytes: a literal '@', a moved barcode, a stray newline
 #pragma unroll
             for (int w = 0; w < NWIN; ++w) {
@@ -1427,6 +1517,7 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
                 else dst_of(w)[0] = src_of(w)[0];
             }
         }
+#endif
         // ---- overflow records: any number of pieces / work items, piece by piece (records of more than 1 KiB, more than
         //      eight pieces or four patches)
         if (more) {
