@@ -13,6 +13,39 @@
 
 namespace aqc {
 
+// ---- loads / stores that SAY the pointer is global memory ---------------------------------------------------------------------------
+// A pointer that reached a lane through LDS, v_readlane or a select between arrays is "generic" to the compiler: it emits flat_load /
+// flat_store, which count on lgkmcnt as well as vmcnt — every wait for an LDS read behind one then waits for the memory round trip
+// too (the general copy kernel's four window loads and the k-mer kernel's prefetch were serialised that way, rounds 1 - 5).  These
+// helpers cast to address space 1 first: global_load / global_store at any alignment, vmcnt only.
+#ifdef AQC_FLAT_AS
+#define AQC_GLOBAL_AS      // (A/B builds only: the pointers stay generic, as in rounds 1 - 5)
+#else
+#define AQC_GLOBAL_AS __attribute__((address_space(1)))
+#endif
+typedef uint32_t aqc_u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t aqc_u32x2_u __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t aqc_u32_u __attribute__((aligned(1)));
+typedef uint16_t aqc_u16_u __attribute__((aligned(1)));
+__device__ __forceinline__ uint4 gload_u128(const uint8_t* p) {
+    const aqc_u32x4_u t = *(const AQC_GLOBAL_AS aqc_u32x4_u*)p;
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ uint32_t gload_u32(const uint8_t* p) { return *(const AQC_GLOBAL_AS aqc_u32_u*)p; }
+__device__ __forceinline__ void gstore_u128(uint8_t* p, uint4 v) {
+    aqc_u32x4_u t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    *(AQC_GLOBAL_AS aqc_u32x4_u*)p = t;
+}
+__device__ __forceinline__ void gstore_u64(uint8_t* p, uint32_t a, uint32_t b) {
+    aqc_u32x2_u t;
+    t.x = a; t.y = b;
+    *(AQC_GLOBAL_AS aqc_u32x2_u*)p = t;
+}
+__device__ __forceinline__ void gstore_u32(uint8_t* p, uint32_t a) { *(AQC_GLOBAL_AS aqc_u32_u*)p = a; }
+__device__ __forceinline__ void gstore_u16(uint8_t* p, uint16_t a) { *(AQC_GLOBAL_AS aqc_u16_u*)p = a; }
+__device__ __forceinline__ void gstore_u8(uint8_t* p, uint8_t a) { *(AQC_GLOBAL_AS uint8_t*)p = a; }
+
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;
 constexpr int WPB = BLOCK / WAVE;      // waves (= records in flight) per workgroup
@@ -929,7 +962,7 @@ __device__ __forceinline__ ReadDesc bcast_desc(const ReadDesc& d, int j) {
 __device__ __forceinline__ uint32_t load4(const uint8_t* p, int x, int len, uint32_t pad) {
     const int xa = min(x, len - 4);
     uint32_t dw = pad;
-    if (x < len) __builtin_memcpy(&dw, p + xa, 4);
+    if (x < len) dw = gload_u32(p + xa);      // (global_load: the pointer came through v_readlane and would otherwise be a flat_load)
     return __builtin_amdgcn_alignbit(pad, dw, (unsigned)(8 * (x - xa)) & 31u);
 }
 

@@ -828,8 +828,8 @@ constexpr int FMT_MAXP = 10;
 #ifndef AQC_GEN_SMALL
 #define AQC_GEN_SMALL 1       // the general copy kernel's pieces of < 16 bytes: loaded with the windows, stored straight-line (0: rounds 2 - 5, a branch per size)
 #endif
-#ifndef AQC_GEN_PREFETCH
-#define AQC_GEN_PREFETCH 0
+#ifndef AQC_GEN_DECODE_LDS
+#define AQC_GEN_DECODE_LDS 1
 #endif
 constexpr uint32_t GRID_MIN = 48;
 // work items of a piece of `len` bytes in the general copy kernel: a short piece is one, a long one a 16-byte window per item —
@@ -1345,33 +1345,14 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
     const uint4* pg = plan_gen + (uint64_t)lj * gen_cap * PLAN_Q;
     const uint32_t n_list = n_gen[lj];
     const uint32_t stride = (gridDim.x / GEN_LISTS) * GEN_ROUND;
-#if AQC_GEN_PREFETCH
-    // the next round's plans are on their way while this round is worked on (one 16-byte word and one list entry per thread)
-    uint4 nx_plan = make_uint4(0, 0, 0, 0);
-    uint32_t nx_ti = 0;
-    auto fetch_round = [&](uint32_t r0) {
-        if (r0 < n_list) {
-            const uint32_t cnt = min((uint32_t)GEN_ROUND, n_list - r0);
-            if (threadIdx.x < cnt * PLAN_Q) nx_plan = pg[(uint64_t)r0 * PLAN_Q + threadIdx.x];
-            if (threadIdx.x < cnt) nx_ti = gen_list[r0 + threadIdx.x];
-        }
-    };
-    fetch_round((blockIdx.x / GEN_LISTS) * GEN_ROUND);
-#endif
     for (uint32_t r0 = (blockIdx.x / GEN_LISTS) * GEN_ROUND; r0 < n_list; r0 += stride) {
         const uint32_t cnt = min((uint32_t)GEN_ROUND, n_list - r0);
         __syncthreads();                                     // (the previous round's plans are no longer read)
-#if AQC_GEN_PREFETCH
-        if (threadIdx.x < cnt * PLAN_Q) s_plan[threadIdx.x] = nx_plan;
-        if (threadIdx.x < cnt) s_ti[threadIdx.x] = nx_ti;
-        fetch_round(r0 + stride);
-#else
         if (threadIdx.x < cnt * PLAN_Q) s_plan[threadIdx.x] = pg[(uint64_t)r0 * PLAN_Q + threadIdx.x];
         if (threadIdx.x < cnt) s_ti[threadIdx.x] = gen_list[r0 + threadIdx.x];
-#endif
         __syncthreads();
-        // (round 6, measured and left out: the next round's plans prefetched into registers while this round is worked on — 84 instead of
-        //  79 registers, a wave less per SIMD: config 5 2.32 -> 2.41 ms, config 3 unchanged)
+        // (round 6, measured twice and left out: the next round's plans prefetched into registers while this round is worked on — with the
+        //  79-register kernel a wave less per SIMD, config 5 2.32 -> 2.41 ms; with this one 4.82 -> 4.80 ms per step: not what a round waits for)
         constexpr int NWIN = GEN_U * GEN_PASSES;          // windows in flight per lane: plan u, pass j -> slot u * GEN_PASSES + j
         uint4 val[NWIN];
         uint32_t so[NWIN], dof[NWIN], mw[NWIN];           // source offset (FMT_LIT_BIT: literal table), offset in the output stream,
@@ -1387,6 +1368,35 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
             const uint32_t idx = (uint32_t)(hwi * GEN_U + u);
             const bool live = idx < cnt;
             const uint4* P = s_plan + (live ? idx : 0u) * PLAN_Q;
+#if AQC_GEN_DECODE_LDS
+            // (round 6) the fields of my piece are READ from the plan in LDS at an address worked out from k — a 32-bit source, two 16-bit
+            // reads — and k itself is a packed byte compare: the eight-way selects and seven compares per window they replace were a
+            // third of this kernel's vector instructions
+            const uint8_t* const pb = reinterpret_cast<const uint8_t*>(P);
+            const uint4 q0 = P[0];
+            const uint2 cumw = *reinterpret_cast<const uint2*>(pb + 56);                                 // q3.z, q3.w: cumulative items, a byte per piece
+            const uint32_t q4w = *reinterpret_cast<const uint32_t*>(pb + 76);
+            const bool ovf = live && (q0.y & PLAN_OVER) != 0;
+            more |= ovf ? 1u << u : 0u;
+            const uint32_t file = nfiles == 2 ? (s_ti[live ? idx : 0u] & 1u) : 0u;
+            const uint32_t fs = file * 3u + (q0.y & 0xffu);
+            const uint32_t items = (live && !ovf) ? q4w >> 16 : 0u;
+            const unsigned long long cum = ((unsigned long long)cumw.y << 32) | cumw.x;
+#pragma unroll
+            for (int j = 0; j < GEN_PASSES; ++j) {
+                const int w = u * GEN_PASSES + j;
+                const uint32_t item = (uint32_t)lane32 + 32u * j;
+                const bool on = item < items;
+                // my piece: the pieces whose cumulative item count I am at or beyond (bytes 0..6; counts and items are < 128)
+                const uint32_t rep = (item * 0x01010101u) | 0x80808080u;
+                int k = __popc((rep - cumw.x) & 0x80808080u) + __popc((rep - cumw.y) & 0x00808080u);
+                k = on ? k : 0;
+                const int first_item = (int)(((cum << 8) >> (8 * k)) & 0xffu);
+                const int lk = (int)*reinterpret_cast<const uint16_t*>(pb + (k < 2 ? 12 : 40) + 2 * k);                    // lengths: q0.w | q2.w, q3.x, q3.y
+                const int dst_rd = (int)*reinterpret_cast<const uint16_t*>(pb + 62 + 2 * max(k, 1));                      // output offsets of pieces 1..7: q4
+                const int dst_off = k == 0 ? 0 : dst_rd;                                                                  // (read, then chosen: no branch around the read)
+                const uint32_t sk = *reinterpret_cast<const uint32_t*>(pb + (k == 0 ? 8 : 12 + 4 * k));                    // sources: q0.z | q1, q2.xyz
+#else
             const uint4 q0 = P[0], q1 = P[1], q2 = P[2], q3 = P[3], q4 = P[4];
             const bool ovf = live && (q0.y & PLAN_OVER) != 0;
             more |= ovf ? 1u << u : 0u;
@@ -1410,6 +1420,7 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
                 const uint32_t ow = k < 1 ? 0u : k < 3 ? q4.x : k < 5 ? q4.y : k < 7 ? q4.z : q4.w;     // output offsets of pieces 1..7
                 const int dst_off = k == 0 ? 0 : (int)((ow >> (16 * ((k - 1) & 1))) & 0xffffu);
                 const uint32_t sk = k == 0 ? q0.z : k == 1 ? q1.x : k == 2 ? q1.y : k == 3 ? q1.z : k == 4 ? q1.w : k == 5 ? q2.x : k == 6 ? q2.y : q2.z;
+#endif
                 // a long piece: my 16-byte window of it, the last one aligned to the piece's end; a short piece: all of it
                 int off = 16 * ((int)item - first_item);
 #if AQC_GEN_ALIGN
@@ -1418,7 +1429,8 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
                 {
                     const uint32_t tb = (uint32_t)(uintptr_t)(file ? tp1 : tp0);
                     const int a = (int)((0u - (tb + sk)) & 15u);
-                    off = (lk >= (int)GRID_MIN && !(sk & FMT_LIT_BIT) && off) ? off - 16 + a : off;
+                    const bool grid = lk >= (int)GRID_MIN && !(sk & FMT_LIT_BIT) && off;
+                    off += (a - 16) & -(int)grid;                                    // (arithmetic, not a branch around eight instructions)
                 }
 #endif
                 off = lk >= 16 ? min(off, lk - 16) : 0;
@@ -1440,7 +1452,7 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
         for (int w = 0; w < NWIN; ++w) {
             const uint32_t md = mw[w] & 31u;
 #if AQC_GEN_SMALL
-            val[w] = load16u_t(md ? src_of(w) : tp0);        // (a short piece's 16 bytes too: the text is padded, a literal is a 16-byte row)
+            val[w] = gload_u128(md ? src_of(w) : tp0);       // (a short piece's 16 bytes too: the text is padded, a literal is a 16-byte row)
 #else
             val[w] = load16u_t(md == 16u ? src_of(w) : tp0);
 #endif
@@ -1484,7 +1496,7 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
         }
 #pragma unroll
         for (int w = 0; w < NWIN; ++w)
-            if ((mw[w] & 31u) == 16u) store16u(dst_of(w), val[w]);
+            if ((mw[w] & 31u) == 16u) gstore_u128(dst_of(w), val[w]);
 #if AQC_GEN_SMALL
         // pieces of 1..15 bytes — a literal '@', a moved barcode, a stray newline: their bytes came with the windows' loads; 8 + 4 + 2 + 1
         // bytes stored as the length's bits say.  (Rounds 2 - 5 copied them behind the windows, a branch per size class with its own
@@ -1499,10 +1511,10 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
                 uint32_t vx = val[w].x, vy = val[w].y, vz = val[w].z, vw = val[w].w;
                 asm volatile("" : "+v"(vx), "+v"(vy), "+v"(vz), "+v"(vw));      // (values, not addresses: a select of loads would put val[] into scratch)
                 const uint32_t pick = i2 == 0u ? vx : i2 == 1u ? vy : i2 == 2u ? vz : vw;      // the word of byte (md & 12)
-                if (sm && (md & 8u)) { const uint2 t8 = make_uint2(vx, vy); __builtin_memcpy(d, &t8, 8); }
-                if (sm && (md & 4u)) { const uint32_t t4 = (md & 8u) ? vz : vx; __builtin_memcpy(d + (md & 8u), &t4, 4); }
-                if (sm && (md & 2u)) { const uint16_t t2 = (uint16_t)pick; __builtin_memcpy(d + (md & 12u), &t2, 2); }
-                if (sm && (md & 1u)) d[md & 14u] = (uint8_t)(pick >> ((md & 2u) * 8u));
+                if (sm && (md & 8u)) gstore_u64(d, vx, vy);
+                if (sm && (md & 4u)) gstore_u32(d + (md & 8u), (md & 8u) ? vz : vx);
+                if (sm && (md & 2u)) gstore_u16(d + (md & 12u), (uint16_t)pick);
+                if (sm && (md & 1u)) gstore_u8(d + (md & 14u), (uint8_t)(pick >> ((md & 2u) * 8u)));
             }
         }
 #else
