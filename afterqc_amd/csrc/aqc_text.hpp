@@ -1264,7 +1264,7 @@ __device__ __forceinline__ void copy_whole_tasks(const FormatView& v, const uint
     }
 #pragma unroll
     for (int u = 0; u < NU; ++u)
-        if (on[u]) store16u(dptr[u], val[u]);
+        if (on[u]) store16u(dptr[u], val[u]);      // (non-temporal loads / stores here: 3.95 -> 4.23 ms per step either way — measured, left out)
 }
 
 __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_kernel(FormatView v, uint64_t n_tasks, const uint4* __restrict__ plan,
@@ -1320,7 +1320,10 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_whole_list_kernel(FormatV
 // item — a 16-byte window of a long piece (16-byte load + 16-byte store at any alignment, the piece's last window
 // end-aligned) or a whole short piece.  Stages (list, plans, decode, loads, patches, stores) run over both plans so that
 // each stage's memory operations travel together.
-constexpr int GEN_U = 2;                                   // plans per half-wave per round
+#ifndef AQC_GEN_U
+#define AQC_GEN_U 2
+#endif
+constexpr int GEN_U = AQC_GEN_U;                           // plans per half-wave per round
 constexpr int GEN_ROUND = (COPY_BLOCK / 32) * GEN_U;       // plans per workgroup per round
 static_assert(GEN_ROUND * PLAN_Q <= COPY_BLOCK, "one 16-byte word per thread stages a round's plans");
 
@@ -1611,7 +1614,10 @@ constexpr int PC_BLOCK = 2 * FMT_TILE;       // thread = (record of the tile, fi
 constexpr int PC_UNROLL = AQC_PC_UNROLL;     // records in flight per half-wave in the copy phase
 static_assert(PC_BLOCK == COPY_BLOCK, "the copy phase is fmt_copy_whole_kernel's");
 
-__global__ __launch_bounds__(PC_BLOCK) void fmt_place_copy_kernel(FormatView v, uint64_t n, uint64_t n_tiles, uint64_t n_super,
+#ifndef AQC_PC_WAVES
+#define AQC_PC_WAVES 1
+#endif
+__global__ __launch_bounds__(PC_BLOCK, AQC_PC_WAVES) void fmt_place_copy_kernel(FormatView v, uint64_t n, uint64_t n_tiles, uint64_t n_super,
                                                                    const unsigned long long* __restrict__ tile_base, const unsigned long long* __restrict__ super_base,
                                                                    uint4* __restrict__ plan_gen, uint32_t* __restrict__ gen_list, unsigned int* __restrict__ n_gen,
                                                                    uint64_t gen_cap, FormatOut outs) {
