@@ -1237,19 +1237,19 @@ __device__ __forceinline__ void copy_whole_tasks(const FormatView& v, const uint
         if (on[u]) val[u] = load16u_t(s0 + off);
     }
     // the correction walk's edits: byte patches applied in registers (windows that overlap carry the same patch)
-    uint32_t any_patch = 0;
+    // (a wave-level test per record in flight and per patch: 8 % of a 2 x 150 run's records carry one or two, and half the rounds of a wave
+    //  — eight records — met one: all 16 patch slots were worked through for them)
 #pragma unroll
-    for (int u = 0; u < NU; ++u) any_patch |= on[u] ? (pa[u].y >> 16) & 0xffu : 0u;
-    if (__ballot(any_patch != 0)) {
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const uint32_t np = on[u] ? (pa[u].y >> 16) & 0xffu : 0u;
+    for (int u = 0; u < NU; ++u) {
+        const uint32_t np = on[u] ? (pa[u].y >> 16) & 0xffu : 0u;
+        if (__ballot(np != 0)) {
             if (np) {
                 const uint4 q5 = *pq[u];
                 const uint32_t pt[4] = {q5.x, q5.y, q5.z, q5.w};
                 const uint32_t wpos = (uint32_t)(dptr[u] - (outs.p[file_of[u] * 3 + (int)(pa[u].y & 0xffu)] + pa[u].x));      // (the window's place in the record)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    if (e > 0 && __ballot((uint32_t)e < np) == 0) break;
                     const uint32_t i = (pt[e] & 0xffffu) - wpos;
                     const bool hit = (uint32_t)e < np && i < 16u;
                     const uint32_t sh = (i & 3u) * 8u, m = hit ? 0xffu << sh : 0u, cb = hit ? ((pt[e] >> 16) & 0xffu) << sh : 0u;
@@ -1474,6 +1474,8 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
             if (__ballot(any_patch != 0)) {
 #pragma unroll
                 for (int u = 0; u < GEN_U; ++u) {
+                    // (a wave-level test per plan and per patch: a record carries two patches or none, and few records any)
+                    if (__ballot(np_[u] != 0) == 0) continue;
                     const uint32_t idx = min((uint32_t)(hwi * GEN_U + u), cnt - 1u);
                     const uint4 q5 = s_plan[idx * PLAN_Q + 5];
                     const uint32_t pt[4] = {q5.x, q5.y, q5.z, q5.w};
@@ -1484,6 +1486,7 @@ __global__ __launch_bounds__(COPY_BLOCK) void fmt_copy_kernel(FormatView v, cons
                         const uint32_t wpos = (mw[w] >> 5) & 0xffffu;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
+                            if (e > 0 && __ballot((uint32_t)e < np_[u]) == 0) break;
                             const uint32_t i = (pt[e] & 0xffffu) - wpos;
                             const bool hit = win && (uint32_t)e < np_[u] && i < 16u;
                             const uint32_t sh = (i & 3u) * 8u, m = hit ? 0xffu << sh : 0u, cb = hit ? ((pt[e] >> 16) & 0xffu) << sh : 0u;
