@@ -4,8 +4,9 @@
 #   usage: tools/gpu_final.sh [tag] [parts]      parts: any of  smoke tests bench steps cli   (default: all)
 cd "$GRAFT_REPO_ROOT"; TAG=${1:-final}; PARTS=${2:-smoke tests bench steps cli}; D=gpurun_out/$TAG; mkdir -p $D; export TMPDIR=/tmp
 has() { [[ " $PARTS " == *" $1 "* ]]; }
+rm -rf /tmp/pytest-of-* /tmp/aqc_* 2>/dev/null      # (a box may be one of this round's earlier ones: pytest keeps the last three runs' files, 39 GB each)
 if has smoke; then python -c "import __graft_entry__ as g; g.smoke()" > $D/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $D/smoke.log; fi
-if has tests; then timeout 2400 python -m pytest tests -m gpu -q > $D/all.log 2>&1; echo rc=$? >> $D/all.log; grep -v "^{\|options:$" $D/all.log | tail -4 | cut -c1-300; fi
+if has tests; then timeout 2400 python -m pytest tests -m gpu -q > $D/all.log 2>&1; echo rc=$? >> $D/all.log; grep -v "^{\|options:$" $D/all.log | tail -4 | cut -c1-300; rm -rf /tmp/pytest-of-* 2>/dev/null; fi
 if has bench; then
   python bench.py > $D/bench.json 2> $D/bench.err; tail -c 200 $D/bench.err
   python - <<PY
