@@ -686,8 +686,9 @@ __global__ __launch_bounds__(WPBT * WAVE, (WPBT + 3) / 4 < AQC_MIN_WAVES ? (WPBT
             if (!ALL_UP) issue2();
             // Read 2 is cut into chunks from its END: chunk c holds the bases [L2 - 16 (c + 1), L2 - 16 c), so that reversed
             // (and complemented) it IS word c of reverse_r2 — the stream starts at bit 0 of word 0 whatever the length,
-            // and an untrimmed pair needs no alignment pass in phase 2.  (Unaligned 16-byte loads cost the same as aligned
-            // ones; the chunk of the read's first bases may begin up to 15 bytes before the read, chunks wholly before it
+            // and an untrimmed pair needs no alignment pass in phase 2.  (Unaligned 16-byte loads were taken to cost the same as
+            // aligned ones — round 6's ablation says they cost this kernel ~9 %, AQC_ABL 128, profiles/r06_copy_window_grid.txt, not acted
+            // on here; the chunk of the read's first bases may begin up to 15 bytes before the read, chunks wholly before it
             // are clamped to 16 bytes before: hence the 64-byte bias, every arena has that much readable space in front.)
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
