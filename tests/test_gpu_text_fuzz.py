@@ -134,3 +134,34 @@ def test_text_path_random_options(gpu_engine, seed):
     assert g["hist"] == o["hist"]
     assert g["qc"] == o["qc"]
     assert g["kmers"] == o["kmers"]
+
+
+@pytest.mark.parametrize("paired", [True, False])
+def test_whole_record_windows_around_the_32_window_limit(gpu_engine, paired):
+    """the whole-record copy cuts a record into a head window + 16-byte windows on the SOURCE's 16-byte grid when that takes at most 32
+    of them (records of <= 496 bytes at any alignment), plain windows otherwise (497..512 bytes off the grid), and leaves longer records
+    to the general kernel: records of 470..540 bytes at every source alignment, untrimmed and good (corrections of the overlap walk
+    included: their byte patches land in windows of both kinds), byte for byte against the oracle"""
+    from oracle import oracle
+    rng = np.random.default_rng(77)
+    n = 1200
+    d = synth.make_pairs(n=n, L=250, seed=4242, dirty=False)
+    for m in ("1", "2"):
+        d["len" + m] = np.minimum(d["len" + m], 210 + (np.arange(n) * 7 + (3 if m == "2" else 0)) % 36).astype(d["len" + m].dtype)
+    t1 = render(d, "1", rng, False)
+    t2 = render(d, "2", rng, False) if paired else None
+    sizes = np.diff([0] + [i + 1 for i, c in enumerate(t1) if c == 10][3::4])
+    assert sizes.min() < 480 and ((sizes > 496) & (sizes <= 512)).any() and sizes.max() > 512
+    cfg = capi.Config()
+    cfg.paired = 1 if paired else 0
+    cfg.qualified_quality_phred = 15
+    cfg.qc_kmer = 8
+    cfg.barcode_length = 12
+    cfg.set_verify("CAGTA")
+    g = run_text(gpu_engine, cfg, t1, t2, 10_000_000, False)
+    o = run_text(oracle.OracleEngine(), cfg, t1, t2, 10_000_000, False)
+    assert np.array_equal(g["res"].view(np.uint8), o["res"].view(np.uint8))
+    for q in range(6):
+        assert g["streams"][q] == o["streams"][q], "stream %d" % q
+    assert len(g["streams"][0]) > 0.9 * len(t1)          # (nearly everything is good and goes out as its own bytes)
+    assert g["counters"] == o["counters"]
