@@ -20,26 +20,33 @@ def _fastq_text(n_pairs, seed):
     return bytes(memoryview(buf)[:n])
 
 
+@pytest.fixture(scope="module")
+def gzb_selftest_exe(tmp_path_factory):
+    """tests/native/gzb_selftest.cpp built once for the tests of this module that run it"""
+    exe = str(tmp_path_factory.mktemp("gzb") / "gzb_selftest")
+    src = [os.path.join(ROOT, "tests", "native", "gzb_selftest.cpp")] + [os.path.join(ROOT, "afterqc_amd", "csrc", f) for f in ("aqc_inflate.cpp", "aqc_gunzip.cpp")]
+    subprocess.check_call(["g++", "-O3", "-std=c++17", "-pthread", "-Wno-stringop-overflow"] + src + ["-lz", "-o", exe])
+    return exe
+
+
 def test_native_selftest(tmp_path):
     """inflate vs zlib streams of every level / strategy, deflate_block -> zlib, ParallelGunzip over single- and multi-member
     files in small sections, truncated / corrupted / bad-CRC / trailing-garbage inputs (tests/native/gz_selftest.cpp)"""
     exe = str(tmp_path / "gz_selftest")
     src = [os.path.join(ROOT, "tests", "native", "gz_selftest.cpp")] + [os.path.join(ROOT, "afterqc_amd", "csrc", f) for f in
                                                                       ("aqc_inflate.cpp", "aqc_gunzip.cpp", "aqc_deflate.cpp")]
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wno-stringop-overflow"] + src + ["-lz", "-o", exe])
+    subprocess.check_call(["g++", "-O3", "-std=c++17", "-pthread", "-Wno-stringop-overflow"] + src + ["-lz", "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "all gz codec checks passed" in out.stdout
 
 
-def test_device_gunzip_logic_on_the_cpu(tmp_path):
+def test_device_gunzip_logic_on_the_cpu(gzb_selftest_exe):
     """csrc/aqc_gunzip_dev.hpp's per-lane functions (block-start scan, table builder, block decoder, chain walk, marker
     re-basing) dealt out by plain loops and plugged into the real ParallelGunzip through the SectionOffload interface the GPU
     uses (tests/native/gzb_selftest.cpp): zlib streams of every level and strategy, flush-separated blocks, concatenated
     members, damaged and truncated files — byte-identical or a loud error, and the offloaded sections really are committed"""
-    exe = str(tmp_path / "gzb_selftest")
-    src = [os.path.join(ROOT, "tests", "native", "gzb_selftest.cpp")] + [os.path.join(ROOT, "afterqc_amd", "csrc", f) for f in ("aqc_inflate.cpp", "aqc_gunzip.cpp")]
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wno-stringop-overflow"] + src + ["-lz", "-o", exe])
+    exe = gzb_selftest_exe
     # (every case runs in two modes — symbols handed back / resolved by the decoder: two processes side by side, half the wall time)
     procs = [subprocess.Popen([exe, str(mode)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for mode in (0, 1)]
     for pr in procs:
@@ -49,16 +56,14 @@ def test_device_gunzip_logic_on_the_cpu(tmp_path):
 
 
 @pytest.mark.parametrize("level", [1, 6, 9])
-def test_device_gunzip_logic_on_gnu_gzip_files(tmp_path, level):
+def test_device_gunzip_logic_on_gnu_gzip_files(tmp_path, gzb_selftest_exe, level):
     """files written by the `gzip` PROGRAM (GNU gzip closes a block every 32 K tokens, twice zlib's) through the same CPU emulation
     of the device decoder in its file mode, which runs with the kernels' own budget (6 slices of 2048 tokens per lane, 12 x symbol
     space): byte-identical, and the emulated device supplied sections"""
     import shutil
     if not shutil.which("gzip"):
         pytest.skip("no gzip program")
-    exe = str(tmp_path / "gzb_selftest")
-    src = [os.path.join(ROOT, "tests", "native", "gzb_selftest.cpp")] + [os.path.join(ROOT, "afterqc_amd", "csrc", f) for f in ("aqc_inflate.cpp", "aqc_gunzip.cpp")]
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wno-stringop-overflow"] + src + ["-lz", "-o", exe])
+    exe = gzb_selftest_exe
     d = synth.make_pairs(30000, 150, seed=300 + level, dirty=True)
     buf, n = synth.render_fastq_fixed(d["seq1"], d["qual1"], 1)
     plain = str(tmp_path / "t.fq")
